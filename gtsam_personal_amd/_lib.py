@@ -1,0 +1,105 @@
+"""ctypes binding of liblmgpu.so (C ABI declared in include/lmgpu.h).
+
+The library is built in-tree by `make -C gtsam_personal_amd/csrc` (see __graft_entry__.build()).
+There is no Python/CPU fallback: if the shared object is missing, importing the hot path fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as ct
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblmgpu.so")
+
+LMGPU_OK, LMGPU_INDETERMINATE, LMGPU_INVALID, LMGPU_HIP_ERROR = 0, 1, 2, 3
+
+
+class lmgpu_config(ct.Structure):
+    _fields_ = [("device", ct.c_int32), ("rank", ct.c_int32), ("world_size", ct.c_int32), ("flags", ct.c_int32)]
+
+
+class lmgpu_lm_params(ct.Structure):
+    _fields_ = [
+        ("maxIterations", ct.c_int32),
+        ("relativeErrorTol", ct.c_double), ("absoluteErrorTol", ct.c_double), ("errorTol", ct.c_double),
+        ("lambdaInitial", ct.c_double), ("lambdaFactor", ct.c_double), ("lambdaUpperBound", ct.c_double), ("lambdaLowerBound", ct.c_double),
+        ("minModelFidelity", ct.c_double),
+        ("diagonalDamping", ct.c_int32), ("useFixedLambdaFactor", ct.c_int32),
+        ("minDiagonal", ct.c_double), ("maxDiagonal", ct.c_double),
+    ]
+
+
+class lmgpu_lm_state(ct.Structure):
+    _fields_ = [("error", ct.c_double), ("lambda_", ct.c_double), ("currentFactor", ct.c_double), ("iterations", ct.c_int32),
+                ("totalNumberInnerIterations", ct.c_int32)]
+
+
+class lmgpu_timings(ct.Structure):
+    _fields_ = [("linearize_ms", ct.c_double), ("eliminate_ms", ct.c_double), ("backsub_ms", ct.c_double), ("linear_error_ms", ct.c_double),
+                ("retract_error_ms", ct.c_double), ("total_ms", ct.c_double), ("inner_iterations", ct.c_int32)]
+
+
+# every symbol include/lmgpu.h declares: name -> (restype, argtypes)
+_H = ct.c_void_p
+_D = ct.POINTER(ct.c_double)
+_I = ct.POINTER(ct.c_int32)
+SYMBOLS = {
+    "lmgpu_create": (ct.c_int, [ct.POINTER(lmgpu_config), ct.POINTER(_H)]),
+    "lmgpu_destroy": (ct.c_int, [_H]),
+    "lmgpu_last_error": (ct.c_char_p, [_H]),
+    "lmgpu_last_failed_slot": (ct.c_int, [_H]),
+    "lmgpu_set_variables": (ct.c_int, [_H, ct.c_int32, ct.POINTER(ct.c_uint64), _I]),
+    "lmgpu_add_factor_bucket": (ct.c_int, [_H, ct.c_int32, ct.c_int32, _I, _I, _D, ct.c_int32, _D]),
+    "lmgpu_finalize_structure": (ct.c_int, [_H]),
+    "lmgpu_set_values": (ct.c_int, [_H, _D]),
+    "lmgpu_get_values": (ct.c_int, [_H, _D]),
+    "lmgpu_total_dim": (ct.c_int, [_H]),
+    "lmgpu_total_store": (ct.c_int, [_H]),
+    "lmgpu_error": (ct.c_int, [_H, _D]),
+    "lmgpu_linearize": (ct.c_int, [_H]),
+    "lmgpu_solve": (ct.c_int, [_H, ct.c_double, ct.c_int32, ct.c_double, ct.c_double, _D, _D, _D]),
+    "lmgpu_retract": (ct.c_int, [_H, _D]),
+    "lmgpu_hessian_diagonal": (ct.c_int, [_H, _D]),
+    "lmgpu_lm_init": (ct.c_int, [_H, ct.POINTER(lmgpu_lm_params), ct.POINTER(lmgpu_lm_state)]),
+    "lmgpu_iterate": (ct.c_int, [_H, ct.POINTER(lmgpu_lm_params), ct.POINTER(lmgpu_lm_state)]),
+    "lmgpu_optimize": (ct.c_int, [_H, ct.POINTER(lmgpu_lm_params), ct.POINTER(lmgpu_lm_state)]),
+    "lmgpu_get_timings": (ct.c_int, [_H, ct.POINTER(lmgpu_timings)]),
+    "lmgpu_get_jacobian": (ct.c_int, [_H, ct.c_int32, _D, _I, _I]),
+    "lmgpu_num_fronts": (ct.c_int, [_H]),
+    "lmgpu_front_info": (ct.c_int, [_H, ct.c_int32, _I]),
+    "lmgpu_get_front": (ct.c_int, [_H, ct.c_int32, _I, _D]),
+    "lmgpu_comm_unique_id": (ct.c_int, [ct.c_char_p]),
+    "lmgpu_comm_init": (ct.c_int, [_H, ct.c_char_p]),
+    "lmgpu_peak_mfma_f64": (ct.c_int, [ct.c_int32, ct.c_int32, _D]),
+    "lmgpu_peak_hbm_copy": (ct.c_int, [ct.c_int32, ct.c_int64, ct.c_int32, _D]),
+}
+
+_lib = None
+
+
+def load():
+    """Load liblmgpu.so once; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(or `make -C gtsam_personal_amd/csrc`). The LM hot path has no CPU fallback.")
+        lib = ct.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+class LmgpuError(RuntimeError):
+    pass
+
+
+class IndeterminantLinearSystemException(LmgpuError):
+    """mirror of gtsam/linear/linearExceptions.h; `slot` is the first frontal variable of the failing front"""
+
+    def __init__(self, slot):
+        super().__init__(f"indeterminant linear system near variable slot {slot}")
+        self.slot = slot

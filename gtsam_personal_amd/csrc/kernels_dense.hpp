@@ -1,0 +1,250 @@
+// HBM fronts: fronts too large for one workgroup's LDS live in HBM (row-major upper, leading dimension ld)
+// and are processed by a blocked right-looking partial Cholesky:
+//   per 64-row panel:  potrf (diagonal block, LDS) + trsm (row panel, one lane per column)   -> potrf_trsm_kernel
+//                      trailing update C -= P^T P on the matrix cores (v_mfma_f64_16x16x4_f64) -> syrk_mfma_kernel
+// This is choleskyPartial (gtsam/base/cholesky.cpp:108-159: LLT(A); S = R^-T B; C -= S^T S; pivot-exponent test)
+// in blocked form; the root of a BAL problem (all cameras, 9001 x 9001) spends >95 % of the solve here.
+// Assembly (a11/a12) into an HBM front uses FP64 global atomics (children and factors scatter concurrently).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels_front.hpp"
+
+namespace lmgpu {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------- assembly
+// one 64-lane block per own factor: F += [A b]^T [A b]
+__global__ __launch_bounds__(64) void hbm_assemble_factors_kernel(FrontDesc F, int64_t f_off, int ld, const FrontFac* __restrict__ ffac,
+                                                                   const FacDesc* __restrict__ fd, double* __restrict__ pool) {
+  const FrontFac ff = ffac[F.fac_begin + blockIdx.x];
+  const FacDesc d = fd[ff.fac];
+  const double* J = pool + d.joff;
+  double* A = pool + f_off;
+  const int n = F.n, m = d.rows, nc = d.d0 + d.d1 + 1;
+  const int npair = nc * (nc + 1) / 2;
+  for (int pidx = threadIdx.x; pidx < npair; pidx += 64) {
+    int p = 0, rem = pidx, rowlen = nc;
+    while (rem >= rowlen) {
+      rem -= rowlen;
+      rowlen--;
+      p++;
+    }
+    const int q = p + rem;
+    double v = 0;
+    for (int r = 0; r < m; r++) v += J[p * m + r] * J[q * m + r];
+    const int gp = (p < d.d0) ? ff.c0 + p : (p < d.d0 + d.d1 ? ff.c1 + (p - d.d0) : n - 1);
+    const int gq = (q < d.d0) ? ff.c0 + q : (q < d.d0 + d.d1 ? ff.c1 + (q - d.d0) : n - 1);
+    const int lo = gp < gq ? gp : gq, hi = gp < gq ? gq : gp;
+    atomicAdd(&A[(size_t)lo * ld + hi], v);
+  }
+}
+
+// one block per child: extend-add of its update matrix
+__global__ __launch_bounds__(256) void hbm_assemble_children_kernel(FrontDesc F, int64_t f_off, int ld, const ChildRef* __restrict__ childs,
+                                                                    const int32_t* __restrict__ cmap, double* __restrict__ pool) {
+  const ChildRef c = childs[F.child_begin + blockIdx.x];
+  const double* U = pool + c.u_off;
+  const int32_t* map = cmap + c.map_begin;
+  double* A = pool + f_off;
+  for (int idx = threadIdx.x; idx < c.m * c.m; idx += 256) {
+    const int i = idx / c.m, j = idx - i * c.m;
+    if (j < i) continue;
+    const int gi = map[i], gj = map[j];
+    const int lo = gi < gj ? gi : gj, hi = gi < gj ? gj : gi;
+    atomicAdd(&A[(size_t)lo * ld + hi], U[(size_t)i * c.ld + j]);
+  }
+}
+
+__global__ __launch_bounds__(256) void hbm_damp_kernel(FrontDesc F, int64_t f_off, int ld, const int32_t* __restrict__ fxoff,
+                                                        double* __restrict__ pool, double lambda, const double* __restrict__ dampw) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= F.nf) return;
+  pool[f_off + (size_t)i * ld + i] += lambda * dampw[fxoff[F.fx_begin + i]];
+}
+
+// ---------------------------------------------------------------- panel: potrf + trsm
+// Every block factors the nb x nb diagonal block in LDS (redundantly: it is 64^3/3 flop), block 0 writes it back;
+// then each lane forward-substitutes one column of the row panel:  P = R_kk^-T A_panel.
+template <int NB>
+__global__ __launch_bounds__(256) void potrf_trsm_kernel(double* __restrict__ A, int ld, int n, int nf, int k0, int nb, int front_id,
+                                                          int* __restrict__ status) {
+  __shared__ double D[NB][NB + 1];
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < NB * NB; idx += 256) {
+    const int p = idx / NB, q = idx - p * NB;
+    double v = (p == q) ? 1.0 : 0.0;
+    if (p < nb && q < nb && q >= p) v = A[(size_t)(k0 + p) * ld + k0 + q];
+    D[p][q] = v;
+  }
+  __syncthreads();
+  bool failed = false;
+  for (int k = 0; k < nb; k++) {
+    double piv = D[k][k];
+    if (!(piv > 0.0)) {
+      if (piv <= 0.0) failed = true;
+      piv = (piv == piv && piv != 0.0) ? fabs(piv) : 1.0;
+    }
+    const double r = sqrt(piv), inv = 1.0 / r;
+    __syncthreads();
+    if (tid < nb - k) {
+      const int j = k + tid;
+      D[k][j] = (j == k) ? r : D[k][j] * inv;
+    }
+    __syncthreads();
+    const int t = nb - k - 1;
+    for (int idx = tid; idx < t * t; idx += 256) {
+      const int a = idx / t, b = idx - a * t;
+      if (b < a) continue;
+      D[k + 1 + a][k + 1 + b] -= D[k][k + 1 + a] * D[k][k + 1 + b];
+    }
+    __syncthreads();
+  }
+  if (blockIdx.x == 0) {
+    for (int idx = tid; idx < nb * nb; idx += 256) {
+      const int p = idx / nb, q = idx - p * nb;
+      if (q >= p) A[(size_t)(k0 + p) * ld + k0 + q] = D[p][q];
+    }
+    if (tid == 0) {
+      if (k0 + nb >= nf) {  // last panel: pivot-exponent test, gtsam/base/cholesky.cpp:146-158
+        if (nf >= 2) {
+          const double r1 = D[nb - 1][nb - 1];
+          const double r2 = (nb >= 2) ? D[nb - 2][nb - 2] : A[(size_t)(nf - 2) * ld + nf - 2];
+          if (!(frexp_exp(r2) - frexp_exp(r1) < 12)) failed = true;
+        } else {
+          if (!(frexp_exp(D[0][0]) > -12)) failed = true;
+        }
+      }
+      if (failed) atomicMin(status, front_id);
+    }
+  }
+  // trsm: one lane per column of the row panel
+  const int j = k0 + nb + blockIdx.x * 256 + tid;
+  if (j >= n) return;
+  double a[NB];
+#pragma unroll
+  for (int p = 0; p < NB; p++) a[p] = (p < nb) ? A[(size_t)(k0 + p) * ld + j] : 0.0;
+#pragma unroll
+  for (int q = 0; q < NB; q++) {
+    const double x = a[q] / D[q][q];
+    a[q] = x;
+#pragma unroll
+    for (int p = q + 1; p < NB; p++) a[p] -= D[q][p] * x;
+  }
+#pragma unroll
+  for (int p = 0; p < NB; p++)
+    if (p < nb) A[(size_t)(k0 + p) * ld + j] = a[p];
+}
+
+// ---------------------------------------------------------------- trailing update on the matrix cores
+// C[i][j] -= sum_p P[p][i] P[p][j]   for c0 <= i <= j < n, P = rows k0..k0+nb-1 of A (already [R S d] rows).
+// Block = 4 waves computing a 128x128 tile (each wave 64x64 = 4x4 MFMA 16x16x4 f64 tiles, 128 accumulator VGPRs).
+// Operand fragments are read straight from the (L2-resident) panel rows: lane l holds P[k + (l>>4)][col + (l&15)],
+// i.e. four 128-B row segments per wave load; no LDS staging is needed at 1 MFMA issue per 64 cycles per SIMD.
+__global__ __launch_bounds__(256) void syrk_mfma_kernel(double* __restrict__ A, int ld, int n, int k0, int nb) {
+  const int c0 = k0 + nb;
+  const int ti = blockIdx.y, tj = blockIdx.x;
+  if (tj < ti) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wr = wave >> 1, wc = wave & 1;
+  if (ti == tj && wr > wc) return;  // strictly-lower quadrant of a diagonal tile
+  const int i0 = c0 + ti * 128 + wr * 64;
+  const int j0 = c0 + tj * 128 + wc * 64;
+  if (i0 >= n || j0 >= n) return;
+  const int kk = lane >> 4, cc = lane & 15;
+  double4_t acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = 0; b < 4; b++) acc[a][b] = double4_t{0, 0, 0, 0};
+  const double* P = A + (size_t)k0 * ld;
+  for (int k = 0; k < nb; k += 4) {
+    const int row = k + kk;
+    const bool rok = row < nb;
+    const double* prow = P + (size_t)row * ld;
+    double af[4], bf[4];
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+      const int col = i0 + a * 16 + cc;
+      af[a] = (rok && col < n) ? -prow[col] : 0.0;
+    }
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const int col = j0 + b * 16 + cc;
+      bf[b] = (rok && col < n) ? prow[col] : 0.0;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+      for (int b = 0; b < 4; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+  }
+  // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = i0 + a * 16 + kk + 4 * r;
+        const int col = j0 + b * 16 + cc;
+        if (row < n && col < n && col >= row) A[(size_t)row * ld + col] += acc[a][b][r];
+      }
+}
+
+// ---------------------------------------------------------------- back-substitution on an HBM front
+// y_i = d_i - sum_j S_ij x_S[j]     (one wave per row)
+__global__ __launch_bounds__(64) void hbm_rhs_init_kernel(FrontDesc F, int64_t f_off, int ld, const int32_t* __restrict__ sxoff,
+                                                           const double* __restrict__ pool, const double* __restrict__ delta,
+                                                           double* __restrict__ y) {
+  const int i = blockIdx.x, lane = threadIdx.x;
+  const int n = F.n, nf = F.nf, ns = n - nf - 1;
+  const double* row = pool + f_off + (size_t)i * ld;
+  double s = 0;
+  for (int j = lane; j < ns; j += 64) s += row[nf + j] * delta[sxoff[F.sx_begin + j]];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) y[i] = row[n - 1] - s;
+}
+
+// one 64-row block step of the backward solve R x = y:  every workgroup solves the diagonal block in LDS,
+// workgroup 0 publishes x, and each wave folds x into 8 rows above:  y_row -= R[row, r0:r0+nb] x
+template <int NB>
+__global__ __launch_bounds__(256) void hbm_backsolve_step_kernel(FrontDesc F, int64_t f_off, int ld, int r0, int nb,
+                                                                  const int32_t* __restrict__ fxoff, const double* __restrict__ pool,
+                                                                  double* __restrict__ y, double* __restrict__ delta, int* __restrict__ status) {
+  __shared__ double T[NB][NB + 1];
+  __shared__ double x[NB];
+  const int tid = threadIdx.x;
+  const double* A = pool + f_off;
+  for (int idx = tid; idx < NB * NB; idx += 256) {
+    const int p = idx / NB, q = idx - p * NB;
+    T[p][q] = (p < nb && q < nb && q >= p) ? A[(size_t)(r0 + p) * ld + r0 + q] : 0.0;
+  }
+  if (tid < NB) x[tid] = (tid < nb) ? y[r0 + tid] : 0.0;
+  __syncthreads();
+  for (int i = nb - 1; i >= 0; i--) {
+    if (tid == 0) x[i] = x[i] / T[i][i];
+    __syncthreads();
+    if (tid < i) x[tid] -= T[tid][i] * x[i];
+    __syncthreads();
+  }
+  if (blockIdx.x == 0 && tid < nb) {
+    const double v = x[tid];
+    delta[fxoff[F.fx_begin + r0 + tid]] = v;
+    if (v != v) atomicMin(status, F.id);
+  }
+  // rows above
+  const int wave = tid >> 6, lane = tid & 63;
+  const double xl = x[lane];
+  for (int rr = 0; rr < 8; rr++) {
+    const int row = blockIdx.x * 32 + wave * 8 + rr;
+    if (row >= r0) break;
+    double s = (lane < nb) ? A[(size_t)row * ld + r0 + lane] * xl : 0.0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) y[row] -= s;
+  }
+}
+
+}  // namespace lmgpu

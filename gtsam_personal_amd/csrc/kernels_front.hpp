@@ -1,0 +1,181 @@
+// LDS fronts: one workgroup assembles, partially factors and emits one small front of the multifrontal
+// Cholesky.  Restates per clique what EliminateCholesky does on the CPU:
+//   a11 Scatter + HessianFactor(gfg, scatter)    gtsam/linear/HessianFactor.cpp:240-253, Scatter.cpp:39-73
+//   a12 updateHessian ([A b]^T [A b] into the upper triangle; child separator Hessians added block-wise)
+//                                                gtsam/linear/JacobianFactor.cpp:586-624, BinaryJacobianFactor.h:51-83,
+//                                                HessianFactor.cpp:349-373
+//   a1  damping prior lambda*I (or lambda*diag)  gtsam/nonlinear/internal/LevenbergMarquardtState.h:125-156
+//   a13 choleskyPartial + split                  gtsam/base/cholesky.cpp:108-159, SymmetricBlockMatrix.cpp:83-107
+//   a14 back-substitution per clique             gtsam/linear/linearAlgorithms-inst.h:54-116
+// Storage: the front is ROW-major upper (row k of R is contiguous); [R S d] is written nf x n row-major,
+// the update (separator Hessian) (n-nf)^2 row-major upper with ld = n-nf.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels_factors.hpp"
+
+namespace lmgpu {
+
+struct FrontFac {
+  int32_t fac;     // index into FacDesc[]
+  int32_t c0, c1;  // column offsets of the factor's variables inside the front
+};
+struct ChildRef {
+  int64_t u_off;      // pool offset of the child's update matrix
+  int32_t ld, m;      // leading dimension and size (child's ns + 1)
+  int32_t map_begin;  // into cmap[]: child update index -> parent front column
+  int32_t pad;
+};
+struct FrontDesc {
+  int32_t n, nf;
+  int32_t fac_begin, fac_count;
+  int32_t child_begin, child_count;
+  int32_t fx_begin;  // into fxoff[]: delta offset of each frontal scalar (nf entries)
+  int32_t sx_begin;  // into sxoff[]: delta offset of each separator scalar (n-nf-1 entries)
+  int64_t rsd_off;   // [R S d], row-major nf x ld_rsd
+  int64_t u_off;     // update matrix, row-major (n-nf) x ld_u, upper
+  int32_t ld_rsd, ld_u;
+  int32_t id;        // front index (failure report)
+  int32_t pad;
+};
+
+__device__ __forceinline__ int frexp_exp(double x) {
+  int e;
+  (void)frexp(x, &e);
+  return e;
+}
+
+// grid: one block per front in `list`; dynamic LDS = nmax*nmax doubles
+__global__ __launch_bounds__(256) void lds_front_kernel(const int32_t* __restrict__ list, const FrontDesc* __restrict__ fronts,
+                                                         const FrontFac* __restrict__ ffac, const FacDesc* __restrict__ fd,
+                                                         const ChildRef* __restrict__ childs, const int32_t* __restrict__ cmap,
+                                                         const int32_t* __restrict__ fxoff, double* __restrict__ pool, double lambda,
+                                                         const double* __restrict__ dampw, int* __restrict__ status) {
+  extern __shared__ double S[];
+  const FrontDesc F = fronts[list[blockIdx.x]];
+  const int n = F.n, nf = F.nf, tid = threadIdx.x, nt = blockDim.x;
+  for (int i = tid; i < n * n; i += nt) S[i] = 0.0;
+  __syncthreads();
+  // ---- own factors: S += [A b]^T [A b]
+  for (int k = 0; k < F.fac_count; k++) {
+    const FrontFac ff = ffac[F.fac_begin + k];
+    const FacDesc d = fd[ff.fac];
+    const double* J = pool + d.joff;
+    const int m = d.rows, nc = d.d0 + d.d1 + 1;
+    const int npair = nc * (nc + 1) / 2;
+    for (int pidx = tid; pidx < npair; pidx += nt) {
+      // unrank pair (p <= q) from linear index over the upper triangle, row by row
+      int p = 0, rem = pidx, rowlen = nc;
+      while (rem >= rowlen) {
+        rem -= rowlen;
+        rowlen--;
+        p++;
+      }
+      const int q = p + rem;
+      double v = 0;
+      for (int r = 0; r < m; r++) v += J[p * m + r] * J[q * m + r];
+      const int gp = (p < d.d0) ? ff.c0 + p : (p < d.d0 + d.d1 ? ff.c1 + (p - d.d0) : n - 1);
+      const int gq = (q < d.d0) ? ff.c0 + q : (q < d.d0 + d.d1 ? ff.c1 + (q - d.d0) : n - 1);
+      const int lo = gp < gq ? gp : gq, hi = gp < gq ? gq : gp;
+      S[lo * n + hi] += v;
+    }
+    __syncthreads();
+  }
+  // ---- children: extend-add of their update matrices
+  for (int k = 0; k < F.child_count; k++) {
+    const ChildRef c = childs[F.child_begin + k];
+    const double* U = pool + c.u_off;
+    const int32_t* map = cmap + c.map_begin;
+    for (int idx = tid; idx < c.m * c.m; idx += nt) {
+      const int i = idx / c.m, j = idx - i * c.m;
+      if (j < i) continue;
+      const int gi = map[i], gj = map[j];
+      const int lo = gi < gj ? gi : gj, hi = gi < gj ? gj : gi;
+      S[lo * n + hi] += U[(size_t)i * c.ld + j];
+    }
+    __syncthreads();
+  }
+  // ---- damping on the frontal diagonal
+  for (int i = tid; i < nf; i += nt) S[i * n + i] += lambda * dampw[fxoff[F.fx_begin + i]];
+  __syncthreads();
+  // ---- partial Cholesky (right-looking, row k of R at a time)
+  bool failed = false;
+  for (int k = 0; k < nf; k++) {
+    double piv = S[k * n + k];
+    if (!(piv > 0.0)) {
+      if (piv <= 0.0) failed = true;  // Eigen LLT: pivot <= 0 -> NumericalIssue (NaN passes, like Eigen)
+      piv = (piv == piv && piv != 0.0) ? fabs(piv) : 1.0;
+    }
+    const double r = sqrt(piv), inv = 1.0 / r;
+    __syncthreads();
+    for (int j = k + tid; j < n; j += nt) S[k * n + j] = (j == k) ? r : S[k * n + j] * inv;
+    __syncthreads();
+    const int t = n - k - 1;
+    for (int idx = tid; idx < t * t; idx += nt) {
+      const int a = idx / t, b = idx - a * t;
+      if (b < a) continue;
+      const int i = k + 1 + a, j = k + 1 + b;
+      S[i * n + j] -= S[k * n + i] * S[k * n + j];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    // pivot-exponent test, gtsam/base/cholesky.cpp:146-158
+    if (nf >= 2) {
+      if (!(frexp_exp(S[(nf - 2) * n + nf - 2]) - frexp_exp(S[(nf - 1) * n + nf - 1]) < 12)) failed = true;
+    } else if (nf == 1) {
+      if (!(frexp_exp(S[0]) > -12)) failed = true;
+    }
+    if (failed) atomicMin(status, F.id);
+  }
+  // ---- emit [R S d] (strictly-lower zeroed) and the update matrix
+  double* RSd = pool + F.rsd_off;
+  for (int idx = tid; idx < nf * n; idx += nt) {
+    const int i = idx / n, j = idx - i * n;
+    RSd[(size_t)i * F.ld_rsd + j] = (j >= i) ? S[i * n + j] : 0.0;
+  }
+  const int m = n - nf;
+  double* U = pool + F.u_off;
+  for (int idx = tid; idx < m * m; idx += nt) {
+    const int i = idx / m, j = idx - i * m;
+    if (j >= i) U[(size_t)i * F.ld_u + j] = S[(nf + i) * n + nf + j];
+  }
+}
+
+// back-substitution for LDS-class fronts: x_F = R^-1 (d - S x_S).  One wave per front, 4 fronts per block.
+__global__ __launch_bounds__(256) void lds_backsub_kernel(const int32_t* __restrict__ list, int nlist, const FrontDesc* __restrict__ fronts,
+                                                           const int32_t* __restrict__ fxoff, const int32_t* __restrict__ sxoff,
+                                                           const double* __restrict__ pool, double* __restrict__ delta, int* __restrict__ status) {
+  __shared__ double rhs_s[4][160];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int li = blockIdx.x * 4 + w;
+  if (li >= nlist) return;
+  const FrontDesc F = fronts[list[li]];
+  const int n = F.n, nf = F.nf, ns = n - nf - 1;
+  const double* RSd = pool + F.rsd_off;
+  double* rhs = rhs_s[w];
+  // rhs_i = d_i - sum_j S_ij x_S[j]
+  for (int i = 0; i < nf; i++) {
+    double s = 0;
+    for (int j = lane; j < ns; j += 64) s += RSd[(size_t)i * F.ld_rsd + nf + j] * delta[sxoff[F.sx_begin + j]];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) rhs[i] = RSd[(size_t)i * F.ld_rsd + n - 1] - s;
+  }
+  __builtin_amdgcn_wave_barrier();
+  // R x = rhs (upper, backward), serial in lane 0 (nf is small for LDS fronts)
+  if (lane == 0) {
+    bool bad = false;
+    for (int i = nf - 1; i >= 0; i--) {
+      double s = rhs[i];
+      for (int j = i + 1; j < nf; j++) s -= RSd[(size_t)i * F.ld_rsd + j] * rhs[j];
+      s /= RSd[(size_t)i * F.ld_rsd + i];
+      rhs[i] = s;
+      if (s != s) bad = true;
+    }
+    for (int i = 0; i < nf; i++) delta[fxoff[F.fx_begin + i]] = rhs[i];
+    if (bad) atomicMin(status, F.id);  // NaN -> IndeterminantLinearSystemException (linearAlgorithms-inst.h:99)
+  }
+}
+
+}  // namespace lmgpu

@@ -1,0 +1,1080 @@
+// liblmgpu — C ABI (include/lmgpu.h) over the HIP engine.  gfx950 only; no CPU fallback: every compute entry
+// point fails with LMGPU_HIP_ERROR when no device is bound.
+//
+// Host-side pieces in this file:
+//   * graph intake + symbolic plan (plan.cpp) -> device descriptors
+//   * the level-scheduled multifrontal solve (LDS fronts batched per level, HBM fronts blocked on MFMA)
+//   * the LM control loop: a restatement of LevenbergMarquardtOptimizer::iterate / tryLambda
+//     (gtsam/nonlinear/LevenbergMarquardtOptimizer.cpp:121-308) and NonlinearOptimizer::defaultOptimize
+//     (gtsam/nonlinear/NonlinearOptimizer.cpp:62-117) that only reads three scalars back per inner iteration.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/lmgpu.h"
+#include "kernels_dense.hpp"
+#include "plan.hpp"
+
+using namespace lmgpu;
+
+#define HIPCHECK(expr)                                                                         \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess) {                                                                    \
+      h->err = std::string(#expr) + ": " + hipGetErrorString(_e);                              \
+      return LMGPU_HIP_ERROR;                                                                  \
+    }                                                                                          \
+  } while (0)
+
+namespace {
+
+struct Bucket {
+  int type = 0, n = 0, noise_kind = 0;
+  std::vector<int32_t> graph_index, slots;
+  std::vector<double> meas, noise;
+  int rows = 0, cols = 0;  // Jacobian shape (cols includes b)
+  int64_t joff = 0;        // pool offset of the bucket's Jacobians
+  // device
+  int32_t* d_vidx = nullptr;
+  double* d_meas = nullptr;
+  double* d_noise = nullptr;
+  int32_t* d_epos = nullptr;
+};
+
+struct LevelWork {
+  // LDS fronts of this level, grouped by LDS-size bin: [bin_begin[b], bin_begin[b+1]) inside the level's list
+  int list_begin = 0, list_count = 0;
+  int bin_begin[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  std::vector<int> hbm;  // HBM fronts of this level
+};
+
+const int kBinN[6] = {24, 48, 72, 96, 120, 140};
+const int kNumBins = 6;
+const int kLdsLimitN = 140;
+const int NB = 64;
+
+}  // namespace
+
+struct lmgpu_handle {
+  lmgpu_config cfg;
+  int device = -1;
+  std::string err;
+  int failed_slot = -1;
+  Plan plan;
+  std::vector<Bucket> buckets;
+  bool finalized = false, have_values = false, linearized = false, solved = false;
+  std::vector<std::pair<int, int>> fac_of_graph;  // graph-index rank -> (bucket, idx) ; parallel to plan.factors
+  std::vector<int32_t> graph_index_sorted;
+
+  // ---- device state
+  hipStream_t stream = nullptr;
+  double* pool = nullptr;
+  size_t pool_doubles = 0;
+  double* vals[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+  int cur = 0;
+  int32_t* type_xoff[4] = {nullptr, nullptr, nullptr, nullptr};
+  double *delta = nullptr, *dampw = nullptr, *hdiag = nullptr, *ebuf0 = nullptr, *ebuf1 = nullptr, *partial = nullptr, *dscal = nullptr,
+         *ywork = nullptr;
+  int* d_status = nullptr;
+  double* h_scal = nullptr;  // pinned: [0]=err, [1]=lin0, [2]=lin1
+  int* h_status = nullptr;   // pinned
+  FacDesc* d_fd = nullptr;
+  FrontDesc* d_fronts = nullptr;
+  FrontFac* d_ffac = nullptr;
+  ChildRef* d_childs = nullptr;
+  int32_t *d_cmap = nullptr, *d_fxoff = nullptr, *d_sxoff = nullptr, *d_lists = nullptr;
+  int32_t *d_scalar_var = nullptr, *d_scalar_col = nullptr, *d_vi_ptr = nullptr, *d_vi_fac = nullptr;
+  int8_t* d_vi_pos = nullptr;
+  std::vector<FrontDesc> h_fronts;
+  std::vector<int64_t> f_off;  // HBM fronts: pool offset of the dense front (else -1)
+  std::vector<int> f_ld;
+  std::vector<LevelWork> levels;
+  int nfac = 0, ntot = 0, nstore = 0;
+  bool dampw_is_ones = false;
+
+  // ---- LM
+  lmgpu_lm_state lm{};
+  lmgpu_timings tim{};
+  hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+
+  // ---- multi-GPU
+  ncclComm_t comm = nullptr;
+};
+
+namespace {
+
+template <typename T>
+int upload(lmgpu_handle* h, T** dst, const std::vector<T>& src) {
+  *dst = nullptr;
+  if (src.empty()) {
+    HIPCHECK(hipMalloc((void**)dst, sizeof(T)));
+    return LMGPU_OK;
+  }
+  HIPCHECK(hipMalloc((void**)dst, src.size() * sizeof(T)));
+  HIPCHECK(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+  return LMGPU_OK;
+}
+
+int need_device(lmgpu_handle* h) {
+  if (h->device < 0) {
+    h->err = "no HIP device bound to this handle (structure-only handle); the hot path has no CPU fallback";
+    return LMGPU_HIP_ERROR;
+  }
+  return LMGPU_OK;
+}
+
+ValuesDev values_dev(lmgpu_handle* h, int which) {
+  ValuesDev v;
+  for (int t = 0; t < 4; t++) v.v[t] = h->vals[which][t];
+  return v;
+}
+
+BucketDev bucket_dev(lmgpu_handle* h, const Bucket& b) {
+  BucketDev d;
+  d.type = b.type;
+  d.n = b.n;
+  d.noise_kind = b.noise_kind;
+  d.vidx = b.d_vidx;
+  d.meas = b.d_meas;
+  d.noise = b.d_noise;
+  d.J = h->pool + b.joff;
+  d.epos = b.d_epos;
+  return d;
+}
+
+// launch the factor kernels of every bucket: JAC -> Jacobians, else per-factor errors into ebuf0
+template <bool JAC>
+void launch_factors(lmgpu_handle* h, int which) {
+  const ValuesDev vals = values_dev(h, which);
+  for (const Bucket& b : h->buckets) {
+    if (b.n == 0) continue;
+    const BucketDev d = bucket_dev(h, b);
+    const int g256 = (b.n + 255) / 256, g128 = (b.n + 127) / 128;
+    hipStream_t s = h->stream;
+    switch (b.type) {
+      case LMGPU_F_SFM:
+        if (JAC)
+          hipLaunchKernelGGL(sfm_linearize_kernel, dim3(g256), dim3(256), 0, s, d, vals);
+        else
+          hipLaunchKernelGGL(sfm_error_kernel, dim3(g256), dim3(256), 0, s, d, vals, h->ebuf0);
+        break;
+      case LMGPU_F_BETWEEN_POSE2:
+        hipLaunchKernelGGL((generic_factor_kernel<1, 3, 3, 3, 3, 0, 3, 0, 3, JAC>), dim3(g128), dim3(128), 0, s, d, vals, h->ebuf0);
+        break;
+      case LMGPU_F_BETWEEN_POSE3:
+        hipLaunchKernelGGL((generic_factor_kernel<2, 6, 6, 6, 12, 1, 12, 1, 12, JAC>), dim3(g128), dim3(128), 0, s, d, vals, h->ebuf0);
+        break;
+      case LMGPU_F_PRIOR_POSE2:
+        hipLaunchKernelGGL((generic_factor_kernel<3, 3, 3, 0, 3, 0, 3, -1, 0, JAC>), dim3(g128), dim3(128), 0, s, d, vals, h->ebuf0);
+        break;
+      case LMGPU_F_PRIOR_POSE3:
+        hipLaunchKernelGGL((generic_factor_kernel<4, 6, 6, 0, 12, 1, 12, -1, 0, JAC>), dim3(g128), dim3(128), 0, s, d, vals, h->ebuf0);
+        break;
+      case LMGPU_F_PRIOR_POINT3:
+        hipLaunchKernelGGL((generic_factor_kernel<5, 3, 3, 0, 3, 2, 3, -1, 0, JAC>), dim3(g128), dim3(128), 0, s, d, vals, h->ebuf0);
+        break;
+      case LMGPU_F_PRIOR_CAM:
+        hipLaunchKernelGGL((generic_factor_kernel<6, 9, 9, 0, 15, 3, 15, -1, 0, JAC>), dim3(g128), dim3(128), 0, s, d, vals, h->ebuf0);
+        break;
+      case LMGPU_F_PROJECTION:
+        hipLaunchKernelGGL((generic_factor_kernel<7, 2, 6, 3, 7, 1, 12, 2, 3, JAC>), dim3(g128), dim3(128), 0, s, d, vals, h->ebuf0);
+        break;
+    }
+  }
+}
+
+void reduce_to(lmgpu_handle* h, const double* buf, int n, double* dst) {
+  const int g = std::min(256, std::max(1, (n + 255) / 256));
+  hipLaunchKernelGGL(reduce_stage1, dim3(g), dim3(256), 0, h->stream, buf, n, h->partial);
+  hipLaunchKernelGGL(reduce_stage2, dim3(1), dim3(256), 0, h->stream, (const double*)h->partial, g, dst);
+}
+
+int compute_error(lmgpu_handle* h, int which, double* out) {
+  launch_factors<false>(h, which);
+  reduce_to(h, h->ebuf0, h->nfac, h->dscal);
+  HIPCHECK(hipMemcpyAsync(h->h_scal, h->dscal, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  *out = h->h_scal[0];
+  return LMGPU_OK;
+}
+
+int do_linearize(lmgpu_handle* h) {
+  launch_factors<true>(h, h->cur);
+  HIPCHECK(hipGetLastError());
+  h->linearized = true;
+  return LMGPU_OK;
+}
+
+int fill_dampw(lmgpu_handle* h, int diagonal, double min_diag, double max_diag) {
+  if (!diagonal) {
+    if (!h->dampw_is_ones) {
+      std::vector<double> ones(h->ntot, 1.0);
+      HIPCHECK(hipMemcpyAsync(h->dampw, ones.data(), ones.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+      HIPCHECK(hipStreamSynchronize(h->stream));
+      h->dampw_is_ones = true;
+    }
+    return LMGPU_OK;
+  }
+  // hessianDiagonal, clamped (LevenbergMarquardtOptimizer.cpp:291-298: sqrt then squared by the prior = clamp(diag))
+  hipLaunchKernelGGL(hessian_diag_kernel, dim3((h->ntot + 255) / 256), dim3(256), 0, h->stream, h->ntot, h->d_scalar_var, h->d_scalar_col,
+                     h->d_vi_ptr, h->d_vi_fac, h->d_vi_pos, h->d_fd, (const double*)h->pool, h->hdiag);
+  std::vector<double> d(h->ntot);
+  HIPCHECK(hipMemcpyAsync(d.data(), h->hdiag, d.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  for (auto& x : d) {
+    const double s = std::sqrt(std::min(std::max(x, min_diag), max_diag));
+    x = s * s;
+  }
+  HIPCHECK(hipMemcpyAsync(h->dampw, d.data(), d.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  h->dampw_is_ones = false;
+  return LMGPU_OK;
+}
+
+// ---- numeric elimination of all fronts, level by level (a10-a13)
+int do_eliminate(lmgpu_handle* h, double lambda) {
+  hipStream_t s = h->stream;
+  HIPCHECK(hipMemsetAsync(h->d_status, 0x7f, sizeof(int), s));
+  for (const LevelWork& L : h->levels) {
+    for (int b = 0; b < kNumBins; b++) {
+      const int cnt = L.bin_begin[b + 1] - L.bin_begin[b];
+      if (cnt == 0) continue;
+      const int nmax = kBinN[b];
+      const int threads = (b == 0) ? 64 : (b == 1 ? 128 : 256);
+      hipLaunchKernelGGL(lds_front_kernel, dim3(cnt), dim3(threads), (size_t)nmax * nmax * sizeof(double), s,
+                         (const int32_t*)(h->d_lists + L.list_begin + L.bin_begin[b]), (const FrontDesc*)h->d_fronts,
+                         (const FrontFac*)h->d_ffac, (const FacDesc*)h->d_fd, (const ChildRef*)h->d_childs, (const int32_t*)h->d_cmap,
+                         (const int32_t*)h->d_fxoff, h->pool, lambda, (const double*)h->dampw, h->d_status);
+    }
+    for (int fi : L.hbm) {
+      const FrontDesc& F = h->h_fronts[fi];
+      const int64_t off = h->f_off[fi];
+      const int ld = h->f_ld[fi];
+      double* A = h->pool + off;
+      HIPCHECK(hipMemsetAsync(A, 0, (size_t)F.n * ld * sizeof(double), s));
+      if (F.fac_count > 0)
+        hipLaunchKernelGGL(hbm_assemble_factors_kernel, dim3(F.fac_count), dim3(64), 0, s, F, off, ld, (const FrontFac*)h->d_ffac,
+                           (const FacDesc*)h->d_fd, h->pool);
+      if (F.child_count > 0)
+        hipLaunchKernelGGL(hbm_assemble_children_kernel, dim3(F.child_count), dim3(256), 0, s, F, off, ld, (const ChildRef*)h->d_childs,
+                           (const int32_t*)h->d_cmap, h->pool);
+      hipLaunchKernelGGL(hbm_damp_kernel, dim3((F.nf + 255) / 256), dim3(256), 0, s, F, off, ld, (const int32_t*)h->d_fxoff, h->pool, lambda,
+                         (const double*)h->dampw);
+      if (h->comm && F.pad == 1) {
+        // replicated top front: sum the ranks' partial assemblies (separator contributions) over xGMI
+        ncclResult_t r = ncclAllReduce(A, A, (size_t)F.n * ld, ncclDouble, ncclSum, h->comm, s);
+        if (r != ncclSuccess) {
+          h->err = std::string("ncclAllReduce: ") + ncclGetErrorString(r);
+          return LMGPU_HIP_ERROR;
+        }
+      }
+      for (int k0 = 0; k0 < F.nf; k0 += NB) {
+        const int nb = std::min(NB, F.nf - k0);
+        const int cols = F.n - k0 - nb;
+        const int g = std::max(1, (cols + 255) / 256);
+        hipLaunchKernelGGL((potrf_trsm_kernel<NB>), dim3(g), dim3(256), 0, s, A, ld, F.n, F.nf, k0, nb, F.id, h->d_status);
+        if (cols > 0) {
+          const int T = (cols + 127) / 128;
+          hipLaunchKernelGGL(syrk_mfma_kernel, dim3(T, T), dim3(256), 0, s, A, ld, F.n, k0, nb);
+        }
+      }
+    }
+  }
+  HIPCHECK(hipGetLastError());
+  return LMGPU_OK;
+}
+
+// ---- back-substitution, top-down (a14)
+int do_backsub(lmgpu_handle* h) {
+  hipStream_t s = h->stream;
+  for (int li = (int)h->levels.size() - 1; li >= 0; li--) {
+    const LevelWork& L = h->levels[li];
+    for (int fi : L.hbm) {
+      const FrontDesc& F = h->h_fronts[fi];
+      const int64_t off = h->f_off[fi];
+      const int ld = h->f_ld[fi];
+      hipLaunchKernelGGL(hbm_rhs_init_kernel, dim3(F.nf), dim3(64), 0, s, F, off, ld, (const int32_t*)h->d_sxoff, (const double*)h->pool,
+                         (const double*)h->delta, h->ywork);
+      const int nblk = (F.nf + NB - 1) / NB;
+      for (int kb = nblk - 1; kb >= 0; kb--) {
+        const int r0 = kb * NB, nb = std::min(NB, F.nf - r0);
+        const int g = std::max(1, (r0 + 31) / 32);
+        hipLaunchKernelGGL((hbm_backsolve_step_kernel<NB>), dim3(g), dim3(256), 0, s, F, off, ld, r0, nb, (const int32_t*)h->d_fxoff,
+                           (const double*)h->pool, h->ywork, h->delta, h->d_status);
+      }
+    }
+    if (L.list_count > 0)
+      hipLaunchKernelGGL(lds_backsub_kernel, dim3((L.list_count + 3) / 4), dim3(256), 0, s, (const int32_t*)(h->d_lists + L.list_begin),
+                         L.list_count, (const FrontDesc*)h->d_fronts, (const int32_t*)h->d_fxoff, (const int32_t*)h->d_sxoff,
+                         (const double*)h->pool, h->delta, h->d_status);
+  }
+  HIPCHECK(hipGetLastError());
+  return LMGPU_OK;
+}
+
+// solve the damped system; returns LMGPU_OK / LMGPU_INDETERMINATE.  lin errors into h_scal[1], h_scal[2].
+int do_solve(lmgpu_handle* h, double lambda) {
+  hipStream_t s = h->stream;
+  hipEventRecord(h->ev[1], s);
+  int rc = do_eliminate(h, lambda);
+  if (rc) return rc;
+  hipEventRecord(h->ev[2], s);
+  rc = do_backsub(h);
+  if (rc) return rc;
+  hipEventRecord(h->ev[3], s);
+  hipLaunchKernelGGL(linear_error_kernel, dim3((h->nfac + 255) / 256), dim3(256), 0, s, (const FacDesc*)h->d_fd, h->nfac,
+                     (const double*)h->pool, (const double*)h->delta, h->ebuf0, h->ebuf1);
+  reduce_to(h, h->ebuf0, h->nfac, h->dscal + 1);
+  reduce_to(h, h->ebuf1, h->nfac, h->dscal + 2);
+  hipEventRecord(h->ev[4], s);
+  HIPCHECK(hipMemcpyAsync(h->h_scal + 1, h->dscal + 1, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHECK(hipMemcpyAsync(h->h_status, h->d_status, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHECK(hipStreamSynchronize(s));
+  h->solved = true;
+  if (*h->h_status < (int)h->h_fronts.size()) {
+    const Front& fr = h->plan.fronts[*h->h_status];
+    h->failed_slot = fr.vars[0];
+    return LMGPU_INDETERMINATE;
+  }
+  return LMGPU_OK;
+}
+
+int do_retract(lmgpu_handle* h, int from, int to) {
+  for (int t = 0; t < 4; t++) {
+    const int n = h->plan.type_count[t];
+    if (n == 0) continue;
+    hipLaunchKernelGGL(retract_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, t, n, (const double*)h->vals[from][t], h->vals[to][t],
+                       (const int32_t*)h->type_xoff[t], (const double*)h->delta);
+  }
+  HIPCHECK(hipGetLastError());
+  return LMGPU_OK;
+}
+
+void accumulate_times(lmgpu_handle* h, bool with_retract) {
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, h->ev[1], h->ev[2]) == hipSuccess) h->tim.eliminate_ms += ms;
+  if (hipEventElapsedTime(&ms, h->ev[2], h->ev[3]) == hipSuccess) h->tim.backsub_ms += ms;
+  if (hipEventElapsedTime(&ms, h->ev[3], h->ev[4]) == hipSuccess) h->tim.linear_error_ms += ms;
+  if (with_retract && hipEventElapsedTime(&ms, h->ev[5], h->ev[6]) == hipSuccess) h->tim.retract_error_ms += ms;
+}
+
+// LevenbergMarquardtOptimizer::tryLambda  (gtsam/nonlinear/LevenbergMarquardtOptimizer.cpp:121-270)
+int try_lambda(lmgpu_handle* h, const lmgpu_lm_params* p, bool* done) {
+  lmgpu_lm_state& st = h->lm;
+  double modelFidelity = 0.0;
+  bool step_is_successful = false, stopSearchingLambda = false;
+  double newError = std::numeric_limits<double>::infinity(), costChange = 0.0;
+  int rc = do_solve(h, st.lambda);
+  if (rc == LMGPU_HIP_ERROR) return rc;
+  const bool solved = (rc == LMGPU_OK);
+  bool retracted = false;
+  if (solved) {
+    const double oldLin = h->h_scal[1], newLin = h->h_scal[2];
+    const double linearizedCostChange = oldLin - newLin;
+    if (linearizedCostChange >= 0) {
+      hipEventRecord(h->ev[5], h->stream);
+      rc = do_retract(h, h->cur, h->cur ^ 1);
+      if (rc) return rc;
+      rc = compute_error(h, h->cur ^ 1, &newError);
+      if (rc) return rc;
+      hipEventRecord(h->ev[6], h->stream);
+      hipEventSynchronize(h->ev[6]);
+      retracted = true;
+      costChange = st.error - newError;
+      if (linearizedCostChange > std::numeric_limits<double>::epsilon() * oldLin) {
+        modelFidelity = costChange / linearizedCostChange;
+        step_is_successful = modelFidelity > p->minModelFidelity;
+      }
+      const double minAbsoluteTolerance = p->relativeErrorTol * st.error;
+      if (std::abs(costChange) < minAbsoluteTolerance) stopSearchingLambda = true;
+    }
+  }
+  accumulate_times(h, retracted);
+  h->tim.inner_iterations += 1;
+  if (step_is_successful) {
+    // decreaseLambda (LevenbergMarquardtState.h:80-93)
+    double newLambda = st.lambda, newFactor = st.currentFactor;
+    if (p->useFixedLambdaFactor) {
+      newLambda /= st.currentFactor;
+    } else {
+      newLambda *= std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * modelFidelity - 1.0, 3));
+      newFactor = 2.0 * st.currentFactor;
+    }
+    newLambda = std::max(p->lambdaLowerBound, newLambda);
+    h->cur ^= 1;
+    h->linearized = false;
+    st.error = newError;
+    st.lambda = newLambda;
+    st.currentFactor = newFactor;
+    st.iterations += 1;
+    st.totalNumberInnerIterations += 1;
+    *done = true;
+  } else if (!stopSearchingLambda) {
+    // increaseLambda (:70-76)
+    st.lambda *= st.currentFactor;
+    st.totalNumberInnerIterations += 1;
+    if (!p->useFixedLambdaFactor) st.currentFactor *= 2.0;
+    *done = (st.lambda >= p->lambdaUpperBound);
+  } else {
+    *done = true;
+  }
+  return LMGPU_OK;
+}
+
+int lm_iterate(lmgpu_handle* h, const lmgpu_lm_params* p) {
+  std::memset(&h->tim, 0, sizeof(h->tim));
+  hipEventRecord(h->ev[0], h->stream);
+  int rc = do_linearize(h);
+  if (rc) return rc;
+  hipEventRecord(h->ev[7], h->stream);
+  rc = fill_dampw(h, p->diagonalDamping, p->minDiagonal, p->maxDiagonal);
+  if (rc) return rc;
+  bool done = false;
+  while (!done) {
+    rc = try_lambda(h, p, &done);
+    if (rc) return rc;
+  }
+  hipStreamSynchronize(h->stream);
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, h->ev[0], h->ev[7]) == hipSuccess) h->tim.linearize_ms = ms;
+  h->tim.total_ms = h->tim.linearize_ms + h->tim.eliminate_ms + h->tim.backsub_ms + h->tim.linear_error_ms + h->tim.retract_error_ms;
+  return LMGPU_OK;
+}
+
+// checkConvergence gtsam/nonlinear/NonlinearOptimizer.cpp:182-231
+bool check_convergence(double relTol, double absTol, double errTol, double currentError, double newError) {
+  if (newError <= errTol) return true;
+  const double absoluteDecrease = currentError - newError;
+  const double relativeDecrease = absoluteDecrease / currentError;
+  return (relTol && (relativeDecrease <= relTol)) || (absoluteDecrease <= absTol);
+}
+
+}  // namespace
+
+// =============================================================================================== C ABI
+extern "C" {
+
+int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
+  if (!cfg || !out) return LMGPU_INVALID;
+  lmgpu_handle* h = new lmgpu_handle();
+  h->cfg = *cfg;
+  h->device = cfg->device;
+  *out = h;
+  if (h->device >= 0) {
+    HIPCHECK(hipSetDevice(h->device));
+    HIPCHECK(hipStreamCreate(&h->stream));
+    for (int i = 0; i < 8; i++) HIPCHECK(hipEventCreate(&h->ev[i]));
+    HIPCHECK(hipHostMalloc((void**)&h->h_scal, 8 * sizeof(double), hipHostMallocDefault));
+    HIPCHECK(hipHostMalloc((void**)&h->h_status, sizeof(int), hipHostMallocDefault));
+    HIPCHECK(hipFuncSetAttribute((const void*)lds_front_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8));
+  }
+  return LMGPU_OK;
+}
+
+int lmgpu_destroy(lmgpu_handle* h) {
+  if (!h) return LMGPU_INVALID;
+  if (h->device >= 0) {
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->comm) ncclCommDestroy(h->comm);
+    auto fr = [](void* p) {
+      if (p) hipFree(p);
+    };
+    fr(h->pool);
+    for (int w = 0; w < 2; w++)
+      for (int t = 0; t < 4; t++) fr(h->vals[w][t]);
+    for (int t = 0; t < 4; t++) fr(h->type_xoff[t]);
+    fr(h->delta); fr(h->dampw); fr(h->hdiag); fr(h->ebuf0); fr(h->ebuf1); fr(h->partial); fr(h->dscal); fr(h->ywork); fr(h->d_status);
+    fr(h->d_fd); fr(h->d_fronts); fr(h->d_ffac); fr(h->d_childs); fr(h->d_cmap); fr(h->d_fxoff); fr(h->d_sxoff); fr(h->d_lists);
+    fr(h->d_scalar_var); fr(h->d_scalar_col); fr(h->d_vi_ptr); fr(h->d_vi_fac); fr(h->d_vi_pos);
+    for (Bucket& b : h->buckets) {
+      fr(b.d_vidx); fr(b.d_meas); fr(b.d_noise); fr(b.d_epos);
+    }
+    if (h->h_scal) hipHostFree(h->h_scal);
+    if (h->h_status) hipHostFree(h->h_status);
+    for (int i = 0; i < 8; i++)
+      if (h->ev[i]) hipEventDestroy(h->ev[i]);
+    if (h->stream) hipStreamDestroy(h->stream);
+  }
+  delete h;
+  return LMGPU_OK;
+}
+
+const char* lmgpu_last_error(const lmgpu_handle* h) { return h ? h->err.c_str() : "null handle"; }
+int lmgpu_last_failed_slot(const lmgpu_handle* h) { return h ? h->failed_slot : -1; }
+
+int lmgpu_set_variables(lmgpu_handle* h, int32_t n_vars, const uint64_t* keys, const int32_t* types) {
+  if (!h || n_vars <= 0 || !keys || !types || h->finalized) return LMGPU_INVALID;
+  h->plan.n_vars = n_vars;
+  h->plan.keys.assign(keys, keys + n_vars);
+  h->plan.types.assign(types, types + n_vars);
+  for (int i = 0; i < n_vars; i++)
+    if (types[i] < 0 || types[i] >= LMGPU_NUM_VAR_TYPES) {
+      h->err = "bad variable type";
+      return LMGPU_INVALID;
+    }
+  return LMGPU_OK;
+}
+
+int lmgpu_add_factor_bucket(lmgpu_handle* h, int32_t type, int32_t n, const int32_t* graph_index, const int32_t* var_slots, const double* meas,
+                            int32_t noise_kind, const double* noise) {
+  if (!h || h->finalized || type < 0 || type >= LMGPU_NUM_FACTOR_TYPES || n < 0 || h->plan.n_vars == 0) return LMGPU_INVALID;
+  if (noise_kind != LMGPU_N_UNIT && noise_kind != LMGPU_N_DIAG && noise_kind != LMGPU_N_GAUSS) return LMGPU_INVALID;
+  if (n == 0) return LMGPU_OK;
+  if (!graph_index || !var_slots || !meas || (noise_kind != LMGPU_N_UNIT && !noise)) return LMGPU_INVALID;
+  const int ar = kFactorArity[type], rows = kFactorRows[type], ml = kFactorMeas[type];
+  for (int i = 0; i < n; i++)
+    for (int k = 0; k < ar; k++) {
+      const int s = var_slots[i * ar + k];
+      if (s < 0 || s >= h->plan.n_vars) {
+        h->err = "factor references unknown slot";
+        return LMGPU_INVALID;
+      }
+      const int want = (k == 0) ? kFactorVar0[type] : kFactorVar1[type];
+      if (h->plan.types[s] != want) {
+        h->err = "factor/variable type mismatch";
+        return LMGPU_INVALID;
+      }
+    }
+  Bucket b;
+  b.type = type;
+  b.n = n;
+  b.noise_kind = noise_kind;
+  b.graph_index.assign(graph_index, graph_index + n);
+  b.slots.assign(var_slots, var_slots + (size_t)n * ar);
+  b.meas.assign(meas, meas + (size_t)n * ml);
+  const int nl = noise_kind == LMGPU_N_DIAG ? rows : (noise_kind == LMGPU_N_GAUSS ? rows * rows : 0);
+  if (nl) b.noise.assign(noise, noise + (size_t)n * nl);
+  int cols = 1;
+  for (int k = 0; k < ar; k++) cols += kVarDim[(k == 0) ? kFactorVar0[type] : kFactorVar1[type]];
+  b.rows = rows;
+  b.cols = cols;
+  const int bi = (int)h->buckets.size();
+  for (int i = 0; i < n; i++) {
+    FactorRef f;
+    f.bucket = bi;
+    f.idx = i;
+    f.slots[0] = var_slots[i * ar];
+    f.slots[1] = ar > 1 ? var_slots[i * ar + 1] : -1;
+    f.graph_index = graph_index[i];
+    h->plan.factors.push_back(f);
+  }
+  h->buckets.push_back(std::move(b));
+  return LMGPU_OK;
+}
+
+int lmgpu_finalize_structure(lmgpu_handle* h) {
+  if (!h || h->finalized) return LMGPU_INVALID;
+  std::string e = h->plan.build(kLdsLimitN);
+  if (!e.empty()) {
+    h->err = e;
+    return LMGPU_INVALID;
+  }
+  Plan& P = h->plan;
+  h->nfac = (int)P.factors.size();
+  h->ntot = P.xoff[P.n_vars];
+  h->nstore = P.voff[P.n_vars];
+  for (int i = 1; i < h->nfac; i++)
+    if (P.factors[i].graph_index == P.factors[i - 1].graph_index) {
+      h->err = "duplicate graph_index";
+      return LMGPU_INVALID;
+    }
+  h->fac_of_graph.resize(h->nfac);
+  h->graph_index_sorted.resize(h->nfac);
+  for (int i = 0; i < h->nfac; i++) {
+    h->fac_of_graph[i] = {P.factors[i].bucket, P.factors[i].idx};
+    h->graph_index_sorted[i] = P.factors[i].graph_index;
+  }
+  // ---- pool layout: Jacobians | [R S d] + updates of LDS fronts | dense HBM fronts
+  int64_t off = 0;
+  for (Bucket& b : h->buckets) {
+    b.joff = off;
+    off += (int64_t)b.n * b.rows * b.cols;
+    off = (off + 15) & ~int64_t(15);
+  }
+  const int NF = (int)P.fronts.size();
+  h->h_fronts.assign(NF, FrontDesc{});
+  h->f_off.assign(NF, -1);
+  h->f_ld.assign(NF, 0);
+  std::vector<FacDesc> fd(h->nfac);
+  for (int i = 0; i < h->nfac; i++) {
+    const FactorRef& f = P.factors[i];
+    const Bucket& b = h->buckets[f.bucket];
+    FacDesc d{};
+    d.joff = b.joff + (int64_t)f.idx * b.rows * b.cols;
+    d.rows = (int16_t)b.rows;
+    d.d0 = (int16_t)P.dims[f.slots[0]];
+    d.d1 = (int16_t)(f.slots[1] >= 0 ? P.dims[f.slots[1]] : 0);
+    d.x0 = P.xoff[f.slots[0]];
+    d.x1 = f.slots[1] >= 0 ? P.xoff[f.slots[1]] : -1;
+    fd[i] = d;
+  }
+  std::vector<FrontFac> ffac;
+  std::vector<ChildRef> childs;
+  std::vector<int32_t> cmap, fxoff, sxoff;
+  std::vector<int32_t> colof(P.n_vars, -1);
+  for (int fi = 0; fi < NF; fi++) {
+    const Front& fr = P.fronts[fi];
+    FrontDesc& F = h->h_fronts[fi];
+    F.n = fr.n;
+    F.nf = fr.nf;
+    F.id = fi;
+    F.pad = 0;
+    if (fr.cls == 0) {
+      F.ld_rsd = fr.n;
+      F.rsd_off = off;
+      off += (int64_t)fr.nf * fr.n;
+      F.ld_u = fr.n - fr.nf;
+      F.u_off = off;
+      off += (int64_t)F.ld_u * F.ld_u;
+    } else {
+      const int ld = (fr.n + 15) & ~15;
+      off = (off + 15) & ~int64_t(15);
+      h->f_off[fi] = off;
+      h->f_ld[fi] = ld;
+      F.ld_rsd = ld;
+      F.rsd_off = off;
+      F.ld_u = ld;
+      F.u_off = off + (int64_t)fr.nf * ld + fr.nf;
+      off += (int64_t)fr.n * ld;
+    }
+    for (size_t k = 0; k < fr.vars.size(); k++) colof[fr.vars[k]] = fr.col_off[k];
+    // factors
+    F.fac_begin = (int)ffac.size();
+    F.fac_count = (int)fr.factors.size();
+    for (int32_t f : fr.factors) {
+      FrontFac ff;
+      ff.fac = f;
+      ff.c0 = colof[P.factors[f].slots[0]];
+      ff.c1 = P.factors[f].slots[1] >= 0 ? colof[P.factors[f].slots[1]] : 0;
+      ffac.push_back(ff);
+    }
+    // children: map child's separator scalars (+ rhs) to this front's columns
+    F.child_begin = (int)childs.size();
+    F.child_count = (int)fr.children.size();
+    for (int32_t c : fr.children) {
+      const Front& ch = P.fronts[c];
+      const FrontDesc& CF = h->h_fronts[c];
+      ChildRef cr{};
+      cr.u_off = CF.u_off;
+      cr.ld = CF.ld_u;
+      cr.m = ch.n - ch.nf;
+      cr.map_begin = (int)cmap.size();
+      for (size_t k = ch.n_frontal_vars; k < ch.vars.size(); k++)
+        for (int d = 0; d < P.dims[ch.vars[k]]; d++) cmap.push_back(colof[ch.vars[k]] + d);
+      cmap.push_back(fr.n - 1);
+      childs.push_back(cr);
+    }
+    F.fx_begin = (int)fxoff.size();
+    for (int k = 0; k < fr.n_frontal_vars; k++)
+      for (int d = 0; d < P.dims[fr.vars[k]]; d++) fxoff.push_back(P.xoff[fr.vars[k]] + d);
+    F.sx_begin = (int)sxoff.size();
+    for (size_t k = fr.n_frontal_vars; k < fr.vars.size(); k++)
+      for (int d = 0; d < P.dims[fr.vars[k]]; d++) sxoff.push_back(P.xoff[fr.vars[k]] + d);
+  }
+  h->pool_doubles = (size_t)off + 16;
+  // ---- level work lists
+  h->levels.assign(P.n_levels, LevelWork());
+  std::vector<std::vector<std::vector<int>>> byLevelBin(P.n_levels, std::vector<std::vector<int>>(kNumBins));
+  for (int fi = 0; fi < NF; fi++) {
+    const Front& fr = P.fronts[fi];
+    if (fr.cls == 1) {
+      h->levels[fr.level].hbm.push_back(fi);
+    } else {
+      int b = 0;
+      while (fr.n > kBinN[b]) b++;
+      byLevelBin[fr.level][b].push_back(fi);
+    }
+  }
+  std::vector<int32_t> lists;
+  for (int l = 0; l < P.n_levels; l++) {
+    LevelWork& L = h->levels[l];
+    L.list_begin = (int)lists.size();
+    int c = 0;
+    for (int b = 0; b < kNumBins; b++) {
+      L.bin_begin[b] = c;
+      for (int fi : byLevelBin[l][b]) lists.push_back(fi);
+      c += (int)byLevelBin[l][b].size();
+    }
+    L.bin_begin[kNumBins] = c;
+    L.list_count = c;
+  }
+  h->finalized = true;
+  if (h->device < 0) return LMGPU_OK;  // structure-only handle: symbolic analysis available, no compute
+
+  // ---- device upload
+  HIPCHECK(hipSetDevice(h->device));
+  HIPCHECK(hipMalloc((void**)&h->pool, h->pool_doubles * sizeof(double)));
+  int rc;
+  if ((rc = upload(h, &h->d_fd, fd))) return rc;
+  if ((rc = upload(h, &h->d_fronts, h->h_fronts))) return rc;
+  if ((rc = upload(h, &h->d_ffac, ffac))) return rc;
+  if ((rc = upload(h, &h->d_childs, childs))) return rc;
+  if ((rc = upload(h, &h->d_cmap, cmap))) return rc;
+  if ((rc = upload(h, &h->d_fxoff, fxoff))) return rc;
+  if ((rc = upload(h, &h->d_sxoff, sxoff))) return rc;
+  if ((rc = upload(h, &h->d_lists, lists))) return rc;
+  // per-bucket arrays
+  std::vector<int32_t> rank_of(h->nfac);
+  for (Bucket& b : h->buckets) {
+    const int ar = kFactorArity[b.type];
+    std::vector<int32_t> vidx((size_t)b.n * ar);
+    for (size_t i = 0; i < vidx.size(); i++) vidx[i] = P.tidx[b.slots[i]];
+    if ((rc = upload(h, &b.d_vidx, vidx))) return rc;
+    if ((rc = upload(h, &b.d_meas, b.meas))) return rc;
+    if (!b.noise.empty()) {
+      if ((rc = upload(h, &b.d_noise, b.noise))) return rc;
+    }
+  }
+  {
+    std::vector<std::vector<int32_t>> epos(h->buckets.size());
+    for (size_t bi = 0; bi < h->buckets.size(); bi++) epos[bi].resize(h->buckets[bi].n);
+    for (int i = 0; i < h->nfac; i++) epos[P.factors[i].bucket][P.factors[i].idx] = i;
+    for (size_t bi = 0; bi < h->buckets.size(); bi++)
+      if ((rc = upload(h, &h->buckets[bi].d_epos, epos[bi]))) return rc;
+  }
+  // values, per type
+  for (int t = 0; t < 4; t++) {
+    const size_t bytes = std::max<size_t>(1, (size_t)P.type_count[t] * kVarStore[t]) * sizeof(double);
+    HIPCHECK(hipMalloc((void**)&h->vals[0][t], bytes));
+    HIPCHECK(hipMalloc((void**)&h->vals[1][t], bytes));
+    std::vector<int32_t> xo(P.type_count[t]);
+    for (int s = 0; s < P.n_vars; s++)
+      if (P.types[s] == t) xo[P.tidx[s]] = P.xoff[s];
+    if ((rc = upload(h, &h->type_xoff[t], xo))) return rc;
+  }
+  // hessian-diagonal CSR
+  {
+    std::vector<int32_t> scalar_var(h->ntot), scalar_col(h->ntot), vi_ptr(P.n_vars + 1, 0), vi_fac;
+    std::vector<int8_t> vi_pos;
+    for (int s = 0; s < P.n_vars; s++)
+      for (int d = 0; d < P.dims[s]; d++) {
+        scalar_var[P.xoff[s] + d] = s;
+        scalar_col[P.xoff[s] + d] = d;
+      }
+    std::vector<std::vector<std::pair<int32_t, int8_t>>> vi(P.n_vars);
+    for (int i = 0; i < h->nfac; i++) {
+      vi[P.factors[i].slots[0]].push_back({i, 0});
+      if (P.factors[i].slots[1] >= 0) vi[P.factors[i].slots[1]].push_back({i, 1});
+    }
+    for (int s = 0; s < P.n_vars; s++) {
+      vi_ptr[s] = (int32_t)vi_fac.size();
+      for (auto& pr : vi[s]) {
+        vi_fac.push_back(pr.first);
+        vi_pos.push_back(pr.second);
+      }
+    }
+    vi_ptr[P.n_vars] = (int32_t)vi_fac.size();
+    if ((rc = upload(h, &h->d_scalar_var, scalar_var))) return rc;
+    if ((rc = upload(h, &h->d_scalar_col, scalar_col))) return rc;
+    if ((rc = upload(h, &h->d_vi_ptr, vi_ptr))) return rc;
+    if ((rc = upload(h, &h->d_vi_fac, vi_fac))) return rc;
+    if ((rc = upload(h, &h->d_vi_pos, vi_pos))) return rc;
+  }
+  HIPCHECK(hipMalloc((void**)&h->delta, h->ntot * sizeof(double)));
+  HIPCHECK(hipMemset(h->delta, 0, h->ntot * sizeof(double)));
+  HIPCHECK(hipMalloc((void**)&h->dampw, h->ntot * sizeof(double)));
+  HIPCHECK(hipMalloc((void**)&h->hdiag, h->ntot * sizeof(double)));
+  HIPCHECK(hipMalloc((void**)&h->ebuf0, std::max(1, h->nfac) * sizeof(double)));
+  HIPCHECK(hipMalloc((void**)&h->ebuf1, std::max(1, h->nfac) * sizeof(double)));
+  HIPCHECK(hipMalloc((void**)&h->partial, 256 * sizeof(double)));
+  HIPCHECK(hipMalloc((void**)&h->dscal, 8 * sizeof(double)));
+  HIPCHECK(hipMalloc((void**)&h->ywork, std::max(1, P.max_front_n) * sizeof(double)));
+  HIPCHECK(hipMalloc((void**)&h->d_status, sizeof(int)));
+  return LMGPU_OK;
+}
+
+int lmgpu_total_dim(const lmgpu_handle* h) { return (h && h->finalized) ? h->ntot : -1; }
+int lmgpu_total_store(const lmgpu_handle* h) { return (h && h->finalized) ? h->nstore : -1; }
+
+int lmgpu_set_values(lmgpu_handle* h, const double* packed) {
+  if (!h || !h->finalized || !packed) return LMGPU_INVALID;
+  int rc = need_device(h);
+  if (rc) return rc;
+  const Plan& P = h->plan;
+  for (int t = 0; t < 4; t++) {
+    if (P.type_count[t] == 0) continue;
+    std::vector<double> buf((size_t)P.type_count[t] * kVarStore[t]);
+    for (int s = 0; s < P.n_vars; s++)
+      if (P.types[s] == t) std::memcpy(&buf[(size_t)P.tidx[s] * kVarStore[t]], packed + P.voff[s], kVarStore[t] * sizeof(double));
+    HIPCHECK(hipMemcpy(h->vals[h->cur][t], buf.data(), buf.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
+  h->have_values = true;
+  h->linearized = false;
+  return LMGPU_OK;
+}
+
+int lmgpu_get_values(lmgpu_handle* h, double* packed) {
+  if (!h || !h->finalized || !packed || !h->have_values) return LMGPU_INVALID;
+  int rc = need_device(h);
+  if (rc) return rc;
+  const Plan& P = h->plan;
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  for (int t = 0; t < 4; t++) {
+    if (P.type_count[t] == 0) continue;
+    std::vector<double> buf((size_t)P.type_count[t] * kVarStore[t]);
+    HIPCHECK(hipMemcpy(buf.data(), h->vals[h->cur][t], buf.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int s = 0; s < P.n_vars; s++)
+      if (P.types[s] == t) std::memcpy(packed + P.voff[s], &buf[(size_t)P.tidx[s] * kVarStore[t]], kVarStore[t] * sizeof(double));
+  }
+  return LMGPU_OK;
+}
+
+int lmgpu_error(lmgpu_handle* h, double* total) {
+  if (!h || !h->finalized || !total || !h->have_values) return LMGPU_INVALID;
+  int rc = need_device(h);
+  if (rc) return rc;
+  return compute_error(h, h->cur, total);
+}
+
+int lmgpu_linearize(lmgpu_handle* h) {
+  if (!h || !h->finalized || !h->have_values) return LMGPU_INVALID;
+  int rc = need_device(h);
+  if (rc) return rc;
+  rc = do_linearize(h);
+  if (rc) return rc;
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  return LMGPU_OK;
+}
+
+int lmgpu_solve(lmgpu_handle* h, double lambda, int32_t diagonal_damping, double min_diag, double max_diag, double* delta_packed,
+                double* lin_err0, double* lin_err1) {
+  if (!h || !h->finalized || !h->linearized) return LMGPU_INVALID;
+  int rc = need_device(h);
+  if (rc) return rc;
+  rc = fill_dampw(h, diagonal_damping, min_diag, max_diag);
+  if (rc) return rc;
+  rc = do_solve(h, lambda);
+  if (rc == LMGPU_HIP_ERROR) return rc;
+  if (delta_packed) HIPCHECK(hipMemcpy(delta_packed, h->delta, h->ntot * sizeof(double), hipMemcpyDeviceToHost));
+  if (lin_err0) *lin_err0 = h->h_scal[1];
+  if (lin_err1) *lin_err1 = h->h_scal[2];
+  return rc;
+}
+
+int lmgpu_retract(lmgpu_handle* h, const double* delta_packed) {
+  if (!h || !h->finalized || !h->have_values) return LMGPU_INVALID;
+  int rc = need_device(h);
+  if (rc) return rc;
+  if (delta_packed) HIPCHECK(hipMemcpy(h->delta, delta_packed, h->ntot * sizeof(double), hipMemcpyHostToDevice));
+  rc = do_retract(h, h->cur, h->cur ^ 1);
+  if (rc) return rc;
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  h->cur ^= 1;
+  h->linearized = false;
+  return LMGPU_OK;
+}
+
+int lmgpu_hessian_diagonal(lmgpu_handle* h, double* diag) {
+  if (!h || !h->finalized || !h->linearized || !diag) return LMGPU_INVALID;
+  int rc = need_device(h);
+  if (rc) return rc;
+  hipLaunchKernelGGL(hessian_diag_kernel, dim3((h->ntot + 255) / 256), dim3(256), 0, h->stream, h->ntot, h->d_scalar_var, h->d_scalar_col,
+                     h->d_vi_ptr, h->d_vi_fac, h->d_vi_pos, h->d_fd, (const double*)h->pool, h->hdiag);
+  HIPCHECK(hipMemcpyAsync(diag, h->hdiag, h->ntot * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  return LMGPU_OK;
+}
+
+int lmgpu_lm_init(lmgpu_handle* h, const lmgpu_lm_params* p, lmgpu_lm_state* out) {
+  if (!h || !p || !h->finalized || !h->have_values) return LMGPU_INVALID;
+  int rc = need_device(h);
+  if (rc) return rc;
+  // LevenbergMarquardtOptimizer ctor (LevenbergMarquardtOptimizer.cpp:47-63): state(values, graph.error(values), lambdaInitial, lambdaFactor)
+  double e = 0;
+  rc = compute_error(h, h->cur, &e);
+  if (rc) return rc;
+  h->lm.error = e;
+  h->lm.lambda = p->lambdaInitial;
+  h->lm.currentFactor = p->lambdaFactor;
+  h->lm.iterations = 0;
+  h->lm.totalNumberInnerIterations = 0;
+  if (out) *out = h->lm;
+  return LMGPU_OK;
+}
+
+int lmgpu_iterate(lmgpu_handle* h, const lmgpu_lm_params* p, lmgpu_lm_state* inout) {
+  if (!h || !p || !h->finalized || !h->have_values) return LMGPU_INVALID;
+  int rc = need_device(h);
+  if (rc) return rc;
+  if (inout) {
+    h->lm.lambda = inout->lambda;
+    h->lm.currentFactor = inout->currentFactor;
+  }
+  rc = lm_iterate(h, p);
+  if (inout) *inout = h->lm;
+  return rc;
+}
+
+int lmgpu_optimize(lmgpu_handle* h, const lmgpu_lm_params* p, lmgpu_lm_state* inout) {
+  if (!h || !p || !h->finalized || !h->have_values) return LMGPU_INVALID;
+  int rc = need_device(h);
+  if (rc) return rc;
+  // NonlinearOptimizer::defaultOptimize (gtsam/nonlinear/NonlinearOptimizer.cpp:62-117)
+  double currentError = h->lm.error;
+  if (currentError <= p->errorTol || h->lm.iterations >= p->maxIterations) {
+    if (inout) *inout = h->lm;
+    return LMGPU_OK;
+  }
+  double newError = currentError;
+  do {
+    currentError = newError;
+    rc = lm_iterate(h, p);
+    if (rc) return rc;
+    newError = h->lm.error;
+  } while (h->lm.iterations < p->maxIterations &&
+           !check_convergence(p->relativeErrorTol, p->absoluteErrorTol, p->errorTol, currentError, newError) && std::isfinite(currentError));
+  if (inout) *inout = h->lm;
+  return LMGPU_OK;
+}
+
+int lmgpu_get_timings(const lmgpu_handle* h, lmgpu_timings* out) {
+  if (!h || !out) return LMGPU_INVALID;
+  *out = h->tim;
+  return LMGPU_OK;
+}
+
+int lmgpu_get_jacobian(lmgpu_handle* h, int32_t graph_index, double* out, int32_t* rows, int32_t* cols) {
+  if (!h || !h->finalized) return LMGPU_INVALID;
+  auto it = std::lower_bound(h->graph_index_sorted.begin(), h->graph_index_sorted.end(), graph_index);
+  if (it == h->graph_index_sorted.end() || *it != graph_index) return LMGPU_INVALID;
+  const auto [bi, idx] = h->fac_of_graph[it - h->graph_index_sorted.begin()];
+  const Bucket& b = h->buckets[bi];
+  if (rows) *rows = b.rows;
+  if (cols) *cols = b.cols;
+  if (out) {
+    int rc = need_device(h);
+    if (rc) return rc;
+    if (!h->linearized) return LMGPU_INVALID;
+    HIPCHECK(hipMemcpy(out, h->pool + b.joff + (int64_t)idx * b.rows * b.cols, (size_t)b.rows * b.cols * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  return LMGPU_OK;
+}
+
+int lmgpu_num_fronts(const lmgpu_handle* h) { return (h && h->finalized) ? (int)h->plan.fronts.size() : -1; }
+
+int lmgpu_front_info(const lmgpu_handle* h, int32_t front, int32_t* info6) {
+  if (!h || !h->finalized || front < 0 || front >= (int)h->plan.fronts.size() || !info6) return LMGPU_INVALID;
+  const Front& fr = h->plan.fronts[front];
+  info6[0] = (int)fr.vars.size();
+  info6[1] = fr.n_frontal_vars;
+  info6[2] = fr.nf;
+  info6[3] = fr.n;
+  info6[4] = fr.parent;
+  info6[5] = fr.cls;
+  return LMGPU_OK;
+}
+
+int lmgpu_get_front(lmgpu_handle* h, int32_t front, int32_t* slots, double* RSd) {
+  if (!h || !h->finalized || front < 0 || front >= (int)h->plan.fronts.size()) return LMGPU_INVALID;
+  const Front& fr = h->plan.fronts[front];
+  if (slots) std::memcpy(slots, fr.vars.data(), fr.vars.size() * sizeof(int32_t));
+  if (RSd) {
+    int rc = need_device(h);
+    if (rc) return rc;
+    if (!h->solved) return LMGPU_INVALID;
+    const FrontDesc& F = h->h_fronts[front];
+    std::vector<double> rows((size_t)F.nf * F.ld_rsd);
+    HIPCHECK(hipMemcpy(rows.data(), h->pool + F.rsd_off, rows.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int i = 0; i < F.nf; i++)
+      for (int j = 0; j < F.n; j++) RSd[(size_t)j * F.nf + i] = (j >= i) ? rows[(size_t)i * F.ld_rsd + j] : 0.0;
+  }
+  return LMGPU_OK;
+}
+
+int lmgpu_comm_unique_id(char id128[128]) {
+  ncclUniqueId id;
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+  if (ncclGetUniqueId(&id) != ncclSuccess) return LMGPU_HIP_ERROR;
+  std::memcpy(id128, &id, 128);
+  return LMGPU_OK;
+}
+
+int lmgpu_comm_init(lmgpu_handle* h, const char id128[128]) {
+  if (!h || !id128) return LMGPU_INVALID;
+  int rc = need_device(h);
+  if (rc) return rc;
+  ncclUniqueId id;
+  std::memcpy(&id, id128, 128);
+  HIPCHECK(hipSetDevice(h->device));
+  ncclResult_t r = ncclCommInitRank(&h->comm, h->cfg.world_size, id, h->cfg.rank);
+  if (r != ncclSuccess) {
+    h->err = std::string("ncclCommInitRank: ") + ncclGetErrorString(r);
+    return LMGPU_HIP_ERROR;
+  }
+  return LMGPU_OK;
+}
+
+// ---------------------------------------------------------------- peak micro-benchmarks
+__global__ __launch_bounds__(256) void peak_mfma_f64_kernel(double* out, int iters) {
+  double4_t acc[4];
+  for (int i = 0; i < 4; i++) acc[i] = double4_t{0, 0, 0, 0};
+  const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  double s = 0;
+  for (int i = 0; i < 4; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void peak_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+int lmgpu_peak_mfma_f64(int32_t device, int32_t iters, double* tflops) {
+  if (hipSetDevice(device) != hipSuccess) return LMGPU_HIP_ERROR;
+  const int blocks = 256 * 8;
+  double* out = nullptr;
+  if (hipMalloc((void**)&out, (size_t)blocks * 256 * sizeof(double)) != hipSuccess) return LMGPU_HIP_ERROR;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  hipLaunchKernelGGL(peak_mfma_f64_kernel, dim3(blocks), dim3(256), 0, 0, out, 16);
+  hipEventRecord(e0, 0);
+  hipLaunchKernelGGL(peak_mfma_f64_kernel, dim3(blocks), dim3(256), 0, 0, out, iters);
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  const double flops = (double)blocks * 4 /*waves*/ * (double)iters * 4 * 2048.0;
+  *tflops = flops / (ms * 1e-3) / 1e12;
+  hipFree(out);
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  return LMGPU_OK;
+}
+
+int lmgpu_peak_hbm_copy(int32_t device, int64_t bytes, int32_t iters, double* gbps) {
+  if (hipSetDevice(device) != hipSuccess) return LMGPU_HIP_ERROR;
+  float4 *a = nullptr, *b = nullptr;
+  if (hipMalloc((void**)&a, bytes) != hipSuccess || hipMalloc((void**)&b, bytes) != hipSuccess) return LMGPU_HIP_ERROR;
+  hipMemset(a, 1, bytes);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  const size_t n = bytes / 16;
+  hipLaunchKernelGGL(peak_copy_kernel, dim3(2048), dim3(256), 0, 0, a, b, n);
+  hipEventRecord(e0, 0);
+  for (int i = 0; i < iters; i++) hipLaunchKernelGGL(peak_copy_kernel, dim3(2048), dim3(256), 0, 0, a, b, n);
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  *gbps = 2.0 * (double)bytes * iters / (ms * 1e-3) / 1e9;
+  hipFree(a);
+  hipFree(b);
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  return LMGPU_OK;
+}
+
+}  // extern "C"

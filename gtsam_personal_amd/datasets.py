@@ -1,0 +1,223 @@
+"""Wire formats either side of the hot path: BAL, g2o / TORO 2D, EDGE3 / g2o 3D.
+
+Restates the readers the reference's examples use so that the harness ingests the same numbers:
+  SfmData::FromBalFile           gtsam/sfm/SfmData.cpp:189-246  (parses through FLOAT, negates v, openGL2gtsam :79-85)
+  load2D / readG2o               gtsam/slam/dataset.cpp:505-569, 621-633 (noise: createNoiseModel :216-296)
+  load3D                         gtsam/slam/dataset.cpp:922-944 (EDGE3 / EDGE_SE3:QUAT :811-863, VERTEX3 / VERTEX_SE3:QUAT :758-776)
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .graph import NonlinearFactorGraph, P, Values, noiseModel, symbol
+
+
+# ---------------------------------------------------------------- small host geometry (loader-side only)
+def rot3_expmap(w):
+    """Rot3::Rodrigues = SO3::Expmap (gtsam/geometry/SO3.cpp:61-95)."""
+    w = np.asarray(w, dtype=np.float64)
+    theta2 = float(w @ w)
+    W = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    if theta2 <= np.finfo(np.float64).eps:
+        A, B = 1.0 - theta2 / 6.0, 0.5 - theta2 / 24.0
+    else:
+        theta = np.sqrt(theta2)
+        A = np.sin(theta) / theta
+        s2 = np.sin(theta / 2.0)
+        B = 2.0 * s2 * s2 / theta2
+    return np.eye(3) + A * W + B * (W @ W)
+
+
+def rot3_rzryrx(x, y, z):
+    """Rot3::RzRyRx (gtsam/geometry/Rot3M.cpp:84-108)."""
+    cx, sx, cy, sy, cz, sz = np.cos(x), np.sin(x), np.cos(y), np.sin(y), np.cos(z), np.sin(z)
+    ss_, cs_, sc_, cc_ = sx * sy, cx * sy, sx * cy, cx * cy
+    c_s, s_s, _cs, _cc, s_c, c_c = cx * sz, sx * sz, cy * sz, cy * cz, sx * cz, cx * cz
+    ssc, csc, sss, css = ss_ * cz, cs_ * cz, ss_ * sz, cs_ * sz
+    return np.array([[_cc, -c_s + ssc, s_s + csc], [_cs, c_c + sss, -s_c + css], [-sy, sc_, cc_]])
+
+
+def rot3_ypr(y, p, r):
+    return rot3_rzryrx(r, p, y)
+
+
+def rot3_quat(w, x, y, z):
+    """Eigen::Quaternion::toRotationMatrix (normalised by the parser, dataset.cpp:737-743)."""
+    nrm = np.sqrt(w * w + x * x + y * y + z * z)
+    f = 1.0 / nrm
+    w, x, y, z = f * w, f * x, f * y, f * z
+    tx, ty, tz = 2 * x, 2 * y, 2 * z
+    twx, twy, twz = tx * w, ty * w, tz * w
+    txx, txy, txz = tx * x, ty * x, tz * x
+    tyy, tyz, tzz = ty * y, tz * y, tz * z
+    return np.array([[1 - (tyy + tzz), txy - twz, txz + twy], [txy + twz, 1 - (txx + tzz), tyz - twx], [txz - twy, tyz + twx, 1 - (txx + tyy)]])
+
+
+def pose3_compose(Ra, ta, Rb, tb):
+    return Ra @ Rb, ta + Ra @ tb
+
+
+# ---------------------------------------------------------------- BAL
+class SfmData:
+    def __init__(self):
+        self.cameras = []  # (R 3x3, t 3, f, k1, k2)
+        self.tracks = []   # dict(p=3, measurements=[(i, (u, v))])
+
+    def numberCameras(self):
+        return len(self.cameras)
+
+    def numberTracks(self):
+        return len(self.tracks)
+
+    @staticmethod
+    def FromBalFile(filename):
+        """every number goes through float32 like the reference's `float u, v; is >> ...`."""
+        with open(filename) as fh:
+            tok = fh.read().split()
+        it = iter(tok)
+        nP, nT, nO = int(next(it)), int(next(it)), int(next(it))
+        d = SfmData()
+        d.tracks = [dict(p=None, measurements=[]) for _ in range(nT)]
+        f32 = lambda s: float(np.float32(s))  # noqa: E731
+        for _ in range(nO):
+            i, j = int(next(it)), int(next(it))
+            u, v = f32(next(it)), f32(next(it))
+            d.tracks[j]["measurements"].append((i, (u, -v)))
+        R90 = np.diag([1.0, -1.0, -1.0])  # openGLFixedRotation
+        for _ in range(nP):
+            w = [f32(next(it)) for _ in range(3)]
+            t = np.array([f32(next(it)) for _ in range(3)])
+            R = rot3_expmap(w)
+            wRc = R.T @ R90                      # openGL2gtsam
+            wtc = R.T @ (-t)
+            f, k1, k2 = f32(next(it)), f32(next(it)), f32(next(it))
+            d.cameras.append((wRc, wtc, f, k1, k2))
+        for j in range(nT):
+            d.tracks[j]["p"] = np.array([f32(next(it)) for _ in range(3)])
+        return d
+
+
+def bal_graph(db: SfmData, noise=None, camera_key=lambda i: i, point_key=P):
+    """graph of tests/testGeneralSFMFactorB.cpp:44-63 (cameras keyed by bare index, points P(j)) by default;
+    pass camera_key=C for examples/SFMExample_bal.cpp."""
+    graph = NonlinearFactorGraph()
+    noise = noise if noise is not None else noiseModel.Unit.Create(2)
+    cams, pts, zs = [], [], []
+    for j, tr in enumerate(db.tracks):
+        for i, uv in tr["measurements"]:
+            cams.append(camera_key(i))
+            pts.append(point_key(j))
+            zs.append(uv)
+    graph.add_GeneralSFMFactor(np.array(zs), noise, np.array(cams, dtype=np.uint64), np.array(pts, dtype=np.uint64))
+    initial = Values()
+    for i, (R, t, f, k1, k2) in enumerate(db.cameras):
+        initial.insert_camera(camera_key(i), R, t, f, k1, k2)
+    for j, tr in enumerate(db.tracks):
+        initial.insert_point3(point_key(j), tr["p"])
+    return graph, initial
+
+
+# ---------------------------------------------------------------- 2D: g2o / TORO
+def _noise2d(v, smart, fmt):
+    v = [float(x) for x in v]
+    if fmt == "g2o":
+        if v[0] == 0.0 or v[3] == 0.0 or v[5] == 0.0:
+            raise RuntimeError("load2D::readNoiseModel looks like this is not G2O matrix order")
+        M = np.array([[v[0], v[1], v[2]], [v[1], v[3], v[4]], [v[2], v[4], v[5]]])
+        return noiseModel.Gaussian.Information(M, smart)
+    if fmt == "toro":
+        M = np.array([[v[0], v[1], v[4]], [v[1], v[2], v[5]], [v[4], v[5], v[3]]])
+        return noiseModel.Gaussian.Information(M, smart)
+    raise ValueError(fmt)
+
+
+def load2D(filename, noise_format="g2o", smart=True):
+    """(graph, initial) with Pose2 vertices keyed by their integer id."""
+    graph, initial = NonlinearFactorGraph(), Values()
+    lines = [ln.split() for ln in open(filename) if ln.strip()]
+    for t in lines:
+        if t[0] in ("VERTEX2", "VERTEX_SE2", "VERTEX"):
+            initial.insert_pose2(int(t[1]), float(t[2]), float(t[3]), float(t[4]))
+    for t in lines:
+        if t[0] in ("EDGE2", "EDGE", "EDGE_SE2", "ODOMETRY"):
+            id1, id2 = int(t[1]), int(t[2])
+            x, y, yaw = float(t[3]), float(t[4]), float(t[5])
+            graph.add_BetweenFactorPose2(id1, id2, [x, y, yaw], _noise2d(t[6:12], smart, noise_format))
+            if not initial.exists(id1):
+                initial.insert_pose2(id1, 0.0, 0.0, 0.0)
+            if not initial.exists(id2):
+                a = initial.at(id1)
+                c, s = np.cos(a[2]), np.sin(a[2])
+                initial.insert_pose2(id2, a[0] + c * x - s * y, a[1] + s * x + c * y, np.arctan2(np.sin(a[2] + yaw), np.cos(a[2] + yaw)))
+    return graph, initial
+
+
+def readG2o(filename, is3D=False):
+    return load3D(filename) if is3D else load2D(filename, "g2o", True)
+
+
+# ---------------------------------------------------------------- 3D
+def _sym6(vals):
+    m = np.zeros((6, 6))
+    k = 0
+    for i in range(6):
+        for j in range(i, 6):
+            m[i, j] = m[j, i] = float(vals[k])
+            k += 1
+    return m
+
+
+def load3D(filename):
+    """does NOT create missing vertices (dataset.cpp:929-938)."""
+    graph, initial = NonlinearFactorGraph(), Values()
+    for ln in open(filename):
+        t = ln.split()
+        if not t:
+            continue
+        if t[0] == "VERTEX3":
+            x, y, z, roll, pitch, yaw = (float(a) for a in t[2:8])
+            initial.insert_pose3(int(t[1]), rot3_ypr(yaw, pitch, roll), [x, y, z])
+        elif t[0] == "VERTEX_SE3:QUAT":
+            x, y, z, qx, qy, qz, qw = (float(a) for a in t[2:9])
+            initial.insert_pose3(int(t[1]), rot3_quat(qw, qx, qy, qz), [x, y, z])
+        elif t[0] == "VERTEX_TRACKXYZ":
+            initial.insert_point3(symbol("l", int(t[1])), [float(a) for a in t[2:5]])
+        elif t[0] == "EDGE3":
+            id1, id2 = int(t[1]), int(t[2])
+            x, y, z, roll, pitch, yaw = (float(a) for a in t[3:9])
+            m = _sym6(t[9:30])
+            graph.add_BetweenFactorPose3(id1, id2, rot3_ypr(yaw, pitch, roll), [x, y, z], noiseModel.Gaussian.Information(m))
+        elif t[0] == "EDGE_SE3:QUAT":
+            id1, id2 = int(t[1]), int(t[2])
+            x, y, z, qx, qy, qz, qw = (float(a) for a in t[3:10])
+            m = _sym6(t[10:31])
+            mg = np.zeros((6, 6))
+            mg[0:3, 0:3] = m[3:6, 3:6]
+            mg[3:6, 3:6] = m[0:3, 0:3]
+            mg[3:6, 0:3] = m[0:3, 3:6]
+            mg[0:3, 3:6] = m[3:6, 0:3]
+            graph.add_BetweenFactorPose3(id1, id2, rot3_quat(qw, qx, qy, qz), [x, y, z], noiseModel.Gaussian.Information(mg))
+    return graph, initial
+
+
+def chain_initial_pose3(graph: NonlinearFactorGraph, n_poses=None):
+    """odometry-chained initial estimate for files without vertices (sphere2500.txt has EDGE3 lines only):
+    pose 0 = identity, pose k+1 = pose k * measured(k, k+1) using the first edge (i, i+1) seen."""
+    from .graph import F_BETWEEN_POSE3
+    initial = Values()
+    edges = {}
+    for ftype, _, gi, keys, meas, _, _ in graph.buckets():
+        if ftype != F_BETWEEN_POSE3:
+            continue
+        for k, m in zip(keys.tolist(), meas):
+            if k[1] == k[0] + 1 and k[0] not in edges:
+                edges[int(k[0])] = m
+    R, t = np.eye(3), np.zeros(3)
+    initial.insert_pose3(0, R, t)
+    i = 0
+    while i in edges and (n_poses is None or i + 1 < n_poses):
+        m = edges[i]
+        R, t = pose3_compose(R, t, m[:9].reshape(3, 3), m[9:12])
+        i += 1
+        initial.insert_pose3(i, R, t)
+    return initial

@@ -1,0 +1,251 @@
+"""LevenbergMarquardtOptimizer mirror over the C ABI (include/lmgpu.h).
+
+Same names / argument meaning / error behaviour as the reference interface it stands in for:
+  LevenbergMarquardtParams       gtsam/nonlinear/LevenbergMarquardtParams.h:35-157
+  LevenbergMarquardtOptimizer    gtsam/nonlinear/LevenbergMarquardtOptimizer.h  (iterate :103, linearize :113, lambda, getInnerIterations)
+  NonlinearOptimizer             gtsam/nonlinear/NonlinearOptimizer.h (optimize :98, error, iterations, values, solve :129)
+All numerics run in liblmgpu.so on the GPU; this file only marshals arrays.
+"""
+from __future__ import annotations
+
+import ctypes as ct
+
+import numpy as np
+
+from . import _lib
+from .graph import (CAM_BUNDLER, F_PRIOR_CAM, F_SFM, FACTOR_ARITY, N_UNIT, VAR_DIM, VAR_STORE, VAR_STORE_DEV, NonlinearFactorGraph, Ordering,
+                    Values)
+
+
+class LevenbergMarquardtParams:
+    def __init__(self):
+        self.ordering = None
+        LevenbergMarquardtParams.SetLegacyDefaults(self)
+        self.errorTol = 0.0
+        self.minDiagonal = 1e-6
+        self.maxDiagonal = 1e32
+
+    @staticmethod
+    def SetLegacyDefaults(p):  # LevenbergMarquardtParams.h:69-82
+        p.maxIterations = 100
+        p.relativeErrorTol = 1e-5
+        p.absoluteErrorTol = 1e-5
+        p.lambdaInitial = 1e-5
+        p.lambdaFactor = 10.0
+        p.lambdaUpperBound = 1e5
+        p.lambdaLowerBound = 0.0
+        p.minModelFidelity = 1e-3
+        p.diagonalDamping = False
+        p.useFixedLambdaFactor = True
+
+    @staticmethod
+    def SetCeresDefaults(p):  # LevenbergMarquardtParams.h:85-98
+        p.maxIterations = 50
+        p.absoluteErrorTol = 0.0
+        p.relativeErrorTol = 1e-6
+        p.lambdaUpperBound = 1e32
+        p.lambdaLowerBound = 1e-16
+        p.lambdaInitial = 1e-4
+        p.lambdaFactor = 2.0
+        p.minModelFidelity = 1e-3
+        p.diagonalDamping = True
+        p.useFixedLambdaFactor = False
+
+    @staticmethod
+    def LegacyDefaults():
+        return LevenbergMarquardtParams()
+
+    @staticmethod
+    def CeresDefaults():
+        p = LevenbergMarquardtParams()
+        LevenbergMarquardtParams.SetCeresDefaults(p)
+        return p
+
+    def _c(self):
+        return _lib.lmgpu_lm_params(int(self.maxIterations), self.relativeErrorTol, self.absoluteErrorTol, self.errorTol, self.lambdaInitial,
+                                    self.lambdaFactor, self.lambdaUpperBound, self.lambdaLowerBound, self.minModelFidelity,
+                                    int(bool(self.diagonalDamping)), int(bool(self.useFixedLambdaFactor)), self.minDiagonal, self.maxDiagonal)
+
+
+def _dp(a):
+    return a.ctypes.data_as(ct.POINTER(ct.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(ct.POINTER(ct.c_int32))
+
+
+class LevenbergMarquardtOptimizer:
+    """LevenbergMarquardtOptimizer(graph, initialValues, ordering, params).
+
+    `ordering` (an Ordering = list of keys in elimination order) is a boundary input, as it is for the
+    reference's hot loop (computed once at construction, LevenbergMarquardtParams.h:112-117).
+    `device=-1` builds a structure-only handle (symbolic analysis, no compute)."""
+
+    def __init__(self, graph: NonlinearFactorGraph, initialValues: Values, ordering=None, params: LevenbergMarquardtParams | None = None,
+                 device: int = 0, rank: int = 0, world_size: int = 1):
+        self.params = params or LevenbergMarquardtParams()
+        ordering = ordering if ordering is not None else self.params.ordering
+        if ordering is None:
+            raise ValueError("an elimination Ordering is required (Ordering.Schur / Ordering.Natural, or COLAMD/METIS from the caller)")
+        self.graph, self.ordering = graph, Ordering(ordering)
+        self.lib = _lib.load()
+        self._h = ct.c_void_p()
+        cfg = _lib.lmgpu_config(device, rank, world_size, 0)
+        self._check(self.lib.lmgpu_create(ct.byref(cfg), ct.byref(self._h)))
+        self.device = device
+        # variables in elimination order
+        self._keys = np.array(self.ordering, dtype=np.uint64)
+        if len(set(self.ordering)) != len(self.ordering):
+            raise ValueError("ordering has duplicate keys")
+        self._slot = {int(k): i for i, k in enumerate(self.ordering)}
+        self._types = np.array([initialValues.type(k) for k in self.ordering], dtype=np.int32)
+        self._check(self.lib.lmgpu_set_variables(self._h, len(self.ordering), self._keys.ctypes.data_as(ct.POINTER(ct.c_uint64)), _ip(self._types)))
+        self._template = initialValues.copy()
+        for ftype, kind, gi, keys, meas, noise, _ in graph.buckets():
+            ar = FACTOR_ARITY[ftype]
+            slots = np.array([self._slot[int(k)] for k in keys.reshape(-1)], dtype=np.int32).reshape(-1, ar)
+            meas = meas.copy()
+            if ftype == F_SFM:
+                # fold Cal3Bundler's constant principal point into z (see include/lmgpu.h, CAM_BUNDLER)
+                uv = np.array([initialValues.at(k)[15:17] for k in keys[:, 0]])
+                meas = meas - uv
+            if ftype == F_PRIOR_CAM:
+                meas = np.ascontiguousarray(meas[:, :15])
+            meas = np.ascontiguousarray(meas, dtype=np.float64)
+            gi32 = np.ascontiguousarray(gi, dtype=np.int32)
+            slots = np.ascontiguousarray(slots)
+            nptr = _dp(np.ascontiguousarray(noise)) if kind != N_UNIT else None
+            self._check(self.lib.lmgpu_add_factor_bucket(self._h, ftype, len(gi32), _ip(gi32), _ip(slots), _dp(meas), kind, nptr))
+        self._check(self.lib.lmgpu_finalize_structure(self._h))
+        self._ntot = self.lib.lmgpu_total_dim(self._h)
+        self._nstore = self.lib.lmgpu_total_store(self._h)
+        self._voff = np.concatenate([[0], np.cumsum([VAR_STORE_DEV[t] for t in self._types])]).astype(np.int64)
+        self._xoff = np.concatenate([[0], np.cumsum([VAR_DIM[t] for t in self._types])]).astype(np.int64)
+        self.state = _lib.lmgpu_lm_state()
+        if device >= 0:
+            self.set_values(initialValues)
+            cp = self.params._c()
+            self._check(self.lib.lmgpu_lm_init(self._h, ct.byref(cp), ct.byref(self.state)))
+
+    # ------------------------------------------------------------ plumbing
+    def _check(self, rc):
+        if rc == _lib.LMGPU_OK:
+            return
+        if rc == _lib.LMGPU_INDETERMINATE:
+            raise _lib.IndeterminantLinearSystemException(self.lib.lmgpu_last_failed_slot(self._h))
+        msg = self.lib.lmgpu_last_error(self._h)
+        raise _lib.LmgpuError(f"lmgpu status {rc}: {msg.decode() if msg else ''}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.lmgpu_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _pack(self, values: Values):
+        out = np.empty(self._nstore)
+        for i, k in enumerate(self.ordering):
+            n = VAR_STORE_DEV[self._types[i]]
+            out[self._voff[i]:self._voff[i] + n] = values.at(k)[:n]
+        return out
+
+    def set_values(self, values: Values):
+        packed = self._pack(values)
+        self._check(self.lib.lmgpu_set_values(self._h, _dp(packed)))
+
+    # ------------------------------------------------------------ NonlinearOptimizer interface
+    def values(self) -> Values:
+        packed = np.empty(self._nstore)
+        self._check(self.lib.lmgpu_get_values(self._h, _dp(packed)))
+        out = self._template.copy()
+        for i, k in enumerate(self.ordering):
+            n = VAR_STORE_DEV[self._types[i]]
+            v = out.at(k).copy()
+            v[:n] = packed[self._voff[i]:self._voff[i] + n]
+            out.update(k, v)
+        return out
+
+    def error(self) -> float:
+        return self.state.error
+
+    def iterations(self) -> int:
+        return self.state.iterations
+
+    def lambda_(self) -> float:
+        return self.state.lambda_
+
+    def getInnerIterations(self) -> int:
+        return self.state.totalNumberInnerIterations
+
+    def iterate(self):
+        cp = self.params._c()
+        self._check(self.lib.lmgpu_iterate(self._h, ct.byref(cp), ct.byref(self.state)))
+
+    def optimize(self) -> Values:
+        cp = self.params._c()
+        self._check(self.lib.lmgpu_optimize(self._h, ct.byref(cp), ct.byref(self.state)))
+        return self.values()
+
+    def timings(self):
+        t = _lib.lmgpu_timings()
+        self._check(self.lib.lmgpu_get_timings(self._h, ct.byref(t)))
+        return {f: getattr(t, f) for f, _ in t._fields_}
+
+    # ------------------------------------------------------------ piecewise hot path (tryLambda's calls)
+    def graph_error(self) -> float:
+        e = ct.c_double()
+        self._check(self.lib.lmgpu_error(self._h, ct.byref(e)))
+        return e.value
+
+    def linearize(self):
+        self._check(self.lib.lmgpu_linearize(self._h))
+
+    def solve(self, lam, diagonal_damping=False, min_diag=1e-6, max_diag=1e32):
+        """returns (delta by key dict, packed delta in slot order, linear error at 0, linear error at delta)"""
+        d = np.empty(self._ntot)
+        e0, e1 = ct.c_double(), ct.c_double()
+        self._check(self.lib.lmgpu_solve(self._h, lam, int(diagonal_damping), min_diag, max_diag, _dp(d), ct.byref(e0), ct.byref(e1)))
+        return self.delta_by_key(d), d, e0.value, e1.value
+
+    def delta_by_key(self, packed):
+        return {int(k): packed[self._xoff[i]:self._xoff[i + 1]].copy() for i, k in enumerate(self.ordering)}
+
+    def retract(self, packed_delta=None):
+        p = None if packed_delta is None else _dp(np.ascontiguousarray(packed_delta, dtype=np.float64))
+        self._check(self.lib.lmgpu_retract(self._h, p))
+
+    def hessian_diagonal(self):
+        d = np.empty(self._ntot)
+        self._check(self.lib.lmgpu_hessian_diagonal(self._h, _dp(d)))
+        return self.delta_by_key(d)
+
+    # ------------------------------------------------------------ parity taps
+    def jacobian(self, graph_index):
+        r, c = ct.c_int32(), ct.c_int32()
+        self._check(self.lib.lmgpu_get_jacobian(self._h, graph_index, None, ct.byref(r), ct.byref(c)))
+        out = np.empty(r.value * c.value)
+        self._check(self.lib.lmgpu_get_jacobian(self._h, graph_index, _dp(out), ct.byref(r), ct.byref(c)))
+        return out.reshape(c.value, r.value).T.copy()  # column-major -> (rows, cols)
+
+    def num_fronts(self):
+        return self.lib.lmgpu_num_fronts(self._h)
+
+    def front_info(self, i):
+        info = np.zeros(6, dtype=np.int32)
+        self._check(self.lib.lmgpu_front_info(self._h, i, _ip(info)))
+        return dict(n_keys=int(info[0]), n_frontal_keys=int(info[1]), nf=int(info[2]), n=int(info[3]), parent=int(info[4]), cls=int(info[5]))
+
+    def front(self, i, numeric=True):
+        """(keys in Scatter order, [R S d] as (nf, n) array or None)"""
+        fi = self.front_info(i)
+        slots = np.zeros(fi["n_keys"], dtype=np.int32)
+        rsd = np.empty(fi["nf"] * fi["n"]) if numeric else None
+        self._check(self.lib.lmgpu_get_front(self._h, i, _ip(slots), _dp(rsd) if numeric else None))
+        keys = [int(self._keys[s]) for s in slots]
+        return keys, (rsd.reshape(fi["n"], fi["nf"]).T.copy() if numeric else None)

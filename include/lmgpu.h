@@ -1,0 +1,169 @@
+/* lmgpu.h — C ABI of the MI355X-native Levenberg-Marquardt inner loop.
+ *
+ * Drop-in boundary for GTSAM's LM hot path (citations relative to the reference tree):
+ *   - LevenbergMarquardtOptimizer::iterate()      gtsam/nonlinear/LevenbergMarquardtOptimizer.h:103, .cpp:273-308
+ *   - LevenbergMarquardtOptimizer::linearize()    gtsam/nonlinear/LevenbergMarquardtOptimizer.h:113
+ *   - NonlinearOptimizer::solve()                 gtsam/nonlinear/NonlinearOptimizer.h:129-130, .cpp:132-178
+ *   - NonlinearFactorGraph::error()/linearize()   gtsam/nonlinear/NonlinearFactorGraph.cpp:170-179, 239-278
+ *   - GaussianFactorGraph::optimize()             gtsam/linear/GaussianFactorGraph.cpp:316-319
+ * The reference has no FFI of its own: its extension points are C++ virtuals.  INTEGRATION.md shows the
+ * thin C++ adapter (a LevenbergMarquardtOptimizer subclass) that binds these entry points.
+ *
+ * Conventions: plain C, opaque handle, caller-owned host pointers with explicit counts, int status return,
+ * no exceptions across the boundary.  One HIP stream per handle; a handle is not thread-safe; handles are
+ * independent.  All arithmetic is IEEE double.  The library REQUIRES a HIP device: there is no CPU fallback.
+ *
+ * Variable order: lmgpu_set_variables() receives the variables in ELIMINATION order (the Ordering of
+ * NonlinearOptimizerParams::ordering, gtsam/nonlinear/NonlinearOptimizerParams.h:47); the position in that
+ * list is the variable's "slot".  Every packed per-variable vector crossing this boundary (values, delta,
+ * hessian diagonal) is the concatenation over slots 0..n-1.
+ */
+#ifndef LMGPU_H
+#define LMGPU_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lmgpu_handle lmgpu_handle;
+
+enum lmgpu_status {
+  LMGPU_OK = 0,
+  LMGPU_INDETERMINATE = 1, /* IndeterminantLinearSystemException (gtsam/linear/linearExceptions.h); see lmgpu_last_failed_slot */
+  LMGPU_INVALID = 2,       /* invalid argument / call order */
+  LMGPU_HIP_ERROR = 3      /* HIP or RCCL runtime failure; see lmgpu_last_error */
+};
+
+/* Variable types.  dim = tangent dimension, store = doubles per packed value.
+ *   POSE2       dim 3  store 3   (x, y, theta)                                   gtsam/geometry/Pose2.h
+ *   POSE3       dim 6  store 12  (R row-major 9, t 3)   tangent (omega, v)       gtsam/geometry/Pose3.h
+ *   POINT3      dim 3  store 3
+ *   CAM_BUNDLER dim 9  store 15  (R 9, t 3, f, k1, k2)  PinholeCamera<Cal3Bundler>; tangent (omega, v, f, k1, k2).
+ *               The constant principal point (u0, v0) of Cal3Bundler is folded into the measurement by the host
+ *               (z' = z - (u0, v0)); Cal3Bundler::retract keeps it constant (gtsam/geometry/Cal3Bundler.h:134-136).
+ */
+enum lmgpu_var_type { LMGPU_POSE2 = 0, LMGPU_POSE3 = 1, LMGPU_POINT3 = 2, LMGPU_CAM_BUNDLER = 3, LMGPU_NUM_VAR_TYPES = 4 };
+
+/* Factor types ("buckets" are keyed by (factor type, noise kind) = fixed block shape).
+ *   type             arity rows  measurement doubles
+ *   SFM              2     2     2   z                         GeneralSFMFactor<PinholeCamera<Cal3Bundler>,Point3>  gtsam/slam/GeneralSFMFactor.h:141-177
+ *   BETWEEN_POSE2    2     3     3   (x,y,theta)               BetweenFactor<Pose2>   gtsam/slam/BetweenFactor.h:111-124
+ *   BETWEEN_POSE3    2     6     12  (R row-major, t)          BetweenFactor<Pose3>
+ *   PRIOR_POSE2      1     3     3                             PriorFactor<Pose2>     gtsam/nonlinear/PriorFactor.h:98-102
+ *   PRIOR_POSE3      1     6     12
+ *   PRIOR_POINT3     1     3     3
+ *   PRIOR_CAM        1     9     15  (R, t, f, k1, k2)         PriorFactor<PinholeCamera<Cal3Bundler>>
+ *   PROJECTION       2     2     7   (z, fx, fy, s, u0, v0)    GenericProjectionFactor<Pose3,Point3,Cal3_S2>  gtsam/slam/ProjectionFactor.h:138-165
+ */
+enum lmgpu_factor_type {
+  LMGPU_F_SFM = 0,
+  LMGPU_F_BETWEEN_POSE2 = 1,
+  LMGPU_F_BETWEEN_POSE3 = 2,
+  LMGPU_F_PRIOR_POSE2 = 3,
+  LMGPU_F_PRIOR_POSE3 = 4,
+  LMGPU_F_PRIOR_POINT3 = 5,
+  LMGPU_F_PRIOR_CAM = 6,
+  LMGPU_F_PROJECTION = 7,
+  LMGPU_NUM_FACTOR_TYPES = 8
+};
+
+/* Noise models (gtsam/linear/NoiseModel.cpp).  Per-factor noise data, `rows` = factor rows:
+ *   UNIT   0 doubles
+ *   DIAG   rows doubles: INVERSE sigmas (Isotropic = all equal)          whiten: v .* invsigma   (:314-332, :653-665)
+ *   GAUSS  rows*rows doubles: sqrt information R, row-major              whiten: R v             (:160-186)
+ */
+enum lmgpu_noise_kind { LMGPU_N_UNIT = 0, LMGPU_N_DIAG = 2, LMGPU_N_GAUSS = 3 };
+
+typedef struct lmgpu_config {
+  int32_t device;     /* HIP device ordinal */
+  int32_t rank;       /* this process' rank among the cooperating handles (0 if single) */
+  int32_t world_size; /* number of cooperating ranks (1 if single) */
+  int32_t flags;      /* reserved, 0 */
+} lmgpu_config;
+
+/* LevenbergMarquardtParams subset honoured by lmgpu_iterate / lmgpu_optimize
+ * (gtsam/nonlinear/LevenbergMarquardtParams.h:35-157; defaults = SetLegacyDefaults :69-82). */
+typedef struct lmgpu_lm_params {
+  int32_t maxIterations;
+  double relativeErrorTol, absoluteErrorTol, errorTol;
+  double lambdaInitial, lambdaFactor, lambdaUpperBound, lambdaLowerBound;
+  double minModelFidelity;
+  int32_t diagonalDamping, useFixedLambdaFactor;
+  double minDiagonal, maxDiagonal;
+} lmgpu_lm_params;
+
+/* LevenbergMarquardtState (gtsam/nonlinear/internal/LevenbergMarquardtState.h:42-68) */
+typedef struct lmgpu_lm_state {
+  double error;
+  double lambda;
+  double currentFactor;
+  int32_t iterations;
+  int32_t totalNumberInnerIterations;
+} lmgpu_lm_state;
+
+/* per-phase device time of the last lmgpu_iterate, milliseconds (HIP events on the handle's stream) */
+typedef struct lmgpu_timings {
+  double linearize_ms, eliminate_ms, backsub_ms, linear_error_ms, retract_error_ms, total_ms;
+  int32_t inner_iterations;
+} lmgpu_timings;
+
+/* ---- lifetime ---- */
+int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out);
+int lmgpu_destroy(lmgpu_handle* h);
+const char* lmgpu_last_error(const lmgpu_handle* h);
+int lmgpu_last_failed_slot(const lmgpu_handle* h); /* slot of the first frontal variable of the failing front */
+
+/* ---- structure (once per graph + ordering; replaces the symbolic work eliminateMultifrontal redoes per solve,
+ *      gtsam/inference/EliminateableFactorGraph-inst.h:123-146) ---- */
+int lmgpu_set_variables(lmgpu_handle* h, int32_t n_vars, const uint64_t* keys, const int32_t* types);
+/* graph_index[i] = index of factor i in the NonlinearFactorGraph (defines VariableIndex order and error-sum order);
+ * var_slots: n x arity slots; meas: n x measurement doubles; noise: n x noise doubles (NULL for UNIT). */
+int lmgpu_add_factor_bucket(lmgpu_handle* h, int32_t factor_type, int32_t n, const int32_t* graph_index, const int32_t* var_slots,
+                            const double* meas, int32_t noise_kind, const double* noise);
+int lmgpu_finalize_structure(lmgpu_handle* h);
+
+/* ---- values ---- */
+int lmgpu_set_values(lmgpu_handle* h, const double* packed_values);
+int lmgpu_get_values(lmgpu_handle* h, double* packed_values);
+int lmgpu_total_dim(const lmgpu_handle* h);   /* sum of tangent dims */
+int lmgpu_total_store(const lmgpu_handle* h); /* doubles in packed values */
+
+/* ---- the hot path, piecewise (what LevenbergMarquardtOptimizer::tryLambda calls) ---- */
+int lmgpu_error(lmgpu_handle* h, double* total);  /* NonlinearFactorGraph::error at the current values */
+int lmgpu_linearize(lmgpu_handle* h);             /* NonlinearFactorGraph::linearize -> device-resident whitened [A|b] per factor */
+/* buildDampedSystem + solve + linear.error(0), linear.error(delta).  delta_packed may be NULL. */
+int lmgpu_solve(lmgpu_handle* h, double lambda, int32_t diagonal_damping, double min_diag, double max_diag, double* delta_packed,
+                double* lin_err0, double* lin_err1);
+int lmgpu_retract(lmgpu_handle* h, const double* delta_packed); /* values <- values.retract(delta); NULL = last solve's delta */
+int lmgpu_hessian_diagonal(lmgpu_handle* h, double* diag_packed); /* GaussianFactorGraph::hessianDiagonal */
+
+/* ---- the hot path, whole (drop-in for LevenbergMarquardtOptimizer::iterate / NonlinearOptimizer::optimize) ---- */
+int lmgpu_lm_init(lmgpu_handle* h, const lmgpu_lm_params* p, lmgpu_lm_state* state_out);
+int lmgpu_iterate(lmgpu_handle* h, const lmgpu_lm_params* p, lmgpu_lm_state* inout);
+int lmgpu_optimize(lmgpu_handle* h, const lmgpu_lm_params* p, lmgpu_lm_state* inout);
+int lmgpu_get_timings(const lmgpu_handle* h, lmgpu_timings* out);
+
+/* ---- parity taps ---- */
+/* whitened Jacobian of graph factor `graph_index`, column-major rows x (sum dims + 1) like the reference's
+ * VerticalBlockMatrix ([A1 A2 b]); out may be NULL to query the shape. */
+int lmgpu_get_jacobian(lmgpu_handle* h, int32_t graph_index, double* out, int32_t* rows, int32_t* cols);
+int lmgpu_num_fronts(const lmgpu_handle* h);
+/* info6: n_keys, n_frontal_keys, nf (rows of [R S d]), n (cols), parent front (-1 root), class (0 = LDS front, 1 = HBM front) */
+int lmgpu_front_info(const lmgpu_handle* h, int32_t front, int32_t* info6);
+/* slots: the front's variables in Scatter order (gtsam/linear/Scatter.cpp:39-73); RSd: column-major nf x n */
+int lmgpu_get_front(lmgpu_handle* h, int32_t front, int32_t* slots, double* RSd_colmajor);
+
+/* ---- multi-GPU (points/subtrees sharded over ranks; separator contributions summed with RCCL over xGMI) ---- */
+/* rank 0 fills id[128] (ncclUniqueId bytes); the caller broadcasts it; every rank then calls lmgpu_comm_init. */
+int lmgpu_comm_unique_id(char id128[128]);
+int lmgpu_comm_init(lmgpu_handle* h, const char id128[128]);
+
+/* ---- micro-benchmarks used by bench.py for roofline peaks (device-only, no graph needed) ---- */
+int lmgpu_peak_mfma_f64(int32_t device, int32_t iters, double* tflops);
+int lmgpu_peak_hbm_copy(int32_t device, int64_t bytes, int32_t iters, double* gbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LMGPU_H */

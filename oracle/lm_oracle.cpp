@@ -1,0 +1,1242 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+//
+// CPU restatement (plain C++17, single thread, no Eigen) of the reference's
+// Levenberg-Marquardt inner loop: NonlinearFactorGraph::linearize / error,
+// eliminateMultifrontal with EliminateCholesky, GaussianBayesTree::optimize,
+// Values::retract and LevenbergMarquardtOptimizer::iterate/tryLambda.
+// Citations are file:line relative to /root/reference.
+//
+// Parity pinning: checked in tests/ against the reference's own known answers
+// (gtsam/base/tests/testCholesky.cpp, gtsam/linear/tests/testHessianFactor.cpp,
+// tests/testGeneralSFMFactorB.cpp, gtsam/geometry/tests/testCal3Bundler.cpp, ...).
+// The reference itself is unbuildable here without its CMake-generated headers
+// (gtsam/config.h, gtsam/dllexport.h); only the vendored plain-C
+// CCOLAMD / METIS sources are compiled into oracle/_ref (oracle/Makefile).
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+#include <algorithm>
+#include <cassert>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <vector>
+
+#include "geometry.hpp"
+
+namespace orc {
+
+typedef uint64_t Key;
+
+// Column-major dense matrix (gtsam/base/Matrix.h:39: Eigen::MatrixXd is column-major)
+struct Mat {
+  int r = 0, c = 0;
+  std::vector<double> a;
+  Mat() {}
+  Mat(int r_, int c_) : r(r_), c(c_), a((size_t)r_ * c_, 0.0) {}
+  double& operator()(int i, int j) { return a[(size_t)j * r + i]; }
+  double operator()(int i, int j) const { return a[(size_t)j * r + i]; }
+};
+
+enum VarType { POSE2 = 0, POSE3 = 1, POINT3 = 2, CAM_BUNDLER = 3 };
+static const int kVarDim[4] = {3, 6, 3, 9};
+static const int kVarStore[4] = {3, 12, 3, 17};  // packed value doubles (oracle keeps u0,v0 with the camera)
+
+enum FactorType {
+  F_SFM = 0,            // GeneralSFMFactor<PinholeCamera<Cal3Bundler>,Point3>  (cam, point), meas 2
+  F_BETWEEN_POSE2 = 1,  // BetweenFactor<Pose2>  meas 3 (x,y,theta)
+  F_BETWEEN_POSE3 = 2,  // BetweenFactor<Pose3>  meas 12 (R row-major, t)
+  F_PRIOR_POSE2 = 3,
+  F_PRIOR_POSE3 = 4,
+  F_PRIOR_POINT3 = 5,
+  F_PRIOR_CAM = 6,      // PriorFactor<PinholeCamera<Cal3Bundler>>  meas 17
+  F_PROJECTION = 7      // GenericProjectionFactor<Pose3,Point3,Cal3_S2> meas 2 + K(fx,fy,s,u0,v0)
+};
+static const int kFactorArity[8] = {2, 2, 2, 1, 1, 1, 1, 2};
+static const int kFactorRows[8] = {2, 3, 6, 3, 6, 3, 9, 2};
+static const int kFactorMeas[8] = {2, 3, 12, 3, 12, 3, 17, 7};
+
+enum NoiseKind { N_UNIT = 0, N_ISO = 1, N_DIAG = 2, N_GAUSS = 3 };
+
+struct Value {
+  int type;
+  double v[17];
+};
+
+struct Factor {
+  int type;
+  Key keys[2];
+  double meas[17];
+  int noise_kind;
+  std::vector<double> noise;  // ISO: sigma ; DIAG: sigmas[m] ; GAUSS: R m x m row-major (sqrt information)
+};
+
+// Linear (Gaussian) factor: either Jacobian [A1 A2 .. b] (already whitened) or Hessian
+struct GFactor {
+  std::vector<Key> keys;
+  std::vector<int> dims;
+  bool hessian = false;
+  Mat Ab;    // Jacobian: m x (sum dims + 1)
+  Mat info;  // Hessian: (sum dims + 1)^2, upper triangle valid
+  bool empty() const { return keys.empty(); }
+};
+
+typedef std::map<Key, Value> Values;
+typedef std::map<Key, std::vector<double>> VectorValues;
+
+// ------------------------------------------------------------------ noise
+// whiten a vector / rows of a matrix: Gaussian R*v (NoiseModel.cpp:160-186), Diagonal v.*invsigmas
+// (:314-332), Isotropic v*invsigma (:616-665), Unit identity.
+static void whiten_rows(const Factor& f, int m, double* data, int ncols, int ld /*col-major ld*/) {
+  if (f.noise_kind == N_UNIT) return;
+  if (f.noise_kind == N_ISO) {
+    const double inv = 1.0 / f.noise[0];
+    for (int j = 0; j < ncols; j++)
+      for (int i = 0; i < m; i++) data[(size_t)j * ld + i] *= inv;
+  } else if (f.noise_kind == N_DIAG) {
+    for (int j = 0; j < ncols; j++)
+      for (int i = 0; i < m; i++) data[(size_t)j * ld + i] *= (1.0 / f.noise[i]);
+  } else {
+    std::vector<double> tmp(m);
+    for (int j = 0; j < ncols; j++) {
+      double* col = data + (size_t)j * ld;
+      for (int i = 0; i < m; i++) {
+        double s = 0;
+        for (int k = 0; k < m; k++) s += f.noise[(size_t)i * m + k] * col[k];
+        tmp[i] = s;
+      }
+      for (int i = 0; i < m; i++) col[i] = tmp[i];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ values helpers
+static Pose3 as_pose3(const double* v) {
+  Pose3 p;
+  std::memcpy(p.R.m, v, 9 * sizeof(double));
+  p.t = {v[9], v[10], v[11]};
+  return p;
+}
+static void store_pose3(const Pose3& p, double* v) {
+  std::memcpy(v, p.R.m, 9 * sizeof(double));
+  v[9] = p.t.x; v[10] = p.t.y; v[11] = p.t.z;
+}
+
+// Values::retract per variable (gtsam/nonlinear/Values.cpp:53-64,99-101)
+static Value retract(const Value& x, const double* d) {
+  Value r = x;
+  switch (x.type) {
+    case POSE2: {
+      // Pose2 retract = compose(Pose2(v0,v1,v2))  gtsam/geometry/Pose2.cpp:100-110
+      Pose2 a = pose2_from(x.v[0], x.v[1], x.v[2]);
+      Pose2 b = pose2_from(d[0], d[1], d[2]);
+      Pose2 c = compose(a, b);
+      r.v[0] = c.x; r.v[1] = c.y; r.v[2] = pose2_theta(c);
+      break;
+    }
+    case POSE3: {
+      store_pose3(pose3_retract(as_pose3(x.v), d), r.v);
+      break;
+    }
+    case POINT3:
+      for (int i = 0; i < 3; i++) r.v[i] = x.v[i] + d[i];
+      break;
+    case CAM_BUNDLER: {
+      // PinholeCamera::retract gtsam/geometry/PinholeCamera.h:197-203; Cal3Bundler.h:134-136
+      store_pose3(pose3_retract(as_pose3(x.v), d), r.v);
+      r.v[12] = x.v[12] + d[6];
+      r.v[13] = x.v[13] + d[7];
+      r.v[14] = x.v[14] + d[8];
+      break;
+    }
+  }
+  return r;
+}
+
+// ------------------------------------------------------------------ factors: unwhitened error + Jacobians
+// H1, H2: row-major m x dim (nullptr to skip).  Returns error e (size m).
+static void evaluate_error(const Factor& f, const Values& vals, double* e, double* H1, double* H2) {
+  switch (f.type) {
+    case F_SFM: {
+      // GeneralSFMFactor::evaluateError gtsam/slam/GeneralSFMFactor.h:127-138
+      const Value& cam = vals.at(f.keys[0]);
+      const Value& pt = vals.at(f.keys[1]);
+      Pose3 pose = as_pose3(cam.v);
+      Cal3Bundler K{cam.v[12], cam.v[13], cam.v[14], cam.v[15], cam.v[16]};
+      double pn[2], Dpose[12], Dpoint[6];
+      bool ok = pinhole_project2(pose, V3{pt.v[0], pt.v[1], pt.v[2]}, pn, H1 ? Dpose : nullptr, H2 || H1 ? Dpoint : nullptr);
+      if (!ok) {
+        if (H1) std::memset(H1, 0, 18 * sizeof(double));
+        if (H2) std::memset(H2, 0, 6 * sizeof(double));
+        e[0] = e[1] = 0.0;
+        return;
+      }
+      double pi[2], Dcal[6], Dp[4];
+      cal3bundler_uncalibrate(K, pn[0], pn[1], pi, H1 ? Dcal : nullptr, (H1 || H2) ? Dp : nullptr);
+      // chain rule, gtsam/geometry/PinholePose.h:103-106; [Dpose Dcal] gtsam/geometry/PinholeCamera.h:228-240
+      if (H1) {
+        for (int i = 0; i < 2; i++) {
+          for (int j = 0; j < 6; j++) H1[9 * i + j] = Dp[2 * i] * Dpose[j] + Dp[2 * i + 1] * Dpose[6 + j];
+          for (int j = 0; j < 3; j++) H1[9 * i + 6 + j] = Dcal[3 * i + j];
+        }
+      }
+      if (H2) {
+        for (int i = 0; i < 2; i++)
+          for (int j = 0; j < 3; j++) H2[3 * i + j] = Dp[2 * i] * Dpoint[j] + Dp[2 * i + 1] * Dpoint[3 + j];
+      }
+      e[0] = pi[0] - f.meas[0];
+      e[1] = pi[1] - f.meas[1];
+      return;
+    }
+    case F_PROJECTION: {
+      // GenericProjectionFactor::evaluateError gtsam/slam/ProjectionFactor.h:138-165 (no body_P_sensor)
+      const Value& po = vals.at(f.keys[0]);
+      const Value& pt = vals.at(f.keys[1]);
+      Pose3 pose = as_pose3(po.v);
+      const double fx = f.meas[2], fy = f.meas[3], s = f.meas[4], u0 = f.meas[5], v0 = f.meas[6];
+      double pn[2], Dpose[12], Dpoint[6];
+      bool ok = pinhole_project2(pose, V3{pt.v[0], pt.v[1], pt.v[2]}, pn, H1 ? Dpose : nullptr, H2 ? Dpoint : nullptr);
+      if (!ok) {
+        if (H1) std::memset(H1, 0, 12 * sizeof(double));
+        if (H2) std::memset(H2, 0, 6 * sizeof(double));
+        e[0] = e[1] = 2.0 * fx;
+        return;
+      }
+      // Cal3_S2::uncalibrate gtsam/geometry/Cal3_S2.cpp:44-50 ; Dp = [fx s; 0 fy]
+      if (H1)
+        for (int j = 0; j < 6; j++) {
+          H1[j] = fx * Dpose[j] + s * Dpose[6 + j];
+          H1[6 + j] = fy * Dpose[6 + j];
+        }
+      if (H2)
+        for (int j = 0; j < 3; j++) {
+          H2[j] = fx * Dpoint[j] + s * Dpoint[3 + j];
+          H2[3 + j] = fy * Dpoint[3 + j];
+        }
+      e[0] = fx * pn[0] + s * pn[1] + u0 - f.meas[0];
+      e[1] = fy * pn[1] + v0 - f.meas[1];
+      return;
+    }
+    case F_BETWEEN_POSE3: {
+      // BetweenFactor::evaluateError gtsam/slam/BetweenFactor.h:111-124 (fast path: Local Jacobian NOT applied)
+      // LieGroup::between gtsam/base/Lie.h:63-69 : H1 = -Ad(h^-1), H2 = I
+      Pose3 p1 = as_pose3(vals.at(f.keys[0]).v), p2 = as_pose3(vals.at(f.keys[1]).v);
+      Pose3 h = compose(inverse(p1), p2);
+      if (H1) {
+        double adj[36];
+        adjointMap(inverse(h), adj);
+        for (int i = 0; i < 36; i++) H1[i] = -adj[i];
+      }
+      if (H2) {
+        std::memset(H2, 0, 36 * sizeof(double));
+        for (int i = 0; i < 6; i++) H2[7 * i] = 1.0;
+      }
+      Pose3 z = as_pose3(f.meas);
+      pose3_local(z, h, e);
+      return;
+    }
+    case F_BETWEEN_POSE2: {
+      const Value& a = vals.at(f.keys[0]);
+      const Value& b = vals.at(f.keys[1]);
+      Pose2 p1 = pose2_from(a.v[0], a.v[1], a.v[2]), p2 = pose2_from(b.v[0], b.v[1], b.v[2]);
+      Pose2 h = compose(inverse(p1), p2);
+      if (H1) {
+        double adj[9];
+        adjointMap(inverse(h), adj);
+        for (int i = 0; i < 9; i++) H1[i] = -adj[i];
+      }
+      if (H2) {
+        std::memset(H2, 0, 9 * sizeof(double));
+        H2[0] = H2[4] = H2[8] = 1.0;
+      }
+      // Local(measured, h) = ChartAtOrigin::Local(measured^-1 h) = (x, y, theta)  Pose2.cpp:112-121
+      Pose2 z = pose2_from(f.meas[0], f.meas[1], f.meas[2]);
+      Pose2 d = compose(inverse(z), h);
+      e[0] = d.x; e[1] = d.y; e[2] = pose2_theta(d);
+      return;
+    }
+    case F_PRIOR_POSE2: {
+      // PriorFactor::evaluateError gtsam/nonlinear/PriorFactor.h:98-102 : -Local(x, prior), H = I
+      const Value& a = vals.at(f.keys[0]);
+      Pose2 x = pose2_from(a.v[0], a.v[1], a.v[2]);
+      Pose2 z = pose2_from(f.meas[0], f.meas[1], f.meas[2]);
+      Pose2 d = compose(inverse(x), z);
+      e[0] = -d.x; e[1] = -d.y; e[2] = -pose2_theta(d);
+      if (H1) {
+        std::memset(H1, 0, 9 * sizeof(double));
+        H1[0] = H1[4] = H1[8] = 1.0;
+      }
+      return;
+    }
+    case F_PRIOR_POSE3: {
+      Pose3 x = as_pose3(vals.at(f.keys[0]).v), z = as_pose3(f.meas);
+      pose3_local(x, z, e);
+      for (int i = 0; i < 6; i++) e[i] = -e[i];
+      if (H1) {
+        std::memset(H1, 0, 36 * sizeof(double));
+        for (int i = 0; i < 6; i++) H1[7 * i] = 1.0;
+      }
+      return;
+    }
+    case F_PRIOR_POINT3: {
+      const Value& a = vals.at(f.keys[0]);
+      for (int i = 0; i < 3; i++) e[i] = -(f.meas[i] - a.v[i]);
+      if (H1) {
+        std::memset(H1, 0, 9 * sizeof(double));
+        H1[0] = H1[4] = H1[8] = 1.0;
+      }
+      return;
+    }
+    case F_PRIOR_CAM: {
+      // PinholeCamera::localCoordinates gtsam/geometry/PinholeCamera.h:206-211
+      const Value& a = vals.at(f.keys[0]);
+      Pose3 x = as_pose3(a.v), z = as_pose3(f.meas);
+      pose3_local(x, z, e);
+      e[6] = f.meas[12] - a.v[12];
+      e[7] = f.meas[13] - a.v[13];
+      e[8] = f.meas[14] - a.v[14];
+      for (int i = 0; i < 9; i++) e[i] = -e[i];
+      if (H1) {
+        std::memset(H1, 0, 81 * sizeof(double));
+        for (int i = 0; i < 9; i++) H1[10 * i] = 1.0;
+      }
+      return;
+    }
+  }
+  throw std::runtime_error("unknown factor type");
+}
+
+// NoiseModelFactor::error gtsam/nonlinear/NonlinearFactor.cpp:138-149: 0.5 * ||whiten(e)||^2
+static double factor_error(const Factor& f, const Values& vals) {
+  const int m = kFactorRows[f.type];
+  double e[9];
+  evaluate_error(f, vals, e, nullptr, nullptr);
+  whiten_rows(f, m, e, 1, m);
+  double s = 0;
+  for (int i = 0; i < m; i++) s += e[i] * e[i];
+  return 0.5 * s;
+}
+
+// NoiseModelFactor::linearize gtsam/nonlinear/NonlinearFactor.cpp:152-184 and
+// GeneralSFMFactor::linearize gtsam/slam/GeneralSFMFactor.h:141-177 (same result, see
+// gtsam/slam/tests/testGeneralSFMFactor.cpp:439-491): A = whiten(H), b = whiten(-e)
+static GFactor linearize_factor(const Factor& f, const Values& vals) {
+  const int m = kFactorRows[f.type];
+  const int ar = kFactorArity[f.type];
+  GFactor g;
+  int tot = 0;
+  for (int j = 0; j < ar; j++) {
+    g.keys.push_back(f.keys[j]);
+    g.dims.push_back(kVarDim[vals.at(f.keys[j]).type]);
+    tot += g.dims.back();
+  }
+  double e[9], H1[81], H2[54];
+  evaluate_error(f, vals, e, H1, ar > 1 ? H2 : nullptr);
+  g.Ab = Mat(m, tot + 1);
+  for (int i = 0; i < m; i++) {
+    for (int j = 0; j < g.dims[0]; j++) g.Ab(i, j) = H1[i * g.dims[0] + j];
+    if (ar > 1)
+      for (int j = 0; j < g.dims[1]; j++) g.Ab(i, g.dims[0] + j) = H2[i * g.dims[1] + j];
+    g.Ab(i, tot) = -e[i];
+  }
+  whiten_rows(f, m, g.Ab.a.data(), tot + 1, m);
+  return g;
+}
+
+// ------------------------------------------------------------------ dense partial Cholesky
+// choleskyPartial gtsam/base/cholesky.cpp:108-159.  ABC col-major n x n, upper triangle used.
+// Unblocked upper Cholesky (Eigen LLT<Upper> numerics up to rounding order), then
+// S = R^-T B, C -= S^T S (upper only), then the pivot-exponent test.
+static bool cholesky_partial(double* ABC, int ld, int n, int nFrontal) {
+  if (nFrontal == 0) return true;
+  auto A = [&](int i, int j) -> double& { return ABC[(size_t)j * ld + i]; };
+  // right-looking, row by row of R
+  for (int k = 0; k < nFrontal; k++) {
+    double x = A(k, k);
+    // Eigen llt_inplace unblocked: pivot x = a_kk - sum; fails if x <= 0
+    if (!(x > 0.0)) {
+      if (x <= 0.0) return false;  // NaN passes like Eigen (x<=0 is false for NaN)
+    }
+    const double rkk = std::sqrt(x);
+    A(k, k) = rkk;
+    const double inv = 1.0 / rkk;
+    for (int j = k + 1; j < n; j++) A(k, j) *= inv;
+    // trailing update restricted to what is needed: rows k+1..n-1 (frontal part and C)
+    for (int j = k + 1; j < n; j++) {
+      const double rkj = A(k, j);
+      if (rkj == 0.0) continue;
+      for (int i = k + 1; i <= j; i++) A(i, j) -= A(k, i) * rkj;
+    }
+  }
+  if (nFrontal >= 2) {
+    int exp2, exp1;
+    (void)std::frexp(A(nFrontal - 2, nFrontal - 2), &exp2);
+    (void)std::frexp(A(nFrontal - 1, nFrontal - 1), &exp1);
+    return (exp2 - exp1 < 12);
+  } else {
+    int exp1;
+    (void)std::frexp(A(0, 0), &exp1);
+    return (exp1 > -12);
+  }
+}
+
+// ------------------------------------------------------------------ symbolic
+// VariableIndex (gtsam/inference/VariableIndex-inl.h:27-49): key -> factor indices ascending
+typedef std::map<Key, std::vector<size_t>> VariableIndex;
+
+struct ENode {
+  Key key;
+  std::vector<size_t> factors;              // indices into the gaussian graph
+  std::vector<std::shared_ptr<ENode>> children;
+};
+
+// EliminationTree ctor gtsam/inference/EliminationTree-inst.h:78-156
+static std::vector<std::shared_ptr<ENode>> build_etree(const std::vector<std::vector<Key>>& fkeys, const VariableIndex& vi,
+                                                        const std::vector<Key>& order) {
+  const size_t m = fkeys.size(), n = order.size();
+  const size_t none = std::numeric_limits<size_t>::max();
+  std::vector<std::shared_ptr<ENode>> nodes(n);
+  std::vector<size_t> parents(n, none), prevCol(m, none);
+  for (size_t j = 0; j < n; j++) {
+    auto it = vi.find(order[j]);
+    if (it == vi.end()) throw std::invalid_argument("EliminationTree: ordering contains variables not in the graph");
+    auto node = std::make_shared<ENode>();
+    node->key = order[j];
+    for (size_t i : it->second) {
+      if (prevCol[i] != none) {
+        size_t r = prevCol[i];
+        while (parents[r] != none) r = parents[r];
+        if (r != j) {
+          parents[r] = j;
+          node->children.push_back(nodes[r]);
+        }
+      } else {
+        node->factors.push_back(i);
+      }
+      prevCol[i] = j;
+    }
+    nodes[j] = node;
+  }
+  std::vector<std::shared_ptr<ENode>> roots;
+  for (size_t j = 0; j < n; j++)
+    if (parents[j] == none) roots.push_back(nodes[j]);
+  return roots;
+}
+
+struct JNode {
+  std::vector<Key> orderedFrontalKeys;
+  std::vector<size_t> factors;
+  std::vector<std::shared_ptr<JNode>> children;
+};
+
+// JunctionTree ctor + ConstructorTraversalVisitorPostAlg2 (gtsam/inference/JunctionTree-inst.h:65-153),
+// Cluster::merge / mergeChildren (gtsam/inference/ClusterTree-inst.h:45-96).
+// Returns the separator (symbolic "parents" of the conditional on ETree node's key) as sorted key set.
+static std::vector<Key> jt_visit(const std::shared_ptr<ENode>& en, const std::vector<std::vector<Key>>& fkeys,
+                                 std::shared_ptr<JNode>& out) {
+  auto node = std::make_shared<JNode>();
+  node->orderedFrontalKeys.push_back(en->key);
+  node->factors = en->factors;
+  std::vector<std::vector<Key>> childSeps;
+  for (auto& ch : en->children) {
+    std::shared_ptr<JNode> cj;
+    childSeps.push_back(jt_visit(ch, fkeys, cj));
+    node->children.push_back(cj);
+  }
+  // symbolic elimination of en->key over own factors + child separator factors
+  std::vector<Key> all;
+  for (size_t f : en->factors)
+    for (Key k : fkeys[f]) all.push_back(k);
+  for (auto& s : childSeps)
+    for (Key k : s) all.push_back(k);
+  std::sort(all.begin(), all.end());
+  all.erase(std::unique(all.begin(), all.end()), all.end());
+  std::vector<Key> sep;
+  for (Key k : all)
+    if (k != en->key) sep.push_back(k);
+  const size_t myNrParents = sep.size();
+  const size_t nrChildren = node->children.size();
+  std::vector<bool> merge(nrChildren, false);
+  size_t myNrFrontals = 1;
+  for (size_t i = 0; i < nrChildren; i++) {
+    if (myNrParents + myNrFrontals == childSeps[i].size()) {
+      myNrFrontals += node->children[i]->orderedFrontalKeys.size();
+      merge[i] = true;
+    }
+  }
+  // mergeChildren
+  auto oldChildren = node->children;
+  node->children.clear();
+  for (size_t i = 0; i < nrChildren; i++) {
+    auto& child = oldChildren[i];
+    if (merge[i]) {
+      node->orderedFrontalKeys.insert(node->orderedFrontalKeys.end(), child->orderedFrontalKeys.rbegin(),
+                                      child->orderedFrontalKeys.rend());
+      node->factors.insert(node->factors.end(), child->factors.begin(), child->factors.end());
+      node->children.insert(node->children.end(), child->children.begin(), child->children.end());
+    } else {
+      node->children.push_back(child);
+    }
+  }
+  std::reverse(node->orderedFrontalKeys.begin(), node->orderedFrontalKeys.end());
+  out = node;
+  return sep;
+}
+
+// ------------------------------------------------------------------ numeric elimination
+struct Clique {
+  std::vector<Key> keys;  // frontals then separator (Scatter order)
+  std::vector<int> dims;
+  int nFrontal = 0;       // number of frontal keys
+  Mat RSd;                // nf x (n) : [R S d], strictly-lower zeroed
+  std::vector<int> children;
+  int parent = -1;
+};
+
+struct BayesTree {
+  std::vector<Clique> cliques;  // post-order (children before parents)
+  std::vector<int> roots;
+};
+
+struct Indeterminate : std::runtime_error {
+  Key key;
+  Indeterminate(Key k) : std::runtime_error("IndeterminantLinearSystemException"), key(k) {}
+};
+
+// JacobianFactor::updateHessian / BinaryJacobianFactor::updateHessian / HessianFactor::updateHessian
+// (gtsam/linear/JacobianFactor.cpp:586-624, BinaryJacobianFactor.h:51-83, HessianFactor.cpp:349-373):
+// info(upper) += [A b]^T [A b] at the slots of this factor's keys.
+static void update_hessian(const GFactor& f, const std::vector<Key>& infoKeys, const std::vector<int>& offs, Mat& info) {
+  const int nv = (int)f.keys.size();
+  std::vector<int> start(nv + 1), dim(nv + 1), loc(nv + 1);
+  int o = 0;
+  for (int j = 0; j < nv; j++) {
+    size_t slot = std::find(infoKeys.begin(), infoKeys.end(), f.keys[j]) - infoKeys.begin();
+    if (slot == infoKeys.size()) throw std::runtime_error("update_hessian: key not in scatter");
+    start[j] = offs[slot];
+    dim[j] = f.dims[j];
+    loc[j] = o;
+    o += f.dims[j];
+  }
+  start[nv] = offs[infoKeys.size()];
+  dim[nv] = 1;
+  loc[nv] = o;
+  const int m = f.hessian ? 0 : f.Ab.r;
+  for (int bj = 0; bj <= nv; bj++)
+    for (int bi = 0; bi <= bj; bi++) {
+      for (int cj = 0; cj < dim[bj]; cj++)
+        for (int ci = 0; ci < dim[bi]; ci++) {
+          if (bi == bj && ci > cj) continue;
+          double v;
+          if (f.hessian) {
+            v = f.info(loc[bi] + ci, loc[bj] + cj);
+          } else {
+            v = 0;
+            for (int r = 0; r < m; r++) v += f.Ab(r, loc[bi] + ci) * f.Ab(r, loc[bj] + cj);
+          }
+          int gi = start[bi] + ci, gj = start[bj] + cj;
+          if (gi > gj) std::swap(gi, gj);  // SymmetricBlockMatrix.h:230-236 transposes into the upper triangle
+          info(gi, gj) += v;
+        }
+    }
+}
+
+// EliminateCholesky gtsam/linear/HessianFactor.cpp:515-535 with Scatter (gtsam/linear/Scatter.cpp:39-73)
+static void eliminate_clique(const std::vector<const GFactor*>& gathered, const std::vector<Key>& frontals,
+                             const std::map<Key, int>& keyDim, Clique& cq, GFactor& separator) {
+  // Scatter: frontal keys in the given order, then all other keys sorted
+  std::vector<Key> keys = frontals, rest;
+  for (auto* g : gathered)
+    for (Key k : g->keys)
+      if (std::find(frontals.begin(), frontals.end(), k) == frontals.end()) rest.push_back(k);
+  std::sort(rest.begin(), rest.end());
+  rest.erase(std::unique(rest.begin(), rest.end()), rest.end());
+  keys.insert(keys.end(), rest.begin(), rest.end());
+  std::vector<int> dims, offs;
+  int n = 0;
+  for (Key k : keys) {
+    dims.push_back(keyDim.at(k));
+    offs.push_back(n);
+    n += dims.back();
+  }
+  offs.push_back(n);
+  n += 1;
+  Mat info(n, n);
+  for (auto* g : gathered) update_hessian(*g, keys, offs, info);
+  int nf = 0;
+  for (size_t i = 0; i < frontals.size(); i++) nf += dims[i];
+  if (!cholesky_partial(info.a.data(), n, n, nf)) throw Indeterminate(frontals.front());
+  // split (gtsam/base/SymmetricBlockMatrix.cpp:93-107)
+  cq.keys = keys;
+  cq.dims = dims;
+  cq.nFrontal = (int)frontals.size();
+  cq.RSd = Mat(nf, n);
+  for (int j = 0; j < n; j++)
+    for (int i = 0; i < nf && i <= j; i++) cq.RSd(i, j) = info(i, j);
+  separator = GFactor();
+  separator.hessian = true;
+  for (size_t i = frontals.size(); i < keys.size(); i++) {
+    separator.keys.push_back(keys[i]);
+    separator.dims.push_back(dims[i]);
+  }
+  const int ns = n - nf;
+  separator.info = Mat(ns, ns);
+  for (int j = 0; j < ns; j++)
+    for (int i = 0; i <= j; i++) separator.info(i, j) = info(nf + i, nf + j);
+}
+
+static int eliminate_tree(const std::shared_ptr<JNode>& node, const std::vector<GFactor>& graph,
+                          const std::map<Key, int>& keyDim, BayesTree& bt, GFactor& sepOut) {
+  // post-order: children first (gtsam/inference/ClusterTree-inst.h:219-266)
+  std::vector<GFactor> childFactors(node->children.size());
+  std::vector<int> childIdx;
+  for (size_t i = 0; i < node->children.size(); i++) childIdx.push_back(eliminate_tree(node->children[i], graph, keyDim, bt, childFactors[i]));
+  std::vector<const GFactor*> gathered;
+  for (size_t f : node->factors) gathered.push_back(&graph[f]);
+  for (auto& cf : childFactors)
+    if (!cf.empty()) gathered.push_back(&cf);
+  Clique cq;
+  eliminate_clique(gathered, node->orderedFrontalKeys, keyDim, cq, sepOut);
+  cq.children = childIdx;
+  int me = (int)bt.cliques.size();
+  bt.cliques.push_back(std::move(cq));
+  for (int c : childIdx) bt.cliques[c].parent = me;
+  return me;
+}
+
+// optimizeBayesTree gtsam/linear/linearAlgorithms-inst.h:54-155
+static void backsub(const BayesTree& bt, VectorValues& x) {
+  for (int ci = (int)bt.cliques.size() - 1; ci >= 0; ci--) {  // reverse post-order = parents before children
+    const Clique& c = bt.cliques[ci];
+    const int nf = c.RSd.r, n = c.RSd.c;
+    std::vector<double> rhs(nf);
+    for (int i = 0; i < nf; i++) rhs[i] = c.RSd(i, n - 1);
+    int col = nf;
+    for (size_t k = c.nFrontal; k < c.keys.size(); k++) {
+      const auto& xs = x.at(c.keys[k]);
+      for (int d = 0; d < c.dims[k]; d++, col++)
+        for (int i = 0; i < nf; i++) rhs[i] -= c.RSd(i, col) * xs[d];
+    }
+    for (int i = nf - 1; i >= 0; i--) {
+      double s = rhs[i];
+      for (int j = i + 1; j < nf; j++) s -= c.RSd(i, j) * rhs[j];
+      rhs[i] = s / c.RSd(i, i);
+    }
+    for (int i = 0; i < nf; i++)
+      if (std::isnan(rhs[i])) throw Indeterminate(c.keys.front());
+    int o = 0;
+    for (int k = 0; k < c.nFrontal; k++) {
+      x[c.keys[k]] = std::vector<double>(rhs.begin() + o, rhs.begin() + o + c.dims[k]);
+      o += c.dims[k];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ problem / optimizer state
+struct LMParams {
+  // gtsam/nonlinear/LevenbergMarquardtParams.h:69-82 (legacy defaults)
+  int maxIterations = 100;
+  double relativeErrorTol = 1e-5, absoluteErrorTol = 1e-5, errorTol = 0.0;
+  double lambdaInitial = 1e-5, lambdaFactor = 10.0, lambdaUpperBound = 1e5, lambdaLowerBound = 0.0;
+  double minModelFidelity = 1e-3;
+  int diagonalDamping = 0, useFixedLambdaFactor = 1;
+  double minDiagonal = 1e-6, maxDiagonal = 1e32;
+};
+
+struct Problem {
+  Values values;
+  std::vector<Factor> factors;
+  std::vector<Key> ordering;
+  // linear state
+  std::vector<GFactor> linear;  // one per nonlinear factor
+  BayesTree bt;
+  VectorValues delta;
+  // LM state (gtsam/nonlinear/internal/LevenbergMarquardtState.h:42-157)
+  double lambda = 1e-5, currentFactor = 10.0, error = 0.0;
+  int iterations = 0, totalInner = 0;
+  std::vector<double> trace;  // per inner iteration: lambda, newError, modelFidelity, accepted, solved
+  // timing (seconds) of last iterate
+  double t_linearize = 0, t_eliminate = 0, t_backsub = 0;
+};
+
+static double graph_error(const Problem& p, const Values& v) {
+  // NonlinearFactorGraph::error gtsam/nonlinear/NonlinearFactorGraph.cpp:170-179 (factor index order)
+  double total = 0;
+  for (auto& f : p.factors) total += factor_error(f, v);
+  return total;
+}
+
+static void linearize(Problem& p) {
+  p.linear.clear();
+  p.linear.reserve(p.factors.size());
+  for (auto& f : p.factors) p.linear.push_back(linearize_factor(f, p.values));
+}
+
+// GaussianFactorGraph::error gtsam/linear/GaussianFactorGraph.cpp:71-78, JacobianFactor::error :509-514
+static double linear_error(const std::vector<GFactor>& g, const VectorValues& x) {
+  double total = 0;
+  for (auto& f : g) {
+    const int m = f.Ab.r, n = f.Ab.c;
+    double s = 0;
+    for (int i = 0; i < m; i++) {
+      double e = -f.Ab(i, n - 1);
+      int col = 0;
+      for (size_t k = 0; k < f.keys.size(); k++) {
+        const auto& xv = x.at(f.keys[k]);
+        for (int d = 0; d < f.dims[k]; d++, col++) e += f.Ab(i, col) * xv[d];
+      }
+      s += e * e;
+    }
+    total += 0.5 * s;
+  }
+  return total;
+}
+
+// hessianDiagonal gtsam/linear/GaussianFactorGraph.cpp:279-287
+static VectorValues hessian_diagonal(const Problem& p) {
+  VectorValues d;
+  for (auto& kv : p.values) d[kv.first] = std::vector<double>(kVarDim[kv.second.type], 0.0);
+  for (auto& f : p.linear) {
+    int col = 0;
+    for (size_t k = 0; k < f.keys.size(); k++) {
+      auto& dv = d[f.keys[k]];
+      for (int c = 0; c < f.dims[k]; c++, col++) {
+        double s = 0;
+        for (int i = 0; i < f.Ab.r; i++) s += f.Ab(i, col) * f.Ab(i, col);
+        dv[c] += s;
+      }
+    }
+  }
+  return d;
+}
+
+static double now_s();
+
+// buildDampedSystem + solve.  LevenbergMarquardtState.h:125-156, NonlinearOptimizer.cpp:132-146,
+// GaussianFactorGraph::optimize -> eliminateMultifrontal (EliminateableFactorGraph-inst.h:123-146)
+static void solve_damped(Problem& p, double lambda, const VectorValues* sqrtHessianDiagonal) {
+  std::vector<GFactor> damped = p.linear;
+  const double sigma = 1.0 / std::sqrt(lambda);
+  for (auto& kv : p.values) {
+    const int dim = kVarDim[kv.second.type];
+    GFactor g;
+    g.keys = {kv.first};
+    g.dims = {dim};
+    g.Ab = Mat(dim, dim + 1);
+    for (int i = 0; i < dim; i++) {
+      double a = sqrtHessianDiagonal ? sqrtHessianDiagonal->at(kv.first)[i] : 1.0;
+      g.Ab(i, i) = a / sigma;  // JacobianFactor with Isotropic sigma: whitened at updateHessian (JacobianFactor.cpp:769-776)
+    }
+    damped.push_back(std::move(g));
+  }
+  std::vector<std::vector<Key>> fkeys;
+  for (auto& g : damped) fkeys.push_back(g.keys);
+  VariableIndex vi;
+  for (size_t i = 0; i < fkeys.size(); i++)
+    for (Key k : fkeys[i]) vi[k].push_back(i);
+  std::map<Key, int> keyDim;
+  for (auto& kv : p.values) keyDim[kv.first] = kVarDim[kv.second.type];
+  double t0 = now_s();
+  auto roots = build_etree(fkeys, vi, p.ordering);
+  p.bt = BayesTree();
+  for (auto& r : roots) {
+    std::shared_ptr<JNode> jr;
+    jt_visit(r, fkeys, jr);
+    GFactor rem;
+    int idx = eliminate_tree(jr, damped, keyDim, p.bt, rem);
+    p.bt.roots.push_back(idx);
+  }
+  double t1 = now_s();
+  p.delta.clear();
+  backsub(p.bt, p.delta);
+  double t2 = now_s();
+  p.t_eliminate = t1 - t0;
+  p.t_backsub = t2 - t1;
+}
+
+static Values retract_all(const Values& v, const VectorValues& d) {
+  Values r;
+  for (auto& kv : v) r[kv.first] = retract(kv.second, d.at(kv.first).data());
+  return r;
+}
+
+// LevenbergMarquardtOptimizer::tryLambda gtsam/nonlinear/LevenbergMarquardtOptimizer.cpp:121-270
+static bool try_lambda(Problem& p, const LMParams& prm, const VectorValues* sqrtHD) {
+  double modelFidelity = 0.0;
+  bool step_is_successful = false, stopSearchingLambda = false;
+  double newError = std::numeric_limits<double>::infinity(), costChange = 0.0;
+  Values newValues;
+  bool solved;
+  try {
+    solve_damped(p, p.lambda, sqrtHD);
+    solved = true;
+  } catch (const Indeterminate&) {
+    solved = false;
+  }
+  const double lambdaTried = p.lambda;
+  if (solved) {
+    VectorValues zero;
+    for (auto& kv : p.delta) zero[kv.first] = std::vector<double>(kv.second.size(), 0.0);
+    double oldLin = linear_error(p.linear, zero);
+    double newLin = linear_error(p.linear, p.delta);
+    double linearizedCostChange = oldLin - newLin;
+    if (linearizedCostChange >= 0) {
+      newValues = retract_all(p.values, p.delta);
+      newError = graph_error(p, newValues);
+      costChange = p.error - newError;
+      if (linearizedCostChange > std::numeric_limits<double>::epsilon() * oldLin) {
+        modelFidelity = costChange / linearizedCostChange;
+        step_is_successful = modelFidelity > prm.minModelFidelity;
+      }
+      double minAbsoluteTolerance = prm.relativeErrorTol * p.error;
+      if (std::abs(costChange) < minAbsoluteTolerance) stopSearchingLambda = true;
+    }
+  }
+  p.trace.push_back(lambdaTried);
+  p.trace.push_back(newError);
+  p.trace.push_back(modelFidelity);
+  p.trace.push_back(step_is_successful ? 1.0 : 0.0);
+  p.trace.push_back(solved ? 1.0 : 0.0);
+  if (step_is_successful) {
+    // decreaseLambda LevenbergMarquardtState.h:80-93
+    double newLambda = p.lambda, newFactor = p.currentFactor;
+    if (prm.useFixedLambdaFactor) {
+      newLambda /= p.currentFactor;
+    } else {
+      newLambda *= std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * modelFidelity - 1.0, 3));
+      newFactor = 2.0 * p.currentFactor;
+    }
+    newLambda = std::max(prm.lambdaLowerBound, newLambda);
+    p.values = std::move(newValues);
+    p.error = newError;
+    p.lambda = newLambda;
+    p.currentFactor = newFactor;
+    p.iterations += 1;
+    p.totalInner += 1;
+    return true;
+  } else if (!stopSearchingLambda) {
+    // increaseLambda :70-76
+    p.lambda *= p.currentFactor;
+    p.totalInner += 1;
+    if (!prm.useFixedLambdaFactor) p.currentFactor *= 2.0;
+    if (p.lambda >= prm.lambdaUpperBound) return true;
+    return false;
+  } else {
+    return true;
+  }
+}
+
+// LevenbergMarquardtOptimizer::iterate :273-308
+static void lm_iterate(Problem& p, const LMParams& prm) {
+  double t0 = now_s();
+  linearize(p);
+  p.t_linearize = now_s() - t0;
+  VectorValues sqrtHD;
+  if (prm.diagonalDamping) {
+    sqrtHD = hessian_diagonal(p);
+    for (auto& kv : sqrtHD)
+      for (auto& x : kv.second) x = std::sqrt(std::min(std::max(x, prm.minDiagonal), prm.maxDiagonal));
+  }
+  while (!try_lambda(p, prm, prm.diagonalDamping ? &sqrtHD : nullptr)) {
+  }
+}
+
+// checkConvergence gtsam/nonlinear/NonlinearOptimizer.cpp:182-231
+static bool check_convergence(double relTol, double absTol, double errTol, double currentError, double newError) {
+  if (newError <= errTol) return true;
+  double absoluteDecrease = currentError - newError;
+  double relativeDecrease = absoluteDecrease / currentError;
+  return (relTol && (relativeDecrease <= relTol)) || (absoluteDecrease <= absTol);
+}
+
+// NonlinearOptimizer::defaultOptimize gtsam/nonlinear/NonlinearOptimizer.cpp:62-117
+static void lm_optimize(Problem& p, const LMParams& prm) {
+  double currentError = p.error;
+  if (currentError <= prm.errorTol) return;
+  if (p.iterations >= prm.maxIterations) return;
+  double newError = currentError;
+  do {
+    currentError = newError;
+    lm_iterate(p, prm);
+    newError = p.error;
+  } while (p.iterations < prm.maxIterations &&
+           !check_convergence(prm.relativeErrorTol, prm.absoluteErrorTol, prm.errorTol, currentError, newError) &&
+           std::isfinite(currentError));
+}
+
+}  // namespace orc
+
+#include <chrono>
+namespace orc {
+static double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+}  // namespace orc
+
+// =================================================================== C interface (ctypes)
+using namespace orc;
+extern "C" {
+
+void* orc_create() { return new Problem(); }
+void orc_destroy(void* h) { delete (Problem*)h; }
+
+int orc_add_variable(void* h, uint64_t key, int type, const double* value) {
+  auto* p = (Problem*)h;
+  if (type < 0 || type > 3) return 2;
+  Value v;
+  v.type = type;
+  std::memset(v.v, 0, sizeof(v.v));
+  std::memcpy(v.v, value, kVarStore[type] * sizeof(double));
+  p->values[key] = v;
+  return 0;
+}
+
+int orc_add_factor(void* h, int type, const uint64_t* keys, const double* meas, int noise_kind, const double* noise) {
+  auto* p = (Problem*)h;
+  if (type < 0 || type > 7) return 2;
+  Factor f;
+  f.type = type;
+  f.keys[0] = keys[0];
+  f.keys[1] = kFactorArity[type] > 1 ? keys[1] : 0;
+  std::memset(f.meas, 0, sizeof(f.meas));
+  std::memcpy(f.meas, meas, kFactorMeas[type] * sizeof(double));
+  f.noise_kind = noise_kind;
+  const int m = kFactorRows[type];
+  if (noise_kind == N_ISO) f.noise.assign(noise, noise + 1);
+  if (noise_kind == N_DIAG) f.noise.assign(noise, noise + m);
+  if (noise_kind == N_GAUSS) f.noise.assign(noise, noise + m * m);
+  p->factors.push_back(f);
+  return 0;
+}
+
+int orc_set_ordering(void* h, int n, const uint64_t* keys) {
+  auto* p = (Problem*)h;
+  p->ordering.assign(keys, keys + n);
+  return 0;
+}
+
+int orc_num_variables(void* h) { return (int)((Problem*)h)->values.size(); }
+int orc_num_factors(void* h) { return (int)((Problem*)h)->factors.size(); }
+int orc_total_dim(void* h) {
+  int n = 0;
+  for (auto& kv : ((Problem*)h)->values) n += kVarDim[kv.second.type];
+  return n;
+}
+
+// values in key-sorted order, packed kVarStore doubles each
+int orc_get_values(void* h, double* out) {
+  for (auto& kv : ((Problem*)h)->values) {
+    std::memcpy(out, kv.second.v, kVarStore[kv.second.type] * sizeof(double));
+    out += kVarStore[kv.second.type];
+  }
+  return 0;
+}
+
+double orc_error(void* h) {
+  auto* p = (Problem*)h;
+  return graph_error(*p, p->values);
+}
+
+int orc_linearize(void* h) {
+  linearize(*(Problem*)h);
+  return 0;
+}
+
+// Jacobian of factor i: col-major m x (sum dims + 1)  (the VerticalBlockMatrix of the JacobianFactor)
+int orc_get_jacobian(void* h, int i, double* out, int* rows, int* cols) {
+  auto* p = (Problem*)h;
+  const GFactor& g = p->linear.at(i);
+  *rows = g.Ab.r;
+  *cols = g.Ab.c;
+  if (out) std::memcpy(out, g.Ab.a.data(), g.Ab.a.size() * sizeof(double));
+  return 0;
+}
+
+// one damped solve; delta_out packed in key-sorted order.  returns 0 ok, 1 indeterminate
+int orc_solve(void* h, double lambda, int diagonal_damping, double min_diag, double max_diag, double* delta_out,
+              double* lin_err0, double* lin_err1) {
+  auto* p = (Problem*)h;
+  VectorValues sqrtHD;
+  if (diagonal_damping) {
+    sqrtHD = hessian_diagonal(*p);
+    for (auto& kv : sqrtHD)
+      for (auto& x : kv.second) x = std::sqrt(std::min(std::max(x, min_diag), max_diag));
+  }
+  try {
+    solve_damped(*p, lambda, diagonal_damping ? &sqrtHD : nullptr);
+  } catch (const Indeterminate&) {
+    return 1;
+  }
+  if (delta_out)
+    for (auto& kv : p->values) {
+      auto& d = p->delta.at(kv.first);
+      std::memcpy(delta_out, d.data(), d.size() * sizeof(double));
+      delta_out += d.size();
+    }
+  VectorValues zero;
+  for (auto& kv : p->delta) zero[kv.first] = std::vector<double>(kv.second.size(), 0.0);
+  if (lin_err0) *lin_err0 = linear_error(p->linear, zero);
+  if (lin_err1) *lin_err1 = linear_error(p->linear, p->delta);
+  return 0;
+}
+
+int orc_hessian_diagonal(void* h, double* out) {
+  auto* p = (Problem*)h;
+  auto d = hessian_diagonal(*p);
+  for (auto& kv : p->values) {
+    auto& v = d.at(kv.first);
+    std::memcpy(out, v.data(), v.size() * sizeof(double));
+    out += v.size();
+  }
+  return 0;
+}
+
+int orc_retract(void* h, const double* delta) {
+  auto* p = (Problem*)h;
+  VectorValues d;
+  for (auto& kv : p->values) {
+    int dim = kVarDim[kv.second.type];
+    d[kv.first] = std::vector<double>(delta, delta + dim);
+    delta += dim;
+  }
+  p->values = retract_all(p->values, d);
+  return 0;
+}
+
+// Bayes tree taps
+int orc_num_cliques(void* h) { return (int)((Problem*)h)->bt.cliques.size(); }
+// sizes: nkeys, nfrontal_keys, nf (rows), n (cols), parent
+int orc_clique_info(void* h, int i, int* info5) {
+  const Clique& c = ((Problem*)h)->bt.cliques.at(i);
+  info5[0] = (int)c.keys.size();
+  info5[1] = c.nFrontal;
+  info5[2] = c.RSd.r;
+  info5[3] = c.RSd.c;
+  info5[4] = c.parent;
+  return 0;
+}
+int orc_clique_get(void* h, int i, uint64_t* keys, double* RSd_colmajor) {
+  const Clique& c = ((Problem*)h)->bt.cliques.at(i);
+  if (keys) std::memcpy(keys, c.keys.data(), c.keys.size() * sizeof(uint64_t));
+  if (RSd_colmajor) std::memcpy(RSd_colmajor, c.RSd.a.data(), c.RSd.a.size() * sizeof(double));
+  return 0;
+}
+
+struct orc_lm_params {
+  int maxIterations;
+  double relativeErrorTol, absoluteErrorTol, errorTol;
+  double lambdaInitial, lambdaFactor, lambdaUpperBound, lambdaLowerBound;
+  double minModelFidelity;
+  int diagonalDamping, useFixedLambdaFactor;
+  double minDiagonal, maxDiagonal;
+};
+static LMParams to_params(const orc_lm_params* q) {
+  LMParams p;
+  p.maxIterations = q->maxIterations;
+  p.relativeErrorTol = q->relativeErrorTol;
+  p.absoluteErrorTol = q->absoluteErrorTol;
+  p.errorTol = q->errorTol;
+  p.lambdaInitial = q->lambdaInitial;
+  p.lambdaFactor = q->lambdaFactor;
+  p.lambdaUpperBound = q->lambdaUpperBound;
+  p.lambdaLowerBound = q->lambdaLowerBound;
+  p.minModelFidelity = q->minModelFidelity;
+  p.diagonalDamping = q->diagonalDamping;
+  p.useFixedLambdaFactor = q->useFixedLambdaFactor;
+  p.minDiagonal = q->minDiagonal;
+  p.maxDiagonal = q->maxDiagonal;
+  return p;
+}
+
+// LevenbergMarquardtOptimizer ctor: state = (values, graph.error(values), lambdaInitial, lambdaFactor)
+int orc_lm_init(void* h, const orc_lm_params* q) {
+  auto* p = (Problem*)h;
+  p->error = graph_error(*p, p->values);
+  p->lambda = q->lambdaInitial;
+  p->currentFactor = q->lambdaFactor;
+  p->iterations = 0;
+  p->totalInner = 0;
+  p->trace.clear();
+  return 0;
+}
+int orc_lm_iterate(void* h, const orc_lm_params* q) {
+  lm_iterate(*(Problem*)h, to_params(q));
+  return 0;
+}
+int orc_lm_optimize(void* h, const orc_lm_params* q) {
+  lm_optimize(*(Problem*)h, to_params(q));
+  return 0;
+}
+// state: error, lambda, iterations, totalInner, currentFactor
+int orc_lm_state(void* h, double* out5) {
+  auto* p = (Problem*)h;
+  out5[0] = p->error;
+  out5[1] = p->lambda;
+  out5[2] = p->iterations;
+  out5[3] = p->totalInner;
+  out5[4] = p->currentFactor;
+  return 0;
+}
+int orc_lm_trace_len(void* h) { return (int)((Problem*)h)->trace.size(); }
+int orc_lm_trace(void* h, double* out) {
+  auto* p = (Problem*)h;
+  std::memcpy(out, p->trace.data(), p->trace.size() * sizeof(double));
+  return 0;
+}
+int orc_timings(void* h, double* out3) {
+  auto* p = (Problem*)h;
+  out3[0] = p->t_linearize;
+  out3[1] = p->t_eliminate;
+  out3[2] = p->t_backsub;
+  return 0;
+}
+
+// ---- low-level taps used to pin the oracle against the reference's golden vectors ----
+// choleskyPartial on a col-major n x n matrix (upper triangle), in place.  returns 1 on success.
+int orc_cholesky_partial(double* ABC, int n, int nFrontal) { return cholesky_partial(ABC, n, n, nFrontal) ? 1 : 0; }
+
+// Linear (Gaussian) factor graph built directly: Jacobian factors [A|b] with diagonal sigmas, or Hessian
+// factors, then eliminated with a given ordering.  Used for testHessianFactor / testGaussianBayesTree vectors.
+struct LinearProblem {
+  std::vector<GFactor> graph;
+  std::map<Key, int> keyDim;
+  BayesTree bt;
+  VectorValues x;
+  std::vector<GFactor> remaining;
+};
+void* orc_linear_create() { return new LinearProblem(); }
+void orc_linear_destroy(void* h) { delete (LinearProblem*)h; }
+// A: col-major m x (sum dims), b: m, sigmas: m or null (unit).  Whitening as JacobianFactor::whiten (JacobianFactor.cpp:769-776)
+int orc_linear_add_jacobian(void* h, int nkeys, const uint64_t* keys, const int* dims, int m, const double* A, const double* b,
+                            const double* sigmas) {
+  auto* p = (LinearProblem*)h;
+  GFactor g;
+  int tot = 0;
+  for (int i = 0; i < nkeys; i++) {
+    g.keys.push_back(keys[i]);
+    g.dims.push_back(dims[i]);
+    p->keyDim[keys[i]] = dims[i];
+    tot += dims[i];
+  }
+  g.Ab = Mat(m, tot + 1);
+  for (int j = 0; j < tot; j++)
+    for (int i = 0; i < m; i++) g.Ab(i, j) = A[(size_t)j * m + i] / (sigmas ? sigmas[i] : 1.0);
+  for (int i = 0; i < m; i++) g.Ab(i, tot) = b[i] / (sigmas ? sigmas[i] : 1.0);
+  p->graph.push_back(g);
+  return 0;
+}
+// info: col-major (sum dims + 1)^2 augmented information matrix [G g; g' f] (upper triangle read)
+int orc_linear_add_hessian(void* h, int nkeys, const uint64_t* keys, const int* dims, const double* info) {
+  auto* p = (LinearProblem*)h;
+  GFactor g;
+  g.hessian = true;
+  int tot = 1;
+  for (int i = 0; i < nkeys; i++) {
+    g.keys.push_back(keys[i]);
+    g.dims.push_back(dims[i]);
+    p->keyDim[keys[i]] = dims[i];
+    tot += dims[i];
+  }
+  g.info = Mat(tot, tot);
+  std::memcpy(g.info.a.data(), info, sizeof(double) * tot * tot);
+  p->graph.push_back(g);
+  return 0;
+}
+// EliminateCholesky of the whole graph on the given frontal keys (one dense step).  Outputs: keys in Scatter
+// order, [R S d] (col-major nf x n) and the remaining separator information (col-major ns x ns, upper).
+int orc_linear_eliminate_dense(void* h, int nfrontal, const uint64_t* frontal, int* nkeys_out, uint64_t* keys_out, int* nf_out,
+                               int* n_out, double* RSd, double* sep_info) {
+  auto* p = (LinearProblem*)h;
+  std::vector<const GFactor*> gathered;
+  for (auto& g : p->graph) gathered.push_back(&g);
+  std::vector<Key> fr(frontal, frontal + nfrontal);
+  Clique cq;
+  GFactor sep;
+  try {
+    eliminate_clique(gathered, fr, p->keyDim, cq, sep);
+  } catch (const Indeterminate&) {
+    return 1;
+  }
+  *nkeys_out = (int)cq.keys.size();
+  std::memcpy(keys_out, cq.keys.data(), cq.keys.size() * sizeof(uint64_t));
+  *nf_out = cq.RSd.r;
+  *n_out = cq.RSd.c;
+  std::memcpy(RSd, cq.RSd.a.data(), cq.RSd.a.size() * sizeof(double));
+  if (sep_info) std::memcpy(sep_info, sep.info.a.data(), sep.info.a.size() * sizeof(double));
+  return 0;
+}
+// multifrontal solve of the linear graph with the given ordering; x packed in key-sorted order
+int orc_linear_optimize(void* h, int n, const uint64_t* ordering, double* x_out) {
+  auto* p = (LinearProblem*)h;
+  std::vector<std::vector<Key>> fkeys;
+  for (auto& g : p->graph) fkeys.push_back(g.keys);
+  VariableIndex vi;
+  for (size_t i = 0; i < fkeys.size(); i++)
+    for (Key k : fkeys[i]) vi[k].push_back(i);
+  std::vector<Key> order(ordering, ordering + n);
+  try {
+    auto roots = build_etree(fkeys, vi, order);
+    p->bt = BayesTree();
+    for (auto& r : roots) {
+      std::shared_ptr<JNode> jr;
+      jt_visit(r, fkeys, jr);
+      GFactor rem;
+      p->bt.roots.push_back(eliminate_tree(jr, p->graph, p->keyDim, p->bt, rem));
+    }
+    p->x.clear();
+    backsub(p->bt, p->x);
+  } catch (const Indeterminate&) {
+    return 1;
+  }
+  for (auto& kv : p->keyDim) {
+    auto& v = p->x.at(kv.first);
+    std::memcpy(x_out, v.data(), v.size() * sizeof(double));
+    x_out += v.size();
+  }
+  return 0;
+}
+int orc_linear_num_cliques(void* h) { return (int)((LinearProblem*)h)->bt.cliques.size(); }
+int orc_linear_clique_info(void* h, int i, int* info5) {
+  const Clique& c = ((LinearProblem*)h)->bt.cliques.at(i);
+  info5[0] = (int)c.keys.size();
+  info5[1] = c.nFrontal;
+  info5[2] = c.RSd.r;
+  info5[3] = c.RSd.c;
+  info5[4] = c.parent;
+  return 0;
+}
+int orc_linear_clique_get(void* h, int i, uint64_t* keys, double* RSd_colmajor) {
+  const Clique& c = ((LinearProblem*)h)->bt.cliques.at(i);
+  if (keys) std::memcpy(keys, c.keys.data(), c.keys.size() * sizeof(uint64_t));
+  if (RSd_colmajor) std::memcpy(RSd_colmajor, c.RSd.a.data(), c.RSd.a.size() * sizeof(double));
+  return 0;
+}
+
+// geometry taps for golden tests (testCal3Bundler, testPose3, testSO3)
+void orc_cal3bundler_uncalibrate(const double K[5], double x, double y, double out[2], double Dcal[6], double Dp[4]) {
+  Cal3Bundler k{K[0], K[1], K[2], K[3], K[4]};
+  cal3bundler_uncalibrate(k, x, y, out, Dcal, Dp);
+}
+void orc_pose3_expmap(const double xi[6], double out12[12]) { store_pose3(pose3_expmap(xi), out12); }
+void orc_pose3_logmap(const double in12[12], double xi[6]) { pose3_logmap(as_pose3(in12), xi); }
+void orc_rot3_expmap(const double w[3], double R[9]) {
+  M3 r = ExpmapFunctor(V3{w[0], w[1], w[2]}).expmap();
+  std::memcpy(R, r.m, sizeof(r.m));
+}
+void orc_rot3_logmap(const double R[9], double w[3]) {
+  M3 r;
+  std::memcpy(r.m, R, sizeof(r.m));
+  V3 o = so3_logmap(r);
+  w[0] = o.x; w[1] = o.y; w[2] = o.z;
+}
+// unwhitened error + Jacobians of a single factor (row-major H1, H2)
+int orc_factor_evaluate(void* h, int i, double* e, double* H1, double* H2) {
+  auto* p = (Problem*)h;
+  evaluate_error(p->factors.at(i), p->values, e, H1, H2);
+  return 0;
+}
+}

@@ -1,0 +1,322 @@
+"""TEST INFRASTRUCTURE: ctypes harness over oracle/liblm_oracle.so (the CPU restatement of the reference's
+LM path) and oracle/_ref/*.so (CCOLAMD / METIS compiled from the reference's vendored C sources).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this."""
+from __future__ import annotations
+
+import ctypes as ct
+import os
+
+import numpy as np
+
+from gtsam_personal_amd.graph import FACTOR_ARITY, FACTOR_MEAS, N_DIAG, N_GAUSS, N_ISO, N_UNIT, VAR_DIM, VAR_STORE, NonlinearFactorGraph, Values
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_SO = os.path.join(ROOT, "oracle", "liblm_oracle.so")
+REF_DIR = os.path.join(ROOT, "oracle", "_ref")
+
+_D = ct.POINTER(ct.c_double)
+_I = ct.POINTER(ct.c_int)
+_U = ct.POINTER(ct.c_uint64)
+
+
+class orc_lm_params(ct.Structure):
+    _fields_ = [
+        ("maxIterations", ct.c_int),
+        ("relativeErrorTol", ct.c_double), ("absoluteErrorTol", ct.c_double), ("errorTol", ct.c_double),
+        ("lambdaInitial", ct.c_double), ("lambdaFactor", ct.c_double), ("lambdaUpperBound", ct.c_double), ("lambdaLowerBound", ct.c_double),
+        ("minModelFidelity", ct.c_double),
+        ("diagonalDamping", ct.c_int), ("useFixedLambdaFactor", ct.c_int),
+        ("minDiagonal", ct.c_double), ("maxDiagonal", ct.c_double),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = ct.CDLL(ORACLE_SO)
+        L.orc_create.restype = ct.c_void_p
+        L.orc_linear_create.restype = ct.c_void_p
+        L.orc_error.restype = ct.c_double
+        for name in ("orc_destroy", "orc_linear_destroy"):
+            getattr(L, name).argtypes = [ct.c_void_p]
+        L.orc_add_variable.argtypes = [ct.c_void_p, ct.c_uint64, ct.c_int, _D]
+        L.orc_add_factor.argtypes = [ct.c_void_p, ct.c_int, _U, _D, ct.c_int, _D]
+        L.orc_set_ordering.argtypes = [ct.c_void_p, ct.c_int, _U]
+        L.orc_get_values.argtypes = [ct.c_void_p, _D]
+        L.orc_error.argtypes = [ct.c_void_p]
+        L.orc_linearize.argtypes = [ct.c_void_p]
+        L.orc_get_jacobian.argtypes = [ct.c_void_p, ct.c_int, _D, _I, _I]
+        L.orc_solve.argtypes = [ct.c_void_p, ct.c_double, ct.c_int, ct.c_double, ct.c_double, _D, _D, _D]
+        L.orc_hessian_diagonal.argtypes = [ct.c_void_p, _D]
+        L.orc_retract.argtypes = [ct.c_void_p, _D]
+        L.orc_num_cliques.argtypes = [ct.c_void_p]
+        L.orc_clique_info.argtypes = [ct.c_void_p, ct.c_int, _I]
+        L.orc_clique_get.argtypes = [ct.c_void_p, ct.c_int, _U, _D]
+        for name in ("orc_lm_init", "orc_lm_iterate", "orc_lm_optimize"):
+            getattr(L, name).argtypes = [ct.c_void_p, ct.POINTER(orc_lm_params)]
+        L.orc_lm_state.argtypes = [ct.c_void_p, _D]
+        L.orc_lm_trace_len.argtypes = [ct.c_void_p]
+        L.orc_lm_trace.argtypes = [ct.c_void_p, _D]
+        L.orc_timings.argtypes = [ct.c_void_p, _D]
+        L.orc_num_variables.argtypes = [ct.c_void_p]
+        L.orc_num_factors.argtypes = [ct.c_void_p]
+        L.orc_total_dim.argtypes = [ct.c_void_p]
+        L.orc_cholesky_partial.argtypes = [_D, ct.c_int, ct.c_int]
+        L.orc_linear_add_jacobian.argtypes = [ct.c_void_p, ct.c_int, _U, _I, ct.c_int, _D, _D, _D]
+        L.orc_linear_add_hessian.argtypes = [ct.c_void_p, ct.c_int, _U, _I, _D]
+        L.orc_linear_eliminate_dense.argtypes = [ct.c_void_p, ct.c_int, _U, _I, _U, _I, _I, _D, _D]
+        L.orc_linear_optimize.argtypes = [ct.c_void_p, ct.c_int, _U, _D]
+        L.orc_linear_num_cliques.argtypes = [ct.c_void_p]
+        L.orc_linear_clique_info.argtypes = [ct.c_void_p, ct.c_int, _I]
+        L.orc_linear_clique_get.argtypes = [ct.c_void_p, ct.c_int, _U, _D]
+        L.orc_cal3bundler_uncalibrate.argtypes = [_D, ct.c_double, ct.c_double, _D, _D, _D]
+        L.orc_pose3_expmap.argtypes = [_D, _D]
+        L.orc_pose3_logmap.argtypes = [_D, _D]
+        L.orc_rot3_expmap.argtypes = [_D, _D]
+        L.orc_rot3_logmap.argtypes = [_D, _D]
+        L.orc_factor_evaluate.argtypes = [ct.c_void_p, ct.c_int, _D, _D, _D]
+        _lib = L
+    return _lib
+
+
+def dp(a):
+    return a.ctypes.data_as(_D)
+
+
+def up(a):
+    return a.ctypes.data_as(_U)
+
+
+def ip(a):
+    return a.ctypes.data_as(_I)
+
+
+def lm_params_c(p):
+    return orc_lm_params(int(p.maxIterations), p.relativeErrorTol, p.absoluteErrorTol, p.errorTol, p.lambdaInitial, p.lambdaFactor,
+                         p.lambdaUpperBound, p.lambdaLowerBound, p.minModelFidelity, int(bool(p.diagonalDamping)),
+                         int(bool(p.useFixedLambdaFactor)), p.minDiagonal, p.maxDiagonal)
+
+
+class OracleProblem:
+    """the same (graph, values, ordering) fed to the CPU oracle"""
+
+    def __init__(self, graph: NonlinearFactorGraph, values: Values, ordering):
+        self.L = lib()
+        self.h = ct.c_void_p(self.L.orc_create())
+        self.keys = values.keys()
+        self.types = [values.type(k) for k in self.keys]
+        for k in self.keys:
+            v = np.ascontiguousarray(values.at(k), dtype=np.float64)
+            assert self.L.orc_add_variable(self.h, k, values.type(k), dp(v)) == 0
+        # factors in graph order
+        n = graph.size()
+        rec = [None] * n
+        for ftype, kind, gi, keys, meas, noise, models in graph.buckets():
+            for i, g in enumerate(gi.tolist()):
+                rec[g] = (ftype, keys[i], meas[i], models[i])
+        for ftype, keys, meas, model in rec:
+            kk = np.zeros(2, dtype=np.uint64)
+            kk[:FACTOR_ARITY[ftype]] = keys
+            m = np.ascontiguousarray(meas, dtype=np.float64)
+            if model.kind == N_UNIT:
+                nd = None
+            elif model.kind == N_ISO:
+                nd = dp(np.array([float(model.data)]))
+            else:
+                nd = dp(np.ascontiguousarray(model.data, dtype=np.float64).reshape(-1))
+            assert self.L.orc_add_factor(self.h, ftype, up(kk), dp(m), model.kind, nd) == 0
+        o = np.array(list(ordering), dtype=np.uint64)
+        self.L.orc_set_ordering(self.h, len(o), up(o))
+        self.ntot = self.L.orc_total_dim(self.h)
+        self.xoff = np.concatenate([[0], np.cumsum([VAR_DIM[t] for t in self.types])]).astype(int)
+
+    def __del__(self):
+        try:
+            self.L.orc_destroy(self.h)
+        except Exception:
+            pass
+
+    def error(self):
+        return self.L.orc_error(self.h)
+
+    def linearize(self):
+        self.L.orc_linearize(self.h)
+
+    def jacobian(self, i):
+        r, c = ct.c_int(), ct.c_int()
+        self.L.orc_get_jacobian(self.h, i, None, ct.byref(r), ct.byref(c))
+        out = np.empty(r.value * c.value)
+        self.L.orc_get_jacobian(self.h, i, dp(out), ct.byref(r), ct.byref(c))
+        return out.reshape(c.value, r.value).T.copy()
+
+    def solve(self, lam, diagonal=False, min_diag=1e-6, max_diag=1e32):
+        d = np.empty(self.ntot)
+        e0, e1 = ct.c_double(), ct.c_double()
+        rc = self.L.orc_solve(self.h, lam, int(diagonal), min_diag, max_diag, dp(d), ct.byref(e0), ct.byref(e1))
+        return rc, self.by_key(d), e0.value, e1.value
+
+    def by_key(self, packed):
+        return {k: packed[self.xoff[i]:self.xoff[i + 1]].copy() for i, k in enumerate(self.keys)}
+
+    def hessian_diagonal(self):
+        d = np.empty(self.ntot)
+        self.L.orc_hessian_diagonal(self.h, dp(d))
+        return self.by_key(d)
+
+    def retract(self, delta_by_key):
+        d = np.concatenate([delta_by_key[k] for k in self.keys])
+        self.L.orc_retract(self.h, dp(np.ascontiguousarray(d)))
+
+    def values(self):
+        tot = sum(VAR_STORE[t] for t in self.types)
+        out = np.empty(tot)
+        self.L.orc_get_values(self.h, dp(out))
+        res, o = {}, 0
+        for k, t in zip(self.keys, self.types):
+            res[k] = out[o:o + VAR_STORE[t]].copy()
+            o += VAR_STORE[t]
+        return res
+
+    def cliques(self):
+        """[(keys, n_frontal_keys, RSd (nf, n), parent)] in post-order"""
+        out = []
+        for i in range(self.L.orc_num_cliques(self.h)):
+            info = np.zeros(5, dtype=np.int32)
+            self.L.orc_clique_info(self.h, i, ip(info))
+            keys = np.zeros(info[0], dtype=np.uint64)
+            rsd = np.empty(info[2] * info[3])
+            self.L.orc_clique_get(self.h, i, up(keys), dp(rsd))
+            out.append(([int(k) for k in keys], int(info[1]), rsd.reshape(info[3], info[2]).T.copy(), int(info[4])))
+        return out
+
+    def lm_init(self, params):
+        c = lm_params_c(params)
+        self.L.orc_lm_init(self.h, ct.byref(c))
+
+    def lm_iterate(self, params):
+        c = lm_params_c(params)
+        self.L.orc_lm_iterate(self.h, ct.byref(c))
+
+    def lm_optimize(self, params):
+        c = lm_params_c(params)
+        self.L.orc_lm_optimize(self.h, ct.byref(c))
+
+    def lm_state(self):
+        s = np.empty(5)
+        self.L.orc_lm_state(self.h, dp(s))
+        return dict(error=s[0], lambda_=s[1], iterations=int(s[2]), inner=int(s[3]), factor=s[4])
+
+    def lm_trace(self):
+        n = self.L.orc_lm_trace_len(self.h)
+        t = np.empty(n)
+        self.L.orc_lm_trace(self.h, dp(t))
+        return t.reshape(-1, 5)  # lambda, newError, modelFidelity, accepted, solved
+
+    def timings(self):
+        t = np.empty(3)
+        self.L.orc_timings(self.h, dp(t))
+        return dict(linearize_s=t[0], eliminate_s=t[1], backsub_s=t[2])
+
+
+# ---------------------------------------------------------------- reference orderings (oracle/_ref)
+def have_ref():
+    return os.path.exists(os.path.join(REF_DIR, "libccolamd_ref.so")) and os.path.exists(os.path.join(REF_DIR, "libmetis_ref.so"))
+
+
+def variable_index(graph: NonlinearFactorGraph):
+    """VariableIndex (gtsam/inference/VariableIndex-inl.h:27-49): sorted key -> ascending factor indices"""
+    vi = {}
+    for i, keys in enumerate(graph.factor_keys_in_graph_order()):
+        for k in keys:
+            vi.setdefault(k, []).append(i)
+    return dict(sorted(vi.items()))
+
+
+def colamd_from_index(vi, n_factors, cmember=None):
+    """Ordering::ColamdConstrained (gtsam/inference/Ordering.cpp:50-125) on top of the reference's own ccolamd.c"""
+    L = ct.CDLL(os.path.join(REF_DIR, "libccolamd_ref.so"))
+    L.ccolamd_recommended.restype = ct.c_size_t
+    L.ccolamd_recommended.argtypes = [ct.c_int, ct.c_int, ct.c_int]
+    keys = list(vi.keys())
+    nVars = len(keys)
+    if nVars == 0:
+        return []
+    if nVars == 1:
+        return keys
+    nEntries = sum(len(v) for v in vi.values())
+    Alen = L.ccolamd_recommended(nEntries, n_factors, nVars)
+    A = np.zeros(Alen, dtype=np.int32)
+    p = np.zeros(nVars + 1, dtype=np.int32)
+    cnt = 0
+    for idx, k in enumerate(keys):
+        col = vi[k]
+        A[cnt:cnt + len(col)] = col
+        cnt += len(col)
+        p[idx + 1] = cnt
+    knobs = (ct.c_double * 20)()
+    L.ccolamd_set_defaults(knobs)
+    knobs[0] = -1  # CCOLAMD_DENSE_ROW
+    knobs[1] = -1  # CCOLAMD_DENSE_COL
+    stats = (ct.c_int * 20)()
+    cm = np.zeros(nVars, dtype=np.int32) if cmember is None else np.asarray(cmember, dtype=np.int32)
+    rv = L.ccolamd(ct.c_int(n_factors), ct.c_int(nVars), ct.c_int(Alen), ip(A), ip(p), knobs, stats, ip(cm))
+    if rv != 1:
+        raise RuntimeError(f"ccolamd failed with return value {rv}")
+    return [keys[p[j]] for j in range(nVars)]
+
+
+def colamd(graph: NonlinearFactorGraph):
+    return colamd_from_index(variable_index(graph), graph.size())
+
+
+def metis_from_adjacency(xadj, adj):
+    L = ct.CDLL(os.path.join(REF_DIR, "libmetis_ref.so"))
+    n = ct.c_int32(len(xadj) - 1)
+    xadj = np.asarray(xadj, dtype=np.int32)
+    adj = np.asarray(adj, dtype=np.int32)
+    perm = np.zeros(n.value, dtype=np.int32)
+    iperm = np.zeros(n.value, dtype=np.int32)
+    rc = L.METIS_NodeND(ct.byref(n), ip(xadj), ip(adj), None, None, ip(perm), ip(iperm))
+    if rc != 1:
+        raise RuntimeError("METIS failed")
+    return perm, iperm
+
+
+def metis_index(factor_keys):
+    """MetisIndex::augment (gtsam/inference/MetisIndex-inl.h:27-82): keys are numbered in order of first
+    appearance; CSR adjacency rows in integer order (only keys that have a neighbour get a row, as in the reference)."""
+    int_of, keys = {}, []
+    for fk in factor_keys:
+        for k in fk:
+            if k not in int_of:
+                int_of[k] = len(keys)
+                keys.append(k)
+    adjmap = {}
+    for fk in factor_keys:
+        for k1 in fk:
+            for k2 in fk:
+                if k1 != k2:
+                    adjmap.setdefault(int_of[k1], set()).add(int_of[k2])
+    xadj, adj = [0], []
+    for i in sorted(adjmap):
+        adj.extend(sorted(adjmap[i]))
+        xadj.append(len(adj))
+    return keys, xadj, adj
+
+
+def metis(graph: NonlinearFactorGraph):
+    return metis_from_factor_keys(graph.factor_keys_in_graph_order())
+
+
+def metis_from_factor_keys(factor_keys):
+    """Ordering::Metis (gtsam/inference/Ordering.cpp:211-256)"""
+    keys, xadj, adj = metis_index(factor_keys)
+    if len(keys) == 0:
+        return []
+    if len(keys) == 1:
+        return keys
+    perm, _ = metis_from_adjacency(xadj, adj)
+    return [keys[i] for i in perm]

@@ -1,0 +1,341 @@
+"""Pins the CPU oracle (oracle/lm_oracle.cpp) against the reference's OWN known answers and test strategy.
+Each test names the reference test it restates (file:line under the reference tree).  CPU only."""
+import ctypes as ct
+import os
+
+import numpy as np
+import pytest
+
+import oracle_harness as oh
+from gtsam_personal_amd import LevenbergMarquardtParams, NonlinearFactorGraph, P, Values, noiseModel
+from gtsam_personal_amd.datasets import SfmData, bal_graph, rot3_expmap
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _chol_partial(M, nf):
+    A = np.asfortranarray(M, dtype=np.float64).copy(order="F")
+    ok = oh.lib().orc_cholesky_partial(oh.dp(A), A.shape[0], nf)
+    return bool(ok), A
+
+
+# ---- gtsam/base/tests/testCholesky.cpp:42-67
+ABC7 = np.array([
+    [4.0375, 3.4584, 3.5735, 2.4815, 2.1471, 2.7400, 2.2063],
+    [0., 4.7267, 3.8423, 2.3624, 2.8091, 2.9579, 2.5914],
+    [0., 0., 5.1600, 2.0797, 3.4690, 3.2419, 2.9992],
+    [0., 0., 0., 1.8786, 1.0535, 1.4250, 1.3347],
+    [0., 0., 0., 0., 3.0788, 2.6283, 2.3791],
+    [0., 0., 0., 0., 0., 2.9227, 2.4056],
+    [0., 0., 0., 0., 0., 0., 2.5776]])
+
+
+def test_cholesky_partial_decomposition():
+    ok, RSL = _chol_partial(ABC7, 3)
+    assert ok
+    R1 = RSL.T.copy()
+    R2 = RSL.copy()
+    R1[3:, 3:] = np.eye(4)
+    tri = np.triu(R2[3:, 3:])
+    R2[3:, 3:] = tri + tri.T - np.diag(np.diag(tri))
+    R1 = np.tril(R1)  # choleskyPartial leaves the strict lower triangle of the input untouched (zero here)
+    R2[:3, :] = np.triu(R2)[:3, :]
+    expected = np.triu(ABC7) + np.triu(ABC7, 1).T
+    assert np.allclose(R1 @ R2, expected, atol=1e-9)
+
+
+def test_cholesky_partial_zero_frontals():
+    ok, A = _chol_partial(ABC7[:3, :3], 0)
+    assert ok and np.allclose(A, ABC7[:3, :3])
+
+
+# ---- gtsam/base/tests/testCholesky.cpp:70-81 (BadScalingCholesky)
+def test_cholesky_bad_scaling():
+    A = np.array([[1e-40, 0.0], [0.0, 1.0]])
+    ok, R = _chol_partial(A.T @ A, 2)
+    assert abs(R[0, 0] / R[1, 1] - 1e-40) < 1e-41
+
+
+# ---- gtsam/base/tests/testCholesky.cpp:101-138 (underconstrained -> false)
+def test_cholesky_underconstrained():
+    L = np.array([
+        [1, 0, 0, 0, 0, 0],
+        [1.11177808157954, 1.06204809504665, 0.507342638873381, 1.34953401829486, 1, 0],
+        [0.155864888199928, 1.10933048588373, 0.501255576961674, 1, 0, 0],
+        [1.12108665967793, 1.01584408366945, 1, 0, 0, 0],
+        [0.776164062474843, 0.117617236580373, -0.0236628691347294, 0.814118199972143, 0.694309975328922, 1],
+        [0.1197220685104, 1, 0, 0, 0, 0]])
+    d = [0.814723686393179, 0.811780089277421, 1.82596950680844, 0.240287537694585]
+    for tail in ([1.34342584865901, 1e-12], [0, 0], [-0.5, -0.6]):
+        A = L @ np.diag(d + tail) @ L.T
+        ok, _ = _chol_partial(A, 6)
+        assert not ok
+
+
+def _linear(jacobians):
+    L = oh.lib()
+    h = ct.c_void_p(L.orc_linear_create())
+    for keys, dims, A, b, sig in jacobians:
+        keys = np.array(keys, dtype=np.uint64)
+        dims = np.array(dims, dtype=np.int32)
+        A = np.asfortranarray(A, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        s = None if sig is None else oh.dp(np.ascontiguousarray(sig, dtype=np.float64))
+        L.orc_linear_add_jacobian(h, len(keys), oh.up(keys), oh.ip(dims), A.shape[0], oh.dp(A), oh.dp(b), s)
+    return h
+
+
+def _eliminate_dense(h, frontal, nmax=32):
+    L = oh.lib()
+    fr = np.array(frontal, dtype=np.uint64)
+    nk, nf, n = ct.c_int(), ct.c_int(), ct.c_int()
+    keys = np.zeros(nmax, dtype=np.uint64)
+    RSd = np.zeros(nmax * nmax)
+    sep = np.zeros(nmax * nmax)
+    rc = L.orc_linear_eliminate_dense(h, len(fr), oh.up(fr), ct.byref(nk), oh.up(keys), ct.byref(nf), ct.byref(n), oh.dp(RSd), oh.dp(sep))
+    assert rc == 0
+    ns = n.value - nf.value
+    return ([int(k) for k in keys[:nk.value]], RSd[:nf.value * n.value].reshape(n.value, nf.value).T.copy(),
+            sep[:ns * ns].reshape(ns, ns).T.copy())
+
+
+# ---- gtsam/linear/tests/testHessianFactor.cpp:447-477 (combine: expected 7x7 A'A)
+def test_hessian_combine():
+    A = np.hstack([11.1803399 * np.eye(2), -2.23606798 * np.eye(2), -8.94427191 * np.eye(2)])
+    b = np.array([2.23606798, -1.56524758])
+    h = _linear([([0, 1, 2], [2, 2, 2], A, b, np.ones(2))])
+    # eliminating zero frontals is not allowed; use one frontal of key 0 and rebuild A'A from [R S d] and the separator
+    keys, RSd, sep = _eliminate_dense(h, [0])
+    expected = np.array([
+        [125.0, 0.0, -25.0, 0.0, -100.0, 0.0, 25.0],
+        [0.0, 125.0, 0.0, -25.0, 0.0, -100.0, -17.5],
+        [-25.0, 0.0, 5.0, 0.0, 20.0, 0.0, -5.0],
+        [0.0, -25.0, 0.0, 5.0, 0.0, 20.0, 3.5],
+        [-100.0, 0.0, 20.0, 0.0, 80.0, 0.0, -20.0],
+        [0.0, -100.0, 0.0, 20.0, 0.0, 80.0, 14.0],
+        [25.0, -17.5, -5.0, 3.5, -20.0, 14.0, 7.45]])
+    full = RSd.T @ RSd
+    S = np.triu(sep) + np.triu(sep, 1).T
+    full[2:, 2:] += S
+    assert np.allclose(full, expected, atol=1e-4)
+    oh.lib().orc_linear_destroy(h)
+
+
+# ---- gtsam/linear/tests/testHessianFactor.cpp:377-444 (eliminate2: expected R, S, d and separator factor)
+def test_hessian_eliminate2():
+    sig = np.array([0.2, 0.2, 0.1, 0.1])
+    Ax2 = np.array([[-1., 0.], [0., -1.], [1., 0.], [0., 1.]])
+    Al1x1 = np.array([[1., 0., 0., 0.], [0., 1., 0., 0.], [0., 0., -1., 0.], [0., 0., 0., -1.]])
+    b2 = np.array([-0.2, 0.3, 0.2, -0.1])
+    h = _linear([([0, 1], [2, 4], np.hstack([Ax2, Al1x1]), b2, sig)])
+    keys, RSd, sep = _eliminate_dense(h, [0])
+    assert keys == [0, 1]
+    old = 0.0894427
+    # the conditional is sign-ambiguous per row between QR and Cholesky; Cholesky gives positive diagonal
+    R11 = np.eye(2) / old
+    S12 = np.array([[-0.2, 0., -0.8, 0.], [0., -0.2, 0., -0.8]]) / old
+    d = np.array([0.2, -0.14]) / old
+    assert np.allclose(RSd[:, :2], R11, atol=1e-3)
+    assert np.allclose(RSd[:, 2:6], S12, atol=1e-3)
+    assert np.allclose(RSd[:, 6], d, atol=1e-3)
+    sigma = 0.2236
+    Bl1x1 = np.array([[1., 0., -1., 0.], [0., 1., 0., -1.]]) / sigma
+    b1 = np.array([0.0, 0.894427])
+    Ab = np.hstack([Bl1x1, b1[:, None]])
+    expected = Ab.T @ Ab
+    S = np.triu(sep) + np.triu(sep, 1).T
+    assert np.allclose(S, expected, atol=2e-2)  # reference tolerance is 1.5e-3 relative to entries of size ~20
+    oh.lib().orc_linear_destroy(h)
+
+
+# ---- gtsam/linear/tests/testHessianFactor.cpp:264-313 (CombineAndEliminate1: R = 5 I, d = (0.6, 0, 0))
+def test_hessian_combine_and_eliminate1():
+    h = _linear([([1], [3], 3.0 * np.eye(3), np.array([1., 0, 0]), None), ([1], [3], 4.0 * np.eye(3), np.zeros(3), None)])
+    keys, RSd, sep = _eliminate_dense(h, [1])
+    assert np.allclose(RSd[:, :3], 5.0 * np.eye(3), atol=1e-9)  # information 25 I
+    assert np.allclose(RSd[:, 3], [0.6, 0, 0], atol=1e-9)
+    oh.lib().orc_linear_destroy(h)
+
+
+# ---- gtsam/linear/tests/testHessianFactor.cpp:316-374 (CombineAndEliminate2 vs. QR of the stacked Jacobian)
+def test_hessian_combine_and_eliminate2():
+    s0, s1, s2 = np.full(3, 1.6), np.full(3, 2.6), np.full(3, 3.6)
+    h = _linear([([1], [3], np.eye(3), np.full(3, 1.5), s0),
+                 ([0, 1], [3, 3], np.hstack([2 * np.eye(3), -2 * np.eye(3)]), np.full(3, 2.5), s1),
+                 ([1], [3], 3 * np.eye(3), np.full(3, 3.5), s2)])
+    keys, RSd, sep = _eliminate_dense(h, [0])
+    A0 = np.vstack([2 * np.eye(3), np.zeros((3, 3)), np.zeros((3, 3))])
+    A1 = np.vstack([-2 * np.eye(3), np.eye(3), 3 * np.eye(3)])
+    b = np.concatenate([np.full(3, 2.5), np.full(3, 1.5), np.full(3, 3.5)])
+    sg = np.concatenate([s1, s0, s2])
+    Ab = np.hstack([A0, A1, b[:, None]]) / sg[:, None]
+    Q, R = np.linalg.qr(Ab)
+    R = R * np.sign(np.diag(R))[:, None]
+    assert np.allclose(RSd, R[:3, :], atol=1e-6)
+    oh.lib().orc_linear_destroy(h)
+
+
+# ---- gtsam/inference/tests/testOrdering.cpp:40-107, 276-337 : orderings from the reference's own C sources
+needs_ref = pytest.mark.skipif(not oh.have_ref(), reason="oracle/_ref not built (reference tree absent)")
+
+
+def _chain():
+    return [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5)]
+
+
+def _vi(fk):
+    vi = {}
+    for i, ks in enumerate(fk):
+        for k in ks:
+            vi.setdefault(k, []).append(i)
+    return dict(sorted(vi.items()))
+
+
+@needs_ref
+def test_colamd_chain():
+    fk = _chain()
+    assert oh.colamd_from_index(_vi(fk), len(fk)) == [0, 1, 2, 3, 4, 5]
+
+
+@needs_ref
+def test_colamd_constrained_last_and_groups():
+    fk = _chain()
+    vi = _vi(fk)
+    # ColamdConstrainedLast({2, 4}) -> cmember 1 for those keys (Ordering.cpp:128-158)
+    assert oh.colamd_from_index(vi, len(fk), [0, 0, 1, 0, 1, 0]) == [0, 1, 5, 3, 4, 2]
+    # grouped constraints 2,4 -> group 1 ; 5 -> group 2 (testOrdering.cpp:90-107)
+    assert oh.colamd_from_index(vi, len(fk), [0, 0, 1, 0, 1, 2]) == [0, 1, 3, 2, 4, 5]
+
+
+def test_metis_csr_format():
+    fk = [(0, 1), (1, 2), (2, 3), (3, 4), (5, 6), (6, 7), (7, 8), (8, 9), (10, 11), (11, 12), (12, 13), (13, 14),
+          (0, 5), (5, 10), (1, 6), (6, 11), (2, 7), (7, 12), (3, 8), (8, 13), (4, 9), (9, 14)]
+    keys, xadj, adj = oh.metis_index(fk)
+    assert xadj == [0, 2, 5, 8, 11, 13, 16, 20, 24, 28, 31, 33, 36, 39, 42, 44]
+    assert adj == [1, 5, 0, 2, 6, 1, 3, 7, 2, 4, 8, 3, 9, 0, 6, 10, 1, 5, 7, 11, 2, 6, 8, 12, 3, 7, 9, 13, 4, 8, 14, 5, 11, 6, 10, 12, 7, 11,
+                   13, 8, 12, 14, 9, 13]
+    keys, xadj, adj = oh.metis_index([(100,), (100, 101), (101, 102), (102, 103), (103, 104), (104, 101)])
+    assert xadj == [0, 1, 4, 6, 8, 10] and adj == [1, 0, 2, 4, 1, 3, 2, 4, 1, 3]
+
+
+@needs_ref
+def test_metis_loop():
+    # testOrdering.cpp:297-337, the Linux expectation
+    fk = _chain() + [(0, 5)]
+    assert oh.metis_from_factor_keys(fk) == [3, 2, 5, 0, 4, 1]
+
+
+# ---- geometry: the reference's strategy is analytic Jacobian == numerical derivative
+def test_cal3bundler_uncalibrate_and_derivatives():
+    # gtsam/geometry/tests/testCal3Bundler.cpp:40-48, 123-153 : K(500, 1e-3, 2e-3, 1000, 2000), p(2, 3)
+    K = np.array([500, 1e-3, 2.0 * 1e-3, 1000, 2000.0])
+    x, y = 2.0, 3.0
+    out, Dcal, Dp = np.zeros(2), np.zeros(6), np.zeros(4)
+    oh.lib().orc_cal3bundler_uncalibrate(oh.dp(K), x, y, oh.dp(out), oh.dp(Dcal), oh.dp(Dp))
+    r = x * x + y * y
+    g = 1 + K[1] * r + K[2] * r * r
+    assert np.allclose(out, [K[3] + K[0] * g * x, K[4] + K[0] * g * y])
+
+    def f(K_, x_, y_):
+        o = np.zeros(2)
+        oh.lib().orc_cal3bundler_uncalibrate(oh.dp(np.asarray(K_, dtype=np.float64)), x_, y_, oh.dp(o), None, None)
+        return o
+    h = 1e-5
+    num_cal = np.stack([(f(K + h * np.eye(5)[i], x, y) - f(K - h * np.eye(5)[i], x, y)) / (2 * h) for i in range(3)], axis=1)
+    num_p = np.stack([(f(K, x + h, y) - f(K, x - h, y)) / (2 * h), (f(K, x, y + h) - f(K, x, y - h)) / (2 * h)], axis=1)
+    assert np.allclose(Dcal.reshape(2, 3), num_cal, atol=1e-5, rtol=1e-7)
+    assert np.allclose(Dp.reshape(2, 2), num_p, atol=1e-5, rtol=1e-7)
+
+
+def test_pose3_expmap_logmap_roundtrip_and_rodrigues():
+    # gtsam/geometry/tests/testPose3.cpp (Expmap/Logmap round trips), testRot3.cpp (Rodrigues == expm)
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        xi = rng.normal(0, 0.7, 6)
+        T = np.zeros(12)
+        oh.lib().orc_pose3_expmap(oh.dp(xi), oh.dp(T))
+        back = np.zeros(6)
+        oh.lib().orc_pose3_logmap(oh.dp(T), oh.dp(back))
+        assert np.allclose(back, xi, atol=1e-9)
+        R = T[:9].reshape(3, 3)
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-12)
+        # matrix exponential of the twist, by series
+        X = np.zeros((4, 4))
+        w, v = xi[:3], xi[3:]
+        X[:3, :3] = [[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]
+        X[:3, 3] = v
+        E, term = np.eye(4), np.eye(4)
+        for k in range(1, 30):
+            term = term @ X / k
+            E = E + term
+        assert np.allclose(E[:3, :3], R, atol=1e-10) and np.allclose(E[:3, 3], T[9:], atol=1e-10)
+    # near-pi rotation exercises the special branch of SO3::Logmap (gtsam/geometry/SO3.cpp:318-357)
+    for axis in np.eye(3):
+        w = axis * (np.pi - 1e-4)
+        R = np.zeros(9)
+        oh.lib().orc_rot3_expmap(oh.dp(w), oh.dp(R))
+        back = np.zeros(3)
+        oh.lib().orc_rot3_logmap(oh.dp(R), oh.dp(back))
+        assert np.allclose(back, w, atol=1e-7)
+    assert np.allclose(rot3_expmap([0.1, -0.2, 0.3]).reshape(-1), (lambda r: (oh.lib().orc_rot3_expmap(oh.dp(np.array([0.1, -0.2, 0.3])), oh.dp(r)), r)[1])(np.zeros(9)))
+
+
+def _numeric_jacobian(orc, graph, values, ordering, fidx, which_key):
+    """d e / d (retract tangent) by central differences, like gtsam/base/numericalDerivative.h"""
+    from gtsam_personal_amd.graph import VAR_DIM
+    dim = VAR_DIM[values.type(which_key)]
+    cols = []
+    for i in range(dim):
+        es = []
+        for sgn in (+1, -1):
+            o = oh.OracleProblem(graph, values, ordering)
+            d = {k: np.zeros(VAR_DIM[values.type(k)]) for k in values.keys()}
+            d[which_key][i] = sgn * 1e-6
+            o.retract(d)
+            e = np.zeros(9)
+            oh.lib().orc_factor_evaluate(o.h, fidx, oh.dp(e), None, None)
+            es.append(e.copy())
+        cols.append((es[0] - es[1]) / 2e-6)
+    return np.stack(cols, axis=1)
+
+
+def test_sfm_factor_jacobians_match_numerical():
+    # gtsam/slam/tests/testGeneralSFMFactor.cpp (Jacobians vs numericalDerivative), Cal3Bundler camera
+    from gtsam_personal_amd.synthetic import make_bal
+    graph, initial, _, ordering = make_bal(n_cam=3, n_pt=4, obs_per_point=2, seed=3, with_priors=False)
+    orc = oh.OracleProblem(graph, initial, ordering)
+    fk = graph.factor_keys_in_graph_order()
+    for fidx in range(3):
+        e, H1, H2 = np.zeros(9), np.zeros(81), np.zeros(54)
+        oh.lib().orc_factor_evaluate(orc.h, fidx, oh.dp(e), oh.dp(H1), oh.dp(H2))
+        n1 = _numeric_jacobian(orc, graph, initial, ordering, fidx, fk[fidx][0])[:2]
+        n2 = _numeric_jacobian(orc, graph, initial, ordering, fidx, fk[fidx][1])[:2]
+        assert np.allclose(H1[:18].reshape(2, 9), n1, rtol=1e-5, atol=1e-4)
+        assert np.allclose(H2[:6].reshape(2, 3), n2, rtol=1e-5, atol=1e-4)
+
+
+# ---- tests/testGeneralSFMFactorB.cpp:44-63 : THE BAL golden number
+@needs_ref
+def test_bal_dubrovnik_golden_error():
+    db = SfmData.FromBalFile(os.path.join(GOLD, "dubrovnik-3-7-pre.txt"))
+    assert db.numberCameras() == 3 and db.numberTracks() == 7
+    graph, initial = bal_graph(db)  # unit noise, cameras keyed 0..2, points P(j), no priors
+    ordering = oh.colamd(graph)
+    orc = oh.OracleProblem(graph, initial, ordering)
+    params = LevenbergMarquardtParams()
+    orc.lm_init(params)
+    orc.lm_optimize(params)
+    assert abs(orc.lm_state()["error"] - 0.0199833) < 1e-5
+    assert abs(orc.error() - 0.0199833) < 1e-5
+
+
+def test_bal_dubrovnik_golden_error_any_ordering():
+    """the converged error does not depend on the elimination ordering (agreement to ~1e-11)"""
+    from gtsam_personal_amd import Ordering
+    db = SfmData.FromBalFile(os.path.join(GOLD, "dubrovnik-3-7-pre.txt"))
+    graph, initial = bal_graph(db)
+    orc = oh.OracleProblem(graph, initial, Ordering.Schur(graph, initial))
+    params = LevenbergMarquardtParams()
+    orc.lm_init(params)
+    orc.lm_optimize(params)
+    assert abs(orc.lm_state()["error"] - 0.0199833) < 1e-5
