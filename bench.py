@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py — LM iterations/s of the MI355X-native Levenberg-Marquardt inner loop on a synthetic BAL-shaped graph.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched under
+torch.distributed.run (one rank per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env).  A "step" is ONE
+LevenbergMarquardtOptimizer::iterate() (linearize all factors + damped multifrontal Cholesky solve(s) + linear-error,
+retract and error evaluation) on the SAME graph, continuing the LM trajectory from the perturbed initial estimate:
+W untimed iterations, then exactly K timed ones between barrier + device synchronisation; MAX over ranks; rank 0
+prints ONE JSON line.  Workload = BASELINE.json configs[3] (1 000 cameras / 100 000 points / 1 000 000 projection
+factors, seed 42), which fits one GPU; N > 1 shards the point subtrees over the ranks and sums the camera-separator
+contributions with RCCL, i.e. STRONG scaling of the same graph.  Inputs are resident in HBM before the timed region.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet FP64 matrix peak (not listed in MI355X_MICROARCH.md; measured alongside)
+HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def cpu_baseline(n_cam, n_pt, obs, seed):
+    """the CPU oracle (a port of the reference's algorithm, 1 thread) timed on a bounded sample of the workload"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_harness as oh  # the oracle is only ever the baseline / the checker
+    from gtsam_personal_amd import LevenbergMarquardtParams
+    from gtsam_personal_amd.synthetic import make_bal
+    graph, initial, _, ordering = make_bal(n_cam, n_pt, obs, seed=seed)
+    orc = oh.OracleProblem(graph, initial, ordering)
+    params = LevenbergMarquardtParams()
+    orc.lm_init(params)
+    times = []
+    t_all = time.perf_counter()
+    while len(times) < 3 and (time.perf_counter() - t_all) < 25.0:
+        t0 = time.perf_counter()
+        orc.lm_iterate(params)
+        times.append(time.perf_counter() - t0)
+    tm = orc.timings()
+    return dict(value=len(times) / sum(times), unit="LM iterations/s", cores=1, kind="port",
+                sample=f"synthetic BAL {n_cam} cameras / {n_pt} points / {graph.size()} factors (1/10 of the GPU workload per dimension), "
+                       f"{len(times)} LM iterations, oracle/liblm_oracle.so single thread",
+                ms_per_iteration=1e3 * sum(times) / len(times), linearize_ms=1e3 * tm["linearize_s"], eliminate_ms=1e3 * tm["eliminate_s"])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--cams", type=int, default=1000)
+    ap.add_argument("--points", type=int, default=100000)
+    ap.add_argument("--obs", type=int, default=10)
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from gtsam_personal_amd import LevenbergMarquardtOptimizer, LevenbergMarquardtParams
+    from gtsam_personal_amd.synthetic import make_bal
+
+    t_setup = time.perf_counter()
+    graph, initial, _, ordering = make_bal(args.cams, args.points, args.obs, seed=args.seed)
+    params = LevenbergMarquardtParams()
+    comm_id = None
+    if world > 1:
+        obj = [LevenbergMarquardtOptimizer.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(obj, src=0)
+        comm_id = obj[0]
+    opt = LevenbergMarquardtOptimizer(graph, initial, ordering, params, device=local_rank, rank=rank, world_size=world, comm_id=comm_id)
+    t_setup = time.perf_counter() - t_setup
+    n_factors = graph.size()
+    e_initial = opt.error()
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        opt.iterate()
+    if not args.no_kernel_timing:
+        opt.set_kernel_timing(True)
+    phases = dict(linearize_ms=0.0, eliminate_ms=0.0, backsub_ms=0.0, linear_error_ms=0.0, retract_error_ms=0.0)
+    inner = 0
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        opt.iterate()
+        tm = opt.timings()
+        for k in phases:
+            phases[k] += tm[k]
+        inner += tm["inner_iterations"]
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kt = opt.kernel_times() if not args.no_kernel_timing else None
+    e_final = opt.error()
+
+    if rank == 0:
+        steps = args.steps
+        out = {
+            "metric": "LM iterations/sec",
+            "value": steps / elapsed,
+            "unit": "LM iterations/s",
+            "n_gpus": world,
+            "steps": steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"synthetic BAL {args.cams} cameras / {args.points} points / {n_factors} factors (GeneralSFMFactor<Cal3Bundler> + 2 priors), "
+                                   f"seed {args.seed}, Schur ordering (points then cameras), LM legacy defaults",
+                       "cameras": args.cams, "points": args.points, "factors": n_factors, "fronts": opt.num_fronts(),
+                       "parallelism": "single GPU" if world == 1 else f"point subtrees sharded over {world} ranks, camera root replicated after ncclAllReduce"},
+            "ms_per_linearize": phases["linearize_ms"] / steps,
+            "ms_per_eliminate": phases["eliminate_ms"] / max(1, inner),
+            "ms_per_backsub": phases["backsub_ms"] / max(1, inner),
+            "ms_per_linear_error": phases["linear_error_ms"] / max(1, inner),
+            "ms_per_retract_error": phases["retract_error_ms"] / max(1, inner),
+            "inner_iterations": inner,
+            "error_initial": e_initial,
+            "error_final": e_final,
+            "setup_s": t_setup,
+        }
+        if kt is not None:
+            syrk, lin = kt["syrk"], kt["linearize"]
+            if syrk["launches"] > 0 and syrk["ms"] > 0:
+                tf = syrk["work"] / (syrk["ms"] * 1e-3) / 1e12
+                out["roofline"] = {"kernel": "syrk_mfma_kernel (v_mfma_f64_16x16x4_f64 trailing update of the dense camera front)",
+                                   "bound": "mfma", "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": tf / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                                   "launches": syrk["launches"], "avg_launch_us": 1e3 * syrk["ms"] / syrk["launches"],
+                                   "flop_per_launch": syrk["work"] / syrk["launches"]}
+            if lin["launches"] > 0 and lin["ms"] > 0:
+                gbs = lin["work"] / (lin["ms"] * 1e-3) / 1e9
+                out["roofline_linearize"] = {"kernel": "sfm_linearize_kernel", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                             "frac": gbs / HBM_PEAK_GBPS, "traffic": None, "launches": lin["launches"],
+                                             "avg_launch_us": 1e3 * lin["ms"] / lin["launches"], "bytes_per_launch": lin["work"] / lin["launches"]}
+            out["kernel_ms_per_step"] = {k: v["ms"] / steps for k, v in kt.items()}
+        # measured device peaks for context (not the roofline denominators)
+        import ctypes as ct
+        from gtsam_personal_amd import _lib
+        lib = _lib.load()
+        v = ct.c_double()
+        if lib.lmgpu_peak_mfma_f64(local_rank, 4000, ct.byref(v)) == 0:
+            out["measured_peak_mfma_f64_tflops"] = v.value
+        if lib.lmgpu_peak_hbm_copy(local_rank, 1 << 30, 5, ct.byref(v)) == 0:
+            out["measured_hbm_copy_gbps"] = v.value
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(max(2, args.cams // 10), max(10, args.points // 10), args.obs, args.seed)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -64,6 +64,8 @@ SYMBOLS = {
     "lmgpu_iterate": (ct.c_int, [_H, ct.POINTER(lmgpu_lm_params), ct.POINTER(lmgpu_lm_state)]),
     "lmgpu_optimize": (ct.c_int, [_H, ct.POINTER(lmgpu_lm_params), ct.POINTER(lmgpu_lm_state)]),
     "lmgpu_get_timings": (ct.c_int, [_H, ct.POINTER(lmgpu_timings)]),
+    "lmgpu_set_kernel_timing": (ct.c_int, [_H, ct.c_int32]),
+    "lmgpu_get_kernel_times": (ct.c_int, [_H, _D, _D, ct.POINTER(ct.c_int64)]),
     "lmgpu_get_jacobian": (ct.c_int, [_H, ct.c_int32, _D, _I, _I]),
     "lmgpu_num_fronts": (ct.c_int, [_H]),
     "lmgpu_front_info": (ct.c_int, [_H, ct.c_int32, _I]),
@@ -73,6 +75,8 @@ SYMBOLS = {
     "lmgpu_peak_mfma_f64": (ct.c_int, [ct.c_int32, ct.c_int32, _D]),
     "lmgpu_peak_hbm_copy": (ct.c_int, [ct.c_int32, ct.c_int64, ct.c_int32, _D]),
 }
+
+KT_NAMES = ("linearize", "lds_front", "hbm_assemble", "panel", "syrk", "backsub_hbm", "backsub_lds", "linear_error", "retract_error", "allreduce")
 
 _lib = None
 

@@ -1,9 +1,11 @@
 // HBM fronts: fronts too large for one workgroup's LDS live in HBM (row-major upper, leading dimension ld)
-// and are processed by a blocked right-looking partial Cholesky:
-//   per 64-row panel:  potrf (diagonal block, LDS) + trsm (row panel, one lane per column)   -> potrf_trsm_kernel
-//                      trailing update C -= P^T P on the matrix cores (v_mfma_f64_16x16x4_f64) -> syrk_mfma_kernel
+// and are processed by a two-level blocked right-looking partial Cholesky:
+//   outer panel = 256 rows:   4 x [ potrf (64x64 diagonal block, LDS) + trsm (row panel)      -> potrf_trsm_kernel
+//                                   + update of the remaining rows of the outer panel (K = 64)  -> syrk_mfma_kernel ]
+//                             then ONE trailing update of everything below with K = 256          -> syrk_mfma_kernel
+// so the big trailing matrix is read-modified-written once per 256 eliminated rows (HBM traffic / 4 vs. 64-row steps).
 // This is choleskyPartial (gtsam/base/cholesky.cpp:108-159: LLT(A); S = R^-T B; C -= S^T S; pivot-exponent test)
-// in blocked form; the root of a BAL problem (all cameras, 9001 x 9001) spends >95 % of the solve here.
+// in blocked form; the root of a BAL problem (all cameras, 9001 x 9001) spends >90 % of the solve here.
 // Assembly (a11/a12) into an HBM front uses FP64 global atomics (children and factors scatter concurrently).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -44,16 +46,24 @@ __global__ __launch_bounds__(64) void hbm_assemble_factors_kernel(FrontDesc F, i
 // one block per child: extend-add of its update matrix
 __global__ __launch_bounds__(256) void hbm_assemble_children_kernel(FrontDesc F, int64_t f_off, int ld, const ChildRef* __restrict__ childs,
                                                                     const int32_t* __restrict__ cmap, double* __restrict__ pool) {
+  __shared__ int32_t smap[160];
   const ChildRef c = childs[F.child_begin + blockIdx.x];
   const double* U = pool + c.u_off;
   const int32_t* map = cmap + c.map_begin;
   double* A = pool + f_off;
-  for (int idx = threadIdx.x; idx < c.m * c.m; idx += 256) {
-    const int i = idx / c.m, j = idx - i * c.m;
-    if (j < i) continue;
-    const int gi = map[i], gj = map[j];
-    const int lo = gi < gj ? gi : gj, hi = gi < gj ? gj : gi;
-    atomicAdd(&A[(size_t)lo * ld + hi], U[(size_t)i * c.ld + j]);
+  const bool small = c.m <= 160;
+  if (small) {
+    for (int i = threadIdx.x; i < c.m; i += 256) smap[i] = map[i];
+    __syncthreads();
+  }
+  for (int i = threadIdx.x >> 6; i < c.m; i += 4) {  // one wave per row: row i of U is contiguous
+    const int gi = small ? smap[i] : map[i];
+    const double* Ui = U + (size_t)i * c.ld;
+    for (int j = i + (threadIdx.x & 63); j < c.m; j += 64) {
+      const int gj = small ? smap[j] : map[j];
+      const int lo = gi < gj ? gi : gj, hi = gi < gj ? gj : gi;
+      atomicAdd(&A[(size_t)lo * ld + hi], Ui[j]);
+    }
   }
 }
 
@@ -66,7 +76,8 @@ __global__ __launch_bounds__(256) void hbm_damp_kernel(FrontDesc F, int64_t f_of
 
 // ---------------------------------------------------------------- panel: potrf + trsm
 // Every block factors the nb x nb diagonal block in LDS (redundantly: it is 64^3/3 flop), block 0 writes it back;
-// then each lane forward-substitutes one column of the row panel:  P = R_kk^-T A_panel.
+// then each lane forward-substitutes one column of the row panel,  P = R_kk^-T A_panel,  16 rows at a time
+// (x of the finished 16-row groups is re-read from the panel, so only 16 values live in registers).
 template <int NB>
 __global__ __launch_bounds__(256) void potrf_trsm_kernel(double* __restrict__ A, int ld, int n, int nf, int k0, int nb, int front_id,
                                                           int* __restrict__ status) {
@@ -81,26 +92,25 @@ __global__ __launch_bounds__(256) void potrf_trsm_kernel(double* __restrict__ A,
   __syncthreads();
   bool failed = false;
   for (int k = 0; k < nb; k++) {
+    __syncthreads();  // trailing update of the previous step is complete
     double piv = D[k][k];
     if (!(piv > 0.0)) {
       if (piv <= 0.0) failed = true;
       piv = (piv == piv && piv != 0.0) ? fabs(piv) : 1.0;
     }
     const double r = sqrt(piv), inv = 1.0 / r;
-    __syncthreads();
-    if (tid < nb - k) {
-      const int j = k + tid;
-      D[k][j] = (j == k) ? r : D[k][j] * inv;
-    }
-    __syncthreads();
     const int t = nb - k - 1;
-    for (int idx = tid; idx < t * t; idx += 256) {
-      const int a = idx / t, b = idx - a * t;
-      if (b < a) continue;
-      D[k + 1 + a][k + 1 + b] -= D[k][k + 1 + a] * D[k][k + 1 + b];
+    if (tid < t) D[k][k + 1 + tid] *= inv;
+    __syncthreads();  // row k scaled; every thread has read the pivot
+    if (tid == 0) D[k][k] = r;
+    // trailing update of the t x t block: thread column b = tid % 64, rows a = tid / 64 + 4 i
+    const int b = tid & 63;
+    if (b < t) {
+      const double rb = D[k][k + 1 + b];
+      for (int a = tid >> 6; a <= b; a += 4) D[k + 1 + a][k + 1 + b] -= D[k][k + 1 + a] * rb;
     }
-    __syncthreads();
   }
+  __syncthreads();
   if (blockIdx.x == 0) {
     for (int idx = tid; idx < nb * nb; idx += 256) {
       const int p = idx / nb, q = idx - p * nb;
@@ -119,67 +129,108 @@ __global__ __launch_bounds__(256) void potrf_trsm_kernel(double* __restrict__ A,
       if (failed) atomicMin(status, front_id);
     }
   }
-  // trsm: one lane per column of the row panel
+  // trsm: one lane per column of the row panel;  R^T x = a  (R^T lower: (R^T)[p][q] = D[q][p])
   const int j = k0 + nb + blockIdx.x * 256 + tid;
   if (j >= n) return;
-  double a[NB];
+  double* col = A + (size_t)k0 * ld + j;
+  constexpr int G = 16;
+  for (int g0 = 0; g0 < nb; g0 += G) {
+    double a[G];
 #pragma unroll
-  for (int p = 0; p < NB; p++) a[p] = (p < nb) ? A[(size_t)(k0 + p) * ld + j] : 0.0;
+    for (int p = 0; p < G; p++) a[p] = (g0 + p < nb) ? col[(size_t)(g0 + p) * ld] : 0.0;
+    // contributions of the already solved rows
+    for (int q = 0; q < g0; q++) {
+      const double x = col[(size_t)q * ld];
 #pragma unroll
-  for (int q = 0; q < NB; q++) {
-    const double x = a[q] / D[q][q];
-    a[q] = x;
+      for (int p = 0; p < G; p++) a[p] -= D[q][g0 + p] * x;
+    }
 #pragma unroll
-    for (int p = q + 1; p < NB; p++) a[p] -= D[q][p] * x;
+    for (int q = 0; q < G; q++) {
+      const double x = a[q] / D[g0 + q][g0 + q];
+      a[q] = x;
+#pragma unroll
+      for (int p = q + 1; p < G; p++) a[p] -= D[g0 + q][g0 + p] * x;
+    }
+#pragma unroll
+    for (int p = 0; p < G; p++)
+      if (g0 + p < nb) col[(size_t)(g0 + p) * ld] = a[p];
   }
-#pragma unroll
-  for (int p = 0; p < NB; p++)
-    if (p < nb) A[(size_t)(k0 + p) * ld + j] = a[p];
 }
 
 // ---------------------------------------------------------------- trailing update on the matrix cores
-// C[i][j] -= sum_p P[p][i] P[p][j]   for c0 <= i <= j < n, P = rows k0..k0+nb-1 of A (already [R S d] rows).
+// C[i][j] -= sum_{p < kp} P[p][i] P[p][j]   for r0 <= i < r1, i <= j < n,   P = rows p0 .. p0+kp-1 of A (finished [R S d] rows).
 // Block = 4 waves computing a 128x128 tile (each wave 64x64 = 4x4 MFMA 16x16x4 f64 tiles, 128 accumulator VGPRs).
-// Operand fragments are read straight from the (L2-resident) panel rows: lane l holds P[k + (l>>4)][col + (l&15)],
-// i.e. four 128-B row segments per wave load; no LDS staging is needed at 1 MFMA issue per 64 cycles per SIMD.
-__global__ __launch_bounds__(256) void syrk_mfma_kernel(double* __restrict__ A, int ld, int n, int k0, int nb) {
-  const int c0 = k0 + nb;
+// The two 16-row x 128-column operand slabs of each K-chunk are DMA'd HBM/L2 -> LDS with global_load_lds (one 1-KiB
+// row per wave-instruction, no VGPR staging), double-buffered; fragments are ds_read_b64 (lane l: P[k + (l>>4)][col + (l&15)]).
+// LDS row stride 144 doubles: rows k and k+1 of a fragment land on opposite halves of the 64-bank row (conflict-free).
+#define SYRK_KC 16
+#define SYRK_LDW 144
+__device__ __forceinline__ void glds_row(const double* g, double* lds_row) {
+  // 64 lanes x 16 B = one 128-double row; LDS destination = wave-uniform base + lane * 16
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_row, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void syrk_mfma_kernel(double* __restrict__ A, int ld, int n, int p0, int kp, int r0, int r1) {
+  extern __shared__ double sm[];  // [2 stages][2 operands][SYRK_KC][SYRK_LDW]
   const int ti = blockIdx.y, tj = blockIdx.x;
   if (tj < ti) return;
+  const int it0 = r0 + ti * 128, jt0 = r0 + tj * 128;  // tile origins
+  if (it0 >= r1 || jt0 >= n) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wr = wave >> 1, wc = wave & 1;
-  if (ti == tj && wr > wc) return;  // strictly-lower quadrant of a diagonal tile
-  const int i0 = c0 + ti * 128 + wr * 64;
-  const int j0 = c0 + tj * 128 + wc * 64;
-  if (i0 >= n || j0 >= n) return;
+  const bool diag = (ti == tj);
+  const bool active = !(diag && wr > wc) && (it0 + wr * 64 < r1) && (jt0 + wc * 64 < n);  // wave has something to store
   const int kk = lane >> 4, cc = lane & 15;
   double4_t acc[4][4];
 #pragma unroll
   for (int a = 0; a < 4; a++)
 #pragma unroll
     for (int b = 0; b < 4; b++) acc[a][b] = double4_t{0, 0, 0, 0};
-  const double* P = A + (size_t)k0 * ld;
-  for (int k = 0; k < nb; k += 4) {
-    const int row = k + kk;
-    const bool rok = row < nb;
-    const double* prow = P + (size_t)row * ld;
-    double af[4], bf[4];
+  const int nchunk = (kp + SYRK_KC - 1) / SYRK_KC;
+  const double* P = A + (size_t)p0 * ld;
+  // stage loader: 2 operands x 16 rows = 32 row-DMAs per chunk, 8 per wave.  Rows >= kp are zero-filled.
+  auto issue = [&](int c, int buf) {
+    double* base = sm + (size_t)buf * 2 * SYRK_KC * SYRK_LDW;
 #pragma unroll
-    for (int a = 0; a < 4; a++) {
-      const int col = i0 + a * 16 + cc;
-      af[a] = (rok && col < n) ? -prow[col] : 0.0;
+    for (int q = 0; q < 8; q++) {
+      const int rr = wave * 8 + q;           // 0..31
+      const int op = rr >> 4, row = rr & 15;  // operand (0 = A side / tile rows, 1 = B side / tile cols), k-row in chunk
+      double* dst = base + ((size_t)op * SYRK_KC + row) * SYRK_LDW;
+      const int krow = c * SYRK_KC + row;
+      const int col0 = (op == 0) ? it0 : jt0;
+      if (krow < kp) {
+        glds_row(P + (size_t)krow * ld + col0 + lane * 2, dst);
+      } else {
+        dst[lane * 2] = 0.0;
+        dst[lane * 2 + 1] = 0.0;
+      }
     }
+  };
+  issue(0, 0);
+  for (int c = 0; c < nchunk; c++) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (c + 1 < nchunk) issue(c + 1, (c + 1) & 1);
+    if (active) {
+      const double* sA = sm + (size_t)(c & 1) * 2 * SYRK_KC * SYRK_LDW + wr * 64 + cc;
+      const double* sB = sm + (size_t)(c & 1) * 2 * SYRK_KC * SYRK_LDW + (size_t)SYRK_KC * SYRK_LDW + wc * 64 + cc;
 #pragma unroll
-    for (int b = 0; b < 4; b++) {
-      const int col = j0 + b * 16 + cc;
-      bf[b] = (rok && col < n) ? prow[col] : 0.0;
+      for (int ks = 0; ks < SYRK_KC; ks += 4) {
+        double af[4], bf[4];
+#pragma unroll
+        for (int a = 0; a < 4; a++) af[a] = -sA[(ks + kk) * SYRK_LDW + a * 16];
+#pragma unroll
+        for (int b = 0; b < 4; b++) bf[b] = sB[(ks + kk) * SYRK_LDW + b * 16];
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+          for (int b = 0; b < 4; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+      }
     }
-#pragma unroll
-    for (int a = 0; a < 4; a++)
-#pragma unroll
-      for (int b = 0; b < 4; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
   }
+  if (!active) return;
   // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+  const int i0 = it0 + wr * 64, j0 = jt0 + wc * 64;
 #pragma unroll
   for (int a = 0; a < 4; a++)
 #pragma unroll
@@ -188,7 +239,7 @@ __global__ __launch_bounds__(256) void syrk_mfma_kernel(double* __restrict__ A, 
       for (int r = 0; r < 4; r++) {
         const int row = i0 + a * 16 + kk + 4 * r;
         const int col = j0 + b * 16 + cc;
-        if (row < n && col < n && col >= row) A[(size_t)row * ld + col] += acc[a][b][r];
+        if (row < r1 && col < n && col >= row) A[(size_t)row * ld + col] += acc[a][b][r];
       }
 }
 

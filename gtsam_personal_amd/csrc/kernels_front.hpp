@@ -45,80 +45,103 @@ __device__ __forceinline__ int frexp_exp(double x) {
   return e;
 }
 
-// grid: one block per front in `list`; dynamic LDS = nmax*nmax doubles
+// grid: one block per front in `list`; dynamic LDS = nmax*nmax doubles (the front) + LDSF_JCAP doubles (staged Jacobians)
+// + LDSF_MAXB ints.  Lanes run along the contiguous (column) index of the row-major front, waves along rows.
+#define LDSF_JCAP 960
+#define LDSF_MAXB 64
 __global__ __launch_bounds__(256) void lds_front_kernel(const int32_t* __restrict__ list, const FrontDesc* __restrict__ fronts,
                                                          const FrontFac* __restrict__ ffac, const FacDesc* __restrict__ fd,
                                                          const ChildRef* __restrict__ childs, const int32_t* __restrict__ cmap,
                                                          const int32_t* __restrict__ fxoff, double* __restrict__ pool, double lambda,
-                                                         const double* __restrict__ dampw, int* __restrict__ status) {
+                                                         const double* __restrict__ dampw, int* __restrict__ status, int nmax) {
   extern __shared__ double S[];
+  double* Jb = S + (size_t)nmax * nmax;
+  int* Joff = (int*)(Jb + LDSF_JCAP);
   const FrontDesc F = fronts[list[blockIdx.x]];
   const int n = F.n, nf = F.nf, tid = threadIdx.x, nt = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
   for (int i = tid; i < n * n; i += nt) S[i] = 0.0;
-  __syncthreads();
-  // ---- own factors: S += [A b]^T [A b]
-  for (int k = 0; k < F.fac_count; k++) {
-    const FrontFac ff = ffac[F.fac_begin + k];
-    const FacDesc d = fd[ff.fac];
-    const double* J = pool + d.joff;
-    const int m = d.rows, nc = d.d0 + d.d1 + 1;
-    const int npair = nc * (nc + 1) / 2;
-    for (int pidx = tid; pidx < npair; pidx += nt) {
-      // unrank pair (p <= q) from linear index over the upper triangle, row by row
-      int p = 0, rem = pidx, rowlen = nc;
-      while (rem >= rowlen) {
-        rem -= rowlen;
-        rowlen--;
-        p++;
+  // ---- own factors: S += [A b]^T [A b], Jacobians staged through LDS in batches (coalesced HBM reads, no per-factor latency)
+  for (int k0 = 0; k0 < F.fac_count;) {
+    __syncthreads();
+    if (tid == 0) {
+      int o = 0, b = 0;
+      while (k0 + b < F.fac_count && b < LDSF_MAXB) {
+        const FacDesc d = fd[ffac[F.fac_begin + k0 + b].fac];
+        const int sz = d.rows * (d.d0 + d.d1 + 1);
+        if (o + sz > LDSF_JCAP) break;
+        Joff[b] = o;
+        o += sz;
+        b++;
       }
-      const int q = p + rem;
-      double v = 0;
-      for (int r = 0; r < m; r++) v += J[p * m + r] * J[q * m + r];
-      const int gp = (p < d.d0) ? ff.c0 + p : (p < d.d0 + d.d1 ? ff.c1 + (p - d.d0) : n - 1);
-      const int gq = (q < d.d0) ? ff.c0 + q : (q < d.d0 + d.d1 ? ff.c1 + (q - d.d0) : n - 1);
-      const int lo = gp < gq ? gp : gq, hi = gp < gq ? gq : gp;
-      S[lo * n + hi] += v;
+      Joff[LDSF_MAXB + 1] = b;  // batch size (>= 1: a single factor is at most 90 doubles)
+      Joff[b] = o;
     }
     __syncthreads();
+    const int B = Joff[LDSF_MAXB + 1];
+    for (int b = wave; b < B; b += nw) {
+      const double* J = pool + fd[ffac[F.fac_begin + k0 + b].fac].joff;
+      const int o = Joff[b], sz = Joff[b + 1] - o;
+      for (int i = lane; i < sz; i += 64) Jb[o + i] = J[i];
+    }
+    __syncthreads();
+    for (int b = 0; b < B; b++) {
+      const FrontFac ff = ffac[F.fac_begin + k0 + b];
+      const FacDesc d = fd[ff.fac];
+      const double* J = Jb + Joff[b];
+      const int m = d.rows, nc = d.d0 + d.d1 + 1;
+      // thread (p = tid / 16, q = p + tid % 16 ...) : p over columns in steps of nt/16, q strided by 16
+      for (int p = tid >> 4; p < nc; p += (nt >> 4)) {
+        const int gp = (p < d.d0) ? ff.c0 + p : (p < d.d0 + d.d1 ? ff.c1 + (p - d.d0) : n - 1);
+        for (int q = p + (tid & 15); q < nc; q += 16) {
+          double v = 0;
+          for (int r = 0; r < m; r++) v += J[p * m + r] * J[q * m + r];
+          const int gq = (q < d.d0) ? ff.c0 + q : (q < d.d0 + d.d1 ? ff.c1 + (q - d.d0) : n - 1);
+          const int lo = gp < gq ? gp : gq, hi = gp < gq ? gq : gp;
+          S[lo * n + hi] += v;
+        }
+      }
+      __syncthreads();
+    }
+    k0 += B;
   }
-  // ---- children: extend-add of their update matrices
+  __syncthreads();
+  // ---- children: extend-add of their update matrices (row i of U contiguous: lanes along j)
   for (int k = 0; k < F.child_count; k++) {
     const ChildRef c = childs[F.child_begin + k];
     const double* U = pool + c.u_off;
     const int32_t* map = cmap + c.map_begin;
-    for (int idx = tid; idx < c.m * c.m; idx += nt) {
-      const int i = idx / c.m, j = idx - i * c.m;
-      if (j < i) continue;
-      const int gi = map[i], gj = map[j];
-      const int lo = gi < gj ? gi : gj, hi = gi < gj ? gj : gi;
-      S[lo * n + hi] += U[(size_t)i * c.ld + j];
+    for (int i = wave; i < c.m; i += nw) {
+      const int gi = map[i];
+      for (int j = i + lane; j < c.m; j += 64) {
+        const int gj = map[j];
+        const int lo = gi < gj ? gi : gj, hi = gi < gj ? gj : gi;
+        S[lo * n + hi] += U[(size_t)i * c.ld + j];
+      }
     }
     __syncthreads();
   }
   // ---- damping on the frontal diagonal
   for (int i = tid; i < nf; i += nt) S[i * n + i] += lambda * dampw[fxoff[F.fx_begin + i]];
-  __syncthreads();
   // ---- partial Cholesky (right-looking, row k of R at a time)
   bool failed = false;
   for (int k = 0; k < nf; k++) {
+    __syncthreads();  // previous trailing update (or assembly) complete
     double piv = S[k * n + k];
     if (!(piv > 0.0)) {
       if (piv <= 0.0) failed = true;  // Eigen LLT: pivot <= 0 -> NumericalIssue (NaN passes, like Eigen)
       piv = (piv == piv && piv != 0.0) ? fabs(piv) : 1.0;
     }
     const double r = sqrt(piv), inv = 1.0 / r;
-    __syncthreads();
-    for (int j = k + tid; j < n; j += nt) S[k * n + j] = (j == k) ? r : S[k * n + j] * inv;
-    __syncthreads();
-    const int t = n - k - 1;
-    for (int idx = tid; idx < t * t; idx += nt) {
-      const int a = idx / t, b = idx - a * t;
-      if (b < a) continue;
-      const int i = k + 1 + a, j = k + 1 + b;
-      S[i * n + j] -= S[k * n + i] * S[k * n + j];
+    for (int j = k + 1 + tid; j < n; j += nt) S[k * n + j] *= inv;
+    __syncthreads();  // row k scaled; every thread has read the pivot
+    if (tid == 0) S[k * n + k] = r;
+    for (int i = k + 1 + wave; i < n; i += nw) {
+      const double rki = S[k * n + i];
+      for (int j = i + lane; j < n; j += 64) S[i * n + j] -= rki * S[k * n + j];
     }
-    __syncthreads();
   }
+  __syncthreads();
   if (tid == 0) {
     // pivot-exponent test, gtsam/base/cholesky.cpp:146-158
     if (nf >= 2) {
@@ -130,16 +153,12 @@ __global__ __launch_bounds__(256) void lds_front_kernel(const int32_t* __restric
   }
   // ---- emit [R S d] (strictly-lower zeroed) and the update matrix
   double* RSd = pool + F.rsd_off;
-  for (int idx = tid; idx < nf * n; idx += nt) {
-    const int i = idx / n, j = idx - i * n;
-    RSd[(size_t)i * F.ld_rsd + j] = (j >= i) ? S[i * n + j] : 0.0;
-  }
+  for (int i = wave; i < nf; i += nw)
+    for (int j = lane; j < n; j += 64) RSd[(size_t)i * F.ld_rsd + j] = (j >= i) ? S[i * n + j] : 0.0;
   const int m = n - nf;
   double* U = pool + F.u_off;
-  for (int idx = tid; idx < m * m; idx += nt) {
-    const int i = idx / m, j = idx - i * m;
-    if (j >= i) U[(size_t)i * F.ld_u + j] = S[(nf + i) * n + nf + j];
-  }
+  for (int i = wave; i < m; i += nw)
+    for (int j = i + lane; j < m; j += 64) U[(size_t)i * F.ld_u + j] = S[(nf + i) * n + nf + j];
 }
 
 // back-substitution for LDS-class fronts: x_F = R^-1 (d - S x_S).  One wave per front, 4 fronts per block.

@@ -7,6 +7,9 @@
 //   * the LM control loop: a restatement of LevenbergMarquardtOptimizer::iterate / tryLambda
 //     (gtsam/nonlinear/LevenbergMarquardtOptimizer.cpp:121-308) and NonlinearOptimizer::defaultOptimize
 //     (gtsam/nonlinear/NonlinearOptimizer.cpp:62-117) that only reads three scalars back per inner iteration.
+//   * multi-GPU: the subtrees hanging below the replicated top (HBM) fronts are dealt to the ranks; each rank
+//     linearizes / eliminates / back-substitutes its own subtrees, the separator contributions into the top
+//     fronts are summed with one ncclAllReduce (RCCL over xGMI), error scalars with a 3-double all-reduce.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -32,16 +35,26 @@ using namespace lmgpu;
       return LMGPU_HIP_ERROR;                                                                  \
     }                                                                                          \
   } while (0)
+#define NCCLCHECK(expr)                                                                        \
+  do {                                                                                         \
+    ncclResult_t _r = (expr);                                                                  \
+    if (_r != ncclSuccess) {                                                                   \
+      h->err = std::string(#expr) + ": " + ncclGetErrorString(_r);                             \
+      return LMGPU_HIP_ERROR;                                                                  \
+    }                                                                                          \
+  } while (0)
 
 namespace {
 
 struct Bucket {
-  int type = 0, n = 0, noise_kind = 0;
+  int type = 0, n = 0, noise_kind = 0;  // n = factors given by the caller
   std::vector<int32_t> graph_index, slots;
   std::vector<double> meas, noise;
   int rows = 0, cols = 0;  // Jacobian shape (cols includes b)
-  int64_t joff = 0;        // pool offset of the bucket's Jacobians
-  // device
+  // local (this rank's) part
+  int n_loc = 0;
+  std::vector<int32_t> loc_of;  // caller idx -> local idx inside the bucket, -1 if not evaluated on this rank
+  int64_t joff = 0;             // pool offset of the bucket's local Jacobians
   int32_t* d_vidx = nullptr;
   double* d_meas = nullptr;
   double* d_noise = nullptr;
@@ -55,10 +68,61 @@ struct LevelWork {
   std::vector<int> hbm;  // HBM fronts of this level
 };
 
-const int kBinN[6] = {24, 48, 72, 96, 120, 140};
+struct KTimer {
+  bool on = false;
+  std::vector<hipEvent_t> pool;
+  struct Rec {
+    int cat, e0, e1;
+  };
+  std::vector<Rec> recs;
+  int used = 0;
+  double ms[LMGPU_KT_NUM] = {0}, work[LMGPU_KT_NUM] = {0};
+  long long cnt[LMGPU_KT_NUM] = {0};
+  int grab() {
+    if (used == (int)pool.size()) {
+      hipEvent_t e;
+      (void)hipEventCreate(&e);
+      pool.push_back(e);
+    }
+    return used++;
+  }
+  int begin(int cat, hipStream_t s) {
+    if (!on) return -1;
+    const int e = grab();
+    (void)hipEventRecord(pool[e], s);
+    recs.push_back({cat, e, -1});
+    return (int)recs.size() - 1;
+  }
+  void end(int r, hipStream_t s, double w = 0) {
+    if (!on || r < 0) return;
+    const int e = grab();
+    (void)hipEventRecord(pool[e], s);
+    recs[r].e1 = e;
+    work[recs[r].cat] += w;
+  }
+  void resolve() {  // call after the stream is synchronised
+    for (const Rec& r : recs) {
+      float t = 0;
+      if (r.e1 >= 0 && hipEventElapsedTime(&t, pool[r.e0], pool[r.e1]) == hipSuccess) {
+        ms[r.cat] += t;
+        cnt[r.cat] += 1;
+      }
+    }
+    recs.clear();
+    used = 0;
+  }
+  void reset() {
+    for (int i = 0; i < LMGPU_KT_NUM; i++) ms[i] = work[i] = 0, cnt[i] = 0;
+  }
+};
+
+const int kBinN[6] = {24, 48, 72, 96, 120, 139};  // 139^2 * 8 + staging = 162.5 KB <= 160 KiB of LDS per workgroup
 const int kNumBins = 6;
-const int kLdsLimitN = 140;
-const int NB = 64;
+const int kLdsLimitN = 139;
+const int kLdsFrontExtra = LDSF_JCAP * 8 + (LDSF_MAXB + 2) * 4;
+const int NB = 64;    // potrf / trsm step
+const int NBO = 256;  // outer panel: rows eliminated per trailing update of the HBM front
+const int kSyrkLds = 2 * 2 * SYRK_KC * SYRK_LDW * 8;
 
 }  // namespace
 
@@ -70,8 +134,14 @@ struct lmgpu_handle {
   Plan plan;
   std::vector<Bucket> buckets;
   bool finalized = false, have_values = false, linearized = false, solved = false;
-  std::vector<std::pair<int, int>> fac_of_graph;  // graph-index rank -> (bucket, idx) ; parallel to plan.factors
-  std::vector<int32_t> graph_index_sorted;
+  std::vector<int32_t> graph_index_sorted;  // parallel to plan.factors
+
+  // ---- ownership (multi-GPU).  Everything is "active" and "counted" when world_size == 1.
+  std::vector<int> front_owner;      // -1 = replicated on every rank
+  std::vector<char> front_active;    // this rank assembles / factors / back-substitutes the front
+  std::vector<int32_t> fac_local;    // plan.factors index -> local factor index (-1: not on this rank)
+  int nfac = 0;                      // local factors
+  int n_counted = 0;                 // local factors [0, n_counted) enter this rank's error sums (each factor counted on one rank)
 
   // ---- device state
   hipStream_t stream = nullptr;
@@ -96,15 +166,15 @@ struct lmgpu_handle {
   std::vector<int64_t> f_off;  // HBM fronts: pool offset of the dense front (else -1)
   std::vector<int> f_ld;
   std::vector<LevelWork> levels;
-  int nfac = 0, ntot = 0, nstore = 0;
+  int ntot = 0, nstore = 0;
   bool dampw_is_ones = false;
 
   // ---- LM
   lmgpu_lm_state lm{};
   lmgpu_timings tim{};
   hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  KTimer kt;
 
-  // ---- multi-GPU
   ncclComm_t comm = nullptr;
 };
 
@@ -130,6 +200,14 @@ int need_device(lmgpu_handle* h) {
   return LMGPU_OK;
 }
 
+int need_comm(lmgpu_handle* h) {
+  if (h->cfg.world_size > 1 && !h->comm) {
+    h->err = "world_size > 1 but lmgpu_comm_init has not been called";
+    return LMGPU_INVALID;
+  }
+  return LMGPU_OK;
+}
+
 ValuesDev values_dev(lmgpu_handle* h, int which) {
   ValuesDev v;
   for (int t = 0; t < 4; t++) v.v[t] = h->vals[which][t];
@@ -139,7 +217,7 @@ ValuesDev values_dev(lmgpu_handle* h, int which) {
 BucketDev bucket_dev(lmgpu_handle* h, const Bucket& b) {
   BucketDev d;
   d.type = b.type;
-  d.n = b.n;
+  d.n = b.n_loc;
   d.noise_kind = b.noise_kind;
   d.vidx = b.d_vidx;
   d.meas = b.d_meas;
@@ -154,16 +232,20 @@ template <bool JAC>
 void launch_factors(lmgpu_handle* h, int which) {
   const ValuesDev vals = values_dev(h, which);
   for (const Bucket& b : h->buckets) {
-    if (b.n == 0) continue;
+    if (b.n_loc == 0) continue;
     const BucketDev d = bucket_dev(h, b);
-    const int g256 = (b.n + 255) / 256, g128 = (b.n + 127) / 128;
+    const int g256 = (b.n_loc + 255) / 256, g128 = (b.n_loc + 127) / 128;
     hipStream_t s = h->stream;
     switch (b.type) {
       case LMGPU_F_SFM:
-        if (JAC)
+        if (JAC) {
+          // algorithmic bytes: 232 B per factor + each variable once (120 B camera, 24 B point)
+          const int kt = h->kt.begin(LMGPU_KT_LINEARIZE, s);
           hipLaunchKernelGGL(sfm_linearize_kernel, dim3(g256), dim3(256), 0, s, d, vals);
-        else
+          h->kt.end(kt, s, 232.0 * b.n_loc + 120.0 * h->plan.type_count[3] + 24.0 * h->plan.type_count[2]);
+        } else {
           hipLaunchKernelGGL(sfm_error_kernel, dim3(g256), dim3(256), 0, s, d, vals, h->ebuf0);
+        }
         break;
       case LMGPU_F_BETWEEN_POSE2:
         hipLaunchKernelGGL((generic_factor_kernel<1, 3, 3, 3, 3, 0, 3, 0, 3, JAC>), dim3(g128), dim3(128), 0, s, d, vals, h->ebuf0);
@@ -196,9 +278,17 @@ void reduce_to(lmgpu_handle* h, const double* buf, int n, double* dst) {
   hipLaunchKernelGGL(reduce_stage2, dim3(1), dim3(256), 0, h->stream, (const double*)h->partial, g, dst);
 }
 
+// sum `count` doubles at dscal+first over the ranks (each factor is counted on exactly one rank)
+int allreduce_scalars(lmgpu_handle* h, int first, int count) {
+  if (h->comm) NCCLCHECK(ncclAllReduce(h->dscal + first, h->dscal + first, count, ncclDouble, ncclSum, h->comm, h->stream));
+  return LMGPU_OK;
+}
+
 int compute_error(lmgpu_handle* h, int which, double* out) {
   launch_factors<false>(h, which);
-  reduce_to(h, h->ebuf0, h->nfac, h->dscal);
+  reduce_to(h, h->ebuf0, h->n_counted, h->dscal);
+  int rc = allreduce_scalars(h, 0, 1);
+  if (rc) return rc;
   HIPCHECK(hipMemcpyAsync(h->h_scal, h->dscal, sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(hipStreamSynchronize(h->stream));
   *out = h->h_scal[0];
@@ -209,6 +299,13 @@ int do_linearize(lmgpu_handle* h) {
   launch_factors<true>(h, h->cur);
   HIPCHECK(hipGetLastError());
   h->linearized = true;
+  return LMGPU_OK;
+}
+
+int launch_hessian_diag(lmgpu_handle* h) {
+  hipLaunchKernelGGL(hessian_diag_kernel, dim3((h->ntot + 255) / 256), dim3(256), 0, h->stream, h->ntot, h->d_scalar_var, h->d_scalar_col,
+                     h->d_vi_ptr, h->d_vi_fac, h->d_vi_pos, h->d_fd, (const double*)h->pool, h->hdiag);
+  if (h->comm) NCCLCHECK(ncclAllReduce(h->hdiag, h->hdiag, h->ntot, ncclDouble, ncclSum, h->comm, h->stream));
   return LMGPU_OK;
 }
 
@@ -223,8 +320,8 @@ int fill_dampw(lmgpu_handle* h, int diagonal, double min_diag, double max_diag) 
     return LMGPU_OK;
   }
   // hessianDiagonal, clamped (LevenbergMarquardtOptimizer.cpp:291-298: sqrt then squared by the prior = clamp(diag))
-  hipLaunchKernelGGL(hessian_diag_kernel, dim3((h->ntot + 255) / 256), dim3(256), 0, h->stream, h->ntot, h->d_scalar_var, h->d_scalar_col,
-                     h->d_vi_ptr, h->d_vi_fac, h->d_vi_pos, h->d_fd, (const double*)h->pool, h->hdiag);
+  int rc = launch_hessian_diag(h);
+  if (rc) return rc;
   std::vector<double> d(h->ntot);
   HIPCHECK(hipMemcpyAsync(d.data(), h->hdiag, d.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(hipStreamSynchronize(h->stream));
@@ -238,7 +335,7 @@ int fill_dampw(lmgpu_handle* h, int diagonal, double min_diag, double max_diag) 
   return LMGPU_OK;
 }
 
-// ---- numeric elimination of all fronts, level by level (a10-a13)
+// ---- numeric elimination of all (active) fronts, level by level (a10-a13)
 int do_eliminate(lmgpu_handle* h, double lambda) {
   hipStream_t s = h->stream;
   HIPCHECK(hipMemsetAsync(h->d_status, 0x7f, sizeof(int), s));
@@ -248,42 +345,59 @@ int do_eliminate(lmgpu_handle* h, double lambda) {
       if (cnt == 0) continue;
       const int nmax = kBinN[b];
       const int threads = (b == 0) ? 64 : (b == 1 ? 128 : 256);
-      hipLaunchKernelGGL(lds_front_kernel, dim3(cnt), dim3(threads), (size_t)nmax * nmax * sizeof(double), s,
+      const int kt = h->kt.begin(LMGPU_KT_LDS_FRONT, s);
+      hipLaunchKernelGGL(lds_front_kernel, dim3(cnt), dim3(threads), kLdsFrontExtra + (size_t)nmax * nmax * sizeof(double), s,
                          (const int32_t*)(h->d_lists + L.list_begin + L.bin_begin[b]), (const FrontDesc*)h->d_fronts,
                          (const FrontFac*)h->d_ffac, (const FacDesc*)h->d_fd, (const ChildRef*)h->d_childs, (const int32_t*)h->d_cmap,
-                         (const int32_t*)h->d_fxoff, h->pool, lambda, (const double*)h->dampw, h->d_status);
+                         (const int32_t*)h->d_fxoff, h->pool, lambda, (const double*)h->dampw, h->d_status, nmax);
+      h->kt.end(kt, s);
     }
     for (int fi : L.hbm) {
       const FrontDesc& F = h->h_fronts[fi];
       const int64_t off = h->f_off[fi];
       const int ld = h->f_ld[fi];
       double* A = h->pool + off;
+      const bool replicated = (F.pad & 1) != 0, own_terms = (F.pad & 2) == 0;
+      int kt = h->kt.begin(LMGPU_KT_HBM_ASSEMBLE, s);
       HIPCHECK(hipMemsetAsync(A, 0, (size_t)F.n * ld * sizeof(double), s));
-      if (F.fac_count > 0)
+      if (F.fac_count > 0 && own_terms)
         hipLaunchKernelGGL(hbm_assemble_factors_kernel, dim3(F.fac_count), dim3(64), 0, s, F, off, ld, (const FrontFac*)h->d_ffac,
                            (const FacDesc*)h->d_fd, h->pool);
       if (F.child_count > 0)
         hipLaunchKernelGGL(hbm_assemble_children_kernel, dim3(F.child_count), dim3(256), 0, s, F, off, ld, (const ChildRef*)h->d_childs,
                            (const int32_t*)h->d_cmap, h->pool);
-      hipLaunchKernelGGL(hbm_damp_kernel, dim3((F.nf + 255) / 256), dim3(256), 0, s, F, off, ld, (const int32_t*)h->d_fxoff, h->pool, lambda,
-                         (const double*)h->dampw);
-      if (h->comm && F.pad == 1) {
+      if (own_terms)
+        hipLaunchKernelGGL(hbm_damp_kernel, dim3((F.nf + 255) / 256), dim3(256), 0, s, F, off, ld, (const int32_t*)h->d_fxoff, h->pool, lambda,
+                           (const double*)h->dampw);
+      h->kt.end(kt, s);
+      if (h->comm && replicated) {
         // replicated top front: sum the ranks' partial assemblies (separator contributions) over xGMI
-        ncclResult_t r = ncclAllReduce(A, A, (size_t)F.n * ld, ncclDouble, ncclSum, h->comm, s);
-        if (r != ncclSuccess) {
-          h->err = std::string("ncclAllReduce: ") + ncclGetErrorString(r);
-          return LMGPU_HIP_ERROR;
-        }
+        kt = h->kt.begin(LMGPU_KT_ALLREDUCE, s);
+        NCCLCHECK(ncclAllReduce(A, A, (size_t)F.n * ld, ncclDouble, ncclSum, h->comm, s));
+        h->kt.end(kt, s, (double)F.n * ld * 8.0);
       }
-      for (int k0 = 0; k0 < F.nf; k0 += NB) {
-        const int nb = std::min(NB, F.nf - k0);
-        const int cols = F.n - k0 - nb;
-        const int g = std::max(1, (cols + 255) / 256);
-        hipLaunchKernelGGL((potrf_trsm_kernel<NB>), dim3(g), dim3(256), 0, s, A, ld, F.n, F.nf, k0, nb, F.id, h->d_status);
-        if (cols > 0) {
-          const int T = (cols + 127) / 128;
-          hipLaunchKernelGGL(syrk_mfma_kernel, dim3(T, T), dim3(256), 0, s, A, ld, F.n, k0, nb);
+      // two-level blocking: outer panels of NBO rows; inside, NB-row steps update only the rest of the outer panel
+      auto syrk = [&](int p0, int kp, int r0, int r1) {
+        if (r0 >= r1 || r0 >= F.n) return;
+        const int Tr = (r1 - r0 + 127) / 128, Tc = (F.n - r0 + 127) / 128;
+        const int kts = h->kt.begin(LMGPU_KT_SYRK, s);
+        hipLaunchKernelGGL(syrk_mfma_kernel, dim3(Tc, Tr), dim3(256), kSyrkLds, s, A, ld, F.n, p0, kp, r0, r1);
+        // algorithmic flop: 2 x kp x (upper-trapezoid entries of rows r0..r1-1, columns row..n-1)
+        const double rows = r1 - r0, first = F.n - r0;
+        h->kt.end(kts, s, 2.0 * kp * (rows * first - rows * (rows - 1.0) / 2.0));
+      };
+      for (int k0 = 0; k0 < F.nf; k0 += NBO) {
+        const int kend = std::min(F.nf, k0 + NBO);
+        for (int k = k0; k < kend; k += NB) {
+          const int nb = std::min(NB, kend - k);
+          const int cols = F.n - k - nb;
+          const int g = std::max(1, (cols + 255) / 256);
+          kt = h->kt.begin(LMGPU_KT_PANEL, s);
+          hipLaunchKernelGGL((potrf_trsm_kernel<NB>), dim3(g), dim3(256), 0, s, A, ld, F.n, F.nf, k, nb, F.id, h->d_status);
+          h->kt.end(kt, s, (double)nb * nb * nb / 3.0 + (double)nb * nb * cols);
+          syrk(k, nb, k + nb, kend);       // rest of the outer panel's rows
         }
+        syrk(k0, kend - k0, kend, F.n);    // everything below the outer panel, K = up to NBO
       }
     }
   }
@@ -294,12 +408,14 @@ int do_eliminate(lmgpu_handle* h, double lambda) {
 // ---- back-substitution, top-down (a14)
 int do_backsub(lmgpu_handle* h) {
   hipStream_t s = h->stream;
+  if (h->cfg.world_size > 1) HIPCHECK(hipMemsetAsync(h->delta, 0, h->ntot * sizeof(double), s));
   for (int li = (int)h->levels.size() - 1; li >= 0; li--) {
     const LevelWork& L = h->levels[li];
     for (int fi : L.hbm) {
       const FrontDesc& F = h->h_fronts[fi];
       const int64_t off = h->f_off[fi];
       const int ld = h->f_ld[fi];
+      const int kt = h->kt.begin(LMGPU_KT_BACKSUB_HBM, s);
       hipLaunchKernelGGL(hbm_rhs_init_kernel, dim3(F.nf), dim3(64), 0, s, F, off, ld, (const int32_t*)h->d_sxoff, (const double*)h->pool,
                          (const double*)h->delta, h->ywork);
       const int nblk = (F.nf + NB - 1) / NB;
@@ -309,11 +425,15 @@ int do_backsub(lmgpu_handle* h) {
         hipLaunchKernelGGL((hbm_backsolve_step_kernel<NB>), dim3(g), dim3(256), 0, s, F, off, ld, r0, nb, (const int32_t*)h->d_fxoff,
                            (const double*)h->pool, h->ywork, h->delta, h->d_status);
       }
+      h->kt.end(kt, s);
     }
-    if (L.list_count > 0)
+    if (L.list_count > 0) {
+      const int kt = h->kt.begin(LMGPU_KT_BACKSUB_LDS, s);
       hipLaunchKernelGGL(lds_backsub_kernel, dim3((L.list_count + 3) / 4), dim3(256), 0, s, (const int32_t*)(h->d_lists + L.list_begin),
                          L.list_count, (const FrontDesc*)h->d_fronts, (const int32_t*)h->d_fxoff, (const int32_t*)h->d_sxoff,
                          (const double*)h->pool, h->delta, h->d_status);
+      h->kt.end(kt, s);
+    }
   }
   HIPCHECK(hipGetLastError());
   return LMGPU_OK;
@@ -322,21 +442,28 @@ int do_backsub(lmgpu_handle* h) {
 // solve the damped system; returns LMGPU_OK / LMGPU_INDETERMINATE.  lin errors into h_scal[1], h_scal[2].
 int do_solve(lmgpu_handle* h, double lambda) {
   hipStream_t s = h->stream;
-  hipEventRecord(h->ev[1], s);
+  (void)hipEventRecord(h->ev[1], s);
   int rc = do_eliminate(h, lambda);
   if (rc) return rc;
-  hipEventRecord(h->ev[2], s);
+  (void)hipEventRecord(h->ev[2], s);
   rc = do_backsub(h);
   if (rc) return rc;
-  hipEventRecord(h->ev[3], s);
-  hipLaunchKernelGGL(linear_error_kernel, dim3((h->nfac + 255) / 256), dim3(256), 0, s, (const FacDesc*)h->d_fd, h->nfac,
-                     (const double*)h->pool, (const double*)h->delta, h->ebuf0, h->ebuf1);
-  reduce_to(h, h->ebuf0, h->nfac, h->dscal + 1);
-  reduce_to(h, h->ebuf1, h->nfac, h->dscal + 2);
-  hipEventRecord(h->ev[4], s);
+  (void)hipEventRecord(h->ev[3], s);
+  const int kt = h->kt.begin(LMGPU_KT_LINEAR_ERROR, s);
+  if (h->nfac > 0)
+    hipLaunchKernelGGL(linear_error_kernel, dim3((h->nfac + 255) / 256), dim3(256), 0, s, (const FacDesc*)h->d_fd, h->nfac,
+                       (const double*)h->pool, (const double*)h->delta, h->ebuf0, h->ebuf1);
+  reduce_to(h, h->ebuf0, h->n_counted, h->dscal + 1);
+  reduce_to(h, h->ebuf1, h->n_counted, h->dscal + 2);
+  h->kt.end(kt, s);
+  rc = allreduce_scalars(h, 1, 2);
+  if (rc) return rc;
+  if (h->comm) NCCLCHECK(ncclAllReduce(h->d_status, h->d_status, 1, ncclInt, ncclMin, h->comm, s));
+  (void)hipEventRecord(h->ev[4], s);
   HIPCHECK(hipMemcpyAsync(h->h_scal + 1, h->dscal + 1, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHECK(hipMemcpyAsync(h->h_status, h->d_status, sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHECK(hipStreamSynchronize(s));
+  h->kt.resolve();
   h->solved = true;
   if (*h->h_status < (int)h->h_fronts.size()) {
     const Front& fr = h->plan.fronts[*h->h_status];
@@ -372,20 +499,27 @@ int try_lambda(lmgpu_handle* h, const lmgpu_lm_params* p, bool* done) {
   bool step_is_successful = false, stopSearchingLambda = false;
   double newError = std::numeric_limits<double>::infinity(), costChange = 0.0;
   int rc = do_solve(h, st.lambda);
-  if (rc == LMGPU_HIP_ERROR) return rc;
+  if (rc != LMGPU_OK && rc != LMGPU_INDETERMINATE) return rc;
   const bool solved = (rc == LMGPU_OK);
   bool retracted = false;
   if (solved) {
     const double oldLin = h->h_scal[1], newLin = h->h_scal[2];
     const double linearizedCostChange = oldLin - newLin;
     if (linearizedCostChange >= 0) {
-      hipEventRecord(h->ev[5], h->stream);
+      (void)hipEventRecord(h->ev[5], h->stream);
+      const int kt = h->kt.begin(LMGPU_KT_RETRACT_ERROR, h->stream);
       rc = do_retract(h, h->cur, h->cur ^ 1);
       if (rc) return rc;
-      rc = compute_error(h, h->cur ^ 1, &newError);
+      launch_factors<false>(h, h->cur ^ 1);
+      reduce_to(h, h->ebuf0, h->n_counted, h->dscal);
+      h->kt.end(kt, h->stream);
+      rc = allreduce_scalars(h, 0, 1);
       if (rc) return rc;
-      hipEventRecord(h->ev[6], h->stream);
-      hipEventSynchronize(h->ev[6]);
+      (void)hipEventRecord(h->ev[6], h->stream);
+      HIPCHECK(hipMemcpyAsync(h->h_scal, h->dscal, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      HIPCHECK(hipStreamSynchronize(h->stream));
+      h->kt.resolve();
+      newError = h->h_scal[0];
       retracted = true;
       costChange = st.error - newError;
       if (linearizedCostChange > std::numeric_limits<double>::epsilon() * oldLin) {
@@ -430,10 +564,10 @@ int try_lambda(lmgpu_handle* h, const lmgpu_lm_params* p, bool* done) {
 
 int lm_iterate(lmgpu_handle* h, const lmgpu_lm_params* p) {
   std::memset(&h->tim, 0, sizeof(h->tim));
-  hipEventRecord(h->ev[0], h->stream);
+  (void)hipEventRecord(h->ev[0], h->stream);
   int rc = do_linearize(h);
   if (rc) return rc;
-  hipEventRecord(h->ev[7], h->stream);
+  (void)hipEventRecord(h->ev[7], h->stream);
   rc = fill_dampw(h, p->diagonalDamping, p->minDiagonal, p->maxDiagonal);
   if (rc) return rc;
   bool done = false;
@@ -441,7 +575,7 @@ int lm_iterate(lmgpu_handle* h, const lmgpu_lm_params* p) {
     rc = try_lambda(h, p, &done);
     if (rc) return rc;
   }
-  hipStreamSynchronize(h->stream);
+  HIPCHECK(hipStreamSynchronize(h->stream));
   float ms = 0;
   if (hipEventElapsedTime(&ms, h->ev[0], h->ev[7]) == hipSuccess) h->tim.linearize_ms = ms;
   h->tim.total_ms = h->tim.linearize_ms + h->tim.eliminate_ms + h->tim.backsub_ms + h->tim.linear_error_ms + h->tim.retract_error_ms;
@@ -456,6 +590,45 @@ bool check_convergence(double relTol, double absTol, double errTol, double curre
   return (relTol && (relativeDecrease <= relTol)) || (absoluteDecrease <= absTol);
 }
 
+// Deal the subtrees below the replicated top fronts to the ranks.  A front is replicated iff it is an HBM front
+// whose ancestors are all replicated (for BAL: the camera root); with no such front every rank does everything.
+void assign_owners(lmgpu_handle* h) {
+  const Plan& P = h->plan;
+  const int NF = (int)P.fronts.size(), W = std::max(1, h->cfg.world_size), R = h->cfg.rank;
+  h->front_owner.assign(NF, -1);
+  h->front_active.assign(NF, 1);
+  if (W == 1) return;
+  std::vector<char> rep(NF, 0);
+  bool any = false;
+  for (int fi = NF - 1; fi >= 0; fi--) {
+    const Front& fr = P.fronts[fi];
+    rep[fi] = (fr.cls == 1) && (fr.parent < 0 || rep[fr.parent]);
+    any = any || rep[fi];
+  }
+  if (!any) return;  // nothing to shard: replicate the whole (small) tree
+  // weights: factors below each subtree root (post-order: children come first)
+  std::vector<double> wsub(NF, 0.0);
+  for (int fi = 0; fi < NF; fi++) {
+    wsub[fi] += (double)P.fronts[fi].factors.size() + 1.0;
+    if (P.fronts[fi].parent >= 0) wsub[P.fronts[fi].parent] += wsub[fi];
+  }
+  double total = 0;
+  for (int fi = 0; fi < NF; fi++)
+    if (!rep[fi] && (P.fronts[fi].parent < 0 || rep[P.fronts[fi].parent])) total += wsub[fi];
+  double cum = 0;
+  for (int fi = NF - 1; fi >= 0; fi--) {  // parents before children
+    const Front& fr = P.fronts[fi];
+    if (rep[fi]) continue;
+    if (fr.parent < 0 || rep[fr.parent]) {
+      h->front_owner[fi] = std::min(W - 1, (int)(cum / total * W));
+      cum += wsub[fi];
+    } else {
+      h->front_owner[fi] = h->front_owner[fr.parent];
+    }
+  }
+  for (int fi = 0; fi < NF; fi++) h->front_active[fi] = rep[fi] || h->front_owner[fi] == R;
+}
+
 }  // namespace
 
 // =============================================================================================== C ABI
@@ -465,6 +638,7 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
   if (!cfg || !out) return LMGPU_INVALID;
   lmgpu_handle* h = new lmgpu_handle();
   h->cfg = *cfg;
+  if (h->cfg.world_size < 1) h->cfg.world_size = 1;
   h->device = cfg->device;
   *out = h;
   if (h->device >= 0) {
@@ -473,7 +647,8 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
     for (int i = 0; i < 8; i++) HIPCHECK(hipEventCreate(&h->ev[i]));
     HIPCHECK(hipHostMalloc((void**)&h->h_scal, 8 * sizeof(double), hipHostMallocDefault));
     HIPCHECK(hipHostMalloc((void**)&h->h_status, sizeof(int), hipHostMallocDefault));
-    HIPCHECK(hipFuncSetAttribute((const void*)lds_front_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8));
+    HIPCHECK(hipFuncSetAttribute((const void*)lds_front_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra));
+    HIPCHECK(hipFuncSetAttribute((const void*)syrk_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSyrkLds));
   }
   return LMGPU_OK;
 }
@@ -481,11 +656,11 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
 int lmgpu_destroy(lmgpu_handle* h) {
   if (!h) return LMGPU_INVALID;
   if (h->device >= 0) {
-    hipSetDevice(h->device);
-    if (h->stream) hipStreamSynchronize(h->stream);
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm) ncclCommDestroy(h->comm);
     auto fr = [](void* p) {
-      if (p) hipFree(p);
+      if (p) (void)hipFree(p);
     };
     fr(h->pool);
     for (int w = 0; w < 2; w++)
@@ -497,11 +672,12 @@ int lmgpu_destroy(lmgpu_handle* h) {
     for (Bucket& b : h->buckets) {
       fr(b.d_vidx); fr(b.d_meas); fr(b.d_noise); fr(b.d_epos);
     }
-    if (h->h_scal) hipHostFree(h->h_scal);
-    if (h->h_status) hipHostFree(h->h_status);
+    if (h->h_scal) (void)hipHostFree(h->h_scal);
+    if (h->h_status) (void)hipHostFree(h->h_status);
     for (int i = 0; i < 8; i++)
-      if (h->ev[i]) hipEventDestroy(h->ev[i]);
-    if (h->stream) hipStreamDestroy(h->stream);
+      if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    for (hipEvent_t e : h->kt.pool) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
   }
   delete h;
   return LMGPU_OK;
@@ -578,43 +754,73 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
     return LMGPU_INVALID;
   }
   Plan& P = h->plan;
-  h->nfac = (int)P.factors.size();
+  const int NFAC = (int)P.factors.size();
   h->ntot = P.xoff[P.n_vars];
   h->nstore = P.voff[P.n_vars];
-  for (int i = 1; i < h->nfac; i++)
+  for (int i = 1; i < NFAC; i++)
     if (P.factors[i].graph_index == P.factors[i - 1].graph_index) {
       h->err = "duplicate graph_index";
       return LMGPU_INVALID;
     }
-  h->fac_of_graph.resize(h->nfac);
-  h->graph_index_sorted.resize(h->nfac);
-  for (int i = 0; i < h->nfac; i++) {
-    h->fac_of_graph[i] = {P.factors[i].bucket, P.factors[i].idx};
-    h->graph_index_sorted[i] = P.factors[i].graph_index;
+  h->graph_index_sorted.resize(NFAC);
+  for (int i = 0; i < NFAC; i++) h->graph_index_sorted[i] = P.factors[i].graph_index;
+
+  // ---- ownership: which fronts / factors live on this rank
+  assign_owners(h);
+  const int NF = (int)P.fronts.size(), R = h->cfg.rank;
+  std::vector<char> fac_active(NFAC, 0), fac_counted(NFAC, 0);
+  for (int fi = 0; fi < NF; fi++) {
+    if (!h->front_active[fi]) continue;
+    const bool counted = (h->front_owner[fi] == R) || (h->front_owner[fi] < 0 && R == 0);
+    for (int32_t f : P.fronts[fi].factors) {
+      fac_active[f] = 1;
+      fac_counted[f] = counted;
+    }
   }
+  h->fac_local.assign(NFAC, -1);
+  int nloc = 0;
+  for (int i = 0; i < NFAC; i++)
+    if (fac_active[i] && fac_counted[i]) h->fac_local[i] = nloc++;
+  h->n_counted = nloc;
+  for (int i = 0; i < NFAC; i++)
+    if (fac_active[i] && !fac_counted[i]) h->fac_local[i] = nloc++;
+  h->nfac = nloc;
+  for (Bucket& b : h->buckets) {
+    b.loc_of.assign(b.n, -1);
+    b.n_loc = 0;
+  }
+  for (int i = 0; i < NFAC; i++)  // factors are sorted by graph index; bucket-local order follows it
+    if (fac_active[i]) {
+      Bucket& b = h->buckets[P.factors[i].bucket];
+      b.loc_of[P.factors[i].idx] = 0;  // mark
+    }
+  for (Bucket& b : h->buckets)
+    for (int i = 0; i < b.n; i++)
+      if (b.loc_of[i] == 0) b.loc_of[i] = b.n_loc++;
+
   // ---- pool layout: Jacobians | [R S d] + updates of LDS fronts | dense HBM fronts
   int64_t off = 0;
   for (Bucket& b : h->buckets) {
     b.joff = off;
-    off += (int64_t)b.n * b.rows * b.cols;
+    off += (int64_t)b.n_loc * b.rows * b.cols;
     off = (off + 15) & ~int64_t(15);
   }
-  const int NF = (int)P.fronts.size();
   h->h_fronts.assign(NF, FrontDesc{});
   h->f_off.assign(NF, -1);
   h->f_ld.assign(NF, 0);
   std::vector<FacDesc> fd(h->nfac);
-  for (int i = 0; i < h->nfac; i++) {
+  for (int i = 0; i < NFAC; i++) {
+    if (h->fac_local[i] < 0) continue;
     const FactorRef& f = P.factors[i];
     const Bucket& b = h->buckets[f.bucket];
     FacDesc d{};
-    d.joff = b.joff + (int64_t)f.idx * b.rows * b.cols;
+    d.joff = b.joff + (int64_t)b.loc_of[f.idx] * b.rows * b.cols;
     d.rows = (int16_t)b.rows;
     d.d0 = (int16_t)P.dims[f.slots[0]];
     d.d1 = (int16_t)(f.slots[1] >= 0 ? P.dims[f.slots[1]] : 0);
     d.x0 = P.xoff[f.slots[0]];
     d.x1 = f.slots[1] >= 0 ? P.xoff[f.slots[1]] : -1;
-    fd[i] = d;
+    fd[h->fac_local[i]] = d;
   }
   std::vector<FrontFac> ffac;
   std::vector<ChildRef> childs;
@@ -627,6 +833,8 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
     F.nf = fr.nf;
     F.id = fi;
     F.pad = 0;
+    if (!h->front_active[fi]) continue;
+    if (h->cfg.world_size > 1 && h->front_owner[fi] < 0 && fr.cls == 1) F.pad = (R == 0) ? 1 : 3;  // replicated; own terms on rank 0 only
     if (fr.cls == 0) {
       F.ld_rsd = fr.n;
       F.rsd_off = off;
@@ -648,18 +856,18 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
     for (size_t k = 0; k < fr.vars.size(); k++) colof[fr.vars[k]] = fr.col_off[k];
     // factors
     F.fac_begin = (int)ffac.size();
-    F.fac_count = (int)fr.factors.size();
     for (int32_t f : fr.factors) {
       FrontFac ff;
-      ff.fac = f;
+      ff.fac = h->fac_local[f];
       ff.c0 = colof[P.factors[f].slots[0]];
       ff.c1 = P.factors[f].slots[1] >= 0 ? colof[P.factors[f].slots[1]] : 0;
       ffac.push_back(ff);
     }
-    // children: map child's separator scalars (+ rhs) to this front's columns
+    F.fac_count = (int)ffac.size() - F.fac_begin;
+    // children present on this rank: map child's separator scalars (+ rhs) to this front's columns
     F.child_begin = (int)childs.size();
-    F.child_count = (int)fr.children.size();
     for (int32_t c : fr.children) {
+      if (!h->front_active[c]) continue;
       const Front& ch = P.fronts[c];
       const FrontDesc& CF = h->h_fronts[c];
       ChildRef cr{};
@@ -672,6 +880,7 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
       cmap.push_back(fr.n - 1);
       childs.push_back(cr);
     }
+    F.child_count = (int)childs.size() - F.child_begin;
     F.fx_begin = (int)fxoff.size();
     for (int k = 0; k < fr.n_frontal_vars; k++)
       for (int d = 0; d < P.dims[fr.vars[k]]; d++) fxoff.push_back(P.xoff[fr.vars[k]] + d);
@@ -679,11 +888,12 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
     for (size_t k = fr.n_frontal_vars; k < fr.vars.size(); k++)
       for (int d = 0; d < P.dims[fr.vars[k]]; d++) sxoff.push_back(P.xoff[fr.vars[k]] + d);
   }
-  h->pool_doubles = (size_t)off + 16;
-  // ---- level work lists
+  h->pool_doubles = (size_t)off + 1024;  // slack: the syrk operand DMA may read up to 127 columns past a row end
+  // ---- level work lists (active fronts only)
   h->levels.assign(P.n_levels, LevelWork());
   std::vector<std::vector<std::vector<int>>> byLevelBin(P.n_levels, std::vector<std::vector<int>>(kNumBins));
   for (int fi = 0; fi < NF; fi++) {
+    if (!h->front_active[fi]) continue;
     const Front& fr = P.fronts[fi];
     if (fr.cls == 1) {
       h->levels[fr.level].hbm.push_back(fi);
@@ -721,24 +931,30 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
   if ((rc = upload(h, &h->d_fxoff, fxoff))) return rc;
   if ((rc = upload(h, &h->d_sxoff, sxoff))) return rc;
   if ((rc = upload(h, &h->d_lists, lists))) return rc;
-  // per-bucket arrays
-  std::vector<int32_t> rank_of(h->nfac);
-  for (Bucket& b : h->buckets) {
-    const int ar = kFactorArity[b.type];
-    std::vector<int32_t> vidx((size_t)b.n * ar);
-    for (size_t i = 0; i < vidx.size(); i++) vidx[i] = P.tidx[b.slots[i]];
-    if ((rc = upload(h, &b.d_vidx, vidx))) return rc;
-    if ((rc = upload(h, &b.d_meas, b.meas))) return rc;
-    if (!b.noise.empty()) {
-      if ((rc = upload(h, &b.d_noise, b.noise))) return rc;
-    }
-  }
+  // per-bucket arrays, compacted to this rank's factors
   {
     std::vector<std::vector<int32_t>> epos(h->buckets.size());
-    for (size_t bi = 0; bi < h->buckets.size(); bi++) epos[bi].resize(h->buckets[bi].n);
-    for (int i = 0; i < h->nfac; i++) epos[P.factors[i].bucket][P.factors[i].idx] = i;
-    for (size_t bi = 0; bi < h->buckets.size(); bi++)
-      if ((rc = upload(h, &h->buckets[bi].d_epos, epos[bi]))) return rc;
+    for (size_t bi = 0; bi < h->buckets.size(); bi++) epos[bi].resize(h->buckets[bi].n_loc);
+    for (int i = 0; i < NFAC; i++)
+      if (h->fac_local[i] >= 0) epos[P.factors[i].bucket][h->buckets[P.factors[i].bucket].loc_of[P.factors[i].idx]] = h->fac_local[i];
+    for (size_t bi = 0; bi < h->buckets.size(); bi++) {
+      Bucket& b = h->buckets[bi];
+      const int ar = kFactorArity[b.type], ml = kFactorMeas[b.type];
+      const int nl = b.noise_kind == LMGPU_N_DIAG ? b.rows : (b.noise_kind == LMGPU_N_GAUSS ? b.rows * b.rows : 0);
+      std::vector<int32_t> vidx((size_t)b.n_loc * ar);
+      std::vector<double> meas((size_t)b.n_loc * ml), noise((size_t)b.n_loc * nl);
+      for (int i = 0; i < b.n; i++) {
+        const int l = b.loc_of[i];
+        if (l < 0) continue;
+        for (int k = 0; k < ar; k++) vidx[(size_t)l * ar + k] = P.tidx[b.slots[(size_t)i * ar + k]];
+        std::memcpy(&meas[(size_t)l * ml], &b.meas[(size_t)i * ml], ml * sizeof(double));
+        if (nl) std::memcpy(&noise[(size_t)l * nl], &b.noise[(size_t)i * nl], nl * sizeof(double));
+      }
+      if ((rc = upload(h, &b.d_vidx, vidx))) return rc;
+      if ((rc = upload(h, &b.d_meas, meas))) return rc;
+      if (nl && (rc = upload(h, &b.d_noise, noise))) return rc;
+      if ((rc = upload(h, &b.d_epos, epos[bi]))) return rc;
+    }
   }
   // values, per type
   for (int t = 0; t < 4; t++) {
@@ -750,7 +966,7 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
       if (P.types[s] == t) xo[P.tidx[s]] = P.xoff[s];
     if ((rc = upload(h, &h->type_xoff[t], xo))) return rc;
   }
-  // hessian-diagonal CSR
+  // hessian-diagonal CSR over the factors COUNTED on this rank (summed over ranks by all-reduce)
   {
     std::vector<int32_t> scalar_var(h->ntot), scalar_col(h->ntot), vi_ptr(P.n_vars + 1, 0), vi_fac;
     std::vector<int8_t> vi_pos;
@@ -760,9 +976,11 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
         scalar_col[P.xoff[s] + d] = d;
       }
     std::vector<std::vector<std::pair<int32_t, int8_t>>> vi(P.n_vars);
-    for (int i = 0; i < h->nfac; i++) {
-      vi[P.factors[i].slots[0]].push_back({i, 0});
-      if (P.factors[i].slots[1] >= 0) vi[P.factors[i].slots[1]].push_back({i, 1});
+    for (int i = 0; i < NFAC; i++) {
+      const int l = h->fac_local[i];
+      if (l < 0 || l >= h->n_counted) continue;
+      vi[P.factors[i].slots[0]].push_back({l, 0});
+      if (P.factors[i].slots[1] >= 0) vi[P.factors[i].slots[1]].push_back({l, 1});
     }
     for (int s = 0; s < P.n_vars; s++) {
       vi_ptr[s] = (int32_t)vi_fac.size();
@@ -831,6 +1049,7 @@ int lmgpu_error(lmgpu_handle* h, double* total) {
   if (!h || !h->finalized || !total || !h->have_values) return LMGPU_INVALID;
   int rc = need_device(h);
   if (rc) return rc;
+  if ((rc = need_comm(h))) return rc;
   return compute_error(h, h->cur, total);
 }
 
@@ -841,6 +1060,7 @@ int lmgpu_linearize(lmgpu_handle* h) {
   rc = do_linearize(h);
   if (rc) return rc;
   HIPCHECK(hipStreamSynchronize(h->stream));
+  h->kt.resolve();
   return LMGPU_OK;
 }
 
@@ -849,10 +1069,11 @@ int lmgpu_solve(lmgpu_handle* h, double lambda, int32_t diagonal_damping, double
   if (!h || !h->finalized || !h->linearized) return LMGPU_INVALID;
   int rc = need_device(h);
   if (rc) return rc;
+  if ((rc = need_comm(h))) return rc;
   rc = fill_dampw(h, diagonal_damping, min_diag, max_diag);
   if (rc) return rc;
   rc = do_solve(h, lambda);
-  if (rc == LMGPU_HIP_ERROR) return rc;
+  if (rc != LMGPU_OK && rc != LMGPU_INDETERMINATE) return rc;
   if (delta_packed) HIPCHECK(hipMemcpy(delta_packed, h->delta, h->ntot * sizeof(double), hipMemcpyDeviceToHost));
   if (lin_err0) *lin_err0 = h->h_scal[1];
   if (lin_err1) *lin_err1 = h->h_scal[2];
@@ -876,8 +1097,8 @@ int lmgpu_hessian_diagonal(lmgpu_handle* h, double* diag) {
   if (!h || !h->finalized || !h->linearized || !diag) return LMGPU_INVALID;
   int rc = need_device(h);
   if (rc) return rc;
-  hipLaunchKernelGGL(hessian_diag_kernel, dim3((h->ntot + 255) / 256), dim3(256), 0, h->stream, h->ntot, h->d_scalar_var, h->d_scalar_col,
-                     h->d_vi_ptr, h->d_vi_fac, h->d_vi_pos, h->d_fd, (const double*)h->pool, h->hdiag);
+  if ((rc = need_comm(h))) return rc;
+  if ((rc = launch_hessian_diag(h))) return rc;
   HIPCHECK(hipMemcpyAsync(diag, h->hdiag, h->ntot * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(hipStreamSynchronize(h->stream));
   return LMGPU_OK;
@@ -887,6 +1108,7 @@ int lmgpu_lm_init(lmgpu_handle* h, const lmgpu_lm_params* p, lmgpu_lm_state* out
   if (!h || !p || !h->finalized || !h->have_values) return LMGPU_INVALID;
   int rc = need_device(h);
   if (rc) return rc;
+  if ((rc = need_comm(h))) return rc;
   // LevenbergMarquardtOptimizer ctor (LevenbergMarquardtOptimizer.cpp:47-63): state(values, graph.error(values), lambdaInitial, lambdaFactor)
   double e = 0;
   rc = compute_error(h, h->cur, &e);
@@ -904,6 +1126,7 @@ int lmgpu_iterate(lmgpu_handle* h, const lmgpu_lm_params* p, lmgpu_lm_state* ino
   if (!h || !p || !h->finalized || !h->have_values) return LMGPU_INVALID;
   int rc = need_device(h);
   if (rc) return rc;
+  if ((rc = need_comm(h))) return rc;
   if (inout) {
     h->lm.lambda = inout->lambda;
     h->lm.currentFactor = inout->currentFactor;
@@ -917,6 +1140,7 @@ int lmgpu_optimize(lmgpu_handle* h, const lmgpu_lm_params* p, lmgpu_lm_state* in
   if (!h || !p || !h->finalized || !h->have_values) return LMGPU_INVALID;
   int rc = need_device(h);
   if (rc) return rc;
+  if ((rc = need_comm(h))) return rc;
   // NonlinearOptimizer::defaultOptimize (gtsam/nonlinear/NonlinearOptimizer.cpp:62-117)
   double currentError = h->lm.error;
   if (currentError <= p->errorTol || h->lm.iterations >= p->maxIterations) {
@@ -941,34 +1165,54 @@ int lmgpu_get_timings(const lmgpu_handle* h, lmgpu_timings* out) {
   return LMGPU_OK;
 }
 
+int lmgpu_set_kernel_timing(lmgpu_handle* h, int32_t on) {
+  if (!h) return LMGPU_INVALID;
+  h->kt.on = on != 0;
+  h->kt.reset();
+  return LMGPU_OK;
+}
+
+int lmgpu_get_kernel_times(const lmgpu_handle* h, double* ms, double* work, int64_t* launches) {
+  if (!h) return LMGPU_INVALID;
+  for (int i = 0; i < LMGPU_KT_NUM; i++) {
+    if (ms) ms[i] = h->kt.ms[i];
+    if (work) work[i] = h->kt.work[i];
+    if (launches) launches[i] = h->kt.cnt[i];
+  }
+  return LMGPU_OK;
+}
+
 int lmgpu_get_jacobian(lmgpu_handle* h, int32_t graph_index, double* out, int32_t* rows, int32_t* cols) {
   if (!h || !h->finalized) return LMGPU_INVALID;
   auto it = std::lower_bound(h->graph_index_sorted.begin(), h->graph_index_sorted.end(), graph_index);
   if (it == h->graph_index_sorted.end() || *it != graph_index) return LMGPU_INVALID;
-  const auto [bi, idx] = h->fac_of_graph[it - h->graph_index_sorted.begin()];
-  const Bucket& b = h->buckets[bi];
+  const FactorRef& f = h->plan.factors[it - h->graph_index_sorted.begin()];
+  const Bucket& b = h->buckets[f.bucket];
   if (rows) *rows = b.rows;
   if (cols) *cols = b.cols;
   if (out) {
     int rc = need_device(h);
     if (rc) return rc;
-    if (!h->linearized) return LMGPU_INVALID;
-    HIPCHECK(hipMemcpy(out, h->pool + b.joff + (int64_t)idx * b.rows * b.cols, (size_t)b.rows * b.cols * sizeof(double), hipMemcpyDeviceToHost));
+    if (!h->linearized || b.loc_of[f.idx] < 0) return LMGPU_INVALID;  // not linearized, or the factor lives on another rank
+    HIPCHECK(hipMemcpy(out, h->pool + b.joff + (int64_t)b.loc_of[f.idx] * b.rows * b.cols, (size_t)b.rows * b.cols * sizeof(double),
+                       hipMemcpyDeviceToHost));
   }
   return LMGPU_OK;
 }
 
 int lmgpu_num_fronts(const lmgpu_handle* h) { return (h && h->finalized) ? (int)h->plan.fronts.size() : -1; }
 
-int lmgpu_front_info(const lmgpu_handle* h, int32_t front, int32_t* info6) {
-  if (!h || !h->finalized || front < 0 || front >= (int)h->plan.fronts.size() || !info6) return LMGPU_INVALID;
+int lmgpu_front_info(const lmgpu_handle* h, int32_t front, int32_t* info) {
+  if (!h || !h->finalized || front < 0 || front >= (int)h->plan.fronts.size() || !info) return LMGPU_INVALID;
   const Front& fr = h->plan.fronts[front];
-  info6[0] = (int)fr.vars.size();
-  info6[1] = fr.n_frontal_vars;
-  info6[2] = fr.nf;
-  info6[3] = fr.n;
-  info6[4] = fr.parent;
-  info6[5] = fr.cls;
+  info[0] = (int)fr.vars.size();
+  info[1] = fr.n_frontal_vars;
+  info[2] = fr.nf;
+  info[3] = fr.n;
+  info[4] = fr.parent;
+  info[5] = fr.cls;
+  info[6] = h->front_owner[front];
+  info[7] = fr.level;
   return LMGPU_OK;
 }
 
@@ -979,7 +1223,7 @@ int lmgpu_get_front(lmgpu_handle* h, int32_t front, int32_t* slots, double* RSd)
   if (RSd) {
     int rc = need_device(h);
     if (rc) return rc;
-    if (!h->solved) return LMGPU_INVALID;
+    if (!h->solved || !h->front_active[front]) return LMGPU_INVALID;
     const FrontDesc& F = h->h_fronts[front];
     std::vector<double> rows((size_t)F.nf * F.ld_rsd);
     HIPCHECK(hipMemcpy(rows.data(), h->pool + F.rsd_off, rows.size() * sizeof(double), hipMemcpyDeviceToHost));
@@ -1004,11 +1248,7 @@ int lmgpu_comm_init(lmgpu_handle* h, const char id128[128]) {
   ncclUniqueId id;
   std::memcpy(&id, id128, 128);
   HIPCHECK(hipSetDevice(h->device));
-  ncclResult_t r = ncclCommInitRank(&h->comm, h->cfg.world_size, id, h->cfg.rank);
-  if (r != ncclSuccess) {
-    h->err = std::string("ncclCommInitRank: ") + ncclGetErrorString(r);
-    return LMGPU_HIP_ERROR;
-  }
+  NCCLCHECK(ncclCommInitRank(&h->comm, h->cfg.world_size, id, h->cfg.rank));
   return LMGPU_OK;
 }
 
@@ -1036,20 +1276,20 @@ int lmgpu_peak_mfma_f64(int32_t device, int32_t iters, double* tflops) {
   double* out = nullptr;
   if (hipMalloc((void**)&out, (size_t)blocks * 256 * sizeof(double)) != hipSuccess) return LMGPU_HIP_ERROR;
   hipEvent_t e0, e1;
-  hipEventCreate(&e0);
-  hipEventCreate(&e1);
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
   hipLaunchKernelGGL(peak_mfma_f64_kernel, dim3(blocks), dim3(256), 0, 0, out, 16);
-  hipEventRecord(e0, 0);
+  (void)hipEventRecord(e0, 0);
   hipLaunchKernelGGL(peak_mfma_f64_kernel, dim3(blocks), dim3(256), 0, 0, out, iters);
-  hipEventRecord(e1, 0);
-  hipEventSynchronize(e1);
+  (void)hipEventRecord(e1, 0);
+  (void)hipEventSynchronize(e1);
   float ms = 0;
-  hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventElapsedTime(&ms, e0, e1);
   const double flops = (double)blocks * 4 /*waves*/ * (double)iters * 4 * 2048.0;
   *tflops = flops / (ms * 1e-3) / 1e12;
-  hipFree(out);
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
+  (void)hipFree(out);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   return LMGPU_OK;
 }
 
@@ -1057,23 +1297,23 @@ int lmgpu_peak_hbm_copy(int32_t device, int64_t bytes, int32_t iters, double* gb
   if (hipSetDevice(device) != hipSuccess) return LMGPU_HIP_ERROR;
   float4 *a = nullptr, *b = nullptr;
   if (hipMalloc((void**)&a, bytes) != hipSuccess || hipMalloc((void**)&b, bytes) != hipSuccess) return LMGPU_HIP_ERROR;
-  hipMemset(a, 1, bytes);
+  (void)hipMemset(a, 1, bytes);
   hipEvent_t e0, e1;
-  hipEventCreate(&e0);
-  hipEventCreate(&e1);
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
   const size_t n = bytes / 16;
   hipLaunchKernelGGL(peak_copy_kernel, dim3(2048), dim3(256), 0, 0, a, b, n);
-  hipEventRecord(e0, 0);
+  (void)hipEventRecord(e0, 0);
   for (int i = 0; i < iters; i++) hipLaunchKernelGGL(peak_copy_kernel, dim3(2048), dim3(256), 0, 0, a, b, n);
-  hipEventRecord(e1, 0);
-  hipEventSynchronize(e1);
+  (void)hipEventRecord(e1, 0);
+  (void)hipEventSynchronize(e1);
   float ms = 0;
-  hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventElapsedTime(&ms, e0, e1);
   *gbps = 2.0 * (double)bytes * iters / (ms * 1e-3) / 1e9;
-  hipFree(a);
-  hipFree(b);
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
+  (void)hipFree(a);
+  (void)hipFree(b);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   return LMGPU_OK;
 }
 

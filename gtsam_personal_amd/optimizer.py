@@ -83,7 +83,7 @@ class LevenbergMarquardtOptimizer:
     `device=-1` builds a structure-only handle (symbolic analysis, no compute)."""
 
     def __init__(self, graph: NonlinearFactorGraph, initialValues: Values, ordering=None, params: LevenbergMarquardtParams | None = None,
-                 device: int = 0, rank: int = 0, world_size: int = 1):
+                 device: int = 0, rank: int = 0, world_size: int = 1, comm_id: bytes | None = None):
         self.params = params or LevenbergMarquardtParams()
         ordering = ordering if ordering is not None else self.params.ordering
         if ordering is None:
@@ -102,13 +102,19 @@ class LevenbergMarquardtOptimizer:
         self._types = np.array([initialValues.type(k) for k in self.ordering], dtype=np.int32)
         self._check(self.lib.lmgpu_set_variables(self._h, len(self.ordering), self._keys.ctypes.data_as(ct.POINTER(ct.c_uint64)), _ip(self._types)))
         self._template = initialValues.copy()
+        order_sorted = np.argsort(self._keys, kind="stable")
+        keys_sorted = self._keys[order_sorted]
         for ftype, kind, gi, keys, meas, noise, _ in graph.buckets():
             ar = FACTOR_ARITY[ftype]
-            slots = np.array([self._slot[int(k)] for k in keys.reshape(-1)], dtype=np.int32).reshape(-1, ar)
+            pos = np.searchsorted(keys_sorted, keys.reshape(-1))
+            if (pos >= len(keys_sorted)).any() or (keys_sorted[np.minimum(pos, len(keys_sorted) - 1)] != keys.reshape(-1)).any():
+                raise KeyError("a factor references a key that is not in the ordering")
+            slots = order_sorted[pos].astype(np.int32).reshape(-1, ar)
             meas = meas.copy()
             if ftype == F_SFM:
                 # fold Cal3Bundler's constant principal point into z (see include/lmgpu.h, CAM_BUNDLER)
-                uv = np.array([initialValues.at(k)[15:17] for k in keys[:, 0]])
+                ucam, inv = np.unique(keys[:, 0], return_inverse=True)
+                uv = np.array([initialValues.at(k)[15:17] for k in ucam])[inv]
                 meas = meas - uv
             if ftype == F_PRIOR_CAM:
                 meas = np.ascontiguousarray(meas[:, :15])
@@ -124,6 +130,10 @@ class LevenbergMarquardtOptimizer:
         self._xoff = np.concatenate([[0], np.cumsum([VAR_DIM[t] for t in self._types])]).astype(np.int64)
         self.state = _lib.lmgpu_lm_state()
         if device >= 0:
+            if world_size > 1:
+                if comm_id is None:
+                    raise ValueError("world_size > 1 needs comm_id (lmgpu_comm_unique_id bytes broadcast from rank 0)")
+                self.comm_init(comm_id)
             self.set_values(initialValues)
             cp = self.params._c()
             self._check(self.lib.lmgpu_lm_init(self._h, ct.byref(cp), ct.byref(self.state)))
@@ -197,6 +207,28 @@ class LevenbergMarquardtOptimizer:
         self._check(self.lib.lmgpu_get_timings(self._h, ct.byref(t)))
         return {f: getattr(t, f) for f, _ in t._fields_}
 
+    def set_kernel_timing(self, on=True):
+        self._check(self.lib.lmgpu_set_kernel_timing(self._h, int(on)))
+
+    def kernel_times(self):
+        """{category: dict(ms, work, launches)} accumulated since set_kernel_timing(True)"""
+        n = len(_lib.KT_NAMES)
+        ms, work, cnt = np.zeros(n), np.zeros(n), np.zeros(n, dtype=np.int64)
+        self._check(self.lib.lmgpu_get_kernel_times(self._h, _dp(ms), _dp(work), cnt.ctypes.data_as(ct.POINTER(ct.c_int64))))
+        return {name: dict(ms=float(ms[i]), work=float(work[i]), launches=int(cnt[i])) for i, name in enumerate(_lib.KT_NAMES)}
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """ncclUniqueId bytes (rank 0 creates it; the caller broadcasts it to the other ranks)"""
+        buf = ct.create_string_buffer(128)
+        rc = _lib.load().lmgpu_comm_unique_id(buf)
+        if rc != 0:
+            raise _lib.LmgpuError("lmgpu_comm_unique_id failed")
+        return buf.raw
+
+    def comm_init(self, id128: bytes):
+        self._check(self.lib.lmgpu_comm_init(self._h, id128))
+
     # ------------------------------------------------------------ piecewise hot path (tryLambda's calls)
     def graph_error(self) -> float:
         e = ct.c_double()
@@ -237,9 +269,10 @@ class LevenbergMarquardtOptimizer:
         return self.lib.lmgpu_num_fronts(self._h)
 
     def front_info(self, i):
-        info = np.zeros(6, dtype=np.int32)
+        info = np.zeros(8, dtype=np.int32)
         self._check(self.lib.lmgpu_front_info(self._h, i, _ip(info)))
-        return dict(n_keys=int(info[0]), n_frontal_keys=int(info[1]), nf=int(info[2]), n=int(info[3]), parent=int(info[4]), cls=int(info[5]))
+        return dict(n_keys=int(info[0]), n_frontal_keys=int(info[1]), nf=int(info[2]), n=int(info[3]), parent=int(info[4]), cls=int(info[5]),
+                    owner=int(info[6]), level=int(info[7]))
 
     def front(self, i, numeric=True):
         """(keys in Scatter order, [R S d] as (nf, n) array or None)"""

@@ -144,13 +144,34 @@ int lmgpu_iterate(lmgpu_handle* h, const lmgpu_lm_params* p, lmgpu_lm_state* ino
 int lmgpu_optimize(lmgpu_handle* h, const lmgpu_lm_params* p, lmgpu_lm_state* inout);
 int lmgpu_get_timings(const lmgpu_handle* h, lmgpu_timings* out);
 
+/* Per-kernel device time (HIP events on the handle's stream around each launch), accumulated since
+ * lmgpu_set_kernel_timing(h, 1).  work[] is the ALGORITHMIC work of the launches in the category:
+ * bytes for LINEARIZE (232 B per SFM factor + every camera / point row once) and ALLREDUCE,
+ * FP64 flop for PANEL and SYRK (nb * m * (m + 1) per trailing update = the n^3/3 of the dense front). */
+enum lmgpu_kernel_category {
+  LMGPU_KT_LINEARIZE = 0,   /* sfm_linearize_kernel */
+  LMGPU_KT_LDS_FRONT = 1,   /* lds_front_kernel (assemble + partial Cholesky of one small front per workgroup) */
+  LMGPU_KT_HBM_ASSEMBLE = 2,/* memset + factor / child extend-add + damping of an HBM front */
+  LMGPU_KT_PANEL = 3,       /* potrf_trsm_kernel */
+  LMGPU_KT_SYRK = 4,        /* syrk_mfma_kernel (v_mfma_f64_16x16x4_f64) */
+  LMGPU_KT_BACKSUB_HBM = 5,
+  LMGPU_KT_BACKSUB_LDS = 6,
+  LMGPU_KT_LINEAR_ERROR = 7,
+  LMGPU_KT_RETRACT_ERROR = 8,
+  LMGPU_KT_ALLREDUCE = 9,
+  LMGPU_KT_NUM = 10
+};
+int lmgpu_set_kernel_timing(lmgpu_handle* h, int32_t on);
+int lmgpu_get_kernel_times(const lmgpu_handle* h, double* ms /*[LMGPU_KT_NUM]*/, double* work /*[LMGPU_KT_NUM]*/, int64_t* launches /*[LMGPU_KT_NUM]*/);
+
 /* ---- parity taps ---- */
 /* whitened Jacobian of graph factor `graph_index`, column-major rows x (sum dims + 1) like the reference's
  * VerticalBlockMatrix ([A1 A2 b]); out may be NULL to query the shape. */
 int lmgpu_get_jacobian(lmgpu_handle* h, int32_t graph_index, double* out, int32_t* rows, int32_t* cols);
 int lmgpu_num_fronts(const lmgpu_handle* h);
-/* info6: n_keys, n_frontal_keys, nf (rows of [R S d]), n (cols), parent front (-1 root), class (0 = LDS front, 1 = HBM front) */
-int lmgpu_front_info(const lmgpu_handle* h, int32_t front, int32_t* info6);
+/* info8: n_keys, n_frontal_keys, nf (rows of [R S d]), n (cols), parent front (-1 root), class (0 = LDS front, 1 = HBM front),
+ *        owner rank (-1 = replicated on every rank), level (0 = leaf) */
+int lmgpu_front_info(const lmgpu_handle* h, int32_t front, int32_t* info8);
 /* slots: the front's variables in Scatter order (gtsam/linear/Scatter.cpp:39-73); RSd: column-major nf x n */
 int lmgpu_get_front(lmgpu_handle* h, int32_t front, int32_t* slots, double* RSd_colmajor);
 

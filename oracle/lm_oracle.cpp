@@ -354,6 +354,7 @@ static GFactor linearize_factor(const Factor& f, const Values& vals) {
 static bool cholesky_partial(double* ABC, int ld, int n, int nFrontal) {
   if (nFrontal == 0) return true;
   auto A = [&](int i, int j) -> double& { return ABC[(size_t)j * ld + i]; };
+  std::vector<double> rowk;
   // right-looking, row by row of R
   for (int k = 0; k < nFrontal; k++) {
     double x = A(k, k);
@@ -364,12 +365,15 @@ static bool cholesky_partial(double* ABC, int ld, int n, int nFrontal) {
     const double rkk = std::sqrt(x);
     A(k, k) = rkk;
     const double inv = 1.0 / rkk;
-    for (int j = k + 1; j < n; j++) A(k, j) *= inv;
-    // trailing update restricted to what is needed: rows k+1..n-1 (frontal part and C)
+    rowk.resize(n);
+    for (int j = k + 1; j < n; j++) rowk[j] = (A(k, j) *= inv);
+    // trailing update restricted to what is needed: rows k+1..n-1 (frontal part and C); row k is copied
+    // to a contiguous buffer so the inner loop streams one column
     for (int j = k + 1; j < n; j++) {
-      const double rkj = A(k, j);
+      const double rkj = rowk[j];
       if (rkj == 0.0) continue;
-      for (int i = k + 1; i <= j; i++) A(i, j) -= A(k, i) * rkj;
+      double* col = &A(0, j);
+      for (int i = k + 1; i <= j; i++) col[i] -= rowk[i] * rkj;
     }
   }
   if (nFrontal >= 2) {
@@ -589,14 +593,14 @@ static void eliminate_clique(const std::vector<const GFactor*>& gathered, const 
     for (int i = 0; i <= j; i++) separator.info(i, j) = info(nf + i, nf + j);
 }
 
-static int eliminate_tree(const std::shared_ptr<JNode>& node, const std::vector<GFactor>& graph,
+static int eliminate_tree(const std::shared_ptr<JNode>& node, const std::vector<const GFactor*>& graph,
                           const std::map<Key, int>& keyDim, BayesTree& bt, GFactor& sepOut) {
   // post-order: children first (gtsam/inference/ClusterTree-inst.h:219-266)
   std::vector<GFactor> childFactors(node->children.size());
   std::vector<int> childIdx;
   for (size_t i = 0; i < node->children.size(); i++) childIdx.push_back(eliminate_tree(node->children[i], graph, keyDim, bt, childFactors[i]));
   std::vector<const GFactor*> gathered;
-  for (size_t f : node->factors) gathered.push_back(&graph[f]);
+  for (size_t f : node->factors) gathered.push_back(graph[f]);
   for (auto& cf : childFactors)
     if (!cf.empty()) gathered.push_back(&cf);
   Clique cq;
@@ -719,7 +723,9 @@ static double now_s();
 // buildDampedSystem + solve.  LevenbergMarquardtState.h:125-156, NonlinearOptimizer.cpp:132-146,
 // GaussianFactorGraph::optimize -> eliminateMultifrontal (EliminateableFactorGraph-inst.h:123-146)
 static void solve_damped(Problem& p, double lambda, const VectorValues* sqrtHessianDiagonal) {
-  std::vector<GFactor> damped = p.linear;
+  // the damped graph = the linear factors followed by one prior per variable (no copies of the linear factors)
+  std::vector<GFactor> priors;
+  priors.reserve(p.values.size());
   const double sigma = 1.0 / std::sqrt(lambda);
   for (auto& kv : p.values) {
     const int dim = kVarDim[kv.second.type];
@@ -731,10 +737,15 @@ static void solve_damped(Problem& p, double lambda, const VectorValues* sqrtHess
       double a = sqrtHessianDiagonal ? sqrtHessianDiagonal->at(kv.first)[i] : 1.0;
       g.Ab(i, i) = a / sigma;  // JacobianFactor with Isotropic sigma: whitened at updateHessian (JacobianFactor.cpp:769-776)
     }
-    damped.push_back(std::move(g));
+    priors.push_back(std::move(g));
   }
+  std::vector<const GFactor*> damped;
+  damped.reserve(p.linear.size() + priors.size());
+  for (auto& g : p.linear) damped.push_back(&g);
+  for (auto& g : priors) damped.push_back(&g);
   std::vector<std::vector<Key>> fkeys;
-  for (auto& g : damped) fkeys.push_back(g.keys);
+  fkeys.reserve(damped.size());
+  for (auto* g : damped) fkeys.push_back(g->keys);
   VariableIndex vi;
   for (size_t i = 0; i < fkeys.size(); i++)
     for (Key k : fkeys[i]) vi[k].push_back(i);
@@ -1185,7 +1196,9 @@ int orc_linear_optimize(void* h, int n, const uint64_t* ordering, double* x_out)
       std::shared_ptr<JNode> jr;
       jt_visit(r, fkeys, jr);
       GFactor rem;
-      p->bt.roots.push_back(eliminate_tree(jr, p->graph, p->keyDim, p->bt, rem));
+      std::vector<const GFactor*> gp;
+      for (auto& g : p->graph) gp.push_back(&g);
+      p->bt.roots.push_back(eliminate_tree(jr, gp, p->keyDim, p->bt, rem));
     }
     p->x.clear();
     backsub(p->bt, p->x);

@@ -189,6 +189,40 @@ def test_pose2_slam_between_prior_gaussian_noise():
     _check_lm(opt, orc, params)
 
 
+def test_hbm_front_with_odd_dimensions_and_separator():
+    """a dense Pose2 cluster (61 poses, all pairs) hanging off a chain: the cluster's front is 184 x 184 with an ODD
+    frontal dimension, so the MFMA trailing update runs with misaligned tile origins, a partial last panel and a
+    non-empty separator; everything is compared with the oracle"""
+    rng = np.random.default_rng(3)
+    graph, initial = NonlinearFactorGraph(), Values()
+    n_dense, n_chain = 62, 6
+    for i in range(n_dense + n_chain):
+        initial.insert_pose2(i, rng.normal(0, 2.0), rng.normal(0, 2.0), rng.normal(0, 0.5))
+    model = noiseModel.Diagonal.Sigmas([0.3, 0.3, 0.1])
+    truth = {i: np.array([np.cos(i * 0.1) * 5, np.sin(i * 0.1) * 5, i * 0.05]) for i in range(n_dense + n_chain)}
+
+    def between(a, b):
+        xa, ya, ta = truth[a]
+        xb, yb, tb = truth[b]
+        c, s = np.cos(ta), np.sin(ta)
+        return [c * (xb - xa) + s * (yb - ya), -s * (xb - xa) + c * (yb - ya), tb - ta]
+    for a in range(n_dense):
+        for b in range(a + 1, n_dense):
+            graph.add_BetweenFactorPose2(a, b, between(a, b), model)
+    for i in range(n_dense - 1, n_dense + n_chain - 1):
+        graph.add_BetweenFactorPose2(i, i + 1, between(i, i + 1), model)
+    graph.add_PriorFactorPose2(n_dense + n_chain - 1, list(truth[n_dense + n_chain - 1]), noiseModel.Diagonal.Sigmas([0.05, 0.05, 0.02]))
+    # eliminate the dense cluster first (its separator is pose n_dense-1 ... no: pose 60 is in the cluster; order cluster minus one first)
+    ordering = Ordering(list(range(0, n_dense - 1)) + list(range(n_dense - 1, n_dense + n_chain)))
+    opt, orc, params = _pair(graph, initial, ordering)
+    big = max(range(opt.num_fronts()), key=lambda i: opt.front_info(i)["n"])
+    info = opt.front_info(big)
+    assert info["cls"] == 1 and info["nf"] == 183 and info["n"] == 187
+    _check_linearize(opt, orc, graph)
+    _check_solve(opt, orc, 1e-3)
+    _check_lm(opt, orc, params)
+
+
 def test_pose3_slam_example_file():
     """examples/Data/pose3example.txt (g2o 3D; committed fixture) as in examples/Pose3SLAMExample_g2o.cpp:42-48"""
     graph, initial = load3D(os.path.join(GOLD, "pose3example.txt"))
