@@ -53,6 +53,8 @@ SYMBOLS = {
     "lmgpu_finalize_structure": (ct.c_int, [_H]),
     "lmgpu_set_values": (ct.c_int, [_H, _D]),
     "lmgpu_get_values": (ct.c_int, [_H, _D]),
+    "lmgpu_save_values": (ct.c_int, [_H]),
+    "lmgpu_restore_values": (ct.c_int, [_H]),
     "lmgpu_total_dim": (ct.c_int, [_H]),
     "lmgpu_total_store": (ct.c_int, [_H]),
     "lmgpu_error": (ct.c_int, [_H, _D]),

@@ -138,11 +138,15 @@ __global__ __launch_bounds__(256) void potrf_trsm_kernel(double* __restrict__ A,
     double a[G];
 #pragma unroll
     for (int p = 0; p < G; p++) a[p] = (g0 + p < nb) ? col[(size_t)(g0 + p) * ld] : 0.0;
-    // contributions of the already solved rows
-    for (int q = 0; q < g0; q++) {
-      const double x = col[(size_t)q * ld];
+    // contributions of the already solved rows, 16 at a time (the 16 re-reads are independent loads in flight together)
+    for (int q0 = 0; q0 < g0; q0 += G) {
+      double xq[G];
 #pragma unroll
-      for (int p = 0; p < G; p++) a[p] -= D[q][g0 + p] * x;
+      for (int q = 0; q < G; q++) xq[q] = col[(size_t)(q0 + q) * ld];
+#pragma unroll
+      for (int q = 0; q < G; q++)
+#pragma unroll
+        for (int p = 0; p < G; p++) a[p] -= D[q0 + q][g0 + p] * xq[q];
     }
 #pragma unroll
     for (int q = 0; q < G; q++) {
@@ -296,6 +300,114 @@ __global__ __launch_bounds__(256) void hbm_backsolve_step_kernel(FrontDesc F, in
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (lane == 0) y[row] -= s;
   }
+}
+
+// ---------------------------------------------------------------- dataflow back-substitution (one launch per HBM front)
+// Inverse of every NB x NB diagonal block of R (upper triangular), all blocks in parallel: one block per workgroup,
+// thread j back-substitutes column j of the inverse in LDS.  Partial last block is identity-padded.
+template <int NB>
+__global__ __launch_bounds__(64) void hbm_invert_diag_kernel(const double* __restrict__ A, int ld, int nf, double* __restrict__ inv) {
+  __shared__ double T[NB][NB];  // T[i][k] is read as a broadcast, X[k][j] lane-contiguous: no padding needed (2 x 32 KB)
+  __shared__ double X[NB][NB];
+  const int b = blockIdx.x, r0 = b * NB, nb = min(NB, nf - r0), j = threadIdx.x;
+  for (int idx = j; idx < NB * NB; idx += NB) {
+    const int p = idx / NB, q = idx - p * NB;
+    double v = (p == q) ? 1.0 : 0.0;
+    if (p < nb && q < nb && q >= p) v = A[(size_t)(r0 + p) * ld + r0 + q];
+    T[p][q] = v;
+  }
+  __syncthreads();
+  // column j of X = T^-1:  X[j][j] = 1/T[j][j];  X[i][j] = -(sum_{k=i+1..j} T[i][k] X[k][j]) / T[i][i]
+  for (int i = NB - 1; i >= 0; i--) {
+    double s = (i == j) ? 1.0 : 0.0;
+    if (i <= j) {
+      for (int k = i + 1; k <= j; k++) s -= T[i][k] * X[k][j];
+      s /= T[i][i];
+    } else {
+      s = 0.0;
+    }
+    X[i][j] = s;
+  }
+  __syncthreads();
+  double* out = inv + (size_t)b * NB * NB;
+  for (int idx = j; idx < NB * NB; idx += NB) out[idx] = X[idx / NB][idx % NB];
+}
+
+// R x = y, R = rows 0..nf-1 of the front (upper).  Workgroup b owns row block b:  it folds x_j (j > b) into its right-hand side
+// as the blocks are published, then x_b = inv(R_bb) rhs, publishes x_b and raises flag[b].  All workgroups are co-resident
+// (grid <= #CUs, checked on the host).  Hand-off: 8-byte agent-scope atomics for the payload and the flag on both sides
+// (cdna_hip_programming.md Guideline 16, "8-B agent atomics both sides"), bounded spin.
+template <int NB>
+__global__ __launch_bounds__(256) void hbm_backsolve_dataflow_kernel(FrontDesc F, int64_t f_off, int ld, const int32_t* __restrict__ fxoff,
+                                                                      const double* __restrict__ pool, const double* __restrict__ inv,
+                                                                      const double* __restrict__ y, double* __restrict__ xbuf,
+                                                                      unsigned int* __restrict__ flags, double* __restrict__ delta,
+                                                                      int* __restrict__ status) {
+  __shared__ double acc[NB];
+  __shared__ double xs[NB];
+  __shared__ int ok;
+  const int nblk = gridDim.x;
+  const int b = nblk - 1 - blockIdx.x;  // the last row block (first to finish) gets the first-dispatched workgroup
+  const int r0 = b * NB, nb = min(NB, F.nf - r0);
+  const int tid = threadIdx.x, row = tid >> 2, quarter = tid & 3;
+  const double* A = pool + f_off;
+  if (tid < NB) acc[tid] = (tid < nb) ? y[r0 + tid] : 0.0;
+  if (tid == 0) ok = 1;
+  __syncthreads();
+  const double* arow = A + (size_t)(r0 + row) * ld;
+  for (int j = nblk - 1; j > b; j--) {
+    const int c0 = j * NB, ncol = min(NB, F.nf - c0);
+    // prefetch this thread's 16 entries of R[b rows, j cols] while the producer is still working
+    double rv[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int c = quarter * 16 + k;
+      rv[k] = (row < nb && c < ncol) ? arow[c0 + c] : 0.0;
+    }
+    if (tid == 0) {
+      long spins = 0;
+      while (__hip_atomic_load(&flags[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > 20000000L) {
+          ok = 0;
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    if (!ok) break;
+    if (tid < NB) xs[tid] = __hip_atomic_load(&xbuf[c0 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) s += rv[k] * xs[quarter * 16 + k];
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    if (quarter == 0) acc[row] -= s;
+    __syncthreads();
+  }
+  if (!ok) {
+    if (tid == 0) atomicMin(status, F.id);  // never expected: spin bound hit
+    // still publish something so that waiters terminate
+  }
+  // x_b = inv(R_bb) acc   (thread (row, quarter): 16 columns of the row)
+  const double* ib = inv + (size_t)b * NB * NB;
+  double s = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int c = quarter * 16 + k;
+    s += ib[row * NB + c] * acc[c];
+  }
+  s += __shfl_xor(s, 1);
+  s += __shfl_xor(s, 2);
+  if (quarter == 0 && row < nb) {
+    __hip_atomic_store(&xbuf[r0 + row], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    delta[fxoff[F.fx_begin + r0 + row]] = s;
+    if (s != s) atomicMin(status, F.id);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(&flags[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace lmgpu

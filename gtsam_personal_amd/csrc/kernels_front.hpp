@@ -7,8 +7,10 @@
 //   a1  damping prior lambda*I (or lambda*diag)  gtsam/nonlinear/internal/LevenbergMarquardtState.h:125-156
 //   a13 choleskyPartial + split                  gtsam/base/cholesky.cpp:108-159, SymmetricBlockMatrix.cpp:83-107
 //   a14 back-substitution per clique             gtsam/linear/linearAlgorithms-inst.h:54-116
-// Storage: the front is ROW-major upper (row k of R is contiguous); [R S d] is written nf x n row-major,
-// the update (separator Hessian) (n-nf)^2 row-major upper with ld = n-nf.
+// Storage: the front is ROW-major upper (row k of R is contiguous); [R S d] is written nf x n row-major.
+// The update (separator Hessian) either goes to HBM ((n-nf)^2 row-major upper, ld = n-nf) for the parent to gather,
+// or — when the parent is an HBM front — is scattered straight into the parent with FP64 atomics (no 33-KB
+// round trip per BAL point).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -33,10 +35,13 @@ struct FrontDesc {
   int32_t fx_begin;  // into fxoff[]: delta offset of each frontal scalar (nf entries)
   int32_t sx_begin;  // into sxoff[]: delta offset of each separator scalar (n-nf-1 entries)
   int64_t rsd_off;   // [R S d], row-major nf x ld_rsd
-  int64_t u_off;     // update matrix, row-major (n-nf) x ld_u, upper
+  int64_t u_off;     // update matrix, row-major (n-nf) x ld_u, upper (-1: scattered into the parent instead)
   int32_t ld_rsd, ld_u;
   int32_t id;        // front index (failure report)
-  int32_t pad;
+  int32_t pad;       // bit 0: replicated over ranks (all-reduce after assembly); bit 1: this rank skips own factors + damping
+  int64_t par_off;   // direct scatter: pool offset of the parent HBM front
+  int32_t par_ld;    // its leading dimension (0 = no direct scatter)
+  int32_t par_map;   // into cmap[]: this front's update index -> parent column
 };
 
 __device__ __forceinline__ int frexp_exp(double x) {
@@ -45,10 +50,20 @@ __device__ __forceinline__ int frexp_exp(double x) {
   return e;
 }
 
+// staged descriptor of one own factor of the front being assembled
+struct LFac {
+  int64_t joff;
+  int32_t c0, c1;
+  int16_t rows, d0, d1, pad;
+  int32_t off, sz;
+};
+
 // grid: one block per front in `list`; dynamic LDS = nmax*nmax doubles (the front) + LDSF_JCAP doubles (staged Jacobians)
-// + LDSF_MAXB ints.  Lanes run along the contiguous (column) index of the row-major front, waves along rows.
-#define LDSF_JCAP 960
-#define LDSF_MAXB 64
+// + LDSF_MAXB staged factor descriptors + 4 ints.  Lanes run along the contiguous (column) index of the row-major front,
+// waves along rows.
+#define LDSF_JCAP 704
+#define LDSF_MAXB 32
+#define LDSF_EXTRA_BYTES (LDSF_JCAP * 8 + LDSF_MAXB * 32 + 16)
 __global__ __launch_bounds__(256) void lds_front_kernel(const int32_t* __restrict__ list, const FrontDesc* __restrict__ fronts,
                                                          const FrontFac* __restrict__ ffac, const FacDesc* __restrict__ fd,
                                                          const ChildRef* __restrict__ childs, const int32_t* __restrict__ cmap,
@@ -56,47 +71,61 @@ __global__ __launch_bounds__(256) void lds_front_kernel(const int32_t* __restric
                                                          const double* __restrict__ dampw, int* __restrict__ status, int nmax) {
   extern __shared__ double S[];
   double* Jb = S + (size_t)nmax * nmax;
-  int* Joff = (int*)(Jb + LDSF_JCAP);
+  LFac* LF = (LFac*)(Jb + LDSF_JCAP);
+  int* meta = (int*)(LF + LDSF_MAXB);
   const FrontDesc F = fronts[list[blockIdx.x]];
   const int n = F.n, nf = F.nf, tid = threadIdx.x, nt = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
   for (int i = tid; i < n * n; i += nt) S[i] = 0.0;
-  // ---- own factors: S += [A b]^T [A b], Jacobians staged through LDS in batches (coalesced HBM reads, no per-factor latency)
+  // ---- own factors: S += [A b]^T [A b].  Descriptors and Jacobians are staged through LDS in batches: all the
+  //      dependent HBM reads (list -> front -> factor -> Jacobian) of a batch are in flight together.
   for (int k0 = 0; k0 < F.fac_count;) {
+    __syncthreads();
+    const int cand = min(LDSF_MAXB, F.fac_count - k0);
+    for (int b = tid; b < cand; b += nt) {
+      const FrontFac ff = ffac[F.fac_begin + k0 + b];
+      const FacDesc d = fd[ff.fac];
+      LFac l;
+      l.joff = d.joff;
+      l.c0 = ff.c0;
+      l.c1 = ff.c1;
+      l.rows = d.rows;
+      l.d0 = d.d0;
+      l.d1 = d.d1;
+      l.pad = 0;
+      l.off = 0;
+      l.sz = d.rows * (d.d0 + d.d1 + 1);
+      LF[b] = l;
+    }
     __syncthreads();
     if (tid == 0) {
       int o = 0, b = 0;
-      while (k0 + b < F.fac_count && b < LDSF_MAXB) {
-        const FacDesc d = fd[ffac[F.fac_begin + k0 + b].fac];
-        const int sz = d.rows * (d.d0 + d.d1 + 1);
-        if (o + sz > LDSF_JCAP) break;
-        Joff[b] = o;
-        o += sz;
+      while (b < cand && o + LF[b].sz <= LDSF_JCAP) {
+        LF[b].off = o;
+        o += LF[b].sz;
         b++;
       }
-      Joff[LDSF_MAXB + 1] = b;  // batch size (>= 1: a single factor is at most 90 doubles)
-      Joff[b] = o;
+      meta[0] = b;  // >= 1: a single factor is at most 90 doubles
     }
     __syncthreads();
-    const int B = Joff[LDSF_MAXB + 1];
+    const int B = meta[0];
     for (int b = wave; b < B; b += nw) {
-      const double* J = pool + fd[ffac[F.fac_begin + k0 + b].fac].joff;
-      const int o = Joff[b], sz = Joff[b + 1] - o;
+      const double* J = pool + LF[b].joff;
+      const int o = LF[b].off, sz = LF[b].sz;
       for (int i = lane; i < sz; i += 64) Jb[o + i] = J[i];
     }
     __syncthreads();
     for (int b = 0; b < B; b++) {
-      const FrontFac ff = ffac[F.fac_begin + k0 + b];
-      const FacDesc d = fd[ff.fac];
-      const double* J = Jb + Joff[b];
+      const LFac d = LF[b];
+      const double* J = Jb + d.off;
       const int m = d.rows, nc = d.d0 + d.d1 + 1;
-      // thread (p = tid / 16, q = p + tid % 16 ...) : p over columns in steps of nt/16, q strided by 16
+      // thread (p = tid / 16 + k nt/16, q = p + tid % 16 + 16 l): every pair p <= q exactly once, no two threads on one entry
       for (int p = tid >> 4; p < nc; p += (nt >> 4)) {
-        const int gp = (p < d.d0) ? ff.c0 + p : (p < d.d0 + d.d1 ? ff.c1 + (p - d.d0) : n - 1);
+        const int gp = (p < d.d0) ? d.c0 + p : (p < d.d0 + d.d1 ? d.c1 + (p - d.d0) : n - 1);
         for (int q = p + (tid & 15); q < nc; q += 16) {
           double v = 0;
           for (int r = 0; r < m; r++) v += J[p * m + r] * J[q * m + r];
-          const int gq = (q < d.d0) ? ff.c0 + q : (q < d.d0 + d.d1 ? ff.c1 + (q - d.d0) : n - 1);
+          const int gq = (q < d.d0) ? d.c0 + q : (q < d.d0 + d.d1 ? d.c1 + (q - d.d0) : n - 1);
           const int lo = gp < gq ? gp : gq, hi = gp < gq ? gq : gp;
           S[lo * n + hi] += v;
         }
@@ -156,9 +185,25 @@ __global__ __launch_bounds__(256) void lds_front_kernel(const int32_t* __restric
   for (int i = wave; i < nf; i += nw)
     for (int j = lane; j < n; j += 64) RSd[(size_t)i * F.ld_rsd + j] = (j >= i) ? S[i * n + j] : 0.0;
   const int m = n - nf;
-  double* U = pool + F.u_off;
-  for (int i = wave; i < m; i += nw)
-    for (int j = i + lane; j < m; j += 64) U[(size_t)i * F.ld_u + j] = S[(nf + i) * n + nf + j];
+  if (F.par_ld > 0) {
+    // scatter-add straight into the parent HBM front (extend-add, a12); the column map is staged in the free Jacobian area
+    int* pm = (int*)Jb;
+    for (int i = tid; i < m; i += nt) pm[i] = cmap[F.par_map + i];
+    __syncthreads();
+    double* PA = pool + F.par_off;
+    for (int i = wave; i < m; i += nw) {
+      const int gi = pm[i];
+      for (int j = i + lane; j < m; j += 64) {
+        const int gj = pm[j];
+        const int lo = gi < gj ? gi : gj, hi = gi < gj ? gj : gi;
+        atomicAdd(&PA[(size_t)lo * F.par_ld + hi], S[(nf + i) * n + nf + j]);
+      }
+    }
+  } else {
+    double* U = pool + F.u_off;
+    for (int i = wave; i < m; i += nw)
+      for (int j = i + lane; j < m; j += 64) U[(size_t)i * F.ld_u + j] = S[(nf + i) * n + nf + j];
+  }
 }
 
 // back-substitution for LDS-class fronts: x_F = R^-1 (d - S x_S).  One wave per front, 4 fronts per block.

@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -119,7 +120,7 @@ struct KTimer {
 const int kBinN[6] = {24, 48, 72, 96, 120, 139};  // 139^2 * 8 + staging = 162.5 KB <= 160 KiB of LDS per workgroup
 const int kNumBins = 6;
 const int kLdsLimitN = 139;
-const int kLdsFrontExtra = LDSF_JCAP * 8 + (LDSF_MAXB + 2) * 4;
+const int kLdsFrontExtra = LDSF_EXTRA_BYTES;
 const int NB = 64;    // potrf / trsm step
 const int NBO = 256;  // outer panel: rows eliminated per trailing update of the HBM front
 const int kSyrkLds = 2 * 2 * SYRK_KC * SYRK_LDW * 8;
@@ -144,10 +145,14 @@ struct lmgpu_handle {
   int n_counted = 0;                 // local factors [0, n_counted) enter this rank's error sums (each factor counted on one rank)
 
   // ---- device state
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr, stream2 = nullptr;
+  std::vector<hipEvent_t> la_events;  // look-ahead ordering between the two streams
+  double *bs_inv = nullptr, *bs_x = nullptr;  // dataflow back-substitution scratch
+  unsigned int* bs_flags = nullptr;
   double* pool = nullptr;
   size_t pool_doubles = 0;
   double* vals[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+  double* saved[4] = {nullptr, nullptr, nullptr, nullptr};
   int cur = 0;
   int32_t* type_xoff[4] = {nullptr, nullptr, nullptr, nullptr};
   double *delta = nullptr, *dampw = nullptr, *hdiag = nullptr, *ebuf0 = nullptr, *ebuf1 = nullptr, *partial = nullptr, *dscal = nullptr,
@@ -174,6 +179,7 @@ struct lmgpu_handle {
   lmgpu_timings tim{};
   hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   KTimer kt;
+  bool lookahead = false;  // LMGPU_LOOKAHEAD=1: experimental two-stream look-ahead (measured r01: wrong results for >1 outer panel; off)
 
   ncclComm_t comm = nullptr;
 };
@@ -339,6 +345,12 @@ int fill_dampw(lmgpu_handle* h, int diagonal, double min_diag, double max_diag) 
 int do_eliminate(lmgpu_handle* h, double lambda) {
   hipStream_t s = h->stream;
   HIPCHECK(hipMemsetAsync(h->d_status, 0x7f, sizeof(int), s));
+  {  // HBM fronts are accumulated into by their children (atomics) before their own level runs: clear them all first
+    const int kt0 = h->kt.begin(LMGPU_KT_HBM_ASSEMBLE, s);
+    for (const LevelWork& L : h->levels)
+      for (int fi : L.hbm) HIPCHECK(hipMemsetAsync(h->pool + h->f_off[fi], 0, (size_t)h->h_fronts[fi].n * h->f_ld[fi] * sizeof(double), s));
+    h->kt.end(kt0, s);
+  }
   for (const LevelWork& L : h->levels) {
     for (int b = 0; b < kNumBins; b++) {
       const int cnt = L.bin_begin[b + 1] - L.bin_begin[b];
@@ -359,7 +371,6 @@ int do_eliminate(lmgpu_handle* h, double lambda) {
       double* A = h->pool + off;
       const bool replicated = (F.pad & 1) != 0, own_terms = (F.pad & 2) == 0;
       int kt = h->kt.begin(LMGPU_KT_HBM_ASSEMBLE, s);
-      HIPCHECK(hipMemsetAsync(A, 0, (size_t)F.n * ld * sizeof(double), s));
       if (F.fac_count > 0 && own_terms)
         hipLaunchKernelGGL(hbm_assemble_factors_kernel, dim3(F.fac_count), dim3(64), 0, s, F, off, ld, (const FrontFac*)h->d_ffac,
                            (const FacDesc*)h->d_fd, h->pool);
@@ -376,29 +387,47 @@ int do_eliminate(lmgpu_handle* h, double lambda) {
         NCCLCHECK(ncclAllReduce(A, A, (size_t)F.n * ld, ncclDouble, ncclSum, h->comm, s));
         h->kt.end(kt, s, (double)F.n * ld * 8.0);
       }
-      // two-level blocking: outer panels of NBO rows; inside, NB-row steps update only the rest of the outer panel
-      auto syrk = [&](int p0, int kp, int r0, int r1) {
+      // two-level blocking: outer panels of NBO rows; inside, NB-row steps update only the rest of the outer panel.
+      // Look-ahead on a second stream: the big trailing update UB_i (rows beyond panel i+1) runs on stream B while stream A
+      // updates just the rows of panel i+1 (UA_i) and factors that panel (P_{i+1}).
+      //   P_i  needs UA_{i-1} (A, in order).   UA_i needs P_i (A) and UB_{i-1} (same rows: event).   UB_i needs P_i (event), UB_{i-1} (B).
+      hipStream_t sA = s, sB = h->lookahead ? h->stream2 : s;
+      auto syrk = [&](hipStream_t st, int p0, int kp, int r0, int r1) {
         if (r0 >= r1 || r0 >= F.n) return;
         const int Tr = (r1 - r0 + 127) / 128, Tc = (F.n - r0 + 127) / 128;
-        const int kts = h->kt.begin(LMGPU_KT_SYRK, s);
-        hipLaunchKernelGGL(syrk_mfma_kernel, dim3(Tc, Tr), dim3(256), kSyrkLds, s, A, ld, F.n, p0, kp, r0, r1);
+        const int kts = h->kt.begin(LMGPU_KT_SYRK, st);
+        hipLaunchKernelGGL(syrk_mfma_kernel, dim3(Tc, Tr), dim3(256), kSyrkLds, st, A, ld, F.n, p0, kp, r0, r1);
         // algorithmic flop: 2 x kp x (upper-trapezoid entries of rows r0..r1-1, columns row..n-1)
         const double rows = r1 - r0, first = F.n - r0;
-        h->kt.end(kts, s, 2.0 * kp * (rows * first - rows * (rows - 1.0) / 2.0));
+        h->kt.end(kts, st, 2.0 * kp * (rows * first - rows * (rows - 1.0) / 2.0));
       };
-      for (int k0 = 0; k0 < F.nf; k0 += NBO) {
-        const int kend = std::min(F.nf, k0 + NBO);
-        for (int k = k0; k < kend; k += NB) {
+      const int np = (F.nf + NBO - 1) / NBO;
+      while ((int)h->la_events.size() < 2 * np) {
+        hipEvent_t e;
+        HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->la_events.push_back(e);
+      }
+      for (int i = 0; i < np; i++) {
+        const int k0 = i * NBO, kend = std::min(F.nf, k0 + NBO);
+        hipEvent_t evP = h->la_events[2 * i], evUB = h->la_events[2 * i + 1];
+        for (int k = k0; k < kend; k += NB) {  // P_i
           const int nb = std::min(NB, kend - k);
           const int cols = F.n - k - nb;
           const int g = std::max(1, (cols + 255) / 256);
-          kt = h->kt.begin(LMGPU_KT_PANEL, s);
-          hipLaunchKernelGGL((potrf_trsm_kernel<NB>), dim3(g), dim3(256), 0, s, A, ld, F.n, F.nf, k, nb, F.id, h->d_status);
-          h->kt.end(kt, s, (double)nb * nb * nb / 3.0 + (double)nb * nb * cols);
-          syrk(k, nb, k + nb, kend);       // rest of the outer panel's rows
+          kt = h->kt.begin(LMGPU_KT_PANEL, sA);
+          hipLaunchKernelGGL((potrf_trsm_kernel<NB>), dim3(g), dim3(256), 0, sA, A, ld, F.n, F.nf, k, nb, F.id, h->d_status);
+          h->kt.end(kt, sA, (double)nb * nb * nb / 3.0 + (double)nb * nb * cols);
+          syrk(sA, k, nb, k + nb, kend);  // rest of the outer panel's rows
         }
-        syrk(k0, kend - k0, kend, F.n);    // everything below the outer panel, K = up to NBO
+        HIPCHECK(hipEventRecord(evP, sA));
+        const int next_end = std::min(F.n, kend + NBO);  // rows of panel i+1 (or the separator rows if this was the last panel)
+        if (i > 0) HIPCHECK(hipStreamWaitEvent(sA, h->la_events[2 * (i - 1) + 1], 0));
+        syrk(sA, k0, kend - k0, kend, next_end);  // UA_i
+        HIPCHECK(hipStreamWaitEvent(sB, evP, 0));
+        syrk(sB, k0, kend - k0, next_end, F.n);   // UB_i
+        HIPCHECK(hipEventRecord(evUB, sB));
       }
+      HIPCHECK(hipStreamWaitEvent(sA, h->la_events[2 * (np - 1) + 1], 0));  // join
     }
   }
   HIPCHECK(hipGetLastError());
@@ -419,12 +448,12 @@ int do_backsub(lmgpu_handle* h) {
       hipLaunchKernelGGL(hbm_rhs_init_kernel, dim3(F.nf), dim3(64), 0, s, F, off, ld, (const int32_t*)h->d_sxoff, (const double*)h->pool,
                          (const double*)h->delta, h->ywork);
       const int nblk = (F.nf + NB - 1) / NB;
-      for (int kb = nblk - 1; kb >= 0; kb--) {
-        const int r0 = kb * NB, nb = std::min(NB, F.nf - r0);
-        const int g = std::max(1, (r0 + 31) / 32);
-        hipLaunchKernelGGL((hbm_backsolve_step_kernel<NB>), dim3(g), dim3(256), 0, s, F, off, ld, r0, nb, (const int32_t*)h->d_fxoff,
-                           (const double*)h->pool, h->ywork, h->delta, h->d_status);
-      }
+      // inverse of the diagonal blocks (all in parallel), then ONE dataflow launch: workgroup b waits for x_j (j > b) flags
+      HIPCHECK(hipMemsetAsync(h->bs_flags, 0, nblk * sizeof(unsigned int), s));
+      hipLaunchKernelGGL((hbm_invert_diag_kernel<NB>), dim3(nblk), dim3(NB), 0, s, (const double*)(h->pool + off), ld, F.nf, h->bs_inv);
+      hipLaunchKernelGGL((hbm_backsolve_dataflow_kernel<NB>), dim3(nblk), dim3(256), 0, s, F, off, ld, (const int32_t*)h->d_fxoff,
+                         (const double*)h->pool, (const double*)h->bs_inv, (const double*)h->ywork, h->bs_x, h->bs_flags, h->delta,
+                         h->d_status);
       h->kt.end(kt, s);
     }
     if (L.list_count > 0) {
@@ -640,10 +669,12 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
   h->cfg = *cfg;
   if (h->cfg.world_size < 1) h->cfg.world_size = 1;
   h->device = cfg->device;
+  h->lookahead = getenv("LMGPU_LOOKAHEAD") != nullptr;
   *out = h;
   if (h->device >= 0) {
     HIPCHECK(hipSetDevice(h->device));
     HIPCHECK(hipStreamCreate(&h->stream));
+    HIPCHECK(hipStreamCreate(&h->stream2));
     for (int i = 0; i < 8; i++) HIPCHECK(hipEventCreate(&h->ev[i]));
     HIPCHECK(hipHostMalloc((void**)&h->h_scal, 8 * sizeof(double), hipHostMallocDefault));
     HIPCHECK(hipHostMalloc((void**)&h->h_status, sizeof(int), hipHostMallocDefault));
@@ -666,6 +697,7 @@ int lmgpu_destroy(lmgpu_handle* h) {
     for (int w = 0; w < 2; w++)
       for (int t = 0; t < 4; t++) fr(h->vals[w][t]);
     for (int t = 0; t < 4; t++) fr(h->type_xoff[t]);
+    for (int t = 0; t < 4; t++) fr(h->saved[t]);
     fr(h->delta); fr(h->dampw); fr(h->hdiag); fr(h->ebuf0); fr(h->ebuf1); fr(h->partial); fr(h->dscal); fr(h->ywork); fr(h->d_status);
     fr(h->d_fd); fr(h->d_fronts); fr(h->d_ffac); fr(h->d_childs); fr(h->d_cmap); fr(h->d_fxoff); fr(h->d_sxoff); fr(h->d_lists);
     fr(h->d_scalar_var); fr(h->d_scalar_col); fr(h->d_vi_ptr); fr(h->d_vi_fac); fr(h->d_vi_pos);
@@ -677,6 +709,9 @@ int lmgpu_destroy(lmgpu_handle* h) {
     for (int i = 0; i < 8; i++)
       if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     for (hipEvent_t e : h->kt.pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->la_events) (void)hipEventDestroy(e);
+    fr(h->bs_inv); fr(h->bs_x); fr(h->bs_flags);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
   }
   delete h;
@@ -840,8 +875,14 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
       F.rsd_off = off;
       off += (int64_t)fr.nf * fr.n;
       F.ld_u = fr.n - fr.nf;
-      F.u_off = off;
-      off += (int64_t)F.ld_u * F.ld_u;
+      // an LDS front whose parent lives in HBM scatters its update straight into the parent (no update matrix in HBM)
+      const bool direct = fr.parent >= 0 && P.fronts[fr.parent].cls == 1;
+      if (direct) {
+        F.u_off = -1;
+      } else {
+        F.u_off = off;
+        off += (int64_t)F.ld_u * F.ld_u;
+      }
     } else {
       const int ld = (fr.n + 15) & ~15;
       off = (off + 15) & ~int64_t(15);
@@ -869,15 +910,22 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
     for (int32_t c : fr.children) {
       if (!h->front_active[c]) continue;
       const Front& ch = P.fronts[c];
-      const FrontDesc& CF = h->h_fronts[c];
+      FrontDesc& CF = h->h_fronts[c];
+      const int map_begin = (int)cmap.size();
+      for (size_t k = ch.n_frontal_vars; k < ch.vars.size(); k++)
+        for (int d = 0; d < P.dims[ch.vars[k]]; d++) cmap.push_back(colof[ch.vars[k]] + d);
+      cmap.push_back(fr.n - 1);
+      if (CF.u_off < 0) {  // direct scatter child: tell it where its parent is
+        CF.par_off = h->f_off[fi];
+        CF.par_ld = h->f_ld[fi];
+        CF.par_map = map_begin;
+        continue;
+      }
       ChildRef cr{};
       cr.u_off = CF.u_off;
       cr.ld = CF.ld_u;
       cr.m = ch.n - ch.nf;
-      cr.map_begin = (int)cmap.size();
-      for (size_t k = ch.n_frontal_vars; k < ch.vars.size(); k++)
-        for (int d = 0; d < P.dims[ch.vars[k]]; d++) cmap.push_back(colof[ch.vars[k]] + d);
-      cmap.push_back(fr.n - 1);
+      cr.map_begin = map_begin;
       childs.push_back(cr);
     }
     F.child_count = (int)childs.size() - F.child_begin;
@@ -1006,6 +1054,15 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
   HIPCHECK(hipMalloc((void**)&h->dscal, 8 * sizeof(double)));
   HIPCHECK(hipMalloc((void**)&h->ywork, std::max(1, P.max_front_n) * sizeof(double)));
   HIPCHECK(hipMalloc((void**)&h->d_status, sizeof(int)));
+  {
+    int max_nf = 1;
+    for (int fi = 0; fi < NF; fi++)
+      if (h->front_active[fi] && P.fronts[fi].cls == 1) max_nf = std::max(max_nf, P.fronts[fi].nf);
+    const int max_blk = (max_nf + NB - 1) / NB;
+    HIPCHECK(hipMalloc((void**)&h->bs_inv, (size_t)max_blk * NB * NB * sizeof(double)));
+    HIPCHECK(hipMalloc((void**)&h->bs_x, (size_t)max_blk * NB * sizeof(double)));
+    HIPCHECK(hipMalloc((void**)&h->bs_flags, (size_t)max_blk * sizeof(unsigned int)));
+  }
   return LMGPU_OK;
 }
 
@@ -1042,6 +1099,32 @@ int lmgpu_get_values(lmgpu_handle* h, double* packed) {
     for (int s = 0; s < P.n_vars; s++)
       if (P.types[s] == t) std::memcpy(packed + P.voff[s], &buf[(size_t)P.tidx[s] * kVarStore[t]], kVarStore[t] * sizeof(double));
   }
+  return LMGPU_OK;
+}
+
+// device-side snapshot of the current values (e.g. the initial estimate) and its restore: device-to-device copies
+int lmgpu_save_values(lmgpu_handle* h) {
+  if (!h || !h->finalized || !h->have_values) return LMGPU_INVALID;
+  int rc = need_device(h);
+  if (rc) return rc;
+  for (int t = 0; t < 4; t++) {
+    const size_t bytes = std::max<size_t>(1, (size_t)h->plan.type_count[t] * kVarStore[t]) * sizeof(double);
+    if (!h->saved[t]) HIPCHECK(hipMalloc((void**)&h->saved[t], bytes));
+    HIPCHECK(hipMemcpyAsync(h->saved[t], h->vals[h->cur][t], bytes, hipMemcpyDeviceToDevice, h->stream));
+  }
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  return LMGPU_OK;
+}
+
+int lmgpu_restore_values(lmgpu_handle* h) {
+  if (!h || !h->finalized || !h->saved[0]) return LMGPU_INVALID;
+  int rc = need_device(h);
+  if (rc) return rc;
+  for (int t = 0; t < 4; t++) {
+    const size_t bytes = std::max<size_t>(1, (size_t)h->plan.type_count[t] * kVarStore[t]) * sizeof(double);
+    HIPCHECK(hipMemcpyAsync(h->vals[h->cur][t], h->saved[t], bytes, hipMemcpyDeviceToDevice, h->stream));
+  }
+  h->linearized = false;
   return LMGPU_OK;
 }
 
@@ -1127,10 +1210,7 @@ int lmgpu_iterate(lmgpu_handle* h, const lmgpu_lm_params* p, lmgpu_lm_state* ino
   int rc = need_device(h);
   if (rc) return rc;
   if ((rc = need_comm(h))) return rc;
-  if (inout) {
-    h->lm.lambda = inout->lambda;
-    h->lm.currentFactor = inout->currentFactor;
-  }
+  if (inout) h->lm = *inout;  // the caller owns the LevenbergMarquardtState (error, lambda, factor, counters)
   rc = lm_iterate(h, p);
   if (inout) *inout = h->lm;
   return rc;

@@ -207,6 +207,20 @@ class LevenbergMarquardtOptimizer:
         self._check(self.lib.lmgpu_get_timings(self._h, ct.byref(t)))
         return {f: getattr(t, f) for f, _ in t._fields_}
 
+    def save_values(self):
+        self._check(self.lib.lmgpu_save_values(self._h))
+
+    def restore_values(self, state=None):
+        """restore the device-side snapshot; optionally also the LM state (a copy of a previous `opt.state`)"""
+        self._check(self.lib.lmgpu_restore_values(self._h))
+        if state is not None:
+            ct.memmove(ct.byref(self.state), ct.byref(state), ct.sizeof(_lib.lmgpu_lm_state))
+
+    def copy_state(self):
+        s = _lib.lmgpu_lm_state()
+        ct.memmove(ct.byref(s), ct.byref(self.state), ct.sizeof(_lib.lmgpu_lm_state))
+        return s
+
     def set_kernel_timing(self, on=True):
         self._check(self.lib.lmgpu_set_kernel_timing(self._h, int(on)))
 

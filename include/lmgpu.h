@@ -126,6 +126,9 @@ int lmgpu_finalize_structure(lmgpu_handle* h);
 /* ---- values ---- */
 int lmgpu_set_values(lmgpu_handle* h, const double* packed_values);
 int lmgpu_get_values(lmgpu_handle* h, double* packed_values);
+/* device-side snapshot / restore of the values (e.g. keep the initial estimate around to restart an optimisation) */
+int lmgpu_save_values(lmgpu_handle* h);
+int lmgpu_restore_values(lmgpu_handle* h);
 int lmgpu_total_dim(const lmgpu_handle* h);   /* sum of tangent dims */
 int lmgpu_total_store(const lmgpu_handle* h); /* doubles in packed values */
 
