@@ -75,42 +75,82 @@ __global__ __launch_bounds__(256) void hbm_damp_kernel(FrontDesc F, int64_t f_of
 }
 
 // ---------------------------------------------------------------- panel: potrf + trsm
-// Every block factors the nb x nb diagonal block in LDS (redundantly: it is 64^3/3 flop), block 0 writes it back;
-// then each lane forward-substitutes one column of the row panel,  P = R_kk^-T A_panel,  16 rows at a time
-// (x of the finished 16-row groups is re-read from the panel, so only 16 values live in registers).
+// potrf of one 64x64 diagonal block by 256 lanes with ONE barrier per pivot.  Lane t owns column b = t % 64 and the
+// rows a = 4 i + t / 64 (i = 0..15) of it, in registers.  Step k (fully unrolled, so every register index is static):
+// the wave that owns row k publishes it (unscaled) through a double-buffered LDS row; every lane then applies
+//   A'[a][b] -= A'[k][a] * (A'[k][b] / p_k)     to its rows a > k
+// reading A'[k][a] as a wave-uniform (broadcast) LDS word.  R[a][b] = A'[a][b] / sqrt(p_a) at the end.
+// Slots below the diagonal (a > b) carry don't-care values that are never stored.  Blocks smaller than 64 are
+// identity-padded.
+#define POTRF_LDW 66  // row stride of the factor in LDS: even, so that 16-byte ds_read_b128 pairs are aligned
+__device__ __forceinline__ double fast_rcp(double p) {
+  double r = __builtin_amdgcn_rcp(p);
+  r = fma(fma(-p, r, 1.0), r, r);
+  r = fma(fma(-p, r, 1.0), r, r);
+  return r;
+}
+
+template <int NB>
+__device__ __forceinline__ bool potrf64_regs(const double* __restrict__ A, int ld, int k0, int nb, double (*D)[POTRF_LDW],
+                                             double (*rowbuf)[NB], double* piv) {
+  static_assert(NB == 64, "register distribution below assumes a 64x64 block and 256 lanes");
+  const int tid = threadIdx.x, b = tid & 63, w = tid >> 6;
+  double v[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const int a = 4 * i + w;
+    double x = (a == b) ? 1.0 : 0.0;
+    if (a <= b && b < nb) x = A[(size_t)(k0 + a) * ld + k0 + b];
+    v[i] = x;
+  }
+  bool failed = false;
+#pragma unroll
+  for (int k = 0; k < NB; k++) {
+    constexpr int dummy = 0;
+    (void)dummy;
+    const int ks = k >> 2, kw = k & 3;
+    double* row = rowbuf[k & 1];
+    if (w == kw) row[b] = v[ks];
+    __syncthreads();
+    double p = row[k];
+    if (!(p > 0.0)) {
+      if (p <= 0.0) failed = true;  // Eigen LLT: pivot <= 0 -> failure (NaN passes like Eigen)
+      p = (p == p && p != 0.0) ? fabs(p) : 1.0;
+    }
+    if (tid == 0) piv[k] = p;
+    const double rb = row[b] * fast_rcp(p);
+    if (w > kw) v[ks] -= row[4 * ks + w] * rb;
+#pragma unroll
+    for (int i = ks + 1; i < 16; i++) v[i] -= row[4 * i + w] * rb;
+  }
+  __syncthreads();
+  if (tid < NB) piv[tid] = 1.0 / sqrt(piv[tid]);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const int a = 4 * i + w;
+    if (a <= b) D[a][b] = v[i] * piv[a];
+  }
+  __syncthreads();
+  return failed;
+}
+
+// Every block factors the nb x nb diagonal block (redundantly: it is 64^3/3 flop), block 0 writes it back; then the
+// row panel  P = R_kk^-T A_panel  is solved ON THE MATRIX CORES, 16 rows at a time:
+//     T_g = A_g - sum_{i<g} R_ig^T X_i          (v_mfma_f64_16x16x4_f64, K = 16 per finished group)
+//     X_g = inv(R_gg)^T T_g                     (only the four 16x16 diagonal blocks are inverted, in LDS)
+// A wave owns 64 columns (4 column tiles) and keeps all X_g tiles in registers: the f64 C/D layout
+// (row = (lane>>4) + 4*reg, col = lane&15) IS the B-operand layout of k-step `reg`, so finished tiles feed the
+// next products without any LDS round trip.
 template <int NB>
 __global__ __launch_bounds__(256) void potrf_trsm_kernel(double* __restrict__ A, int ld, int n, int nf, int k0, int nb, int front_id,
                                                           int* __restrict__ status) {
-  __shared__ double D[NB][NB + 1];
+  __shared__ __attribute__((aligned(16))) double D[NB][POTRF_LDW];
+  __shared__ double rowbuf[2][NB];
+  __shared__ double piv[NB];
+  __shared__ double I16[4][16][17];
   const int tid = threadIdx.x;
-  for (int idx = tid; idx < NB * NB; idx += 256) {
-    const int p = idx / NB, q = idx - p * NB;
-    double v = (p == q) ? 1.0 : 0.0;
-    if (p < nb && q < nb && q >= p) v = A[(size_t)(k0 + p) * ld + k0 + q];
-    D[p][q] = v;
-  }
-  __syncthreads();
-  bool failed = false;
-  for (int k = 0; k < nb; k++) {
-    __syncthreads();  // trailing update of the previous step is complete
-    double piv = D[k][k];
-    if (!(piv > 0.0)) {
-      if (piv <= 0.0) failed = true;
-      piv = (piv == piv && piv != 0.0) ? fabs(piv) : 1.0;
-    }
-    const double r = sqrt(piv), inv = 1.0 / r;
-    const int t = nb - k - 1;
-    if (tid < t) D[k][k + 1 + tid] *= inv;
-    __syncthreads();  // row k scaled; every thread has read the pivot
-    if (tid == 0) D[k][k] = r;
-    // trailing update of the t x t block: thread column b = tid % 64, rows a = tid / 64 + 4 i
-    const int b = tid & 63;
-    if (b < t) {
-      const double rb = D[k][k + 1 + b];
-      for (int a = tid >> 6; a <= b; a += 4) D[k + 1 + a][k + 1 + b] -= D[k][k + 1 + a] * rb;
-    }
-  }
-  __syncthreads();
+  bool failed = potrf64_regs<NB>(A, ld, k0, nb, D, rowbuf, piv);
   if (blockIdx.x == 0) {
     for (int idx = tid; idx < nb * nb; idx += 256) {
       const int p = idx / nb, q = idx - p * nb;
@@ -129,35 +169,66 @@ __global__ __launch_bounds__(256) void potrf_trsm_kernel(double* __restrict__ A,
       if (failed) atomicMin(status, front_id);
     }
   }
-  // trsm: one lane per column of the row panel;  R^T x = a  (R^T lower: (R^T)[p][q] = D[q][p])
-  const int j = k0 + nb + blockIdx.x * 256 + tid;
-  if (j >= n) return;
-  double* col = A + (size_t)k0 * ld + j;
-  constexpr int G = 16;
-  for (int g0 = 0; g0 < nb; g0 += G) {
-    double a[G];
+  // inverses of the four 16x16 diagonal blocks: lane (blk, j) back-substitutes column j of inv(R_blk)
+  if (tid < 64) {
+    const int blk = tid >> 4, j = tid & 15, base = 16 * blk;
+    double x[16];
 #pragma unroll
-    for (int p = 0; p < G; p++) a[p] = (g0 + p < nb) ? col[(size_t)(g0 + p) * ld] : 0.0;
-    // contributions of the already solved rows, 16 at a time (the 16 re-reads are independent loads in flight together)
-    for (int q0 = 0; q0 < g0; q0 += G) {
-      double xq[G];
+    for (int i = 15; i >= 0; i--) {
+      double sacc = (i == j) ? 1.0 : 0.0;
 #pragma unroll
-      for (int q = 0; q < G; q++) xq[q] = col[(size_t)(q0 + q) * ld];
-#pragma unroll
-      for (int q = 0; q < G; q++)
-#pragma unroll
-        for (int p = 0; p < G; p++) a[p] -= D[q0 + q][g0 + p] * xq[q];
+      for (int k = i + 1; k < 16; k++) sacc -= D[base + i][base + k] * x[k];
+      x[i] = (i <= j) ? sacc / D[base + i][base + i] : 0.0;
     }
 #pragma unroll
-    for (int q = 0; q < G; q++) {
-      const double x = a[q] / D[g0 + q][g0 + q];
-      a[q] = x;
+    for (int i = 0; i < 16; i++) I16[blk][i][j] = x[i];
+  }
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63, kk = lane >> 4, cc = lane & 15;
+  const int c0 = k0 + nb + blockIdx.x * 256 + wave * 64;
+  if (c0 >= n) return;
+  double* P = A + (size_t)k0 * ld;
+  double4_t X[4][4];
 #pragma unroll
-      for (int p = q + 1; p < G; p++) a[p] -= D[g0 + q][g0 + p] * x;
+  for (int g = 0; g < 4; g++) {
+    double4_t acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const int col = min(c0 + 16 * t + cc, n - 1);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = 16 * g + kk + 4 * r;
+        const double v = P[(size_t)min(row, nb - 1) * ld + col];
+        acc[t][r] = (row < nb) ? v : 0.0;
+      }
     }
 #pragma unroll
-    for (int p = 0; p < G; p++)
-      if (g0 + p < nb) col[(size_t)(g0 + p) * ld] = a[p];
+    for (int i = 0; i < g; i++)
+#pragma unroll
+      for (int sx = 0; sx < 4; sx++) {
+        const double af = -D[16 * i + 4 * sx + kk][16 * g + cc];
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, X[i][t][sx], acc[t], 0, 0, 0);
+      }
+    double4_t out[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) out[t] = double4_t{0, 0, 0, 0};
+#pragma unroll
+    for (int sx = 0; sx < 4; sx++) {
+      const double af = I16[g][4 * sx + kk][cc];
+#pragma unroll
+      for (int t = 0; t < 4; t++) out[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, acc[t][sx], out[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      X[g][t] = out[t];
+      const int col = c0 + 16 * t + cc;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = 16 * g + kk + 4 * r;
+        if (row < nb && col < n) P[(size_t)row * ld + col] = out[t][r];
+      }
+    }
   }
 }
 

@@ -1,0 +1,110 @@
+// Development microbenchmark (not part of the product): times the dense-front kernels on a synthetic SPD matrix and
+// prints per-phase cycle shares of the panel kernel from s_memtime stamps.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../gtsam_personal_amd/csrc tools/microbench.hip -o tools/microbench
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "kernels_dense.hpp"
+
+using namespace lmgpu;
+
+#define CK(x)                                                                   \
+  do {                                                                          \
+    hipError_t e = (x);                                                         \
+    if (e != hipSuccess) {                                                      \
+      printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); \
+      exit(1);                                                                  \
+    }                                                                           \
+  } while (0)
+
+__device__ __forceinline__ unsigned long long stamp() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+
+static void fill_spd(std::vector<double>& h, int n, int ld) {
+  // diagonally dominant SPD: A = 0.01 * (random symmetric) + n * I   (upper triangle used)
+  srand(1);
+  for (int i = 0; i < n; i++)
+    for (int j = i; j < n; j++) h[(size_t)i * ld + j] = (i == j) ? (double)n : 0.01 * ((rand() % 2001) / 1000.0 - 1.0);
+}
+
+int main(int argc, char** argv) {
+  const int n = argc > 1 ? atoi(argv[1]) : 9001;
+  const int ld = (n + 15) & ~15;
+  std::vector<double> h((size_t)n * ld + 1024, 0.0);
+  fill_spd(h, n, ld);
+  double* A;
+  CK(hipMalloc((void**)&A, h.size() * sizeof(double)));
+  unsigned long long* st;
+  CK(hipMalloc((void**)&st, 64 * sizeof(unsigned long long)));
+  int* status;
+  CK(hipMalloc((void**)&status, sizeof(int)));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  const int kSyrkLds = 2 * 2 * SYRK_KC * SYRK_LDW * 8;
+  CK(hipFuncSetAttribute((const void*)syrk_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSyrkLds));
+  auto reset = [&]() { CK(hipMemcpy(A, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice)); };
+  auto timeit = [&](const char* name, int reps, auto&& fn) {
+    float best = 1e30f, tot = 0;
+    for (int r = 0; r < reps; r++) {
+      reset();
+      CK(hipDeviceSynchronize());
+      CK(hipEventRecord(e0, 0));
+      fn();
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      best = ms < best ? ms : best;
+      tot += ms;
+    }
+    printf("%-44s best %9.1f us   avg %9.1f us\n", name, best * 1e3, tot / reps * 1e3);
+  };
+  // 1. panel kernel at several trailing widths
+  for (int k0 : {0, 4096, 8192}) {
+    const int cols = n - k0 - 64;
+    const int g = (cols + 255) / 256;
+    char nm[128];
+    snprintf(nm, sizeof nm, "potrf_trsm<64>  k0=%d cols=%d blocks=%d", k0, cols, g);
+    timeit(nm, 5, [&]() { hipLaunchKernelGGL((potrf_trsm_kernel<64>), dim3(g), dim3(256), 0, 0, A, ld, n, n - 1, k0, 64, 0, status); });
+  }
+  timeit("potrf only (1 block, no columns)", 5,
+         [&]() { hipLaunchKernelGGL((potrf_trsm_kernel<64>), dim3(1), dim3(256), 0, 0, A, ld, 64 + 64, 64, 0, 64, 0, status); });
+  // 3. strip updates (K = 64, <= 192 rows) and big updates (K = 256) at several trailing sizes
+  for (int r0 : {64, 4160, 8256}) {
+    char nm[128];
+    const int r1 = r0 + 192;
+    snprintf(nm, sizeof nm, "syrk strip K=64 rows [%d,%d) cols..n", r0, r1);
+    timeit(nm, 5, [&]() {
+      const int Tr = (r1 - r0 + 127) / 128, Tc = (n - r0 + 127) / 128;
+      hipLaunchKernelGGL(syrk_mfma_kernel, dim3(Tc, Tr), dim3(256), kSyrkLds, 0, A, ld, n, r0 - 64, 64, r0, r1);
+    });
+  }
+  for (int r0 : {256, 2304, 4352, 6400, 8448}) {
+    char nm[128];
+    snprintf(nm, sizeof nm, "syrk big K=256 rows [%d,n)", r0);
+    const double m = n - r0;
+    float best = 1e30f;
+    for (int r = 0; r < 3; r++) {
+      reset();
+      CK(hipDeviceSynchronize());
+      CK(hipEventRecord(e0, 0));
+      const int T = (n - r0 + 127) / 128;
+      hipLaunchKernelGGL(syrk_mfma_kernel, dim3(T, T), dim3(256), kSyrkLds, 0, A, ld, n, r0 - 256, 256, r0, n);
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      best = ms < best ? ms : best;
+    }
+    printf("%-44s best %9.1f us   %6.1f TFLOP/s\n", nm, best * 1e3, 256.0 * m * (m + 1) / (best * 1e-3) / 1e12);
+  }
+  CK(hipGetLastError());
+  return 0;
+}
