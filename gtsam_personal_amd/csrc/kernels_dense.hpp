@@ -91,18 +91,13 @@ __device__ __forceinline__ double fast_rcp(double p) {
 }
 
 template <int NB>
-__device__ __forceinline__ bool potrf64_regs(const double* __restrict__ A, int ld, int k0, int nb, double (*D)[POTRF_LDW],
-                                             double (*rowbuf)[NB], double* piv) {
+__device__ __forceinline__ bool potrf64_lds(double (*D)[POTRF_LDW], double (*rowbuf)[NB], double* piv) {
   static_assert(NB == 64, "register distribution below assumes a 64x64 block and 256 lanes");
   const int tid = threadIdx.x, b = tid & 63, w = tid >> 6;
   double v[16];
 #pragma unroll
-  for (int i = 0; i < 16; i++) {
-    const int a = 4 * i + w;
-    double x = (a == b) ? 1.0 : 0.0;
-    if (a <= b && b < nb) x = A[(size_t)(k0 + a) * ld + k0 + b];
-    v[i] = x;
-  }
+  for (int i = 0; i < 16; i++) v[i] = D[4 * i + w][b];  // the block (upper triangle valid, identity-padded) is already in LDS
+  __syncthreads();
   bool failed = false;
 #pragma unroll
   for (int k = 0; k < NB; k++) {
@@ -135,29 +130,69 @@ __device__ __forceinline__ bool potrf64_regs(const double* __restrict__ A, int l
   return failed;
 }
 
-// Every block factors the nb x nb diagonal block (redundantly: it is 64^3/3 flop), block 0 writes it back; then the
-// row panel  P = R_kk^-T A_panel  is solved ON THE MATRIX CORES, 16 rows at a time:
-//     T_g = A_g - sum_{i<g} R_ig^T X_i          (v_mfma_f64_16x16x4_f64, K = 16 per finished group)
-//     X_g = inv(R_gg)^T T_g                     (only the four 16x16 diagonal blocks are inverted, in LDS)
-// A wave owns 64 columns (4 column tiles) and keeps all X_g tiles in registers: the f64 C/D layout
-// (row = (lane>>4) + 4*reg, col = lane&15) IS the B-operand layout of k-step `reg`, so finished tiles feed the
-// next products without any LDS round trip.
+// One 64-row step of the panel factorisation, LEFT-LOOKING inside the current 256-row outer panel [ko, ko+256):
+// rows [k, k+nb) have received the trailing updates of all previous OUTER panels, but not yet those of the inner
+// steps ko..k of this outer panel (kprev = k - ko finished rows).  Every workgroup (4 waves, 64 columns) does:
+//   1. stage  Pj = R[ko..k, k..k+64)  (kprev x 64, <= 96 KB) in LDS
+//   2. D = A[k.., k..] - Pj^T Pj  on the matrix cores (redundantly per workgroup), potrf64 in registers/LDS,
+//      invert the four 16x16 diagonal blocks; workgroup 0 writes R_kk back
+//   3. its 64 columns:  T = A[k.., cols] - Pj^T R[ko..k, cols]   (MFMA, K = kprev),  X_g = inv(R_gg)^T (T_g - sum_{i<g} R_ig^T X_i)
+//      with finished X tiles fed back as B operands straight from the accumulator registers (f64 C/D layout
+//      row = (lane>>4) + 4*reg, col = lane&15  ==  B layout of k-step `reg`).
+// This removes the separate K = 64 "strip" updates (one launch + one pass over the panel rows each).
+#define PANEL_MAXPREV 192
 template <int NB>
-__global__ __launch_bounds__(256) void potrf_trsm_kernel(double* __restrict__ A, int ld, int n, int nf, int k0, int nb, int front_id,
-                                                          int* __restrict__ status) {
-  __shared__ __attribute__((aligned(16))) double D[NB][POTRF_LDW];
-  __shared__ double rowbuf[2][NB];
-  __shared__ double piv[NB];
-  __shared__ double I16[4][16][17];
-  const int tid = threadIdx.x;
-  bool failed = potrf64_regs<NB>(A, ld, k0, nb, D, rowbuf, piv);
+__global__ __launch_bounds__(256) void panel_fused_kernel(double* __restrict__ A, int ld, int n, int nf, int ko, int k, int nb, int front_id,
+                                                           int* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) double psm[];
+  double(*D)[POTRF_LDW] = (double(*)[POTRF_LDW])psm;                 // [NB][POTRF_LDW]
+  double(*rowbuf)[NB] = (double(*)[NB])(psm + NB * POTRF_LDW);       // [2][NB]
+  double* piv = psm + NB * POTRF_LDW + 2 * NB;                        // [NB]
+  double(*I16)[16][17] = (double(*)[16][17])(piv + NB);               // [4][16][17]
+  double(*Pj)[NB + 2] = (double(*)[NB + 2])(piv + NB + 4 * 16 * 17);  // [kprev][NB + 2]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kk = lane >> 4, cc = lane & 15;
+  const int kprev = k - ko;
+  const double* Pko = A + (size_t)ko * ld;
+  // ---- 1. stage Pj (columns k..k+63 of the finished rows of this outer panel); columns >= k+nb are never used un-masked
+  for (int idx = tid; idx < kprev * NB; idx += 256) {
+    const int q = idx >> 6, c = idx & 63;
+    Pj[q][c] = (c < nb) ? Pko[(size_t)q * ld + k + c] : 0.0;
+  }
+  __syncthreads();
+  // ---- 2. updated diagonal block: wave w computes tile row w (tiles (w, bt), bt >= w), writes it into D (identity-padded)
+  {
+    double4_t acc[4];
+#pragma unroll
+    for (int bt = 0; bt < 4; bt++) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int a = 16 * wave + kk + 4 * r, b = 16 * bt + cc;
+        const double v = A[(size_t)(k + min(a, nb - 1)) * ld + k + min(b, nb - 1)];  // branch-free: clamped address + select
+        acc[bt][r] = (a < nb && b < nb) ? v : ((a == b) ? 1.0 : 0.0);
+      }
+    }
+    for (int q = 0; q < kprev; q += 4) {
+      const double af = -Pj[q + kk][16 * wave + cc];
+#pragma unroll
+      for (int bt = 0; bt < 4; bt++) {
+        const double bf = Pj[q + kk][16 * bt + cc];
+        acc[bt] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc[bt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int bt = 0; bt < 4; bt++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) D[16 * wave + kk + 4 * r][16 * bt + cc] = acc[bt][r];
+  }
+  __syncthreads();
+  bool failed = potrf64_lds<NB>(D, rowbuf, piv);
   if (blockIdx.x == 0) {
     for (int idx = tid; idx < nb * nb; idx += 256) {
       const int p = idx / nb, q = idx - p * nb;
-      if (q >= p) A[(size_t)(k0 + p) * ld + k0 + q] = D[p][q];
+      if (q >= p) A[(size_t)(k + p) * ld + k + q] = D[p][q];
     }
     if (tid == 0) {
-      if (k0 + nb >= nf) {  // last panel: pivot-exponent test, gtsam/base/cholesky.cpp:146-158
+      if (k + nb >= nf) {  // last panel: pivot-exponent test, gtsam/base/cholesky.cpp:146-158
         if (nf >= 2) {
           const double r1 = D[nb - 1][nb - 1];
           const double r2 = (nb >= 2) ? D[nb - 2][nb - 2] : A[(size_t)(nf - 2) * ld + nf - 2];
@@ -177,60 +212,64 @@ __global__ __launch_bounds__(256) void potrf_trsm_kernel(double* __restrict__ A,
     for (int i = 15; i >= 0; i--) {
       double sacc = (i == j) ? 1.0 : 0.0;
 #pragma unroll
-      for (int k = i + 1; k < 16; k++) sacc -= D[base + i][base + k] * x[k];
+      for (int kq = i + 1; kq < 16; kq++) sacc -= D[base + i][base + kq] * x[kq];
       x[i] = (i <= j) ? sacc / D[base + i][base + i] : 0.0;
     }
 #pragma unroll
     for (int i = 0; i < 16; i++) I16[blk][i][j] = x[i];
   }
   __syncthreads();
-  const int wave = tid >> 6, lane = tid & 63, kk = lane >> 4, cc = lane & 15;
-  const int c0 = k0 + nb + blockIdx.x * 256 + wave * 64;
+  // ---- 3. this wave's 16 columns of the row panel
+  const int c0 = k + nb + blockIdx.x * 64 + wave * 16;
   if (c0 >= n) return;
-  double* P = A + (size_t)k0 * ld;
-  double4_t X[4][4];
+  const int col = min(c0 + cc, n - 1);
+  double* P = A + (size_t)k * ld;
+  double4_t T[4];
 #pragma unroll
-  for (int g = 0; g < 4; g++) {
-    double4_t acc[4];
+  for (int g = 0; g < 4; g++)
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
-      const int col = min(c0 + 16 * t + cc, n - 1);
+    for (int r = 0; r < 4; r++) {
+      const int row = 16 * g + kk + 4 * r;
+      const double v = P[(size_t)min(row, nb - 1) * ld + col];
+      T[g][r] = (row < nb) ? v : 0.0;
+    }
+  // left-looking update with the finished rows of this outer panel: B fragments straight from HBM/L2, 16 k-steps in flight
+  for (int q0 = 0; q0 < kprev; q0 += 64) {
+    double bq[16];
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int row = 16 * g + kk + 4 * r;
-        const double v = P[(size_t)min(row, nb - 1) * ld + col];
-        acc[t][r] = (row < nb) ? v : 0.0;
+    for (int sx = 0; sx < 16; sx++) bq[sx] = Pko[(size_t)(q0 + 4 * sx + kk) * ld + col];
+#pragma unroll
+    for (int sx = 0; sx < 16; sx++) {
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const double af = -Pj[q0 + 4 * sx + kk][16 * g + cc];
+        T[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bq[sx], T[g], 0, 0, 0);
       }
     }
+  }
+  double4_t X[4];
+#pragma unroll
+  for (int g = 0; g < 4; g++) {
+    double4_t acc = T[g];
 #pragma unroll
     for (int i = 0; i < g; i++)
 #pragma unroll
       for (int sx = 0; sx < 4; sx++) {
         const double af = -D[16 * i + 4 * sx + kk][16 * g + cc];
-#pragma unroll
-        for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, X[i][t][sx], acc[t], 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af, X[i][sx], acc, 0, 0, 0);
       }
-    double4_t out[4];
+    double4_t out = double4_t{0, 0, 0, 0};
 #pragma unroll
-    for (int t = 0; t < 4; t++) out[t] = double4_t{0, 0, 0, 0};
+    for (int sx = 0; sx < 4; sx++) out = __builtin_amdgcn_mfma_f64_16x16x4f64(I16[g][4 * sx + kk][cc], acc[sx], out, 0, 0, 0);
+    X[g] = out;
 #pragma unroll
-    for (int sx = 0; sx < 4; sx++) {
-      const double af = I16[g][4 * sx + kk][cc];
-#pragma unroll
-      for (int t = 0; t < 4; t++) out[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, acc[t][sx], out[t], 0, 0, 0);
-    }
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-      X[g][t] = out[t];
-      const int col = c0 + 16 * t + cc;
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int row = 16 * g + kk + 4 * r;
-        if (row < nb && col < n) P[(size_t)row * ld + col] = out[t][r];
-      }
+    for (int r = 0; r < 4; r++) {
+      const int row = 16 * g + kk + 4 * r;
+      if (row < nb && c0 + cc < n) P[(size_t)row * ld + c0 + cc] = out[r];
     }
   }
 }
+#define PANEL_LDS_BYTES ((64 * POTRF_LDW + 2 * 64 + 64 + 4 * 16 * 17 + PANEL_MAXPREV * 66) * 8)
 
 // ---------------------------------------------------------------- trailing update on the matrix cores
 // C[i][j] -= sum_{p < kp} P[p][i] P[p][j]   for r0 <= i < r1, i <= j < n,   P = rows p0 .. p0+kp-1 of A (finished [R S d] rows).

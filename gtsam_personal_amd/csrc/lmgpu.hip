@@ -179,6 +179,7 @@ struct lmgpu_handle {
   lmgpu_timings tim{};
   hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   KTimer kt;
+  int la_debug = 0;  // LMGPU_LA_DEBUG: 1 = device-sync after every enqueue, 2 = after every outer panel (bisecting aid)
   bool lookahead = false;  // LMGPU_LOOKAHEAD=1: experimental two-stream look-ahead (measured r01: wrong results for >1 outer panel; off)
 
   ncclComm_t comm = nullptr;
@@ -413,19 +414,24 @@ int do_eliminate(lmgpu_handle* h, double lambda) {
         for (int k = k0; k < kend; k += NB) {  // P_i
           const int nb = std::min(NB, kend - k);
           const int cols = F.n - k - nb;
-          const int g = std::max(1, (cols + 255) / 256);
+          const int g = std::max(1, (cols + 63) / 64);
           kt = h->kt.begin(LMGPU_KT_PANEL, sA);
-          hipLaunchKernelGGL((potrf_trsm_kernel<NB>), dim3(g), dim3(256), 0, sA, A, ld, F.n, F.nf, k, nb, F.id, h->d_status);
-          h->kt.end(kt, sA, (double)nb * nb * nb / 3.0 + (double)nb * nb * cols);
-          syrk(sA, k, nb, k + nb, kend);  // rest of the outer panel's rows
+          hipLaunchKernelGGL((panel_fused_kernel<NB>), dim3(g), dim3(256), PANEL_LDS_BYTES, sA, A, ld, F.n, F.nf, k0, k, nb, F.id, h->d_status);
+          h->kt.end(kt, sA, (double)nb * nb * nb / 3.0 + (double)nb * nb * cols + 2.0 * (k - k0) * nb * (cols + nb));
         }
         HIPCHECK(hipEventRecord(evP, sA));
+        if (h->la_debug == 1) HIPCHECK(hipDeviceSynchronize());
         const int next_end = std::min(F.n, kend + NBO);  // rows of panel i+1 (or the separator rows if this was the last panel)
         if (i > 0) HIPCHECK(hipStreamWaitEvent(sA, h->la_events[2 * (i - 1) + 1], 0));
         syrk(sA, k0, kend - k0, kend, next_end);  // UA_i
+        if (h->la_debug == 1) HIPCHECK(hipDeviceSynchronize());
+        if (h->la_debug == 5) HIPCHECK(hipEventRecord(evP, sA));  // level 5: UB_i waits for UA_i too (only UB_i || P_{i+1} overlaps)
         HIPCHECK(hipStreamWaitEvent(sB, evP, 0));
         syrk(sB, k0, kend - k0, next_end, F.n);   // UB_i
         HIPCHECK(hipEventRecord(evUB, sB));
+        if (h->la_debug == 1 || h->la_debug == 2) HIPCHECK(hipDeviceSynchronize());
+        if (h->la_debug == 3) HIPCHECK(hipStreamWaitEvent(sA, evUB, 0));  // event-only serialisation (no overlap, no host sync)
+        if (h->la_debug == 4) HIPCHECK(hipStreamWaitEvent(sA, evUB, 0));  // level 4: same as 3 here (UA_i || UB_i still overlaps: UA_i was enqueued before)
       }
       HIPCHECK(hipStreamWaitEvent(sA, h->la_events[2 * (np - 1) + 1], 0));  // join
     }
@@ -670,6 +676,7 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
   if (h->cfg.world_size < 1) h->cfg.world_size = 1;
   h->device = cfg->device;
   h->lookahead = getenv("LMGPU_LOOKAHEAD") != nullptr;
+  h->la_debug = getenv("LMGPU_LA_DEBUG") ? atoi(getenv("LMGPU_LA_DEBUG")) : 0;
   *out = h;
   if (h->device >= 0) {
     HIPCHECK(hipSetDevice(h->device));
@@ -680,6 +687,7 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
     HIPCHECK(hipHostMalloc((void**)&h->h_status, sizeof(int), hipHostMallocDefault));
     HIPCHECK(hipFuncSetAttribute((const void*)lds_front_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra));
     HIPCHECK(hipFuncSetAttribute((const void*)syrk_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSyrkLds));
+    HIPCHECK(hipFuncSetAttribute((const void*)panel_fused_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS_BYTES));
   }
   return LMGPU_OK;
 }

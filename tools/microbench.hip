@@ -66,16 +66,16 @@ int main(int argc, char** argv) {
     }
     printf("%-44s best %9.1f us   avg %9.1f us\n", name, best * 1e3, tot / reps * 1e3);
   };
-  // 1. panel kernel at several trailing widths
-  for (int k0 : {0, 4096, 8192}) {
-    const int cols = n - k0 - 64;
-    const int g = (cols + 255) / 256;
-    char nm[128];
-    snprintf(nm, sizeof nm, "potrf_trsm<64>  k0=%d cols=%d blocks=%d", k0, cols, g);
-    timeit(nm, 5, [&]() { hipLaunchKernelGGL((potrf_trsm_kernel<64>), dim3(g), dim3(256), 0, 0, A, ld, n, n - 1, k0, 64, 0, status); });
-  }
-  timeit("potrf only (1 block, no columns)", 5,
-         [&]() { hipLaunchKernelGGL((potrf_trsm_kernel<64>), dim3(1), dim3(256), 0, 0, A, ld, 64 + 64, 64, 0, 64, 0, status); });
+  // 1. fused panel kernel at several trailing widths, without (kprev = 0) and with (kprev = 192) left-looking work
+  CK(hipFuncSetAttribute((const void*)panel_fused_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS_BYTES));
+  for (int kprev : {0, 192})
+    for (int k0 : {256, 4352, 8192}) {
+      const int cols = n - k0 - 64;
+      const int g = (cols + 63) / 64;
+      char nm[128];
+      snprintf(nm, sizeof nm, "panel_fused<64> k=%d kprev=%d cols=%d blocks=%d", k0, kprev, cols, g);
+      timeit(nm, 5, [&]() { hipLaunchKernelGGL((panel_fused_kernel<64>), dim3(g), dim3(256), PANEL_LDS_BYTES, 0, A, ld, n, n - 1, k0 - kprev, k0, 64, 0, status); });
+    }
   // 3. strip updates (K = 64, <= 192 rows) and big updates (K = 256) at several trailing sizes
   for (int r0 : {64, 4160, 8256}) {
     char nm[128];
