@@ -58,25 +58,36 @@ struct LFac {
   int32_t off, sz;
 };
 
-// grid: one block per front in `list`; dynamic LDS = nmax*nmax doubles (the front) + LDSF_JCAP doubles (staged Jacobians)
-// + LDSF_MAXB staged factor descriptors + 4 ints.  Lanes run along the contiguous (column) index of the row-major front,
-// waves along rows.
+// grid: one block per front in `list`; dynamic LDS = srows*nmax (+8) doubles (the front) + LDSF_JCAP doubles (staged
+// Jacobians) + LDSF_MAXB staged factor descriptors + 4 ints.  Lanes run along the contiguous (column) index of the
+// row-major front, waves along rows.  GATHER fronts (leaves whose HBM parent gathers their update itself,
+// kernels_schur.hpp) only keep their nf frontal rows and the (rhs, rhs) corner: srows = max nf of the launch, which
+// lets ~7 workgroups share a CU instead of 2.
 #define LDSF_JCAP 704
 #define LDSF_MAXB 32
 #define LDSF_EXTRA_BYTES (LDSF_JCAP * 8 + LDSF_MAXB * 32 + 16)
+template <bool GATHER>
 __global__ __launch_bounds__(256) void lds_front_kernel(const int32_t* __restrict__ list, const FrontDesc* __restrict__ fronts,
                                                          const FrontFac* __restrict__ ffac, const FacDesc* __restrict__ fd,
                                                          const ChildRef* __restrict__ childs, const int32_t* __restrict__ cmap,
                                                          const int32_t* __restrict__ fxoff, double* __restrict__ pool, double lambda,
-                                                         const double* __restrict__ dampw, int* __restrict__ status, int nmax) {
+                                                         const double* __restrict__ dampw, int* __restrict__ status, int nmax, int srows,
+                                                         double* __restrict__ gcorner) {
   extern __shared__ double S[];
-  double* Jb = S + (size_t)nmax * nmax;
+  double* corner_g = S + (size_t)srows * nmax;  // GATHER: the (rhs, rhs) entry lives here
+  double* Jb = corner_g + 8;
   LFac* LF = (LFac*)(Jb + LDSF_JCAP);
   int* meta = (int*)(LF + LDSF_MAXB);
   const FrontDesc F = fronts[list[blockIdx.x]];
   const int n = F.n, nf = F.nf, tid = threadIdx.x, nt = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
-  for (int i = tid; i < n * n; i += nt) S[i] = 0.0;
+  // gather mode (par_ld < 0): the parent assembles this leaf's update itself from [R S d] (kernels_schur.hpp); only the
+  // frontal rows and the (rhs, rhs) corner of the trailing block are needed here
+  constexpr bool gather = GATHER;
+  const int urows = gather ? nf : n;
+  double* corner = gather ? corner_g : &S[(n - 1) * n + n - 1];
+  for (int i = tid; i < urows * n; i += nt) S[i] = 0.0;
+  if (gather && tid == 0) *corner = 0.0;
   // ---- own factors: S += [A b]^T [A b].  Descriptors and Jacobians are staged through LDS in batches: all the
   //      dependent HBM reads (list -> front -> factor -> Jacobian) of a batch are in flight together.
   for (int k0 = 0; k0 < F.fac_count;) {
@@ -127,7 +138,10 @@ __global__ __launch_bounds__(256) void lds_front_kernel(const int32_t* __restric
           for (int r = 0; r < m; r++) v += J[p * m + r] * J[q * m + r];
           const int gq = (q < d.d0) ? d.c0 + q : (q < d.d0 + d.d1 ? d.c1 + (q - d.d0) : n - 1);
           const int lo = gp < gq ? gp : gq, hi = gp < gq ? gq : gp;
-          S[lo * n + hi] += v;
+          if (!gather || lo < nf)
+            S[lo * n + hi] += v;
+          else if (lo == n - 1)
+            *corner += v;  // (b, b): exactly one lane per factor
         }
       }
       __syncthreads();
@@ -164,8 +178,11 @@ __global__ __launch_bounds__(256) void lds_front_kernel(const int32_t* __restric
     const double r = sqrt(piv), inv = 1.0 / r;
     for (int j = k + 1 + tid; j < n; j += nt) S[k * n + j] *= inv;
     __syncthreads();  // row k scaled; every thread has read the pivot
-    if (tid == 0) S[k * n + k] = r;
-    for (int i = k + 1 + wave; i < n; i += nw) {
+    if (tid == 0) {
+      S[k * n + k] = r;
+      if (gather) *corner -= S[k * n + n - 1] * S[k * n + n - 1];
+    }
+    for (int i = k + 1 + wave; i < urows; i += nw) {
       const double rki = S[k * n + i];
       for (int j = i + lane; j < n; j += 64) S[i * n + j] -= rki * S[k * n + j];
     }
@@ -185,7 +202,9 @@ __global__ __launch_bounds__(256) void lds_front_kernel(const int32_t* __restric
   for (int i = wave; i < nf; i += nw)
     for (int j = lane; j < n; j += 64) RSd[(size_t)i * F.ld_rsd + j] = (j >= i) ? S[i * n + j] : 0.0;
   const int m = n - nf;
-  if (F.par_ld > 0) {
+  if (gather) {
+    if (tid == 0) gcorner[F.par_map] = *corner;
+  } else if (F.par_ld > 0) {
     // scatter-add straight into the parent HBM front (extend-add, a12); the column map is staged in the free Jacobian area
     int* pm = (int*)Jb;
     for (int i = tid; i < m; i += nt) pm[i] = cmap[F.par_map + i];

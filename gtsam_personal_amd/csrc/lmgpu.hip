@@ -24,6 +24,7 @@
 
 #include "../../include/lmgpu.h"
 #include "kernels_dense.hpp"
+#include "kernels_schur.hpp"
 #include "plan.hpp"
 
 using namespace lmgpu;
@@ -65,7 +66,8 @@ struct Bucket {
 struct LevelWork {
   // LDS fronts of this level, grouped by LDS-size bin: [bin_begin[b], bin_begin[b+1]) inside the level's list
   int list_begin = 0, list_count = 0;
-  int bin_begin[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int bin_begin[16] = {0};
+  int bin_srows[16] = {0};  // rows of the front kept in LDS for the bin's launch
   std::vector<int> hbm;  // HBM fronts of this level
 };
 
@@ -118,7 +120,7 @@ struct KTimer {
 };
 
 const int kBinN[6] = {24, 48, 72, 96, 120, 139};  // 139^2 * 8 + staging = 162.5 KB <= 160 KiB of LDS per workgroup
-const int kNumBins = 6;
+const int kNumBins = 12;  // 0..5: LDS fronts by size; 6..11: the same sizes for GATHER leaves (only nf rows in LDS)
 const int kLdsLimitN = 139;
 const int kLdsFrontExtra = LDSF_EXTRA_BYTES;
 const int NB = 64;    // potrf / trsm step
@@ -167,6 +169,16 @@ struct lmgpu_handle {
   int32_t *d_cmap = nullptr, *d_fxoff = nullptr, *d_sxoff = nullptr, *d_lists = nullptr;
   int32_t *d_scalar_var = nullptr, *d_scalar_col = nullptr, *d_vi_ptr = nullptr, *d_vi_fac = nullptr;
   int8_t* d_vi_pos = nullptr;
+  // gather-mode (Schur form) assembly of HBM fronts from their leaf children
+  struct GatherRange {
+    int pblk_begin = 0, pblk_short = 0, pblk_long = 0, vblk_begin = 0, vblk_count = 0, leaf_begin = 0, leaf_count = 0;  // short blocks first
+  };
+  std::vector<GatherRange> gather;  // per front (only HBM fronts have non-empty ranges)
+  GPairBlock* d_gpblk = nullptr;
+  GPairEntry* d_gpent = nullptr;
+  GVarBlock* d_gvblk = nullptr;
+  GVarEntry* d_gvent = nullptr;
+  double* d_gcorner = nullptr;
   std::vector<FrontDesc> h_fronts;
   std::vector<int64_t> f_off;  // HBM fronts: pool offset of the dense front (else -1)
   std::vector<int> f_ld;
@@ -356,13 +368,20 @@ int do_eliminate(lmgpu_handle* h, double lambda) {
     for (int b = 0; b < kNumBins; b++) {
       const int cnt = L.bin_begin[b + 1] - L.bin_begin[b];
       if (cnt == 0) continue;
-      const int nmax = kBinN[b];
-      const int threads = (b == 0) ? 64 : (b == 1 ? 128 : 256);
+      const int nmax = kBinN[b % 6], srows = L.bin_srows[b];
+      const int threads = (b % 6 == 0) ? 64 : (b % 6 == 1 ? 128 : 256);
+      const size_t lds = kLdsFrontExtra + 64 + (size_t)srows * nmax * sizeof(double);
       const int kt = h->kt.begin(LMGPU_KT_LDS_FRONT, s);
-      hipLaunchKernelGGL(lds_front_kernel, dim3(cnt), dim3(threads), kLdsFrontExtra + (size_t)nmax * nmax * sizeof(double), s,
-                         (const int32_t*)(h->d_lists + L.list_begin + L.bin_begin[b]), (const FrontDesc*)h->d_fronts,
-                         (const FrontFac*)h->d_ffac, (const FacDesc*)h->d_fd, (const ChildRef*)h->d_childs, (const int32_t*)h->d_cmap,
-                         (const int32_t*)h->d_fxoff, h->pool, lambda, (const double*)h->dampw, h->d_status, nmax);
+      if (b < 6)
+        hipLaunchKernelGGL(lds_front_kernel<false>, dim3(cnt), dim3(threads), lds, s,
+                           (const int32_t*)(h->d_lists + L.list_begin + L.bin_begin[b]), (const FrontDesc*)h->d_fronts,
+                           (const FrontFac*)h->d_ffac, (const FacDesc*)h->d_fd, (const ChildRef*)h->d_childs, (const int32_t*)h->d_cmap,
+                           (const int32_t*)h->d_fxoff, h->pool, lambda, (const double*)h->dampw, h->d_status, nmax, srows, h->d_gcorner);
+      else
+        hipLaunchKernelGGL(lds_front_kernel<true>, dim3(cnt), dim3(threads), lds, s,
+                           (const int32_t*)(h->d_lists + L.list_begin + L.bin_begin[b]), (const FrontDesc*)h->d_fronts,
+                           (const FrontFac*)h->d_ffac, (const FacDesc*)h->d_fd, (const ChildRef*)h->d_childs, (const int32_t*)h->d_cmap,
+                           (const int32_t*)h->d_fxoff, h->pool, lambda, (const double*)h->dampw, h->d_status, nmax, srows, h->d_gcorner);
       h->kt.end(kt, s);
     }
     for (int fi : L.hbm) {
@@ -378,6 +397,22 @@ int do_eliminate(lmgpu_handle* h, double lambda) {
       if (F.child_count > 0)
         hipLaunchKernelGGL(hbm_assemble_children_kernel, dim3(F.child_count), dim3(256), 0, s, F, off, ld, (const ChildRef*)h->d_childs,
                            (const int32_t*)h->d_cmap, h->pool);
+      {  // leaf children in Schur form: deterministic gather instead of atomics
+        const lmgpu_handle::GatherRange& G = h->gather[fi];
+        if (G.pblk_short > 0)
+          hipLaunchKernelGGL((schur_pairs_kernel<1>), dim3(G.pblk_short), dim3(64), 0, s, (const GPairBlock*)(h->d_gpblk + G.pblk_begin),
+                             (const GPairEntry*)h->d_gpent, h->pool, off, ld);
+        if (G.pblk_long > 0)
+          hipLaunchKernelGGL((schur_pairs_kernel<4>), dim3(G.pblk_long), dim3(256), 0, s,
+                             (const GPairBlock*)(h->d_gpblk + G.pblk_begin + G.pblk_short), (const GPairEntry*)h->d_gpent, h->pool, off, ld);
+        if (G.vblk_count > 0)
+          hipLaunchKernelGGL(schur_factor_kernel, dim3(G.vblk_count), dim3(64 * SCHUR_FW), 0, s, (const GVarBlock*)(h->d_gvblk + G.vblk_begin),
+                             (const GVarEntry*)h->d_gvent, h->pool, off, ld, F.n);
+        if (G.leaf_count > 0) {
+          reduce_to(h, h->d_gcorner + G.leaf_begin, G.leaf_count, h->dscal + 4);
+          hipLaunchKernelGGL(add_scalar_kernel, dim3(1), dim3(1), 0, s, A + (size_t)(F.n - 1) * ld + F.n - 1, (const double*)(h->dscal + 4));
+        }
+      }
       if (own_terms)
         hipLaunchKernelGGL(hbm_damp_kernel, dim3((F.nf + 255) / 256), dim3(256), 0, s, F, off, ld, (const int32_t*)h->d_fxoff, h->pool, lambda,
                            (const double*)h->dampw);
@@ -685,7 +720,8 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
     for (int i = 0; i < 8; i++) HIPCHECK(hipEventCreate(&h->ev[i]));
     HIPCHECK(hipHostMalloc((void**)&h->h_scal, 8 * sizeof(double), hipHostMallocDefault));
     HIPCHECK(hipHostMalloc((void**)&h->h_status, sizeof(int), hipHostMallocDefault));
-    HIPCHECK(hipFuncSetAttribute((const void*)lds_front_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra));
+    HIPCHECK(hipFuncSetAttribute((const void*)lds_front_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra + 64));
+    HIPCHECK(hipFuncSetAttribute((const void*)lds_front_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra + 64));
     HIPCHECK(hipFuncSetAttribute((const void*)syrk_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSyrkLds));
     HIPCHECK(hipFuncSetAttribute((const void*)panel_fused_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS_BYTES));
   }
@@ -719,6 +755,7 @@ int lmgpu_destroy(lmgpu_handle* h) {
     for (hipEvent_t e : h->kt.pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->la_events) (void)hipEventDestroy(e);
     fr(h->bs_inv); fr(h->bs_x); fr(h->bs_flags);
+    fr(h->d_gpblk); fr(h->d_gpent); fr(h->d_gvblk); fr(h->d_gvent); fr(h->d_gcorner);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
   }
@@ -865,6 +902,24 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
     d.x1 = f.slots[1] >= 0 ? P.xoff[f.slots[1]] : -1;
     fd[h->fac_local[i]] = d;
   }
+  struct GPairTmp {
+    int64_t key;
+    int16_t da, db;
+    GPairEntry ent;
+  };
+  struct GVarTmp {
+    int32_t pv;
+    int16_t dv;
+    GVarEntry ent;
+  };
+  int n_gleaf = 0;
+  std::vector<GPairTmp> gp_tmp;
+  std::vector<GVarTmp> gv_tmp;
+  std::vector<GPairBlock> gpblk;
+  std::vector<GPairEntry> gpent;
+  std::vector<GVarBlock> gvblk;
+  std::vector<GVarEntry> gvent;
+  h->gather.assign(NF, lmgpu_handle::GatherRange());
   std::vector<FrontFac> ffac;
   std::vector<ChildRef> childs;
   std::vector<int32_t> cmap, fxoff, sxoff;
@@ -883,10 +938,13 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
       F.rsd_off = off;
       off += (int64_t)fr.nf * fr.n;
       F.ld_u = fr.n - fr.nf;
-      // an LDS front whose parent lives in HBM scatters its update straight into the parent (no update matrix in HBM)
+      // an LDS front whose parent lives in HBM hands its update over without an update matrix in HBM:
+      //   leaves (no children): the parent GATHERS -[S d]^T [S d] and the factor terms itself (kernels_schur.hpp), par_ld = -1
+      //   others: scattered straight into the parent with FP64 atomics (par_ld > 0, filled in when the parent is laid out)
       const bool direct = fr.parent >= 0 && P.fronts[fr.parent].cls == 1;
       if (direct) {
         F.u_off = -1;
+        if (fr.children.empty() && !getenv("LMGPU_NO_GATHER")) F.par_ld = -1;
       } else {
         F.u_off = off;
         off += (int64_t)F.ld_u * F.ld_u;
@@ -923,6 +981,37 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
       for (size_t k = ch.n_frontal_vars; k < ch.vars.size(); k++)
         for (int d = 0; d < P.dims[ch.vars[k]]; d++) cmap.push_back(colof[ch.vars[k]] + d);
       cmap.push_back(fr.n - 1);
+      if (CF.u_off < 0 && CF.par_ld < 0) {  // gather-mode leaf: register its S blocks and factors with this (HBM) front
+        cmap.resize(map_begin);
+        lmgpu_handle::GatherRange& G = h->gather[fi];
+        const int li = n_gleaf++;
+        if (G.leaf_count == 0) G.leaf_begin = li;
+        G.leaf_count++;
+        CF.par_map = li;  // index of its corner scalar
+        struct Ent {
+          int pc, lc, d;
+        };
+        std::vector<Ent> ents;
+        for (size_t k = ch.n_frontal_vars; k < ch.vars.size(); k++) ents.push_back({colof[ch.vars[k]], ch.col_off[k], P.dims[ch.vars[k]]});
+        ents.push_back({fr.n - 1, ch.n - 1, 1});
+        for (size_t x = 0; x < ents.size(); x++)
+          for (size_t y = x; y < ents.size(); y++) {
+            if (x + 1 == ents.size()) continue;  // (rhs, rhs): the corner goes through the scalar reduction
+            Ent a = ents[x], b = ents[y];
+            if (a.pc > b.pc) std::swap(a, b);
+            gp_tmp.push_back(GPairTmp{((int64_t)a.pc << 32) | (uint32_t)b.pc, (int16_t)a.d, (int16_t)b.d,
+                                      GPairEntry{CF.rsd_off, (int16_t)a.lc, (int16_t)b.lc, (int16_t)ch.nf, (int16_t)CF.ld_rsd}});
+          }
+        for (int32_t f : ch.factors)
+          for (int pos = 0; pos < 2; pos++) {
+            const int v = P.factors[f].slots[pos];
+            if (v < 0 || P.front_of_var[v] == c) continue;  // frontal in the leaf: no separator contribution
+            const FacDesc& fdd = fd[h->fac_local[f]];
+            gv_tmp.push_back(GVarTmp{colof[v], (int16_t)P.dims[v],
+                                     GVarEntry{fdd.joff, fdd.rows, (int16_t)(pos == 0 ? 0 : fdd.d0), (int16_t)(fdd.d0 + fdd.d1), 0}});
+          }
+        continue;
+      }
       if (CF.u_off < 0) {  // direct scatter child: tell it where its parent is
         CF.par_off = h->f_off[fi];
         CF.par_ld = h->f_ld[fi];
@@ -937,6 +1026,36 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
       childs.push_back(cr);
     }
     F.child_count = (int)childs.size() - F.child_begin;
+    if (!gp_tmp.empty() || !gv_tmp.empty()) {
+      lmgpu_handle::GatherRange& G = h->gather[fi];
+      std::stable_sort(gp_tmp.begin(), gp_tmp.end(), [](const GPairTmp& a, const GPairTmp& b) { return a.key < b.key; });
+      G.pblk_begin = (int)gpblk.size();
+      std::vector<GPairBlock> longs;
+      for (size_t i = 0; i < gp_tmp.size();) {
+        size_t j = i;
+        while (j < gp_tmp.size() && gp_tmp[j].key == gp_tmp[i].key) j++;
+        const GPairBlock blk{(int32_t)(gp_tmp[i].key >> 32), (int32_t)(gp_tmp[i].key & 0xffffffff), gp_tmp[i].da, gp_tmp[i].db,
+                             (int32_t)gpent.size(), (int32_t)(j - i)};
+        if (j - i <= 32) gpblk.push_back(blk); else longs.push_back(blk);
+        for (size_t e = i; e < j; e++) gpent.push_back(gp_tmp[e].ent);
+        i = j;
+      }
+      G.pblk_short = (int)gpblk.size() - G.pblk_begin;
+      G.pblk_long = (int)longs.size();
+      gpblk.insert(gpblk.end(), longs.begin(), longs.end());
+      std::stable_sort(gv_tmp.begin(), gv_tmp.end(), [](const GVarTmp& a, const GVarTmp& b) { return a.pv < b.pv; });
+      G.vblk_begin = (int)gvblk.size();
+      for (size_t i = 0; i < gv_tmp.size();) {
+        size_t j = i;
+        while (j < gv_tmp.size() && gv_tmp[j].pv == gv_tmp[i].pv) j++;
+        gvblk.push_back(GVarBlock{gv_tmp[i].pv, gv_tmp[i].dv, 0, (int32_t)gvent.size(), (int32_t)(j - i)});
+        for (size_t e = i; e < j; e++) gvent.push_back(gv_tmp[e].ent);
+        i = j;
+      }
+      G.vblk_count = (int)gvblk.size() - G.vblk_begin;
+      std::vector<GPairTmp>().swap(gp_tmp);
+      std::vector<GVarTmp>().swap(gv_tmp);
+    }
     F.fx_begin = (int)fxoff.size();
     for (int k = 0; k < fr.n_frontal_vars; k++)
       for (int d = 0; d < P.dims[fr.vars[k]]; d++) fxoff.push_back(P.xoff[fr.vars[k]] + d);
@@ -956,6 +1075,7 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
     } else {
       int b = 0;
       while (fr.n > kBinN[b]) b++;
+      if (h->h_fronts[fi].par_ld < 0) b += 6;  // gather leaf
       byLevelBin[fr.level][b].push_back(fi);
     }
   }
@@ -966,6 +1086,12 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
     int c = 0;
     for (int b = 0; b < kNumBins; b++) {
       L.bin_begin[b] = c;
+      L.bin_srows[b] = kBinN[b % 6];
+      if (b >= 6) {
+        int mx = 1;
+        for (int fi : byLevelBin[l][b]) mx = std::max(mx, P.fronts[fi].nf);
+        L.bin_srows[b] = mx;
+      }
       for (int fi : byLevelBin[l][b]) lists.push_back(fi);
       c += (int)byLevelBin[l][b].size();
     }
@@ -987,6 +1113,11 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
   if ((rc = upload(h, &h->d_fxoff, fxoff))) return rc;
   if ((rc = upload(h, &h->d_sxoff, sxoff))) return rc;
   if ((rc = upload(h, &h->d_lists, lists))) return rc;
+  if ((rc = upload(h, &h->d_gpblk, gpblk))) return rc;
+  if ((rc = upload(h, &h->d_gpent, gpent))) return rc;
+  if ((rc = upload(h, &h->d_gvblk, gvblk))) return rc;
+  if ((rc = upload(h, &h->d_gvent, gvent))) return rc;
+  HIPCHECK(hipMalloc((void**)&h->d_gcorner, std::max<size_t>(1, (size_t)n_gleaf) * sizeof(double)));
   // per-bucket arrays, compacted to this rank's factors
   {
     std::vector<std::vector<int32_t>> epos(h->buckets.size());
