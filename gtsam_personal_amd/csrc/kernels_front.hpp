@@ -204,6 +204,12 @@ __global__ __launch_bounds__(256) void lds_front_kernel(const int32_t* __restric
   const int m = n - nf;
   if (gather) {
     if (tid == 0) gcorner[F.par_map] = *corner;
+    // [S d] transposed, (n - nf) x nf: each separator variable's block is contiguous for the parent's gather
+    double* St = pool + F.u_off;
+    for (int idx = tid; idx < m * nf; idx += nt) {
+      const int c = idx / nf, r = idx - c * nf;
+      St[idx] = S[r * n + nf + c];
+    }
   } else if (F.par_ld > 0) {
     // scatter-add straight into the parent HBM front (extend-add, a12); the column map is staged in the free Jacobian area
     int* pm = (int*)Jb;

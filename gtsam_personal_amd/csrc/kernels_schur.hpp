@@ -28,9 +28,9 @@ struct GPairBlock {
   int32_t begin, count;
 };
 struct GPairEntry {  // 16 bytes
-  int64_t rsd_off;   // pool offset of the leaf's [R S d]
-  int16_t sa, sb;    // columns of S_a / S_b inside a [R S d] row
-  int16_t nf, ld;    // rows and leading dimension of [R S d]
+  int64_t rsd_off;   // pool offset of the leaf's TRANSPOSED [S d]  ((n - nf) x nf, written by lds_front_kernel<true>)
+  int16_t sa, sb;    // element offsets of the (contiguous, [column][row]) blocks S_a / S_b inside it
+  int16_t nf, ld;    // rows of [R S d]; ld unused
 };
 struct GVarBlock {
   int32_t pv;       // parent column of the variable
@@ -76,12 +76,12 @@ __global__ __launch_bounds__(64 * WAVES) void schur_pairs_kernel(const GPairBloc
         const int eu = min(e + u, cnt - 1);
         const long long off = shfl_ll(moff, eu), meta = shfl_ll(mmeta, eu);
         const int sa = (int)(meta & 0xffff), sb = (int)((meta >> 16) & 0xffff), nf = (int)((meta >> 32) & 0xffff), lde = (int)((meta >> 48) & 0xffff);
-        const double* R = pool + off;
+        const double* St = pool + off;
+        (void)lde;
         double a0 = 0, a1 = 0;
         for (int r = 0; r < nf; r++) {
-          const double* row = R + (size_t)r * lde;
-          if (v0) a0 += row[sa + i0] * row[sb + j0];
-          if (v1) a1 += row[sa + i1] * row[sb + j1];
+          if (v0) a0 += St[sa + i0 * nf + r] * St[sb + j0 * nf + r];
+          if (v1) a1 += St[sa + i1 * nf + r] * St[sb + j1 * nf + r];
         }
         const bool valid = e + u < cnt;
         t0[u] = valid ? a0 : 0.0;

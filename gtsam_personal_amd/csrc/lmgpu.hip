@@ -456,6 +456,10 @@ int do_eliminate(lmgpu_handle* h, double lambda) {
         }
         HIPCHECK(hipEventRecord(evP, sA));
         if (h->la_debug == 1) HIPCHECK(hipDeviceSynchronize());
+        if (!h->lookahead) {  // single stream: one trailing update of everything below the panel
+          syrk(sA, k0, kend - k0, kend, F.n);
+          continue;
+        }
         const int next_end = std::min(F.n, kend + NBO);  // rows of panel i+1 (or the separator rows if this was the last panel)
         if (i > 0) HIPCHECK(hipStreamWaitEvent(sA, h->la_events[2 * (i - 1) + 1], 0));
         syrk(sA, k0, kend - k0, kend, next_end);  // UA_i
@@ -468,7 +472,7 @@ int do_eliminate(lmgpu_handle* h, double lambda) {
         if (h->la_debug == 3) HIPCHECK(hipStreamWaitEvent(sA, evUB, 0));  // event-only serialisation (no overlap, no host sync)
         if (h->la_debug == 4) HIPCHECK(hipStreamWaitEvent(sA, evUB, 0));  // level 4: same as 3 here (UA_i || UB_i still overlaps: UA_i was enqueued before)
       }
-      HIPCHECK(hipStreamWaitEvent(sA, h->la_events[2 * (np - 1) + 1], 0));  // join
+      if (h->lookahead) HIPCHECK(hipStreamWaitEvent(sA, h->la_events[2 * (np - 1) + 1], 0));  // join
     }
   }
   HIPCHECK(hipGetLastError());
@@ -944,7 +948,11 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
       const bool direct = fr.parent >= 0 && P.fronts[fr.parent].cls == 1;
       if (direct) {
         F.u_off = -1;
-        if (fr.children.empty() && !getenv("LMGPU_NO_GATHER")) F.par_ld = -1;
+        if (fr.children.empty() && !getenv("LMGPU_NO_GATHER")) {
+          F.par_ld = -1;
+          F.u_off = off;  // gather leaves also keep [S d] transposed ((n - nf) x nf: every variable's block contiguous)
+          off += (int64_t)F.ld_u * fr.nf;
+        }
       } else {
         F.u_off = off;
         off += (int64_t)F.ld_u * F.ld_u;
@@ -981,7 +989,7 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
       for (size_t k = ch.n_frontal_vars; k < ch.vars.size(); k++)
         for (int d = 0; d < P.dims[ch.vars[k]]; d++) cmap.push_back(colof[ch.vars[k]] + d);
       cmap.push_back(fr.n - 1);
-      if (CF.u_off < 0 && CF.par_ld < 0) {  // gather-mode leaf: register its S blocks and factors with this (HBM) front
+      if (CF.par_ld < 0) {  // gather-mode leaf: register its S blocks and factors with this (HBM) front
         cmap.resize(map_begin);
         lmgpu_handle::GatherRange& G = h->gather[fi];
         const int li = n_gleaf++;
@@ -1000,7 +1008,7 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
             Ent a = ents[x], b = ents[y];
             if (a.pc > b.pc) std::swap(a, b);
             gp_tmp.push_back(GPairTmp{((int64_t)a.pc << 32) | (uint32_t)b.pc, (int16_t)a.d, (int16_t)b.d,
-                                      GPairEntry{CF.rsd_off, (int16_t)a.lc, (int16_t)b.lc, (int16_t)ch.nf, (int16_t)CF.ld_rsd}});
+                                      GPairEntry{CF.u_off, (int16_t)((a.lc - ch.nf) * ch.nf), (int16_t)((b.lc - ch.nf) * ch.nf), (int16_t)ch.nf, 0}});
           }
         for (int32_t f : ch.factors)
           for (int pos = 0; pos < 2; pos++) {
