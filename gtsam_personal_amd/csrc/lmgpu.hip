@@ -18,7 +18,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -129,6 +131,36 @@ const int kSyrkLds = 2 * 2 * SYRK_KC * SYRK_LDW * 8;
 
 }  // namespace
 
+// In-process stand-in for the RCCL communicator: W handles of ONE process (one thread each) sum their buffers through a
+// host rendezvous.  Same call sites and semantics as the ncclAllReduce path; exists so that the sharded LM loop can be
+// exercised end to end on a single GPU (two RCCL ranks may not share a device).  Not a performance path.
+struct lmgpu_local_group {
+  int world = 0;
+  std::mutex mu;
+  std::condition_variable cv;
+  int arrived = 0;
+  long generation = 0;
+  std::vector<void*> ptr;
+  std::vector<hipStream_t> stream;
+  // rendezvous: returns once all ranks are in
+  void barrier() {
+    std::unique_lock<std::mutex> lk(mu);
+    const long g = generation;
+    if (++arrived == world) {
+      arrived = 0;
+      generation++;
+      cv.notify_all();
+    } else {
+      cv.wait(lk, [&] { return generation != g; });
+    }
+  }
+};
+
+__global__ void local_sum_kernel(double* __restrict__ dst, const double* __restrict__ src, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] += src[i];
+}
+__global__ void local_min_kernel(int* __restrict__ dst, const int* __restrict__ src) { *dst = min(*dst, *src); }
+
 struct lmgpu_handle {
   lmgpu_config cfg;
   int device = -1;
@@ -195,6 +227,7 @@ struct lmgpu_handle {
   bool lookahead = false;  // LMGPU_LOOKAHEAD=1: experimental two-stream look-ahead (measured r01: wrong results for >1 outer panel; off)
 
   ncclComm_t comm = nullptr;
+  lmgpu_local_group* lgroup = nullptr;  // test-only in-process communicator (lmgpu_comm_init_local)
 };
 
 namespace {
@@ -220,7 +253,7 @@ int need_device(lmgpu_handle* h) {
 }
 
 int need_comm(lmgpu_handle* h) {
-  if (h->cfg.world_size > 1 && !h->comm) {
+  if (h->cfg.world_size > 1 && !h->comm && !h->lgroup) {
     h->err = "world_size > 1 but lmgpu_comm_init has not been called";
     return LMGPU_INVALID;
   }
@@ -297,10 +330,46 @@ void reduce_to(lmgpu_handle* h, const double* buf, int n, double* dst) {
   hipLaunchKernelGGL(reduce_stage2, dim3(1), dim3(256), 0, h->stream, (const double*)h->partial, g, dst);
 }
 
+// all-reduce over the ranks: RCCL, or the in-process local group
+int allreduce_sum(lmgpu_handle* h, double* buf, size_t count, hipStream_t s) {
+  if (h->comm) {
+    NCCLCHECK(ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, h->comm, s));
+  } else if (h->lgroup) {
+    lmgpu_local_group* g = h->lgroup;
+    HIPCHECK(hipStreamSynchronize(s));
+    g->ptr[h->cfg.rank] = buf;
+    g->barrier();
+    if (h->cfg.rank == 0) {
+      for (int r = 1; r < g->world; r++)
+        hipLaunchKernelGGL(local_sum_kernel, dim3(1024), dim3(256), 0, s, buf, (const double*)g->ptr[r], count);
+      HIPCHECK(hipStreamSynchronize(s));
+      for (int r = 1; r < g->world; r++) HIPCHECK(hipMemcpy(g->ptr[r], buf, count * sizeof(double), hipMemcpyDeviceToDevice));
+    }
+    g->barrier();
+  }
+  return LMGPU_OK;
+}
+int allreduce_min_int(lmgpu_handle* h, int* buf, hipStream_t s) {
+  if (h->comm) {
+    NCCLCHECK(ncclAllReduce(buf, buf, 1, ncclInt, ncclMin, h->comm, s));
+  } else if (h->lgroup) {
+    lmgpu_local_group* g = h->lgroup;
+    HIPCHECK(hipStreamSynchronize(s));
+    g->ptr[h->cfg.rank] = buf;
+    g->barrier();
+    if (h->cfg.rank == 0) {
+      for (int r = 1; r < g->world; r++) hipLaunchKernelGGL(local_min_kernel, dim3(1), dim3(1), 0, s, buf, (const int*)g->ptr[r]);
+      HIPCHECK(hipStreamSynchronize(s));
+      for (int r = 1; r < g->world; r++) HIPCHECK(hipMemcpy(g->ptr[r], buf, sizeof(int), hipMemcpyDeviceToDevice));
+    }
+    g->barrier();
+  }
+  return LMGPU_OK;
+}
+
 // sum `count` doubles at dscal+first over the ranks (each factor is counted on exactly one rank)
 int allreduce_scalars(lmgpu_handle* h, int first, int count) {
-  if (h->comm) NCCLCHECK(ncclAllReduce(h->dscal + first, h->dscal + first, count, ncclDouble, ncclSum, h->comm, h->stream));
-  return LMGPU_OK;
+  return allreduce_sum(h, h->dscal + first, count, h->stream);
 }
 
 int compute_error(lmgpu_handle* h, int which, double* out) {
@@ -324,8 +393,7 @@ int do_linearize(lmgpu_handle* h) {
 int launch_hessian_diag(lmgpu_handle* h) {
   hipLaunchKernelGGL(hessian_diag_kernel, dim3((h->ntot + 255) / 256), dim3(256), 0, h->stream, h->ntot, h->d_scalar_var, h->d_scalar_col,
                      h->d_vi_ptr, h->d_vi_fac, h->d_vi_pos, h->d_fd, (const double*)h->pool, h->hdiag);
-  if (h->comm) NCCLCHECK(ncclAllReduce(h->hdiag, h->hdiag, h->ntot, ncclDouble, ncclSum, h->comm, h->stream));
-  return LMGPU_OK;
+  return allreduce_sum(h, h->hdiag, h->ntot, h->stream);
 }
 
 int fill_dampw(lmgpu_handle* h, int diagonal, double min_diag, double max_diag) {
@@ -417,10 +485,10 @@ int do_eliminate(lmgpu_handle* h, double lambda) {
         hipLaunchKernelGGL(hbm_damp_kernel, dim3((F.nf + 255) / 256), dim3(256), 0, s, F, off, ld, (const int32_t*)h->d_fxoff, h->pool, lambda,
                            (const double*)h->dampw);
       h->kt.end(kt, s);
-      if (h->comm && replicated) {
+      if ((h->comm || h->lgroup) && replicated) {
         // replicated top front: sum the ranks' partial assemblies (separator contributions) over xGMI
         kt = h->kt.begin(LMGPU_KT_ALLREDUCE, s);
-        NCCLCHECK(ncclAllReduce(A, A, (size_t)F.n * ld, ncclDouble, ncclSum, h->comm, s));
+        { const int rca = allreduce_sum(h, A, (size_t)F.n * ld, s); if (rca) return rca; }
         h->kt.end(kt, s, (double)F.n * ld * 8.0);
       }
       // two-level blocking: outer panels of NBO rows; inside, NB-row steps update only the rest of the outer panel.
@@ -532,7 +600,7 @@ int do_solve(lmgpu_handle* h, double lambda) {
   h->kt.end(kt, s);
   rc = allreduce_scalars(h, 1, 2);
   if (rc) return rc;
-  if (h->comm) NCCLCHECK(ncclAllReduce(h->d_status, h->d_status, 1, ncclInt, ncclMin, h->comm, s));
+  { const int rcs = allreduce_min_int(h, h->d_status, s); if (rcs) return rcs; }
   (void)hipEventRecord(h->ev[4], s);
   HIPCHECK(hipMemcpyAsync(h->h_scal + 1, h->dscal + 1, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHECK(hipMemcpyAsync(h->h_status, h->d_status, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1476,6 +1544,25 @@ int lmgpu_comm_init(lmgpu_handle* h, const char id128[128]) {
   std::memcpy(&id, id128, 128);
   HIPCHECK(hipSetDevice(h->device));
   NCCLCHECK(ncclCommInitRank(&h->comm, h->cfg.world_size, id, h->cfg.rank));
+  return LMGPU_OK;
+}
+
+int lmgpu_local_group_create(int32_t world_size, lmgpu_local_group** out) {
+  if (!out || world_size < 1) return LMGPU_INVALID;
+  lmgpu_local_group* g = new lmgpu_local_group();
+  g->world = world_size;
+  g->ptr.assign(world_size, nullptr);
+  g->stream.assign(world_size, nullptr);
+  *out = g;
+  return LMGPU_OK;
+}
+int lmgpu_local_group_destroy(lmgpu_local_group* g) {
+  delete g;
+  return LMGPU_OK;
+}
+int lmgpu_comm_init_local(lmgpu_handle* h, lmgpu_local_group* g) {
+  if (!h || !g || g->world != h->cfg.world_size) return LMGPU_INVALID;
+  h->lgroup = g;
   return LMGPU_OK;
 }
 

@@ -83,7 +83,8 @@ class LevenbergMarquardtOptimizer:
     `device=-1` builds a structure-only handle (symbolic analysis, no compute)."""
 
     def __init__(self, graph: NonlinearFactorGraph, initialValues: Values, ordering=None, params: LevenbergMarquardtParams | None = None,
-                 device: int = 0, rank: int = 0, world_size: int = 1, comm_id: bytes | None = None):
+                 device: int = 0, rank: int = 0, world_size: int = 1, comm_id: bytes | None = None,
+                 local_group=None):
         self.params = params or LevenbergMarquardtParams()
         ordering = ordering if ordering is not None else self.params.ordering
         if ordering is None:
@@ -131,9 +132,12 @@ class LevenbergMarquardtOptimizer:
         self.state = _lib.lmgpu_lm_state()
         if device >= 0:
             if world_size > 1:
-                if comm_id is None:
+                if local_group is not None:  # in-process communicator (tests): one thread per rank
+                    self._check(self.lib.lmgpu_comm_init_local(self._h, local_group))
+                elif comm_id is None:
                     raise ValueError("world_size > 1 needs comm_id (lmgpu_comm_unique_id bytes broadcast from rank 0)")
-                self.comm_init(comm_id)
+                else:
+                    self.comm_init(comm_id)
             self.set_values(initialValues)
             cp = self.params._c()
             self._check(self.lib.lmgpu_lm_init(self._h, ct.byref(cp), ct.byref(self.state)))

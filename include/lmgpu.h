@@ -183,6 +183,14 @@ int lmgpu_get_front(lmgpu_handle* h, int32_t front, int32_t* slots, double* RSd_
 int lmgpu_comm_unique_id(char id128[128]);
 int lmgpu_comm_init(lmgpu_handle* h, const char id128[128]);
 
+/* In-process stand-in for the RCCL communicator (testing aid): W handles created by W threads of ONE process on one
+ * device sum their buffers through a host rendezvous, at exactly the call sites where the RCCL path all-reduces.
+ * Lets the sharded LM loop run end to end on a single GPU.  Every rank must drive its handle from its own thread. */
+typedef struct lmgpu_local_group lmgpu_local_group;
+int lmgpu_local_group_create(int32_t world_size, lmgpu_local_group** out);
+int lmgpu_local_group_destroy(lmgpu_local_group* g);
+int lmgpu_comm_init_local(lmgpu_handle* h, lmgpu_local_group* g);
+
 /* ---- micro-benchmarks used by bench.py for roofline peaks (device-only, no graph needed) ---- */
 int lmgpu_peak_mfma_f64(int32_t device, int32_t iters, double* tflops);
 int lmgpu_peak_hbm_copy(int32_t device, int64_t bytes, int32_t iters, double* gbps);
