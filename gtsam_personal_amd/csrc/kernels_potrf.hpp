@@ -1,0 +1,554 @@
+// Single-wave Cholesky of a 64x64 diagonal block held entirely in registers, in the accumulator layout of
+// v_mfma_f64_16x16x4_f64: tile T[g][h] (16x16, h >= g) keeps element (row 16g + (lane>>4) + 4r, column 16h + (lane&15))
+// in register r.  No LDS and no barriers: the 16 pivots of a 16-row strip are eliminated with cross-lane shuffles
+// (ds_bpermute) across the whole strip, so the strip's off-diagonal tiles come out already solved (R_gh = R_gg^-T A_gh:
+// no explicit triangular inverse), and the remaining strips are updated on the matrix cores with both operands taken
+// straight from accumulator registers (C/D layout of k-step s  ==  A/B operand layout:  A[i = lane&15][k = lane>>4]).
+// The per-pivot dependency chain is   fma -> v_readlane -> v_rsq_f64 + 2 Newton steps   with the row shuffles in flight
+// beside it (they carry the unscaled row; the update multiplies by 1/p).
+// Arithmetic = Eigen::LLT on the block (gtsam/base/cholesky.cpp:108-159) up to rounding; a pivot <= 0 reports failure.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace lmgpu {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double readlane_d(double v, int src_lane) {  // src_lane: compile-time constant
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), src_lane);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src_lane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+__device__ __forceinline__ double fast_rsqrt(double p) {
+  double y = __builtin_amdgcn_rsq(p);
+  const double h = 0.5 * p;
+  y = y * fma(-h * y, y, 1.5);
+  y = y * fma(-h * y, y, 1.5);
+  return y;
+}
+
+__device__ __forceinline__ double rcp_nr2(double p) {
+  double r = __builtin_amdgcn_rcp(p);
+  r = fma(fma(-p, r, 1.0), r, r);
+  r = fma(fma(-p, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ double rcp_nr1(double p) {
+  double r = __builtin_amdgcn_rcp(p);
+  r = fma(fma(-p, r, 1.0), r, r);
+  return r;
+}
+#ifndef POTRF_RCP
+#define POTRF_RCP rcp_nr2
+#endif
+
+// T[g][h], h >= g: in = upper triangle of the SPD block (entries below the diagonal inside diagonal tiles: don't care),
+// out = R with R^T R = A.  Returns true if a pivot was <= 0 (the factor is then garbage, like Eigen's info() != Success).
+__device__ __forceinline__ bool potrf64_wave(double4_t (&T)[4][4]) {
+  const int lane = threadIdx.x & 63, kk = lane >> 4, cc = lane & 15;
+  bool failed = false;
+#pragma unroll
+  for (int g = 0; g < 4; g++) {
+#pragma unroll
+    for (int kq = 0; kq < 16; kq++) {
+      const int rk = kq >> 2, kw = kq & 3, src = kw * 16;
+      double p = readlane_d(T[g][g][rk], src + kq);
+      // branch-free (the whole 64-pivot chain is one scheduling region): pivot <= 0 -> failure, NaN passes like Eigen's LLT
+      failed |= (p <= 0.0);
+      p = (p > 0.0) ? p : ((p == p && p != 0.0) ? fabs(p) : 1.0);
+      double ra[4], rb[4];
+#pragma unroll
+      for (int r = rk; r < 4; r++) ra[r] = __shfl(T[g][g][rk], src + kk + 4 * r, 64);  // A'[k][a], a = kk + 4r (this strip's rows)
+#pragma unroll
+      for (int h = g; h < 4; h++) rb[h] = __shfl(T[g][h][rk], src + cc, 64);           // A'[k][b], b = column of tile h
+      const double ip = POTRF_RCP(p);   // on the pivot-to-pivot dependency chain
+      const double rs = fast_rsqrt(p);  // beside it: only scales the finished row
+#pragma unroll
+      for (int h = g; h < 4; h++) {
+        {  // register rk: rows kk + 4 rk -- below the pivot row for kk > kw, the pivot row itself for kk == kw
+          const double cur = T[g][h][rk];
+          const double upd = fma(-(ra[rk] * rb[h]), ip, cur);
+          T[g][h][rk] = (kk > kw) ? upd : ((kk == kw) ? cur * rs : cur);
+        }
+#pragma unroll
+        for (int r = rk + 1; r < 4; r++) T[g][h][r] = fma(-(ra[r] * rb[h]), ip, T[g][h][r]);
+      }
+    }
+    // remaining strips: T[g2][h] -= R[g][g2]^T R[g][h]
+#pragma unroll
+    for (int g2 = g + 1; g2 < 4; g2++)
+#pragma unroll
+      for (int h = g2; h < 4; h++)
+#pragma unroll
+        for (int s = 0; s < 4; s++) T[g2][h] = __builtin_amdgcn_mfma_f64_16x16x4f64(-T[g][g2][s], T[g][h][s], T[g2][h], 0, 0, 0);
+  }
+  return failed;
+}
+
+// ---------------------------------------------------------------- one 256-row outer panel of an HBM front, two launches
+// diag_potrf_kernel  (ONE workgroup): Cholesky of the kb x kb diagonal block A[ko.., ko..] (kb <= 256), right-looking over
+//   64-blocks: wave 0 factors the 64x64 diagonal tile in registers (potrf64_wave), all four waves then solve the tiles to
+//   its right on the matrix cores (R_j,jj = R_jj^-T A_j,jj through the four 16x16 triangular inverses) and update the
+//   remaining tiles of the block with both operands from LDS / accumulator registers.  Every lane re-reads from global
+//   memory only what the same lane wrote (wave w <-> columns 16w..16w+15 of every tile), so the block needs no device-scope
+//   fences.  Also writes the sixteen 16x16 inverses of the diagonal tiles (inv16) for the panel solve.
+// panel_trsm_kernel  (one wave per 16 columns): the row panel right of the diagonal block,
+//   X_j = R_jj^-T (A_j,cols - sum_{i<j} R_ij^T X_i), all 256 rows of the wave's 16 columns held in accumulator registers
+//   (finished X tiles are fed back as B operands straight from those registers).
+// Together they replace four launches of a fused 64-row panel step in which EVERY workgroup re-factored the diagonal tile.
+#define DP_LDW 66
+#define DIAG_LDS_DOUBLES (64 * DP_LDW + 4 * 16 * 17 + 3 * 64 * DP_LDW)
+#define DIAG_LDS_BYTES (DIAG_LDS_DOUBLES * 8)
+
+__device__ __forceinline__ int frexp_exp_d(double x) {
+  int e;
+  frexp(x, &e);
+  return e;
+}
+
+// X = R_jj^-T T for one wave's 16 columns (4 row tiles), D = R_jj (LDS, identity-padded), I16 = inverses of its diagonal 16x16 tiles
+__device__ __forceinline__ void trsm64_wave(double4_t (&T)[4], const double (*D)[DP_LDW], const double (*I16)[16][17], int kk, int cc) {
+#pragma unroll
+  for (int g = 0; g < 4; g++) {
+    double4_t acc = T[g];
+#pragma unroll
+    for (int i = 0; i < g; i++)
+#pragma unroll
+      for (int sx = 0; sx < 4; sx++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-D[16 * i + 4 * sx + kk][16 * g + cc], T[i][sx], acc, 0, 0, 0);
+    double4_t out = double4_t{0, 0, 0, 0};
+#pragma unroll
+    for (int sx = 0; sx < 4; sx++) out = __builtin_amdgcn_mfma_f64_16x16x4f64(I16[g][4 * sx + kk][cc], acc[sx], out, 0, 0, 0);
+    T[g] = out;
+  }
+}
+
+__global__ __launch_bounds__(256) void diag_potrf_kernel(double* __restrict__ A, int ld, int nf, int ko, int kb, int front_id,
+                                                          int* __restrict__ status, double* __restrict__ inv16) {
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  double(*D)[DP_LDW] = (double(*)[DP_LDW])dsm;                                   // [64][DP_LDW]   R_jj
+  double(*I16)[16][17] = (double(*)[16][17])(dsm + 64 * DP_LDW);                // [4][16][17]
+  double(*XB)[64][DP_LDW] = (double(*)[64][DP_LDW])(dsm + 64 * DP_LDW + 4 * 16 * 17);  // [3][64][DP_LDW]  R_j,jj  (jj = j+1 ..)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kk = lane >> 4, cc = lane & 15;
+  const int nblk = (kb + 63) >> 6;
+  double* Ab = A + (size_t)ko * ld + ko;
+  const int wc = 16 * wave + cc;  // this lane's column inside every 64-wide tile
+  for (int j = 0; j < nblk; j++) {
+    const int nbj = min(64, kb - 64 * j);
+    double* Aj = Ab + (size_t)(64 * j) * ld;  // row block j
+    // ---- 1. diagonal tile -> D (identity-padded), each wave its own 16 columns
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = 16 * g + kk + 4 * r;
+        const double v = Aj[(size_t)min(row, nbj - 1) * ld + 64 * j + min(wc, nbj - 1)];
+        D[row][wc] = (row < nbj && wc < nbj) ? v : ((row == wc) ? 1.0 : 0.0);
+      }
+    __syncthreads();
+    // ---- 2. wave 0 factors it in registers
+    if (wave == 0) {
+      double4_t T[4][4];
+#pragma unroll
+      for (int g = 0; g < 4; g++)
+#pragma unroll
+        for (int h = g; h < 4; h++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) T[g][h][r] = D[16 * g + kk + 4 * r][16 * h + cc];
+      bool failed = potrf64_wave(T);
+#pragma unroll
+      for (int g = 0; g < 4; g++)
+#pragma unroll
+        for (int h = g; h < 4; h++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) D[16 * g + kk + 4 * r][16 * h + cc] = T[g][h][r];
+      if (ko + 64 * j + nbj >= nf) {  // last rows of the frontal part: pivot-exponent test, gtsam/base/cholesky.cpp:146-158
+        // R[nf-1][nf-1] is element (nbj-1, nbj-1) of this tile: tile (3,3) if nbj == 64, else read back below
+        __builtin_amdgcn_s_waitcnt(0);
+        const double r1 = D[nbj - 1][nbj - 1];
+        if (nf >= 2) {
+          const double r2 = (nbj >= 2) ? D[nbj - 2][nbj - 2] : A[(size_t)(nf - 2) * ld + nf - 2];
+          if (!(frexp_exp_d(r2) - frexp_exp_d(r1) < 12)) failed = true;
+        } else {
+          if (!(frexp_exp_d(r1) > -12)) failed = true;
+        }
+      }
+      if (failed && lane == 0) atomicMin(status, front_id);
+    }
+    __syncthreads();
+    // ---- 3. 16x16 inverses (lane (blk, c) back-substitutes column c of inv(R_blk)); R_jj -> global
+    if (tid < 64) {
+      const int blk = tid >> 4, c = tid & 15, base = 16 * blk;
+      double x[16];
+#pragma unroll
+      for (int i = 15; i >= 0; i--) {
+        double sacc = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+        for (int kq = i + 1; kq < 16; kq++) sacc -= D[base + i][base + kq] * x[kq];
+        x[i] = (i <= c) ? sacc / D[base + i][base + i] : 0.0;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        I16[blk][i][c] = x[i];
+        inv16[(size_t)(4 * j + blk) * 256 + i * 16 + c] = x[i];
+      }
+    } else {
+      for (int idx = tid - 64; idx < nbj * 64; idx += 192) {
+        const int p = idx >> 6, q = idx & 63;
+        if (q >= p && q < nbj) Aj[(size_t)p * ld + 64 * j + q] = D[p][q];
+      }
+    }
+    __syncthreads();
+    if (j + 1 == nblk) break;
+    // ---- 4. tiles to the right of the diagonal one (inside the block)
+    double4_t X[3][4];
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      const int jj = j + 1 + t;
+      if (jj < nblk) {
+        const int col = 64 * jj + wc;  // column inside the block
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int row = 16 * g + kk + 4 * r;
+            const double v = Aj[(size_t)min(row, nbj - 1) * ld + min(col, kb - 1)];
+            X[t][g][r] = (row < nbj && col < kb) ? v : 0.0;
+          }
+        trsm64_wave(X[t], D, I16, kk, cc);
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int row = 16 * g + kk + 4 * r;
+            XB[t][row][wc] = X[t][g][r];
+            if (row < nbj && col < kb) Aj[(size_t)row * ld + col] = X[t][g][r];
+          }
+      }
+    }
+    __syncthreads();
+    // ---- 5. update the remaining tiles (i, jj), j < i <= jj:  C -= R_j,i^T R_j,jj   (this wave's 16 columns of each)
+#pragma unroll
+    for (int ti = 0; ti < 3; ti++)
+#pragma unroll
+      for (int tj = ti; tj < 3; tj++) {
+        const int i = j + 1 + ti, jj = j + 1 + tj;
+        if (jj < nblk) {
+          const int nbi = min(64, kb - 64 * i), col = 64 * jj + wc;
+          double* Ai = Ab + (size_t)(64 * i) * ld;
+          double4_t C[4];
+#pragma unroll
+          for (int g = 0; g < 4; g++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) C[g][r] = Ai[(size_t)min(16 * g + kk + 4 * r, nbi - 1) * ld + min(col, kb - 1)];
+#pragma unroll
+          for (int s = 0; s < 16; s++)
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+              C[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(-XB[ti][4 * s + kk][16 * g + cc], X[tj][s >> 2][s & 3], C[g], 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < 4; g++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              const int row = 16 * g + kk + 4 * r;
+              if (row < nbi && col < kb) Ai[(size_t)row * ld + col] = C[g][r];
+            }
+        }
+      }
+    __syncthreads();
+  }
+}
+
+// grid = ceil(cols / 64) workgroups of 4 independent waves; cols = n - ko - kb columns right of the diagonal block
+#define PTRSM_LDS_BYTES (16 * 16 * 17 * 8)
+__global__ __launch_bounds__(256) void panel_trsm_kernel(double* __restrict__ A, int ld, int n, int ko, int kb, const double* __restrict__ inv16) {
+  __shared__ double I16[16][16][17];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kk = lane >> 4, cc = lane & 15;
+  const int nblk = (kb + 63) >> 6;
+  for (int idx = tid; idx < nblk * 4 * 256; idx += 256) I16[idx >> 8][(idx >> 4) & 15][idx & 15] = inv16[idx];
+  __syncthreads();
+  const int c0 = ko + kb + (blockIdx.x * 4 + wave) * 16;
+  if (c0 >= n) return;
+  const int col = min(c0 + cc, n - 1);
+  const bool cvalid = c0 + cc < n;
+  const double* Ab = A + (size_t)ko * ld + ko;  // diagonal block (finished R)
+  double* P = A + (size_t)ko * ld;              // row panel
+  double4_t X[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    if (j < nblk) {
+      const int nbj = min(64, kb - 64 * j);
+      double4_t T[4];
+#pragma unroll
+      for (int g = 0; g < 4; g++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int row = 16 * g + kk + 4 * r;
+          const double v = P[(size_t)(64 * j + min(row, nbj - 1)) * ld + col];
+          T[g][r] = (row < nbj) ? v : 0.0;
+        }
+      // T -= R_ij^T X_i for the finished row blocks (A fragments of R_ij straight from L2)
+#pragma unroll
+      for (int i = 0; i < j; i++) {
+        const double* Rij = Ab + (size_t)(64 * i) * ld + 64 * j;
+#pragma unroll
+        for (int s0 = 0; s0 < 16; s0 += 4) {
+          double af[4][4];
+#pragma unroll
+          for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+              const int q = 16 * g + cc;  // column inside tile (i, j): valid iff < nbj (rows of block i are always full)
+              const double v = Rij[(size_t)(4 * (s0 + s) + kk) * ld + min(q, nbj - 1)];
+              af[s][g] = (q < nbj) ? -v : 0.0;
+            }
+#pragma unroll
+          for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) T[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s][g], X[i][(s0 + s) >> 2][(s0 + s) & 3], T[g], 0, 0, 0);
+        }
+      }
+      // solve with R_jj: sub-tiles from L2, inverses from LDS
+      const double* Rjj = Ab + (size_t)(64 * j) * ld + 64 * j;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        double4_t acc = T[g];
+#pragma unroll
+        for (int i = 0; i < g; i++)
+#pragma unroll
+          for (int sx = 0; sx < 4; sx++) {
+            const int p = 16 * i + 4 * sx + kk, q = 16 * g + cc;
+            const double v = Rjj[(size_t)min(p, nbj - 1) * ld + min(q, nbj - 1)];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64((p < nbj && q < nbj) ? -v : 0.0, T[i][sx], acc, 0, 0, 0);
+          }
+        double4_t out = double4_t{0, 0, 0, 0};
+#pragma unroll
+        for (int sx = 0; sx < 4; sx++) out = __builtin_amdgcn_mfma_f64_16x16x4f64(I16[4 * j + g][4 * sx + kk][cc], acc[sx], out, 0, 0, 0);
+        T[g] = out;
+        X[j][g] = out;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int row = 16 * g + kk + 4 * r;
+          if (row < nbj && cvalid) P[(size_t)(64 * j + row) * ld + c0 + cc] = out[r];
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- the same outer panel as ONE dataflow launch
+// Workgroup b < nblk owns block column b of the diagonal block (and factors diagonal tile b); the others own 64 columns
+// right of it.  Every workgroup runs the left-looking column algorithm of panel_trsm_kernel on its own columns and
+// consumes  R_jj + its 16x16 inverses   (flag diag_ready[j], published by workgroup j after potrf64_wave)  and the tiles
+// R_ij of block column j (flag tile_ready[i][j], published by workgroup j) from global memory.  A diagonal workgroup keeps
+// its diagonal tile in registers and folds X_j into it as soon as X_j exists, so the dependency chain of the launch is
+//   potrf(0) -> hand-off -> [workgroup 1: solve X_0, one tile update, potrf(1)] -> hand-off -> ...
+// i.e. four register Choleskys, three tile solves/updates and four hand-offs per 256 rows, with all other work beside it.
+// Hand-offs follow cdna_hip_programming.md Guideline 16: plain stores, every wave drains (s_waitcnt vmcnt(0)), workgroup
+// barrier, ONE lane: agent-scope release fence, wait, relaxed agent-scope flag store; consumer: ONE lane polls relaxed,
+// ONE agent-scope acquire fence, wait, workgroup barrier, then plain vector loads.  Logical workgroup ids come from a
+// ticket counter, so a workgroup only ever waits for workgroups that started before it (no dispatch-order assumption).
+// flags: [0] ticket, [4 + j] diag_ready[j], [8 + 4 i + j] tile_ready[i][j]; zeroed by the host before the launch.
+#define PDF_FLAG_WORDS 32
+#define PDF_SPIN_LIMIT 40000000L
+
+__device__ __forceinline__ bool pdf_wait(unsigned int* flags, unsigned int need_mask, int* s_ok, int tid) {
+  // need_mask: bit w set <=> flags[w] must be non-zero
+  if (tid == 0) {
+    bool ok = true;
+    for (int w = 4; w < PDF_FLAG_WORDS && ok; w++) {
+      if (!((need_mask >> w) & 1u)) continue;
+      long spins = 0;
+      while (__hip_atomic_load(&flags[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > PDF_SPIN_LIMIT) {
+          ok = false;
+          break;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    *s_ok = ok ? 1 : 0;
+  }
+  __syncthreads();
+  return *s_ok != 0;
+}
+
+// every wave calls this after its last store of the payload; `signaller` = the one thread that raises the flag
+__device__ __forceinline__ void pdf_publish(unsigned int* flag, bool signaller) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (signaller) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+__global__ __launch_bounds__(256) void panel_dataflow_kernel(double* A, int ld, int n, int nf, int ko, int kb, int front_id, int* status,
+                                                              double* inv16, unsigned int* flags) {
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  double(*D)[DP_LDW] = (double(*)[DP_LDW])dsm;
+  double(*I16)[16][17] = (double(*)[16][17])(dsm + 64 * DP_LDW);
+  double(*XB)[64][DP_LDW] = (double(*)[64][DP_LDW])(dsm + 64 * DP_LDW + 4 * 16 * 17);
+  __shared__ int s_bid, s_ok;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kk = lane >> 4, cc = lane & 15;
+  if (tid == 0) s_bid = (int)atomicAdd(&flags[0], 1u);
+  __syncthreads();
+  const int b = s_bid;
+  const int nblk = kb >> 6;  // kb is a multiple of 64 (host guarantees; partial panels take the two-launch path)
+  const bool diagwg = b < nblk;
+  const int c0 = diagwg ? ko + 64 * b + 16 * wave : ko + kb + 64 * (b - nblk) + 16 * wave;
+  const int col = min(c0 + cc, n - 1);
+  const bool cvalid = c0 + cc < n;
+  const int wc = 16 * wave + cc;
+  double* Ab = A + (size_t)ko * ld + ko;  // diagonal block
+  double* P = A + (size_t)ko * ld;        // row panel
+  bool healthy = true;
+  double4_t X[4][4];
+  double4_t Td[4];  // diagonal workgroup: its strip of tile (b, b), right-looking
+  if (diagwg) {
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) Td[g][r] = P[(size_t)(64 * b + 16 * g + kk + 4 * r) * ld + col];
+  }
+  const int jend = diagwg ? b : nblk;  // exclusive
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    if (j < jend) {
+      double4_t T[4];
+#pragma unroll
+      for (int g = 0; g < 4; g++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) T[g][r] = P[(size_t)(64 * j + 16 * g + kk + 4 * r) * ld + col];
+      if (j > 0) {
+        // tiles R_ij (i < j) of block column j, published by workgroup j
+        unsigned int mask = 0;
+        for (int i = 0; i < j; i++) mask |= 1u << (8 + 4 * i + j);
+        healthy &= pdf_wait(flags, mask, &s_ok, tid);
+#pragma unroll
+        for (int i = 0; i < j; i++) {
+          const double* Rij = Ab + (size_t)(64 * i) * ld + 64 * j;
+#pragma unroll
+          for (int s0 = 0; s0 < 16; s0 += 4) {
+            double af[4][4];
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+              for (int g = 0; g < 4; g++) af[s][g] = -Rij[(size_t)(4 * (s0 + s) + kk) * ld + 16 * g + cc];
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+              for (int g = 0; g < 4; g++) T[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s][g], X[i][(s0 + s) >> 2][(s0 + s) & 3], T[g], 0, 0, 0);
+          }
+        }
+      }
+      healthy &= pdf_wait(flags, 1u << (4 + j), &s_ok, tid);
+      {
+        const double* Rjj = Ab + (size_t)(64 * j) * ld + 64 * j;
+        const double* Ij = inv16 + (size_t)(4 * j) * 256;
+        double rsub[6][4], isub[4][4];
+        int q = 0;
+#pragma unroll
+        for (int g = 1; g < 4; g++)
+#pragma unroll
+          for (int i = 0; i < g; i++) {
+#pragma unroll
+            for (int sx = 0; sx < 4; sx++) rsub[q][sx] = -Rjj[(size_t)(16 * i + 4 * sx + kk) * ld + 16 * g + cc];
+            q++;
+          }
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+#pragma unroll
+          for (int sx = 0; sx < 4; sx++) isub[g][sx] = Ij[g * 256 + (4 * sx + kk) * 16 + cc];
+        q = 0;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          double4_t acc = T[g];
+#pragma unroll
+          for (int i = 0; i < g; i++) {
+#pragma unroll
+            for (int sx = 0; sx < 4; sx++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(rsub[q][sx], T[i][sx], acc, 0, 0, 0);
+            q++;
+          }
+          double4_t out = double4_t{0, 0, 0, 0};
+#pragma unroll
+          for (int sx = 0; sx < 4; sx++) out = __builtin_amdgcn_mfma_f64_16x16x4f64(isub[g][sx], acc[sx], out, 0, 0, 0);
+          T[g] = out;
+          X[j][g] = out;
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            if (cvalid) P[(size_t)(64 * j + 16 * g + kk + 4 * r) * ld + c0 + cc] = out[r];
+        }
+      }
+      if (diagwg) {
+        // own tile (j, b): keep a copy in LDS for the A operands, publish it, fold it into the diagonal tile
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) XB[j][16 * g + kk + 4 * r][wc] = X[j][g][r];
+        pdf_publish(&flags[8 + 4 * j + b], tid == 64);
+#pragma unroll
+        for (int s = 0; s < 16; s++)
+#pragma unroll
+          for (int g = 0; g < 4; g++)
+            Td[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(-XB[j][4 * s + kk][16 * g + cc], X[j][s >> 2][s & 3], Td[g], 0, 0, 0);
+      }
+    }
+  }
+  if (!healthy && tid == 0) atomicMin(status, front_id);  // never expected: spin bound hit
+  if (!diagwg) return;
+  // ---- diagonal tile b: gather the four strips, factor in wave 0, publish R_bb and its inverses
+#pragma unroll
+  for (int g = 0; g < 4; g++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) D[16 * g + kk + 4 * r][wc] = Td[g][r];
+  __syncthreads();
+  if (wave == 0) {
+    double4_t T[4][4];
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+#pragma unroll
+      for (int h = g; h < 4; h++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) T[g][h][r] = D[16 * g + kk + 4 * r][16 * h + cc];
+    bool failed = potrf64_wave(T);
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+#pragma unroll
+      for (int h = g; h < 4; h++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) D[16 * g + kk + 4 * r][16 * h + cc] = T[g][h][r];
+    if (ko + 64 * b + 64 >= nf) {  // last frontal rows: pivot-exponent test, gtsam/base/cholesky.cpp:146-158
+      const double r1 = D[63][63], r2 = D[62][62];
+      if (!(frexp_exp_d(r2) - frexp_exp_d(r1) < 12)) failed = true;
+    }
+    if (failed && lane == 0) atomicMin(status, front_id);
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int blk = tid >> 4, c = tid & 15, base = 16 * blk;
+    double x[16];
+#pragma unroll
+    for (int i = 15; i >= 0; i--) {
+      double sacc = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+      for (int kq = i + 1; kq < 16; kq++) sacc -= D[base + i][base + kq] * x[kq];
+      x[i] = (i <= c) ? sacc / D[base + i][base + i] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) inv16[(size_t)(4 * b + blk) * 256 + i * 16 + c] = x[i];
+  } else {
+    double* Aj = Ab + (size_t)(64 * b) * ld + 64 * b;
+    for (int idx = tid - 64; idx < 64 * 64; idx += 192) {
+      const int p = idx >> 6, q = idx & 63;
+      if (q >= p) Aj[(size_t)p * ld + q] = D[p][q];
+    }
+  }
+  pdf_publish(&flags[4 + b], tid == 64);
+}
+
+}  // namespace lmgpu

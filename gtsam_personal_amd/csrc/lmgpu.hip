@@ -26,6 +26,7 @@
 
 #include "../../include/lmgpu.h"
 #include "kernels_dense.hpp"
+#include "kernels_potrf.hpp"
 #include "kernels_schur.hpp"
 #include "plan.hpp"
 
@@ -182,6 +183,11 @@ struct lmgpu_handle {
   hipStream_t stream = nullptr, stream2 = nullptr;
   std::vector<hipEvent_t> la_events;  // look-ahead ordering between the two streams
   double *bs_inv = nullptr, *bs_x = nullptr;  // dataflow back-substitution scratch
+  double* inv16 = nullptr;                     // 16 x (16x16) inverses of the current outer panel's diagonal tiles
+  bool old_panel = false;                      // LMGPU_OLD_PANEL=1: the fused 64-row panel steps (kept for A/B measurements)
+  bool two_launch_panel = false;               // LMGPU_PANEL_2L=1: diag_potrf + panel_trsm for every outer panel (A/B)
+  unsigned int* d_pflags = nullptr;            // hand-off flags of panel_dataflow_kernel, PDF_FLAG_WORDS per outer panel
+  int pflags_panels = 0;
   unsigned int* bs_flags = nullptr;
   double* pool = nullptr;
   size_t pool_doubles = 0;
@@ -511,10 +517,28 @@ int do_eliminate(lmgpu_handle* h, double lambda) {
         HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         h->la_events.push_back(e);
       }
+      if (np > h->pflags_panels) {
+        h->err = "panel flag buffer too small";
+        return LMGPU_INVALID;
+      }
+      HIPCHECK(hipMemsetAsync(h->d_pflags, 0, (size_t)np * PDF_FLAG_WORDS * sizeof(unsigned int), sA));
       for (int i = 0; i < np; i++) {
         const int k0 = i * NBO, kend = std::min(F.nf, k0 + NBO);
         hipEvent_t evP = h->la_events[2 * i], evUB = h->la_events[2 * i + 1];
-        for (int k = k0; k < kend; k += NB) {  // P_i
+        if (!h->old_panel) {  // P_i = diagonal block (one workgroup) + row panel solve
+          const int kb = kend - k0, cols = F.n - kend;
+          kt = h->kt.begin(LMGPU_KT_PANEL, sA);
+          if (kb % 64 == 0 && !h->two_launch_panel) {
+            hipLaunchKernelGGL(panel_dataflow_kernel, dim3(kb / 64 + (cols + 63) / 64), dim3(256), DIAG_LDS_BYTES, sA, A, ld, F.n, F.nf, k0, kb, F.id,
+                               h->d_status, h->inv16, h->d_pflags + (size_t)i * PDF_FLAG_WORDS);
+          } else {  // partial last panel
+            hipLaunchKernelGGL(diag_potrf_kernel, dim3(1), dim3(256), DIAG_LDS_BYTES, sA, A, ld, F.nf, k0, kb, F.id, h->d_status, h->inv16);
+            if (cols > 0)
+              hipLaunchKernelGGL(panel_trsm_kernel, dim3((cols + 63) / 64), dim3(256), 0, sA, A, ld, F.n, k0, kb, (const double*)h->inv16);
+          }
+          h->kt.end(kt, sA, (double)kb * kb * kb / 3.0 + (double)kb * kb * cols);
+        }
+        for (int k = k0; h->old_panel && k < kend; k += NB) {  // P_i, previous form
           const int nb = std::min(NB, kend - k);
           const int cols = F.n - k - nb;
           const int g = std::max(1, (cols + 63) / 64);
@@ -783,6 +807,8 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
   if (h->cfg.world_size < 1) h->cfg.world_size = 1;
   h->device = cfg->device;
   h->lookahead = getenv("LMGPU_LOOKAHEAD") != nullptr;
+  h->old_panel = getenv("LMGPU_OLD_PANEL") != nullptr;
+  h->two_launch_panel = getenv("LMGPU_PANEL_2L") != nullptr;
   h->la_debug = getenv("LMGPU_LA_DEBUG") ? atoi(getenv("LMGPU_LA_DEBUG")) : 0;
   *out = h;
   if (h->device >= 0) {
@@ -796,6 +822,8 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
     HIPCHECK(hipFuncSetAttribute((const void*)lds_front_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra + 64));
     HIPCHECK(hipFuncSetAttribute((const void*)syrk_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSyrkLds));
     HIPCHECK(hipFuncSetAttribute((const void*)panel_fused_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS_BYTES));
+    HIPCHECK(hipFuncSetAttribute((const void*)diag_potrf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
+    HIPCHECK(hipFuncSetAttribute((const void*)panel_dataflow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
   }
   return LMGPU_OK;
 }
@@ -826,7 +854,7 @@ int lmgpu_destroy(lmgpu_handle* h) {
       if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     for (hipEvent_t e : h->kt.pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->la_events) (void)hipEventDestroy(e);
-    fr(h->bs_inv); fr(h->bs_x); fr(h->bs_flags);
+    fr(h->bs_inv); fr(h->bs_x); fr(h->bs_flags); fr(h->inv16); fr(h->d_pflags);
     fr(h->d_gpblk); fr(h->d_gpent); fr(h->d_gvblk); fr(h->d_gvent); fr(h->d_gcorner);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1275,6 +1303,9 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
       if (h->front_active[fi] && P.fronts[fi].cls == 1) max_nf = std::max(max_nf, P.fronts[fi].nf);
     const int max_blk = (max_nf + NB - 1) / NB;
     HIPCHECK(hipMalloc((void**)&h->bs_inv, (size_t)max_blk * NB * NB * sizeof(double)));
+    HIPCHECK(hipMalloc((void**)&h->inv16, 16 * 256 * sizeof(double)));
+    h->pflags_panels = (P.max_front_n + NBO - 1) / NBO + 1;
+    HIPCHECK(hipMalloc((void**)&h->d_pflags, (size_t)h->pflags_panels * PDF_FLAG_WORDS * sizeof(unsigned int)));
     HIPCHECK(hipMalloc((void**)&h->bs_x, (size_t)max_blk * NB * sizeof(double)));
     HIPCHECK(hipMalloc((void**)&h->bs_flags, (size_t)max_blk * sizeof(unsigned int)));
   }
