@@ -284,9 +284,8 @@ __device__ __forceinline__ void glds_row(const double* g, double* lds_row) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_row, 16, 0, 0);
 }
 
-__global__ __launch_bounds__(256, 2) void syrk_mfma_kernel(double* __restrict__ A, int ld, int n, int p0, int kp, int r0, int r1) {
-  extern __shared__ double sm[];  // [2 stages][2 operands][SYRK_KC][SYRK_LDW]
-  const int ti = blockIdx.y, tj = blockIdx.x;
+__device__ __forceinline__ void syrk_tile(double* __restrict__ A, int ld, int n, int p0, int kp, int r0, int r1, int ti, int tj,
+                                          double* sm /* [2 stages][2 operands][SYRK_KC][SYRK_LDW] */) {
   if (tj < ti) return;
   const int it0 = r0 + ti * 128, jt0 = r0 + tj * 128;  // tile origins
   if (it0 >= r1 || jt0 >= n) return;
@@ -355,6 +354,11 @@ __global__ __launch_bounds__(256, 2) void syrk_mfma_kernel(double* __restrict__ 
         const int col = j0 + b * 16 + cc;
         if (row < r1 && col < n && col >= row) A[(size_t)row * ld + col] += acc[a][b][r];
       }
+}
+
+__global__ __launch_bounds__(256, 2) void syrk_mfma_kernel(double* __restrict__ A, int ld, int n, int p0, int kp, int r0, int r1) {
+  extern __shared__ double sm[];
+  syrk_tile(A, ld, n, p0, kp, r0, r1, blockIdx.y, blockIdx.x, sm);
 }
 
 // ---------------------------------------------------------------- back-substitution on an HBM front

@@ -346,21 +346,28 @@ __global__ __launch_bounds__(256) void panel_trsm_kernel(double* __restrict__ A,
 //   potrf(0) -> hand-off -> [workgroup 1: solve X_0, one tile update, potrf(1)] -> hand-off -> ...
 // i.e. four register Choleskys, three tile solves/updates and four hand-offs per 256 rows, with all other work beside it.
 // Hand-offs follow cdna_hip_programming.md Guideline 16: plain stores, every wave drains (s_waitcnt vmcnt(0)), workgroup
-// barrier, ONE lane: agent-scope release fence, wait, relaxed agent-scope flag store; consumer: ONE lane polls relaxed,
-// ONE agent-scope acquire fence, wait, workgroup barrier, then plain vector loads.  Logical workgroup ids come from a
-// ticket counter, so a workgroup only ever waits for workgroups that started before it (no dispatch-order assumption).
-// flags: [0] ticket, [4 + j] diag_ready[j], [8 + 4 i + j] tile_ready[i][j]; zeroed by the host before the launch.
-#define PDF_FLAG_WORDS 32
+// barrier, ONE lane: agent-scope release fence, wait, relaxed agent-scope flag store / add; consumer: ONE lane polls
+// relaxed, ONE agent-scope acquire fence, wait, workgroup barrier, then plain vector loads.  Logical workgroup ids come
+// from a ticket counter, so a workgroup only ever waits for workgroups that started before it (no dispatch-order assumption).
+// flags (zeroed by the host before the launch): [0] ticket, [4 + j] diag_ready[j], [8 + 4 i + j] tile_ready[i][j],
+// [PDF_TA0 + tj] number of finished trailing-update tiles of column tile tj in the next panel's rows (fused step only).
+#define PDF_TA0 32
+#define PDF_FLAG_WORDS 256
+#define PDF_MAX_COLTILES (PDF_FLAG_WORDS - PDF_TA0)
 #define PDF_SPIN_LIMIT 40000000L
+#define PDF_LDS_DOUBLES (2 * 64 * DP_LDW)
+#define PDF_LDS_BYTES (PDF_LDS_DOUBLES * 8)
 
-__device__ __forceinline__ bool pdf_wait(unsigned int* flags, unsigned int need_mask, int* s_ok, int tid) {
-  // need_mask: bit w set <=> flags[w] must be non-zero
+// all threads call; thread 0 waits until flags[w] >= need for the (up to two) words given, then one acquire covers the workgroup
+__device__ __forceinline__ bool pdf_wait(unsigned int* flags, int w0, unsigned int need0, int w1, unsigned int need1, int* s_ok, int tid) {
   if (tid == 0) {
     bool ok = true;
-    for (int w = 4; w < PDF_FLAG_WORDS && ok; w++) {
-      if (!((need_mask >> w) & 1u)) continue;
+    for (int q = 0; q < 2 && ok; q++) {
+      const int w = q ? w1 : w0;
+      const unsigned int need = q ? need1 : need0;
+      if (w < 0) continue;
       long spins = 0;
-      while (__hip_atomic_load(&flags[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+      while (__hip_atomic_load(&flags[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
         __builtin_amdgcn_s_sleep(1);
         if (++spins > PDF_SPIN_LIMIT) {
           ok = false;
@@ -383,22 +390,18 @@ __device__ __forceinline__ void pdf_publish(unsigned int* flag, bool signaller) 
   if (signaller) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
-__global__ __launch_bounds__(256) void panel_dataflow_kernel(double* A, int ld, int n, int nf, int ko, int kb, int front_id, int* status,
-                                                              double* inv16, unsigned int* flags) {
-  extern __shared__ __attribute__((aligned(16))) double dsm[];
+// The work of logical workgroup b on the outer panel [ko, ko + kb) (kb a multiple of 64).  ta_need > 0: the panel's rows
+// are being produced by trailing-update tiles of the same launch; wait for the ones covering this workgroup's columns.
+__device__ __forceinline__ void panel_role(double* A, int ld, int n, int nf, int ko, int kb, int b, int front_id, int* status, double* inv16,
+                                           unsigned int* flags, double* dsm, int* s_ok, bool fused) {
   double(*D)[DP_LDW] = (double(*)[DP_LDW])dsm;
-  double(*I16)[16][17] = (double(*)[16][17])(dsm + 64 * DP_LDW);
-  double(*XB)[64][DP_LDW] = (double(*)[64][DP_LDW])(dsm + 64 * DP_LDW + 4 * 16 * 17);
-  __shared__ int s_bid, s_ok;
+  double(*XB)[DP_LDW] = (double(*)[DP_LDW])(dsm + 64 * DP_LDW);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kk = lane >> 4, cc = lane & 15;
-  if (tid == 0) s_bid = (int)atomicAdd(&flags[0], 1u);
-  __syncthreads();
-  const int b = s_bid;
-  const int nblk = kb >> 6;  // kb is a multiple of 64 (host guarantees; partial panels take the two-launch path)
+  const int nblk = kb >> 6;
   const bool diagwg = b < nblk;
   const int c0 = diagwg ? ko + 64 * b + 16 * wave : ko + kb + 64 * (b - nblk) + 16 * wave;
   const int col = min(c0 + cc, n - 1);
@@ -407,6 +410,10 @@ __global__ __launch_bounds__(256) void panel_dataflow_kernel(double* A, int ld, 
   double* Ab = A + (size_t)ko * ld + ko;  // diagonal block
   double* P = A + (size_t)ko * ld;        // row panel
   bool healthy = true;
+  if (fused) {
+    const int tj = (diagwg ? 64 * b : kb + 64 * (b - nblk)) >> 7;  // 128-column tile of the trailing update (its origin is ko)
+    healthy &= pdf_wait(flags, PDF_TA0 + tj, (unsigned int)(min(tj, 1) + 1), -1, 0u, s_ok, tid);
+  }
   double4_t X[4][4];
   double4_t Td[4];  // diagonal workgroup: its strip of tile (b, b), right-looking
   if (diagwg) {
@@ -425,10 +432,8 @@ __global__ __launch_bounds__(256) void panel_dataflow_kernel(double* A, int ld, 
 #pragma unroll
         for (int r = 0; r < 4; r++) T[g][r] = P[(size_t)(64 * j + 16 * g + kk + 4 * r) * ld + col];
       if (j > 0) {
-        // tiles R_ij (i < j) of block column j, published by workgroup j
-        unsigned int mask = 0;
-        for (int i = 0; i < j; i++) mask |= 1u << (8 + 4 * i + j);
-        healthy &= pdf_wait(flags, mask, &s_ok, tid);
+        // tiles R_ij (i < j) of block column j, published by workgroup j in the order i = 0, 1, ..: the last one implies the others
+        healthy &= pdf_wait(flags, 8 + 4 * (j - 1) + j, 1u, -1, 0u, s_ok, tid);
 #pragma unroll
         for (int i = 0; i < j; i++) {
           const double* Rij = Ab + (size_t)(64 * i) * ld + 64 * j;
@@ -446,7 +451,7 @@ __global__ __launch_bounds__(256) void panel_dataflow_kernel(double* A, int ld, 
           }
         }
       }
-      healthy &= pdf_wait(flags, 1u << (4 + j), &s_ok, tid);
+      healthy &= pdf_wait(flags, 4 + j, 1u, -1, 0u, s_ok, tid);
       {
         const double* Rjj = Ab + (size_t)(64 * j) * ld + 64 * j;
         const double* Ij = inv16 + (size_t)(4 * j) * 256;
@@ -485,17 +490,17 @@ __global__ __launch_bounds__(256) void panel_dataflow_kernel(double* A, int ld, 
         }
       }
       if (diagwg) {
-        // own tile (j, b): keep a copy in LDS for the A operands, publish it, fold it into the diagonal tile
+        // own tile (j, b): a copy in LDS for the A operands, publish it, fold it into the diagonal tile
 #pragma unroll
         for (int g = 0; g < 4; g++)
 #pragma unroll
-          for (int r = 0; r < 4; r++) XB[j][16 * g + kk + 4 * r][wc] = X[j][g][r];
+          for (int r = 0; r < 4; r++) XB[16 * g + kk + 4 * r][wc] = X[j][g][r];
         pdf_publish(&flags[8 + 4 * j + b], tid == 64);
 #pragma unroll
         for (int s = 0; s < 16; s++)
 #pragma unroll
           for (int g = 0; g < 4; g++)
-            Td[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(-XB[j][4 * s + kk][16 * g + cc], X[j][s >> 2][s & 3], Td[g], 0, 0, 0);
+            Td[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(-XB[4 * s + kk][16 * g + cc], X[j][s >> 2][s & 3], Td[g], 0, 0, 0);
       }
     }
   }
@@ -549,6 +554,15 @@ __global__ __launch_bounds__(256) void panel_dataflow_kernel(double* A, int ld, 
     }
   }
   pdf_publish(&flags[4 + b], tid == 64);
+}
+
+__global__ __launch_bounds__(256) void panel_dataflow_kernel(double* A, int ld, int n, int nf, int ko, int kb, int front_id, int* status,
+                                                              double* inv16, unsigned int* flags) {
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  __shared__ int s_bid, s_ok;
+  if (threadIdx.x == 0) s_bid = (int)atomicAdd(&flags[0], 1u);
+  __syncthreads();
+  panel_role(A, ld, n, nf, ko, kb, s_bid, front_id, status, inv16, flags, dsm, &s_ok, false);
 }
 
 }  // namespace lmgpu

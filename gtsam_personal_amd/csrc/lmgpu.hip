@@ -27,6 +27,7 @@
 #include "../../include/lmgpu.h"
 #include "kernels_dense.hpp"
 #include "kernels_potrf.hpp"
+#include "kernels_step.hpp"
 #include "kernels_schur.hpp"
 #include "plan.hpp"
 
@@ -180,12 +181,11 @@ struct lmgpu_handle {
   int n_counted = 0;                 // local factors [0, n_counted) enter this rank's error sums (each factor counted on one rank)
 
   // ---- device state
-  hipStream_t stream = nullptr, stream2 = nullptr;
-  std::vector<hipEvent_t> la_events;  // look-ahead ordering between the two streams
+  hipStream_t stream = nullptr;
   double *bs_inv = nullptr, *bs_x = nullptr;  // dataflow back-substitution scratch
   double* inv16 = nullptr;                     // 16 x (16x16) inverses of the current outer panel's diagonal tiles
-  bool old_panel = false;                      // LMGPU_OLD_PANEL=1: the fused 64-row panel steps (kept for A/B measurements)
   bool two_launch_panel = false;               // LMGPU_PANEL_2L=1: diag_potrf + panel_trsm for every outer panel (A/B)
+  bool no_fuse = false;                        // LMGPU_NO_FUSE=1: trailing update and next panel as separate launches (A/B)
   unsigned int* d_pflags = nullptr;            // hand-off flags of panel_dataflow_kernel, PDF_FLAG_WORDS per outer panel
   int pflags_panels = 0;
   unsigned int* bs_flags = nullptr;
@@ -229,8 +229,6 @@ struct lmgpu_handle {
   lmgpu_timings tim{};
   hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   KTimer kt;
-  int la_debug = 0;  // LMGPU_LA_DEBUG: 1 = device-sync after every enqueue, 2 = after every outer panel (bisecting aid)
-  bool lookahead = false;  // LMGPU_LOOKAHEAD=1: experimental two-stream look-ahead (measured r01: wrong results for >1 outer panel; off)
 
   ncclComm_t comm = nullptr;
   lmgpu_local_group* lgroup = nullptr;  // test-only in-process communicator (lmgpu_comm_init_local)
@@ -497,74 +495,58 @@ int do_eliminate(lmgpu_handle* h, double lambda) {
         { const int rca = allreduce_sum(h, A, (size_t)F.n * ld, s); if (rca) return rca; }
         h->kt.end(kt, s, (double)F.n * ld * 8.0);
       }
-      // two-level blocking: outer panels of NBO rows; inside, NB-row steps update only the rest of the outer panel.
-      // Look-ahead on a second stream: the big trailing update UB_i (rows beyond panel i+1) runs on stream B while stream A
-      // updates just the rows of panel i+1 (UA_i) and factors that panel (P_{i+1}).
-      //   P_i  needs UA_{i-1} (A, in order).   UA_i needs P_i (A) and UB_{i-1} (same rows: event).   UB_i needs P_i (event), UB_{i-1} (B).
-      hipStream_t sA = s, sB = h->lookahead ? h->stream2 : s;
-      auto syrk = [&](hipStream_t st, int p0, int kp, int r0, int r1) {
-        if (r0 >= r1 || r0 >= F.n) return;
-        const int Tr = (r1 - r0 + 127) / 128, Tc = (F.n - r0 + 127) / 128;
-        const int kts = h->kt.begin(LMGPU_KT_SYRK, st);
-        hipLaunchKernelGGL(syrk_mfma_kernel, dim3(Tc, Tr), dim3(256), kSyrkLds, st, A, ld, F.n, p0, kp, r0, r1);
-        // algorithmic flop: 2 x kp x (upper-trapezoid entries of rows r0..r1-1, columns row..n-1)
-        const double rows = r1 - r0, first = F.n - r0;
-        h->kt.end(kts, st, 2.0 * kp * (rows * first - rows * (rows - 1.0) / 2.0));
-      };
+      // Blocked right-looking partial Cholesky, outer panels of NBO = 256 rows.  Panel 0 is one dataflow launch
+      // (panel_dataflow_kernel); after that ONE launch per outer panel i (step_kernel): trailing update with panel i
+      // + factorisation of panel i+1 beside/behind it (look-ahead inside the launch, kernels_step.hpp).  A panel whose row
+      // count is not a multiple of 64 (the last one) takes the two-launch form diag_potrf_kernel + panel_trsm_kernel.
       const int np = (F.nf + NBO - 1) / NBO;
-      while ((int)h->la_events.size() < 2 * np) {
-        hipEvent_t e;
-        HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        h->la_events.push_back(e);
-      }
-      if (np > h->pflags_panels) {
+      if (np + 1 > h->pflags_panels) {
         h->err = "panel flag buffer too small";
         return LMGPU_INVALID;
       }
-      HIPCHECK(hipMemsetAsync(h->d_pflags, 0, (size_t)np * PDF_FLAG_WORDS * sizeof(unsigned int), sA));
+      HIPCHECK(hipMemsetAsync(h->d_pflags, 0, (size_t)(np + 1) * PDF_FLAG_WORDS * sizeof(unsigned int), s));
+      auto rows_of = [&](int i) { return std::min(F.nf, (i + 1) * NBO) - i * NBO; };
+      auto dataflow_ok = [&](int i) {  // panel i can run as block-column workgroups with flag hand-offs
+        return rows_of(i) % 64 == 0 && !h->two_launch_panel && (F.n - i * NBO + 127) / 128 <= PDF_MAX_COLTILES;
+      };
+      auto panel_flop = [&](int i) {
+        const double kb = rows_of(i), cols = F.n - i * NBO - kb;
+        return kb * kb * kb / 3.0 + kb * kb * cols;
+      };
+      auto panel_alone = [&](int i) {
+        const int k0 = i * NBO, kb = rows_of(i), cols = F.n - k0 - kb;
+        const int ktp = h->kt.begin(LMGPU_KT_PANEL, s);
+        if (dataflow_ok(i)) {
+          hipLaunchKernelGGL(panel_dataflow_kernel, dim3(kb / 64 + (cols + 63) / 64), dim3(256), PDF_LDS_BYTES, s, A, ld, F.n, F.nf, k0, kb, F.id,
+                             h->d_status, h->inv16, h->d_pflags + (size_t)i * PDF_FLAG_WORDS);
+        } else {
+          hipLaunchKernelGGL(diag_potrf_kernel, dim3(1), dim3(256), DIAG_LDS_BYTES, s, A, ld, F.nf, k0, kb, F.id, h->d_status, h->inv16);
+          if (cols > 0) hipLaunchKernelGGL(panel_trsm_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, A, ld, F.n, k0, kb, (const double*)h->inv16);
+        }
+        h->kt.end(ktp, s, panel_flop(i));
+      };
+      panel_alone(0);
       for (int i = 0; i < np; i++) {
-        const int k0 = i * NBO, kend = std::min(F.nf, k0 + NBO);
-        hipEvent_t evP = h->la_events[2 * i], evUB = h->la_events[2 * i + 1];
-        if (!h->old_panel) {  // P_i = diagonal block (one workgroup) + row panel solve
-          const int kb = kend - k0, cols = F.n - kend;
-          kt = h->kt.begin(LMGPU_KT_PANEL, sA);
-          if (kb % 64 == 0 && !h->two_launch_panel) {
-            hipLaunchKernelGGL(panel_dataflow_kernel, dim3(kb / 64 + (cols + 63) / 64), dim3(256), DIAG_LDS_BYTES, sA, A, ld, F.n, F.nf, k0, kb, F.id,
-                               h->d_status, h->inv16, h->d_pflags + (size_t)i * PDF_FLAG_WORDS);
-          } else {  // partial last panel
-            hipLaunchKernelGGL(diag_potrf_kernel, dim3(1), dim3(256), DIAG_LDS_BYTES, sA, A, ld, F.nf, k0, kb, F.id, h->d_status, h->inv16);
-            if (cols > 0)
-              hipLaunchKernelGGL(panel_trsm_kernel, dim3((cols + 63) / 64), dim3(256), 0, sA, A, ld, F.n, k0, kb, (const double*)h->inv16);
-          }
-          h->kt.end(kt, sA, (double)kb * kb * kb / 3.0 + (double)kb * kb * cols);
+        const int k0 = i * NBO, kb = rows_of(i), r0 = k0 + kb, m = F.n - r0;
+        if (m <= 0) break;
+        const bool fuse = (i + 1 < np) && dataflow_ok(i + 1) && !h->no_fuse;
+        const int T = (m + 127) / 128;
+        // algorithmic flop of the update: 2 x kb x (upper-triangle entries of the m x m trailing matrix)
+        const double upd_flop = 2.0 * kb * ((double)m * (m + 1) / 2.0);
+        if (fuse) {
+          const int kbn = rows_of(i + 1);
+          StepArgs a{A, ld, F.n, F.nf, k0, kb, kbn, F.id, h->d_status, h->inv16, h->d_pflags + (size_t)(i + 1) * PDF_FLAG_WORDS};
+          const int grid = T * (T + 1) / 2 + kbn / 64 + (m - kbn + 63) / 64;
+          const int kts = h->kt.begin(LMGPU_KT_SYRK, s);
+          hipLaunchKernelGGL(step_kernel, dim3(grid), dim3(256), STEP_LDS_BYTES, s, a);
+          h->kt.end(kts, s, upd_flop + panel_flop(i + 1));
+        } else {
+          const int kts = h->kt.begin(LMGPU_KT_SYRK, s);
+          hipLaunchKernelGGL(syrk_mfma_kernel, dim3(T, T), dim3(256), kSyrkLds, s, A, ld, F.n, k0, kb, r0, F.n);
+          h->kt.end(kts, s, upd_flop);
+          if (i + 1 < np) panel_alone(i + 1);
         }
-        for (int k = k0; h->old_panel && k < kend; k += NB) {  // P_i, previous form
-          const int nb = std::min(NB, kend - k);
-          const int cols = F.n - k - nb;
-          const int g = std::max(1, (cols + 63) / 64);
-          kt = h->kt.begin(LMGPU_KT_PANEL, sA);
-          hipLaunchKernelGGL((panel_fused_kernel<NB>), dim3(g), dim3(256), PANEL_LDS_BYTES, sA, A, ld, F.n, F.nf, k0, k, nb, F.id, h->d_status);
-          h->kt.end(kt, sA, (double)nb * nb * nb / 3.0 + (double)nb * nb * cols + 2.0 * (k - k0) * nb * (cols + nb));
-        }
-        HIPCHECK(hipEventRecord(evP, sA));
-        if (h->la_debug == 1) HIPCHECK(hipDeviceSynchronize());
-        if (!h->lookahead) {  // single stream: one trailing update of everything below the panel
-          syrk(sA, k0, kend - k0, kend, F.n);
-          continue;
-        }
-        const int next_end = std::min(F.n, kend + NBO);  // rows of panel i+1 (or the separator rows if this was the last panel)
-        if (i > 0) HIPCHECK(hipStreamWaitEvent(sA, h->la_events[2 * (i - 1) + 1], 0));
-        syrk(sA, k0, kend - k0, kend, next_end);  // UA_i
-        if (h->la_debug == 1) HIPCHECK(hipDeviceSynchronize());
-        if (h->la_debug == 5) HIPCHECK(hipEventRecord(evP, sA));  // level 5: UB_i waits for UA_i too (only UB_i || P_{i+1} overlaps)
-        HIPCHECK(hipStreamWaitEvent(sB, evP, 0));
-        syrk(sB, k0, kend - k0, next_end, F.n);   // UB_i
-        HIPCHECK(hipEventRecord(evUB, sB));
-        if (h->la_debug == 1 || h->la_debug == 2) HIPCHECK(hipDeviceSynchronize());
-        if (h->la_debug == 3) HIPCHECK(hipStreamWaitEvent(sA, evUB, 0));  // event-only serialisation (no overlap, no host sync)
-        if (h->la_debug == 4) HIPCHECK(hipStreamWaitEvent(sA, evUB, 0));  // level 4: same as 3 here (UA_i || UB_i still overlaps: UA_i was enqueued before)
       }
-      if (h->lookahead) HIPCHECK(hipStreamWaitEvent(sA, h->la_events[2 * (np - 1) + 1], 0));  // join
     }
   }
   HIPCHECK(hipGetLastError());
@@ -806,24 +788,21 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
   h->cfg = *cfg;
   if (h->cfg.world_size < 1) h->cfg.world_size = 1;
   h->device = cfg->device;
-  h->lookahead = getenv("LMGPU_LOOKAHEAD") != nullptr;
-  h->old_panel = getenv("LMGPU_OLD_PANEL") != nullptr;
   h->two_launch_panel = getenv("LMGPU_PANEL_2L") != nullptr;
-  h->la_debug = getenv("LMGPU_LA_DEBUG") ? atoi(getenv("LMGPU_LA_DEBUG")) : 0;
+  h->no_fuse = getenv("LMGPU_NO_FUSE") != nullptr;
   *out = h;
   if (h->device >= 0) {
     HIPCHECK(hipSetDevice(h->device));
     HIPCHECK(hipStreamCreate(&h->stream));
-    HIPCHECK(hipStreamCreate(&h->stream2));
     for (int i = 0; i < 8; i++) HIPCHECK(hipEventCreate(&h->ev[i]));
     HIPCHECK(hipHostMalloc((void**)&h->h_scal, 8 * sizeof(double), hipHostMallocDefault));
     HIPCHECK(hipHostMalloc((void**)&h->h_status, sizeof(int), hipHostMallocDefault));
     HIPCHECK(hipFuncSetAttribute((const void*)lds_front_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra + 64));
     HIPCHECK(hipFuncSetAttribute((const void*)lds_front_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra + 64));
     HIPCHECK(hipFuncSetAttribute((const void*)syrk_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSyrkLds));
-    HIPCHECK(hipFuncSetAttribute((const void*)panel_fused_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS_BYTES));
     HIPCHECK(hipFuncSetAttribute((const void*)diag_potrf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
-    HIPCHECK(hipFuncSetAttribute((const void*)panel_dataflow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
+    HIPCHECK(hipFuncSetAttribute((const void*)panel_dataflow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PDF_LDS_BYTES));
+    HIPCHECK(hipFuncSetAttribute((const void*)step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STEP_LDS_BYTES));
   }
   return LMGPU_OK;
 }
@@ -853,10 +832,8 @@ int lmgpu_destroy(lmgpu_handle* h) {
     for (int i = 0; i < 8; i++)
       if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     for (hipEvent_t e : h->kt.pool) (void)hipEventDestroy(e);
-    for (hipEvent_t e : h->la_events) (void)hipEventDestroy(e);
     fr(h->bs_inv); fr(h->bs_x); fr(h->bs_flags); fr(h->inv16); fr(h->d_pflags);
     fr(h->d_gpblk); fr(h->d_gpent); fr(h->d_gvblk); fr(h->d_gvent); fr(h->d_gcorner);
-    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
   }
   delete h;
