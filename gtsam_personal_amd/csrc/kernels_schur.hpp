@@ -11,8 +11,8 @@
 //   the (rhs, rhs) corner is a fixed-order reduction of one scalar per leaf.
 // Every destination entry is owned by exactly one lane, source lists have a fixed order and long lists are cut into
 // fixed contiguous chunks (one per wave) whose partial sums are added in chunk order => reproducible sums.
-// Entries are self-contained 16-byte records, fetched 64 at a time by the lanes and broadcast with shuffles, so the only
-// dependent HBM/L2 access per entry is the data itself.
+// Entries are self-contained 16-byte records, fetched 64 at a time by the lanes and broadcast with v_readlane, so the only
+// dependent HBM/L2 access per entry is the data itself; the products run on the matrix cores (one MFMA per entry).
 // This is the same arithmetic as HessianFactor::updateHessian of the child separator factors
 // (gtsam/linear/HessianFactor.cpp:349-373), grouped by destination.
 #pragma once
@@ -42,105 +42,92 @@ struct GVarEntry {   // 16 bytes
   int16_t rows, c0, cb, pad;  // rows, first column of the separator variable, column of b
 };
 
-__device__ __forceinline__ long long shfl_ll(long long v, int src) {
-  const int lo = __shfl((int)(v & 0xffffffffLL), src), hi = __shfl((int)(v >> 32), src);
+typedef double double4s_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ long long readlane_ll(long long v, int src /* wave-uniform */) {
+  const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffLL), src), hi = __builtin_amdgcn_readlane((int)(v >> 32), src);
   return ((long long)hi << 32) | (unsigned int)lo;
 }
 
-// WAVES waves per destination block (1 for short lists, 4 for long ones); grid = number of blocks
+// WAVES waves per destination block (1 for short lists, 4 for long ones); grid = number of blocks.
+// One v_mfma_f64_16x16x4_f64 per list entry:  D[i][j] += sum_k S_a[k][i] S_b[k][j]  with lane (i = lane & 15, k = lane >> 4)
+// supplying S_a[k][i] as the A operand and S_b[k][i] as the B operand (two 8-byte loads per lane and entry; rows k >= nf and
+// columns >= the block dims are zero).  Four accumulators take entries e, e+1, e+2, e+3 of every group of four and are
+// added in a fixed order; waves take fixed contiguous chunks of the list.
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void schur_pairs_kernel(const GPairBlock* __restrict__ blocks, const GPairEntry* __restrict__ entries,
                                                                   double* __restrict__ pool, int64_t f_off, int ld) {
-  __shared__ double part[WAVES][128];
+  __shared__ double part[WAVES][4][64];
   const GPairBlock B = blocks[blockIdx.x];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nout = B.da * B.db;
-  const int o0 = lane, o1 = lane + 64;  // da * db <= 81
-  const int i0 = o0 / B.db, j0 = o0 - i0 * B.db, i1 = o1 / B.db, j1 = o1 - i1 * B.db;
-  const bool v0 = o0 < nout, v1 = o1 < nout;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int kk = lane >> 4, cc = lane & 15;
+  const bool va = cc < B.da, vb = cc < B.db;
   const int per = (B.count + WAVES - 1) / WAVES;
   const int cb = B.begin + wave * per, ce = min(B.begin + B.count, cb + per);
-  double s0 = 0, s1 = 0;
+  double4s_t acc[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) acc[u] = double4s_t{0, 0, 0, 0};
   for (int base = cb; base < ce; base += 64) {
     const int cnt = min(64, ce - base);
     long long moff = 0, mmeta = 0;
     if (lane < cnt) {
       const GPairEntry E = entries[base + lane];
       moff = E.rsd_off;
-      mmeta = ((long long)(unsigned short)E.sa) | ((long long)(unsigned short)E.sb << 16) | ((long long)(unsigned short)E.nf << 32) |
-              ((long long)(unsigned short)E.ld << 48);
+      mmeta = ((long long)(unsigned short)E.sa) | ((long long)(unsigned short)E.sb << 16) | ((long long)(unsigned short)E.nf << 32);
     }
-    for (int e = 0; e < cnt; e += 4) {  // 4 entries per trip: their loads are independent and in flight together
-      double t0[4], t1[4];
+    for (int e = 0; e < cnt; e += 4) {
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const int eu = min(e + u, cnt - 1);
-        const long long off = shfl_ll(moff, eu), meta = shfl_ll(mmeta, eu);
-        const int sa = (int)(meta & 0xffff), sb = (int)((meta >> 16) & 0xffff), nf = (int)((meta >> 32) & 0xffff), lde = (int)((meta >> 48) & 0xffff);
+        const long long off = readlane_ll(moff, eu), meta = readlane_ll(mmeta, eu);
+        const int sa = (int)(meta & 0xffff), sb = (int)((meta >> 16) & 0xffff), nf = (int)((meta >> 32) & 0xffff);
         const double* St = pool + off;
-        (void)lde;
-        double a0 = 0, a1 = 0;
-        for (int r = 0; r < nf; r++) {
-          if (v0) a0 += St[sa + i0 * nf + r] * St[sb + j0 * nf + r];
-          if (v1) a1 += St[sa + i1 * nf + r] * St[sb + j1 * nf + r];
-        }
         const bool valid = e + u < cnt;
-        t0[u] = valid ? a0 : 0.0;
-        t1[u] = valid ? a1 : 0.0;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; u++) {  // fixed order
-        s0 += t0[u];
-        s1 += t1[u];
+        for (int k0 = 0; k0 < nf; k0 += 4) {
+          const int k = k0 + kk;
+          const bool ka = valid && va && k < nf, kb = valid && vb && k < nf;
+          const double av = St[ka ? sa + cc * nf + k : sa], bv = St[kb ? sb + cc * nf + k : sb];
+          acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(ka ? av : 0.0, kb ? bv : 0.0, acc[u], 0, 0, 0);
+        }
       }
     }
   }
+  double4s_t sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
   if (WAVES > 1) {
-    part[wave][lane] = s0;
-    part[wave][lane + 64] = s1;
+#pragma unroll
+    for (int r = 0; r < 4; r++) part[wave][r][lane] = sum[r];
     __syncthreads();
     if (wave != 0) return;
-    s0 = 0;
-    s1 = 0;
+    sum = double4s_t{0, 0, 0, 0};
 #pragma unroll
-    for (int w = 0; w < WAVES; w++) {
-      s0 += part[w][lane];
-      s1 += part[w][lane + 64];
-    }
+    for (int w = 0; w < WAVES; w++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) sum[r] += part[w][r][lane];
   }
   double* A = pool + f_off;
   const bool diag = (B.pa == B.pb);
-  if (v0 && (!diag || i0 <= j0)) A[(size_t)(B.pa + i0) * ld + B.pb + j0] -= s0;
-  if (v1 && (!diag || i1 <= j1)) A[(size_t)(B.pa + i1) * ld + B.pb + j1] -= s1;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int i = kk + 4 * r, j = cc;
+    if (i < B.da && j < B.db && (!diag || i <= j)) A[(size_t)(B.pa + i) * ld + B.pb + j] -= sum[r];
+  }
 }
 
-// 16 waves per separator variable (BAL: ~1000 factors per camera)
+// 16 waves per separator variable (BAL: ~1000 factors per camera):  [A_v^T A_v | A_v^T b]  as one MFMA per factor,
+// A operand lane (i, k): A_v[k][i];  B operand lane (j, k): A_v[k][j] for j < d, b[k] for j == d.
 #define SCHUR_FW 16
 __global__ __launch_bounds__(64 * SCHUR_FW) void schur_factor_kernel(const GVarBlock* __restrict__ blocks, const GVarEntry* __restrict__ entries,
                                                                       double* __restrict__ pool, int64_t f_off, int ld, int n) {
-  __shared__ double part[SCHUR_FW][128];
+  __shared__ double part[SCHUR_FW][4][64];
   const GVarBlock B = blocks[blockIdx.x];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, d = B.dv, nout = d * d + d;  // d x d block, then the rhs column
-  const int o0 = lane, o1 = lane + 64;
-  // output o < d*d: (i, j) of A_v^T A_v ; else row (o - d*d) of A_v^T b   -> columns (ci, cj) relative to the variable / b
-  auto cols = [&](int o, int& ci, int& cj, bool& isb) {
-    if (o < d * d) {
-      ci = o / d;
-      cj = o - ci * d;
-      isb = false;
-    } else {
-      ci = o - d * d;
-      cj = 0;
-      isb = true;
-    }
-  };
-  int a0, b0, a1, b1;
-  bool r0, r1;
-  cols(o0, a0, b0, r0);
-  cols(o1, a1, b1, r1);
-  const bool v0 = o0 < nout, v1 = o1 < nout;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), d = B.dv;
+  const int kk = lane >> 4, cc = lane & 15;
+  const bool va = cc < d, vb = cc <= d;
   const int per = (B.count + SCHUR_FW - 1) / SCHUR_FW;
   const int cbeg = B.begin + wave * per, cend = min(B.begin + B.count, cbeg + per);
-  double s0 = 0, s1 = 0;
+  double4s_t acc[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) acc[u] = double4s_t{0, 0, 0, 0};
   for (int base = cbeg; base < cend; base += 64) {
     const int cnt = min(64, cend - base);
     long long moff = 0, mmeta = 0;
@@ -150,59 +137,43 @@ __global__ __launch_bounds__(64 * SCHUR_FW) void schur_factor_kernel(const GVarB
       mmeta = ((long long)(unsigned short)E.rows) | ((long long)(unsigned short)E.c0 << 16) | ((long long)(unsigned short)E.cb << 32);
     }
     for (int e = 0; e < cnt; e += 4) {
-      double t0[4], t1[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const int eu = min(e + u, cnt - 1);
-        const long long off = shfl_ll(moff, eu), meta = shfl_ll(mmeta, eu);
-        const int m = (int)(meta & 0xffff), c0 = (int)((meta >> 16) & 0xffff), cb = (int)((meta >> 32) & 0xffff);
+        const long long off = readlane_ll(moff, eu), meta = readlane_ll(mmeta, eu);
+        const int m = (int)(meta & 0xffff), c0 = (int)((meta >> 16) & 0xffff), cbc = (int)((meta >> 32) & 0xffff);
         const double* J = pool + off;
-        double x0 = 0, x1 = 0;
-        if (v0) {
-          const double* x = J + (c0 + a0) * m;
-          const double* y = J + (r0 ? cb : c0 + b0) * m;
-          for (int r = 0; r < m; r++) x0 += x[r] * y[r];
-        }
-        if (v1) {
-          const double* x = J + (c0 + a1) * m;
-          const double* y = J + (r1 ? cb : c0 + b1) * m;
-          for (int r = 0; r < m; r++) x1 += x[r] * y[r];
-        }
         const bool valid = e + u < cnt;
-        t0[u] = valid ? x0 : 0.0;
-        t1[u] = valid ? x1 : 0.0;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        s0 += t0[u];
-        s1 += t1[u];
+        const int bcol = (cc < d) ? c0 + cc : cbc;
+        for (int k0 = 0; k0 < m; k0 += 4) {
+          const int k = k0 + kk;
+          const bool ka = valid && va && k < m, kb = valid && vb && k < m;
+          const double av = J[ka ? (c0 + cc) * m + k : 0], bv = J[kb ? bcol * m + k : 0];
+          acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(ka ? av : 0.0, kb ? bv : 0.0, acc[u], 0, 0, 0);
+        }
       }
     }
   }
-  part[wave][lane] = s0;
-  part[wave][lane + 64] = s1;
+  double4s_t sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+  for (int r = 0; r < 4; r++) part[wave][r][lane] = sum[r];
   __syncthreads();
   if (wave != 0) return;
-  s0 = 0;
-  s1 = 0;
+  sum = double4s_t{0, 0, 0, 0};
 #pragma unroll
-  for (int w = 0; w < SCHUR_FW; w++) {
-    s0 += part[w][lane];
-    s1 += part[w][lane + 64];
-  }
+  for (int w = 0; w < SCHUR_FW; w++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) sum[r] += part[w][r][lane];
   double* A = pool + f_off;
-  if (v0) {
-    if (!r0) {
-      if (a0 <= b0) A[(size_t)(B.pv + a0) * ld + B.pv + b0] += s0;
-    } else {
-      A[(size_t)(B.pv + a0) * ld + n - 1] += s0;
-    }
-  }
-  if (v1) {
-    if (!r1) {
-      if (a1 <= b1) A[(size_t)(B.pv + a1) * ld + B.pv + b1] += s1;
-    } else {
-      A[(size_t)(B.pv + a1) * ld + n - 1] += s1;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int i = kk + 4 * r, j = cc;
+    if (i < d) {
+      if (j < d) {
+        if (i <= j) A[(size_t)(B.pv + i) * ld + B.pv + j] += sum[r];
+      } else if (j == d) {
+        A[(size_t)(B.pv + i) * ld + n - 1] += sum[r];
+      }
     }
   }
 }
