@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void panel_trsm_kernel(double* __restrict__ A,
 // relaxed, ONE agent-scope acquire fence, wait, workgroup barrier, then plain vector loads.  Logical workgroup ids come
 // from a ticket counter, so a workgroup only ever waits for workgroups that started before it (no dispatch-order assumption).
 // flags (zeroed by the host before the launch): [0] ticket, [4 + j] diag_ready[j], [8 + 4 i + j] tile_ready[i][j],
-// [PDF_TA0 + tj] number of finished trailing-update tiles of column tile tj in the next panel's rows (fused step only).
+// [PDF_TA0 + sj] number of finished 64x64 trailing-update tiles of column strip sj in the next panel's rows (fused step only).
 #define PDF_TA0 32
 #define PDF_FLAG_WORDS 256
 #define PDF_MAX_COLTILES (PDF_FLAG_WORDS - PDF_TA0)
@@ -411,8 +411,8 @@ __device__ __forceinline__ void panel_role(double* A, int ld, int n, int nf, int
   double* P = A + (size_t)ko * ld;        // row panel
   bool healthy = true;
   if (fused) {
-    const int tj = (diagwg ? 64 * b : kb + 64 * (b - nblk)) >> 7;  // 128-column tile of the trailing update (its origin is ko)
-    healthy &= pdf_wait(flags, PDF_TA0 + tj, (unsigned int)(min(tj, 1) + 1), -1, 0u, s_ok, tid);
+    const int sj = diagwg ? b : nblk + (b - nblk);  // 64-column strip of the trailing update (its origin is ko)
+    healthy &= pdf_wait(flags, PDF_TA0 + sj, (unsigned int)(min(sj, 3) + 1), -1, 0u, s_ok, tid);
   }
   double4_t X[4][4];
   double4_t Td[4];  // diagonal workgroup: its strip of tile (b, b), right-looking

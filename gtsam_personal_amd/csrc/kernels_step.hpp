@@ -24,6 +24,53 @@ struct StepArgs {
   unsigned int* flags;
 };
 
+// 64x64 tile of the trailing update for the rows of the NEXT panel (the head of the dependency chain): four waves, 32x32 each,
+// operand fragments straight from L2 (no LDS staging; 1/4 of a 128x128 tile's latency).  C[i][j] -= sum_p P[p][i] P[p][j].
+__device__ __forceinline__ void syrk_subtile64(double* __restrict__ A, int ld, int n, int p0, int kp, int r0, int si, int sj) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kk = lane >> 4, cc = lane & 15;
+  const int wr = wave >> 1, wc = wave & 1;
+  if (si == sj && wr > wc) return;
+  const int i0 = r0 + 64 * si + 32 * wr, j0 = r0 + 64 * sj + 32 * wc;
+  if (i0 >= n || j0 >= n) return;
+  const double* P = A + (size_t)p0 * ld;
+  double4_t acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++) acc[a][b] = double4_t{0, 0, 0, 0};
+  for (int k0 = 0; k0 < kp; k0 += 16) {
+    double af[4][2], bf[4][2];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const int k = min(k0 + 4 * s + kk, kp - 1);
+      const bool kv = k0 + 4 * s + kk < kp;
+      const double* row = P + (size_t)k * ld;
+#pragma unroll
+      for (int a = 0; a < 2; a++) {
+        const double v = row[i0 + 16 * a + cc];
+        af[s][a] = kv ? -v : 0.0;
+      }
+#pragma unroll
+      for (int b = 0; b < 2; b++) bf[s][b] = row[j0 + 16 * b + cc];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s][a], bf[s][b], acc[a][b], 0, 0, 0);
+  }
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = i0 + 16 * a + kk + 4 * r, col = j0 + 16 * b + cc;
+        if (row < n && col < n && col >= row) A[(size_t)row * ld + col] += acc[a][b][r];
+      }
+}
+
 #define STEP_LDS_BYTES (2 * 2 * SYRK_KC * SYRK_LDW * 8)
 static_assert(STEP_LDS_BYTES >= PDF_LDS_BYTES, "panel roles reuse the update's LDS");
 
@@ -36,13 +83,23 @@ __global__ __launch_bounds__(256, 2) void step_kernel(StepArgs a) {
   const int r0 = a.p0 + a.kp, m = a.n - r0;
   const int T = (m + 127) >> 7;  // tile rows = tile columns of the trailing matrix
   const bool next = a.kb_next > 0;
-  const int nTA = next ? (T >= 2 ? 2 * T - 1 : T) : 0;
+  // rows of the next panel (tile rows 0 and 1) go as 64x64 sub-tiles, strip by strip: strip sj has min(sj, 3) + 1 of them
+  const int S = (m + 63) >> 6;
+  const int nTA = next ? (S >= 4 ? 6 + 4 * (S - 3) : S * (S + 1) / 2) : 0;
+  const int nTArows = next ? (T >= 2 ? 2 * T - 1 : T) : 0;  // 128x128 tiles they replace
   const int nd = next ? (a.kb_next >> 6) : 0;
   const int nTiles = T * (T + 1) / 2;
-  if (t < nTA) {  // tile rows 0 and 1, published per column tile
-    const int ti = (t < T) ? 0 : 1, tj = (t < T) ? t : t - T + 1;
-    syrk_tile(a.A, a.ld, a.n, a.p0, a.kp, r0, a.n, ti, tj, sm);
-    pdf_publish(&a.flags[PDF_TA0 + tj], threadIdx.x == 0);
+  if (t < nTA) {
+    int si, sj;
+    if (t < 6) {
+      sj = (t >= 3) ? 2 : (t >= 1 ? 1 : 0);
+      si = t - sj * (sj + 1) / 2;
+    } else {
+      sj = 3 + ((t - 6) >> 2);
+      si = (t - 6) & 3;
+    }
+    syrk_subtile64(a.A, a.ld, a.n, a.p0, a.kp, r0, si, sj);
+    pdf_publish(&a.flags[PDF_TA0 + sj], threadIdx.x == 0);
     return;
   }
   t -= nTA;
@@ -51,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void step_kernel(StepArgs a) {
     return;
   }
   t -= nd;
-  if (t < nTiles - nTA) {  // remaining tiles, row-major over tile rows first..T-1
+  if (t < nTiles - nTArows) {  // remaining tiles, row-major over tile rows first..T-1
     int ti = next ? 2 : 0;
     if (!next) {
       // all tiles
@@ -64,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void step_kernel(StepArgs a) {
     syrk_tile(a.A, a.ld, a.n, a.p0, a.kp, r0, a.n, ti, ti + rem, sm);
     return;
   }
-  t -= nTiles - nTA;
+  t -= nTiles - nTArows;
   panel_role(a.A, a.ld, a.n, a.nf, r0, a.kb_next, nd + t, a.front_id, a.status, a.inv16, a.flags, sm, &s_ok, true);
 }
 

@@ -507,7 +507,7 @@ int do_eliminate(lmgpu_handle* h, double lambda) {
       HIPCHECK(hipMemsetAsync(h->d_pflags, 0, (size_t)(np + 1) * PDF_FLAG_WORDS * sizeof(unsigned int), s));
       auto rows_of = [&](int i) { return std::min(F.nf, (i + 1) * NBO) - i * NBO; };
       auto dataflow_ok = [&](int i) {  // panel i can run as block-column workgroups with flag hand-offs
-        return rows_of(i) % 64 == 0 && !h->two_launch_panel && (F.n - i * NBO + 127) / 128 <= PDF_MAX_COLTILES;
+        return rows_of(i) % 64 == 0 && !h->two_launch_panel && (F.n - i * NBO + 63) / 64 <= PDF_MAX_COLTILES;
       };
       auto panel_flop = [&](int i) {
         const double kb = rows_of(i), cols = F.n - i * NBO - kb;
@@ -536,7 +536,8 @@ int do_eliminate(lmgpu_handle* h, double lambda) {
         if (fuse) {
           const int kbn = rows_of(i + 1);
           StepArgs a{A, ld, F.n, F.nf, k0, kb, kbn, F.id, h->d_status, h->inv16, h->d_pflags + (size_t)(i + 1) * PDF_FLAG_WORDS};
-          const int grid = T * (T + 1) / 2 + kbn / 64 + (m - kbn + 63) / 64;
+          const int S = (m + 63) / 64;
+          const int grid = T * (T + 1) / 2 - (T >= 2 ? 2 * T - 1 : T) + (S >= 4 ? 6 + 4 * (S - 3) : S * (S + 1) / 2) + kbn / 64 + (m - kbn + 63) / 64;
           const int kts = h->kt.begin(LMGPU_KT_SYRK, s);
           hipLaunchKernelGGL(step_kernel, dim3(grid), dim3(256), STEP_LDS_BYTES, s, a);
           h->kt.end(kts, s, upd_flop + panel_flop(i + 1));
