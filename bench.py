@@ -50,6 +50,19 @@ def cpu_baseline(n_cam, n_pt, obs, seed):
                 ms_per_iteration=1e3 * sum(times) / len(times), linearize_ms=1e3 * tm["linearize_s"], eliminate_ms=1e3 * tm["eliminate_s"])
 
 
+def pmc_traffic():
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (counters cannot be collected
+    from inside the process): {kernel: bytes}.  tools/pmc_summary.py writes the file; absent file -> traffic null."""
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except OSError:
+        return {}
+    return {k: v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"] for k, v in d.items()
+            if "hbm_read_bytes_corrected" in v and "hbm_write_bytes" in v}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,17 +166,20 @@ def main():
         }
         if kt is not None:
             syrk, lin = kt["syrk"], kt["linearize"]
+            pmc = pmc_traffic()
             if syrk["launches"] > 0 and syrk["ms"] > 0:
                 tf = syrk["work"] / (syrk["ms"] * 1e-3) / 1e12
-                out["roofline"] = {"kernel": "syrk_mfma_kernel (v_mfma_f64_16x16x4_f64 trailing update of the dense camera front)",
+                out["roofline"] = {"kernel": "step_kernel (v_mfma_f64_16x16x4_f64: trailing update of the dense camera front with outer panel i "
+                                             "+ factorisation of panel i+1 in the same launch)",
                                    "bound": "mfma", "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": tf / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                                   "frac": tf / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc.get("step_kernel"),
+                                   "traffic_unit": "HBM bytes per launch (FETCH_SIZE x 2 gfx950 correction + WRITE_SIZE; profiles/r01/pmc_summary.json)",
                                    "launches": syrk["launches"], "avg_launch_us": 1e3 * syrk["ms"] / syrk["launches"],
                                    "flop_per_launch": syrk["work"] / syrk["launches"]}
             if lin["launches"] > 0 and lin["ms"] > 0:
                 gbs = lin["work"] / (lin["ms"] * 1e-3) / 1e9
                 out["roofline_linearize"] = {"kernel": "sfm_linearize_kernel", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                             "frac": gbs / HBM_PEAK_GBPS, "traffic": None, "launches": lin["launches"],
+                                             "frac": gbs / HBM_PEAK_GBPS, "traffic": pmc.get("sfm_linearize_kernel"), "launches": lin["launches"],
                                              "avg_launch_us": 1e3 * lin["ms"] / lin["launches"], "bytes_per_launch": lin["work"] / lin["launches"]}
             out["kernel_ms_per_step"] = {k: v["ms"] / steps for k, v in kt.items()}
         # measured device peaks for context (not the roofline denominators)

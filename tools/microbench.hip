@@ -1,5 +1,5 @@
 // Development microbenchmark (not part of the product): times the dense-front kernels on a synthetic SPD matrix and
-// prints per-phase cycle shares of the panel kernel from s_memtime stamps.
+// (trailing-update tile at several sizes).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../gtsam_personal_amd/csrc tools/microbench.hip -o tools/microbench
 #include <hip/hip_runtime.h>
 
@@ -66,16 +66,6 @@ int main(int argc, char** argv) {
     }
     printf("%-44s best %9.1f us   avg %9.1f us\n", name, best * 1e3, tot / reps * 1e3);
   };
-  // 1. fused panel kernel at several trailing widths, without (kprev = 0) and with (kprev = 192) left-looking work
-  CK(hipFuncSetAttribute((const void*)panel_fused_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS_BYTES));
-  for (int kprev : {0, 192})
-    for (int k0 : {256, 4352, 8192}) {
-      const int cols = n - k0 - 64;
-      const int g = (cols + 63) / 64;
-      char nm[128];
-      snprintf(nm, sizeof nm, "panel_fused<64> k=%d kprev=%d cols=%d blocks=%d", k0, kprev, cols, g);
-      timeit(nm, 5, [&]() { hipLaunchKernelGGL((panel_fused_kernel<64>), dim3(g), dim3(256), PANEL_LDS_BYTES, 0, A, ld, n, n - 1, k0 - kprev, k0, 64, 0, status); });
-    }
   // 3. strip updates (K = 64, <= 192 rows) and big updates (K = 256) at several trailing sizes
   for (int r0 : {64, 4160, 8256}) {
     char nm[128];
