@@ -220,6 +220,10 @@ struct lmgpu_handle {
   std::vector<FrontDesc> h_fronts;
   std::vector<int64_t> f_off;  // HBM fronts: pool offset of the dense front (else -1)
   std::vector<int> f_ld;
+  std::vector<int64_t> s_off;  // multi-rank, replicated HBM front: pool offset of this rank's PARTIAL assembly (else -1)
+  hipStream_t comm_stream = nullptr;  // chunked all-reduce of the partial assembly, beside the factorisation
+  hipEvent_t asm_ev = nullptr;
+  std::vector<hipEvent_t> chunk_ev;
   std::vector<LevelWork> levels;
   int ntot = 0, nstore = 0;
   bool dampw_is_ones = false;
@@ -433,7 +437,11 @@ int do_eliminate(lmgpu_handle* h, double lambda) {
   {  // HBM fronts are accumulated into by their children (atomics) before their own level runs: clear them all first
     const int kt0 = h->kt.begin(LMGPU_KT_HBM_ASSEMBLE, s);
     for (const LevelWork& L : h->levels)
-      for (int fi : L.hbm) HIPCHECK(hipMemsetAsync(h->pool + h->f_off[fi], 0, (size_t)h->h_fronts[fi].n * h->f_ld[fi] * sizeof(double), s));
+      for (int fi : L.hbm) {
+        const size_t bytes = (size_t)h->h_fronts[fi].n * h->f_ld[fi] * sizeof(double);
+        HIPCHECK(hipMemsetAsync(h->pool + h->f_off[fi], 0, bytes, s));
+        if (h->s_off[fi] >= 0) HIPCHECK(hipMemsetAsync(h->pool + h->s_off[fi], 0, bytes, s));
+      }
     h->kt.end(kt0, s);
   }
   for (const LevelWork& L : h->levels) {
@@ -462,39 +470,77 @@ int do_eliminate(lmgpu_handle* h, double lambda) {
       const int ld = h->f_ld[fi];
       double* A = h->pool + off;
       const bool replicated = (F.pad & 1) != 0, own_terms = (F.pad & 2) == 0;
+      // multi-rank: the partial assembly goes to its own buffer (aoff) and is summed over the ranks in 256-row chunks while
+      // the factorisation of the earlier chunks is already running; the working matrix A starts from zero
+      const bool split = replicated && h->s_off[fi] >= 0 && (h->comm || h->lgroup);
+      const int64_t aoff = split ? h->s_off[fi] : off;
+      double* Asm = h->pool + aoff;
       int kt = h->kt.begin(LMGPU_KT_HBM_ASSEMBLE, s);
       if (F.fac_count > 0 && own_terms)
-        hipLaunchKernelGGL(hbm_assemble_factors_kernel, dim3(F.fac_count), dim3(64), 0, s, F, off, ld, (const FrontFac*)h->d_ffac,
+        hipLaunchKernelGGL(hbm_assemble_factors_kernel, dim3(F.fac_count), dim3(64), 0, s, F, aoff, ld, (const FrontFac*)h->d_ffac,
                            (const FacDesc*)h->d_fd, h->pool);
       if (F.child_count > 0)
-        hipLaunchKernelGGL(hbm_assemble_children_kernel, dim3(F.child_count), dim3(256), 0, s, F, off, ld, (const ChildRef*)h->d_childs,
+        hipLaunchKernelGGL(hbm_assemble_children_kernel, dim3(F.child_count), dim3(256), 0, s, F, aoff, ld, (const ChildRef*)h->d_childs,
                            (const int32_t*)h->d_cmap, h->pool);
       {  // leaf children in Schur form: deterministic gather instead of atomics
         const lmgpu_handle::GatherRange& G = h->gather[fi];
         if (G.pblk_short > 0)
           hipLaunchKernelGGL((schur_pairs_kernel<1>), dim3(G.pblk_short), dim3(64), 0, s, (const GPairBlock*)(h->d_gpblk + G.pblk_begin),
-                             (const GPairEntry*)h->d_gpent, h->pool, off, ld);
+                             (const GPairEntry*)h->d_gpent, h->pool, aoff, ld);
         if (G.pblk_long > 0)
           hipLaunchKernelGGL((schur_pairs_kernel<4>), dim3(G.pblk_long), dim3(256), 0, s,
-                             (const GPairBlock*)(h->d_gpblk + G.pblk_begin + G.pblk_short), (const GPairEntry*)h->d_gpent, h->pool, off, ld);
+                             (const GPairBlock*)(h->d_gpblk + G.pblk_begin + G.pblk_short), (const GPairEntry*)h->d_gpent, h->pool, aoff, ld);
         if (G.vblk_count > 0)
           hipLaunchKernelGGL(schur_factor_kernel, dim3(G.vblk_count), dim3(64 * SCHUR_FW), 0, s, (const GVarBlock*)(h->d_gvblk + G.vblk_begin),
-                             (const GVarEntry*)h->d_gvent, h->pool, off, ld, F.n);
+                             (const GVarEntry*)h->d_gvent, h->pool, aoff, ld, F.n);
         if (G.leaf_count > 0) {
           reduce_to(h, h->d_gcorner + G.leaf_begin, G.leaf_count, h->dscal + 4);
-          hipLaunchKernelGGL(add_scalar_kernel, dim3(1), dim3(1), 0, s, A + (size_t)(F.n - 1) * ld + F.n - 1, (const double*)(h->dscal + 4));
+          hipLaunchKernelGGL(add_scalar_kernel, dim3(1), dim3(1), 0, s, Asm + (size_t)(F.n - 1) * ld + F.n - 1, (const double*)(h->dscal + 4));
         }
       }
       if (own_terms)
-        hipLaunchKernelGGL(hbm_damp_kernel, dim3((F.nf + 255) / 256), dim3(256), 0, s, F, off, ld, (const int32_t*)h->d_fxoff, h->pool, lambda,
+        hipLaunchKernelGGL(hbm_damp_kernel, dim3((F.nf + 255) / 256), dim3(256), 0, s, F, aoff, ld, (const int32_t*)h->d_fxoff, h->pool, lambda,
                            (const double*)h->dampw);
       h->kt.end(kt, s);
-      if ((h->comm || h->lgroup) && replicated) {
-        // replicated top front: sum the ranks' partial assemblies (separator contributions) over xGMI
-        kt = h->kt.begin(LMGPU_KT_ALLREDUCE, s);
-        { const int rca = allreduce_sum(h, A, (size_t)F.n * ld, s); if (rca) return rca; }
-        h->kt.end(kt, s, (double)F.n * ld * 8.0);
+      // chunk c = rows [256 c, 256 (c+1)) from the first column of its diagonal block to the end of its last row
+      const int nchunks = (F.n + NBO - 1) / NBO;
+      auto chunk_range = [&](int c, size_t& begin, size_t& count) {
+        const int r0c = c * NBO, rows = std::min(F.n, r0c + NBO) - r0c;
+        begin = (size_t)r0c * ld + r0c;  // r0c is a multiple of 256: 16-aligned
+        count = (size_t)rows * ld - r0c;
+      };
+      if (split && h->comm) {  // RCCL: all chunks queued on the communication stream, one event each
+        while ((int)h->chunk_ev.size() < nchunks) {
+          hipEvent_t e;
+          HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+          h->chunk_ev.push_back(e);
+        }
+        HIPCHECK(hipEventRecord(h->asm_ev, s));
+        HIPCHECK(hipStreamWaitEvent(h->comm_stream, h->asm_ev, 0));
+        for (int c = 0; c < nchunks; c++) {
+          size_t cb, cn;
+          chunk_range(c, cb, cn);
+          NCCLCHECK(ncclAllReduce(Asm + cb, Asm + cb, cn, ncclDouble, ncclSum, h->comm, h->comm_stream));
+          HIPCHECK(hipEventRecord(h->chunk_ev[c], h->comm_stream));
+        }
       }
+      // fold the reduced chunk c into the working matrix (which already carries the trailing updates of earlier panels)
+      auto add_chunk = [&](int c) -> int {
+        if (!split || c >= nchunks) return LMGPU_OK;
+        size_t cb, cn;
+        chunk_range(c, cb, cn);
+        const int ktc = h->kt.begin(LMGPU_KT_ALLREDUCE, s);
+        if (h->comm) {
+          HIPCHECK(hipStreamWaitEvent(s, h->chunk_ev[c], 0));
+        } else {
+          const int rca = allreduce_sum(h, Asm + cb, cn, s);
+          if (rca) return rca;
+        }
+        hipLaunchKernelGGL(local_sum_kernel, dim3(std::min<size_t>(2048, (cn + 255) / 256)), dim3(256), 0, s, A + cb, (const double*)(Asm + cb), cn);
+        h->kt.end(ktc, s, (double)cn * 8.0);
+        return LMGPU_OK;
+      };
+      { const int rc0 = add_chunk(0); if (rc0) return rc0; }
       // Blocked right-looking partial Cholesky, outer panels of NBO = 256 rows.  Panel 0 is one dataflow launch
       // (panel_dataflow_kernel); after that ONE launch per outer panel i (step_kernel): trailing update with panel i
       // + factorisation of panel i+1 beside/behind it (look-ahead inside the launch, kernels_step.hpp).  A panel whose row
@@ -529,6 +575,7 @@ int do_eliminate(lmgpu_handle* h, double lambda) {
       for (int i = 0; i < np; i++) {
         const int k0 = i * NBO, kb = rows_of(i), r0 = k0 + kb, m = F.n - r0;
         if (m <= 0) break;
+        { const int rcc = add_chunk(i + 1); if (rcc) return rcc; }  // rows of panel i+1 (and, for i = np-1, of the separator part)
         const bool fuse = (i + 1 < np) && dataflow_ok(i + 1) && !h->no_fuse;
         const int T = (m + 127) / 128;
         // algorithmic flop of the update: 2 x kb x (upper-triangle entries of the m x m trailing matrix)
@@ -547,6 +594,10 @@ int do_eliminate(lmgpu_handle* h, double lambda) {
           h->kt.end(kts, s, upd_flop);
           if (i + 1 < np) panel_alone(i + 1);
         }
+      }
+      for (int c = np + 1; c < nchunks; c++) {  // separator rows beyond the chunk after the last panel
+        const int rcc = add_chunk(c);
+        if (rcc) return rcc;
       }
     }
   }
@@ -795,6 +846,8 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
   if (h->device >= 0) {
     HIPCHECK(hipSetDevice(h->device));
     HIPCHECK(hipStreamCreate(&h->stream));
+    HIPCHECK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+    HIPCHECK(hipEventCreateWithFlags(&h->asm_ev, hipEventDisableTiming));
     for (int i = 0; i < 8; i++) HIPCHECK(hipEventCreate(&h->ev[i]));
     HIPCHECK(hipHostMalloc((void**)&h->h_scal, 8 * sizeof(double), hipHostMallocDefault));
     HIPCHECK(hipHostMalloc((void**)&h->h_status, sizeof(int), hipHostMallocDefault));
@@ -836,6 +889,9 @@ int lmgpu_destroy(lmgpu_handle* h) {
     fr(h->bs_inv); fr(h->bs_x); fr(h->bs_flags); fr(h->inv16); fr(h->d_pflags);
     fr(h->d_gpblk); fr(h->d_gpent); fr(h->d_gvblk); fr(h->d_gvent); fr(h->d_gcorner);
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
+    if (h->asm_ev) (void)hipEventDestroy(h->asm_ev);
+    for (hipEvent_t e : h->chunk_ev) (void)hipEventDestroy(e);
   }
   delete h;
   return LMGPU_OK;
@@ -966,6 +1022,7 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
   h->h_fronts.assign(NF, FrontDesc{});
   h->f_off.assign(NF, -1);
   h->f_ld.assign(NF, 0);
+  h->s_off.assign(NF, -1);
   std::vector<FacDesc> fd(h->nfac);
   for (int i = 0; i < NFAC; i++) {
     if (h->fac_local[i] < 0) continue;
@@ -1041,6 +1098,10 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
       F.ld_u = ld;
       F.u_off = off + (int64_t)fr.nf * ld + fr.nf;
       off += (int64_t)fr.n * ld;
+      if (F.pad & 1) {  // replicated: the rank's partial sums are assembled beside the working matrix and reduced in row chunks
+        h->s_off[fi] = off;
+        off += (int64_t)fr.n * ld;
+      }
     }
     for (size_t k = 0; k < fr.vars.size(); k++) colof[fr.vars[k]] = fr.col_off[k];
     // factors
@@ -1095,7 +1156,7 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
         continue;
       }
       if (CF.u_off < 0) {  // direct scatter child: tell it where its parent is
-        CF.par_off = h->f_off[fi];
+        CF.par_off = h->s_off[fi] >= 0 ? h->s_off[fi] : h->f_off[fi];
         CF.par_ld = h->f_ld[fi];
         CF.par_map = map_begin;
         continue;

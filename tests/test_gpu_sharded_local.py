@@ -47,9 +47,9 @@ def _run_sharded(graph, initial, ordering, params, world, n_iter):
     return out
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_sharded_lm_matches_single(world):
-    n_cam, n_pt = 40, 1500
+@pytest.mark.parametrize("world,n_cam,n_pt", [(2, 40, 1500), (4, 40, 1500), (3, 120, 3000)])
+def test_sharded_lm_matches_single(world, n_cam, n_pt):
+    # 120 cameras -> 1081 x 1081 root: 5 row chunks of the partial assembly are reduced one by one beside the factorisation
     graph, initial, _, ordering = make_bal(n_cam=n_cam, n_pt=n_pt, obs_per_point=6, seed=5)
     params = LevenbergMarquardtParams()
     n_iter = 4
