@@ -146,18 +146,44 @@ __device__ __forceinline__ void syrk_tile(double* __restrict__ A, int ld, int n,
     }
   }
   if (!active) return;
-  // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+  // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg.
+  // Read-modify-write of the wave's 64x64 block in four batches of 16 independent loads (a load -> wait -> add -> store
+  // chain per element would put 64 memory round trips behind every tile).
   const int i0 = it0 + wr * 64, j0 = jt0 + wc * 64;
+  const bool full = (i0 + 64 <= r1) && (j0 + 64 <= n) && (j0 >= i0 + 63);  // wave-uniform: every element valid
+  if (full) {
 #pragma unroll
-  for (int a = 0; a < 4; a++)
+    for (int a = 0; a < 4; a++) {
+      double c[4][4];
 #pragma unroll
-    for (int b = 0; b < 4; b++)
+      for (int b = 0; b < 4; b++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int row = i0 + a * 16 + kk + 4 * r;
-        const int col = j0 + b * 16 + cc;
-        if (row < r1 && col < n && col >= row) A[(size_t)row * ld + col] += acc[a][b][r];
-      }
+        for (int r = 0; r < 4; r++) c[b][r] = A[(size_t)(i0 + a * 16 + kk + 4 * r) * ld + j0 + b * 16 + cc];
+#pragma unroll
+      for (int b = 0; b < 4; b++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) A[(size_t)(i0 + a * 16 + kk + 4 * r) * ld + j0 + b * 16 + cc] = c[b][r] + acc[a][b][r];
+    }
+  } else {
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+      double c[4][4];
+#pragma unroll
+      for (int b = 0; b < 4; b++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {  // clamped (always mapped) address; the value is only used where valid
+          const int row = min(i0 + a * 16 + kk + 4 * r, r1 - 1), col = min(j0 + b * 16 + cc, n - 1);
+          c[b][r] = A[(size_t)row * ld + col];
+        }
+#pragma unroll
+      for (int b = 0; b < 4; b++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int row = i0 + a * 16 + kk + 4 * r, col = j0 + b * 16 + cc;
+          if (row < r1 && col < n && col >= row) A[(size_t)row * ld + col] = c[b][r] + acc[a][b][r];
+        }
+    }
+  }
 }
 
 __global__ __launch_bounds__(256, 2) void syrk_mfma_kernel(double* __restrict__ A, int ld, int n, int p0, int kp, int r0, int r1) {

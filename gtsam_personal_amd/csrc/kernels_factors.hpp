@@ -376,14 +376,36 @@ struct FacDesc {
   int16_t rows, d0, d1, pad;
 };
 
+// One lane per factor.  When the 64 factors of a wave are of one shape and stored back to back (always, inside a bucket),
+// their [A b] blocks are first copied to LDS as ONE contiguous, coalesced stream (a lane-per-factor read would touch 64
+// different cache lines per load instruction and fetch every line several times).
+#define LINERR_MAX_SZ 32
 __global__ __launch_bounds__(256) void linear_error_kernel(const FacDesc* __restrict__ fd, int nfac, const double* __restrict__ pool,
                                                             const double* __restrict__ delta, double* __restrict__ e0buf,
                                                             double* __restrict__ e1buf) {
-  const int f = blockIdx.x * 256 + threadIdx.x;
-  if (f >= nfac) return;
-  const FacDesc d = fd[f];
+  __shared__ double stage[4][64 * LINERR_MAX_SZ + 64];
+  const int f = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool valid = f < nfac;
+  const FacDesc d = fd[valid ? f : nfac - 1];
+  const int m = d.rows, cols = d.d0 + d.d1, sz = m * (cols + 1);
+  const long long j0 = __shfl((long long)d.joff, 0, 64);
+  const int sz0 = __shfl(sz, 0, 64);
+  const int cnt = min(64, nfac - (blockIdx.x * 256 + wave * 64));  // valid lanes of this wave (<= 0: none)
+  const bool fast = __all(!valid || (sz == sz0 && sz0 <= LINERR_MAX_SZ && d.joff == j0 + (long long)lane * sz0));
   const double* J = pool + d.joff;
-  const int m = d.rows, cols = d.d0 + d.d1;
+  if (fast && cnt > 0) {
+    const double* src = pool + j0;
+    double* dst = stage[wave];
+    const int pitch = sz0 | 1;  // odd pitch: lanes spread over the banks
+    for (int i = lane; i < cnt * sz0; i += 64) {
+      const int q = i / sz0;
+      dst[q * pitch + (i - q * sz0)] = src[i];
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    J = dst + lane * pitch;
+  }
+  if (!valid) return;
   double s0 = 0, s1 = 0;
   for (int r = 0; r < m; r++) {
     const double bb = J[cols * m + r];

@@ -449,7 +449,8 @@ int do_eliminate(lmgpu_handle* h, double lambda) {
       const int cnt = L.bin_begin[b + 1] - L.bin_begin[b];
       if (cnt == 0) continue;
       const int nmax = kBinN[b % 6], srows = L.bin_srows[b];
-      const int threads = (b % 6 == 0) ? 64 : (b % 6 == 1 ? 128 : 256);
+      // gather leaves keep only nf rows: one wave per front (barriers become free, ~2.5x more fronts resident per CU)
+      const int threads = (b >= 6 || b % 6 == 0) ? 64 : (b % 6 == 1 ? 128 : 256);
       const size_t lds = kLdsFrontExtra + 64 + (size_t)srows * nmax * sizeof(double);
       const int kt = h->kt.begin(LMGPU_KT_LDS_FRONT, s);
       if (b < 6)
