@@ -135,7 +135,7 @@ __device__ __forceinline__ void syrk_tile(double* __restrict__ A, int ld, int n,
       for (int ks = 0; ks < SYRK_KC; ks += 4) {
         double af[4], bf[4];
 #pragma unroll
-        for (int a = 0; a < 4; a++) af[a] = -sA[(ks + kk) * SYRK_LDW + a * 16];
+        for (int a = 0; a < 4; a++) af[a] = sA[(ks + kk) * SYRK_LDW + a * 16];  // acc = +P^T P, subtracted in the epilogue
 #pragma unroll
         for (int b = 0; b < 4; b++) bf[b] = sB[(ks + kk) * SYRK_LDW + b * 16];
 #pragma unroll
@@ -162,7 +162,7 @@ __device__ __forceinline__ void syrk_tile(double* __restrict__ A, int ld, int n,
 #pragma unroll
       for (int b = 0; b < 4; b++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) A[(size_t)(i0 + a * 16 + kk + 4 * r) * ld + j0 + b * 16 + cc] = c[b][r] + acc[a][b][r];
+        for (int r = 0; r < 4; r++) A[(size_t)(i0 + a * 16 + kk + 4 * r) * ld + j0 + b * 16 + cc] = c[b][r] - acc[a][b][r];
     }
   } else {
 #pragma unroll
@@ -180,7 +180,7 @@ __device__ __forceinline__ void syrk_tile(double* __restrict__ A, int ld, int n,
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const int row = i0 + a * 16 + kk + 4 * r, col = j0 + b * 16 + cc;
-          if (row < r1 && col < n && col >= row) A[(size_t)row * ld + col] = c[b][r] + acc[a][b][r];
+          if (row < r1 && col < n && col >= row) A[(size_t)row * ld + col] = c[b][r] - acc[a][b][r];
         }
     }
   }

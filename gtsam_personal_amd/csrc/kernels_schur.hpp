@@ -106,10 +106,17 @@ __global__ __launch_bounds__(64 * WAVES) void schur_pairs_kernel(const GPairBloc
   }
   double* A = pool + f_off;
   const bool diag = (B.pa == B.pb);
+  // destination read-modify-write: the four loads of a lane in flight together (clamped address where the slot is unused)
+  double cur[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int i = min(kk + 4 * r, B.da - 1), j = min(cc, B.db - 1);
+    cur[r] = A[(size_t)(B.pa + i) * ld + B.pb + j];
+  }
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int i = kk + 4 * r, j = cc;
-    if (i < B.da && j < B.db && (!diag || i <= j)) A[(size_t)(B.pa + i) * ld + B.pb + j] -= sum[r];
+    if (i < B.da && j < B.db && (!diag || i <= j)) A[(size_t)(B.pa + i) * ld + B.pb + j] = cur[r] - sum[r];
   }
 }
 
@@ -165,16 +172,16 @@ __global__ __launch_bounds__(64 * SCHUR_FW) void schur_factor_kernel(const GVarB
 #pragma unroll
     for (int r = 0; r < 4; r++) sum[r] += part[w][r][lane];
   double* A = pool + f_off;
+  double cur[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int i = min(kk + 4 * r, d - 1);
+    cur[r] = A[(size_t)(B.pv + i) * ld + (cc < d ? B.pv + cc : n - 1)];
+  }
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int i = kk + 4 * r, j = cc;
-    if (i < d) {
-      if (j < d) {
-        if (i <= j) A[(size_t)(B.pv + i) * ld + B.pv + j] += sum[r];
-      } else if (j == d) {
-        A[(size_t)(B.pv + i) * ld + n - 1] += sum[r];
-      }
-    }
+    if (i < d && ((j < d && i <= j) || j == d)) A[(size_t)(B.pv + i) * ld + (j < d ? B.pv + j : n - 1)] = cur[r] + sum[r];
   }
 }
 

@@ -60,6 +60,13 @@ __device__ __forceinline__ void syrk_subtile64(double* __restrict__ A, int ld, i
 #pragma unroll
         for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s][a], bf[s][b], acc[a][b], 0, 0, 0);
   }
+  double cur[2][2][4];  // all 16 loads in flight, then the stores
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) cur[a][b][r] = A[(size_t)min(i0 + 16 * a + kk + 4 * r, n - 1) * ld + min(j0 + 16 * b + cc, n - 1)];
 #pragma unroll
   for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -67,7 +74,7 @@ __device__ __forceinline__ void syrk_subtile64(double* __restrict__ A, int ld, i
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int row = i0 + 16 * a + kk + 4 * r, col = j0 + 16 * b + cc;
-        if (row < n && col < n && col >= row) A[(size_t)row * ld + col] += acc[a][b][r];
+        if (row < n && col < n && col >= row) A[(size_t)row * ld + col] = cur[a][b][r] + acc[a][b][r];
       }
 }
 
