@@ -783,6 +783,44 @@ int lm_iterate(lmgpu_handle* h, const lmgpu_lm_params* p) {
   return LMGPU_OK;
 }
 
+// GaussNewtonOptimizer::iterate (gtsam/nonlinear/GaussNewtonOptimizer.cpp:44-66): linearize, solve the UNDAMPED system
+// (lambda = 0: nothing is added to the frontal diagonals), retract, error of the new values, iterations + 1.  An
+// indeterminate system is returned as LMGPU_INDETERMINATE (the reference lets IndeterminantLinearSystemException escape).
+int gn_iterate(lmgpu_handle* h) {
+  std::memset(&h->tim, 0, sizeof(h->tim));
+  (void)hipEventRecord(h->ev[0], h->stream);
+  int rc = do_linearize(h);
+  if (rc) return rc;
+  (void)hipEventRecord(h->ev[7], h->stream);
+  rc = fill_dampw(h, 0, 0.0, 0.0);
+  if (rc) return rc;
+  rc = do_solve(h, 0.0);
+  if (rc) return rc;
+  (void)hipEventRecord(h->ev[5], h->stream);
+  const int kt = h->kt.begin(LMGPU_KT_RETRACT_ERROR, h->stream);
+  rc = do_retract(h, h->cur, h->cur ^ 1);
+  if (rc) return rc;
+  launch_factors<false>(h, h->cur ^ 1);
+  reduce_to(h, h->ebuf0, h->n_counted, h->dscal);
+  h->kt.end(kt, h->stream);
+  rc = allreduce_scalars(h, 0, 1);
+  if (rc) return rc;
+  (void)hipEventRecord(h->ev[6], h->stream);
+  HIPCHECK(hipMemcpyAsync(h->h_scal, h->dscal, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  h->kt.resolve();
+  accumulate_times(h, true);
+  h->tim.inner_iterations += 1;
+  h->cur ^= 1;
+  h->linearized = false;
+  h->lm.error = h->h_scal[0];
+  h->lm.iterations += 1;
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, h->ev[0], h->ev[7]) == hipSuccess) h->tim.linearize_ms = ms;
+  h->tim.total_ms = h->tim.linearize_ms + h->tim.eliminate_ms + h->tim.backsub_ms + h->tim.linear_error_ms + h->tim.retract_error_ms;
+  return LMGPU_OK;
+}
+
 // checkConvergence gtsam/nonlinear/NonlinearOptimizer.cpp:182-231
 bool check_convergence(double relTol, double absTol, double errTol, double currentError, double newError) {
   if (newError <= errTol) return true;
@@ -1502,6 +1540,37 @@ int lmgpu_iterate(lmgpu_handle* h, const lmgpu_lm_params* p, lmgpu_lm_state* ino
   return rc;
 }
 
+int lmgpu_gn_iterate(lmgpu_handle* h, lmgpu_lm_state* inout) {
+  if (!h || !h->finalized || !h->have_values) return LMGPU_INVALID;
+  int rc = need_device(h);
+  if (rc) return rc;
+  if ((rc = need_comm(h))) return rc;
+  if (inout) h->lm = *inout;
+  rc = gn_iterate(h);
+  if (inout) *inout = h->lm;
+  return rc;
+}
+int lmgpu_gn_optimize(lmgpu_handle* h, const lmgpu_lm_params* p, lmgpu_lm_state* inout) {
+  if (!h || !p || !h->finalized || !h->have_values) return LMGPU_INVALID;
+  int rc = need_device(h);
+  if (rc) return rc;
+  if ((rc = need_comm(h))) return rc;
+  if (inout) h->lm = *inout;
+  // NonlinearOptimizer::defaultOptimize (gtsam/nonlinear/NonlinearOptimizer.cpp:62-117) around GaussNewtonOptimizer::iterate
+  double currentError = h->lm.error;
+  if (!(currentError <= p->errorTol || h->lm.iterations >= p->maxIterations)) {
+    double newError = currentError;
+    do {
+      currentError = newError;
+      rc = gn_iterate(h);
+      if (rc) break;
+      newError = h->lm.error;
+    } while (h->lm.iterations < p->maxIterations &&
+             !check_convergence(p->relativeErrorTol, p->absoluteErrorTol, p->errorTol, currentError, newError) && std::isfinite(currentError));
+  }
+  if (inout) *inout = h->lm;
+  return rc;
+}
 int lmgpu_optimize(lmgpu_handle* h, const lmgpu_lm_params* p, lmgpu_lm_state* inout) {
   if (!h || !p || !h->finalized || !h->have_values) return LMGPU_INVALID;
   int rc = need_device(h);

@@ -300,3 +300,27 @@ class LevenbergMarquardtOptimizer:
         self._check(self.lib.lmgpu_get_front(self._h, i, _ip(slots), _dp(rsd) if numeric else None))
         keys = [int(self._keys[s]) for s in slots]
         return keys, (rsd.reshape(fi["n"], fi["nf"]).T.copy() if numeric else None)
+
+
+class GaussNewtonParams(LevenbergMarquardtParams):
+    """NonlinearOptimizerParams defaults (gtsam/nonlinear/NonlinearOptimizerParams.h: maxIterations 100, relativeErrorTol 1e-5,
+    absoluteErrorTol 1e-5, errorTol 0); the LM-only fields of the shared C struct are ignored by the Gauss-Newton entry points."""
+
+    def __init__(self):
+        super().__init__()
+
+
+class GaussNewtonOptimizer(LevenbergMarquardtOptimizer):
+    """gtsam/nonlinear/GaussNewtonOptimizer.h:38-91 on the same device-resident graph and kernels: iterate() = linearize,
+    solve the undamped system, retract, new error (GaussNewtonOptimizer.cpp:44-66); optimize() = defaultOptimize."""
+
+    def __init__(self, graph, initialValues, ordering=None, params=None, **kw):
+        super().__init__(graph, initialValues, ordering, params or GaussNewtonParams(), **kw)
+
+    def iterate(self):
+        self._check(self.lib.lmgpu_gn_iterate(self._h, ct.byref(self.state)))
+
+    def optimize(self) -> Values:
+        cp = self.params._c()
+        self._check(self.lib.lmgpu_gn_optimize(self._h, ct.byref(cp), ct.byref(self.state)))
+        return self.values()

@@ -145,6 +145,14 @@ int lmgpu_hessian_diagonal(lmgpu_handle* h, double* diag_packed); /* GaussianFac
 int lmgpu_lm_init(lmgpu_handle* h, const lmgpu_lm_params* p, lmgpu_lm_state* state_out);
 int lmgpu_iterate(lmgpu_handle* h, const lmgpu_lm_params* p, lmgpu_lm_state* inout);
 int lmgpu_optimize(lmgpu_handle* h, const lmgpu_lm_params* p, lmgpu_lm_state* inout);
+
+/* GaussNewtonOptimizer::iterate (gtsam/nonlinear/GaussNewtonOptimizer.cpp:44-66) on the same device-resident graph:
+ * linearize, solve the undamped system, retract, error of the new values; state->error / iterations are updated, lambda
+ * is not used.  LMGPU_INDETERMINATE where the reference throws IndeterminantLinearSystemException.
+ * lmgpu_gn_optimize = NonlinearOptimizer::defaultOptimize (NonlinearOptimizer.cpp:62-117) around it; of `p` only
+ * maxIterations and the three error tolerances are read (NonlinearOptimizerParams). */
+int lmgpu_gn_iterate(lmgpu_handle* h, lmgpu_lm_state* inout);
+int lmgpu_gn_optimize(lmgpu_handle* h, const lmgpu_lm_params* p, lmgpu_lm_state* inout);
 int lmgpu_get_timings(const lmgpu_handle* h, lmgpu_timings* out);
 
 /* Per-kernel device time (HIP events on the handle's stream around each launch), accumulated since

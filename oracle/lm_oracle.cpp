@@ -728,6 +728,7 @@ static void solve_damped(Problem& p, double lambda, const VectorValues* sqrtHess
   priors.reserve(p.values.size());
   const double sigma = 1.0 / std::sqrt(lambda);
   for (auto& kv : p.values) {
+    if (!(lambda > 0.0)) break;  // Gauss-Newton: the plain linearized graph (GaussNewtonOptimizer.cpp:44-66), no damping priors
     const int dim = kVarDim[kv.second.type];
     GFactor g;
     g.keys = {kv.first};
@@ -854,6 +855,21 @@ static void lm_iterate(Problem& p, const LMParams& prm) {
   }
   while (!try_lambda(p, prm, prm.diagonalDamping ? &sqrtHD : nullptr)) {
   }
+}
+
+// GaussNewtonOptimizer::iterate gtsam/nonlinear/GaussNewtonOptimizer.cpp:44-66: linearize, solve, retract, new error;
+// an IndeterminantLinearSystemException propagates to the caller (returned as false here)
+static bool gn_iterate(Problem& p) {
+  linearize(p);
+  try {
+    solve_damped(p, 0.0, nullptr);
+  } catch (const Indeterminate&) {
+    return false;
+  }
+  p.values = retract_all(p.values, p.delta);
+  p.error = graph_error(p, p.values);
+  p.iterations += 1;
+  return true;
 }
 
 // checkConvergence gtsam/nonlinear/NonlinearOptimizer.cpp:182-231
@@ -1080,6 +1096,22 @@ int orc_lm_iterate(void* h, const orc_lm_params* q) {
 }
 int orc_lm_optimize(void* h, const orc_lm_params* q) {
   lm_optimize(*(Problem*)h, to_params(q));
+  return 0;
+}
+int orc_gn_iterate(void* h) { return gn_iterate(*(Problem*)h) ? 0 : 1; }
+// NonlinearOptimizer::defaultOptimize with GaussNewtonOptimizer::iterate
+int orc_gn_optimize(void* h, const orc_lm_params* q) {
+  auto& p = *(Problem*)h;
+  const LMParams prm = to_params(q);
+  double currentError = p.error;
+  if (currentError <= prm.errorTol || p.iterations >= prm.maxIterations) return 0;
+  double newError = currentError;
+  do {
+    currentError = newError;
+    if (!gn_iterate(p)) return 1;
+    newError = p.error;
+  } while (p.iterations < prm.maxIterations &&
+           !check_convergence(prm.relativeErrorTol, prm.absoluteErrorTol, prm.errorTol, currentError, newError) && std::isfinite(currentError));
   return 0;
 }
 // state: error, lambda, iterations, totalInner, currentFactor

@@ -55,8 +55,9 @@ def lib():
         L.orc_num_cliques.argtypes = [ct.c_void_p]
         L.orc_clique_info.argtypes = [ct.c_void_p, ct.c_int, _I]
         L.orc_clique_get.argtypes = [ct.c_void_p, ct.c_int, _U, _D]
-        for name in ("orc_lm_init", "orc_lm_iterate", "orc_lm_optimize"):
+        for name in ("orc_lm_init", "orc_lm_iterate", "orc_lm_optimize", "orc_gn_optimize"):
             getattr(L, name).argtypes = [ct.c_void_p, ct.POINTER(orc_lm_params)]
+        L.orc_gn_iterate.argtypes = [ct.c_void_p]
         L.orc_lm_state.argtypes = [ct.c_void_p, _D]
         L.orc_lm_trace_len.argtypes = [ct.c_void_p]
         L.orc_lm_trace.argtypes = [ct.c_void_p, _D]
@@ -203,6 +204,13 @@ class OracleProblem:
     def lm_optimize(self, params):
         c = lm_params_c(params)
         self.L.orc_lm_optimize(self.h, ct.byref(c))
+
+    def gn_iterate(self):
+        return self.L.orc_gn_iterate(self.h)
+
+    def gn_optimize(self, params):
+        c = lm_params_c(params)
+        return self.L.orc_gn_optimize(self.h, ct.byref(c))
 
     def lm_state(self):
         s = np.empty(5)

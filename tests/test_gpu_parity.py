@@ -323,3 +323,49 @@ def test_medium_bal_properties_without_oracle():
         errs.append(opt.error())
     assert all(b <= a for a, b in zip(errs, errs[1:]))
     assert errs[-1] < 0.05 * errs[0]
+
+
+def test_gauss_newton_matches_oracle():
+    """GaussNewtonOptimizer (gtsam/nonlinear/GaussNewtonOptimizer.cpp:44-66; examples/Pose2SLAMExample_g2o.cpp:70-80 runs the
+    Pose2 g2o graphs with it): per-iteration error and the defaultOptimize stopping point against the oracle."""
+    from gtsam_personal_amd import GaussNewtonOptimizer, GaussNewtonParams
+    graph, initial = load2D(os.path.join(GOLD, "city10000_head.g2o"))
+    graph.add_PriorFactorPose2(0, initial.at(0), noiseModel.Diagonal.Variances([1e-6, 1e-6, 1e-8]))
+    ordering = oh.colamd(graph) if oh.have_ref() else Ordering.Natural(graph)
+    params = GaussNewtonParams()
+    opt = GaussNewtonOptimizer(graph, initial, ordering, params, device=0)
+    orc = oh.OracleProblem(graph, initial, ordering)
+    orc.lm_init(params)
+    for _ in range(3):
+        opt.iterate()
+        assert orc.gn_iterate() == 0
+        so = orc.lm_state()
+        assert opt.iterations() == so["iterations"]
+        assert abs(opt.error() - so["error"]) <= 1e-6 * max(1e-12, abs(so["error"])) + 1e-12
+    opt.optimize()
+    assert orc.gn_optimize(params) == 0
+    so = orc.lm_state()
+    assert opt.iterations() == so["iterations"]
+    assert abs(opt.error() - so["error"]) <= 1e-6 * max(1e-12, abs(so["error"])) + 1e-12
+    vo, vg = orc.values(), opt.values()
+    for k in vo:
+        assert np.allclose(vo[k], vg.at(k), rtol=1e-6, atol=1e-7), k
+
+
+def test_gauss_newton_indeterminate_propagates():
+    """no prior on a Pose2 chain: the undamped system is singular (gauge freedom); the reference's
+    GaussNewtonOptimizer::iterate lets IndeterminantLinearSystemException escape, and so does the oracle"""
+    from gtsam_personal_amd import GaussNewtonOptimizer, GaussNewtonParams
+    graph, initial = NonlinearFactorGraph(), Values()
+    m = noiseModel.Diagonal.Sigmas([0.2, 0.2, 0.1])
+    for i in range(6):
+        initial.insert_pose2(i, float(i), 0.0, 0.0)
+    for i in range(5):
+        graph.add_BetweenFactorPose2(i, i + 1, [1.0, 0.0, 0.0], m)
+    ordering = Ordering.Natural(graph)
+    orc = oh.OracleProblem(graph, initial, ordering)
+    orc.lm_init(GaussNewtonParams())
+    assert orc.gn_iterate() == 1
+    opt = GaussNewtonOptimizer(graph, initial, ordering, device=0)
+    with pytest.raises(_lib.IndeterminantLinearSystemException):
+        opt.iterate()
