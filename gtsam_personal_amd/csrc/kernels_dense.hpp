@@ -17,6 +17,12 @@ namespace lmgpu {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
+__device__ __forceinline__ double readlane_dyn(double v, int src /* wave-uniform */) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), src), hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 // ---------------------------------------------------------------- assembly
 // one 64-lane block per own factor: F += [A b]^T [A b]
 __global__ __launch_bounds__(64) void hbm_assemble_factors_kernel(FrontDesc F, int64_t f_off, int ld, const FrontFac* __restrict__ ffac,
@@ -204,6 +210,72 @@ __global__ __launch_bounds__(64) void hbm_rhs_init_kernel(FrontDesc F, int64_t f
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
   if (lane == 0) y[i] = row[n - 1] - s;
+}
+
+// ---------------------------------------------------------------- back-substitution of the smaller HBM fronts
+// One workgroup per front (nf <= BSS_MAX_NF), all such fronts of a tree level in ONE launch:  y = d - S x_S, then 64-row
+// blocks from the last to the first: the diagonal block is solved by one wave (lane i carries y_i; per step one v_readlane
+// and one fma), the rows above fold x_b in with one thread per row.  General sparse graphs (SLAM) have dozens of fronts of a
+// few hundred columns; the per-front launches of the dataflow path (pre-inverted diagonal blocks, 141 hops for a 9000-row
+// root) only pay for large fronts.
+#define BSS_MAX_NF 1024
+__global__ __launch_bounds__(256) void hbm_backsolve_small_kernel(const int32_t* __restrict__ list, const FrontDesc* __restrict__ fronts,
+                                                                   const int64_t* __restrict__ f_off, const int32_t* __restrict__ f_ld,
+                                                                   const int32_t* __restrict__ fxoff, const int32_t* __restrict__ sxoff,
+                                                                   const double* __restrict__ pool, double* __restrict__ delta,
+                                                                   int* __restrict__ status) {
+  __shared__ double y[BSS_MAX_NF];
+  __shared__ double Db[64][65];
+  __shared__ double xs[64];
+  const int fi = list[blockIdx.x];
+  const FrontDesc F = fronts[fi];
+  const double* A = pool + f_off[fi];
+  const int ld = f_ld[fi], n = F.n, nf = F.nf, ns = n - nf - 1;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int i = wave; i < nf; i += 4) {
+    const double* row = A + (size_t)i * ld;
+    double s = 0;
+    for (int j = lane; j < ns; j += 64) s += row[nf + j] * delta[sxoff[F.sx_begin + j]];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) y[i] = row[n - 1] - s;
+  }
+  __syncthreads();
+  const int nblk = (nf + 63) >> 6;
+  for (int b = nblk - 1; b >= 0; b--) {
+    const int r0 = 64 * b, nb = min(64, nf - r0);
+    for (int idx = tid; idx < 64 * 64; idx += 256) {
+      const int p = idx >> 6, q = idx & 63;
+      Db[p][q] = (p < nb && q < nb && q >= p) ? A[(size_t)(r0 + p) * ld + r0 + q] : ((p == q) ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    if (wave == 0) {
+      double yi = (lane < nb) ? y[r0 + lane] : 0.0;
+      const double rd = 1.0 / Db[lane][lane];
+      for (int k = nb - 1; k >= 0; k--) {
+        const double xk = readlane_dyn(yi * rd, k);
+        if (lane == k) yi = xk;
+        if (lane < k) yi -= Db[lane][k] * xk;
+      }
+      xs[lane] = (lane < nb) ? yi : 0.0;
+      if (lane < nb) {
+        delta[fxoff[F.fx_begin + r0 + lane]] = yi;
+        if (yi != yi) atomicMin(status, F.id);  // NaN -> IndeterminantLinearSystemException (linearAlgorithms-inst.h:99)
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < r0; i += 256) {
+      const double2* row = (const double2*)(A + (size_t)i * ld + r0);  // r0 and ld are multiples of 16 doubles
+      double s = 0;
+#pragma unroll 8
+      for (int c = 0; c < 32; c++) {
+        const double2 v = row[c];
+        s += v.x * xs[2 * c] + v.y * xs[2 * c + 1];
+      }
+      y[i] -= s;
+    }
+    __syncthreads();
+  }
 }
 
 // ---------------------------------------------------------------- dataflow back-substitution (one launch per HBM front)

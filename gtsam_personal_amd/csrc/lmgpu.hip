@@ -73,6 +73,7 @@ struct LevelWork {
   int bin_begin[16] = {0};
   int bin_srows[16] = {0};  // rows of the front kept in LDS for the bin's launch
   std::vector<int> hbm;  // HBM fronts of this level
+  int small_begin = 0, small_count = 0;  // those with nf <= BSS_MAX_NF, in d_hbm_small: back-substituted in one launch per level
 };
 
 struct KTimer {
@@ -205,6 +206,8 @@ struct lmgpu_handle {
   FrontFac* d_ffac = nullptr;
   ChildRef* d_childs = nullptr;
   int32_t *d_cmap = nullptr, *d_fxoff = nullptr, *d_sxoff = nullptr, *d_lists = nullptr;
+  int32_t *d_hbm_small = nullptr, *d_f_ld = nullptr;
+  int64_t* d_f_off = nullptr;
   int32_t *d_scalar_var = nullptr, *d_scalar_col = nullptr, *d_vi_ptr = nullptr, *d_vi_fac = nullptr;
   int8_t* d_vi_pos = nullptr;
   // gather-mode (Schur form) assembly of HBM fronts from their leaf children
@@ -612,8 +615,16 @@ int do_backsub(lmgpu_handle* h) {
   if (h->cfg.world_size > 1) HIPCHECK(hipMemsetAsync(h->delta, 0, h->ntot * sizeof(double), s));
   for (int li = (int)h->levels.size() - 1; li >= 0; li--) {
     const LevelWork& L = h->levels[li];
+    if (L.small_count > 0) {  // the smaller HBM fronts of the level: one workgroup each, one launch
+      const int kt = h->kt.begin(LMGPU_KT_BACKSUB_HBM, s);
+      hipLaunchKernelGGL(hbm_backsolve_small_kernel, dim3(L.small_count), dim3(256), 0, s, (const int32_t*)(h->d_hbm_small + L.small_begin),
+                         (const FrontDesc*)h->d_fronts, (const int64_t*)h->d_f_off, (const int32_t*)h->d_f_ld, (const int32_t*)h->d_fxoff,
+                         (const int32_t*)h->d_sxoff, (const double*)h->pool, h->delta, h->d_status);
+      h->kt.end(kt, s);
+    }
     for (int fi : L.hbm) {
       const FrontDesc& F = h->h_fronts[fi];
+      if (F.nf <= BSS_MAX_NF) continue;  // done above
       const int64_t off = h->f_off[fi];
       const int ld = h->f_ld[fi];
       const int kt = h->kt.begin(LMGPU_KT_BACKSUB_HBM, s);
@@ -915,7 +926,7 @@ int lmgpu_destroy(lmgpu_handle* h) {
     for (int t = 0; t < 4; t++) fr(h->type_xoff[t]);
     for (int t = 0; t < 4; t++) fr(h->saved[t]);
     fr(h->delta); fr(h->dampw); fr(h->hdiag); fr(h->ebuf0); fr(h->ebuf1); fr(h->partial); fr(h->dscal); fr(h->ywork); fr(h->d_status);
-    fr(h->d_fd); fr(h->d_fronts); fr(h->d_ffac); fr(h->d_childs); fr(h->d_cmap); fr(h->d_fxoff); fr(h->d_sxoff); fr(h->d_lists);
+    fr(h->d_fd); fr(h->d_fronts); fr(h->d_ffac); fr(h->d_childs); fr(h->d_cmap); fr(h->d_fxoff); fr(h->d_sxoff); fr(h->d_lists); fr(h->d_hbm_small); fr(h->d_f_ld); fr(h->d_f_off);
     fr(h->d_scalar_var); fr(h->d_scalar_col); fr(h->d_vi_ptr); fr(h->d_vi_fac); fr(h->d_vi_pos);
     for (Bucket& b : h->buckets) {
       fr(b.d_vidx); fr(b.d_meas); fr(b.d_noise); fr(b.d_epos);
@@ -1261,6 +1272,22 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
       byLevelBin[fr.level][b].push_back(fi);
     }
   }
+  // narrow levels (the upper part of a general clique tree): every launch is bound by one front's latency, so fronts of
+  // different LDS sizes share ONE launch (the largest occupied bin of the group) instead of up to six
+  for (int l = 0; l < P.n_levels; l++)
+    for (int g0 = 0; g0 < kNumBins; g0 += 6) {
+      size_t total = 0;
+      int top = -1;
+      for (int b = g0; b < g0 + 6; b++) {
+        total += byLevelBin[l][b].size();
+        if (!byLevelBin[l][b].empty()) top = b;
+      }
+      if (top < 0 || total > 512) continue;
+      for (int b = g0; b < top; b++) {
+        byLevelBin[l][top].insert(byLevelBin[l][top].end(), byLevelBin[l][b].begin(), byLevelBin[l][b].end());
+        byLevelBin[l][b].clear();
+      }
+    }
   std::vector<int32_t> lists;
   for (int l = 0; l < P.n_levels; l++) {
     LevelWork& L = h->levels[l];
@@ -1295,6 +1322,18 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
   if ((rc = upload(h, &h->d_fxoff, fxoff))) return rc;
   if ((rc = upload(h, &h->d_sxoff, sxoff))) return rc;
   if ((rc = upload(h, &h->d_lists, lists))) return rc;
+  {
+    std::vector<int32_t> small;
+    for (LevelWork& L : h->levels) {
+      L.small_begin = (int)small.size();
+      for (int fi : L.hbm)
+        if (P.fronts[fi].nf <= BSS_MAX_NF) small.push_back(fi);
+      L.small_count = (int)small.size() - L.small_begin;
+    }
+    if ((rc = upload(h, &h->d_hbm_small, small))) return rc;
+    if ((rc = upload(h, &h->d_f_off, h->f_off))) return rc;
+    if ((rc = upload(h, &h->d_f_ld, h->f_ld))) return rc;
+  }
   if ((rc = upload(h, &h->d_gpblk, gpblk))) return rc;
   if ((rc = upload(h, &h->d_gpent, gpent))) return rc;
   if ((rc = upload(h, &h->d_gvblk, gvblk))) return rc;

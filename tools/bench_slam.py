@@ -32,6 +32,19 @@ def run(name, graph, initial, ordering):
         opt.iterate()
     gpu = (time.perf_counter() - t0) / n
     tm = opt.timings()
+    opt.set_kernel_timing(True)
+    opt.restore_values(st)
+    opt.iterate()
+    kt = opt.kernel_times()
+    ncls = [0, 0]
+    sizes = []
+    for i in range(opt.num_fronts()):
+        fi = opt.front_info(i)
+        ncls[fi["cls"]] += 1
+        if fi["cls"] == 1:
+            sizes.append((fi["n"], fi["nf"]))
+    print("   kernel ms:", {k: round(v["ms"], 2) for k, v in kt.items() if v["ms"] > 0}, " launches:", {k: v["launches"] for k, v in kt.items() if v["launches"] > 0})
+    print("   LDS fronts", ncls[0], "HBM fronts", ncls[1], "largest (n, nf):", sorted(sizes)[-5:])
     orc = oh.OracleProblem(graph, initial, ordering)
     orc.lm_init(params)
     t0 = time.perf_counter()
