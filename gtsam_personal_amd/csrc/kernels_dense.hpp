@@ -25,9 +25,9 @@ __device__ __forceinline__ double readlane_dyn(double v, int src /* wave-uniform
 
 // ---------------------------------------------------------------- assembly
 // one 64-lane block per own factor: F += [A b]^T [A b]
-__global__ __launch_bounds__(64) void hbm_assemble_factors_kernel(FrontDesc F, int64_t f_off, int ld, const FrontFac* __restrict__ ffac,
-                                                                   const FacDesc* __restrict__ fd, double* __restrict__ pool) {
-  const FrontFac ff = ffac[F.fac_begin + blockIdx.x];
+__device__ __forceinline__ void assemble_factor_body(const FrontDesc& F, int64_t f_off, int ld, const FrontFac* __restrict__ ffac,
+                                                     const FacDesc* __restrict__ fd, double* __restrict__ pool, int bx) {
+  const FrontFac ff = ffac[F.fac_begin + bx];
   const FacDesc d = fd[ff.fac];
   const double* J = pool + d.joff;
   double* A = pool + f_off;
@@ -50,11 +50,15 @@ __global__ __launch_bounds__(64) void hbm_assemble_factors_kernel(FrontDesc F, i
   }
 }
 
+__global__ __launch_bounds__(64) void hbm_assemble_factors_kernel(FrontDesc F, int64_t f_off, int ld, const FrontFac* __restrict__ ffac,
+                                                                   const FacDesc* __restrict__ fd, double* __restrict__ pool) {
+  assemble_factor_body(F, f_off, ld, ffac, fd, pool, blockIdx.x);
+}
+
 // one block per child: extend-add of its update matrix
-__global__ __launch_bounds__(256) void hbm_assemble_children_kernel(FrontDesc F, int64_t f_off, int ld, const ChildRef* __restrict__ childs,
-                                                                    const int32_t* __restrict__ cmap, double* __restrict__ pool) {
-  __shared__ int32_t smap[160];
-  const ChildRef c = childs[F.child_begin + blockIdx.x];
+__device__ __forceinline__ void assemble_child_body(const FrontDesc& F, int64_t f_off, int ld, const ChildRef* __restrict__ childs,
+                                                    const int32_t* __restrict__ cmap, double* __restrict__ pool, int bx, int32_t* smap) {
+  const ChildRef c = childs[F.child_begin + bx];
   const double* U = pool + c.u_off;
   const int32_t* map = cmap + c.map_begin;
   double* A = pool + f_off;
@@ -72,6 +76,12 @@ __global__ __launch_bounds__(256) void hbm_assemble_children_kernel(FrontDesc F,
       atomicAdd(&A[(size_t)lo * ld + hi], Ui[j]);
     }
   }
+}
+
+__global__ __launch_bounds__(256) void hbm_assemble_children_kernel(FrontDesc F, int64_t f_off, int ld, const ChildRef* __restrict__ childs,
+                                                                    const int32_t* __restrict__ cmap, double* __restrict__ pool) {
+  __shared__ int32_t smap[160];
+  assemble_child_body(F, f_off, ld, childs, cmap, pool, blockIdx.x, smap);
 }
 
 __global__ __launch_bounds__(256) void hbm_damp_kernel(FrontDesc F, int64_t f_off, int ld, const int32_t* __restrict__ fxoff,

@@ -124,9 +124,8 @@ __device__ __forceinline__ void trsm64_wave(double4_t (&T)[4], const double (*D)
   }
 }
 
-__global__ __launch_bounds__(256) void diag_potrf_kernel(double* __restrict__ A, int ld, int nf, int ko, int kb, int front_id,
-                                                          int* __restrict__ status, double* __restrict__ inv16) {
-  extern __shared__ __attribute__((aligned(16))) double dsm[];
+__device__ __forceinline__ void diag_potrf_body(double* __restrict__ A, int ld, int nf, int ko, int kb, int front_id,
+                                                int* __restrict__ status, double* __restrict__ inv16, double* dsm) {
   double(*D)[DP_LDW] = (double(*)[DP_LDW])dsm;                                   // [64][DP_LDW]   R_jj
   double(*I16)[16][17] = (double(*)[16][17])(dsm + 64 * DP_LDW);                // [4][16][17]
   double(*XB)[64][DP_LDW] = (double(*)[64][DP_LDW])(dsm + 64 * DP_LDW + 4 * 16 * 17);  // [3][64][DP_LDW]  R_j,jj  (jj = j+1 ..)
@@ -260,15 +259,21 @@ __global__ __launch_bounds__(256) void diag_potrf_kernel(double* __restrict__ A,
   }
 }
 
+__global__ __launch_bounds__(256) void diag_potrf_kernel(double* __restrict__ A, int ld, int nf, int ko, int kb, int front_id,
+                                                          int* __restrict__ status, double* __restrict__ inv16) {
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  diag_potrf_body(A, ld, nf, ko, kb, front_id, status, inv16, dsm);
+}
+
 // grid = ceil(cols / 64) workgroups of 4 independent waves; cols = n - ko - kb columns right of the diagonal block
 #define PTRSM_LDS_BYTES (16 * 16 * 17 * 8)
-__global__ __launch_bounds__(256) void panel_trsm_kernel(double* __restrict__ A, int ld, int n, int ko, int kb, const double* __restrict__ inv16) {
-  __shared__ double I16[16][16][17];
+__device__ __forceinline__ void panel_trsm_body(double* __restrict__ A, int ld, int n, int ko, int kb, const double* __restrict__ inv16,
+                                                double (*I16)[16][17], int bx) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kk = lane >> 4, cc = lane & 15;
   const int nblk = (kb + 63) >> 6;
   for (int idx = tid; idx < nblk * 4 * 256; idx += 256) I16[idx >> 8][(idx >> 4) & 15][idx & 15] = inv16[idx];
   __syncthreads();
-  const int c0 = ko + kb + (blockIdx.x * 4 + wave) * 16;
+  const int c0 = ko + kb + (bx * 4 + wave) * 16;
   if (c0 >= n) return;
   const int col = min(c0 + cc, n - 1);
   const bool cvalid = c0 + cc < n;
@@ -335,6 +340,11 @@ __global__ __launch_bounds__(256) void panel_trsm_kernel(double* __restrict__ A,
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256) void panel_trsm_kernel(double* __restrict__ A, int ld, int n, int ko, int kb, const double* __restrict__ inv16) {
+  __shared__ double I16[16][16][17];
+  panel_trsm_body(A, ld, n, ko, kb, inv16, I16, blockIdx.x);
 }
 
 // ---------------------------------------------------------------- the same outer panel as ONE dataflow launch

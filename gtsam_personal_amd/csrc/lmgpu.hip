@@ -28,6 +28,7 @@
 #include "kernels_dense.hpp"
 #include "kernels_potrf.hpp"
 #include "kernels_step.hpp"
+#include "kernels_batched.hpp"
 #include "kernels_schur.hpp"
 #include "plan.hpp"
 
@@ -74,6 +75,8 @@ struct LevelWork {
   int bin_srows[16] = {0};  // rows of the front kept in LDS for the bin's launch
   std::vector<int> hbm;  // HBM fronts of this level
   int small_begin = 0, small_count = 0;  // those with nf <= BSS_MAX_NF, in d_hbm_small: back-substituted in one launch per level
+  // "medium" HBM fronts (one outer panel, no gather leaves, not replicated): eliminated with batched launches (kernels_batched.hpp)
+  int med_begin = 0, med_count = 0, med_max_fac = 0, med_max_child = 0, med_max_nf = 0, med_max_cols = 0;
 };
 
 struct KTimer {
@@ -206,7 +209,9 @@ struct lmgpu_handle {
   FrontFac* d_ffac = nullptr;
   ChildRef* d_childs = nullptr;
   int32_t *d_cmap = nullptr, *d_fxoff = nullptr, *d_sxoff = nullptr, *d_lists = nullptr;
-  int32_t *d_hbm_small = nullptr, *d_f_ld = nullptr;
+  int32_t *d_hbm_small = nullptr, *d_f_ld = nullptr, *d_med_list = nullptr;
+  double* inv16_med = nullptr;
+  std::vector<char> is_med;
   int64_t* d_f_off = nullptr;
   int32_t *d_scalar_var = nullptr, *d_scalar_col = nullptr, *d_vi_ptr = nullptr, *d_vi_fac = nullptr;
   int8_t* d_vi_pos = nullptr;
@@ -468,7 +473,34 @@ int do_eliminate(lmgpu_handle* h, double lambda) {
                            (const int32_t*)h->d_fxoff, h->pool, lambda, (const double*)h->dampw, h->d_status, nmax, srows, h->d_gcorner);
       h->kt.end(kt, s);
     }
+    if (L.med_count > 0) {  // medium fronts of this level: six launches for all of them
+      const MedLevel ML{(const int32_t*)(h->d_med_list + L.med_begin), (const FrontDesc*)h->d_fronts, (const int64_t*)h->d_f_off,
+                        (const int32_t*)h->d_f_ld};
+      const unsigned cnt = (unsigned)L.med_count;
+      int ktm = h->kt.begin(LMGPU_KT_HBM_ASSEMBLE, s);
+      if (L.med_max_fac > 0)
+        hipLaunchKernelGGL(med_assemble_factors_kernel, dim3(L.med_max_fac, cnt), dim3(64), 0, s, ML, (const FrontFac*)h->d_ffac,
+                           (const FacDesc*)h->d_fd, h->pool);
+      if (L.med_max_child > 0)
+        hipLaunchKernelGGL(med_assemble_children_kernel, dim3(L.med_max_child, cnt), dim3(256), 0, s, ML, (const ChildRef*)h->d_childs,
+                           (const int32_t*)h->d_cmap, h->pool);
+      hipLaunchKernelGGL(med_damp_kernel, dim3((L.med_max_nf + 255) / 256, cnt), dim3(256), 0, s, ML, (const int32_t*)h->d_fxoff, h->pool, lambda,
+                         (const double*)h->dampw);
+      h->kt.end(ktm, s);
+      ktm = h->kt.begin(LMGPU_KT_PANEL, s);
+      hipLaunchKernelGGL(med_diag_potrf_kernel, dim3(cnt), dim3(256), DIAG_LDS_BYTES, s, ML, h->pool, h->d_status, h->inv16_med);
+      if (L.med_max_cols > 0)
+        hipLaunchKernelGGL(med_panel_trsm_kernel, dim3((L.med_max_cols + 63) / 64, cnt), dim3(256), 0, s, ML, h->pool, (const double*)h->inv16_med);
+      h->kt.end(ktm, s);
+      if (L.med_max_cols > 0) {
+        const int T = (L.med_max_cols + 127) / 128;
+        ktm = h->kt.begin(LMGPU_KT_SYRK, s);
+        hipLaunchKernelGGL(med_syrk_kernel, dim3(T, T, cnt), dim3(256), kSyrkLds, s, ML, h->pool);
+        h->kt.end(ktm, s);
+      }
+    }
     for (int fi : L.hbm) {
+      if (h->is_med[fi]) continue;
       const FrontDesc& F = h->h_fronts[fi];
       const int64_t off = h->f_off[fi];
       const int ld = h->f_ld[fi];
@@ -907,6 +939,8 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
     HIPCHECK(hipFuncSetAttribute((const void*)diag_potrf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
     HIPCHECK(hipFuncSetAttribute((const void*)panel_dataflow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PDF_LDS_BYTES));
     HIPCHECK(hipFuncSetAttribute((const void*)step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STEP_LDS_BYTES));
+    HIPCHECK(hipFuncSetAttribute((const void*)med_diag_potrf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
+    HIPCHECK(hipFuncSetAttribute((const void*)med_syrk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSyrkLds));
   }
   return LMGPU_OK;
 }
@@ -926,7 +960,7 @@ int lmgpu_destroy(lmgpu_handle* h) {
     for (int t = 0; t < 4; t++) fr(h->type_xoff[t]);
     for (int t = 0; t < 4; t++) fr(h->saved[t]);
     fr(h->delta); fr(h->dampw); fr(h->hdiag); fr(h->ebuf0); fr(h->ebuf1); fr(h->partial); fr(h->dscal); fr(h->ywork); fr(h->d_status);
-    fr(h->d_fd); fr(h->d_fronts); fr(h->d_ffac); fr(h->d_childs); fr(h->d_cmap); fr(h->d_fxoff); fr(h->d_sxoff); fr(h->d_lists); fr(h->d_hbm_small); fr(h->d_f_ld); fr(h->d_f_off);
+    fr(h->d_fd); fr(h->d_fronts); fr(h->d_ffac); fr(h->d_childs); fr(h->d_cmap); fr(h->d_fxoff); fr(h->d_sxoff); fr(h->d_lists); fr(h->d_hbm_small); fr(h->d_med_list); fr(h->inv16_med); fr(h->d_f_ld); fr(h->d_f_off);
     fr(h->d_scalar_var); fr(h->d_scalar_col); fr(h->d_vi_ptr); fr(h->d_vi_fac); fr(h->d_vi_pos);
     for (Bucket& b : h->buckets) {
       fr(b.d_vidx); fr(b.d_meas); fr(b.d_noise); fr(b.d_epos);
@@ -1331,6 +1365,28 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
       L.small_count = (int)small.size() - L.small_begin;
     }
     if ((rc = upload(h, &h->d_hbm_small, small))) return rc;
+    std::vector<int32_t> med;
+    h->is_med.assign(NF, 0);
+    int max_med = 0;
+    for (LevelWork& L : h->levels) {
+      L.med_begin = (int)med.size();
+      for (int fi : L.hbm) {
+        const Front& fr = P.fronts[fi];
+        const FrontDesc& F = h->h_fronts[fi];
+        const lmgpu_handle::GatherRange& G = h->gather[fi];
+        if (fr.nf > NBO || (F.pad & 1) || G.leaf_count > 0 || G.pblk_short + G.pblk_long + G.vblk_count > 0 || getenv("LMGPU_NO_MED")) continue;
+        med.push_back(fi);
+        h->is_med[fi] = 1;
+        L.med_max_fac = std::max(L.med_max_fac, F.fac_count);
+        L.med_max_child = std::max(L.med_max_child, F.child_count);
+        L.med_max_nf = std::max(L.med_max_nf, fr.nf);
+        L.med_max_cols = std::max(L.med_max_cols, fr.n - fr.nf);
+      }
+      L.med_count = (int)med.size() - L.med_begin;
+      max_med = std::max(max_med, L.med_count);
+    }
+    if ((rc = upload(h, &h->d_med_list, med))) return rc;
+    if (max_med > 0) HIPCHECK(hipMalloc((void**)&h->inv16_med, (size_t)max_med * 16 * 256 * sizeof(double)));
     if ((rc = upload(h, &h->d_f_off, h->f_off))) return rc;
     if ((rc = upload(h, &h->d_f_ld, h->f_ld))) return rc;
   }
