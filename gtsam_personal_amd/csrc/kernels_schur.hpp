@@ -64,17 +64,6 @@ __global__ __launch_bounds__(64 * WAVES) void schur_pairs_kernel(const GPairBloc
   const bool va = cc < B.da, vb = cc < B.db;
   const int per = (B.count + WAVES - 1) / WAVES;
   const int cb = B.begin + wave * per, ce = min(B.begin + B.count, cb + per);
-  // destination read-modify-write: its four loads are issued first (clamped address where the slot is unused) and
-  // complete behind the list
-  double* A = pool + f_off;
-  double cur[4];
-  if (WAVES == 1 || wave == 0) {
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int i = min(kk + 4 * r, B.da - 1), j = min(cc, B.db - 1);
-      cur[r] = A[(size_t)(B.pa + i) * ld + B.pb + j];
-    }
-  }
   double4s_t acc[4];
 #pragma unroll
   for (int u = 0; u < 4; u++) acc[u] = double4s_t{0, 0, 0, 0};
@@ -115,7 +104,16 @@ __global__ __launch_bounds__(64 * WAVES) void schur_pairs_kernel(const GPairBloc
 #pragma unroll
       for (int r = 0; r < 4; r++) sum[r] += part[w][r][lane];
   }
+  double* A = pool + f_off;
   const bool diag = (B.pa == B.pb);
+  // destination read-modify-write: the four loads of a lane in flight together (clamped address where the slot is unused).
+  // (Issuing them before the list walk was measured slower: 1.41 vs 1.26 ms per C4 assembly.)
+  double cur[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int i = min(kk + 4 * r, B.da - 1), j = min(cc, B.db - 1);
+    cur[r] = A[(size_t)(B.pa + i) * ld + B.pb + j];
+  }
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int i = kk + 4 * r, j = cc;

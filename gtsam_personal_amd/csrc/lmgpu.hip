@@ -444,12 +444,28 @@ int do_eliminate(lmgpu_handle* h, double lambda) {
   HIPCHECK(hipMemsetAsync(h->d_status, 0x7f, sizeof(int), s));
   {  // HBM fronts are accumulated into by their children (atomics) before their own level runs: clear them all first
     const int kt0 = h->kt.begin(LMGPU_KT_HBM_ASSEMBLE, s);
+    int n_hbm = 0;
+    int64_t lo = INT64_MAX, hi = 0, sum = 0;
     for (const LevelWork& L : h->levels)
       for (int fi : L.hbm) {
-        const size_t bytes = (size_t)h->h_fronts[fi].n * h->f_ld[fi] * sizeof(double);
-        HIPCHECK(hipMemsetAsync(h->pool + h->f_off[fi], 0, bytes, s));
-        if (h->s_off[fi] >= 0) HIPCHECK(hipMemsetAsync(h->pool + h->s_off[fi], 0, bytes, s));
+        const int64_t cnt = (int64_t)h->h_fronts[fi].n * h->f_ld[fi] * (h->s_off[fi] >= 0 ? 2 : 1);
+        n_hbm++;
+        sum += cnt;
+        lo = std::min(lo, h->f_off[fi]);
+        hi = std::max(hi, h->f_off[fi] + cnt);
       }
+    if (n_hbm > 4 && hi - lo <= 2 * sum) {
+      // many mid-size fronts (general sparse graphs): one memset over their span; what lies between them ([R S d] / update
+      // storage of LDS fronts, laid out in the same post-order) is rewritten by this elimination before it is read
+      HIPCHECK(hipMemsetAsync(h->pool + lo, 0, (size_t)(hi - lo) * sizeof(double), s));
+    } else {
+      for (const LevelWork& L : h->levels)
+        for (int fi : L.hbm) {
+          const size_t bytes = (size_t)h->h_fronts[fi].n * h->f_ld[fi] * sizeof(double);
+          HIPCHECK(hipMemsetAsync(h->pool + h->f_off[fi], 0, bytes, s));
+          if (h->s_off[fi] >= 0) HIPCHECK(hipMemsetAsync(h->pool + h->s_off[fi], 0, bytes, s));
+        }
+    }
     h->kt.end(kt0, s);
   }
   for (const LevelWork& L : h->levels) {
