@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--split-root", action="store_true",
+                    help="1-GPU rehearsal of the multi-rank data path: one-rank RCCL communicator, chunked all-reduce of the root")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -81,6 +83,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # RCCL prints a version banner on stdout when the first communicator is created; the contract is ONE JSON line on
+    # stdout, so everything before the final print goes to stderr at file-descriptor level
+    saved_stdout = None
+    if world > 1 or args.split_root:
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
     import torch
     dist = None
     if world > 1:
@@ -98,7 +107,10 @@ def main():
         obj = [LevenbergMarquardtOptimizer.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(obj, src=0)
         comm_id = obj[0]
-    opt = LevenbergMarquardtOptimizer(graph, initial, ordering, params, device=local_rank, rank=rank, world_size=world, comm_id=comm_id)
+    if args.split_root and world == 1:
+        comm_id = LevenbergMarquardtOptimizer.comm_unique_id()
+    opt = LevenbergMarquardtOptimizer(graph, initial, ordering, params, device=local_rank, rank=rank, world_size=world, comm_id=comm_id,
+                                      split_root=args.split_root and world == 1)
     t_setup = time.perf_counter() - t_setup
     n_factors = graph.size()
     e_initial = opt.error()
@@ -193,7 +205,10 @@ def main():
             out["measured_hbm_copy_gbps"] = v.value
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(max(2, args.cams // 10), max(10, args.points // 10), args.obs, args.seed)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        if saved_stdout is not None:
+            os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -269,7 +269,7 @@ int need_device(lmgpu_handle* h) {
 }
 
 int need_comm(lmgpu_handle* h) {
-  if (h->cfg.world_size > 1 && !h->comm && !h->lgroup) {
+  if ((h->cfg.world_size > 1 || (h->cfg.flags & LMGPU_FLAG_SPLIT_ROOT)) && !h->comm && !h->lgroup) {
     h->err = "world_size > 1 but lmgpu_comm_init has not been called";
     return LMGPU_INVALID;
   }
@@ -1167,7 +1167,8 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
     F.id = fi;
     F.pad = 0;
     if (!h->front_active[fi]) continue;
-    if (h->cfg.world_size > 1 && h->front_owner[fi] < 0 && fr.cls == 1) F.pad = (R == 0) ? 1 : 3;  // replicated; own terms on rank 0 only
+    if ((h->cfg.world_size > 1 || (h->cfg.flags & LMGPU_FLAG_SPLIT_ROOT)) && h->front_owner[fi] < 0 && fr.cls == 1)
+      F.pad = (R == 0) ? 1 : 3;  // replicated; own terms on rank 0 only
     if (fr.cls == 0) {
       F.ld_rsd = fr.n;
       F.rsd_off = off;

@@ -84,7 +84,7 @@ class LevenbergMarquardtOptimizer:
 
     def __init__(self, graph: NonlinearFactorGraph, initialValues: Values, ordering=None, params: LevenbergMarquardtParams | None = None,
                  device: int = 0, rank: int = 0, world_size: int = 1, comm_id: bytes | None = None,
-                 local_group=None):
+                 local_group=None, split_root: bool = False):
         self.params = params or LevenbergMarquardtParams()
         ordering = ordering if ordering is not None else self.params.ordering
         if ordering is None:
@@ -92,7 +92,7 @@ class LevenbergMarquardtOptimizer:
         self.graph, self.ordering = graph, Ordering(ordering)
         self.lib = _lib.load()
         self._h = ct.c_void_p()
-        cfg = _lib.lmgpu_config(device, rank, world_size, 0)
+        cfg = _lib.lmgpu_config(device, rank, world_size, 1 if split_root else 0)
         self._check(self.lib.lmgpu_create(ct.byref(cfg), ct.byref(self._h)))
         self.device = device
         # variables in elimination order
@@ -131,7 +131,7 @@ class LevenbergMarquardtOptimizer:
         self._xoff = np.concatenate([[0], np.cumsum([VAR_DIM[t] for t in self._types])]).astype(np.int64)
         self.state = _lib.lmgpu_lm_state()
         if device >= 0:
-            if world_size > 1:
+            if world_size > 1 or split_root:
                 if local_group is not None:  # in-process communicator (tests): one thread per rank
                     self._check(self.lib.lmgpu_comm_init_local(self._h, local_group))
                 elif comm_id is None:

@@ -75,11 +75,14 @@ enum lmgpu_factor_type {
  */
 enum lmgpu_noise_kind { LMGPU_N_UNIT = 0, LMGPU_N_DIAG = 2, LMGPU_N_GAUSS = 3 };
 
+#define LMGPU_FLAG_SPLIT_ROOT 1
 typedef struct lmgpu_config {
   int32_t device;     /* HIP device ordinal */
   int32_t rank;       /* this process' rank among the cooperating handles (0 if single) */
   int32_t world_size; /* number of cooperating ranks (1 if single) */
-  int32_t flags;      /* reserved, 0 */
+  int32_t flags;      /* bit 0 (LMGPU_FLAG_SPLIT_ROOT, testing aid): take the multi-rank data path for the HBM fronts (partial
+                         assembly in its own buffer, chunked all-reduce on the communication stream, fold-in before each panel)
+                         even with world_size == 1, so that a one-rank RCCL communicator exercises it on a single GPU */
 } lmgpu_config;
 
 /* LevenbergMarquardtParams subset honoured by lmgpu_iterate / lmgpu_optimize

@@ -84,3 +84,24 @@ def test_sharded_lm_matches_single(world, n_cam, n_pt):
         n_moved += 1
         np.testing.assert_allclose(vals[moved[0]], ref, rtol=1e-8, atol=1e-9)
     assert n_moved == n_cam + n_pt
+
+
+def test_rccl_one_rank_communicator_takes_the_chunked_path():
+    """The RCCL call sites on ONE GPU: a one-rank communicator (ncclCommInitRank with nranks = 1) and LMGPU_FLAG_SPLIT_ROOT make
+    the handle assemble the root into the partial-sum buffer, all-reduce it in row chunks on the communication stream and
+    fold every chunk in before its panel -- the same stream / event choreography as with N ranks; results must equal the
+    plain single-GPU run (a one-rank all-reduce is the identity)."""
+    graph, initial, _, ordering = make_bal(n_cam=120, n_pt=3000, obs_per_point=6, seed=5)
+    params = LevenbergMarquardtParams()
+    single = LevenbergMarquardtOptimizer(graph, initial, ordering, params, device=0)
+    split = LevenbergMarquardtOptimizer(graph, initial, ordering, params, device=0, split_root=True,
+                                        comm_id=LevenbergMarquardtOptimizer.comm_unique_id())
+    for _ in range(4):
+        single.iterate()
+        split.iterate()
+        assert split.getInnerIterations() == single.getInnerIterations()
+        assert abs(split.error() - single.error()) <= 1e-9 * max(1.0, abs(single.error()))
+        assert split.lambda_() == single.lambda_()
+    a, b = single.values(), split.values()
+    for k in ordering:
+        np.testing.assert_allclose(b.at(k), a.at(k), rtol=1e-8, atol=1e-9)
