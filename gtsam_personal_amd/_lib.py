@@ -50,6 +50,7 @@ SYMBOLS = {
     "lmgpu_last_failed_slot": (ct.c_int, [_H]),
     "lmgpu_set_variables": (ct.c_int, [_H, ct.c_int32, ct.POINTER(ct.c_uint64), _I]),
     "lmgpu_add_factor_bucket": (ct.c_int, [_H, ct.c_int32, ct.c_int32, _I, _I, _D, ct.c_int32, _D]),
+    "lmgpu_add_factor_bucket_robust": (ct.c_int, [_H, ct.c_int32, ct.c_int32, _I, _I, _D, ct.c_int32, _D, ct.c_int32, ct.c_double]),
     "lmgpu_finalize_structure": (ct.c_int, [_H]),
     "lmgpu_set_values": (ct.c_int, [_H, _D]),
     "lmgpu_get_values": (ct.c_int, [_H, _D]),

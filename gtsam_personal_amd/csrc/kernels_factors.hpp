@@ -26,6 +26,8 @@ struct BucketDev {
   const double* noise;    // n x (rows | rows*rows) or null
   double* J;              // n x rows*(cols) whitened [A1 A2 b], col-major per factor
   const int32_t* epos;    // n : position in the error buffer (= rank of the factor by graph index)
+  int32_t robust;         // lmgpu_robust_kind: noiseModel::Robust around the Gaussian model (0 = none)
+  double rk;              // its tuning constant
 };
 
 struct ValuesDev {
@@ -59,12 +61,68 @@ __device__ __forceinline__ void whiten_block(double* Jl, int noise_kind, const d
   }
 }
 
+// m-estimators (gtsam/linear/LossFunctions.cpp), kinds as in lmgpu_robust_kind; d = ||whitened error|| >= 0
+__device__ __forceinline__ double robust_weight(int kind, double k, double d) {
+  switch (kind) {
+    case 1: return 1.0 / (1.0 + d / k);                      // Fair :146-148
+    case 2: return (d <= k) ? 1.0 : k / d;                   // Huber :179-182
+    case 3: return (k * k) / (k * k + d * d);                // Cauchy :217-219
+    case 4: {                                                // Tukey :250-256
+      const double t = 1.0 - d * d / (k * k);
+      return (d <= k) ? t * t : 0.0;
+    }
+    case 5: return exp(-(d * d) / (k * k));                  // Welsch :289-292
+    case 6: {                                                // Geman-McClure :320-325
+      const double c2 = k * k, c2e = c2 + d * d;
+      return c2 * c2 / (c2e * c2e);
+    }
+    case 7: {                                                // DCS :354-362
+      const double e2 = d * d, w = 2.0 * k / (k + e2);
+      return (e2 > k) ? w * w : 1.0;
+    }
+    case 8: return (d <= k) ? 0.0 : (d - k) / d;             // L2WithDeadZone :400-407
+    default: return 1.0;
+  }
+}
+__device__ __forceinline__ double robust_loss(int kind, double k, double d) {
+  switch (kind) {
+    case 1: return k * k * (d / k - log1p(d / k));           // :150-155
+    case 2: return (d <= k) ? d * d / 2 : k * (d - k / 2);   // :184-191
+    case 3: return k * k * log1p(d * d / (k * k)) * 0.5;     // :221-224
+    case 4: {                                                // :258-266
+      const double t = 1.0 - d * d / (k * k);
+      return (d <= k) ? k * k * (1 - t * t * t) / 6.0 : k * k / 6.0;
+    }
+    case 5: return k * k * 0.5 * -expm1(-(d * d) / (k * k)); // :294-297
+    case 6: return 0.5 * (k * k * d * d) / (k * k + d * d);  // :327-331
+    case 7: {                                                // :365-373
+      const double e2 = d * d;
+      return (k * k * e2 + k * e2 * e2) / ((e2 + k) * (e2 + k));
+    }
+    case 8: return (d < k) ? 0.0 : 0.5 * (k - d) * (k - d);  // :409-412
+    default: return 0.5 * d * d;
+  }
+}
+
+// Robust::WhitenSystem after the Gaussian whitening: [A b] *= sqrt(weight(||b||))  (Block reweighting, LossFunctions.cpp:61-76)
+template <int M, int COLS>
+__device__ __forceinline__ void robust_reweight(double* Jl, int kind, double k) {
+  double s = 0;
+#pragma unroll
+  for (int r = 0; r < M; r++) s += Jl[(COLS - 1) * M + r] * Jl[(COLS - 1) * M + r];
+  const double w = sqrt(robust_weight(kind, k, sqrt(s)));
+#pragma unroll
+  for (int i = 0; i < M * COLS; i++) Jl[i] *= w;
+}
+
+// NoiseModelFactor::error: loss(squaredMahalanobisDistance) = 0.5 d^2 (Gaussian) or rho(d) (Robust, NoiseModel.h:717-725)
 template <int M>
-__device__ __forceinline__ double whitened_half_sq(double* e, int noise_kind, const double* nz) {
+__device__ __forceinline__ double whitened_half_sq(double* e, int noise_kind, const double* nz, int robust = 0, double rk = 0.0) {
   whiten_block<M, 1>(e, noise_kind, nz);
   double s = 0;
 #pragma unroll
   for (int r = 0; r < M; r++) s += e[r] * e[r];
+  if (robust) return robust_loss(robust, rk, sqrt(s));
   return 0.5 * s;
 }
 
@@ -148,6 +206,7 @@ __global__ __launch_bounds__(256) void sfm_linearize_kernel(BucketDev b, ValuesD
       for (int i = 0; i < 26; i++) Jl[i] = 0.0;
     }
     if (b.noise_kind != 0) whiten_block<2, 13>(Jl, b.noise_kind, b.noise + (size_t)f * (b.noise_kind == 2 ? 2 : 4));
+    if (b.robust) robust_reweight<2, 13>(Jl, b.robust, b.rk);
   } else {
 #pragma unroll
     for (int i = 0; i < 26; i++) Jl[i] = 0.0;
@@ -185,7 +244,7 @@ __global__ __launch_bounds__(256) void sfm_error_kernel(BucketDev b, ValuesDev v
   } else {
     e[0] = e[1] = 0.0;
   }
-  ebuf[b.epos[f]] = whitened_half_sq<2>(e, b.noise_kind, b.noise ? b.noise + (size_t)f * (b.noise_kind == 2 ? 2 : 4) : nullptr);
+  ebuf[b.epos[f]] = whitened_half_sq<2>(e, b.noise_kind, b.noise ? b.noise + (size_t)f * (b.noise_kind == 2 ? 2 : 4) : nullptr, b.robust, b.rk);
 }
 
 // ---------------------------------------------------------------- generic per-type evaluation
@@ -359,11 +418,12 @@ __global__ __launch_bounds__(128) void generic_factor_kernel(BucketDev b, Values
       Jl[(D0 + D1) * M + r] = -e[r];
     }
     whiten_block<M, COLS>(Jl, b.noise_kind, nz);
+    if (b.robust) robust_reweight<M, COLS>(Jl, b.robust, b.rk);
     double* out = b.J + (size_t)f * (M * COLS);
 #pragma unroll
     for (int i = 0; i < M * COLS; i++) out[i] = Jl[i];
   } else {
-    ebuf[b.epos[f]] = whitened_half_sq<M>(e, b.noise_kind, nz);
+    ebuf[b.epos[f]] = whitened_half_sq<M>(e, b.noise_kind, nz, b.robust, b.rk);
   }
 }
 

@@ -55,6 +55,8 @@ namespace {
 
 struct Bucket {
   int type = 0, n = 0, noise_kind = 0;  // n = factors given by the caller
+  int robust = 0;                       // lmgpu_robust_kind of the whole bucket (noiseModel::Robust around the Gaussian model)
+  double robust_k = 0.0;
   std::vector<int32_t> graph_index, slots;
   std::vector<double> meas, noise;
   int rows = 0, cols = 0;  // Jacobian shape (cols includes b)
@@ -287,6 +289,8 @@ BucketDev bucket_dev(lmgpu_handle* h, const Bucket& b) {
   d.type = b.type;
   d.n = b.n_loc;
   d.noise_kind = b.noise_kind;
+  d.robust = b.robust;
+  d.rk = b.robust_k;
   d.vidx = b.d_vidx;
   d.meas = b.d_meas;
   d.noise = b.d_noise;
@@ -1015,7 +1019,14 @@ int lmgpu_set_variables(lmgpu_handle* h, int32_t n_vars, const uint64_t* keys, c
 
 int lmgpu_add_factor_bucket(lmgpu_handle* h, int32_t type, int32_t n, const int32_t* graph_index, const int32_t* var_slots, const double* meas,
                             int32_t noise_kind, const double* noise) {
+  return lmgpu_add_factor_bucket_robust(h, type, n, graph_index, var_slots, meas, noise_kind, noise, LMGPU_ROBUST_NONE, 0.0);
+}
+
+int lmgpu_add_factor_bucket_robust(lmgpu_handle* h, int32_t type, int32_t n, const int32_t* graph_index, const int32_t* var_slots,
+                                   const double* meas, int32_t noise_kind, const double* noise, int32_t robust_kind, double robust_k) {
   if (!h || h->finalized || type < 0 || type >= LMGPU_NUM_FACTOR_TYPES || n < 0 || h->plan.n_vars == 0) return LMGPU_INVALID;
+  if (robust_kind < LMGPU_ROBUST_NONE || robust_kind > LMGPU_ROBUST_L2_WITH_DEAD_ZONE || (robust_kind != LMGPU_ROBUST_NONE && !(robust_k > 0.0)))
+    return LMGPU_INVALID;
   if (noise_kind != LMGPU_N_UNIT && noise_kind != LMGPU_N_DIAG && noise_kind != LMGPU_N_GAUSS) return LMGPU_INVALID;
   if (n == 0) return LMGPU_OK;
   if (!graph_index || !var_slots || !meas || (noise_kind != LMGPU_N_UNIT && !noise)) return LMGPU_INVALID;
@@ -1037,6 +1048,8 @@ int lmgpu_add_factor_bucket(lmgpu_handle* h, int32_t type, int32_t n, const int3
   b.type = type;
   b.n = n;
   b.noise_kind = noise_kind;
+  b.robust = robust_kind;
+  b.robust_k = robust_k;
   b.graph_index.assign(graph_index, graph_index + n);
   b.slots.assign(var_slots, var_slots + (size_t)n * ar);
   b.meas.assign(meas, meas + (size_t)n * ml);

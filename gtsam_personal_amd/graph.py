@@ -57,6 +57,7 @@ class NoiseModel:
     def __init__(self, dim, kind, data=None):
         self.dim, self.kind = int(dim), kind
         self.data = None if data is None else np.asarray(data, dtype=np.float64)
+        self.robust_kind, self.robust_k = 0, 0.0  # noiseModel.Robust: m-estimator id (lmgpu_robust_kind) and constant
 
     def invsigmas(self):
         if self.kind == N_UNIT:
@@ -137,6 +138,44 @@ class noiseModel:
             if smart and np.count_nonzero(cov - np.diag(np.diag(cov))) == 0:
                 return noiseModel.Diagonal.Variances(np.diag(cov).copy(), True)
             return noiseModel.Gaussian.Information(np.linalg.inv(cov), False)
+
+
+class _MEstimator:
+    def __init__(self, kind, k):
+        self.kind, self.k = int(kind), float(k)
+
+
+def _mest(kind, default_k):
+    class _E:
+        @staticmethod
+        def Create(k=default_k):
+            return _MEstimator(kind, k)
+    return _E
+
+
+class mEstimator:
+    """gtsam/linear/LossFunctions.h m-estimators (default constants as there); ids = lmgpu_robust_kind."""
+    Fair = _mest(1, 1.3998)
+    Huber = _mest(2, 1.345)
+    Cauchy = _mest(3, 0.1)
+    Tukey = _mest(4, 4.6851)
+    Welsch = _mest(5, 2.9846)
+    GemanMcClure = _mest(6, 1.0)
+    DCS = _mest(7, 1.0)
+    L2WithDeadZone = _mest(8, 1.0)
+
+
+class _Robust:
+    @staticmethod
+    def Create(robust: _MEstimator, noise: NoiseModel):
+        """noiseModel::Robust::Create(mEstimator, Gaussian model) (gtsam/linear/NoiseModel.cpp:732-735)"""
+        m = NoiseModel(noise.dim, noise.kind, noise.data)
+        m.robust_kind, m.robust_k = robust.kind, robust.k
+        return m
+
+
+noiseModel.Robust = _Robust
+noiseModel.mEstimator = mEstimator
 
 
 # ---------------------------------------------------------------- values
@@ -251,7 +290,7 @@ class NonlinearFactorGraph:
             dev_kind, ndata = N_DIAG, np.tile(noise.invsigmas(), (n, 1))
         else:
             dev_kind, ndata = N_GAUSS, np.tile(noise.data.reshape(1, rows * rows), (n, 1))
-        b = self._buckets.setdefault((ftype, dev_kind), _Bucket(ftype, dev_kind))
+        b = self._buckets.setdefault((ftype, dev_kind, noise.robust_kind, noise.robust_k), _Bucket(ftype, dev_kind))
         b.graph_index.append(np.arange(self._n, self._n + n, dtype=np.int64))
         b.keys.append(keys)
         b.meas.append(meas)
@@ -294,7 +333,7 @@ class NonlinearFactorGraph:
         """[(ftype, dev_noise_kind, graph_index[n], keys[n, arity], meas[n, ml], noise[n, nl] | None, models[n])]"""
         if self._final is None:
             out = []
-            for (ftype, kind), b in self._buckets.items():
+            for (ftype, kind, _rk, _rc), b in self._buckets.items():
                 gi, keys, meas, noise = b.finalize()
                 out.append((ftype, kind, gi, keys, meas, noise, b.models))
             self._final = out

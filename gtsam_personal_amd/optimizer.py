@@ -105,7 +105,7 @@ class LevenbergMarquardtOptimizer:
         self._template = initialValues.copy()
         order_sorted = np.argsort(self._keys, kind="stable")
         keys_sorted = self._keys[order_sorted]
-        for ftype, kind, gi, keys, meas, noise, _ in graph.buckets():
+        for ftype, kind, gi, keys, meas, noise, models in graph.buckets():
             ar = FACTOR_ARITY[ftype]
             pos = np.searchsorted(keys_sorted, keys.reshape(-1))
             if (pos >= len(keys_sorted)).any() or (keys_sorted[np.minimum(pos, len(keys_sorted) - 1)] != keys.reshape(-1)).any():
@@ -123,7 +123,8 @@ class LevenbergMarquardtOptimizer:
             gi32 = np.ascontiguousarray(gi, dtype=np.int32)
             slots = np.ascontiguousarray(slots)
             nptr = _dp(np.ascontiguousarray(noise)) if kind != N_UNIT else None
-            self._check(self.lib.lmgpu_add_factor_bucket(self._h, ftype, len(gi32), _ip(gi32), _ip(slots), _dp(meas), kind, nptr))
+            self._check(self.lib.lmgpu_add_factor_bucket_robust(self._h, ftype, len(gi32), _ip(gi32), _ip(slots), _dp(meas), kind, nptr,
+                                                                models[0].robust_kind, models[0].robust_k))
         self._check(self.lib.lmgpu_finalize_structure(self._h))
         self._ntot = self.lib.lmgpu_total_dim(self._h)
         self._nstore = self.lib.lmgpu_total_store(self._h)

@@ -124,6 +124,23 @@ int lmgpu_set_variables(lmgpu_handle* h, int32_t n_vars, const uint64_t* keys, c
  * var_slots: n x arity slots; meas: n x measurement doubles; noise: n x noise doubles (NULL for UNIT). */
 int lmgpu_add_factor_bucket(lmgpu_handle* h, int32_t factor_type, int32_t n, const int32_t* graph_index, const int32_t* var_slots,
                             const double* meas, int32_t noise_kind, const double* noise);
+/* The same with a noiseModel::Robust wrapped around the Gaussian model of every factor of the bucket
+ * (gtsam/linear/NoiseModel.h:663-760): linearize multiplies the whitened [A b] of a factor by sqrt(weight(||b||))
+ * (Robust::WhitenSystem NoiseModel.cpp:705-723 -> mEstimator::Base::reweight, Block scheme, LossFunctions.cpp:61-76) and the
+ * factor's error is loss(||whitened error||) (NoiseModel.h:717-725).  robust_k = the m-estimator's tuning constant. */
+enum lmgpu_robust_kind {
+  LMGPU_ROBUST_NONE = 0,
+  LMGPU_ROBUST_FAIR = 1,           /* LossFunctions.cpp:146-155 */
+  LMGPU_ROBUST_HUBER = 2,          /* :179-191 */
+  LMGPU_ROBUST_CAUCHY = 3,         /* :217-224 */
+  LMGPU_ROBUST_TUKEY = 4,          /* :250-266 */
+  LMGPU_ROBUST_WELSCH = 5,         /* :289-297 */
+  LMGPU_ROBUST_GEMAN_MCCLURE = 6,  /* :320-331 */
+  LMGPU_ROBUST_DCS = 7,            /* :354-373 */
+  LMGPU_ROBUST_L2_WITH_DEAD_ZONE = 8 /* :400-412 */
+};
+int lmgpu_add_factor_bucket_robust(lmgpu_handle* h, int32_t factor_type, int32_t n, const int32_t* graph_index, const int32_t* var_slots,
+                                   const double* meas, int32_t noise_kind, const double* noise, int32_t robust_kind, double robust_k);
 int lmgpu_finalize_structure(lmgpu_handle* h);
 
 /* ---- values ---- */

@@ -73,6 +73,8 @@ struct Factor {
   double meas[17];
   int noise_kind;
   std::vector<double> noise;  // ISO: sigma ; DIAG: sigmas[m] ; GAUSS: R m x m row-major (sqrt information)
+  int robust = 0;             // noiseModel::Robust around the Gaussian model: m-estimator id (0 = none), see robust_weight
+  double rk = 0.0;            // its tuning constant
 };
 
 // Linear (Gaussian) factor: either Jacobian [A1 A2 .. b] (already whitened) or Hessian
@@ -310,7 +312,64 @@ static void evaluate_error(const Factor& f, const Values& vals, double* e, doubl
   throw std::runtime_error("unknown factor type");
 }
 
-// NoiseModelFactor::error gtsam/nonlinear/NonlinearFactor.cpp:138-149: 0.5 * ||whiten(e)||^2
+// m-estimators, gtsam/linear/LossFunctions.cpp: weight(distance) and loss(distance) of
+// 1 Fair :146-155, 2 Huber :179-191, 3 Cauchy :217-224, 4 Tukey :250-266, 5 Welsch :289-297, 6 GemanMcClure :320-331,
+// 7 DCS :354-373, 8 L2WithDeadZone :400-412; distance = ||whitened error|| >= 0 (noiseModel::Robust, NoiseModel.h:717-725)
+static double robust_weight(int kind, double k, double d) {
+  switch (kind) {
+    case 1: return 1.0 / (1.0 + std::abs(d) / k);
+    case 2: return (std::abs(d) <= k) ? 1.0 : k / std::abs(d);
+    case 3: return (k * k) / (k * k + d * d);
+    case 4: {
+      if (std::abs(d) <= k) {
+        const double t = 1.0 - d * d / (k * k);
+        return t * t;
+      }
+      return 0.0;
+    }
+    case 5: return std::exp(-(d * d) / (k * k));
+    case 6: {
+      const double c2 = k * k, c4 = c2 * c2, c2e = c2 + d * d;
+      return c4 / (c2e * c2e);
+    }
+    case 7: {
+      const double e2 = d * d;
+      if (e2 > k) {
+        const double w = 2.0 * k / (k + e2);
+        return w * w;
+      }
+      return 1.0;
+    }
+    case 8: return (std::abs(d) <= k) ? 0.0 : (d > k ? (-k + d) / d : (k + d) / d);
+    default: return 1.0;
+  }
+}
+static double robust_loss(int kind, double k, double d) {
+  const double a = std::abs(d);
+  switch (kind) {
+    case 1: return k * k * (a / k - std::log1p(a / k));
+    case 2: return (a <= k) ? d * d / 2 : k * (a - k / 2);
+    case 3: return k * k * std::log1p(d * d / (k * k)) * 0.5;
+    case 4: {
+      if (a <= k) {
+        const double t = 1.0 - d * d / (k * k);
+        return k * k * (1 - t * t * t) / 6.0;
+      }
+      return k * k / 6.0;
+    }
+    case 5: return k * k * 0.5 * -std::expm1(-(d * d) / (k * k));
+    case 6: return 0.5 * (k * k * d * d) / (k * k + d * d);
+    case 7: {
+      const double e2 = d * d, e4 = e2 * e2, c2 = k * k;
+      return (c2 * e2 + k * e4) / ((e2 + k) * (e2 + k));
+    }
+    case 8: return (a < k) ? 0.0 : 0.5 * (k - a) * (k - a);
+    default: return 0.5 * d * d;
+  }
+}
+
+// NoiseModelFactor::error gtsam/nonlinear/NonlinearFactor.cpp:138-149: noiseModel->loss(squaredMahalanobisDistance(e)):
+// 0.5 * ||whiten(e)||^2 for a Gaussian model, rho(||whiten(e)||) for noiseModel::Robust (NoiseModel.h:717-725)
 static double factor_error(const Factor& f, const Values& vals) {
   const int m = kFactorRows[f.type];
   double e[9];
@@ -318,6 +377,7 @@ static double factor_error(const Factor& f, const Values& vals) {
   whiten_rows(f, m, e, 1, m);
   double s = 0;
   for (int i = 0; i < m; i++) s += e[i] * e[i];
+  if (f.robust) return robust_loss(f.robust, f.rk, std::sqrt(s));
   return 0.5 * s;
 }
 
@@ -344,6 +404,13 @@ static GFactor linearize_factor(const Factor& f, const Values& vals) {
     g.Ab(i, tot) = -e[i];
   }
   whiten_rows(f, m, g.Ab.a.data(), tot + 1, m);
+  if (f.robust) {  // Robust::WhitenSystem (NoiseModel.cpp:705-723) = whiten, then mEstimator::Base::reweight (Block scheme,
+                   // LossFunctions.cpp:61-76): every entry of [A b] times sqrt(weight(||b||))
+    double s = 0;
+    for (int i = 0; i < m; i++) s += g.Ab(i, tot) * g.Ab(i, tot);
+    const double w = std::sqrt(robust_weight(f.robust, f.rk, std::sqrt(s)));
+    for (auto& x : g.Ab.a) x *= w;
+  }
   return g;
 }
 
@@ -937,6 +1004,21 @@ int orc_add_factor(void* h, int type, const uint64_t* keys, const double* meas, 
   if (noise_kind == N_DIAG) f.noise.assign(noise, noise + m);
   if (noise_kind == N_GAUSS) f.noise.assign(noise, noise + m * m);
   p->factors.push_back(f);
+  return 0;
+}
+
+// tap: weight and loss of an m-estimator (pinned against gtsam/linear/tests/testNoiseModel.cpp:460-617)
+int orc_robust(int kind, double k, double distance, double* out2) {
+  out2[0] = robust_weight(kind, k, distance);
+  out2[1] = robust_loss(kind, k, distance);
+  return 0;
+}
+
+int orc_set_factor_robust(void* h, int index, int kind, double k) {
+  auto* p = (Problem*)h;
+  if (index < 0 || index >= (int)p->factors.size() || kind < 0 || kind > 8) return 2;
+  p->factors[index].robust = kind;
+  p->factors[index].rk = k;
   return 0;
 }
 

@@ -45,6 +45,8 @@ def lib():
         L.orc_add_variable.argtypes = [ct.c_void_p, ct.c_uint64, ct.c_int, _D]
         L.orc_add_factor.argtypes = [ct.c_void_p, ct.c_int, _U, _D, ct.c_int, _D]
         L.orc_set_ordering.argtypes = [ct.c_void_p, ct.c_int, _U]
+        L.orc_set_factor_robust.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.c_double]
+        L.orc_robust.argtypes = [ct.c_int, ct.c_double, ct.c_double, _D]
         L.orc_get_values.argtypes = [ct.c_void_p, _D]
         L.orc_error.argtypes = [ct.c_void_p]
         L.orc_linearize.argtypes = [ct.c_void_p]
@@ -129,6 +131,8 @@ class OracleProblem:
             else:
                 nd = dp(np.ascontiguousarray(model.data, dtype=np.float64).reshape(-1))
             assert self.L.orc_add_factor(self.h, ftype, up(kk), dp(m), model.kind, nd) == 0
+            if getattr(model, "robust_kind", 0):
+                assert self.L.orc_set_factor_robust(self.h, self.L.orc_num_factors(self.h) - 1, model.robust_kind, model.robust_k) == 0
         o = np.array(list(ordering), dtype=np.uint64)
         self.L.orc_set_ordering(self.h, len(o), up(o))
         self.ntot = self.L.orc_total_dim(self.h)

@@ -369,3 +369,65 @@ def test_gauss_newton_indeterminate_propagates():
     opt = GaussNewtonOptimizer(graph, initial, ordering, device=0)
     with pytest.raises(_lib.IndeterminantLinearSystemException):
         opt.iterate()
+
+
+@pytest.mark.parametrize("est", ["Huber", "Cauchy", "Tukey", "GemanMcClure", "Welsch", "Fair", "DCS", "L2WithDeadZone"])
+def test_robust_noise_pose2_with_outlier(est):
+    """noiseModel::Robust around the loop-closure models of a Pose2 graph, one gross outlier among the closures:
+    error (rho), reweighted Jacobians, one damped solve and three LM iterations against the oracle."""
+    from gtsam_personal_amd.graph import mEstimator
+    rng = np.random.default_rng(3)
+    n = 30
+    graph, initial = NonlinearFactorGraph(), Values()
+    for i in range(n):
+        initial.insert_pose2(i, float(i) + rng.normal(0, 0.05), rng.normal(0, 0.05), rng.normal(0, 0.02))
+    m_odo = noiseModel.Diagonal.Sigmas([0.2, 0.2, 0.1])
+    for i in range(n - 1):
+        graph.add_BetweenFactorPose2(i, i + 1, [1.0, 0.0, 0.0], m_odo)
+    k = {"Huber": 1.345, "Cauchy": 1.0, "Tukey": 4.6851, "GemanMcClure": 1.0, "Welsch": 2.9846, "Fair": 1.3998, "DCS": 1.0,
+         "L2WithDeadZone": 0.5}[est]
+    base = noiseModel.Gaussian.Information(np.array([[40.0, 2.0, 1.0], [2.0, 30.0, 0.5], [1.0, 0.5, 90.0]]))
+    robust = noiseModel.Robust.Create(getattr(mEstimator, est).Create(k), base)
+    for a, b in [(0, 10), (5, 20), (12, 29), (3, 17)]:
+        graph.add_BetweenFactorPose2(a, b, [float(b - a), 0.0, 0.0], robust)
+    graph.add_BetweenFactorPose2(2, 25, [3.0, 4.0, 1.0], robust)  # outlier
+    graph.add_PriorFactorPose2(0, [0.0, 0.0, 0.0], noiseModel.Diagonal.Sigmas([0.01, 0.01, 0.01]))
+    ordering = oh.colamd(graph) if oh.have_ref() else Ordering.Natural(graph)
+    opt, orc, params = _pair(graph, initial, ordering)
+    assert abs(opt.graph_error() - orc.error()) <= 1e-10 * max(1.0, orc.error())
+    _check_linearize(opt, orc, graph)
+    _check_solve(opt, orc, 1e-3)
+    for _ in range(3):
+        opt.iterate()
+        orc.lm_iterate(params)
+        so = orc.lm_state()
+        assert opt.getInnerIterations() == so["inner"]
+        assert abs(opt.error() - so["error"]) <= 1e-6 * max(1e-12, abs(so["error"]))
+
+
+def test_robust_huber_on_projection_factors():
+    """Huber on GeneralSFMFactor (the usual robust BA set-up), with corrupted observations"""
+    from gtsam_personal_amd.graph import C, P, mEstimator
+    graph0, initial, truth, ordering = make_bal(n_cam=8, n_pt=120, obs_per_point=4, seed=11)
+    rng = np.random.default_rng(5)
+    graph = NonlinearFactorGraph()
+    robust = noiseModel.Robust.Create(mEstimator.Huber.Create(1.345), noiseModel.Isotropic.Sigma(2, 1.0))
+    for ftype, kind, gi, keys, meas, noise, models in graph0.buckets():
+        if keys.shape[1] != 2:
+            continue
+        z = meas.copy()
+        bad = rng.random(len(z)) < 0.05
+        z[bad] += rng.normal(0, 40.0, (int(bad.sum()), 2))  # gross outliers
+        graph.add_GeneralSFMFactor(z, robust, keys[:, 0], keys[:, 1])
+    graph.add_PriorFactorCamera(C(0), truth.at(C(0)), noiseModel.Isotropic.Sigma(9, 0.1))
+    graph.add_PriorFactorPoint3(P(0), truth.at(P(0)), noiseModel.Isotropic.Sigma(3, 0.1))
+    opt, orc, params = _pair(graph, initial, ordering)
+    assert abs(opt.graph_error() - orc.error()) <= 1e-9 * max(1.0, orc.error())
+    _check_linearize(opt, orc, graph)
+    _check_solve(opt, orc, 1e-3)
+    for _ in range(3):
+        opt.iterate()
+        orc.lm_iterate(params)
+        so = orc.lm_state()
+        assert opt.getInnerIterations() == so["inner"]
+        assert abs(opt.error() - so["error"]) <= 1e-6 * max(1e-12, abs(so["error"]))

@@ -339,3 +339,25 @@ def test_bal_dubrovnik_golden_error_any_ordering():
     orc.lm_init(params)
     orc.lm_optimize(params)
     assert abs(orc.lm_state()["error"] - 0.0199833) < 1e-5
+
+
+def test_robust_m_estimators_known_answers():
+    """gtsam/linear/tests/testNoiseModel.cpp:460-617: weight(error) and loss(error) of the m-estimators"""
+    L = oh.lib()
+    cases = [  # (kind, k, error, weight, loss)
+        (1, 5.0, 1.0, 0.8333333333333333, 0.441961080151135), (1, 5.0, 10.0, 0.3333333333333333, 22.534692783297260),
+        (1, 5.0, -10.0, 0.3333333333333333, 22.534692783297260),
+        (2, 5.0, 1.0, 1.0, 0.5), (2, 5.0, 10.0, 0.5, 37.5), (2, 5.0, -10.0, 0.5, 37.5), (2, 5.0, -1.0, 1.0, 0.5),
+        (3, 5.0, 1.0, 0.961538461538461, 0.490258914416017), (3, 5.0, 10.0, 0.2, 20.117973905426254), (3, 5.0, -10.0, 0.2, 20.117973905426254),
+        (6, 1.0, 1.0, 0.25, 0.25), (6, 1.0, 10.0, 9.80296e-5, 0.495049504950495), (6, 1.0, -10.0, 9.80296e-5, 0.495049504950495),
+        (5, 5.0, 1.0, 0.960789439152323, 0.490132010595960), (5, 5.0, 10.0, 0.018315638888734, 12.271054513890823),
+        (4, 5.0, 1.0, 0.9216, 0.480266666666667), (4, 5.0, 10.0, 0.0, 4.166666666666667), (4, 5.0, -1.0, 0.9216, 0.480266666666667),
+        (7, 1.0, 1.0, 1.0, 0.5), (7, 1.0, 10.0, 0.00039211, 0.9900990099),
+        (8, 1.0, -10.0, 0.9, 40.5), (8, 1.0, -1.01, 0.00990099009, 0.00005), (8, 1.0, -0.99, 0.0, 0.0), (8, 1.0, 0.99, 0.0, 0.0),
+        (8, 1.0, 1.01, 0.00990099009, 0.00005), (8, 1.0, 10.0, 0.9, 40.5),
+    ]
+    out = np.empty(2)
+    for kind, k, e, w, loss in cases:
+        assert L.orc_robust(kind, k, e, oh.dp(out)) == 0
+        assert abs(out[0] - w) < 1e-8, (kind, e, out[0], w)
+        assert abs(out[1] - loss) < 1e-8, (kind, e, out[1], loss)
