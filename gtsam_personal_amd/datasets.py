@@ -221,3 +221,121 @@ def chain_initial_pose3(graph: NonlinearFactorGraph, n_poses=None):
         i += 1
         initial.insert_pose3(i, R, t)
     return initial
+
+
+# ---------------------------------------------------------------- writers (the formats either side of the hot path)
+def _g(x):
+    """C++ `stream << double` with the default precision 6 (what the reference's writeG2o uses)"""
+    return "%g" % float(x)
+
+
+def _information(model):
+    """Info = R^T R of a Gaussian / Diagonal / Isotropic / Unit model (dataset.cpp:681-682)"""
+    from .graph import N_DIAG, N_GAUSS, N_ISO, N_UNIT
+    if model.kind == N_UNIT:
+        return np.eye(model.dim)
+    if model.kind in (N_ISO, N_DIAG):
+        return np.diag(model.invsigmas() ** 2)
+    assert model.kind == N_GAUSS
+    R = model.data.reshape(model.dim, model.dim)
+    return R.T @ R
+
+
+def _rot3_to_quat(R):
+    """(w, x, y, z), w >= 0 branch structure of Eigen's Quaternion(Matrix3)"""
+    R = np.asarray(R, dtype=np.float64).reshape(3, 3)
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0) * 2
+        return 0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s
+    i = int(np.argmax(np.diag(R)))
+    j, k = (i + 1) % 3, (i + 2) % 3
+    s = np.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0) * 2
+    q = [0.0, 0.0, 0.0, 0.0]
+    q[0] = (R[k, j] - R[j, k]) / s
+    q[1 + i] = 0.25 * s
+    q[1 + j] = (R[j, i] + R[i, j]) / s
+    q[1 + k] = (R[k, i] + R[i, k]) / s
+    return tuple(q)
+
+
+def writeG2o(graph: NonlinearFactorGraph, estimate: Values, filename):
+    """gtsam/slam/dataset.cpp:636-735: VERTEX_SE2 / VERTEX_SE3:QUAT / VERTEX_TRACKXYZ then EDGE_SE2 / EDGE_SE3:QUAT with the upper
+    triangle of the information matrix (3D: reordered to g2o's t,R convention); ids = Symbol(key).index()."""
+    from .graph import F_BETWEEN_POSE2, F_BETWEEN_POSE3, POINT3, POSE2, POSE3
+    index = lambda key: int(key) & ((1 << 56) - 1)  # noqa: E731  Symbol(key).index()
+    keys = sorted(estimate.keys())
+    with open(filename, "w") as o:
+        for k in keys:
+            if estimate.type(k) == POSE2:
+                v = estimate.at(k)
+                o.write(f"VERTEX_SE2 {index(k)} {_g(v[0])} {_g(v[1])} {_g(v[2])}\n")
+        for k in keys:
+            if estimate.type(k) == POSE3:
+                v = estimate.at(k)
+                w, x, y, z = _rot3_to_quat(v[:9])
+                o.write(f"VERTEX_SE3:QUAT {index(k)} {_g(v[9])} {_g(v[10])} {_g(v[11])} {_g(x)} {_g(y)} {_g(z)} {_g(w)}\n")
+        for k in keys:
+            if estimate.type(k) == POINT3:
+                v = estimate.at(k)
+                o.write(f"VERTEX_TRACKXYZ {index(k)} {_g(v[0])} {_g(v[1])} {_g(v[2])}\n")
+        rec = [None] * graph.size()
+        for ftype, _, gi, fkeys, meas, _, models in graph.buckets():
+            for i, g in enumerate(gi.tolist()):
+                rec[g] = (ftype, fkeys[i], meas[i], models[i])
+        for ftype, fk, m, model in rec:
+            if ftype == F_BETWEEN_POSE2:
+                info = _information(model)
+                up = " ".join(_g(info[i, j]) for i in range(3) for j in range(i, 3))
+                o.write(f"EDGE_SE2 {index(fk[0])} {index(fk[1])} {_g(m[0])} {_g(m[1])} {_g(m[2])} {up}\n")
+            elif ftype == F_BETWEEN_POSE3:
+                info = _information(model)
+                ig = np.eye(6)
+                ig[0:3, 0:3] = info[3:6, 3:6]
+                ig[3:6, 3:6] = info[0:3, 0:3]
+                ig[0:3, 3:6] = info[3:6, 0:3]
+                ig[3:6, 0:3] = info[0:3, 3:6]
+                w, x, y, z = _rot3_to_quat(m[:9])
+                up = " ".join(_g(ig[i, j]) for i in range(6) for j in range(i, 6))
+                o.write(f"EDGE_SE3:QUAT {index(fk[0])} {index(fk[1])} {_g(m[9])} {_g(m[10])} {_g(m[11])} {_g(x)} {_g(y)} {_g(z)} {_g(w)} {up}\n")
+
+
+def _rot3_logmap(R):
+    """SO3::Logmap (gtsam/geometry/SO3.cpp:299-375), the branch structure the oracle restates"""
+    R = np.asarray(R, dtype=np.float64).reshape(3, 3)
+    tr = np.trace(R)
+    if tr + 1.0 < 1e-3:  # near pi: fall back on the largest-diagonal construction
+        i = int(np.argmax(np.diag(R)))
+        v = R[:, i].copy()
+        v[i] += 1.0
+        v *= np.pi / np.sqrt(2.0 * (1.0 + R[i, i]))
+        return v
+    tr_3 = tr - 3.0
+    if tr_3 < -1e-6:
+        theta = np.arccos(np.clip((tr - 1.0) / 2.0, -1.0, 1.0))
+        magnitude = theta / (2.0 * np.sin(theta))
+    else:
+        magnitude = 0.5 - tr_3 / 12.0 + tr_3 * tr_3 / 60.0
+    return magnitude * np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+
+
+def writeBAL(filename, db: SfmData):
+    """gtsam/sfm/SfmData.cpp:249-323: precision 20, observations (camera, point, u, -v), cameras in the OpenGL convention
+    (gtsam2openGL: R_gl = (wRc R90)^T ... written as Rodrigues vector, translation, f, k1, k2), then the points."""
+    R90 = np.diag([1.0, -1.0, -1.0])
+    n_obs = sum(len(t["measurements"]) for t in db.tracks)
+    p = lambda x: "%.20g" % float(x)  # noqa: E731
+    with open(filename, "w") as o:
+        o.write(f"{len(db.cameras)} {len(db.tracks)} {n_obs}\n\n")
+        for j, tr in enumerate(db.tracks):
+            for i, (u, v) in tr["measurements"]:
+                o.write(f"{i} {j} {p(u)} {p(-v)}\n")
+        o.write("\n")
+        for (wRc, wtc, f, k1, k2) in db.cameras:
+            Rgl = (np.asarray(wRc) @ R90).T          # inverse of openGL2gtsam: R = (wRc R90)^T, t = -R wtc
+            tgl = -Rgl @ np.asarray(wtc)
+            w = _rot3_logmap(Rgl)
+            o.write(f"{p(w[0])}\n{p(w[1])}\n{p(w[2])}\n{p(tgl[0])}\n{p(tgl[1])}\n{p(tgl[2])}\n{p(f)}\n{p(k1)}\n{p(k2)}\n\n")
+        for tr in db.tracks:
+            o.write(f"{p(tr['p'][0])}\n{p(tr['p'][1])}\n{p(tr['p'][2])}\n\n")
+    return True
