@@ -320,8 +320,7 @@ __global__ __launch_bounds__(64) void hbm_invert_diag_kernel(const double* __res
 }
 
 // R x = y, R = rows 0..nf-1 of the front (upper).  Workgroup b owns row block b:  it folds x_j (j > b) into its right-hand side
-// as the blocks are published, then x_b = inv(R_bb) rhs, publishes x_b and raises flag[b].  All workgroups are co-resident
-// (grid <= #CUs, checked on the host).  Hand-off: 8-byte agent-scope atomics for the payload and the flag on both sides
+// as the blocks are published, then x_b = inv(R_bb) rhs, publishes x_b and raises flag[b].  Hand-off: 8-byte agent-scope atomics for the payload and the flag on both sides
 // (cdna_hip_programming.md Guideline 16, "8-B agent atomics both sides"), bounded spin.
 template <int NB>
 __global__ __launch_bounds__(256) void hbm_backsolve_dataflow_kernel(FrontDesc F, int64_t f_off, int ld, const int32_t* __restrict__ fxoff,
@@ -331,9 +330,12 @@ __global__ __launch_bounds__(256) void hbm_backsolve_dataflow_kernel(FrontDesc F
                                                                       int* __restrict__ status) {
   __shared__ double acc[NB];
   __shared__ double xs[NB];
-  __shared__ int ok;
+  __shared__ int ok, s_ticket;
   const int nblk = gridDim.x;
-  const int b = nblk - 1 - blockIdx.x;  // the last row block (first to finish) gets the first-dispatched workgroup
+  // logical order from a ticket (flags[nblk], zeroed with the flags): a workgroup only waits for workgroups that started before it
+  if (threadIdx.x == 0) s_ticket = (int)atomicAdd(&flags[nblk], 1u);
+  __syncthreads();
+  const int b = nblk - 1 - s_ticket;  // the last row block (first to finish) goes to the first workgroup that starts
   const int r0 = b * NB, nb = min(NB, F.nf - r0);
   const int tid = threadIdx.x, row = tid >> 2, quarter = tid & 3;
   const double* A = pool + f_off;
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(256) void hbm_backsolve_dataflow_kernel(FrontDesc F
       long spins = 0;
       while (__hip_atomic_load(&flags[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
         __builtin_amdgcn_s_sleep(2);
-        if (++spins > 20000000L) {
+        if (++spins > 2000000L) {
           ok = 0;
           break;
         }

@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256) void panel_trsm_kernel(double* __restrict__ A,
 #define PDF_TA0 32
 #define PDF_FLAG_WORDS 256
 #define PDF_MAX_COLTILES (PDF_FLAG_WORDS - PDF_TA0)
-#define PDF_SPIN_LIMIT 40000000L
+#define PDF_SPIN_LIMIT 2000000L  // a legitimate wait is < 1 ms; the bound (~1-2 s) only keeps a logic error from hanging the device
 #define PDF_LDS_DOUBLES (2 * 64 * DP_LDW)
 #define PDF_LDS_BYTES (PDF_LDS_DOUBLES * 8)
 

@@ -684,7 +684,7 @@ int do_backsub(lmgpu_handle* h) {
                          (const double*)h->delta, h->ywork);
       const int nblk = (F.nf + NB - 1) / NB;
       // inverse of the diagonal blocks (all in parallel), then ONE dataflow launch: workgroup b waits for x_j (j > b) flags
-      HIPCHECK(hipMemsetAsync(h->bs_flags, 0, nblk * sizeof(unsigned int), s));
+      HIPCHECK(hipMemsetAsync(h->bs_flags, 0, (nblk + 1) * sizeof(unsigned int), s));  // flags + ticket
       hipLaunchKernelGGL((hbm_invert_diag_kernel<NB>), dim3(nblk), dim3(NB), 0, s, (const double*)(h->pool + off), ld, F.nf, h->bs_inv);
       hipLaunchKernelGGL((hbm_backsolve_dataflow_kernel<NB>), dim3(nblk), dim3(256), 0, s, F, off, ld, (const int32_t*)h->d_fxoff,
                          (const double*)h->pool, (const double*)h->bs_inv, (const double*)h->ywork, h->bs_x, h->bs_flags, h->delta,
@@ -1510,7 +1510,7 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
     h->pflags_panels = (P.max_front_n + NBO - 1) / NBO + 1;
     HIPCHECK(hipMalloc((void**)&h->d_pflags, (size_t)h->pflags_panels * PDF_FLAG_WORDS * sizeof(unsigned int)));
     HIPCHECK(hipMalloc((void**)&h->bs_x, (size_t)max_blk * NB * sizeof(double)));
-    HIPCHECK(hipMalloc((void**)&h->bs_flags, (size_t)max_blk * sizeof(unsigned int)));
+    HIPCHECK(hipMalloc((void**)&h->bs_flags, (size_t)(max_blk + 1) * sizeof(unsigned int)));
   }
   return LMGPU_OK;
 }
