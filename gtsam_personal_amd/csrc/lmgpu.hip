@@ -85,7 +85,7 @@ struct KTimer {
   bool on = false;
   std::vector<hipEvent_t> pool;
   struct Rec {
-    int cat, e0, e1;
+    int cat, e0, e1, launches;
   };
   std::vector<Rec> recs;
   int used = 0;
@@ -103,14 +103,17 @@ struct KTimer {
     if (!on) return -1;
     const int e = grab();
     (void)hipEventRecord(pool[e], s);
-    recs.push_back({cat, e, -1});
+    recs.push_back({cat, e, -1, 1});
     return (int)recs.size() - 1;
   }
-  void end(int r, hipStream_t s, double w = 0) {
+  // `launches` back-to-back launches of one kernel may share one begin / end pair (an event record between two
+  // launches costs ~8 us of idle device time: measured 35 x 11 us on the root's step kernels)
+  void end(int r, hipStream_t s, double w = 0, int launches = 1) {
     if (!on || r < 0) return;
     const int e = grab();
     (void)hipEventRecord(pool[e], s);
     recs[r].e1 = e;
+    recs[r].launches = launches;
     work[recs[r].cat] += w;
   }
   void resolve() {  // call after the stream is synchronised
@@ -118,7 +121,7 @@ struct KTimer {
       float t = 0;
       if (r.e1 >= 0 && hipEventElapsedTime(&t, pool[r.e0], pool[r.e1]) == hipSuccess) {
         ms[r.cat] += t;
-        cnt[r.cat] += 1;
+        cnt[r.cat] += r.launches;
       }
     }
     recs.clear();
@@ -628,9 +631,18 @@ int do_eliminate(lmgpu_handle* h, double lambda) {
         h->kt.end(ktp, s, panel_flop(i));
       };
       panel_alone(0);
+      int kt_run = -1, run_launches = 0;  // one event pair around a run of consecutive step launches
+      double run_flop = 0;
+      auto close_run = [&]() {
+        if (run_launches > 0) h->kt.end(kt_run, s, run_flop, run_launches);
+        kt_run = -1;
+        run_launches = 0;
+        run_flop = 0;
+      };
       for (int i = 0; i < np; i++) {
         const int k0 = i * NBO, kb = rows_of(i), r0 = k0 + kb, m = F.n - r0;
         if (m <= 0) break;
+        if (split && i + 1 < nchunks) close_run();  // the fold-in of the next chunk is timed separately
         { const int rcc = add_chunk(i + 1); if (rcc) return rcc; }  // rows of panel i+1 (and, for i = np-1, of the separator part)
         const bool fuse = (i + 1 < np) && dataflow_ok(i + 1) && !h->no_fuse;
         const int T = (m + 127) / 128;
@@ -641,16 +653,19 @@ int do_eliminate(lmgpu_handle* h, double lambda) {
           StepArgs a{A, ld, F.n, F.nf, k0, kb, kbn, F.id, h->d_status, h->inv16, h->d_pflags + (size_t)(i + 1) * PDF_FLAG_WORDS};
           const int S = (m + 63) / 64;
           const int grid = T * (T + 1) / 2 - (T >= 2 ? 2 * T - 1 : T) + (S >= 4 ? 6 + 4 * (S - 3) : S * (S + 1) / 2) + kbn / 64 + (m - kbn + 63) / 64;
-          const int kts = h->kt.begin(LMGPU_KT_SYRK, s);
+          if (run_launches == 0) kt_run = h->kt.begin(LMGPU_KT_SYRK, s);
           hipLaunchKernelGGL(step_kernel, dim3(grid), dim3(256), STEP_LDS_BYTES, s, a);
-          h->kt.end(kts, s, upd_flop + panel_flop(i + 1));
+          run_launches++;
+          run_flop += upd_flop + panel_flop(i + 1);
         } else {
+          close_run();
           const int kts = h->kt.begin(LMGPU_KT_SYRK, s);
           hipLaunchKernelGGL(syrk_mfma_kernel, dim3(T, T), dim3(256), kSyrkLds, s, A, ld, F.n, k0, kb, r0, F.n);
           h->kt.end(kts, s, upd_flop);
           if (i + 1 < np) panel_alone(i + 1);
         }
       }
+      close_run();
       for (int c = np + 1; c < nchunks; c++) {  // separator rows beyond the chunk after the last panel
         const int rcc = add_chunk(c);
         if (rcc) return rcc;
@@ -703,8 +718,12 @@ int do_backsub(lmgpu_handle* h) {
   return LMGPU_OK;
 }
 
-// solve the damped system; returns LMGPU_OK / LMGPU_INDETERMINATE.  lin errors into h_scal[1], h_scal[2].
-int do_solve(lmgpu_handle* h, double lambda) {
+// Solve the damped system.  do_solve_enqueue queues everything (eliminate, back-substitute, the two linear errors and the
+// copies of the scalars / the status word to pinned host memory) without waiting; do_solve_finish waits for the stream and
+// returns LMGPU_OK / LMGPU_INDETERMINATE with the linear errors in h_scal[1], h_scal[2].  tryLambda queues the retraction and
+// the new error behind the solve BEFORE it waits (one host round trip per inner iteration instead of two); their result is
+// simply not used when the solve failed or the linearised cost went up.
+int do_solve_enqueue(lmgpu_handle* h, double lambda) {
   hipStream_t s = h->stream;
   (void)hipEventRecord(h->ev[1], s);
   int rc = do_eliminate(h, lambda);
@@ -726,7 +745,11 @@ int do_solve(lmgpu_handle* h, double lambda) {
   (void)hipEventRecord(h->ev[4], s);
   HIPCHECK(hipMemcpyAsync(h->h_scal + 1, h->dscal + 1, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHECK(hipMemcpyAsync(h->h_status, h->d_status, sizeof(int), hipMemcpyDeviceToHost, s));
-  HIPCHECK(hipStreamSynchronize(s));
+  return LMGPU_OK;
+}
+
+int do_solve_finish(lmgpu_handle* h) {
+  HIPCHECK(hipStreamSynchronize(h->stream));
   h->kt.resolve();
   h->solved = true;
   if (*h->h_status < (int)h->h_fronts.size()) {
@@ -735,6 +758,12 @@ int do_solve(lmgpu_handle* h, double lambda) {
     return LMGPU_INDETERMINATE;
   }
   return LMGPU_OK;
+}
+
+int do_solve(lmgpu_handle* h, double lambda) {
+  const int rc = do_solve_enqueue(h, lambda);
+  if (rc) return rc;
+  return do_solve_finish(h);
 }
 
 int do_retract(lmgpu_handle* h, int from, int to) {
@@ -756,13 +785,33 @@ void accumulate_times(lmgpu_handle* h, bool with_retract) {
   if (with_retract && hipEventElapsedTime(&ms, h->ev[5], h->ev[6]) == hipSuccess) h->tim.retract_error_ms += ms;
 }
 
+// values[cur ^ 1] = retract(values[cur], delta); its nonlinear error into h_scal[0] (queued, no wait)
+int enqueue_retract_and_error(lmgpu_handle* h) {
+  (void)hipEventRecord(h->ev[5], h->stream);
+  const int kt = h->kt.begin(LMGPU_KT_RETRACT_ERROR, h->stream);
+  int rc = do_retract(h, h->cur, h->cur ^ 1);
+  if (rc) return rc;
+  launch_factors<false>(h, h->cur ^ 1);
+  reduce_to(h, h->ebuf0, h->n_counted, h->dscal);
+  h->kt.end(kt, h->stream);
+  rc = allreduce_scalars(h, 0, 1);
+  if (rc) return rc;
+  (void)hipEventRecord(h->ev[6], h->stream);
+  HIPCHECK(hipMemcpyAsync(h->h_scal, h->dscal, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  return LMGPU_OK;
+}
+
 // LevenbergMarquardtOptimizer::tryLambda  (gtsam/nonlinear/LevenbergMarquardtOptimizer.cpp:121-270)
 int try_lambda(lmgpu_handle* h, const lmgpu_lm_params* p, bool* done) {
   lmgpu_lm_state& st = h->lm;
   double modelFidelity = 0.0;
   bool step_is_successful = false, stopSearchingLambda = false;
   double newError = std::numeric_limits<double>::infinity(), costChange = 0.0;
-  int rc = do_solve(h, st.lambda);
+  int rc = do_solve_enqueue(h, st.lambda);
+  if (rc) return rc;
+  rc = enqueue_retract_and_error(h);  // speculative: used only if the solve succeeded and the linearised cost did not go up
+  if (rc) return rc;
+  rc = do_solve_finish(h);
   if (rc != LMGPU_OK && rc != LMGPU_INDETERMINATE) return rc;
   const bool solved = (rc == LMGPU_OK);
   bool retracted = false;
@@ -770,19 +819,6 @@ int try_lambda(lmgpu_handle* h, const lmgpu_lm_params* p, bool* done) {
     const double oldLin = h->h_scal[1], newLin = h->h_scal[2];
     const double linearizedCostChange = oldLin - newLin;
     if (linearizedCostChange >= 0) {
-      (void)hipEventRecord(h->ev[5], h->stream);
-      const int kt = h->kt.begin(LMGPU_KT_RETRACT_ERROR, h->stream);
-      rc = do_retract(h, h->cur, h->cur ^ 1);
-      if (rc) return rc;
-      launch_factors<false>(h, h->cur ^ 1);
-      reduce_to(h, h->ebuf0, h->n_counted, h->dscal);
-      h->kt.end(kt, h->stream);
-      rc = allreduce_scalars(h, 0, 1);
-      if (rc) return rc;
-      (void)hipEventRecord(h->ev[6], h->stream);
-      HIPCHECK(hipMemcpyAsync(h->h_scal, h->dscal, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-      HIPCHECK(hipStreamSynchronize(h->stream));
-      h->kt.resolve();
       newError = h->h_scal[0];
       retracted = true;
       costChange = st.error - newError;
