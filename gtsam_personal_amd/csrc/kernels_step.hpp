@@ -22,11 +22,14 @@ struct StepArgs {
   int* status;
   double* inv16;
   unsigned int* flags;
+  const double* S;  // != nullptr: partial-assembly buffer (same layout as A) whose rows r0 .. r0+255 are folded in by this launch
 };
 
 // 64x64 tile of the trailing update for the rows of the NEXT panel (the head of the dependency chain): four waves, 32x32 each,
 // operand fragments straight from L2 (no LDS staging; 1/4 of a 128x128 tile's latency).  C[i][j] -= sum_p P[p][i] P[p][j].
-__device__ __forceinline__ void syrk_subtile64(double* __restrict__ A, int ld, int n, int p0, int kp, int r0, int si, int sj) {
+// Sadd != nullptr: the rows of the next panel also receive their (so far separate) assembled contributions, C += Sadd - P^T P
+__device__ __forceinline__ void syrk_subtile64(double* __restrict__ A, int ld, int n, int p0, int kp, int r0, int si, int sj,
+                                               const double* __restrict__ Sadd) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kk = lane >> 4, cc = lane & 15;
   const int wr = wave >> 1, wc = wave & 1;
   if (si == sj && wr > wc) return;
@@ -66,7 +69,11 @@ __device__ __forceinline__ void syrk_subtile64(double* __restrict__ A, int ld, i
 #pragma unroll
     for (int b = 0; b < 2; b++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) cur[a][b][r] = A[(size_t)min(i0 + 16 * a + kk + 4 * r, n - 1) * ld + min(j0 + 16 * b + cc, n - 1)];
+      for (int r = 0; r < 4; r++) {
+        const size_t at = (size_t)min(i0 + 16 * a + kk + 4 * r, n - 1) * ld + min(j0 + 16 * b + cc, n - 1);
+        cur[a][b][r] = A[at];
+        if (Sadd) cur[a][b][r] += Sadd[at];
+      }
 #pragma unroll
   for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -105,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void step_kernel(StepArgs a) {
       sj = 3 + ((t - 6) >> 2);
       si = (t - 6) & 3;
     }
-    syrk_subtile64(a.A, a.ld, a.n, a.p0, a.kp, r0, si, sj);
+    syrk_subtile64(a.A, a.ld, a.n, a.p0, a.kp, r0, si, sj, a.S);
     pdf_publish(&a.flags[PDF_TA0 + sj], threadIdx.x == 0);
     return;
   }

@@ -223,7 +223,17 @@ struct lmgpu_handle {
   // gather-mode (Schur form) assembly of HBM fronts from their leaf children
   struct GatherRange {
     int pblk_begin = 0, pblk_short = 0, pblk_long = 0, vblk_begin = 0, vblk_count = 0, leaf_begin = 0, leaf_count = 0;  // short blocks first
+    // blocks are sorted by destination row: [cs[c], cs[c+1]) = short pair blocks whose rows lie in row chunk c (256 rows),
+    // likewise cl (long pair blocks) and cv (variable blocks); offsets relative to the three list starts
+    std::vector<int> cs, cl, cv;
   };
+  // LMGPU_OVERLAP=1: gather the root's row chunks on a second stream beside its factorisation.  Measured r01 (C4): 13.5 ms per
+  // step instead of 10.4 -- two resident workgroups of the update kernel hold every VGPR of a SIMD (2 x 256), so the gather
+  // waves only get in between workgroups and every panel then waits for its chunk.  Off; kept for A/B.
+  bool overlap_gather = false;
+  hipStream_t asm_stream = nullptr;  // pipelined assembly of a gathered HBM front, chunk by chunk beside its factorisation
+  hipEvent_t ready_ev = nullptr;
+  double *partial2 = nullptr, *dscal2 = nullptr;
   std::vector<GatherRange> gather;  // per front (only HBM fronts have non-empty ranges)
   GPairBlock* d_gpblk = nullptr;
   GPairEntry* d_gpent = nullptr;
@@ -347,10 +357,12 @@ void launch_factors(lmgpu_handle* h, int which) {
   }
 }
 
-void reduce_to(lmgpu_handle* h, const double* buf, int n, double* dst) {
+void reduce_to(lmgpu_handle* h, const double* buf, int n, double* dst, hipStream_t st = nullptr, double* scratch = nullptr) {
   const int g = std::min(256, std::max(1, (n + 255) / 256));
-  hipLaunchKernelGGL(reduce_stage1, dim3(g), dim3(256), 0, h->stream, buf, n, h->partial);
-  hipLaunchKernelGGL(reduce_stage2, dim3(1), dim3(256), 0, h->stream, (const double*)h->partial, g, dst);
+  if (!st) st = h->stream;
+  if (!scratch) scratch = h->partial;
+  hipLaunchKernelGGL(reduce_stage1, dim3(g), dim3(256), 0, st, buf, n, scratch);
+  hipLaunchKernelGGL(reduce_stage2, dim3(1), dim3(256), 0, st, (const double*)scratch, g, dst);
 }
 
 // all-reduce over the ranks: RCCL, or the in-process local group
@@ -529,72 +541,117 @@ int do_eliminate(lmgpu_handle* h, double lambda) {
       const int ld = h->f_ld[fi];
       double* A = h->pool + off;
       const bool replicated = (F.pad & 1) != 0, own_terms = (F.pad & 2) == 0;
-      // multi-rank: the partial assembly goes to its own buffer (aoff) and is summed over the ranks in 256-row chunks while
-      // the factorisation of the earlier chunks is already running; the working matrix A starts from zero
-      const bool split = replicated && h->s_off[fi] >= 0 && (h->comm || h->lgroup);
+      const lmgpu_handle::GatherRange& G = h->gather[fi];
+      const int np = (F.nf + NBO - 1) / NBO;
+      const int nchunks = (F.n + NBO - 1) / NBO;
+      // `split`: the assembled contributions go to a buffer of their own (aoff) and reach the working matrix A (which starts
+      // from zero and collects the trailing updates) in 256-row chunks, each just before its panel is factored.
+      //   multi-rank   : the chunks are summed over the ranks (RCCL on the communication stream / the in-process group)
+      //   `pipelined`  : the chunks are GATHERED one after the other on the assembly stream while the factorisation of the
+      //                  earlier panels runs on the main stream (the gather is memory-bound, the update MFMA-bound, and the
+      //                  tail of the factorisation leaves most CUs idle)
+      const bool multi = replicated && (h->comm || h->lgroup);
+      const bool pipelined = h->overlap_gather && h->s_off[fi] >= 0 && G.leaf_count > 0 && !h->lgroup && (int)G.cs.size() == nchunks + 1;
+      const bool split = h->s_off[fi] >= 0 && (multi || pipelined);
       const int64_t aoff = split ? h->s_off[fi] : off;
       double* Asm = h->pool + aoff;
-      int kt = h->kt.begin(LMGPU_KT_HBM_ASSEMBLE, s);
-      if (F.fac_count > 0 && own_terms)
-        hipLaunchKernelGGL(hbm_assemble_factors_kernel, dim3(F.fac_count), dim3(64), 0, s, F, aoff, ld, (const FrontFac*)h->d_ffac,
-                           (const FacDesc*)h->d_fd, h->pool);
-      if (F.child_count > 0)
-        hipLaunchKernelGGL(hbm_assemble_children_kernel, dim3(F.child_count), dim3(256), 0, s, F, aoff, ld, (const ChildRef*)h->d_childs,
-                           (const int32_t*)h->d_cmap, h->pool);
-      {  // leaf children in Schur form: deterministic gather instead of atomics
-        const lmgpu_handle::GatherRange& G = h->gather[fi];
-        if (G.pblk_short > 0)
-          hipLaunchKernelGGL((schur_pairs_kernel<1>), dim3(G.pblk_short), dim3(64), 0, s, (const GPairBlock*)(h->d_gpblk + G.pblk_begin),
-                             (const GPairEntry*)h->d_gpent, h->pool, aoff, ld);
-        if (G.pblk_long > 0)
-          hipLaunchKernelGGL((schur_pairs_kernel<4>), dim3(G.pblk_long), dim3(256), 0, s,
-                             (const GPairBlock*)(h->d_gpblk + G.pblk_begin + G.pblk_short), (const GPairEntry*)h->d_gpent, h->pool, aoff, ld);
-        if (G.vblk_count > 0)
-          hipLaunchKernelGGL(schur_factor_kernel, dim3(G.vblk_count), dim3(64 * SCHUR_FW), 0, s, (const GVarBlock*)(h->d_gvblk + G.vblk_begin),
-                             (const GVarEntry*)h->d_gvent, h->pool, aoff, ld, F.n);
-        if (G.leaf_count > 0) {
-          reduce_to(h, h->d_gcorner + G.leaf_begin, G.leaf_count, h->dscal + 4);
-          hipLaunchKernelGGL(add_scalar_kernel, dim3(1), dim3(1), 0, s, Asm + (size_t)(F.n - 1) * ld + F.n - 1, (const double*)(h->dscal + 4));
-        }
+      hipStream_t sa = pipelined ? h->asm_stream : s;
+      if (pipelined) {
+        HIPCHECK(hipEventRecord(h->ready_ev, s));
+        HIPCHECK(hipStreamWaitEvent(sa, h->ready_ev, 0));
       }
-      if (own_terms)
-        hipLaunchKernelGGL(hbm_damp_kernel, dim3((F.nf + 255) / 256), dim3(256), 0, s, F, aoff, ld, (const int32_t*)h->d_fxoff, h->pool, lambda,
-                           (const double*)h->dampw);
-      h->kt.end(kt, s);
+      if (split)
+        while ((int)h->chunk_ev.size() < 2 * nchunks) {
+          hipEvent_t e;
+          HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+          h->chunk_ev.push_back(e);
+        }
       // chunk c = rows [256 c, 256 (c+1)) from the first column of its diagonal block to the end of its last row
-      const int nchunks = (F.n + NBO - 1) / NBO;
       auto chunk_range = [&](int c, size_t& begin, size_t& count) {
         const int r0c = c * NBO, rows = std::min(F.n, r0c + NBO) - r0c;
         begin = (size_t)r0c * ld + r0c;  // r0c is a multiple of 256: 16-aligned
         count = (size_t)rows * ld - r0c;
       };
-      if (split && h->comm) {  // RCCL: all chunks queued on the communication stream, one event each
-        while ((int)h->chunk_ev.size() < nchunks) {
-          hipEvent_t e;
-          HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-          h->chunk_ev.push_back(e);
+      int kt = h->kt.begin(LMGPU_KT_HBM_ASSEMBLE, sa);
+      if (F.fac_count > 0 && own_terms)
+        hipLaunchKernelGGL(hbm_assemble_factors_kernel, dim3(F.fac_count), dim3(64), 0, sa, F, aoff, ld, (const FrontFac*)h->d_ffac,
+                           (const FacDesc*)h->d_fd, h->pool);
+      if (F.child_count > 0)
+        hipLaunchKernelGGL(hbm_assemble_children_kernel, dim3(F.child_count), dim3(256), 0, sa, F, aoff, ld, (const ChildRef*)h->d_childs,
+                           (const int32_t*)h->d_cmap, h->pool);
+      if (own_terms)
+        hipLaunchKernelGGL(hbm_damp_kernel, dim3((F.nf + 255) / 256), dim3(256), 0, sa, F, aoff, ld, (const int32_t*)h->d_fxoff, h->pool, lambda,
+                           (const double*)h->dampw);
+      // leaf children in Schur form: deterministic gather instead of atomics; rows [c0, c1) of the chunk table
+      auto gather_chunks = [&](int c0, int c1, bool whole) {
+        const int s0 = whole ? 0 : G.cs[c0], s1 = whole ? G.pblk_short : G.cs[c1];
+        const int l0 = whole ? 0 : G.cl[c0], l1 = whole ? G.pblk_long : G.cl[c1];
+        const int v0 = whole ? 0 : G.cv[c0], v1 = whole ? G.vblk_count : G.cv[c1];
+        if (s1 > s0)
+          hipLaunchKernelGGL((schur_pairs_kernel<1>), dim3(s1 - s0), dim3(64), 0, sa, (const GPairBlock*)(h->d_gpblk + G.pblk_begin + s0),
+                             (const GPairEntry*)h->d_gpent, h->pool, aoff, ld);
+        if (l1 > l0)
+          hipLaunchKernelGGL((schur_pairs_kernel<4>), dim3(l1 - l0), dim3(256), 0, sa,
+                             (const GPairBlock*)(h->d_gpblk + G.pblk_begin + G.pblk_short + l0), (const GPairEntry*)h->d_gpent, h->pool, aoff, ld);
+        if (v1 > v0)
+          hipLaunchKernelGGL(schur_factor_kernel, dim3(v1 - v0), dim3(64 * SCHUR_FW), 0, sa, (const GVarBlock*)(h->d_gvblk + G.vblk_begin + v0),
+                             (const GVarEntry*)h->d_gvent, h->pool, aoff, ld, F.n);
+        if (G.leaf_count > 0 && (whole || c1 == nchunks)) {  // the (rhs, rhs) corner lives in the last chunk
+          double* scal = pipelined ? h->dscal2 : h->dscal + 4;
+          reduce_to(h, h->d_gcorner + G.leaf_begin, G.leaf_count, scal, sa, pipelined ? h->partial2 : nullptr);
+          hipLaunchKernelGGL(add_scalar_kernel, dim3(1), dim3(1), 0, sa, Asm + (size_t)(F.n - 1) * ld + F.n - 1, (const double*)scal);
         }
-        HIPCHECK(hipEventRecord(h->asm_ev, s));
-        HIPCHECK(hipStreamWaitEvent(h->comm_stream, h->asm_ev, 0));
+      };
+      if (!pipelined) {
+        gather_chunks(0, nchunks, true);
+        h->kt.end(kt, sa);
+        if (multi && h->comm && split) {  // RCCL: all chunks queued on the communication stream, one event each
+          HIPCHECK(hipEventRecord(h->asm_ev, s));
+          HIPCHECK(hipStreamWaitEvent(h->comm_stream, h->asm_ev, 0));
+          for (int c = 0; c < nchunks; c++) {
+            size_t cb, cn;
+            chunk_range(c, cb, cn);
+            NCCLCHECK(ncclAllReduce(Asm + cb, Asm + cb, cn, ncclDouble, ncclSum, h->comm, h->comm_stream));
+            HIPCHECK(hipEventRecord(h->chunk_ev[c], h->comm_stream));
+          }
+        }
+      } else {
         for (int c = 0; c < nchunks; c++) {
-          size_t cb, cn;
-          chunk_range(c, cb, cn);
-          NCCLCHECK(ncclAllReduce(Asm + cb, Asm + cb, cn, ncclDouble, ncclSum, h->comm, h->comm_stream));
-          HIPCHECK(hipEventRecord(h->chunk_ev[c], h->comm_stream));
+          gather_chunks(c, c + 1, false);
+          if (c + 1 == nchunks) h->kt.end(kt, sa);
+          if (multi && h->comm) {  // gathered chunk -> summed over the ranks -> event
+            size_t cb, cn;
+            chunk_range(c, cb, cn);
+            HIPCHECK(hipEventRecord(h->chunk_ev[nchunks + c], sa));
+            HIPCHECK(hipStreamWaitEvent(h->comm_stream, h->chunk_ev[nchunks + c], 0));
+            NCCLCHECK(ncclAllReduce(Asm + cb, Asm + cb, cn, ncclDouble, ncclSum, h->comm, h->comm_stream));
+            HIPCHECK(hipEventRecord(h->chunk_ev[c], h->comm_stream));
+          } else {
+            HIPCHECK(hipEventRecord(h->chunk_ev[c], sa));
+          }
         }
       }
-      // fold the reduced chunk c into the working matrix (which already carries the trailing updates of earlier panels)
-      auto add_chunk = [&](int c) -> int {
+      // chunk c is complete (gathered / reduced) for everything queued on the main stream after this call
+      auto wait_chunk = [&](int c) -> int {
         if (!split || c >= nchunks) return LMGPU_OK;
-        size_t cb, cn;
-        chunk_range(c, cb, cn);
-        const int ktc = h->kt.begin(LMGPU_KT_ALLREDUCE, s);
-        if (h->comm) {
+        if (pipelined || h->comm) {
           HIPCHECK(hipStreamWaitEvent(s, h->chunk_ev[c], 0));
-        } else {
+        } else {  // in-process group: synchronous
+          size_t cb, cn;
+          chunk_range(c, cb, cn);
           const int rca = allreduce_sum(h, Asm + cb, cn, s);
           if (rca) return rca;
         }
+        return LMGPU_OK;
+      };
+      // fold chunk c into the working matrix (which already carries the trailing updates of earlier panels)
+      auto add_chunk = [&](int c) -> int {
+        if (!split || c >= nchunks) return LMGPU_OK;
+        const int ktc = h->kt.begin(LMGPU_KT_ALLREDUCE, s);
+        const int rcw = wait_chunk(c);
+        if (rcw) return rcw;
+        size_t cb, cn;
+        chunk_range(c, cb, cn);
         hipLaunchKernelGGL(local_sum_kernel, dim3(std::min<size_t>(2048, (cn + 255) / 256)), dim3(256), 0, s, A + cb, (const double*)(Asm + cb), cn);
         h->kt.end(ktc, s, (double)cn * 8.0);
         return LMGPU_OK;
@@ -604,7 +661,6 @@ int do_eliminate(lmgpu_handle* h, double lambda) {
       // (panel_dataflow_kernel); after that ONE launch per outer panel i (step_kernel): trailing update with panel i
       // + factorisation of panel i+1 beside/behind it (look-ahead inside the launch, kernels_step.hpp).  A panel whose row
       // count is not a multiple of 64 (the last one) takes the two-launch form diag_potrf_kernel + panel_trsm_kernel.
-      const int np = (F.nf + NBO - 1) / NBO;
       if (np + 1 > h->pflags_panels) {
         h->err = "panel flag buffer too small";
         return LMGPU_INVALID;
@@ -642,15 +698,25 @@ int do_eliminate(lmgpu_handle* h, double lambda) {
       for (int i = 0; i < np; i++) {
         const int k0 = i * NBO, kb = rows_of(i), r0 = k0 + kb, m = F.n - r0;
         if (m <= 0) break;
-        if (split && i + 1 < nchunks) close_run();  // the fold-in of the next chunk is timed separately
-        { const int rcc = add_chunk(i + 1); if (rcc) return rcc; }  // rows of panel i+1 (and, for i = np-1, of the separator part)
         const bool fuse = (i + 1 < np) && dataflow_ok(i + 1) && !h->no_fuse;
+        // rows of panel i+1 (and, for i = np-1, of the separator part): a fused step folds them in itself (its 64x64 head tiles
+        // cover exactly those rows), otherwise an add kernel does
+        const bool fold_in_step = split && fuse && r0 == (i + 1) * NBO;
+        if (fold_in_step) {
+          const int rcw = wait_chunk(i + 1);
+          if (rcw) return rcw;
+        } else {
+          if (split && i + 1 < nchunks) close_run();  // the fold-in kernel is timed separately
+          const int rcc = add_chunk(i + 1);
+          if (rcc) return rcc;
+        }
         const int T = (m + 127) / 128;
         // algorithmic flop of the update: 2 x kb x (upper-triangle entries of the m x m trailing matrix)
         const double upd_flop = 2.0 * kb * ((double)m * (m + 1) / 2.0);
         if (fuse) {
           const int kbn = rows_of(i + 1);
-          StepArgs a{A, ld, F.n, F.nf, k0, kb, kbn, F.id, h->d_status, h->inv16, h->d_pflags + (size_t)(i + 1) * PDF_FLAG_WORDS};
+          StepArgs a{A, ld, F.n, F.nf, k0, kb, kbn, F.id, h->d_status, h->inv16, h->d_pflags + (size_t)(i + 1) * PDF_FLAG_WORDS,
+                     fold_in_step ? (const double*)Asm : nullptr};
           const int S = (m + 63) / 64;
           const int grid = T * (T + 1) / 2 - (T >= 2 ? 2 * T - 1 : T) + (S >= 4 ? 6 + 4 * (S - 3) : S * (S + 1) / 2) + kbn / 64 + (m - kbn + 63) / 64;
           if (run_launches == 0) kt_run = h->kt.begin(LMGPU_KT_SYRK, s);
@@ -980,11 +1046,18 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
   h->device = cfg->device;
   h->two_launch_panel = getenv("LMGPU_PANEL_2L") != nullptr;
   h->no_fuse = getenv("LMGPU_NO_FUSE") != nullptr;
+  h->overlap_gather = getenv("LMGPU_OVERLAP") != nullptr;
   *out = h;
   if (h->device >= 0) {
     HIPCHECK(hipSetDevice(h->device));
     HIPCHECK(hipStreamCreate(&h->stream));
     HIPCHECK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+    {  // the assembly chunks are short and each gates a panel of the factorisation: highest dispatch priority
+      int prio_lo = 0, prio_hi = 0;
+      HIPCHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+      HIPCHECK(hipStreamCreateWithPriority(&h->asm_stream, hipStreamNonBlocking, prio_hi));
+    }
+    HIPCHECK(hipEventCreateWithFlags(&h->ready_ev, hipEventDisableTiming));
     HIPCHECK(hipEventCreateWithFlags(&h->asm_ev, hipEventDisableTiming));
     for (int i = 0; i < 8; i++) HIPCHECK(hipEventCreate(&h->ev[i]));
     HIPCHECK(hipHostMalloc((void**)&h->h_scal, 8 * sizeof(double), hipHostMallocDefault));
@@ -1030,6 +1103,9 @@ int lmgpu_destroy(lmgpu_handle* h) {
     fr(h->d_gpblk); fr(h->d_gpent); fr(h->d_gvblk); fr(h->d_gvent); fr(h->d_gcorner);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
+    if (h->asm_stream) (void)hipStreamDestroy(h->asm_stream);
+    if (h->ready_ev) (void)hipEventDestroy(h->ready_ev);
+    fr(h->partial2); fr(h->dscal2);
     if (h->asm_ev) (void)hipEventDestroy(h->asm_ev);
     for (hipEvent_t e : h->chunk_ev) (void)hipEventDestroy(e);
   }
@@ -1248,7 +1324,13 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
       F.ld_u = ld;
       F.u_off = off + (int64_t)fr.nf * ld + fr.nf;
       off += (int64_t)fr.n * ld;
-      if (F.pad & 1) {  // replicated: the rank's partial sums are assembled beside the working matrix and reduced in row chunks
+      bool gathered = false;  // will this front gather leaf children (kernels_schur.hpp)?
+      for (int32_t c : fr.children)
+        if (h->front_active[c] && P.fronts[c].cls == 0 && P.fronts[c].children.empty() && !getenv("LMGPU_NO_GATHER")) gathered = true;
+      // the assembled contributions get a buffer of their own beside the working matrix when they arrive in row chunks while
+      // the factorisation is already running: replicated fronts (chunks all-reduced over the ranks) and multi-panel fronts
+      // that gather their leaves (chunks gathered on a second stream)
+      if ((F.pad & 1) || (gathered && fr.nf > NBO && h->overlap_gather)) {
         h->s_off[fi] = off;
         off += (int64_t)fr.n * ld;
       }
@@ -1346,6 +1428,22 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
         i = j;
       }
       G.vblk_count = (int)gvblk.size() - G.vblk_begin;
+      {  // chunk starts (lists are sorted by destination row)
+        const int nchunks = (fr.n + NBO - 1) / NBO;
+        auto starts = [&](std::vector<int>& out, int count, auto row_of) {
+          out.assign(nchunks + 1, count);
+          int c = 0;
+          out[0] = 0;
+          for (int i = 0; i < count; i++) {
+            const int rc = row_of(i) / NBO;
+            while (c < rc) out[++c] = i;
+          }
+          while (c < nchunks) out[++c] = count;
+        };
+        starts(G.cs, G.pblk_short, [&](int i) { return gpblk[G.pblk_begin + i].pa; });
+        starts(G.cl, G.pblk_long, [&](int i) { return gpblk[G.pblk_begin + G.pblk_short + i].pa; });
+        starts(G.cv, G.vblk_count, [&](int i) { return gvblk[G.vblk_begin + i].pv; });
+      }
       std::vector<GPairTmp>().swap(gp_tmp);
       std::vector<GVarTmp>().swap(gv_tmp);
     }
@@ -1533,6 +1631,8 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
   HIPCHECK(hipMalloc((void**)&h->ebuf0, std::max(1, h->nfac) * sizeof(double)));
   HIPCHECK(hipMalloc((void**)&h->ebuf1, std::max(1, h->nfac) * sizeof(double)));
   HIPCHECK(hipMalloc((void**)&h->partial, 256 * sizeof(double)));
+  HIPCHECK(hipMalloc((void**)&h->partial2, 256 * sizeof(double)));
+  HIPCHECK(hipMalloc((void**)&h->dscal2, 8 * sizeof(double)));
   HIPCHECK(hipMalloc((void**)&h->dscal, 8 * sizeof(double)));
   HIPCHECK(hipMalloc((void**)&h->ywork, std::max(1, P.max_front_n) * sizeof(double)));
   HIPCHECK(hipMalloc((void**)&h->d_status, sizeof(int)));
