@@ -68,6 +68,8 @@ SYMBOLS = {
     "lmgpu_optimize": (ct.c_int, [_H, ct.POINTER(lmgpu_lm_params), ct.POINTER(lmgpu_lm_state)]),
     "lmgpu_gn_iterate": (ct.c_int, [_H, ct.POINTER(lmgpu_lm_state)]),
     "lmgpu_gn_optimize": (ct.c_int, [_H, ct.POINTER(lmgpu_lm_params), ct.POINTER(lmgpu_lm_state)]),
+    "lmgpu_dl_iterate": (ct.c_int, [_H, ct.POINTER(lmgpu_lm_state)]),
+    "lmgpu_dl_optimize": (ct.c_int, [_H, ct.POINTER(lmgpu_lm_params), ct.POINTER(lmgpu_lm_state)]),
     "lmgpu_get_timings": (ct.c_int, [_H, ct.POINTER(lmgpu_timings)]),
     "lmgpu_set_kernel_timing": (ct.c_int, [_H, ct.c_int32]),
     "lmgpu_get_kernel_times": (ct.c_int, [_H, _D, _D, ct.POINTER(ct.c_int64)]),

@@ -29,6 +29,7 @@
 #include "kernels_potrf.hpp"
 #include "kernels_step.hpp"
 #include "kernels_batched.hpp"
+#include "kernels_bayes.hpp"
 #include "kernels_schur.hpp"
 #include "plan.hpp"
 
@@ -215,6 +216,9 @@ struct lmgpu_handle {
   ChildRef* d_childs = nullptr;
   int32_t *d_cmap = nullptr, *d_fxoff = nullptr, *d_sxoff = nullptr, *d_lists = nullptr;
   int32_t *d_hbm_small = nullptr, *d_f_ld = nullptr, *d_med_list = nullptr;
+  int n_lds_fronts = 0;                         // all levels' LDS-class fronts are contiguous in d_lists
+  double *bt_ebuf = nullptr, *bt_vec = nullptr;  // Dogleg: per-clique / per-row squared residuals; gradient / zero vector
+  int bt_ebuf_len = 0;
   double* inv16_med = nullptr;
   std::vector<char> is_med;
   int64_t* d_f_off = nullptr;
@@ -986,6 +990,159 @@ int gn_iterate(lmgpu_handle* h) {
   return LMGPU_OK;
 }
 
+// ---- Dogleg (gtsam/nonlinear/DoglegOptimizer.cpp:84-126; DoglegOptimizerImpl.h:139-254 with ONE_STEP_PER_ITERATION;
+//      DoglegOptimizerImpl.cpp:26-91).  The Bayes tree stays on the device ([R S d] of every front); the three vectors of the
+//      dogleg construction (steepest-descent point, Newton point, dogleg point) are blended on the host.
+// sum over the cliques of ||[R S] x - alpha d||^2
+int bt_forward(lmgpu_handle* h, const double* x, double alpha, double* out) {
+  hipStream_t s = h->stream;
+  int len = h->n_lds_fronts;
+  for (const LevelWork& L : h->levels)
+    for (int fi : L.hbm) len += h->h_fronts[fi].nf;
+  if (len > h->bt_ebuf_len) {
+    if (h->bt_ebuf) (void)hipFree(h->bt_ebuf);
+    HIPCHECK(hipMalloc((void**)&h->bt_ebuf, (size_t)len * sizeof(double)));
+    h->bt_ebuf_len = len;
+  }
+  if (h->n_lds_fronts > 0)
+    hipLaunchKernelGGL(bt_lds_forward_kernel, dim3((h->n_lds_fronts + 3) / 4), dim3(256), 0, s, (const int32_t*)h->d_lists, h->n_lds_fronts,
+                       (const FrontDesc*)h->d_fronts, (const int32_t*)h->d_fxoff, (const int32_t*)h->d_sxoff, (const double*)h->pool, x, alpha,
+                       h->bt_ebuf);
+  int o = h->n_lds_fronts;
+  for (const LevelWork& L : h->levels)
+    for (int fi : L.hbm) {
+      const FrontDesc& F = h->h_fronts[fi];
+      hipLaunchKernelGGL(bt_hbm_forward_kernel, dim3(F.nf), dim3(64), 0, s, F, h->f_off[fi], h->f_ld[fi], (const int32_t*)h->d_fxoff,
+                         (const int32_t*)h->d_sxoff, (const double*)h->pool, x, alpha, h->bt_ebuf + o);
+      o += F.nf;
+    }
+  reduce_to(h, h->bt_ebuf, len, h->dscal + 5);
+  HIPCHECK(hipMemcpyAsync(h->h_scal + 5, h->dscal + 5, sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHECK(hipStreamSynchronize(s));
+  *out = h->h_scal[5];
+  return LMGPU_OK;
+}
+
+// g = - sum over the cliques of [R S]^T d   (into h->bt_vec)
+int bt_gradient(lmgpu_handle* h) {
+  hipStream_t s = h->stream;
+  HIPCHECK(hipMemsetAsync(h->bt_vec, 0, h->ntot * sizeof(double), s));
+  if (h->n_lds_fronts > 0)
+    hipLaunchKernelGGL(bt_lds_transpose_kernel, dim3((h->n_lds_fronts + 3) / 4), dim3(256), 0, s, (const int32_t*)h->d_lists, h->n_lds_fronts,
+                       (const FrontDesc*)h->d_fronts, (const int32_t*)h->d_fxoff, (const int32_t*)h->d_sxoff, (const double*)h->pool, h->bt_vec);
+  for (const LevelWork& L : h->levels)
+    for (int fi : L.hbm) {
+      const FrontDesc& F = h->h_fronts[fi];
+      hipLaunchKernelGGL(bt_hbm_transpose_kernel, dim3((F.n - 1 + 255) / 256, (F.nf + 63) / 64), dim3(256), 0, s, F, h->f_off[fi], h->f_ld[fi],
+                         (const int32_t*)h->d_fxoff, (const int32_t*)h->d_sxoff, (const double*)h->pool, h->bt_vec);
+    }
+  HIPCHECK(hipGetLastError());
+  return LMGPU_OK;
+}
+
+int dl_iterate(lmgpu_handle* h) {
+  if (h->cfg.world_size > 1) {
+    h->err = "Dogleg is single-rank in this round";
+    return LMGPU_INVALID;
+  }
+  hipStream_t s = h->stream;
+  std::memset(&h->tim, 0, sizeof(h->tim));
+  if (!h->bt_vec) HIPCHECK(hipMalloc((void**)&h->bt_vec, std::max(1, h->ntot) * sizeof(double)));
+  int rc = do_linearize(h);
+  if (rc) return rc;
+  rc = fill_dampw(h, 0, 0.0, 0.0);
+  if (rc) return rc;
+  rc = do_solve(h, 0.0);  // undamped Bayes tree; h->delta = Newton point dx_n
+  if (rc) return rc;
+  const int n = h->ntot;
+  std::vector<double> dx_n(n), dx_u(n), dx_d(n);
+  HIPCHECK(hipMemcpyAsync(dx_n.data(), h->delta, n * sizeof(double), hipMemcpyDeviceToHost, s));
+  rc = bt_gradient(h);
+  if (rc) return rc;
+  HIPCHECK(hipMemcpyAsync(dx_u.data(), h->bt_vec, n * sizeof(double), hipMemcpyDeviceToHost, s));
+  double RgSq = 0, M_error = 0;
+  rc = bt_forward(h, h->bt_vec, 0.0, &RgSq);  // synchronises: dx_n / gradient are on the host now
+  if (rc) return rc;
+  double gg = 0;
+  for (int i = 0; i < n; i++) gg += dx_u[i] * dx_u[i];
+  const double step = -gg / RgSq;  // GaussianFactorGraph::optimizeGradientSearch, GaussianFactorGraph.cpp:381-406
+  for (int i = 0; i < n; i++) dx_u[i] *= step;
+  HIPCHECK(hipMemsetAsync(h->bt_vec, 0, n * sizeof(double), s));
+  rc = bt_forward(h, h->bt_vec, 1.0, &M_error);
+  if (rc) return rc;
+  M_error *= 0.5;
+  double uu = 0, nn = 0, un = 0;
+  for (int i = 0; i < n; i++) {
+    uu += dx_u[i] * dx_u[i];
+    nn += dx_n[i] * dx_n[i];
+    un += dx_u[i] * dx_n[i];
+  }
+  double delta = h->lm.lambda;  // trust radius
+  const double f_error = h->lm.error;
+  double new_f = f_error;
+  bool stay = true, moved = true;
+  while (stay) {
+    // ComputeDoglegPoint / ComputeBlend
+    const double deltaSq = delta * delta;
+    if (deltaSq < uu) {
+      const double f = std::sqrt(deltaSq / uu);
+      for (int i = 0; i < n; i++) dx_d[i] = f * dx_u[i];
+    } else if (deltaSq < nn) {
+      const double a = uu - 2. * un + nn, b = 2. * (un - uu), c = uu - delta * delta;
+      const double sq = std::sqrt(b * b - 4 * a * c);
+      const double tau1 = (-b + sq) / (2. * a), tau2 = (-b - sq) / (2. * a);
+      const double eps = std::numeric_limits<double>::epsilon();
+      const double tau = (-eps <= tau1 && tau1 <= 1.0 + eps) ? tau1 : tau2;
+      for (int i = 0; i < n; i++) dx_d[i] = (1. - tau) * dx_u[i] + tau * dx_n[i];
+    } else {
+      dx_d = dx_n;
+    }
+    HIPCHECK(hipMemcpyAsync(h->delta, dx_d.data(), n * sizeof(double), hipMemcpyHostToDevice, s));
+    rc = enqueue_retract_and_error(h);  // values[cur ^ 1] = retract(values[cur], dx_d), f(x_d) -> h_scal[0]
+    if (rc) return rc;
+    double new_M = 0;
+    rc = bt_forward(h, h->delta, 1.0, &new_M);  // synchronises
+    if (rc) return rc;
+    h->kt.resolve();
+    new_M *= 0.5;
+    new_f = h->h_scal[0];
+    h->tim.inner_iterations += 1;
+    const double rho = (std::abs(f_error - new_f) < 1e-15 || std::abs(M_error - new_M) < 1e-15) ? 0.5 : (f_error - new_f) / (M_error - new_M);
+    if (rho >= 0.75) {
+      double nd = 0;
+      for (int i = 0; i < n; i++) nd += dx_d[i] * dx_d[i];
+      delta = std::max(delta, 3.0 * std::sqrt(nd));
+      stay = false;
+    } else if (rho >= 0.25) {
+      stay = false;
+    } else if (rho >= 0.0) {
+      if (delta > 1e-5) delta *= 0.5;
+      stay = false;  // ONE_STEP_PER_ITERATION
+    } else {  // f increased (NaN lands here too): halve the radius until it does not
+      if (delta > 1e-5) {
+        delta *= 0.5;
+        stay = true;
+      } else {
+        moved = false;  // dx_d = 0: keep the values, keep the error
+        new_f = f_error;
+        stay = false;
+      }
+    }
+  }
+  if (moved) {
+    h->cur ^= 1;
+  } else {
+    HIPCHECK(hipMemsetAsync(h->delta, 0, n * sizeof(double), s));
+  }
+  h->linearized = false;
+  h->lm.error = new_f;
+  h->lm.lambda = delta;
+  h->lm.iterations += 1;
+  h->lm.totalNumberInnerIterations += h->tim.inner_iterations;
+  HIPCHECK(hipStreamSynchronize(s));
+  return LMGPU_OK;
+}
+
 // checkConvergence gtsam/nonlinear/NonlinearOptimizer.cpp:182-231
 bool check_convergence(double relTol, double absTol, double errTol, double currentError, double newError) {
   if (newError <= errTol) return true;
@@ -1089,7 +1246,7 @@ int lmgpu_destroy(lmgpu_handle* h) {
     for (int t = 0; t < 4; t++) fr(h->type_xoff[t]);
     for (int t = 0; t < 4; t++) fr(h->saved[t]);
     fr(h->delta); fr(h->dampw); fr(h->hdiag); fr(h->ebuf0); fr(h->ebuf1); fr(h->partial); fr(h->dscal); fr(h->ywork); fr(h->d_status);
-    fr(h->d_fd); fr(h->d_fronts); fr(h->d_ffac); fr(h->d_childs); fr(h->d_cmap); fr(h->d_fxoff); fr(h->d_sxoff); fr(h->d_lists); fr(h->d_hbm_small); fr(h->d_med_list); fr(h->inv16_med); fr(h->d_f_ld); fr(h->d_f_off);
+    fr(h->d_fd); fr(h->d_fronts); fr(h->d_ffac); fr(h->d_childs); fr(h->d_cmap); fr(h->d_fxoff); fr(h->d_sxoff); fr(h->d_lists); fr(h->d_hbm_small); fr(h->d_med_list); fr(h->inv16_med); fr(h->bt_ebuf); fr(h->bt_vec); fr(h->d_f_ld); fr(h->d_f_off);
     fr(h->d_scalar_var); fr(h->d_scalar_col); fr(h->d_vi_ptr); fr(h->d_vi_fac); fr(h->d_vi_pos);
     for (Bucket& b : h->buckets) {
       fr(b.d_vidx); fr(b.d_meas); fr(b.d_noise); fr(b.d_epos);
@@ -1520,6 +1677,7 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
   if ((rc = upload(h, &h->d_fxoff, fxoff))) return rc;
   if ((rc = upload(h, &h->d_sxoff, sxoff))) return rc;
   if ((rc = upload(h, &h->d_lists, lists))) return rc;
+  h->n_lds_fronts = (int)lists.size();
   {
     std::vector<int32_t> small;
     for (LevelWork& L : h->levels) {
@@ -1824,6 +1982,34 @@ int lmgpu_gn_optimize(lmgpu_handle* h, const lmgpu_lm_params* p, lmgpu_lm_state*
     do {
       currentError = newError;
       rc = gn_iterate(h);
+      if (rc) break;
+      newError = h->lm.error;
+    } while (h->lm.iterations < p->maxIterations &&
+             !check_convergence(p->relativeErrorTol, p->absoluteErrorTol, p->errorTol, currentError, newError) && std::isfinite(currentError));
+  }
+  if (inout) *inout = h->lm;
+  return rc;
+}
+int lmgpu_dl_iterate(lmgpu_handle* h, lmgpu_lm_state* inout) {
+  if (!h || !h->finalized || !h->have_values) return LMGPU_INVALID;
+  int rc = need_device(h);
+  if (rc) return rc;
+  if (inout) h->lm = *inout;
+  rc = dl_iterate(h);
+  if (inout) *inout = h->lm;
+  return rc;
+}
+int lmgpu_dl_optimize(lmgpu_handle* h, const lmgpu_lm_params* p, lmgpu_lm_state* inout) {
+  if (!h || !p || !h->finalized || !h->have_values) return LMGPU_INVALID;
+  int rc = need_device(h);
+  if (rc) return rc;
+  if (inout) h->lm = *inout;
+  double currentError = h->lm.error;
+  if (!(currentError <= p->errorTol || h->lm.iterations >= p->maxIterations)) {
+    double newError = currentError;
+    do {
+      currentError = newError;
+      rc = dl_iterate(h);
       if (rc) break;
       newError = h->lm.error;
     } while (h->lm.iterations < p->maxIterations &&

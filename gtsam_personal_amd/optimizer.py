@@ -325,3 +325,31 @@ class GaussNewtonOptimizer(LevenbergMarquardtOptimizer):
         cp = self.params._c()
         self._check(self.lib.lmgpu_gn_optimize(self._h, ct.byref(cp), ct.byref(self.state)))
         return self.values()
+
+
+class DoglegParams(LevenbergMarquardtParams):
+    """gtsam/nonlinear/DoglegOptimizer.h:33-63: NonlinearOptimizerParams + deltaInitial (default 1.0)"""
+
+    def __init__(self):
+        super().__init__()
+        self.deltaInitial = 1.0
+
+
+class DoglegOptimizer(LevenbergMarquardtOptimizer):
+    """gtsam/nonlinear/DoglegOptimizer.h:69-133 (multifrontal elimination) on the device-resident Bayes tree."""
+
+    def __init__(self, graph, initialValues, ordering=None, params=None, **kw):
+        params = params or DoglegParams()
+        super().__init__(graph, initialValues, ordering, params, **kw)
+        self.state.lambda_ = float(getattr(params, "deltaInitial", 1.0))
+
+    def getDelta(self) -> float:
+        return self.state.lambda_
+
+    def iterate(self):
+        self._check(self.lib.lmgpu_dl_iterate(self._h, ct.byref(self.state)))
+
+    def optimize(self) -> Values:
+        cp = self.params._c()
+        self._check(self.lib.lmgpu_dl_optimize(self._h, ct.byref(cp), ct.byref(self.state)))
+        return self.values()

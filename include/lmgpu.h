@@ -173,6 +173,14 @@ int lmgpu_optimize(lmgpu_handle* h, const lmgpu_lm_params* p, lmgpu_lm_state* in
  * maxIterations and the three error tolerances are read (NonlinearOptimizerParams). */
 int lmgpu_gn_iterate(lmgpu_handle* h, lmgpu_lm_state* inout);
 int lmgpu_gn_optimize(lmgpu_handle* h, const lmgpu_lm_params* p, lmgpu_lm_state* inout);
+
+/* DoglegOptimizer::iterate (gtsam/nonlinear/DoglegOptimizer.cpp:84-126, multifrontal elimination, ONE_STEP_PER_ITERATION as there;
+ * DoglegOptimizerImpl.h:139-254, DoglegOptimizerImpl.cpp:26-91): undamped solve, steepest-descent point from the Bayes tree
+ * (GaussianFactorGraph::optimizeGradientSearch, GaussianFactorGraph.cpp:381-406), dogleg point inside the trust region, gain
+ * ratio rho = (f(x) - f(x + dx_d)) / (M(0) - M(dx_d)) with M the Bayes tree's error, radius update.  The trust radius travels in
+ * state->lambda (initialise it to DoglegParams::deltaInitial, default 1.0; state->error as for LM).  Single-rank. */
+int lmgpu_dl_iterate(lmgpu_handle* h, lmgpu_lm_state* inout);
+int lmgpu_dl_optimize(lmgpu_handle* h, const lmgpu_lm_params* p, lmgpu_lm_state* inout);
 int lmgpu_get_timings(const lmgpu_handle* h, lmgpu_timings* out);
 
 /* Per-kernel device time (HIP events on the handle's stream around each launch), accumulated since

@@ -939,6 +939,129 @@ static bool gn_iterate(Problem& p) {
   return true;
 }
 
+// ---- Dogleg (gtsam/nonlinear/DoglegOptimizer.cpp:84-126, DoglegOptimizerImpl.h:139-254, DoglegOptimizerImpl.cpp:26-91)
+// The Bayes tree as a GaussianFactorGraph of unit-noise Jacobian factors [R S | d] (GaussianBayesTree.cpp:73-92).
+// e_c = [R S] x - alpha d for every clique; returns sum ||e_c||^2
+static double bt_residual_sq(const BayesTree& bt, const VectorValues& x, double alpha) {
+  double tot = 0;
+  for (const Clique& c : bt.cliques) {
+    const int nf = c.RSd.r, n = c.RSd.c;
+    std::vector<double> e(nf);
+    for (int i = 0; i < nf; i++) e[i] = -alpha * c.RSd(i, n - 1);
+    int col = 0;
+    for (size_t k = 0; k < c.keys.size(); k++) {
+      const auto& xk = x.at(c.keys[k]);
+      for (int d = 0; d < c.dims[k]; d++, col++)
+        for (int i = 0; i < nf; i++) e[i] += c.RSd(i, col) * xk[d];
+    }
+    for (int i = 0; i < nf; i++) tot += e[i] * e[i];
+  }
+  return tot;
+}
+// GaussianFactorGraph::gradientAtZero (GaussianFactorGraph.cpp:369-378; JacobianFactor.cpp:716-724): g = - sum [R S]^T d
+static VectorValues bt_gradient_at_zero(const BayesTree& bt, const VectorValues& like) {
+  VectorValues g;
+  for (auto& kv : like) g[kv.first] = std::vector<double>(kv.second.size(), 0.0);
+  for (const Clique& c : bt.cliques) {
+    const int nf = c.RSd.r, n = c.RSd.c;
+    int col = 0;
+    for (size_t k = 0; k < c.keys.size(); k++) {
+      auto& gk = g.at(c.keys[k]);
+      for (int d = 0; d < c.dims[k]; d++, col++)
+        for (int i = 0; i < nf; i++) gk[d] -= c.RSd(i, col) * c.RSd(i, n - 1);
+    }
+  }
+  return g;
+}
+static double vv_dot(const VectorValues& a, const VectorValues& b) {
+  double s = 0;
+  for (auto& kv : a) {
+    const auto& y = b.at(kv.first);
+    for (size_t i = 0; i < kv.second.size(); i++) s += kv.second[i] * y[i];
+  }
+  return s;
+}
+// DoglegOptimizerImpl::ComputeDoglegPoint / ComputeBlend (DoglegOptimizerImpl.cpp:26-91)
+static VectorValues dogleg_point(double delta, const VectorValues& dx_u, const VectorValues& dx_n) {
+  const double deltaSq = delta * delta, uu = vv_dot(dx_u, dx_u), nn = vv_dot(dx_n, dx_n);
+  VectorValues out = dx_n;
+  if (deltaSq < uu) {
+    const double f = std::sqrt(deltaSq / uu);
+    out = dx_u;
+    for (auto& kv : out)
+      for (auto& x : kv.second) x *= f;
+  } else if (deltaSq < nn) {
+    const double un = vv_dot(dx_u, dx_n);
+    const double a = uu - 2. * un + nn, b = 2. * (un - uu), c = uu - delta * delta;
+    const double sq = std::sqrt(b * b - 4 * a * c);
+    const double tau1 = (-b + sq) / (2. * a), tau2 = (-b - sq) / (2. * a);
+    const double eps = std::numeric_limits<double>::epsilon();
+    const double tau = (-eps <= tau1 && tau1 <= 1.0 + eps) ? tau1 : tau2;
+    for (auto& kv : out) {
+      const auto& u = dx_u.at(kv.first);
+      for (size_t i = 0; i < kv.second.size(); i++) kv.second[i] = (1. - tau) * u[i] + tau * kv.second[i];
+    }
+  }
+  return out;
+}
+// DoglegOptimizer::iterate with multifrontal elimination and ONE_STEP_PER_ITERATION; p.lambda carries the trust radius Delta
+static bool dl_iterate(Problem& p) {
+  linearize(p);
+  try {
+    solve_damped(p, 0.0, nullptr);  // Bayes tree in p.bt, Newton step in p.delta
+  } catch (const Indeterminate&) {
+    return false;
+  }
+  const VectorValues dx_n = p.delta;
+  VectorValues dx_u = bt_gradient_at_zero(p.bt, dx_n);
+  const double gg = vv_dot(dx_u, dx_u);
+  const double step = -gg / bt_residual_sq(p.bt, dx_u, 0.0);  // GaussianFactorGraph::optimizeGradientSearch :381-406
+  for (auto& kv : dx_u)
+    for (auto& x : kv.second) x *= step;
+  VectorValues zero = dx_n;
+  for (auto& kv : zero)
+    for (auto& x : kv.second) x = 0.0;
+  const double M_error = 0.5 * bt_residual_sq(p.bt, zero, 1.0);
+  double delta = p.lambda;
+  const double f_error = p.error;
+  VectorValues dx_d;
+  double new_f = f_error;
+  bool stay = true;
+  while (stay) {
+    dx_d = dogleg_point(delta, dx_u, dx_n);
+    const Values x_d = retract_all(p.values, dx_d);
+    new_f = graph_error(p, x_d);
+    const double new_M = 0.5 * bt_residual_sq(p.bt, dx_d, 1.0);
+    const double rho = (std::abs(f_error - new_f) < 1e-15 || std::abs(M_error - new_M) < 1e-15) ? 0.5 : (f_error - new_f) / (M_error - new_M);
+    if (rho >= 0.75) {
+      const double nrm = std::sqrt(vv_dot(dx_d, dx_d));
+      delta = std::max(delta, 3.0 * nrm);
+      stay = false;
+    } else if (rho >= 0.25) {
+      stay = false;
+    } else if (rho >= 0.0) {
+      if (delta > 1e-5) delta *= 0.5;
+      stay = false;  // ONE_STEP_PER_ITERATION
+    } else {  // f increased (or NaN): halve until it does not
+      if (delta > 1e-5) {
+        delta *= 0.5;
+        stay = true;
+      } else {
+        for (auto& kv : dx_d)
+          for (auto& x : kv.second) x = 0.0;
+        new_f = f_error;
+        stay = false;
+      }
+    }
+  }
+  p.values = retract_all(p.values, dx_d);
+  p.error = new_f;
+  p.lambda = delta;
+  p.iterations += 1;
+  p.delta = dx_d;
+  return true;
+}
+
 // checkConvergence gtsam/nonlinear/NonlinearOptimizer.cpp:182-231
 static bool check_convergence(double relTol, double absTol, double errTol, double currentError, double newError) {
   if (newError <= errTol) return true;
@@ -1194,6 +1317,70 @@ int orc_gn_optimize(void* h, const orc_lm_params* q) {
     newError = p.error;
   } while (p.iterations < prm.maxIterations &&
            !check_convergence(prm.relativeErrorTol, prm.absoluteErrorTol, prm.errorTol, currentError, newError) && std::isfinite(currentError));
+  return 0;
+}
+// DoglegOptimizer: state.lambda = trust radius Delta (DoglegParams::deltaInitial, default 1.0)
+int orc_dl_init(void* h, double deltaInitial) {
+  auto* p = (Problem*)h;
+  p->error = graph_error(*p, p->values);
+  p->lambda = deltaInitial;
+  p->iterations = 0;
+  p->totalInner = 0;
+  return 0;
+}
+int orc_dl_iterate(void* h) { return dl_iterate(*(Problem*)h) ? 0 : 1; }
+int orc_dl_optimize(void* h, const orc_lm_params* q) {
+  auto& p = *(Problem*)h;
+  const LMParams prm = to_params(q);
+  double currentError = p.error;
+  if (currentError <= prm.errorTol || p.iterations >= prm.maxIterations) return 0;
+  double newError = currentError;
+  do {
+    currentError = newError;
+    if (!dl_iterate(p)) return 1;
+    newError = p.error;
+  } while (p.iterations < prm.maxIterations &&
+           !check_convergence(prm.relativeErrorTol, prm.absoluteErrorTol, prm.errorTol, currentError, newError) && std::isfinite(currentError));
+  return 0;
+}
+// taps: steepest-descent point and Newton point of the current values (ordering order), and the dogleg blend
+int orc_dl_points(void* h, double* xu_out, double* xn_out) {
+  auto& p = *(Problem*)h;
+  linearize(p);
+  try {
+    solve_damped(p, 0.0, nullptr);
+  } catch (const Indeterminate&) {
+    return 1;
+  }
+  VectorValues dx_u = bt_gradient_at_zero(p.bt, p.delta);
+  const double step = -vv_dot(dx_u, dx_u) / bt_residual_sq(p.bt, dx_u, 0.0);
+  int o = 0;
+  for (Key k : p.ordering) {
+    const auto& u = dx_u.at(k);
+    const auto& nn = p.delta.at(k);
+    for (size_t i = 0; i < u.size(); i++, o++) {
+      xu_out[o] = step * u[i];
+      xn_out[o] = nn[i];
+    }
+  }
+  return 0;
+}
+int orc_dogleg_point(int n, const double* xu, const double* xn, double delta, double* out) {
+  VectorValues u, v;
+  u[0] = std::vector<double>(xu, xu + n);
+  v[0] = std::vector<double>(xn, xn + n);
+  const VectorValues d = dogleg_point(delta, u, v);
+  std::memcpy(out, d.at(0).data(), n * sizeof(double));
+  return 0;
+}
+// last step taken (LM / GN: the accepted or last tried delta; Dogleg: dx_d), in ordering order
+int orc_get_delta(void* h, double* out) {
+  auto* p = (Problem*)h;
+  int o = 0;
+  for (Key k : p->ordering) {
+    const auto& v = p->delta.at(k);
+    for (double x : v) out[o++] = x;
+  }
   return 0;
 }
 // state: error, lambda, iterations, totalInner, currentFactor

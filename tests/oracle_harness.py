@@ -60,6 +60,12 @@ def lib():
         for name in ("orc_lm_init", "orc_lm_iterate", "orc_lm_optimize", "orc_gn_optimize"):
             getattr(L, name).argtypes = [ct.c_void_p, ct.POINTER(orc_lm_params)]
         L.orc_gn_iterate.argtypes = [ct.c_void_p]
+        L.orc_dl_init.argtypes = [ct.c_void_p, ct.c_double]
+        L.orc_dl_iterate.argtypes = [ct.c_void_p]
+        L.orc_dl_optimize.argtypes = [ct.c_void_p, ct.POINTER(orc_lm_params)]
+        L.orc_get_delta.argtypes = [ct.c_void_p, _D]
+        L.orc_dl_points.argtypes = [ct.c_void_p, _D, _D]
+        L.orc_dogleg_point.argtypes = [ct.c_int, _D, _D, ct.c_double, _D]
         L.orc_lm_state.argtypes = [ct.c_void_p, _D]
         L.orc_lm_trace_len.argtypes = [ct.c_void_p]
         L.orc_lm_trace.argtypes = [ct.c_void_p, _D]
@@ -215,6 +221,26 @@ class OracleProblem:
     def gn_optimize(self, params):
         c = lm_params_c(params)
         return self.L.orc_gn_optimize(self.h, ct.byref(c))
+
+    def dl_points(self):
+        xu, xn = np.empty(self.ntot), np.empty(self.ntot)
+        assert self.L.orc_dl_points(self.h, dp(xu), dp(xn)) == 0
+        return xu, xn
+
+    def get_delta(self):
+        d = np.empty(self.ntot)
+        self.L.orc_get_delta(self.h, dp(d))
+        return d
+
+    def dl_init(self, delta_initial=1.0):
+        return self.L.orc_dl_init(self.h, float(delta_initial))
+
+    def dl_iterate(self):
+        return self.L.orc_dl_iterate(self.h)
+
+    def dl_optimize(self, params):
+        c = lm_params_c(params)
+        return self.L.orc_dl_optimize(self.h, ct.byref(c))
 
     def lm_state(self):
         s = np.empty(5)

@@ -431,3 +431,39 @@ def test_robust_huber_on_projection_factors():
         so = orc.lm_state()
         assert opt.getInnerIterations() == so["inner"]
         assert abs(opt.error() - so["error"]) <= 1e-6 * max(1e-12, abs(so["error"]))
+
+
+@pytest.mark.parametrize("which", ["bal", "pose2"])
+def test_dogleg_matches_oracle(which):
+    """DoglegOptimizer (gtsam/nonlinear/DoglegOptimizer.cpp:84-126): per-iteration error and trust radius, the dogleg step
+    and the defaultOptimize stopping point against the oracle."""
+    from gtsam_personal_amd import DoglegOptimizer, DoglegParams
+    if which == "bal":
+        graph, initial, _, ordering = make_bal(n_cam=40, n_pt=400, obs_per_point=5, seed=9)  # 361 x 361 HBM root + LDS leaves
+    else:
+        graph, initial = _pose2_graph()
+        ordering = oh.colamd(graph) if oh.have_ref() else Ordering.Natural(graph)
+    params = DoglegParams()
+    opt = DoglegOptimizer(graph, initial, ordering, params, device=0)
+    orc = oh.OracleProblem(graph, initial, ordering)
+    orc.dl_init(params.deltaInitial)
+    assert abs(opt.error() - orc.lm_state()["error"]) <= 1e-9 * max(1.0, opt.error())
+    for it in range(4):
+        opt.iterate()
+        assert orc.dl_iterate() == 0
+        so = orc.lm_state()
+        assert opt.iterations() == so["iterations"]
+        assert abs(opt.error() - so["error"]) <= 1e-6 * max(1e-12, abs(so["error"])) + 1e-12, it
+        assert abs(opt.getDelta() - so["lambda_"]) <= 1e-6 * so["lambda_"], it
+    opt.optimize()
+    assert orc.dl_optimize(params) == 0
+    so = orc.lm_state()
+    assert opt.iterations() == so["iterations"]
+    assert abs(opt.error() - so["error"]) <= 1e-6 * max(1e-12, abs(so["error"])) + 1e-12
+    vo, vg = orc.values(), opt.values()
+    for k in vo:
+        a, b = np.array(vo[k], dtype=float), np.array(vg.at(k), dtype=float)
+        if which == "pose2":  # theta = +pi and -pi are the same rotation
+            a = np.array([a[0], a[1], np.cos(a[2]), np.sin(a[2])])
+            b = np.array([b[0], b[1], np.cos(b[2]), np.sin(b[2])])
+        assert np.allclose(a, b, rtol=1e-6, atol=1e-7), k

@@ -361,3 +361,51 @@ def test_robust_m_estimators_known_answers():
         assert L.orc_robust(kind, k, e, oh.dp(out)) == 0
         assert abs(out[0] - w) < 1e-8, (kind, e, out[0], w)
         assert abs(out[1] - loss) < 1e-8, (kind, e, out[1], loss)
+
+
+def test_dogleg_points_against_dense_algebra():
+    """The oracle's Bayes-tree gradient / steepest-descent point / Newton point against dense algebra on the same linearization,
+    the way gtsam/linear/tests/testGaussianBayesTree.cpp (ComputeSteepestDescentPointBT) pins them:
+    g = -A^T b, x_u = -(g.g / g^T A^T A g) g, x_n = argmin |A x - b|; and ComputeDoglegPoint's three regions
+    (tests/testDoglegOptimizer.cpp: |x_d| = Delta inside the blend / steepest-descent regions, x_d = x_n beyond)."""
+    from gtsam_personal_amd.synthetic import make_bal
+    graph, initial, _, ordering = make_bal(n_cam=4, n_pt=12, obs_per_point=3, seed=2)
+    orc = oh.OracleProblem(graph, initial, ordering)
+    xu, xn = orc.dl_points()
+    n = orc.ntot
+    off = {k: orc.xoff[i] for i, k in enumerate(orc.keys)}
+    pos = {k: i for i, k in enumerate(orc.keys)}
+    # dense [A b] in ORDERING order of the columns
+    col0 = {}
+    o = 0
+    for k in ordering:
+        col0[k] = o
+        o += orc.xoff[pos[k] + 1] - orc.xoff[pos[k]]
+    rows = []
+    fk = graph.factor_keys_in_graph_order()
+    for gi in range(graph.size()):
+        J = orc.jacobian(gi)
+        row = np.zeros((J.shape[0], n + 1))
+        c = 0
+        for k in fk[gi]:
+            d = orc.xoff[pos[k] + 1] - orc.xoff[pos[k]]
+            row[:, col0[k]:col0[k] + d] = J[:, c:c + d]
+            c += d
+        row[:, n] = J[:, -1]
+        rows.append(row)
+    Ab = np.vstack(rows)
+    A, b = Ab[:, :n], Ab[:, n]
+    g = -A.T @ b
+    expect_u = -(g @ g) / (g @ (A.T @ (A @ g))) * g
+    expect_n = np.linalg.lstsq(A, b, rcond=None)[0]
+    assert np.allclose(xu, expect_u, rtol=1e-8, atol=1e-10)
+    assert np.allclose(xn, expect_n, rtol=1e-6, atol=1e-8)
+    L = oh.lib()
+    out = np.empty(n)
+    nu, nn = np.linalg.norm(xu), np.linalg.norm(xn)
+    assert nu < nn
+    for delta in (0.5 * nu, 0.5 * (nu + nn)):
+        L.orc_dogleg_point(n, oh.dp(xu), oh.dp(xn), delta, oh.dp(out))
+        assert abs(np.linalg.norm(out) - delta) < 1e-10 * max(1.0, delta)
+    L.orc_dogleg_point(n, oh.dp(xu), oh.dp(xn), 2.0 * nn, oh.dp(out))
+    assert np.array_equal(out, xn)
