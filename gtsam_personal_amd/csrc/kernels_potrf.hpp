@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void panel_trsm_kernel(double* __restrict__ A,
 // flags (zeroed by the host before the launch): [0] ticket, [4 + j] diag_ready[j], [8 + 4 i + j] tile_ready[i][j],
 // [PDF_TA0 + sj] number of finished 64x64 trailing-update tiles of column strip sj in the next panel's rows (fused step only).
 #define PDF_TA0 32
-#define PDF_FLAG_WORDS 256
+#define PDF_FLAG_WORDS 1024  // 992 column strips: fronts up to 63 488 columns take the fused path
 #define PDF_MAX_COLTILES (PDF_FLAG_WORDS - PDF_TA0)
 #define PDF_SPIN_LIMIT 2000000L  // a legitimate wait is < 1 ms; the bound (~1-2 s) only keeps a logic error from hanging the device
 #define PDF_LDS_DOUBLES (2 * 64 * DP_LDW)

@@ -33,3 +33,37 @@ def test_outer_panels_match_oracle(n_cam):
         rel = np.linalg.norm(a - b) / np.linalg.norm(b)
         assert rel < 1e-6, (lam, rel)
         assert abs(e1 - o1) <= 1e-6 * max(1.0, abs(o1))
+
+
+def test_launch_forms_agree_on_a_large_root(monkeypatch):
+    """Beyond the oracle's reach (600 cameras -> 5401 x 5401 root, 22 outer panels, 15 000 leaf fronts): the default path
+    (dataflow panels fused into the trailing-update launches) against the same arithmetic issued as separate launches
+    (LMGPU_NO_FUSE) and with the two-launch panel form (LMGPU_PANEL_2L) -- three different synchronisation structures, one
+    result."""
+    graph, initial, _, ordering = make_bal(n_cam=600, n_pt=15000, obs_per_point=8, seed=23)
+    params = LevenbergMarquardtParams()
+
+    def run(env):
+        for k in ("LMGPU_NO_FUSE", "LMGPU_PANEL_2L"):
+            monkeypatch.delenv(k, raising=False)
+        for k in env:
+            monkeypatch.setenv(k, "1")
+        opt = LevenbergMarquardtOptimizer(graph, initial, ordering, params, device=0)  # the switches are read at creation
+        e0 = opt.error()
+        trace = []
+        for _ in range(2):
+            opt.iterate()
+            trace.append((opt.error(), opt.lambda_(), opt.getInnerIterations()))
+        dk, d, _, _ = (opt.linearize(), opt.solve(1e-4))[1]
+        opt.close()
+        return e0, trace, d
+
+    base = run([])
+    assert base[1][-1][0] < 0.05 * base[0]
+    for env in (["LMGPU_NO_FUSE"], ["LMGPU_PANEL_2L"], ["LMGPU_NO_FUSE", "LMGPU_PANEL_2L"]):
+        other = run(env)
+        assert other[0] == base[0]
+        for a, b in zip(other[1], base[1]):
+            assert abs(a[0] - b[0]) <= 1e-9 * abs(b[0]) and a[1:] == b[1:], (env, a, b)
+        rel = np.linalg.norm(other[2] - base[2]) / np.linalg.norm(base[2])
+        assert rel < 1e-9, (env, rel)
