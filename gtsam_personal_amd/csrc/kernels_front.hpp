@@ -72,11 +72,11 @@ __global__ __launch_bounds__(256) void lds_front_kernel(const int32_t* __restric
                                                          const ChildRef* __restrict__ childs, const int32_t* __restrict__ cmap,
                                                          const int32_t* __restrict__ fxoff, double* __restrict__ pool, double lambda,
                                                          const double* __restrict__ dampw, int* __restrict__ status, int nmax, int srows,
-                                                         double* __restrict__ gcorner) {
+                                                         double* __restrict__ gcorner, int jcap) {
   extern __shared__ double S[];
   double* corner_g = S + (size_t)srows * nmax;  // GATHER: the (rhs, rhs) entry lives here
   double* Jb = corner_g + 8;
-  LFac* LF = (LFac*)(Jb + LDSF_JCAP);
+  LFac* LF = (LFac*)(Jb + jcap);  // jcap <= LDSF_JCAP doubles of staged Jacobians: the launch's largest front (fewer for small ones => more fronts per CU)
   int* meta = (int*)(LF + LDSF_MAXB);
   const FrontDesc F = fronts[list[blockIdx.x]];
   const int n = F.n, nf = F.nf, tid = threadIdx.x, nt = blockDim.x;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void lds_front_kernel(const int32_t* __restric
     __syncthreads();
     if (tid == 0) {
       int o = 0, b = 0;
-      while (b < cand && o + LF[b].sz <= LDSF_JCAP) {
+      while (b < cand && o + LF[b].sz <= jcap) {
         LF[b].off = o;
         o += LF[b].sz;
         b++;

@@ -76,6 +76,7 @@ struct LevelWork {
   int list_begin = 0, list_count = 0;
   int bin_begin[16] = {0};
   int bin_srows[16] = {0};  // rows of the front kept in LDS for the bin's launch
+  int bin_jcap[16] = {0};   // doubles of Jacobian staging per workgroup (largest front of the bin, 96 .. LDSF_JCAP)
   std::vector<int> hbm;  // HBM fronts of this level
   int small_begin = 0, small_count = 0;  // those with nf <= BSS_MAX_NF, in d_hbm_small: back-substituted in one launch per level
   // "medium" HBM fronts (one outer panel, no gather leaves, not replicated): eliminated with batched launches (kernels_batched.hpp)
@@ -498,18 +499,19 @@ int do_eliminate(lmgpu_handle* h, double lambda) {
       const int nmax = kBinN[b % 6], srows = L.bin_srows[b];
       // gather leaves keep only nf rows: one wave per front (barriers become free, ~2.5x more fronts resident per CU)
       const int threads = (b >= 6 || b % 6 == 0) ? 64 : (b % 6 == 1 ? 128 : 256);
-      const size_t lds = kLdsFrontExtra + 64 + (size_t)srows * nmax * sizeof(double);
+      const int jcap = L.bin_jcap[b];
+      const size_t lds = kLdsFrontExtra - (size_t)(LDSF_JCAP - jcap) * 8 + 64 + (size_t)srows * nmax * sizeof(double);
       const int kt = h->kt.begin(LMGPU_KT_LDS_FRONT, s);
       if (b < 6)
         hipLaunchKernelGGL(lds_front_kernel<false>, dim3(cnt), dim3(threads), lds, s,
                            (const int32_t*)(h->d_lists + L.list_begin + L.bin_begin[b]), (const FrontDesc*)h->d_fronts,
                            (const FrontFac*)h->d_ffac, (const FacDesc*)h->d_fd, (const ChildRef*)h->d_childs, (const int32_t*)h->d_cmap,
-                           (const int32_t*)h->d_fxoff, h->pool, lambda, (const double*)h->dampw, h->d_status, nmax, srows, h->d_gcorner);
+                           (const int32_t*)h->d_fxoff, h->pool, lambda, (const double*)h->dampw, h->d_status, nmax, srows, h->d_gcorner, jcap);
       else
         hipLaunchKernelGGL(lds_front_kernel<true>, dim3(cnt), dim3(threads), lds, s,
                            (const int32_t*)(h->d_lists + L.list_begin + L.bin_begin[b]), (const FrontDesc*)h->d_fronts,
                            (const FrontFac*)h->d_ffac, (const FacDesc*)h->d_fd, (const ChildRef*)h->d_childs, (const int32_t*)h->d_cmap,
-                           (const int32_t*)h->d_fxoff, h->pool, lambda, (const double*)h->dampw, h->d_status, nmax, srows, h->d_gcorner);
+                           (const int32_t*)h->d_fxoff, h->pool, lambda, (const double*)h->dampw, h->d_status, nmax, srows, h->d_gcorner, jcap);
       h->kt.end(kt, s);
     }
     if (L.med_count > 0) {  // medium fronts of this level: six launches for all of them
@@ -1656,6 +1658,13 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
         for (int fi : byLevelBin[l][b]) mx = std::max(mx, P.fronts[fi].nf);
         L.bin_srows[b] = mx;
       }
+      int jc = 96;
+      for (int fi : byLevelBin[l][b]) {
+        int tot = 0;
+        for (int32_t f : P.fronts[fi].factors) tot += fd[h->fac_local[f]].rows * (fd[h->fac_local[f]].d0 + fd[h->fac_local[f]].d1 + 1);
+        jc = std::max(jc, std::min(tot, LDSF_JCAP));
+      }
+      L.bin_jcap[b] = (jc + 7) & ~7;
       for (int fi : byLevelBin[l][b]) lists.push_back(fi);
       c += (int)byLevelBin[l][b].size();
     }
