@@ -117,19 +117,52 @@ __global__ __launch_bounds__(256) void lds_front_kernel(const int32_t* __restric
         b++;
       }
       meta[0] = b;  // >= 1: a single factor is at most 90 doubles
+      meta[1] = o;  // doubles staged in this batch
+      bool contig = true;  // the batch's Jacobians back to back in the pool (factors of one variable added together)?
+      for (int q = 1; q < b; q++) contig = contig && (LF[q].joff == LF[0].joff + LF[q].off);
+      meta[2] = contig ? 1 : 0;
     }
     __syncthreads();
     const int B = meta[0];
-    for (int b = wave; b < B; b += nw) {
-      const double* J = pool + LF[b].joff;
-      const int o = LF[b].off, sz = LF[b].sz;
-      for (int i = lane; i < sz; i += 64) Jb[o + i] = J[i];
+    if (meta[2]) {  // one flat copy: every load independent of the others
+      const double* J = pool + LF[0].joff;
+      const int tot = meta[1];
+      for (int i = tid; i < tot; i += nt) Jb[i] = J[i];
+    } else {
+      for (int b = wave; b < B; b += nw) {
+        const double* J = pool + LF[b].joff;
+        const int o = LF[b].off, sz = LF[b].sz;
+        for (int i = lane; i < sz; i += 64) Jb[o + i] = J[i];
+      }
     }
     __syncthreads();
     for (int b = 0; b < B; b++) {
       const LFac d = LF[b];
       const double* J = Jb + d.off;
       const int m = d.rows, nc = d.d0 + d.d1 + 1;
+      if (gather) {
+        // only the frontal rows are kept: pairs (p, q) with p a FRONTAL column of this factor and q any column (q frontal too:
+        // once, gq >= gp), all of them in one pass of the workgroup (BAL: 3 x 13); the (b, b) corner by one lane
+        const bool f0 = d.c0 < nf, f1 = d.d1 > 0 && d.c1 < nf;
+        const int nfc = (f0 ? d.d0 : 0) + (f1 ? d.d1 : 0);
+        for (int idx = tid; idx < nfc * nc; idx += nt) {
+          const int pf = idx / nc, q = idx - pf * nc;
+          const int p = (f0 && pf < d.d0) ? pf : (f0 ? pf : d.d0 + pf);  // f0: frontal columns start at 0; else they are var1's
+          const int gp = (p < d.d0) ? d.c0 + p : d.c1 + (p - d.d0);
+          const int gq = (q < d.d0) ? d.c0 + q : (q < d.d0 + d.d1 ? d.c1 + (q - d.d0) : n - 1);
+          if (gq < nf && gq < gp) continue;  // both frontal: counted from the other side
+          double v = 0;
+          for (int r = 0; r < m; r++) v += J[p * m + r] * J[q * m + r];
+          S[gp * n + gq] += v;
+        }
+        if (tid == 0) {
+          double v = 0;
+          for (int r = 0; r < m; r++) v += J[(nc - 1) * m + r] * J[(nc - 1) * m + r];
+          *corner += v;
+        }
+        __syncthreads();
+        continue;
+      }
       // thread (p = tid / 16 + k nt/16, q = p + tid % 16 + 16 l): every pair p <= q exactly once, no two threads on one entry
       for (int p = tid >> 4; p < nc; p += (nt >> 4)) {
         const int gp = (p < d.d0) ? d.c0 + p : (p < d.d0 + d.d1 ? d.c1 + (p - d.d0) : n - 1);
