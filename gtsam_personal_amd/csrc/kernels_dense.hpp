@@ -320,7 +320,7 @@ __global__ __launch_bounds__(64) void hbm_invert_diag_kernel(const double* __res
 }
 
 // R x = y, R = rows 0..nf-1 of the front (upper).  Workgroup b owns row block b:  it folds x_j (j > b) into its right-hand side
-// as the blocks are published, then x_b = inv(R_bb) rhs, publishes x_b and raises flag[b].  Hand-off: 8-byte agent-scope atomics for the payload and the flag on both sides
+// as the blocks are published, then x_b = inv(R_bb) rhs and publishes x_b.  Hand-off: 8-byte agent-scope atomics for the payload and the flag on both sides
 // (cdna_hip_programming.md Guideline 16, "8-B agent atomics both sides"), bounded spin.
 template <int NB>
 __global__ __launch_bounds__(256) void hbm_backsolve_dataflow_kernel(FrontDesc F, int64_t f_off, int ld, const int32_t* __restrict__ fxoff,
@@ -343,6 +343,12 @@ __global__ __launch_bounds__(256) void hbm_backsolve_dataflow_kernel(FrontDesc F
   if (tid == 0) ok = 1;
   __syncthreads();
   const double* arow = A + (size_t)(r0 + row) * ld;
+  double ibv[16];  // this thread's part of inv(R_bb): independent of x, so not on the hop-to-hop chain
+  {
+    const double* ib = inv + (size_t)b * NB * NB + row * NB + quarter * 16;
+#pragma unroll
+    for (int k = 0; k < 16; k++) ibv[k] = ib[k];
+  }
   for (int j = nblk - 1; j > b; j--) {
     const int c0 = j * NB, ncol = min(NB, F.nf - c0);
     // prefetch this thread's 16 entries of R[b rows, j cols] while the producer is still working
@@ -352,20 +358,27 @@ __global__ __launch_bounds__(256) void hbm_backsolve_dataflow_kernel(FrontDesc F
       const int c = quarter * 16 + k;
       rv[k] = (row < nb && c < ncol) ? arow[c0 + c] : 0.0;
     }
-    if (tid == 0) {
-      long spins = 0;
-      while (__hip_atomic_load(&flags[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > 2000000L) {
-          ok = 0;
-          break;
+    // the data is the flag: xbuf is preset to a sentinel bit pattern (all ones, a NaN no computation produces: the producer
+    // canonicalises its NaNs); wave 0 polls its 64 values until none is the sentinel -- one round trip per hop instead of two
+    if (tid < NB) {
+      double v = 0.0;
+      if (tid < ncol) {
+        long spins = 0;
+        for (;;) {
+          v = __hip_atomic_load(&xbuf[c0 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (__double_as_longlong(v) != -1LL) break;
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > 2000000L) {
+            ok = 0;
+            v = 0.0;
+            break;
+          }
         }
       }
+      xs[tid] = v;
     }
     __syncthreads();
     if (!ok) break;
-    if (tid < NB) xs[tid] = __hip_atomic_load(&xbuf[c0 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
     double s = 0;
 #pragma unroll
     for (int k = 0; k < 16; k++) s += rv[k] * xs[quarter * 16 + k];
@@ -378,24 +391,18 @@ __global__ __launch_bounds__(256) void hbm_backsolve_dataflow_kernel(FrontDesc F
     if (tid == 0) atomicMin(status, F.id);  // never expected: spin bound hit
     // still publish something so that waiters terminate
   }
-  // x_b = inv(R_bb) acc   (thread (row, quarter): 16 columns of the row)
-  const double* ib = inv + (size_t)b * NB * NB;
+  // x_b = inv(R_bb) acc   (thread (row, quarter): 16 columns of the row; the inverse was fetched before the first hop)
   double s = 0;
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
-    const int c = quarter * 16 + k;
-    s += ib[row * NB + c] * acc[c];
-  }
+  for (int k = 0; k < 16; k++) s += ibv[k] * acc[quarter * 16 + k];
   s += __shfl_xor(s, 1);
   s += __shfl_xor(s, 2);
   if (quarter == 0 && row < nb) {
-    __hip_atomic_store(&xbuf[r0 + row], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double pub = (s != s) ? __longlong_as_double(0x7ff8000000000000LL) : s;  // never the sentinel
+    __hip_atomic_store(&xbuf[r0 + row], pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     delta[fxoff[F.fx_begin + r0 + row]] = s;
     if (s != s) atomicMin(status, F.id);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) __hip_atomic_store(&flags[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace lmgpu

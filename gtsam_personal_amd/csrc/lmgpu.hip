@@ -772,6 +772,7 @@ int do_backsub(lmgpu_handle* h) {
       const int nblk = (F.nf + NB - 1) / NB;
       // inverse of the diagonal blocks (all in parallel), then ONE dataflow launch: workgroup b waits for x_j (j > b) flags
       HIPCHECK(hipMemsetAsync(h->bs_flags, 0, (nblk + 1) * sizeof(unsigned int), s));  // flags + ticket
+      HIPCHECK(hipMemsetAsync(h->bs_x, 0xff, (size_t)nblk * NB * sizeof(double), s));  // sentinel: "not published yet"
       hipLaunchKernelGGL((hbm_invert_diag_kernel<NB>), dim3(nblk), dim3(NB), 0, s, (const double*)(h->pool + off), ld, F.nf, h->bs_inv);
       hipLaunchKernelGGL((hbm_backsolve_dataflow_kernel<NB>), dim3(nblk), dim3(256), 0, s, F, off, ld, (const int32_t*)h->d_fxoff,
                          (const double*)h->pool, (const double*)h->bs_inv, (const double*)h->ywork, h->bs_x, h->bs_flags, h->delta,
