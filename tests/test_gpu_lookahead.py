@@ -67,3 +67,29 @@ def test_launch_forms_agree_on_a_large_root(monkeypatch):
             assert abs(a[0] - b[0]) <= 1e-9 * abs(b[0]) and a[1:] == b[1:], (env, a, b)
         rel = np.linalg.norm(other[2] - base[2]) / np.linalg.norm(base[2])
         assert rel < 1e-9, (env, rel)
+
+
+@pytest.mark.parametrize("n_cam", [16, 17, 21, 22, 28, 29, 35, 36, 42, 43, 50, 56, 57, 71, 72, 85, 86, 100])
+def test_root_sizes_across_block_boundaries(n_cam):
+    """Camera roots of 9 n_cam + 1 columns for n_cam chosen so that nf = 9 n_cam sweeps the residues mod 64 / 128 / 256 that
+    select the code paths of the dense front: medium (one-panel) batched path vs. multi-panel path, dataflow vs. two-launch
+    panels, 1-4 block columns, head-tile strips S < 4, one or two 128-tiles of trailing matrix, partial last blocks."""
+    graph, initial, _, ordering = make_bal(n_cam=n_cam, n_pt=12 * n_cam, obs_per_point=5, seed=100 + n_cam)
+    opt = LevenbergMarquardtOptimizer(graph, initial, ordering, LevenbergMarquardtParams(), device=0)
+    orc = oh.OracleProblem(graph, initial, ordering)
+    opt.linearize()
+    orc.linearize()
+    for lam in (1e-6, 1e-1):
+        dk, d, e0, e1 = opt.solve(lam)
+        rc, do, o0, o1 = orc.solve(lam)
+        assert rc == 0
+        a = np.concatenate([dk[k] for k in sorted(dk)])
+        b = np.concatenate([do[k] for k in sorted(do)])
+        rel = np.linalg.norm(a - b) / np.linalg.norm(b)
+        assert rel < 1e-6, (n_cam, lam, rel)
+        assert abs(e1 - o1) <= 1e-6 * max(1.0, abs(o1))
+    cl = orc.cliques()
+    keys, nfk, rsd, parent = cl[-1]
+    fk, R = opt.front(opt.num_fronts() - 1)
+    assert fk == keys
+    assert np.allclose(R, rsd, rtol=1e-6, atol=1e-7 * max(1.0, np.abs(rsd).max()))
