@@ -6,6 +6,8 @@
 // It is NOT compiled in this repository (GTSAM itself is not buildable here); it documents
 // exactly how the entry points of lmgpu.h bind.  Supported factor types are the ones of SURVEY section 8a; any other
 // factor makes the constructor throw, so a caller can fall back to the stock optimizer explicitly.
+// GaussNewtonOptimizer and DoglegOptimizer bind the same way: the same constructor body, and iterate() forwarding to
+// lmgpu_gn_iterate / lmgpu_dl_iterate (the trust radius of DoglegState travels in lmgpu_lm_state::lambda).
 #pragma once
 
 #include <gtsam/geometry/Cal3Bundler.h>
@@ -18,6 +20,7 @@
 
 #include <map>
 #include <stdexcept>
+#include <tuple>
 #include <vector>
 
 #include "lmgpu.h"
@@ -67,7 +70,7 @@ class GpuLevenbergMarquardtOptimizer : public LevenbergMarquardtOptimizer {
 
     // 2. factors, bucketed by (type, noise kind); graph index = position in the NonlinearFactorGraph
     struct B { std::vector<int32_t> gi, slots; std::vector<double> meas, noise; };
-    std::map<std::pair<int, int>, B> buckets;
+    std::map<std::tuple<int, int, int, double>, B> buckets;  // (factor type, noise kind, m-estimator, its constant)
     for (size_t i = 0; i < graph.size(); i++) {
       if (!graph[i]) continue;
       auto nm = std::dynamic_pointer_cast<NoiseModelFactor>(graph[i]);
@@ -75,10 +78,26 @@ class GpuLevenbergMarquardtOptimizer : public LevenbergMarquardtOptimizer {
       // noise: Unit / Diagonal (inverse sigmas) / Gaussian (R row-major)
       int kind = LMGPU_N_UNIT; std::vector<double> nz;
       auto model = nm->noiseModel();
+      // noiseModel::Robust: unwrap into (m-estimator id, constant) + the Gaussian model underneath (lmgpu_add_factor_bucket_robust);
+      // only the default Block reweighting scheme is bound
+      int rkind = LMGPU_ROBUST_NONE; double rk = 0.0;
+      if (auto rob = std::dynamic_pointer_cast<noiseModel::Robust>(model)) {
+        const auto est = rob->robust();
+        if (auto e1 = std::dynamic_pointer_cast<noiseModel::mEstimator::Huber>(est)) { rkind = LMGPU_ROBUST_HUBER; rk = e1->modelParameter(); }
+        else if (auto e2 = std::dynamic_pointer_cast<noiseModel::mEstimator::Cauchy>(est)) { rkind = LMGPU_ROBUST_CAUCHY; rk = e2->modelParameter(); }
+        else if (auto e3 = std::dynamic_pointer_cast<noiseModel::mEstimator::Tukey>(est)) { rkind = LMGPU_ROBUST_TUKEY; rk = e3->modelParameter(); }
+        else if (auto e4 = std::dynamic_pointer_cast<noiseModel::mEstimator::GemanMcClure>(est)) { rkind = LMGPU_ROBUST_GEMAN_MCCLURE; rk = e4->modelParameter(); }
+        else if (auto e5 = std::dynamic_pointer_cast<noiseModel::mEstimator::Welsch>(est)) { rkind = LMGPU_ROBUST_WELSCH; rk = e5->modelParameter(); }
+        else if (auto e6 = std::dynamic_pointer_cast<noiseModel::mEstimator::Fair>(est)) { rkind = LMGPU_ROBUST_FAIR; rk = e6->modelParameter(); }
+        else if (auto e7 = std::dynamic_pointer_cast<noiseModel::mEstimator::DCS>(est)) { rkind = LMGPU_ROBUST_DCS; rk = e7->modelParameter(); }
+        else if (auto e8 = std::dynamic_pointer_cast<noiseModel::mEstimator::L2WithDeadZone>(est)) { rkind = LMGPU_ROBUST_L2_WITH_DEAD_ZONE; rk = e8->modelParameter(); }
+        else throw std::invalid_argument("GpuLevenbergMarquardtOptimizer: m-estimator not bound");
+        model = rob->noise();
+      }
       if (model && !model->isUnit()) {
         if (auto d = std::dynamic_pointer_cast<noiseModel::Diagonal>(model)) { kind = LMGPU_N_DIAG; const Vector s = d->invsigmas(); nz.assign(s.data(), s.data() + s.size()); }
         else if (auto g = std::dynamic_pointer_cast<noiseModel::Gaussian>(model)) { kind = LMGPU_N_GAUSS; const Matrix R = g->R(); for (int r = 0; r < R.rows(); r++) for (int c = 0; c < R.cols(); c++) nz.push_back(R(r, c)); }
-        else throw std::invalid_argument("GpuLevenbergMarquardtOptimizer: unsupported noise model (robust / constrained)");
+        else throw std::invalid_argument("GpuLevenbergMarquardtOptimizer: unsupported noise model (constrained)");
       }
       int type; std::vector<double> m;
       if (auto f = std::dynamic_pointer_cast<SfmFactor>(graph[i])) {
@@ -93,15 +112,16 @@ class GpuLevenbergMarquardtOptimizer : public LevenbergMarquardtOptimizer {
         // PriorFactor<T>, GenericProjectionFactor<Pose3,Point3,Cal3_S2>: same pattern (measurement packing in lmgpu.h)
         throw std::invalid_argument("GpuLevenbergMarquardtOptimizer: factor type not bound in this sketch");
       }
-      B& b = buckets[{type, kind}];
+      B& b = buckets[std::make_tuple(type, kind, rkind, rk)];
       b.gi.push_back((int32_t)i);
       for (Key k : nm->keys()) b.slots.push_back(slot.at(k));
       b.meas.insert(b.meas.end(), m.begin(), m.end());
       b.noise.insert(b.noise.end(), nz.begin(), nz.end());
     }
     for (auto& kv : buckets)
-      if (lmgpu_add_factor_bucket(h_, kv.first.first, (int32_t)kv.second.gi.size(), kv.second.gi.data(), kv.second.slots.data(), kv.second.meas.data(),
-                                  kv.first.second, kv.second.noise.empty() ? nullptr : kv.second.noise.data()) != LMGPU_OK)
+      if (lmgpu_add_factor_bucket_robust(h_, std::get<0>(kv.first), (int32_t)kv.second.gi.size(), kv.second.gi.data(), kv.second.slots.data(),
+                                         kv.second.meas.data(), std::get<1>(kv.first), kv.second.noise.empty() ? nullptr : kv.second.noise.data(),
+                                         std::get<2>(kv.first), std::get<3>(kv.first)) != LMGPU_OK)
         throw std::runtime_error(lmgpu_last_error(h_));
     if (lmgpu_finalize_structure(h_) != LMGPU_OK) throw std::runtime_error(lmgpu_last_error(h_));
     uploadValues(initial);
