@@ -1211,7 +1211,12 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
   if (h->device >= 0) {
     HIPCHECK(hipSetDevice(h->device));
     HIPCHECK(hipStreamCreate(&h->stream));
-    HIPCHECK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+    // the chunk all-reduces gate the panels of the factorisation that runs beside them: highest dispatch priority
+    {
+      int prio_lo = 0, prio_hi = 0;
+      HIPCHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+      HIPCHECK(hipStreamCreateWithPriority(&h->comm_stream, hipStreamNonBlocking, prio_hi));
+    }
     {  // the assembly chunks are short and each gates a panel of the factorisation: highest dispatch priority
       int prio_lo = 0, prio_hi = 0;
       HIPCHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
