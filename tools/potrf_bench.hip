@@ -8,6 +8,9 @@
 #include <vector>
 
 #include "kernels_potrf.hpp"
+#ifndef POTRF_FN
+#define POTRF_FN potrf64_wave
+#endif
 
 using namespace lmgpu;
 
@@ -31,7 +34,7 @@ __global__ __launch_bounds__(64) void potrf_wave_kernel(const double* __restrict
       for (int h = g; h < 4; h++)
 #pragma unroll
         for (int r = 0; r < 4; r++) T[g][h][r] = __builtin_nontemporal_load(&A[(16 * g + kk + 4 * r) * 64 + 16 * h + cc]);
-    failed |= potrf64_wave(T);
+    failed |= POTRF_FN(T);
     asm volatile("" ::: "memory");
   }
 #pragma unroll
