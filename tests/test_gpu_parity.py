@@ -467,3 +467,40 @@ def test_dogleg_matches_oracle(which):
             a = np.array([a[0], a[1], np.cos(a[2]), np.sin(a[2])])
             b = np.array([b[0], b[1], np.cos(b[2]), np.sin(b[2])])
         assert np.allclose(a, b, rtol=1e-6, atol=1e-7), k
+
+
+def _huber_pose2_cases():
+    """tests/testNonlinearOptimizer.cpp:351-379 (Pose2OptimizationWithHuberNoOutlier) and :416-450 (Pose2OptimizationWithHuber):
+    (graph, initial, expected pose 1, tolerance) exactly as the reference builds them"""
+    from gtsam_personal_amd import NonlinearFactorGraph, Values, noiseModel
+    from gtsam_personal_amd.graph import mEstimator
+    iso1 = noiseModel.Isotropic.Sigma(3, 1.0)
+    cases = []
+    g, v = NonlinearFactorGraph(), Values()
+    g.add_PriorFactorPose2(0, [0.0, 0.0, 0.0], iso1)
+    g.add_BetweenFactorPose2(0, 1, [1.0, 1.1, np.pi / 4], noiseModel.Robust.Create(mEstimator.Huber.Create(2.0), iso1))
+    g.add_BetweenFactorPose2(0, 1, [1.0, 0.9, np.pi / 2], noiseModel.Robust.Create(mEstimator.Huber.Create(3.0), iso1))
+    v.insert_pose2(0, 0.0, 0.0, 0.0)
+    v.insert_pose2(1, 0.961187, 0.99965, 1.1781)
+    cases.append((g, v, np.array([0.961187, 0.99965, 1.1781]), 3e-2))
+    g, v = NonlinearFactorGraph(), Values()
+    g.add_PriorFactorPose2(0, [0.0, 0.0, 0.0], noiseModel.Isotropic.Sigma(3, 0.1))
+    for meas in ([0.0, 9.0, np.pi / 2], [0.0, 11.0, np.pi / 2], [0.0, 10.0, np.pi / 2], [0.0, 9.0, 0.0]):
+        g.add_BetweenFactorPose2(0, 1, meas, noiseModel.Robust.Create(mEstimator.Huber.Create(0.2), iso1))
+    v.insert_pose2(0, 0.0, 0.0, 0.0)
+    v.insert_pose2(1, 0.0, 10.0, np.pi / 4)
+    cases.append((g, v, np.array([0.0, 10.0, 1.45212]), 1e-1))
+    return cases
+
+
+@pytest.mark.parametrize("method", ["gn", "lm", "dl"])
+def test_huber_pose2_known_answers_on_gpu(method):
+    """tests/testNonlinearOptimizer.cpp:351-379, :416-450: the reference's expected optima, reached by the GPU optimizers"""
+    from gtsam_personal_amd import DoglegOptimizer, GaussNewtonOptimizer
+    for graph, initial, expect1, tol in _huber_pose2_cases():
+        ordering = Ordering.Natural(graph)
+        cls = {"gn": GaussNewtonOptimizer, "lm": LevenbergMarquardtOptimizer, "dl": DoglegOptimizer}[method]
+        opt = cls(graph, initial, ordering, device=0)
+        vals = opt.optimize()
+        assert np.abs(vals.at(0)).max() <= tol, (method, vals.at(0))
+        assert np.abs(vals.at(1) - expect1).max() <= tol, (method, vals.at(1), expect1)

@@ -409,3 +409,49 @@ def test_dogleg_points_against_dense_algebra():
         assert abs(np.linalg.norm(out) - delta) < 1e-10 * max(1.0, delta)
     L.orc_dogleg_point(n, oh.dp(xu), oh.dp(xn), 2.0 * nn, oh.dp(out))
     assert np.array_equal(out, xn)
+
+
+def _huber_pose2_cases():
+    """tests/testNonlinearOptimizer.cpp:351-379 (Pose2OptimizationWithHuberNoOutlier) and :416-450 (Pose2OptimizationWithHuber):
+    (graph, initial, expected pose 1, tolerance) exactly as the reference builds them"""
+    from gtsam_personal_amd import NonlinearFactorGraph, Values, noiseModel
+    from gtsam_personal_amd.graph import mEstimator
+    iso1 = noiseModel.Isotropic.Sigma(3, 1.0)
+    cases = []
+    g, v = NonlinearFactorGraph(), Values()
+    g.add_PriorFactorPose2(0, [0.0, 0.0, 0.0], iso1)
+    g.add_BetweenFactorPose2(0, 1, [1.0, 1.1, np.pi / 4], noiseModel.Robust.Create(mEstimator.Huber.Create(2.0), iso1))
+    g.add_BetweenFactorPose2(0, 1, [1.0, 0.9, np.pi / 2], noiseModel.Robust.Create(mEstimator.Huber.Create(3.0), iso1))
+    v.insert_pose2(0, 0.0, 0.0, 0.0)
+    v.insert_pose2(1, 0.961187, 0.99965, 1.1781)
+    cases.append((g, v, np.array([0.961187, 0.99965, 1.1781]), 3e-2))
+    g, v = NonlinearFactorGraph(), Values()
+    g.add_PriorFactorPose2(0, [0.0, 0.0, 0.0], noiseModel.Isotropic.Sigma(3, 0.1))
+    for meas in ([0.0, 9.0, np.pi / 2], [0.0, 11.0, np.pi / 2], [0.0, 10.0, np.pi / 2], [0.0, 9.0, 0.0]):
+        g.add_BetweenFactorPose2(0, 1, meas, noiseModel.Robust.Create(mEstimator.Huber.Create(0.2), iso1))
+    v.insert_pose2(0, 0.0, 0.0, 0.0)
+    v.insert_pose2(1, 0.0, 10.0, np.pi / 4)
+    cases.append((g, v, np.array([0.0, 10.0, 1.45212]), 1e-1))
+    return cases
+
+
+def test_huber_pose2_known_answers_gn_lm_dogleg():
+    """the reference's own expected optima for Gauss-Newton, Levenberg-Marquardt and Dogleg with Huber-robustified Pose2 factors"""
+    from gtsam_personal_amd import LevenbergMarquardtParams, Ordering
+    for graph, initial, expect1, tol in _huber_pose2_cases():
+        ordering = Ordering.Natural(graph)
+        for method in ("gn", "lm", "dl"):
+            orc = oh.OracleProblem(graph, initial, ordering)
+            params = LevenbergMarquardtParams()
+            if method == "gn":
+                orc.lm_init(params)
+                assert orc.gn_optimize(params) == 0
+            elif method == "lm":
+                orc.lm_init(params)
+                orc.lm_optimize(params)
+            else:
+                orc.dl_init(1.0)
+                assert orc.dl_optimize(params) == 0
+            vals = orc.values()
+            assert np.abs(np.array(vals[0])).max() <= tol, (method, vals[0])
+            assert np.abs(np.array(vals[1]) - expect1).max() <= tol, (method, vals[1], expect1)
