@@ -119,20 +119,34 @@ def bal_graph(db: SfmData, noise=None, camera_key=lambda i: i, point_key=P):
 
 # ---------------------------------------------------------------- 2D: g2o / TORO
 def _noise2d(v, smart, fmt):
+    """createNoiseModel, gtsam/slam/dataset.cpp:216-300: the six numbers of an edge line as information (g2o, toro) or covariance
+    (graph, cov) matrix in the G2O/COV or TORO/GRAPH ordering; "auto" guesses GRAPH vs COV from the zero pattern (:219-232)."""
     v = [float(x) for x in v]
-    if fmt == "g2o":
+    if fmt == "auto":
+        if v[0] != 0.0 and v[1] == 0.0 and v[2] != 0.0 and v[3] != 0.0 and v[4] == 0.0 and v[5] == 0.0:
+            fmt = "graph"
+        elif v[0] != 0.0 and v[1] == 0.0 and v[2] == 0.0 and v[3] != 0.0 and v[4] == 0.0 and v[5] != 0.0:
+            fmt = "cov"
+        else:
+            raise ValueError("load2D: unrecognized covariance matrix format in dataset file. Please specify the noise format.")
+    if fmt in ("g2o", "cov"):
         if v[0] == 0.0 or v[3] == 0.0 or v[5] == 0.0:
             raise RuntimeError("load2D::readNoiseModel looks like this is not G2O matrix order")
         M = np.array([[v[0], v[1], v[2]], [v[1], v[3], v[4]], [v[2], v[4], v[5]]])
-        return noiseModel.Gaussian.Information(M, smart)
-    if fmt == "toro":
+    elif fmt in ("toro", "graph"):
+        if v[0] == 0.0 or v[2] == 0.0 or v[3] == 0.0:
+            raise ValueError("load2D::readNoiseModel looks like this is not TORO matrix order")
         M = np.array([[v[0], v[1], v[4]], [v[1], v[2], v[5]], [v[4], v[5], v[3]]])
+    else:
+        raise ValueError(fmt)
+    if fmt in ("g2o", "toro"):
         return noiseModel.Gaussian.Information(M, smart)
-    raise ValueError(fmt)
+    return noiseModel.Gaussian.Covariance(M, smart)
 
 
-def load2D(filename, noise_format="g2o", smart=True):
-    """(graph, initial) with Pose2 vertices keyed by their integer id."""
+def load2D(filename, noise_format="auto", smart=True):
+    """(graph, initial) with Pose2 vertices keyed by their integer id (gtsam/slam/dataset.cpp:505-569; noise_format as the reference's
+    NoiseFormat: "auto" (default), "g2o", "toro", "graph", "cov"; readG2o passes "g2o")."""
     graph, initial = NonlinearFactorGraph(), Values()
     lines = [ln.split() for ln in open(filename) if ln.strip()]
     for t in lines:

@@ -8,7 +8,7 @@ REF = "/root/reference/examples/Data"
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 # verbatim inputs (sphere2500 / city10000 in full: configs C3 / C1 at the reference's own size)
-for name in ("dubrovnik-3-7-pre.txt", "pose3example.txt", "noisyToyGraph.txt", "sphere2500.txt", "city10000.g2o"):
+for name in ("dubrovnik-3-7-pre.txt", "pose3example.txt", "noisyToyGraph.txt", "sphere2500.txt", "city10000.g2o", "w100.graph", "pose2example.txt"):
     shutil.copy(os.path.join(REF, name), os.path.join(HERE, name))
 
 # first 300 poses of sphere2500 (EDGE3 lines whose two ids are < 300)

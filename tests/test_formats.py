@@ -4,7 +4,7 @@ import os
 
 import numpy as np
 
-from gtsam_personal_amd.datasets import SfmData, load2D, load3D, writeBAL, writeG2o
+from gtsam_personal_amd.datasets import SfmData, load2D, load3D, readG2o, writeBAL, writeG2o
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -25,10 +25,10 @@ def _same_graph(g1, v1, g2, v2, tol):
 
 
 def test_write_g2o_2d_round_trip(tmp_path):
-    g, v = load2D(os.path.join(GOLD, "noisyToyGraph.txt"))
+    g, v = readG2o(os.path.join(GOLD, "noisyToyGraph.txt"))
     out = str(tmp_path / "toy.g2o")
     writeG2o(g, v, out)
-    g2, v2 = load2D(out)
+    g2, v2 = readG2o(out)
     _same_graph(g, v, g2, v2, 1e-5)  # the writer prints 6 significant digits like the reference's ostream default
     first = open(out).readline().split()
     assert first[0] == "VERTEX_SE2"
@@ -57,3 +57,64 @@ def test_write_bal_round_trip(tmp_path):
         assert np.allclose(a["p"], b["p"], rtol=1e-6, atol=1e-6)
         assert [m[0] for m in a["measurements"]] == [m[0] for m in b["measurements"]]
         assert np.allclose([m[1] for m in a["measurements"]], [m[1] for m in b["measurements"]], rtol=1e-6, atol=1e-4)
+
+
+def _quat_to_R(w, x, y, z):
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def test_load2d_toro_known_answers():
+    """gtsam/slam/tests/testDataset.cpp:91-103 (w100.graph): 300 factors, 100 poses, first factor
+    BetweenFactor<Pose2>(1, 0, Pose2(-0.99879, 0.0417574, -0.00818381), Unit(3))"""
+    from gtsam_personal_amd.graph import N_UNIT
+    g, v = load2D(os.path.join(GOLD, "w100.graph"))  # NoiseFormatAUTO -> GRAPH (covariance in TORO order), smart -> Unit
+    assert g.size() == 300 and len(v.keys()) == 100
+    (ftype, kind, gi, keys, meas, noise, models), = g.buckets()
+    i0 = int(np.where(gi == 0)[0][0])
+    assert keys[i0].tolist() == [1, 0]
+    assert np.allclose(meas[i0], [-0.99879, 0.0417574, -0.00818381], atol=1e-9)
+    assert models[i0].kind == N_UNIT
+
+
+def test_read_g2o_2d_known_answers():
+    """gtsam/slam/tests/testDataset.cpp:315-337 (pose2example.txt): Diagonal::Precisions(44.721360, 44.721360, 30.901699) and
+    the eleven expected poses"""
+    g, v = readG2o(os.path.join(GOLD, "pose2example.txt"))
+    expected = [(0.0, 0.0, 0.0), (1.030390, 0.011350, -0.081596), (2.036137, -0.129733, -0.301887), (3.015097, -0.442395, -0.345514),
+                (3.343949, 0.506678, 1.214715), (3.684491, 1.464049, 1.183785), (4.064626, 2.414783, 1.176333), (4.429778, 3.300180, 1.259169),
+                (4.128877, 2.321481, -1.825391), (3.884653, 1.327509, -1.953016), (3.531067, 0.388263, -2.148934)]
+    assert len(v.keys()) == 11
+    for i, e in enumerate(expected):
+        assert np.allclose(v.at(i), e, atol=1e-5)
+    for b in g.buckets():
+        for m in b[6]:
+            assert np.allclose(m.invsigmas() ** 2, [44.721360, 44.721360, 30.901699], rtol=1e-6)
+
+
+def test_read_g2o_3d_known_answers():
+    """gtsam/slam/tests/testDataset.cpp:147-203 (pose3example.txt): six relative poses and five poses as (w, x, y, z) quaternion +
+    translation, noise Isotropic::Precision(6, 10000), edges (0,1) (1,2) (2,3) (3,4) (1,4) (3,0)"""
+    g, v = load3D(os.path.join(GOLD, "pose3example.txt"))
+    rel = [((0.854230, 0.190253, 0.283162, -0.392318), (1.001367, 0.015390, 0.004948)),
+           ((0.105373, 0.311512, 0.656877, -0.678505), (0.523923, 0.776654, 0.326659)),
+           ((0.568551, 0.595795, -0.561677, 0.079353), (0.910927, 0.055169, -0.411761)),
+           ((0.542221, -0.592077, 0.303380, -0.513226), (0.775288, 0.228798, -0.596923)),
+           ((0.327419, -0.125250, -0.534379, 0.769122), (-0.577841, 0.628016, -0.543592)),
+           ((0.083672, 0.104639, 0.627755, 0.766795), (-0.623267, 0.086928, 0.773222))]
+    poses = [((1.0, 0.0, 0.0, 0.0), (0, 0, 0)), ((0.854230, 0.190253, 0.283162, -0.392318), (1.001367, 0.015390, 0.004948)),
+             ((0.421446, -0.351729, -0.597838, 0.584174), (1.993500, 0.023275, 0.003793)),
+             ((0.067024, 0.331798, -0.200659, 0.919323), (2.004291, 1.024305, 0.018047)),
+             ((0.765488, -0.035697, -0.462490, 0.445933), (0.999908, 1.055073, 0.020212))]
+    edges = [(0, 1), (1, 2), (2, 3), (3, 4), (1, 4), (3, 0)]
+    (ftype, kind, gi, keys, meas, noise, models), = g.buckets()
+    for i, ((q, t), e) in enumerate(zip(rel, edges)):
+        k = int(np.where(gi == i)[0][0])
+        assert tuple(keys[k].tolist()) == e
+        assert np.allclose(meas[k][:9].reshape(3, 3), _quat_to_R(*q), atol=2e-5)
+        assert np.allclose(meas[k][9:12], t, atol=1e-5)
+        assert np.allclose(models[k].invsigmas() ** 2, 10000.0, rtol=1e-6)
+    for j, (q, t) in enumerate(poses):
+        assert np.allclose(v.at(j)[:9].reshape(3, 3), _quat_to_R(*q), atol=2e-5)
+        assert np.allclose(v.at(j)[9:12], t, atol=1e-5)

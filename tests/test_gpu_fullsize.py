@@ -10,7 +10,7 @@ import pytest
 
 import oracle_harness as oh
 from gtsam_personal_amd import LevenbergMarquardtOptimizer, LevenbergMarquardtParams, noiseModel
-from gtsam_personal_amd.datasets import chain_initial_pose3, load2D, load3D
+from gtsam_personal_amd.datasets import chain_initial_pose3, load2D, load3D, readG2o
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -73,7 +73,7 @@ def test_sphere2500_full(which):
 def test_city10000_full(which):
     if not oh.have_ref():
         pytest.skip("oracle/_ref not present")
-    graph, initial = load2D(os.path.join(GOLD, "city10000.g2o"))
+    graph, initial = readG2o(os.path.join(GOLD, "city10000.g2o"))
     graph.add_PriorFactorPose2(0, initial.at(0), noiseModel.Diagonal.Variances([1e-6, 1e-6, 1e-8]))  # Pose2SLAMExample_g2o.cpp:60-66
     ordering = oh.colamd(graph) if which == "colamd" else oh.metis(graph)
     _compare(graph, initial, ordering, 1e-5, 2, range(0, graph.size(), 211))

@@ -9,7 +9,7 @@ import pytest
 
 import oracle_harness as oh
 from gtsam_personal_amd import (LevenbergMarquardtOptimizer, LevenbergMarquardtParams, NonlinearFactorGraph, Ordering, Values, _lib, noiseModel)
-from gtsam_personal_amd.datasets import SfmData, bal_graph, chain_initial_pose3, load2D, load3D
+from gtsam_personal_amd.datasets import SfmData, bal_graph, chain_initial_pose3, load2D, load3D, readG2o
 from gtsam_personal_amd.synthetic import make_bal
 
 pytestmark = pytest.mark.gpu
@@ -329,7 +329,7 @@ def test_gauss_newton_matches_oracle():
     """GaussNewtonOptimizer (gtsam/nonlinear/GaussNewtonOptimizer.cpp:44-66; examples/Pose2SLAMExample_g2o.cpp:70-80 runs the
     Pose2 g2o graphs with it): per-iteration error and the defaultOptimize stopping point against the oracle."""
     from gtsam_personal_amd import GaussNewtonOptimizer, GaussNewtonParams
-    graph, initial = load2D(os.path.join(GOLD, "city10000_head.g2o"))
+    graph, initial = readG2o(os.path.join(GOLD, "city10000_head.g2o"))
     graph.add_PriorFactorPose2(0, initial.at(0), noiseModel.Diagonal.Variances([1e-6, 1e-6, 1e-8]))
     ordering = oh.colamd(graph) if oh.have_ref() else Ordering.Natural(graph)
     params = GaussNewtonParams()

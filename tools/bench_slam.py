@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_harness as oh  # noqa: E402
 from gtsam_personal_amd import LevenbergMarquardtOptimizer, LevenbergMarquardtParams, noiseModel  # noqa: E402
-from gtsam_personal_amd.datasets import chain_initial_pose3, load2D, load3D  # noqa: E402
+from gtsam_personal_amd.datasets import chain_initial_pose3, load2D, load3D, readG2o  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 
@@ -60,7 +60,7 @@ init = chain_initial_pose3(g)
 g.add_PriorFactorPose3(0, np.eye(3), np.zeros(3), noiseModel.Diagonal.Variances([1e-6, 1e-6, 1e-6, 1e-4, 1e-4, 1e-4]))
 run("sphere2500 / METIS", g, init, oh.metis(g))
 run("sphere2500 / COLAMD", g, init, oh.colamd(g))
-g, init = load2D(os.path.join(GOLD, "city10000.g2o"))
+g, init = readG2o(os.path.join(GOLD, "city10000.g2o"))
 g.add_PriorFactorPose2(0, init.at(0), noiseModel.Diagonal.Variances([1e-6, 1e-6, 1e-8]))
 run("city10000 / METIS", g, init, oh.metis(g))
 run("city10000 / COLAMD", g, init, oh.colamd(g))
