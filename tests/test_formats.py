@@ -118,3 +118,17 @@ def test_read_g2o_3d_known_answers():
     for j, (q, t) in enumerate(poses):
         assert np.allclose(v.at(j)[:9].reshape(3, 3), _quat_to_R(*q), atol=2e-5)
         assert np.allclose(v.at(j)[9:12], t, atol=1e-5)
+
+
+def test_read_bal_dubrovnik_known_answers():
+    """gtsam/sfm/tests/testSfmData.cpp:66-83: 3 cameras, 7 tracks, track 0 has 3 measurements, the first by camera 0, and camera 0
+    projects track 0's point to within 12 px of that measurement"""
+    from gtsam_personal_amd.synthetic import project_bundler
+    db = SfmData.FromBalFile(os.path.join(GOLD, "dubrovnik-3-7-pre.txt"))
+    assert db.numberCameras() == 3 and db.numberTracks() == 7
+    tr = db.tracks[0]
+    assert len(tr["measurements"]) == 3 and tr["measurements"][0][0] == 0
+    R, t, f, k1, k2 = db.cameras[0]
+    z, depth = project_bundler(np.asarray(R)[None], np.asarray(t)[None], np.array([f]), np.array([k1]), np.array([k2]), np.asarray(tr["p"])[None])
+    assert depth[0] > 0
+    assert np.abs(z[0] - np.array(tr["measurements"][0][1])).max() < 12
