@@ -455,3 +455,16 @@ def test_huber_pose2_known_answers_gn_lm_dogleg():
             vals = orc.values()
             assert np.abs(np.array(vals[0])).max() <= tol, (method, vals[0])
             assert np.abs(np.array(vals[1]) - expect1).max() <= tol, (method, vals[1], expect1)
+
+
+def test_dogleg_blend_edge_cases():
+    """tests/testDoglegOptimizer.cpp:76-91 (issue #1861): a trust radius equal to |newton step| gives the Newton step, equal to
+    |gradient step| gives the gradient step"""
+    L = oh.lib()
+    n = np.array([0.3233546123, -0.2133456123, 0.3664345632])
+    u = np.array([0.0023456342, -0.04535687, 0.087345661212])
+    out = np.empty(3)
+    L.orc_dogleg_point(3, oh.dp(u), oh.dp(n), float(np.linalg.norm(n)), oh.dp(out))
+    assert np.allclose(out, n, rtol=0, atol=1e-9)
+    L.orc_dogleg_point(3, oh.dp(u), oh.dp(n), float(np.linalg.norm(u)), oh.dp(out))
+    assert np.allclose(out, u, rtol=0, atol=1e-9)
