@@ -468,3 +468,34 @@ def test_dogleg_blend_edge_cases():
     assert np.allclose(out, n, rtol=0, atol=1e-9)
     L.orc_dogleg_point(3, oh.dp(u), oh.dp(n), float(np.linalg.norm(u)), oh.dp(out))
     assert np.allclose(out, u, rtol=0, atol=1e-9)
+
+
+def test_junction_tree_of_the_smoother_known_structure():
+    """tests/testGaussianJunctionTreeB.cpp:60-112 (constructor2): the 7-step smoother (prior on x1; for t = 2..7 odometry
+    (x_{t-1}, x_t) then a measurement on x_t, tests/smallExample.h:431-461) with the nested-dissection ordering
+    x1 x3 x5 x7 x2 x6 x4 gives the cliques  [x3 x2 x4] <- [x1 : x2],  [x5 x6 : x4] <- [x7 : x6]  with the frontal keys in exactly
+    that order and 5 / 2 / 4 / 2 factors.  (Pose2 variables instead of Point2: the structure only depends on the topology.)"""
+    from gtsam_personal_amd import NonlinearFactorGraph, Values, noiseModel
+    from gtsam_personal_amd.graph import X
+    g, v = NonlinearFactorGraph(), Values()
+    m = noiseModel.Isotropic.Sigma(3, 1.0)
+    g.add_PriorFactorPose2(X(1), [1.0, 0.0, 0.0], m)
+    v.insert_pose2(X(1), 1.0, 0.0, 0.0)
+    for t in range(2, 8):
+        g.add_BetweenFactorPose2(X(t - 1), X(t), [1.0, 0.0, 0.0], m)
+        g.add_PriorFactorPose2(X(t), [float(t), 0.0, 0.0], m)
+        v.insert_pose2(X(t), float(t), 0.0, 0.0)
+    ordering = [X(1), X(3), X(5), X(7), X(2), X(6), X(4)]
+    orc = oh.OracleProblem(g, v, ordering)
+    orc.linearize()
+    rc, _, _, _ = orc.solve(1e-9)
+    assert rc == 0
+    cl = orc.cliques()
+    by_front = {tuple(keys[:nf]): (keys, nf, parent) for keys, nf, rsd, parent in cl}
+    assert set(by_front) == {(X(3), X(2), X(4)), (X(1),), (X(5), X(6)), (X(7),)}
+    fronts = [tuple(keys[:nf]) for keys, nf, rsd, parent in cl]
+    root = fronts.index((X(3), X(2), X(4)))
+    assert by_front[(X(3), X(2), X(4))][2] < 0 and len(by_front[(X(3), X(2), X(4))][0]) == 3
+    assert by_front[(X(1),)][0] == [X(1), X(2)] and by_front[(X(1),)][2] == root
+    assert by_front[(X(5), X(6))][0] == [X(5), X(6), X(4)] and by_front[(X(5), X(6))][2] == root
+    assert by_front[(X(7),)][0] == [X(7), X(6)] and by_front[(X(7),)][2] == fronts.index((X(5), X(6)))
