@@ -499,3 +499,28 @@ def test_junction_tree_of_the_smoother_known_structure():
     assert by_front[(X(1),)][0] == [X(1), X(2)] and by_front[(X(1),)][2] == root
     assert by_front[(X(5), X(6))][0] == [X(5), X(6), X(4)] and by_front[(X(5), X(6))][2] == root
     assert by_front[(X(7),)][0] == [X(7), X(6)] and by_front[(X(7),)][2] == fronts.index((X(5), X(6)))
+
+
+def test_small_example_multifrontal_known_delta():
+    """tests/testGaussianJunctionTreeB.cpp:128-140 (optimizeMultiFrontal2) with the explicit linear graph of
+    tests/smallExample.h:270-289 (createGaussianFactorGraph) and its solution createCorrectDelta (:248-256):
+    l1 = (-0.1, 0.1), x1 = (-0.1, -0.1), x2 = (0.1, -0.2), for every elimination ordering"""
+    import itertools
+    from gtsam_personal_amd.graph import L as Lm, X
+    I2 = np.eye(2)
+    x1, x2, l1 = X(1), X(2), Lm(1)
+    jac = [([x1], [2], 10 * I2, -1.0 * np.ones(2), None),
+           ([x1, x2], [2, 2], np.hstack([-10 * I2, 10 * I2]), np.array([2.0, -1.0]), None),
+           ([x1, l1], [2, 2], np.hstack([-5 * I2, 5 * I2]), np.array([0.0, 1.0]), None),
+           ([x2, l1], [2, 2], np.hstack([-5 * I2, 5 * I2]), np.array([-1.0, 1.5]), None)]
+    expect = {l1: (-0.1, 0.1), x1: (-0.1, -0.1), x2: (0.1, -0.2)}
+    lib = oh.lib()
+    for order in itertools.permutations([x1, x2, l1]):
+        h = _linear(jac)
+        o = np.array(order, dtype=np.uint64)
+        x = np.zeros(6)
+        assert lib.orc_linear_optimize(h, 3, oh.up(o), oh.dp(x)) == 0
+        got = dict(zip(sorted([x1, x2, l1]), x.reshape(3, 2)))  # orc_linear_optimize returns the variables in key order
+        for k, e in expect.items():
+            assert np.allclose(got[k], e, atol=1e-9), (order, k, got[k])
+        lib.orc_linear_destroy(h)
