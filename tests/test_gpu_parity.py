@@ -504,3 +504,26 @@ def test_huber_pose2_known_answers_on_gpu(method):
         vals = opt.optimize()
         assert np.abs(vals.at(0)).max() <= tol, (method, vals.at(0))
         assert np.abs(vals.at(1) - expect1).max() <= tol, (method, vals.at(1), expect1)
+
+
+def _pose2_between_case():
+    """gtsam/geometry/tests/testPose2.cpp:525-563 (between) and :67-76 (retract, default chart)"""
+    from gtsam_personal_amd import NonlinearFactorGraph, Values, noiseModel
+    g, v = NonlinearFactorGraph(), Values()
+    v.insert_pose2(1, 1.0, 2.0, np.pi / 2)    # gT1: robot at (1,2) looking towards y
+    v.insert_pose2(2, -1.0, 4.0, np.pi)       # gT2: robot at (-1,4) looking at negative x
+    g.add_BetweenFactorPose2(1, 2, [0.0, 0.0, 0.0], noiseModel.Unit.Create(3))   # error = (x, y, theta) of gT1.between(gT2)
+    H1 = np.array([[0.0, -1.0, -2.0], [1.0, 0.0, -2.0], [0.0, 0.0, -1.0]])
+    return g, v, np.array([2.0, 2.0, np.pi / 2]), H1, np.eye(3)
+
+
+def test_pose2_between_known_answers_on_gpu():
+    """the reference's expected between pose and Jacobians (testPose2.cpp:525-563) out of the GPU linearize, and its retract (:67-76)"""
+    g, v, e_exp, H1, H2 = _pose2_between_case()
+    opt = LevenbergMarquardtOptimizer(g, v, Ordering.Natural(g), device=0)
+    opt.linearize()
+    J = opt.jacobian(0)
+    assert np.allclose(J[:, 0:3], H1, atol=1e-12) and np.allclose(J[:, 3:6], H2, atol=1e-12)
+    assert np.allclose(-J[:, 6], e_exp, atol=1e-12)
+    opt.retract(np.array([0.01, -0.015, 0.99, 0.0, 0.0, 0.0]))  # packed in ordering order (keys 1, 2)
+    assert np.allclose(opt.values().at(1), [1.015, 2.01, np.pi / 2 + 0.99], atol=1e-5)

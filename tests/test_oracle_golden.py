@@ -524,3 +524,26 @@ def test_small_example_multifrontal_known_delta():
         for k, e in expect.items():
             assert np.allclose(got[k], e, atol=1e-9), (order, k, got[k])
         lib.orc_linear_destroy(h)
+
+
+def _pose2_between_case():
+    """gtsam/geometry/tests/testPose2.cpp:525-563 (between) and :67-76 (retract, default chart)"""
+    from gtsam_personal_amd import NonlinearFactorGraph, Values, noiseModel
+    g, v = NonlinearFactorGraph(), Values()
+    v.insert_pose2(1, 1.0, 2.0, np.pi / 2)    # gT1: robot at (1,2) looking towards y
+    v.insert_pose2(2, -1.0, 4.0, np.pi)       # gT2: robot at (-1,4) looking at negative x
+    g.add_BetweenFactorPose2(1, 2, [0.0, 0.0, 0.0], noiseModel.Unit.Create(3))   # error = (x, y, theta) of gT1.between(gT2)
+    H1 = np.array([[0.0, -1.0, -2.0], [1.0, 0.0, -2.0], [0.0, 0.0, -1.0]])
+    return g, v, np.array([2.0, 2.0, np.pi / 2]), H1, np.eye(3)
+
+
+def test_pose2_between_and_retract_known_answers():
+    from gtsam_personal_amd import Ordering
+    g, v, e_exp, H1, H2 = _pose2_between_case()
+    orc = oh.OracleProblem(g, v, Ordering.Natural(g))
+    orc.linearize()
+    J = orc.jacobian(0)                      # [H1 H2 b], unit noise, b = -e
+    assert np.allclose(J[:, 0:3], H1, atol=1e-12) and np.allclose(J[:, 3:6], H2, atol=1e-12)
+    assert np.allclose(-J[:, 6], e_exp, atol=1e-12)
+    orc.retract({1: np.array([0.01, -0.015, 0.99]), 2: np.zeros(3)})
+    assert np.allclose(orc.values()[1], [1.015, 2.01, np.pi / 2 + 0.99], atol=1e-5)
