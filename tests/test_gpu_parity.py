@@ -527,3 +527,25 @@ def test_pose2_between_known_answers_on_gpu():
     assert np.allclose(-J[:, 6], e_exp, atol=1e-12)
     opt.retract(np.array([0.01, -0.015, 0.99, 0.0, 0.0, 0.0]))  # packed in ordering order (keys 1, 2)
     assert np.allclose(opt.values().at(1), [1.015, 2.01, np.pi / 2 + 0.99], atol=1e-5)
+
+
+def _pose3_expmap_cases():
+    """gtsam/geometry/tests/testPose3.cpp:90-99 (expmap_a_full: R = Rodrigues(0.3, 0, 0), P = (0.2, 0.7, -2)) and :121-137
+    (screw motion, expmap_c_full): (xi, expected R, expected t, tolerance)"""
+    c3, s3 = np.cos(0.3), np.sin(0.3)
+    Rx = np.array([[1, 0, 0], [0, c3, -s3], [0, s3, c3]])
+    Rz = np.array([[c3, -s3, 0], [s3, c3, 0], [0, 0, 1]])
+    return [(np.array([0.3, 0, 0, 0.2, 0.394742, -2.08998]), Rx, np.array([0.2, 0.7, -2.0]), 1e-5),
+            (np.array([0.0, 0.0, 0.3, 0.3, 0.0, 1.0]), Rz, np.array([0.29552, 0.0446635, 1.0]), 1e-6)]
+
+
+def test_pose3_expmap_known_answers_on_gpu():
+    """Pose3::Expmap known answers (testPose3.cpp:90-99, 121-137) out of the GPU retract kernel"""
+    for xi, R, t, tol in _pose3_expmap_cases():
+        g, v = NonlinearFactorGraph(), Values()
+        v.insert_pose3(0, np.eye(3), np.zeros(3))
+        g.add_PriorFactorPose3(0, np.eye(3), np.zeros(3), noiseModel.Unit.Create(6))
+        opt = LevenbergMarquardtOptimizer(g, v, Ordering.Natural(g), device=0)
+        opt.retract(xi)
+        out = opt.values().at(0)
+        assert np.allclose(out[:9].reshape(3, 3), R, atol=tol) and np.allclose(out[9:12], t, atol=tol)
