@@ -569,3 +569,28 @@ def test_pose3_expmap_known_answers():
         orc.retract({0: xi})
         out = np.array(orc.values()[0])
         assert np.allclose(out[:9].reshape(3, 3), R, atol=tol) and np.allclose(out[9:12], t, atol=tol)
+
+
+def _projection_factor_case():
+    """gtsam/slam/tests/testProjectionFactor.cpp:96-115 (Error) and :141-163 (Jacobian): K = Cal3_S2(fov 60 deg, 640 x 480),
+    pose (I, (0,0,-6)), point at the origin, measurement (323, 240)"""
+    from gtsam_personal_amd import NonlinearFactorGraph, Values, noiseModel
+    from gtsam_personal_amd.graph import L, X
+    fx = 640.0 / (2.0 * np.tan(60.0 * np.pi / 360.0))
+    K = [fx, fx, 0.0, 320.0, 240.0]
+    g, v = NonlinearFactorGraph(), Values()
+    v.insert_pose3(X(1), np.eye(3), [0.0, 0.0, -6.0])
+    v.insert_point3(L(1), [0.0, 0.0, 0.0])
+    g.add_GenericProjectionFactor([323.0, 240.0], noiseModel.Unit.Create(2), X(1), L(1), K)
+    H1 = np.array([[0., -554.256, 0., -92.376, 0., 0.], [554.256, 0., 0., 0., -92.376, 0.]])
+    H2 = np.array([[92.376, 0., 0.], [0., 92.376, 0.]])
+    return g, v, [X(1), L(1)], np.array([-3.0, 0.0]), H1, H2
+
+
+def test_projection_factor_known_answers():
+    g, v, order, e, H1, H2 = _projection_factor_case()
+    orc = oh.OracleProblem(g, v, order)
+    orc.linearize()
+    J = orc.jacobian(0)  # [H1 (2x6) H2 (2x3) b], b = -e
+    assert np.allclose(J[:, 0:6], H1, atol=1e-3) and np.allclose(J[:, 6:9], H2, atol=1e-3)
+    assert np.allclose(-J[:, 9], e, atol=1e-9)
