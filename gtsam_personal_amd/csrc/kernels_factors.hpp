@@ -404,6 +404,38 @@ __global__ __launch_bounds__(128) void generic_factor_kernel(BucketDev b, Values
   if (TYPE == 5) eval_prior_point3<JAC>(m, v0, e, H1);
   if (TYPE == 6) eval_prior_cam<JAC>(m, v0, e, H1);
   if (TYPE == 7) eval_projection<JAC>(m, v0, v1, e, H1, H2);
+  if (TYPE == 8) {
+    // GenericProjectionFactor with body_P_sensor (ProjectionFactor.h:142-149): camera pose = pose o sensor; H1 = H1_cam Ad(sensor^-1)
+    const P3 sensor = load_pose3(m + 7);
+    double vc[12];
+    store_pose3(compose3(load_pose3(v0), sensor), vc);
+    double Hc[JAC ? 12 : 1];
+    eval_projection<JAC>(m, vc, v1, e, Hc, H2);
+    if (JAC) {
+      const P3 hi = inverse3(sensor);  // AdjointMap = [R 0; [t]x R, R]  (Pose3.cpp:69-75)
+      const double S[9] = {0, -hi.t.z, hi.t.y, hi.t.z, 0, -hi.t.x, -hi.t.y, hi.t.x, 0};
+      double Ad[36];
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          const double rij = hi.R.m[3 * i + j];
+          Ad[6 * i + j] = rij;
+          Ad[6 * i + 3 + j] = 0.0;
+          Ad[6 * (i + 3) + j] = S[3 * i] * hi.R.m[j] + S[3 * i + 1] * hi.R.m[3 + j] + S[3 * i + 2] * hi.R.m[6 + j];
+          Ad[6 * (i + 3) + 3 + j] = rij;
+        }
+#pragma unroll
+      for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+          double v = 0;
+#pragma unroll
+          for (int k = 0; k < 6; k++) v += Hc[6 * r + k] * Ad[6 * k + j];
+          H1[6 * r + j] = v;
+        }
+    }
+  }
   const double* nz = b.noise ? b.noise + (size_t)f * (b.noise_kind == 2 ? M : M * M) : nullptr;
   if (JAC) {
     double Jl[M * COLS];

@@ -358,6 +358,9 @@ void launch_factors(lmgpu_handle* h, int which) {
       case LMGPU_F_PROJECTION:
         hipLaunchKernelGGL((generic_factor_kernel<7, 2, 6, 3, 7, 1, 12, 2, 3, JAC>), dim3(g128), dim3(128), 0, s, d, vals, h->ebuf0);
         break;
+      case LMGPU_F_PROJECTION_BPS:
+        hipLaunchKernelGGL((generic_factor_kernel<8, 2, 6, 3, 19, 1, 12, 2, 3, JAC>), dim3(g128), dim3(128), 0, s, d, vals, h->ebuf0);
+        break;
     }
   }
 }

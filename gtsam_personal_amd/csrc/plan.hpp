@@ -11,12 +11,12 @@ namespace lmgpu {
 
 static const int kVarDim[4] = {3, 6, 3, 9};
 static const int kVarStore[4] = {3, 12, 3, 15};
-static const int kFactorArity[8] = {2, 2, 2, 1, 1, 1, 1, 2};
-static const int kFactorRows[8] = {2, 3, 6, 3, 6, 3, 9, 2};
-static const int kFactorMeas[8] = {2, 3, 12, 3, 12, 3, 15, 7};
+static const int kFactorArity[9] = {2, 2, 2, 1, 1, 1, 1, 2, 2};
+static const int kFactorRows[9] = {2, 3, 6, 3, 6, 3, 9, 2, 2};
+static const int kFactorMeas[9] = {2, 3, 12, 3, 12, 3, 15, 7, 19};
 // variable types each factor type expects (for validation)
-static const int kFactorVar0[8] = {3, 0, 1, 0, 1, 2, 3, 1};
-static const int kFactorVar1[8] = {2, 0, 1, -1, -1, -1, -1, 2};
+static const int kFactorVar0[9] = {3, 0, 1, 0, 1, 2, 3, 1, 1};
+static const int kFactorVar1[9] = {2, 0, 1, -1, -1, -1, -1, 2, 2};
 
 struct FactorRef {
   int32_t bucket;   // bucket index

@@ -20,11 +20,11 @@ VAR_DIM = (3, 6, 3, 9)
 VAR_STORE = (3, 12, 3, 17)      # host packed value (camera keeps u0, v0)
 VAR_STORE_DEV = (3, 12, 3, 15)  # C-ABI packed value
 
-F_SFM, F_BETWEEN_POSE2, F_BETWEEN_POSE3, F_PRIOR_POSE2, F_PRIOR_POSE3, F_PRIOR_POINT3, F_PRIOR_CAM, F_PROJECTION = range(8)
-FACTOR_ARITY = (2, 2, 2, 1, 1, 1, 1, 2)
-FACTOR_ROWS = (2, 3, 6, 3, 6, 3, 9, 2)
-FACTOR_MEAS = (2, 3, 12, 3, 12, 3, 17, 7)  # host measurement doubles (PRIOR_CAM carries u0, v0)
-FACTOR_VARS = ((CAM_BUNDLER, POINT3), (POSE2, POSE2), (POSE3, POSE3), (POSE2,), (POSE3,), (POINT3,), (CAM_BUNDLER,), (POSE3, POINT3))
+F_SFM, F_BETWEEN_POSE2, F_BETWEEN_POSE3, F_PRIOR_POSE2, F_PRIOR_POSE3, F_PRIOR_POINT3, F_PRIOR_CAM, F_PROJECTION, F_PROJECTION_BPS = range(9)
+FACTOR_ARITY = (2, 2, 2, 1, 1, 1, 1, 2, 2)
+FACTOR_ROWS = (2, 3, 6, 3, 6, 3, 9, 2, 2)
+FACTOR_MEAS = (2, 3, 12, 3, 12, 3, 17, 7, 19)  # host measurement doubles (PRIOR_CAM carries u0, v0)
+FACTOR_VARS = ((CAM_BUNDLER, POINT3), (POSE2, POSE2), (POSE3, POSE3), (POSE2,), (POSE3,), (POINT3,), (CAM_BUNDLER,), (POSE3, POINT3), (POSE3, POINT3))
 
 N_UNIT, N_ISO, N_DIAG, N_GAUSS = 0, 1, 2, 3
 
@@ -324,9 +324,14 @@ class NonlinearFactorGraph:
     def add_PriorFactorCamera(self, key, packed17, model):
         self._add(F_PRIOR_CAM, [[key]], packed17, model)
 
-    def add_GenericProjectionFactor(self, measured, model, poseKey, pointKey, K):
-        """GenericProjectionFactor<Pose3, Point3, Cal3_S2>; K = (fx, fy, s, u0, v0)"""
-        self._add(F_PROJECTION, [[poseKey, pointKey]], np.concatenate([np.asarray(measured, dtype=np.float64), np.asarray(K, dtype=np.float64)]), model)
+    def add_GenericProjectionFactor(self, measured, model, poseKey, pointKey, K, body_P_sensor=None):
+        """GenericProjectionFactor<Pose3, Point3, Cal3_S2>; K = (fx, fy, s, u0, v0); body_P_sensor = (R 3x3, t 3) or None
+        (gtsam/slam/ProjectionFactor.h:99-113)"""
+        zk = np.concatenate([np.asarray(measured, dtype=np.float64), np.asarray(K, dtype=np.float64)])
+        if body_P_sensor is None:
+            self._add(F_PROJECTION, [[poseKey, pointKey]], zk, model)
+        else:
+            self._add(F_PROJECTION_BPS, [[poseKey, pointKey]], np.concatenate([zk, pose3_pack(body_P_sensor[0], body_P_sensor[1])]), model)
 
     # -- bulk access
     def buckets(self):

@@ -55,6 +55,8 @@ enum lmgpu_var_type { LMGPU_POSE2 = 0, LMGPU_POSE3 = 1, LMGPU_POINT3 = 2, LMGPU_
  *   PRIOR_POINT3     1     3     3
  *   PRIOR_CAM        1     9     15  (R, t, f, k1, k2)         PriorFactor<PinholeCamera<Cal3Bundler>>
  *   PROJECTION       2     2     7   (z, fx, fy, s, u0, v0)    GenericProjectionFactor<Pose3,Point3,Cal3_S2>  gtsam/slam/ProjectionFactor.h:138-165
+ *   PROJECTION_BPS   2     2     19  (z, K, body_P_sensor R t) the same with body_P_sensor (ProjectionFactor.h:142-149: camera =
+ *                                                              pose.compose(body_P_sensor), H1 chained with AdjointMap(body_P_sensor^-1))
  */
 enum lmgpu_factor_type {
   LMGPU_F_SFM = 0,
@@ -65,7 +67,8 @@ enum lmgpu_factor_type {
   LMGPU_F_PRIOR_POINT3 = 5,
   LMGPU_F_PRIOR_CAM = 6,
   LMGPU_F_PROJECTION = 7,
-  LMGPU_NUM_FACTOR_TYPES = 8
+  LMGPU_F_PROJECTION_BPS = 8,
+  LMGPU_NUM_FACTOR_TYPES = 9
 };
 
 /* Noise models (gtsam/linear/NoiseModel.cpp).  Per-factor noise data, `rows` = factor rows:

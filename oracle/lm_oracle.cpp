@@ -54,11 +54,12 @@ enum FactorType {
   F_PRIOR_POSE3 = 4,
   F_PRIOR_POINT3 = 5,
   F_PRIOR_CAM = 6,      // PriorFactor<PinholeCamera<Cal3Bundler>>  meas 17
-  F_PROJECTION = 7      // GenericProjectionFactor<Pose3,Point3,Cal3_S2> meas 2 + K(fx,fy,s,u0,v0)
+  F_PROJECTION = 7,     // GenericProjectionFactor<Pose3,Point3,Cal3_S2> meas 2 + K(fx,fy,s,u0,v0)
+  F_PROJECTION_BPS = 8  // the same with body_P_sensor: meas 2 + K 5 + sensor pose (R row-major 9, t 3)
 };
-static const int kFactorArity[8] = {2, 2, 2, 1, 1, 1, 1, 2};
-static const int kFactorRows[8] = {2, 3, 6, 3, 6, 3, 9, 2};
-static const int kFactorMeas[8] = {2, 3, 12, 3, 12, 3, 17, 7};
+static const int kFactorArity[9] = {2, 2, 2, 1, 1, 1, 1, 2, 2};
+static const int kFactorRows[9] = {2, 3, 6, 3, 6, 3, 9, 2, 2};
+static const int kFactorMeas[9] = {2, 3, 12, 3, 12, 3, 17, 7, 19};
 
 enum NoiseKind { N_UNIT = 0, N_ISO = 1, N_DIAG = 2, N_GAUSS = 3 };
 
@@ -70,7 +71,7 @@ struct Value {
 struct Factor {
   int type;
   Key keys[2];
-  double meas[17];
+  double meas[19];
   int noise_kind;
   std::vector<double> noise;  // ISO: sigma ; DIAG: sigmas[m] ; GAUSS: R m x m row-major (sqrt information)
   int robust = 0;             // noiseModel::Robust around the Gaussian model: m-estimator id (0 = none), see robust_weight
@@ -194,11 +195,20 @@ static void evaluate_error(const Factor& f, const Values& vals, double* e, doubl
       e[1] = pi[1] - f.meas[1];
       return;
     }
-    case F_PROJECTION: {
-      // GenericProjectionFactor::evaluateError gtsam/slam/ProjectionFactor.h:138-165 (no body_P_sensor)
+    case F_PROJECTION:
+    case F_PROJECTION_BPS: {
+      // GenericProjectionFactor::evaluateError gtsam/slam/ProjectionFactor.h:138-165; with body_P_sensor (:142-149) the camera is
+      // pose.compose(body_P_sensor) and H1 is chained with H0 = d compose / d pose = AdjointMap(body_P_sensor^-1) (Lie.h:63-69)
       const Value& po = vals.at(f.keys[0]);
       const Value& pt = vals.at(f.keys[1]);
       Pose3 pose = as_pose3(po.v);
+      double H0[36];
+      const bool bps = f.type == F_PROJECTION_BPS;
+      if (bps) {
+        const Pose3 sensor = as_pose3(f.meas + 7);
+        pose = compose(pose, sensor);
+        adjointMap(inverse(sensor), H0);
+      }
       const double fx = f.meas[2], fy = f.meas[3], s = f.meas[4], u0 = f.meas[5], v0 = f.meas[6];
       double pn[2], Dpose[12], Dpoint[6];
       bool ok = pinhole_project2(pose, V3{pt.v[0], pt.v[1], pt.v[2]}, pn, H1 ? Dpose : nullptr, H2 ? Dpoint : nullptr);
@@ -209,11 +219,23 @@ static void evaluate_error(const Factor& f, const Values& vals, double* e, doubl
         return;
       }
       // Cal3_S2::uncalibrate gtsam/geometry/Cal3_S2.cpp:44-50 ; Dp = [fx s; 0 fy]
-      if (H1)
+      if (H1) {
+        double Hc[12];
         for (int j = 0; j < 6; j++) {
-          H1[j] = fx * Dpose[j] + s * Dpose[6 + j];
-          H1[6 + j] = fy * Dpose[6 + j];
+          Hc[j] = fx * Dpose[j] + s * Dpose[6 + j];
+          Hc[6 + j] = fy * Dpose[6 + j];
         }
+        for (int r = 0; r < 2; r++)
+          for (int j = 0; j < 6; j++) {
+            if (!bps) {
+              H1[6 * r + j] = Hc[6 * r + j];
+            } else {
+              double v = 0;
+              for (int k = 0; k < 6; k++) v += Hc[6 * r + k] * H0[6 * k + j];
+              H1[6 * r + j] = v;
+            }
+          }
+      }
       if (H2)
         for (int j = 0; j < 3; j++) {
           H2[j] = fx * Dpoint[j] + s * Dpoint[3 + j];
@@ -1114,7 +1136,7 @@ int orc_add_variable(void* h, uint64_t key, int type, const double* value) {
 
 int orc_add_factor(void* h, int type, const uint64_t* keys, const double* meas, int noise_kind, const double* noise) {
   auto* p = (Problem*)h;
-  if (type < 0 || type > 7) return 2;
+  if (type < 0 || type > 8) return 2;
   Factor f;
   f.type = type;
   f.keys[0] = keys[0];

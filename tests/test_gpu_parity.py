@@ -574,3 +574,33 @@ def test_projection_factor_known_answers_on_gpu():
     J = opt.jacobian(0)
     assert np.allclose(J[:, 0:6], H1, atol=1e-3) and np.allclose(J[:, 6:9], H2, atol=1e-3)
     assert np.allclose(-J[:, 9], e, atol=1e-9)
+
+
+def _projection_factor_bps_case():
+    """gtsam/slam/tests/testProjectionFactor.cpp:118-139 (ErrorWithTransform) and :166-190 (JacobianWithTransform):
+    body_P_sensor = (RzRyRx(-pi/2, 0, -pi/2), (0.25, -0.10, 1.0)), vehicle pose (I, (-6.25, 0.10, -1.0))"""
+    from gtsam_personal_amd import NonlinearFactorGraph, Values, noiseModel
+    from gtsam_personal_amd.datasets import rot3_rzryrx
+    from gtsam_personal_amd.graph import L, X
+    fx = 640.0 / (2.0 * np.tan(60.0 * np.pi / 360.0))
+    K = [fx, fx, 0.0, 320.0, 240.0]
+    g, v = NonlinearFactorGraph(), Values()
+    v.insert_pose3(X(1), np.eye(3), [-6.25, 0.10, -1.0])
+    v.insert_point3(L(1), [0.0, 0.0, 0.0])
+    g.add_GenericProjectionFactor([323.0, 240.0], noiseModel.Unit.Create(2), X(1), L(1), K,
+                                  body_P_sensor=(rot3_rzryrx(-np.pi / 2, 0.0, -np.pi / 2), [0.25, -0.10, 1.0]))
+    H1 = np.array([[-92.376, 0., 577.350, 0., 92.376, 0.], [-9.2376, -577.350, 0., 0., 0., 92.376]])
+    H2 = np.array([[0., -92.376, 0.], [0., 0., -92.376]])
+    return g, v, [X(1), L(1)], np.array([-3.0, 0.0]), H1, H2
+
+
+def test_projection_factor_with_body_p_sensor_on_gpu():
+    g, v, order, e, H1, H2 = _projection_factor_bps_case()
+    opt = LevenbergMarquardtOptimizer(g, v, order, device=0)
+    opt.linearize()
+    J = opt.jacobian(0)
+    assert np.allclose(-J[:, 9], e, atol=1e-9)
+    assert np.allclose(J[:, 0:6], H1, atol=1e-3) and np.allclose(J[:, 6:9], H2, atol=1e-3)
+    orc = oh.OracleProblem(g, v, order)
+    orc.linearize()
+    assert np.allclose(J, orc.jacobian(0), rtol=1e-10, atol=1e-10)
