@@ -1,11 +1,10 @@
 // Single-wave Cholesky of a 64x64 diagonal block held entirely in registers, in the accumulator layout of
 // v_mfma_f64_16x16x4_f64: tile T[g][h] (16x16, h >= g) keeps element (row 16g + (lane>>4) + 4r, column 16h + (lane&15))
-// in register r.  No LDS and no barriers: the 16 pivots of a 16-row strip are eliminated with cross-lane shuffles
-// (ds_bpermute) across the whole strip, so the strip's off-diagonal tiles come out already solved (R_gh = R_gg^-T A_gh:
-// no explicit triangular inverse), and the remaining strips are updated on the matrix cores with both operands taken
-// straight from accumulator registers (C/D layout of k-step s  ==  A/B operand layout:  A[i = lane&15][k = lane>>4]).
-// The per-pivot dependency chain is   fma -> v_readlane -> v_rsq_f64 + 2 Newton steps   with the row shuffles in flight
-// beside it (they carry the unscaled row; the update multiplies by 1/p).
+// in register r.  No LDS and no barriers.  A 16-row strip is eliminated four pivots at a time (potrf64_wave_g4 below), its
+// off-diagonal tiles come out already solved (R_gh = R_gg^-T A_gh: no explicit triangular inverse), and the remaining strips
+// are updated on the matrix cores with both operands taken straight from accumulator registers (C/D layout of k-step s  ==
+// A/B operand layout:  A[i = lane&15][k = lane>>4]).  A first version took the pivots one at a time with ds_bpermute shuffles
+// of the pivot row (9.5-11 us per block in isolation, slower inside the fused step launch where other waves share the LDS pipe).
 // Arithmetic = Eigen::LLT on the block (gtsam/base/cholesky.cpp:108-159) up to rounding; a pivot <= 0 reports failure.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -29,64 +28,9 @@ __device__ __forceinline__ double fast_rsqrt(double p) {
   return y;
 }
 
-__device__ __forceinline__ double rcp_nr2(double p) {
-  double r = __builtin_amdgcn_rcp(p);
-  r = fma(fma(-p, r, 1.0), r, r);
-  r = fma(fma(-p, r, 1.0), r, r);
-  return r;
-}
-__device__ __forceinline__ double rcp_nr1(double p) {
-  double r = __builtin_amdgcn_rcp(p);
-  r = fma(fma(-p, r, 1.0), r, r);
-  return r;
-}
-#ifndef POTRF_RCP
-#define POTRF_RCP rcp_nr2
-#endif
-
 // T[g][h], h >= g: in = upper triangle of the SPD block (entries below the diagonal inside diagonal tiles: don't care),
 // out = R with R^T R = A.  Returns true if a pivot was <= 0 (the factor is then garbage, like Eigen's info() != Success).
-__device__ __forceinline__ bool potrf64_wave(double4_t (&T)[4][4]) {
-  const int lane = threadIdx.x & 63, kk = lane >> 4, cc = lane & 15;
-  bool failed = false;
-#pragma unroll
-  for (int g = 0; g < 4; g++) {
-#pragma unroll
-    for (int kq = 0; kq < 16; kq++) {
-      const int rk = kq >> 2, kw = kq & 3, src = kw * 16;
-      double p = readlane_d(T[g][g][rk], src + kq);
-      // branch-free (the whole 64-pivot chain is one scheduling region): pivot <= 0 -> failure, NaN passes like Eigen's LLT
-      failed |= (p <= 0.0);
-      p = (p > 0.0) ? p : ((p == p && p != 0.0) ? fabs(p) : 1.0);
-      double ra[4], rb[4];
-#pragma unroll
-      for (int r = rk; r < 4; r++) ra[r] = __shfl(T[g][g][rk], src + kk + 4 * r, 64);  // A'[k][a], a = kk + 4r (this strip's rows)
-#pragma unroll
-      for (int h = g; h < 4; h++) rb[h] = __shfl(T[g][h][rk], src + cc, 64);           // A'[k][b], b = column of tile h
-      const double rs = fast_rsqrt(p), ip = rs * rs;  // (a separate reciprocal for ip beside the rsqrt measured slower: 11.1 vs 9.5 us)
-#pragma unroll
-      for (int h = g; h < 4; h++) {
-        {  // register rk: rows kk + 4 rk -- below the pivot row for kk > kw, the pivot row itself for kk == kw
-          const double cur = T[g][h][rk];
-          const double upd = fma(-(ra[rk] * rb[h]), ip, cur);
-          T[g][h][rk] = (kk > kw) ? upd : ((kk == kw) ? cur * rs : cur);
-        }
-#pragma unroll
-        for (int r = rk + 1; r < 4; r++) T[g][h][r] = fma(-(ra[r] * rb[h]), ip, T[g][h][r]);
-      }
-    }
-    // remaining strips: T[g2][h] -= R[g][g2]^T R[g][h]
-#pragma unroll
-    for (int g2 = g + 1; g2 < 4; g2++)
-#pragma unroll
-      for (int h = g2; h < 4; h++)
-#pragma unroll
-        for (int s = 0; s < 4; s++) T[g2][h] = __builtin_amdgcn_mfma_f64_16x16x4f64(-T[g][g2][s], T[g][h][s], T[g2][h], 0, 0, 0);
-  }
-  return failed;
-}
-
-// The same factorisation with the pivots taken FOUR at a time.  A group = the four rows held by register q of a strip.  Its 4x4
+// The pivots are taken FOUR at a time.  A group = the four rows held by register q of a strip.  Its 4x4
 // diagonal mini-block is read with v_readlane (10 values) and factored by every lane redundantly in plain scalar-like code
 // (R4 = chol(M), W = R4^-1); the group's four rows of every tile of the strip are then solved by ONE MFMA per tile
 // (D = W^T [rows], A operand built from the ten W values by lane selects) and the rows below them in the strip updated by one
@@ -166,7 +110,7 @@ __device__ __forceinline__ bool potrf64_wave_g4(double4_t (&T)[4][4]) {
 
 // ---------------------------------------------------------------- one 256-row outer panel of an HBM front, two launches
 // diag_potrf_kernel  (ONE workgroup): Cholesky of the kb x kb diagonal block A[ko.., ko..] (kb <= 256), right-looking over
-//   64-blocks: wave 0 factors the 64x64 diagonal tile in registers (potrf64_wave), all four waves then solve the tiles to
+//   64-blocks: wave 0 factors the 64x64 diagonal tile in registers (potrf64_wave_g4), all four waves then solve the tiles to
 //   its right on the matrix cores (R_j,jj = R_jj^-T A_j,jj through the four 16x16 triangular inverses) and update the
 //   remaining tiles of the block with both operands from LDS / accumulator registers.  Every lane re-reads from global
 //   memory only what the same lane wrote (wave w <-> columns 16w..16w+15 of every tile), so the block needs no device-scope
@@ -427,7 +371,7 @@ __global__ __launch_bounds__(256) void panel_trsm_kernel(double* __restrict__ A,
 // ---------------------------------------------------------------- the same outer panel as ONE dataflow launch
 // Workgroup b < nblk owns block column b of the diagonal block (and factors diagonal tile b); the others own 64 columns
 // right of it.  Every workgroup runs the left-looking column algorithm of panel_trsm_kernel on its own columns and
-// consumes  R_jj + its 16x16 inverses   (flag diag_ready[j], published by workgroup j after potrf64_wave)  and the tiles
+// consumes  R_jj + its 16x16 inverses   (flag diag_ready[j], published by workgroup j after potrf64_wave_g4)  and the tiles
 // R_ij of block column j (flag tile_ready[i][j], published by workgroup j) from global memory.  A diagonal workgroup keeps
 // its diagonal tile in registers and folds X_j into it as soon as X_j exists, so the dependency chain of the launch is
 //   potrf(0) -> hand-off -> [workgroup 1: solve X_0, one tile update, potrf(1)] -> hand-off -> ...

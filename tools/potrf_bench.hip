@@ -9,7 +9,7 @@
 
 #include "kernels_potrf.hpp"
 #ifndef POTRF_FN
-#define POTRF_FN potrf64_wave
+#define POTRF_FN potrf64_wave_g4
 #endif
 
 using namespace lmgpu;
