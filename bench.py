@@ -201,8 +201,12 @@ def main():
         v = ct.c_double()
         if lib.lmgpu_peak_mfma_f64(local_rank, 4000, ct.byref(v)) == 0:
             out["measured_peak_mfma_f64_tflops"] = v.value
+            if "roofline" in out and v.value > 0:  # beside the datasheet-based frac: against what this device sustains
+                out["roofline"]["frac_of_measured_peak"] = out["roofline"]["achieved"] / v.value
         if lib.lmgpu_peak_hbm_copy(local_rank, 1 << 30, 5, ct.byref(v)) == 0:
             out["measured_hbm_copy_gbps"] = v.value
+            if "roofline_linearize" in out and v.value > 0:
+                out["roofline_linearize"]["frac_of_measured_copy"] = out["roofline_linearize"]["achieved"] / v.value
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(max(2, args.cams // 10), max(10, args.points // 10), args.obs, args.seed)
         sys.stdout.flush()
