@@ -621,3 +621,23 @@ def test_projection_factor_with_body_p_sensor_known_answers():
     J = orc.jacobian(0)
     assert np.allclose(-J[:, 9], e, atol=1e-9)
     assert np.allclose(J[:, 0:6], H1, atol=1e-3) and np.allclose(J[:, 6:9], H2, atol=1e-3)
+
+
+def _sfm_error_case():
+    """gtsam/slam/tests/testGeneralSFMFactor_Cal3Bundler.cpp:100-113: default Cal3Bundler (f = 1, no distortion), camera at
+    (I, (0,0,-6)), landmark at the origin, measurement (3, 0): unwhitened error (-3, 0)"""
+    from gtsam_personal_amd import NonlinearFactorGraph, Values, noiseModel
+    from gtsam_personal_amd.graph import L, X
+    g, v = NonlinearFactorGraph(), Values()
+    v.insert_camera(X(1), np.eye(3), [0.0, 0.0, -6.0], 1.0, 0.0, 0.0)
+    v.insert_point3(L(1), [0.0, 0.0, 0.0])
+    g.add_GeneralSFMFactor(np.array([[3.0, 0.0]]), noiseModel.Unit.Create(2), np.array([X(1)], dtype=np.uint64), np.array([L(1)], dtype=np.uint64))
+    return g, v, [L(1), X(1)]
+
+
+def test_general_sfm_factor_error_known_answer():
+    g, v, order = _sfm_error_case()
+    orc = oh.OracleProblem(g, v, order)
+    orc.linearize()
+    assert np.allclose(-orc.jacobian(0)[:, -1], [-3.0, 0.0], atol=1e-12)
+    assert abs(orc.error() - 4.5) < 1e-12
