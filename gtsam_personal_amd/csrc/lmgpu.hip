@@ -8,8 +8,10 @@
 //     (gtsam/nonlinear/LevenbergMarquardtOptimizer.cpp:121-308) and NonlinearOptimizer::defaultOptimize
 //     (gtsam/nonlinear/NonlinearOptimizer.cpp:62-117) that only reads three scalars back per inner iteration.
 //   * multi-GPU: the subtrees hanging below the replicated top (HBM) fronts are dealt to the ranks; each rank
-//     linearizes / eliminates / back-substitutes its own subtrees, the separator contributions into the top
-//     fronts are summed with one ncclAllReduce (RCCL over xGMI), error scalars with a 3-double all-reduce.
+//     linearizes / eliminates / back-substitutes its own subtrees; the partial assembly of a replicated top front is summed
+//     over the ranks in 256-row chunks (ncclAllReduce on a communication stream, RCCL over xGMI) and folded into the
+//     working matrix just before each panel is factored; error scalars with a 3-double all-reduce.
+//   * Gauss-Newton and Dogleg on the same device-resident graph / Bayes tree (gn_iterate, dl_iterate).
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 

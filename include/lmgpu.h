@@ -189,13 +189,14 @@ int lmgpu_get_timings(const lmgpu_handle* h, lmgpu_timings* out);
 /* Per-kernel device time (HIP events on the handle's stream around each launch), accumulated since
  * lmgpu_set_kernel_timing(h, 1).  work[] is the ALGORITHMIC work of the launches in the category:
  * bytes for LINEARIZE (232 B per SFM factor + every camera / point row once) and ALLREDUCE,
- * FP64 flop for PANEL and SYRK (nb * m * (m + 1) per trailing update = the n^3/3 of the dense front). */
+ * FP64 flop for PANEL and SYRK (kb * m * (m + 1) per trailing update = the n^3/3 of the dense front, plus kb^3/3 + kb^2 cols of a
+ * panel factored in the same launch). */
 enum lmgpu_kernel_category {
   LMGPU_KT_LINEARIZE = 0,   /* sfm_linearize_kernel */
   LMGPU_KT_LDS_FRONT = 1,   /* lds_front_kernel (assemble + partial Cholesky of one small front per workgroup) */
-  LMGPU_KT_HBM_ASSEMBLE = 2,/* memset + factor / child extend-add + damping of an HBM front */
-  LMGPU_KT_PANEL = 3,       /* potrf_trsm_kernel */
-  LMGPU_KT_SYRK = 4,        /* syrk_mfma_kernel (v_mfma_f64_16x16x4_f64) */
+  LMGPU_KT_HBM_ASSEMBLE = 2,/* memset + factor / child extend-add / Schur gather + damping of an HBM front */
+  LMGPU_KT_PANEL = 3,       /* panel factorisations launched on their own: panel_dataflow_kernel, diag_potrf_kernel + panel_trsm_kernel */
+  LMGPU_KT_SYRK = 4,        /* step_kernel = trailing update (v_mfma_f64_16x16x4_f64) + the next panel in the same launch; syrk_mfma_kernel */
   LMGPU_KT_BACKSUB_HBM = 5,
   LMGPU_KT_BACKSUB_LDS = 6,
   LMGPU_KT_LINEAR_ERROR = 7,
