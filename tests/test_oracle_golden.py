@@ -641,3 +641,27 @@ def test_general_sfm_factor_error_known_answer():
     orc.linearize()
     assert np.allclose(-orc.jacobian(0)[:, -1], [-3.0, 0.0], atol=1e-12)
     assert abs(orc.error() - 4.5) < 1e-12
+
+
+def _pinhole_project_case():
+    """gtsam/geometry/tests/testPinholeCamera.cpp:36-47, 125-131: K = Cal3_S2(625, 625, 0, 0, 0), pose (diag(1,-1,-1), (0,0,0.5)),
+    the four points (+-0.08, +-0.08, 0) project to (-100, 100), (-100, -100), (100, -100), (100, 100).  As GenericProjectionFactor
+    with a zero measurement the factor error IS the projection."""
+    from gtsam_personal_amd import NonlinearFactorGraph, Values, noiseModel
+    from gtsam_personal_amd.graph import L, X
+    g, v = NonlinearFactorGraph(), Values()
+    v.insert_pose3(X(0), np.diag([1.0, -1.0, -1.0]), [0.0, 0.0, 0.5])
+    pts = [(-0.08, -0.08, 0.0), (-0.08, 0.08, 0.0), (0.08, 0.08, 0.0), (0.08, -0.08, 0.0)]
+    for i, p in enumerate(pts):
+        v.insert_point3(L(i), p)
+        g.add_GenericProjectionFactor([0.0, 0.0], noiseModel.Unit.Create(2), X(0), L(i), [625.0, 625.0, 0.0, 0.0, 0.0])
+    expect = np.array([[-100.0, 100.0], [-100.0, -100.0], [100.0, -100.0], [100.0, 100.0]])
+    return g, v, [L(0), L(1), L(2), L(3), X(0)], expect
+
+
+def test_pinhole_projection_known_answers():
+    g, v, order, expect = _pinhole_project_case()
+    orc = oh.OracleProblem(g, v, order)
+    orc.linearize()
+    for i in range(4):
+        assert np.allclose(-orc.jacobian(i)[:, -1], expect[i], atol=1e-9)
