@@ -36,11 +36,19 @@ __device__ __forceinline__ double fast_rsqrt(double p) {
 // (D = W^T [rows], A operand built from the ten W values by lane selects) and the rows below them in the strip updated by one
 // more (C -= [rows]^T [rows], A operand = the solved rows of the diagonal tile, masked to the rows still to do).  No cross-lane
 // shuffles, and 16 dependent steps per 64x64 block instead of 64.
-__device__ __forceinline__ bool potrf64_wave_g4(double4_t (&T)[4][4]) {
+// INV: E[g] leaves as R_gg^-T of the g-th 16x16 diagonal tile (an identity tile appended to the strip and taken through the same
+// solves and updates), i.e. register r of lane (kk, cc) = Inv_g[cc][kk + 4 r] -- the 16x16 inverses the tile solves of the
+// panel kernels multiply with, at the price of two more MFMAs per group instead of a 16-step substitution after the factorisation.
+template <bool INV>
+__device__ __forceinline__ bool potrf64_wave_g4(double4_t (&T)[4][4], double4_t (&E)[4]) {
   const int lane = threadIdx.x & 63, kk = lane >> 4, cc = lane & 15;
   bool failed = false;
 #pragma unroll
   for (int g = 0; g < 4; g++) {
+    if (INV) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) E[g][r] = (kk + 4 * r == cc) ? 1.0 : 0.0;
+    }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       // M[a][b], a <= b: lane (kk = a, cc = 4q + b) of register q of the diagonal tile
@@ -87,15 +95,26 @@ __device__ __forceinline__ bool potrf64_wave_g4(double4_t (&T)[4][4]) {
       for (int k = 0; k < 4; k++)
 #pragma unroll
         for (int i = k; i < 4; i++) aop = (kk == k && cc == i) ? W[k][i] : aop;
-#pragma unroll
-      for (int h = g; h < 4; h++) {
-        const double4_t x = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, T[g][h][q], double4_t{0, 0, 0, 0}, 0, 0, 0);
-        T[g][h][q] = x[0];  // rows i = 0..3 of D = register 0, lane (kk = i, cc): the layout of register q
+      // the diagonal tile first: the next group's mini-block only waits for these two
+      double bop = 0.0;
+      {
+        const double4_t x = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, T[g][g][q], double4_t{0, 0, 0, 0}, 0, 0, 0);
+        T[g][g][q] = x[0];  // rows i = 0..3 of D = register 0, lane (kk = i, cc): the layout of register q
+        if (q < 3) {        // rows of the strip still to do: A[i = cc][k = kk] = R_new[k][i] for i >= 4 (q + 1)
+          bop = (cc >= 4 * (q + 1)) ? -T[g][g][q] : 0.0;
+          T[g][g] = __builtin_amdgcn_mfma_f64_16x16x4f64(bop, T[g][g][q], T[g][g], 0, 0, 0);
+        }
       }
-      if (q < 3) {  // rows of the strip still to do: A[i = cc][k = kk] = R_new[k][i] for i >= 4 (q + 1)
-        const double bop = (cc >= 4 * (q + 1)) ? -T[g][g][q] : 0.0;
 #pragma unroll
-        for (int h = g; h < 4; h++) T[g][h] = __builtin_amdgcn_mfma_f64_16x16x4f64(bop, T[g][h][q], T[g][h], 0, 0, 0);
+      for (int h = g + 1; h < 4; h++) {
+        const double4_t x = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, T[g][h][q], double4_t{0, 0, 0, 0}, 0, 0, 0);
+        T[g][h][q] = x[0];
+        if (q < 3) T[g][h] = __builtin_amdgcn_mfma_f64_16x16x4f64(bop, T[g][h][q], T[g][h], 0, 0, 0);
+      }
+      if (INV) {
+        const double4_t x = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, E[g][q], double4_t{0, 0, 0, 0}, 0, 0, 0);
+        E[g][q] = x[0];
+        if (q < 3) E[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(bop, E[g][q], E[g], 0, 0, 0);
       }
     }
 #pragma unroll
@@ -107,6 +126,10 @@ __device__ __forceinline__ bool potrf64_wave_g4(double4_t (&T)[4][4]) {
   }
   return failed;
 }
+__device__ __forceinline__ bool potrf64_wave_g4(double4_t (&T)[4][4]) {
+  double4_t E[4];
+  return potrf64_wave_g4<false>(T, E);
+}
 
 // ---------------------------------------------------------------- one 256-row outer panel of an HBM front, two launches
 // diag_potrf_kernel  (ONE workgroup): Cholesky of the kb x kb diagonal block A[ko.., ko..] (kb <= 256), right-looking over
@@ -114,7 +137,7 @@ __device__ __forceinline__ bool potrf64_wave_g4(double4_t (&T)[4][4]) {
 //   its right on the matrix cores (R_j,jj = R_jj^-T A_j,jj through the four 16x16 triangular inverses) and update the
 //   remaining tiles of the block with both operands from LDS / accumulator registers.  Every lane re-reads from global
 //   memory only what the same lane wrote (wave w <-> columns 16w..16w+15 of every tile), so the block needs no device-scope
-//   fences.  Also writes the sixteen 16x16 inverses of the diagonal tiles (inv16) for the panel solve.
+//   fences.  Also writes the sixteen 16x16 inverses of the diagonal tiles (inv16, by-product of the register Cholesky) for the panel solve.
 // panel_trsm_kernel  (one wave per 16 columns): the row panel right of the diagonal block,
 //   X_j = R_jj^-T (A_j,cols - sum_{i<j} R_ij^T X_i), all 256 rows of the wave's 16 columns held in accumulator registers
 //   (finished X tiles are fed back as B operands straight from those registers).
@@ -176,13 +199,18 @@ __device__ __forceinline__ void diag_potrf_body(double* __restrict__ A, int ld, 
         for (int h = g; h < 4; h++)
 #pragma unroll
           for (int r = 0; r < 4; r++) T[g][h][r] = D[16 * g + kk + 4 * r][16 * h + cc];
-      bool failed = potrf64_wave_g4(T);
+      double4_t E[4];
+      bool failed = potrf64_wave_g4<true>(T, E);
 #pragma unroll
       for (int g = 0; g < 4; g++)
 #pragma unroll
-        for (int h = g; h < 4; h++)
+        for (int r = 0; r < 4; r++) {
 #pragma unroll
-          for (int r = 0; r < 4; r++) D[16 * g + kk + 4 * r][16 * h + cc] = T[g][h][r];
+          for (int h = g; h < 4; h++) D[16 * g + kk + 4 * r][16 * h + cc] = T[g][h][r];
+          // the 16x16 inverses come out of the factorisation (E = R_gg^-T; identity padding inverts to identity)
+          I16[g][cc][kk + 4 * r] = E[g][r];
+          inv16[(size_t)(4 * j + g) * 256 + cc * 16 + kk + 4 * r] = E[g][r];
+        }
       if (ko + 64 * j + nbj >= nf) {  // last rows of the frontal part: pivot-exponent test, gtsam/base/cholesky.cpp:146-158
         // R[nf-1][nf-1] is element (nbj-1, nbj-1) of this tile: tile (3,3) if nbj == 64, else read back below
         __builtin_amdgcn_s_waitcnt(0);
@@ -197,27 +225,10 @@ __device__ __forceinline__ void diag_potrf_body(double* __restrict__ A, int ld, 
       if (failed && lane == 0) atomicMin(status, front_id);
     }
     __syncthreads();
-    // ---- 3. 16x16 inverses (lane (blk, c) back-substitutes column c of inv(R_blk)); R_jj -> global
-    if (tid < 64) {
-      const int blk = tid >> 4, c = tid & 15, base = 16 * blk;
-      double x[16];
-#pragma unroll
-      for (int i = 15; i >= 0; i--) {
-        double sacc = (i == c) ? 1.0 : 0.0;
-#pragma unroll
-        for (int kq = i + 1; kq < 16; kq++) sacc -= D[base + i][base + kq] * x[kq];
-        x[i] = (i <= c) ? sacc / D[base + i][base + i] : 0.0;
-      }
-#pragma unroll
-      for (int i = 0; i < 16; i++) {
-        I16[blk][i][c] = x[i];
-        inv16[(size_t)(4 * j + blk) * 256 + i * 16 + c] = x[i];
-      }
-    } else {
-      for (int idx = tid - 64; idx < nbj * 64; idx += 192) {
-        const int p = idx >> 6, q = idx & 63;
-        if (q >= p && q < nbj) Aj[(size_t)p * ld + 64 * j + q] = D[p][q];
-      }
+    // ---- 3. R_jj -> global
+    for (int idx = tid; idx < nbj * 64; idx += 256) {
+      const int p = idx >> 6, q = idx & 63;
+      if (q >= p && q < nbj) Aj[(size_t)p * ld + 64 * j + q] = D[p][q];
     }
     __syncthreads();
     if (j + 1 == nblk) break;
@@ -382,6 +393,10 @@ __global__ __launch_bounds__(256) void panel_trsm_kernel(double* __restrict__ A,
 // from a ticket counter, so a workgroup only ever waits for workgroups that started before it (no dispatch-order assumption).
 // flags (zeroed by the host before the launch): [0] ticket, [4 + j] diag_ready[j], [8 + 4 i + j] tile_ready[i][j],
 // [PDF_TA0 + sj] number of finished 64x64 trailing-update tiles of column strip sj in the next panel's rows (fused step only).
+// development aid (tools/microbench.hip defines it): wave 0 lane 0 of the diagonal workgroups stores s_memtime at the phase boundaries
+#ifndef PDF_STAMP
+#define PDF_STAMP(flags, b, slot)
+#endif
 #define PDF_TA0 32
 #define PDF_FLAG_WORDS 1024  // 992 column strips: fronts up to 63 488 columns take the fused path
 #define PDF_MAX_COLTILES (PDF_FLAG_WORDS - PDF_TA0)
@@ -445,13 +460,22 @@ __device__ __forceinline__ void panel_role(double* A, int ld, int n, int nf, int
     const int sj = diagwg ? b : nblk + (b - nblk);  // 64-column strip of the trailing update (its origin is ko)
     healthy &= pdf_wait(flags, PDF_TA0 + sj, (unsigned int)(min(sj, 3) + 1), -1, 0u, s_ok, tid);
   }
+  PDF_STAMP(flags, b, 0);
   double4_t X[4][4];
-  double4_t Td[4];  // diagonal workgroup: its strip of tile (b, b), right-looking
+  // diagonal workgroup: the ten upper 16x16 tiles of the diagonal tile (b, b), right-looking, dealt three / two per wave:
+  //   wave 0: (0,0) (0,3)   wave 1: (0,1) (1,1) (1,3)   wave 2: (0,2) (1,2) (2,2)   wave 3: (2,3) (3,3)
+  double4_t Td[3];
+  const int td_n = (wave == 0 || wave == 3) ? 2 : 3;
+  const int td_g0 = (wave == 3) ? 2 : 0, td_g1 = (wave == 0) ? 0 : (wave == 3 ? 3 : 1), td_g2 = (wave == 1) ? 1 : 2;
+  const int td_h0 = wave, td_h1 = (wave == 0) ? 3 : wave, td_h2 = (wave == 1) ? 3 : 2;
   if (diagwg) {
+    const double* Pd = P + (size_t)(64 * b) * ld + ko + 64 * b;
 #pragma unroll
-    for (int g = 0; g < 4; g++)
+    for (int t = 0; t < 3; t++) {
+      const int tg = t == 0 ? td_g0 : (t == 1 ? td_g1 : td_g2), th = t == 0 ? td_h0 : (t == 1 ? td_h1 : td_h2);
 #pragma unroll
-      for (int r = 0; r < 4; r++) Td[g][r] = P[(size_t)(64 * b + 16 * g + kk + 4 * r) * ld + col];
+      for (int r = 0; r < 4; r++) Td[t][r] = (t < td_n) ? Pd[(size_t)(16 * tg + kk + 4 * r) * ld + 16 * th + cc] : 0.0;
+    }
   }
   const int jend = diagwg ? b : nblk;  // exclusive
 #pragma unroll
@@ -483,33 +507,26 @@ __device__ __forceinline__ void panel_role(double* A, int ld, int n, int nf, int
         }
       }
       healthy &= pdf_wait(flags, 4 + j, 1u, -1, 0u, s_ok, tid);
+      PDF_STAMP(flags, b, 1 + 4 * j);
       {
+        // -R_jj is staged in LDS once per workgroup (D is free until the final gather): one 512-byte row per wave instruction
         const double* Rjj = Ab + (size_t)(64 * j) * ld + 64 * j;
         const double* Ij = inv16 + (size_t)(4 * j) * 256;
-        double rsub[6][4], isub[4][4];
-        int q = 0;
+        double isub[4][4];
 #pragma unroll
-        for (int g = 1; g < 4; g++)
-#pragma unroll
-          for (int i = 0; i < g; i++) {
-#pragma unroll
-            for (int sx = 0; sx < 4; sx++) rsub[q][sx] = -Rjj[(size_t)(16 * i + 4 * sx + kk) * ld + 16 * g + cc];
-            q++;
-          }
+        for (int u = 0; u < 16; u++) D[wave + 4 * u][lane] = -Rjj[(size_t)(wave + 4 * u) * ld + lane];
 #pragma unroll
         for (int g = 0; g < 4; g++)
 #pragma unroll
           for (int sx = 0; sx < 4; sx++) isub[g][sx] = Ij[g * 256 + (4 * sx + kk) * 16 + cc];
-        q = 0;
+        __syncthreads();
 #pragma unroll
         for (int g = 0; g < 4; g++) {
           double4_t acc = T[g];
 #pragma unroll
-          for (int i = 0; i < g; i++) {
+          for (int i = 0; i < g; i++)
 #pragma unroll
-            for (int sx = 0; sx < 4; sx++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(rsub[q][sx], T[i][sx], acc, 0, 0, 0);
-            q++;
-          }
+            for (int sx = 0; sx < 4; sx++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(D[16 * i + 4 * sx + kk][16 * g + cc], T[i][sx], acc, 0, 0, 0);
           double4_t out = double4_t{0, 0, 0, 0};
 #pragma unroll
           for (int sx = 0; sx < 4; sx++) out = __builtin_amdgcn_mfma_f64_16x16x4f64(isub[g][sx], acc[sx], out, 0, 0, 0);
@@ -520,6 +537,7 @@ __device__ __forceinline__ void panel_role(double* A, int ld, int n, int nf, int
             if (cvalid) P[(size_t)(64 * j + 16 * g + kk + 4 * r) * ld + c0 + cc] = out[r];
         }
       }
+      PDF_STAMP(flags, b, 2 + 4 * j);
       if (diagwg) {
         // own tile (j, b): a copy in LDS for the A operands, publish it, fold it into the diagonal tile
 #pragma unroll
@@ -527,64 +545,60 @@ __device__ __forceinline__ void panel_role(double* A, int ld, int n, int nf, int
 #pragma unroll
           for (int r = 0; r < 4; r++) XB[16 * g + kk + 4 * r][wc] = X[j][g][r];
         pdf_publish(&flags[8 + 4 * j + b], tid == 64);
+        PDF_STAMP(flags, b, 3 + 4 * j);
 #pragma unroll
-        for (int s = 0; s < 16; s++)
-#pragma unroll
-          for (int g = 0; g < 4; g++)
-            Td[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(-XB[4 * s + kk][16 * g + cc], X[j][s >> 2][s & 3], Td[g], 0, 0, 0);
+        for (int s = 0; s < 16; s++) {
+          Td[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-XB[4 * s + kk][16 * td_g0 + cc], X[j][s >> 2][s & 3], Td[0], 0, 0, 0);  // h == wave
+          Td[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-XB[4 * s + kk][16 * td_g1 + cc], XB[4 * s + kk][16 * td_h1 + cc], Td[1], 0, 0, 0);
+          if (td_n == 3) Td[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-XB[4 * s + kk][16 * td_g2 + cc], XB[4 * s + kk][16 * td_h2 + cc], Td[2], 0, 0, 0);
+        }
+        PDF_STAMP(flags, b, 4 + 4 * j);
       }
     }
   }
   if (!healthy && tid == 0) atomicMin(status, front_id);  // never expected: spin bound hit
   if (!diagwg) return;
-  // ---- diagonal tile b: gather the four strips, factor in wave 0, publish R_bb and its inverses
+  // ---- diagonal tile b: gather the ten tiles, factor in wave 0, publish R_bb and its 16x16 inverses straight from registers
 #pragma unroll
-  for (int g = 0; g < 4; g++)
+  for (int t = 0; t < 3; t++) {
+    const int tg = t == 0 ? td_g0 : (t == 1 ? td_g1 : td_g2), th = t == 0 ? td_h0 : (t == 1 ? td_h1 : td_h2);
+    if (t < td_n) {
 #pragma unroll
-    for (int r = 0; r < 4; r++) D[16 * g + kk + 4 * r][wc] = Td[g][r];
+      for (int r = 0; r < 4; r++) D[16 * tg + kk + 4 * r][16 * th + cc] = Td[t][r];
+    }
+  }
   __syncthreads();
+  PDF_STAMP(flags, b, 20);
   if (wave == 0) {
-    double4_t T[4][4];
+    double4_t T[4][4], E[4];
 #pragma unroll
     for (int g = 0; g < 4; g++)
 #pragma unroll
       for (int h = g; h < 4; h++)
 #pragma unroll
         for (int r = 0; r < 4; r++) T[g][h][r] = D[16 * g + kk + 4 * r][16 * h + cc];
-    bool failed = potrf64_wave_g4(T);
+    bool failed = potrf64_wave_g4<true>(T, E);
+    PDF_STAMP(flags, b, 21);
+    double* Aj = Ab + (size_t)(64 * b) * ld + 64 * b;
 #pragma unroll
-    for (int g = 0; g < 4; g++)
+    for (int g = 0; g < 4; g++) {
 #pragma unroll
-      for (int h = g; h < 4; h++)
+      for (int r = 0; r < 4; r++) {
+        if (cc >= kk + 4 * r) Aj[(size_t)(16 * g + kk + 4 * r) * ld + 16 * g + cc] = T[g][g][r];
 #pragma unroll
-        for (int r = 0; r < 4; r++) D[16 * g + kk + 4 * r][16 * h + cc] = T[g][h][r];
+        for (int h = g + 1; h < 4; h++) Aj[(size_t)(16 * g + kk + 4 * r) * ld + 16 * h + cc] = T[g][h][r];
+        inv16[(size_t)(4 * b + g) * 256 + cc * 16 + kk + 4 * r] = E[g][r];  // E = R_gg^-T
+      }
+    }
     if (ko + 64 * b + 64 >= nf) {  // last frontal rows: pivot-exponent test, gtsam/base/cholesky.cpp:146-158
-      const double r1 = D[63][63], r2 = D[62][62];
+      const double r1 = readlane_d(T[3][3][3], 63), r2 = readlane_d(T[3][3][3], 46);  // (63, 63) and (62, 62)
       if (!(frexp_exp_d(r2) - frexp_exp_d(r1) < 12)) failed = true;
     }
     if (failed && lane == 0) atomicMin(status, front_id);
-  }
-  __syncthreads();
-  if (tid < 64) {
-    const int blk = tid >> 4, c = tid & 15, base = 16 * blk;
-    double x[16];
-#pragma unroll
-    for (int i = 15; i >= 0; i--) {
-      double sacc = (i == c) ? 1.0 : 0.0;
-#pragma unroll
-      for (int kq = i + 1; kq < 16; kq++) sacc -= D[base + i][base + kq] * x[kq];
-      x[i] = (i <= c) ? sacc / D[base + i][base + i] : 0.0;
-    }
-#pragma unroll
-    for (int i = 0; i < 16; i++) inv16[(size_t)(4 * b + blk) * 256 + i * 16 + c] = x[i];
-  } else {
-    double* Aj = Ab + (size_t)(64 * b) * ld + 64 * b;
-    for (int idx = tid - 64; idx < 64 * 64; idx += 192) {
-      const int p = idx >> 6, q = idx & 63;
-      if (q >= p) Aj[(size_t)p * ld + q] = D[p][q];
-    }
+    PDF_STAMP(flags, b, 22);
   }
   pdf_publish(&flags[4 + b], tid == 64);
+  PDF_STAMP(flags, b, 23);
 }
 
 __global__ __launch_bounds__(256) void panel_dataflow_kernel(double* A, int ld, int n, int nf, int ko, int kb, int front_id, int* status,

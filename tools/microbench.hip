@@ -7,7 +7,17 @@
 #include <cstdlib>
 #include <vector>
 
+// phase stamps of the diagonal workgroups of panel_dataflow_kernel: flags[512 + 64 b + 2 slot] (two words per 64-bit s_memtime)
+#define PDF_STAMP(flags, b, slot)                                                                  \
+  do {                                                                                             \
+    if ((b) < 4 && threadIdx.x == 0) {                                                             \
+      unsigned long long t_;                                                                       \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                   \
+      *(unsigned long long*)&(flags)[512 + 64 * (b) + 2 * (slot)] = t_;                            \
+    }                                                                                              \
+  } while (0)
 #include "kernels_dense.hpp"
+#include "kernels_potrf.hpp"
 
 using namespace lmgpu;
 
@@ -66,6 +76,45 @@ int main(int argc, char** argv) {
     }
     printf("%-44s best %9.1f us   avg %9.1f us\n", name, best * 1e3, tot / reps * 1e3);
   };
+  // 1. one outer panel as a dataflow launch: duration and the phase stamps of the four diagonal workgroups
+  {
+    unsigned int* flags;
+    double* inv16;
+    CK(hipMalloc((void**)&flags, PDF_FLAG_WORDS * 4));
+    CK(hipMalloc((void**)&inv16, 16 * 256 * 8));
+    CK(hipFuncSetAttribute((const void*)panel_dataflow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PDF_LDS_BYTES));
+    for (int k0 : {0, 4352}) {
+      const int cols = n - k0 - 256, grid = 4 + (cols + 63) / 64;
+      float best = 1e30f;
+      std::vector<unsigned int> hf(PDF_FLAG_WORDS);
+      for (int rep = 0; rep < 3; rep++) {
+        reset();
+        CK(hipMemset(flags, 0, PDF_FLAG_WORDS * 4));
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(panel_dataflow_kernel, dim3(grid), dim3(256), PDF_LDS_BYTES, 0, A, ld, n, n - 1, k0, 256, 0, status, inv16, flags);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        best = ms < best ? ms : best;
+      }
+      CK(hipMemcpy(hf.data(), flags, PDF_FLAG_WORDS * 4, hipMemcpyDeviceToHost));
+      printf("panel_dataflow k0=%d grid=%d: %.1f us\n", k0, grid, best * 1e3);
+      auto st = [&](int b, int slot) { return *(unsigned long long*)&hf[512 + 64 * b + 2 * slot]; };
+      const unsigned long long t0 = st(0, 0);
+      const char* names[24] = {"start", "w0", "x0", "p0", "u0", "w1", "x1", "p1", "u1", "w2", "x2", "p2", "u2", "w3", "x3", "p3", "u3", "", "", "",
+                               "gathered", "potrf done", "inverses", "published"};
+      for (int b = 0; b < 4; b++) {
+        printf("  wg %d:", b);
+        for (int slot = 0; slot < 24; slot++) {
+          const unsigned long long t = st(b, slot);
+          if (t) printf(" %s=%.1f", names[slot], (double)(long long)(t - t0) * 0.01);  // s_memtime: 100 MHz -> 0.01 us per tick
+        }
+        printf("\n");
+      }
+    }
+  }
   // 3. strip updates (K = 64, <= 192 rows) and big updates (K = 256) at several trailing sizes
   for (int r0 : {64, 4160, 8256}) {
     char nm[128];
