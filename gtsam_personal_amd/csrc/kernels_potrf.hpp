@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void panel_trsm_kernel(double* __restrict__ A,
 // relaxed, ONE agent-scope acquire fence, wait, workgroup barrier, then plain vector loads.  Logical workgroup ids come
 // from a ticket counter, so a workgroup only ever waits for workgroups that started before it (no dispatch-order assumption).
 // flags (zeroed by the host before the launch): [0] ticket, [4 + j] diag_ready[j], [8 + 4 i + j] tile_ready[i][j],
-// [PDF_TA0 + sj] number of finished 64x64 trailing-update tiles of column strip sj in the next panel's rows (fused step only).
+// [PDF_TA0 + sj] number of finished trailing-update workgroups of column strip sj in the next panel's rows (fused step only).
 // development aid (tools/microbench.hip defines it): wave 0 lane 0 of the diagonal workgroups stores s_memtime at the phase boundaries
 #ifndef PDF_STAMP
 #define PDF_STAMP(flags, b, slot)
@@ -403,6 +403,10 @@ __global__ __launch_bounds__(256) void panel_trsm_kernel(double* __restrict__ A,
 #define PDF_SPIN_LIMIT 2000000L  // a legitimate wait is < 1 ms; the bound (~1-2 s) only keeps a logic error from hanging the device
 #define PDF_LDS_DOUBLES (2 * 64 * DP_LDW)
 #define PDF_LDS_BYTES (PDF_LDS_DOUBLES * 8)
+
+// publications a finished column strip sj of the next panel's rows has received (kernels_step.hpp): strips 0..3 are cut into
+// 32x32 quadrant workgroups (sj + 1 sub-tiles x 4), the others into four 64x64 sub-tiles
+__host__ __device__ inline unsigned int pdf_ta_need(int sj) { return sj < 4 ? 4u * (unsigned int)(sj + 1) : 4u; }
 
 // all threads call; thread 0 waits until flags[w] >= need for the (up to two) words given, then one acquire covers the workgroup
 __device__ __forceinline__ bool pdf_wait(unsigned int* flags, int w0, unsigned int need0, int w1, unsigned int need1, int* s_ok, int tid) {
@@ -456,9 +460,11 @@ __device__ __forceinline__ void panel_role(double* A, int ld, int n, int nf, int
   double* Ab = A + (size_t)ko * ld + ko;  // diagonal block
   double* P = A + (size_t)ko * ld;        // row panel
   bool healthy = true;
+  if (diagwg) __builtin_amdgcn_s_setprio(3);  // the chain of the launch: ahead of the update waves sharing its SIMDs
+  PDF_STAMP(flags, b, 19);
   if (fused) {
     const int sj = diagwg ? b : nblk + (b - nblk);  // 64-column strip of the trailing update (its origin is ko)
-    healthy &= pdf_wait(flags, PDF_TA0 + sj, (unsigned int)(min(sj, 3) + 1), -1, 0u, s_ok, tid);
+    healthy &= pdf_wait(flags, PDF_TA0 + sj, pdf_ta_need(sj), -1, 0u, s_ok, tid);
   }
   PDF_STAMP(flags, b, 0);
   double4_t X[4][4];

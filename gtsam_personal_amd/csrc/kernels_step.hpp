@@ -41,8 +41,10 @@ __device__ __forceinline__ void syrk_subtile64(double* __restrict__ A, int ld, i
   for (int a = 0; a < 2; a++)
 #pragma unroll
     for (int b = 0; b < 2; b++) acc[a][b] = double4_t{0, 0, 0, 0};
-  for (int k0 = 0; k0 < kp; k0 += 16) {
-    double af[4][2], bf[4][2];
+  // operand fragments three 16-deep stages ahead of the MFMAs (a ring of four register stages): with one stage in flight the
+  // loop ran at one L2 round trip per 16 k (24-40 us per tile at K = 256, the head of every step's dependency chain)
+  double af[4][4][2], bf[4][4][2];
+  auto load_stage = [&](int k0, double(&a_)[4][2], double(&b_)[4][2]) {
 #pragma unroll
     for (int s = 0; s < 4; s++) {
       const int k = min(k0 + 4 * s + kk, kp - 1);
@@ -51,17 +53,27 @@ __device__ __forceinline__ void syrk_subtile64(double* __restrict__ A, int ld, i
 #pragma unroll
       for (int a = 0; a < 2; a++) {
         const double v = row[i0 + 16 * a + cc];
-        af[s][a] = kv ? -v : 0.0;
+        a_[s][a] = kv ? -v : 0.0;
       }
 #pragma unroll
-      for (int b = 0; b < 2; b++) bf[s][b] = row[j0 + 16 * b + cc];
+      for (int b = 0; b < 2; b++) b_[s][b] = row[j0 + 16 * b + cc];
     }
+  };
 #pragma unroll
-    for (int s = 0; s < 4; s++)
+  for (int st = 0; st < 3; st++) load_stage(16 * st, af[st], bf[st]);
+  for (int k0 = 0; k0 < kp; k0 += 64) {
 #pragma unroll
-      for (int a = 0; a < 2; a++)
+    for (int u = 0; u < 4; u++) {
+      load_stage(k0 + 16 * (u + 3), af[(u + 3) & 3], bf[(u + 3) & 3]);  // past kp: clamped address, zero A operand
+      if (k0 + 16 * u < kp) {
 #pragma unroll
-        for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s][a], bf[s][b], acc[a][b], 0, 0, 0);
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+          for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[u][s][a], bf[u][s][b], acc[a][b], 0, 0, 0);
+      }
+    }
   }
   double cur[2][2][4];  // all 16 loads in flight, then the stores
 #pragma unroll
@@ -85,6 +97,64 @@ __device__ __forceinline__ void syrk_subtile64(double* __restrict__ A, int ld, i
       }
 }
 
+// The sub-tiles of column strips 0..3 feed the diagonal workgroups (the head of the launch's dependency chain) and are cut once
+// more: one workgroup per 32x32 quadrant, one 16x16 MFMA tile per wave, i.e. 64 dependent MFMAs per wave at K = 256 instead of
+// 256 (in-kernel timestamps: the first potrf waited 22-40 us for its 64x64 sub-tile, MFMA-bound on SIMDs shared with update tiles).
+__device__ __forceinline__ void syrk_quadrant32(double* __restrict__ A, int ld, int n, int p0, int kp, int r0, int si, int sj, int qd,
+                                                const double* __restrict__ Sadd) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kk = lane >> 4, cc = lane & 15;
+  const int wr = wave >> 1, wc = wave & 1, qr = qd >> 1, qc = qd & 1;
+  if (si == sj && (qr > qc || (qr == qc && wr > wc))) return;
+  const int i0 = r0 + 64 * si + 32 * qr + 16 * wr, j0 = r0 + 64 * sj + 32 * qc + 16 * wc;
+  if (i0 >= n || j0 >= n) return;
+  const double* P = A + (size_t)p0 * ld;
+  double4_t acc = double4_t{0, 0, 0, 0};
+  double af[4][4], bf[4][4];
+  auto load_stage = [&](int k0, double(&a_)[4], double(&b_)[4]) {
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const int k = min(k0 + 4 * s + kk, kp - 1);
+      const double* row = P + (size_t)k * ld;
+      const double v = row[i0 + cc];
+      a_[s] = (k0 + 4 * s + kk < kp) ? -v : 0.0;
+      b_[s] = row[j0 + cc];
+    }
+  };
+#pragma unroll
+  for (int st = 0; st < 3; st++) load_stage(16 * st, af[st], bf[st]);
+  const size_t at[4] = {(size_t)min(i0 + kk, n - 1) * ld + min(j0 + cc, n - 1), (size_t)min(i0 + kk + 4, n - 1) * ld + min(j0 + cc, n - 1),
+                        (size_t)min(i0 + kk + 8, n - 1) * ld + min(j0 + cc, n - 1), (size_t)min(i0 + kk + 12, n - 1) * ld + min(j0 + cc, n - 1)};
+  double cur[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    cur[r] = A[at[r]];
+    if (Sadd) cur[r] += Sadd[at[r]];
+  }
+  for (int k0 = 0; k0 < kp; k0 += 64) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      load_stage(k0 + 16 * (u + 3), af[(u + 3) & 3], bf[(u + 3) & 3]);  // past kp: clamped address, zero A operand
+      if (k0 + 16 * u < kp) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[u][s], bf[u][s], acc, 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int row = i0 + kk + 4 * r, col = j0 + cc;
+    if (row < n && col < n && col >= row) A[(size_t)row * ld + col] = cur[r] + acc[r];
+  }
+}
+
+// workgroups of a step launch that factors a next panel: shared by the kernel and its launchers
+__host__ __device__ inline int step_head_units(int S) { return S >= 4 ? 10 : S * (S + 1) / 2; }  // 64x64 sub-tiles of strips 0..3
+__host__ __device__ inline int step_ta_workgroups(int S) { return 4 * step_head_units(S) + (S > 4 ? 4 * (S - 4) : 0); }
+__host__ inline int step_grid(int m, int kbn) {
+  const int T = (m + 127) / 128, S = (m + 63) / 64;
+  return T * (T + 1) / 2 - (T >= 2 ? 2 * T - 1 : T) + step_ta_workgroups(S) + kbn / 64 + (m - kbn + 63) / 64;
+}
+
 #define STEP_LDS_BYTES (2 * 2 * SYRK_KC * SYRK_LDW * 8)
 static_assert(STEP_LDS_BYTES >= PDF_LDS_BYTES, "panel roles reuse the update's LDS");
 
@@ -97,21 +167,25 @@ __global__ __launch_bounds__(256, 2) void step_kernel(StepArgs a) {
   const int r0 = a.p0 + a.kp, m = a.n - r0;
   const int T = (m + 127) >> 7;  // tile rows = tile columns of the trailing matrix
   const bool next = a.kb_next > 0;
-  // rows of the next panel (tile rows 0 and 1) go as 64x64 sub-tiles, strip by strip: strip sj has min(sj, 3) + 1 of them
+  // rows of the next panel (tile rows 0 and 1) go as 64x64 sub-tiles, strip by strip: strip sj has min(sj, 3) + 1 of them;
+  // those of strips 0..3 as four 32x32 quadrant workgroups each (they gate the diagonal workgroups)
   const int S = (m + 63) >> 6;
-  const int nTA = next ? (S >= 4 ? 6 + 4 * (S - 3) : S * (S + 1) / 2) : 0;
+  const int nHead = next ? 4 * step_head_units(S) : 0;
+  const int nTA = next ? step_ta_workgroups(S) : 0;
   const int nTArows = next ? (T >= 2 ? 2 * T - 1 : T) : 0;  // 128x128 tiles they replace
   const int nd = next ? (a.kb_next >> 6) : 0;
   const int nTiles = T * (T + 1) / 2;
+  if (t < nHead) {
+    const int u = t >> 2;
+    const int sj = (u >= 6) ? 3 : ((u >= 3) ? 2 : (u >= 1 ? 1 : 0));
+    const int si = u - sj * (sj + 1) / 2;
+    __builtin_amdgcn_s_setprio(2);
+    syrk_quadrant32(a.A, a.ld, a.n, a.p0, a.kp, r0, si, sj, t & 3, a.S);
+    pdf_publish(&a.flags[PDF_TA0 + sj], threadIdx.x == 0);
+    return;
+  }
   if (t < nTA) {
-    int si, sj;
-    if (t < 6) {
-      sj = (t >= 3) ? 2 : (t >= 1 ? 1 : 0);
-      si = t - sj * (sj + 1) / 2;
-    } else {
-      sj = 3 + ((t - 6) >> 2);
-      si = (t - 6) & 3;
-    }
+    const int sj = 4 + ((t - nHead) >> 2), si = (t - nHead) & 3;
     syrk_subtile64(a.A, a.ld, a.n, a.p0, a.kp, r0, si, sj, a.S);
     pdf_publish(&a.flags[PDF_TA0 + sj], threadIdx.x == 0);
     return;

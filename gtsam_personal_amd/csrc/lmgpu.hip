@@ -728,8 +728,7 @@ int do_eliminate(lmgpu_handle* h, double lambda) {
           const int kbn = rows_of(i + 1);
           StepArgs a{A, ld, F.n, F.nf, k0, kb, kbn, F.id, h->d_status, h->inv16, h->d_pflags + (size_t)(i + 1) * PDF_FLAG_WORDS,
                      fold_in_step ? (const double*)Asm : nullptr};
-          const int S = (m + 63) / 64;
-          const int grid = T * (T + 1) / 2 - (T >= 2 ? 2 * T - 1 : T) + (S >= 4 ? 6 + 4 * (S - 3) : S * (S + 1) / 2) + kbn / 64 + (m - kbn + 63) / 64;
+          const int grid = step_grid(m, kbn);
           if (run_launches == 0) kt_run = h->kt.begin(LMGPU_KT_SYRK, s);
           hipLaunchKernelGGL(step_kernel, dim3(grid), dim3(256), STEP_LDS_BYTES, s, a);
           run_launches++;

@@ -18,6 +18,7 @@
   } while (0)
 #include "kernels_dense.hpp"
 #include "kernels_potrf.hpp"
+#include "kernels_step.hpp"
 
 using namespace lmgpu;
 
@@ -102,14 +103,58 @@ int main(int argc, char** argv) {
       CK(hipMemcpy(hf.data(), flags, PDF_FLAG_WORDS * 4, hipMemcpyDeviceToHost));
       printf("panel_dataflow k0=%d grid=%d: %.1f us\n", k0, grid, best * 1e3);
       auto st = [&](int b, int slot) { return *(unsigned long long*)&hf[512 + 64 * b + 2 * slot]; };
-      const unsigned long long t0 = st(0, 0);
       const char* names[24] = {"start", "w0", "x0", "p0", "u0", "w1", "x1", "p1", "u1", "w2", "x2", "p2", "u2", "w3", "x3", "p3", "u3", "", "", "",
-                               "gathered", "potrf done", "inverses", "published"};
+                               "gathered", "potrf", "stored", "published"};
       for (int b = 0; b < 4; b++) {
-        printf("  wg %d:", b);
-        for (int slot = 0; slot < 24; slot++) {
+        printf("  wg %d (us from its own start; the counters of different XCDs are not aligned):", b);
+        const unsigned long long t0 = st(b, 0);
+        for (int slot = 1; slot < 24; slot++) {
           const unsigned long long t = st(b, slot);
-          if (t) printf(" %s=%.1f", names[slot], (double)(long long)(t - t0) * 0.01);  // s_memtime: 100 MHz -> 0.01 us per tick
+          if (t) printf(" %s=%.1f", names[slot], (double)(long long)(t - t0) / 2400.0);  // s_memtime ticks at the 2.4 GHz shader clock here
+        }
+        printf("\n");
+      }
+    }
+  }
+  // 2. the fused step launch (update with panel at p0 + factorisation of the next panel) with the same stamps
+  {
+    unsigned int* flags;
+    double* inv16;
+    CK(hipMalloc((void**)&flags, PDF_FLAG_WORDS * 4));
+    CK(hipMalloc((void**)&inv16, 16 * 256 * 8));
+    CK(hipFuncSetAttribute((const void*)step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STEP_LDS_BYTES));
+    for (int p0 : {0, 4352, 6400}) {
+      if (p0 + 512 >= n) continue;
+      const int r0 = p0 + 256, m = n - r0, kbn = 256;
+      const int grid = step_grid(m, kbn);
+      float best = 1e30f;
+      std::vector<unsigned int> hf(PDF_FLAG_WORDS);
+      for (int rep = 0; rep < 3; rep++) {
+        reset();
+        CK(hipMemset(flags, 0, PDF_FLAG_WORDS * 4));
+        CK(hipDeviceSynchronize());
+        StepArgs a{A, ld, n, n - 1, p0, 256, kbn, 0, status, inv16, flags, nullptr};
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(step_kernel, dim3(grid), dim3(256), STEP_LDS_BYTES, 0, a);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        best = ms < best ? ms : best;
+      }
+      CK(hipMemcpy(hf.data(), flags, PDF_FLAG_WORDS * 4, hipMemcpyDeviceToHost));
+      printf("step_kernel p0=%d m=%d grid=%d: %.1f us (%.1f TFLOP/s)\n", p0, m, grid, best * 1e3, 256.0 * m * (m + 1) / (best * 1e-3) / 1e12);
+      auto st = [&](int b, int slot) { return *(unsigned long long*)&hf[512 + 64 * b + 2 * slot]; };
+      const char* names[24] = {"start", "w0", "x0", "p0", "u0", "w1", "x1", "p1", "u1", "w2", "x2", "p2", "u2", "w3", "x3", "p3", "u3", "", "", "",
+                               "gathered", "potrf", "stored", "published"};
+      names[0] = "rows ready";
+      for (int b = 0; b < 4; b++) {
+        printf("  wg %d (us from its own entry):", b);
+        const unsigned long long t0 = st(b, 19);
+        for (int slot = 0; slot < 24; slot++) {
+          if (slot == 19) continue;
+          const unsigned long long t = st(b, slot);
+          if (t) printf(" %s=%.1f", names[slot], (double)(long long)(t - t0) / 2400.0);  // s_memtime ticks at the 2.4 GHz shader clock here
         }
         printf("\n");
       }
