@@ -398,8 +398,14 @@ __global__ __launch_bounds__(256) void panel_trsm_kernel(double* __restrict__ A,
 #define PDF_STAMP(flags, b, slot)
 #endif
 #define PDF_TA0 32
-#define PDF_FLAG_WORDS 1024  // 992 column strips: fronts up to 63 488 columns take the fused path
-#define PDF_MAX_COLTILES (PDF_FLAG_WORDS - PDF_TA0)
+#define PDF_MAX_COLTILES 992  // column strips: fronts up to 63 488 columns take the fused path
+// chained steps only (chain_kernel, kernels_step.hpp):
+//   [PDF_PR0 + q]  finished row-panel workgroups of the 128-column block q right of the panel (its rows there are final),
+//   [PDF_TD0 + x]  trailing-update tile x = (ti, tj) of the step that factors this panel has been stored
+#define PDF_PR0 1024
+#define PDF_TD0 1536
+#define PDF_FLAG_WORDS 8192
+#define PDF_MAX_CHAIN_T 114  // (T + 1) T / 2 <= PDF_FLAG_WORDS - PDF_TD0
 #define PDF_SPIN_LIMIT 2000000L  // a legitimate wait is < 1 ms; the bound (~1-2 s) only keeps a logic error from hanging the device
 #define PDF_LDS_DOUBLES (2 * 64 * DP_LDW)
 #define PDF_LDS_BYTES (PDF_LDS_DOUBLES * 8)
@@ -433,6 +439,32 @@ __device__ __forceinline__ bool pdf_wait(unsigned int* flags, int w0, unsigned i
   return *s_ok != 0;
 }
 
+// the same for up to three flag words given by address (nullptr: none)
+__device__ __forceinline__ bool pdf_wait3(const unsigned int* f0, unsigned int n0, const unsigned int* f1, unsigned int n1, const unsigned int* f2,
+                                          unsigned int n2, int* s_ok, int tid) {
+  if (tid == 0) {
+    bool ok = true;
+    for (int q = 0; q < 3 && ok; q++) {
+      const unsigned int* f = q == 0 ? f0 : (q == 1 ? f1 : f2);
+      const unsigned int need = q == 0 ? n0 : (q == 1 ? n1 : n2);
+      if (!f) continue;
+      long spins = 0;
+      while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > PDF_SPIN_LIMIT) {
+          ok = false;
+          break;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    *s_ok = ok ? 1 : 0;
+  }
+  __syncthreads();
+  return *s_ok != 0;
+}
+
 // every wave calls this after its last store of the payload; `signaller` = the one thread that raises the flag
 __device__ __forceinline__ void pdf_publish(unsigned int* flag, bool signaller) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -446,8 +478,9 @@ __device__ __forceinline__ void pdf_publish(unsigned int* flag, bool signaller) 
 
 // The work of logical workgroup b on the outer panel [ko, ko + kb) (kb a multiple of 64).  ta_need > 0: the panel's rows
 // are being produced by trailing-update tiles of the same launch; wait for the ones covering this workgroup's columns.
+// publish_strips: a row-panel workgroup counts itself into [PDF_PR0 + 128-column block] when its columns are final (chained steps).
 __device__ __forceinline__ void panel_role(double* A, int ld, int n, int nf, int ko, int kb, int b, int front_id, int* status, double* inv16,
-                                           unsigned int* flags, double* dsm, int* s_ok, bool fused) {
+                                           unsigned int* flags, double* dsm, int* s_ok, bool fused, bool publish_strips = false) {
   double(*D)[DP_LDW] = (double(*)[DP_LDW])dsm;
   double(*XB)[DP_LDW] = (double(*)[DP_LDW])(dsm + 64 * DP_LDW);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kk = lane >> 4, cc = lane & 15;
@@ -563,7 +596,10 @@ __device__ __forceinline__ void panel_role(double* A, int ld, int n, int nf, int
     }
   }
   if (!healthy && tid == 0) atomicMin(status, front_id);  // never expected: spin bound hit
-  if (!diagwg) return;
+  if (!diagwg) {
+    if (publish_strips) pdf_publish(&flags[PDF_PR0 + ((b - nblk) >> 1)], tid == 0);
+    return;
+  }
   // ---- diagonal tile b: gather the ten tiles, factor in wave 0, publish R_bb and its 16x16 inverses straight from registers
 #pragma unroll
   for (int t = 0; t < 3; t++) {

@@ -158,12 +158,27 @@ __host__ inline int step_grid(int m, int kbn) {
 #define STEP_LDS_BYTES (2 * 2 * SYRK_KC * SYRK_LDW * 8)
 static_assert(STEP_LDS_BYTES >= PDF_LDS_BYTES, "panel roles reuse the update's LDS");
 
-__global__ __launch_bounds__(256, 2) void step_kernel(StepArgs a) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];
-  __shared__ int s_bid, s_ok;
-  if (threadIdx.x == 0) s_bid = (int)atomicAdd(&a.flags[0], 1u);
-  __syncthreads();
-  int t = s_bid;
+// What a chained step waits for and publishes (null / false for a step that is a launch of its own): the finished panel's
+// 128-column blocks ([PDF_PR0 + q] in `prev`, counted by the row-panel workgroups of the step before) and the tile of the
+// step before that covers the same entries ([PDF_TD0 + x] in `prev`); its own tiles are counted into [PDF_TD0 + x] of a.flags.
+struct ChainLink {
+  const unsigned int* prev;  // flag region of the finished panel (= of the step before), nullptr for the first step of a chain
+  bool publish;              // a later step of the same launch consumes this step's tiles and panel
+};
+
+// one 64-strip count per 128-column block q of a trailing matrix with S strips
+__device__ __forceinline__ unsigned int chain_pr_need(int S, int q) { return (unsigned int)min(2, S - 2 * q); }
+// wait for the inputs of the update of 128-tile (ti, tj) (or a part of it) of a step with T tile rows and S strips
+__device__ __forceinline__ bool chain_wait_tile(const ChainLink& c, int T, int S, int ti, int tj, int* s_ok) {
+  if (!c.prev) return true;
+  const int Tp = T + 2, pi = ti + 2, pj = tj + 2;  // the step before: trailing origin 256 rows / columns earlier
+  const unsigned int* td = c.prev + PDF_TD0 + pi * Tp - pi * (pi - 1) / 2 + (pj - pi);
+  return pdf_wait3(c.prev + PDF_PR0 + ti, chain_pr_need(S, ti), ti == tj ? nullptr : c.prev + PDF_PR0 + tj, chain_pr_need(S, tj), td, 1u, s_ok,
+                   threadIdx.x);
+}
+
+// the work of logical workgroup t of one step
+__device__ __forceinline__ void step_body(const StepArgs& a, int t, const ChainLink& c, double* sm, int* s_ok) {
   const int r0 = a.p0 + a.kp, m = a.n - r0;
   const int T = (m + 127) >> 7;  // tile rows = tile columns of the trailing matrix
   const bool next = a.kb_next > 0;
@@ -175,42 +190,92 @@ __global__ __launch_bounds__(256, 2) void step_kernel(StepArgs a) {
   const int nTArows = next ? (T >= 2 ? 2 * T - 1 : T) : 0;  // 128x128 tiles they replace
   const int nd = next ? (a.kb_next >> 6) : 0;
   const int nTiles = T * (T + 1) / 2;
-  if (t < nHead) {
-    const int u = t >> 2;
-    const int sj = (u >= 6) ? 3 : ((u >= 3) ? 2 : (u >= 1 ? 1 : 0));
-    const int si = u - sj * (sj + 1) / 2;
-    __builtin_amdgcn_s_setprio(2);
-    syrk_quadrant32(a.A, a.ld, a.n, a.p0, a.kp, r0, si, sj, t & 3, a.S);
-    pdf_publish(&a.flags[PDF_TA0 + sj], threadIdx.x == 0);
-    return;
-  }
   if (t < nTA) {
-    const int sj = 4 + ((t - nHead) >> 2), si = (t - nHead) & 3;
-    syrk_subtile64(a.A, a.ld, a.n, a.p0, a.kp, r0, si, sj, a.S);
+    int si, sj;
+    if (t < nHead) {
+      const int u = t >> 2;
+      sj = (u >= 6) ? 3 : ((u >= 3) ? 2 : (u >= 1 ? 1 : 0));
+      si = u - sj * (sj + 1) / 2;
+      __builtin_amdgcn_s_setprio(2);
+    } else {
+      sj = 4 + ((t - nHead) >> 2);
+      si = (t - nHead) & 3;
+    }
+    const bool ok = chain_wait_tile(c, T, S, si >> 1, sj >> 1, s_ok);
+    if (!ok && threadIdx.x == 0) atomicMin(a.status, a.front_id);
+    if (t < nHead)
+      syrk_quadrant32(a.A, a.ld, a.n, a.p0, a.kp, r0, si, sj, t & 3, a.S);
+    else
+      syrk_subtile64(a.A, a.ld, a.n, a.p0, a.kp, r0, si, sj, a.S);
     pdf_publish(&a.flags[PDF_TA0 + sj], threadIdx.x == 0);
     return;
   }
   t -= nTA;
   if (t < nd) {
-    panel_role(a.A, a.ld, a.n, a.nf, r0, a.kb_next, t, a.front_id, a.status, a.inv16, a.flags, sm, &s_ok, true);
+    panel_role(a.A, a.ld, a.n, a.nf, r0, a.kb_next, t, a.front_id, a.status, a.inv16, a.flags, sm, s_ok, true);
     return;
   }
   t -= nd;
   if (t < nTiles - nTArows) {  // remaining tiles, row-major over tile rows first..T-1
     int ti = next ? 2 : 0;
-    if (!next) {
-      // all tiles
-    }
     int rem = t;
     while (rem >= T - ti) {
       rem -= T - ti;
       ti++;
     }
-    syrk_tile(a.A, a.ld, a.n, a.p0, a.kp, r0, a.n, ti, ti + rem, sm);
+    const int tj = ti + rem;
+    const bool ok = chain_wait_tile(c, T, S, ti, tj, s_ok);
+    if (!ok && threadIdx.x == 0) atomicMin(a.status, a.front_id);
+    syrk_tile(a.A, a.ld, a.n, a.p0, a.kp, r0, a.n, ti, tj, sm);
+    if (c.publish) pdf_publish(&a.flags[PDF_TD0 + ti * T - ti * (ti - 1) / 2 + (tj - ti)], threadIdx.x == 0);
     return;
   }
   t -= nTiles - nTArows;
-  panel_role(a.A, a.ld, a.n, a.nf, r0, a.kb_next, nd + t, a.front_id, a.status, a.inv16, a.flags, sm, &s_ok, true);
+  panel_role(a.A, a.ld, a.n, a.nf, r0, a.kb_next, nd + t, a.front_id, a.status, a.inv16, a.flags, sm, s_ok, true, c.publish);
+}
+
+__global__ __launch_bounds__(256, 2) void step_kernel(StepArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  __shared__ int s_bid, s_ok;
+  if (threadIdx.x == 0) s_bid = (int)atomicAdd(&a.flags[0], 1u);
+  __syncthreads();
+  step_body(a, s_bid, ChainLink{nullptr, false}, sm, &s_ok);
+}
+
+// ---------------------------------------------------------------- a run of consecutive steps as ONE launch
+// Steps i0 .. i0 + nsteps - 1 of a front (every one with a full 256-row finished panel and a next panel of whole 64-blocks),
+// tickets in step order.  A workgroup of step i + 1 additionally waits for what the launch boundary used to guarantee: the
+// 128-column blocks of panel i + 1 it multiplies with (counted by the row-panel workgroups of step i) and the tile of step
+// i that holds the entries it updates.  Every dependency points to a lower ticket, and a ticket is drawn when a workgroup
+// starts, so a waiting workgroup only ever waits for workgroups that are resident or done.  What it buys: no drain / launch
+// gap (8-10 us) per 256 columns, and the head tiles of step i + 1 start when THEIR columns are final instead of after the
+// slowest row-panel workgroup -- the dependency chain of a step shrinks to four tile stages plus one head tile.
+#define CHAIN_MAX_STEPS 224
+struct ChainArgs {
+  double* A;
+  int ld, n, nf;
+  int i0, nsteps;
+  int front_id;
+  int* status;
+  double* inv16;        // 16 x 256 doubles per step
+  unsigned int* flags;  // region of panel p at flags + p * PDF_FLAG_WORDS; the ticket counter is word 0 of panel i0 + 1
+  int tick[CHAIN_MAX_STEPS + 1];  // first ticket of every step, and the total
+};
+
+__global__ __launch_bounds__(256, 2) void chain_kernel(ChainArgs ca) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  __shared__ int s_bid, s_ok;
+  if (threadIdx.x == 0) s_bid = (int)atomicAdd(&ca.flags[(size_t)(ca.i0 + 1) * PDF_FLAG_WORDS], 1u);
+  __syncthreads();
+  const int ticket = s_bid;
+  int s = 0;
+  while (s + 1 < ca.nsteps && ticket >= ca.tick[s + 1]) s++;
+  const int i = ca.i0 + s;
+  const int kbn = min(ca.nf, (i + 2) * 256) - (i + 1) * 256;
+  StepArgs a{ca.A, ca.ld, ca.n, ca.nf, 256 * i, 256, kbn, ca.front_id, ca.status, ca.inv16 + (size_t)s * 4096,
+             ca.flags + (size_t)(i + 1) * PDF_FLAG_WORDS, nullptr};
+  const ChainLink c{s > 0 ? ca.flags + (size_t)i * PDF_FLAG_WORDS : nullptr, s + 1 < ca.nsteps};
+  step_body(a, ticket - ca.tick[s], c, sm, &s_ok);
 }
 
 }  // namespace lmgpu

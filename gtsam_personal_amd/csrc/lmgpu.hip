@@ -199,6 +199,7 @@ struct lmgpu_handle {
   double* inv16 = nullptr;                     // 16 x (16x16) inverses of the current outer panel's diagonal tiles
   bool two_launch_panel = false;               // LMGPU_PANEL_2L=1: diag_potrf + panel_trsm for every outer panel (A/B)
   bool no_fuse = false;                        // LMGPU_NO_FUSE=1: trailing update and next panel as separate launches (A/B)
+  bool no_chain = false;                       // LMGPU_NO_CHAIN=1: one launch per fused step instead of one per run of steps (A/B)
   unsigned int* d_pflags = nullptr;            // hand-off flags of panel_dataflow_kernel, PDF_FLAG_WORDS per outer panel
   int pflags_panels = 0;
   unsigned int* bs_flags = nullptr;
@@ -706,10 +707,31 @@ int do_eliminate(lmgpu_handle* h, double lambda) {
         run_launches = 0;
         run_flop = 0;
       };
+      // a step that can be fused with the factorisation of the next panel; consecutive ones with full panels go as ONE launch
+      auto fusable = [&](int i) { return (i + 1 < np) && dataflow_ok(i + 1) && !h->no_fuse && F.n - i * NBO - rows_of(i) > 0; };
+      auto chainable = [&](int i) {
+        return fusable(i) && !split && !h->no_chain && rows_of(i) == NBO && (F.n - (i + 1) * NBO + 127) / 128 <= PDF_MAX_CHAIN_T;
+      };
       for (int i = 0; i < np; i++) {
         const int k0 = i * NBO, kb = rows_of(i), r0 = k0 + kb, m = F.n - r0;
         if (m <= 0) break;
-        const bool fuse = (i + 1 < np) && dataflow_ok(i + 1) && !h->no_fuse;
+        if (chainable(i) && chainable(i + 1)) {
+          ChainArgs ca{A, ld, F.n, F.nf, i, 0, F.id, h->d_status, h->inv16, h->d_pflags, {0}};
+          double flop = 0;
+          while (ca.nsteps < CHAIN_MAX_STEPS && chainable(i + ca.nsteps)) {
+            const int is = i + ca.nsteps, ms = F.n - (is + 1) * NBO;
+            ca.tick[ca.nsteps + 1] = ca.tick[ca.nsteps] + step_grid(ms, rows_of(is + 1));
+            flop += 2.0 * NBO * ((double)ms * (ms + 1) / 2.0) + panel_flop(is + 1);
+            ca.nsteps++;
+          }
+          close_run();
+          const int ktc = h->kt.begin(LMGPU_KT_SYRK, s);
+          hipLaunchKernelGGL(chain_kernel, dim3(ca.tick[ca.nsteps]), dim3(256), STEP_LDS_BYTES, s, ca);
+          h->kt.end(ktc, s, flop, 1);
+          i += ca.nsteps - 1;
+          continue;
+        }
+        const bool fuse = fusable(i);
         // rows of panel i+1 (and, for i = np-1, of the separator part): a fused step folds them in itself (its 64x64 head tiles
         // cover exactly those rows), otherwise an add kernel does
         const bool fold_in_step = split && fuse && r0 == (i + 1) * NBO;
@@ -1210,6 +1232,7 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
   h->device = cfg->device;
   h->two_launch_panel = getenv("LMGPU_PANEL_2L") != nullptr;
   h->no_fuse = getenv("LMGPU_NO_FUSE") != nullptr;
+  h->no_chain = getenv("LMGPU_NO_CHAIN") != nullptr;
   h->overlap_gather = getenv("LMGPU_OVERLAP") != nullptr;
   *out = h;
   if (h->device >= 0) {
@@ -1237,6 +1260,7 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
     HIPCHECK(hipFuncSetAttribute((const void*)diag_potrf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
     HIPCHECK(hipFuncSetAttribute((const void*)panel_dataflow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PDF_LDS_BYTES));
     HIPCHECK(hipFuncSetAttribute((const void*)step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STEP_LDS_BYTES));
+    HIPCHECK(hipFuncSetAttribute((const void*)chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STEP_LDS_BYTES));
     HIPCHECK(hipFuncSetAttribute((const void*)med_diag_potrf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
     HIPCHECK(hipFuncSetAttribute((const void*)med_syrk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSyrkLds));
   }
@@ -1819,7 +1843,7 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
       if (h->front_active[fi] && P.fronts[fi].cls == 1) max_nf = std::max(max_nf, P.fronts[fi].nf);
     const int max_blk = (max_nf + NB - 1) / NB;
     HIPCHECK(hipMalloc((void**)&h->bs_inv, (size_t)max_blk * NB * NB * sizeof(double)));
-    HIPCHECK(hipMalloc((void**)&h->inv16, 16 * 256 * sizeof(double)));
+    HIPCHECK(hipMalloc((void**)&h->inv16, (size_t)((P.max_front_n + NBO - 1) / NBO + 1) * 16 * 256 * sizeof(double)));  // per step of a chained launch
     h->pflags_panels = (P.max_front_n + NBO - 1) / NBO + 1;
     HIPCHECK(hipMalloc((void**)&h->d_pflags, (size_t)h->pflags_panels * PDF_FLAG_WORDS * sizeof(unsigned int)));
     HIPCHECK(hipMalloc((void**)&h->bs_x, (size_t)max_blk * NB * sizeof(double)));

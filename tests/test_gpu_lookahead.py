@@ -44,7 +44,7 @@ def test_launch_forms_agree_on_a_large_root(monkeypatch):
     params = LevenbergMarquardtParams()
 
     def run(env):
-        for k in ("LMGPU_NO_FUSE", "LMGPU_PANEL_2L"):
+        for k in ("LMGPU_NO_FUSE", "LMGPU_PANEL_2L", "LMGPU_NO_CHAIN"):
             monkeypatch.delenv(k, raising=False)
         for k in env:
             monkeypatch.setenv(k, "1")
@@ -60,7 +60,7 @@ def test_launch_forms_agree_on_a_large_root(monkeypatch):
 
     base = run([])
     assert base[1][-1][0] < 0.05 * base[0]
-    for env in (["LMGPU_NO_FUSE"], ["LMGPU_PANEL_2L"], ["LMGPU_NO_FUSE", "LMGPU_PANEL_2L"]):
+    for env in (["LMGPU_NO_CHAIN"], ["LMGPU_NO_FUSE"], ["LMGPU_PANEL_2L"], ["LMGPU_NO_FUSE", "LMGPU_PANEL_2L"]):
         other = run(env)
         assert other[0] == base[0]
         for a, b in zip(other[1], base[1]):
