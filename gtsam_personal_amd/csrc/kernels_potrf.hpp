@@ -63,8 +63,9 @@ __device__ __forceinline__ bool potrf64_wave_g4(double4_t (&T)[4][4], double4_t 
         double p = m[a][a];
 #pragma unroll
         for (int k = 0; k < a; k++) p -= R[k][a] * R[k][a];
-        failed |= (p <= 0.0);
-        p = (p > 0.0) ? p : ((p == p && p != 0.0) ? fabs(p) : 1.0);
+        const bool pok = p > 0.0;  // one select, no branch: after a failure the factor is garbage either way
+        failed |= !pok;
+        p = pok ? p : 1.0;
         const double rs = fast_rsqrt(p);
         inv[a] = rs;
         R[a][a] = p * rs;

@@ -3,16 +3,18 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../gtsam_personal_amd/csrc tools/microbench.hip -o tools/microbench
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 
-// phase stamps of the diagonal workgroups of panel_dataflow_kernel: flags[512 + 64 b + 2 slot] (two words per 64-bit s_memtime)
+// phase stamps of the diagonal workgroups: flags[512 + 64 b + 2 slot] (two words per 64-bit s_memrealtime: the 100 MHz
+// counter shared by all XCDs, so the stamps of different workgroups lie on one time line)
 #define PDF_STAMP(flags, b, slot)                                                                  \
   do {                                                                                             \
     if ((b) < 4 && threadIdx.x == 0) {                                                             \
       unsigned long long t_;                                                                       \
-      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                   \
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
       *(unsigned long long*)&(flags)[512 + 64 * (b) + 2 * (slot)] = t_;                            \
     }                                                                                              \
   } while (0)
@@ -110,7 +112,7 @@ int main(int argc, char** argv) {
         const unsigned long long t0 = st(b, 0);
         for (int slot = 1; slot < 24; slot++) {
           const unsigned long long t = st(b, slot);
-          if (t) printf(" %s=%.1f", names[slot], (double)(long long)(t - t0) / 2400.0);  // s_memtime ticks at the 2.4 GHz shader clock here
+          if (t) printf(" %s=%.1f", names[slot], (double)(long long)(t - t0) / 100.0);  // 100 MHz
         }
         printf("\n");
       }
@@ -154,9 +156,53 @@ int main(int argc, char** argv) {
         for (int slot = 0; slot < 24; slot++) {
           if (slot == 19) continue;
           const unsigned long long t = st(b, slot);
-          if (t) printf(" %s=%.1f", names[slot], (double)(long long)(t - t0) / 2400.0);  // s_memtime ticks at the 2.4 GHz shader clock here
+          if (t) printf(" %s=%.1f", names[slot], (double)(long long)(t - t0) / 100.0);  // 100 MHz
         }
         printf("\n");
+      }
+    }
+  }
+  // 2b. all fused steps of the matrix as ONE chained launch: total time and the time line of the diagonal workgroups per step
+  {
+    const int np = (n - 1 + 255) / 256;  // nf = n - 1
+    unsigned int* flags;
+    double* inv16;
+    CK(hipMalloc((void**)&flags, (size_t)(np + 2) * PDF_FLAG_WORDS * 4));
+    CK(hipMalloc((void**)&inv16, (size_t)(np + 1) * 16 * 256 * 8));
+    CK(hipFuncSetAttribute((const void*)chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STEP_LDS_BYTES));
+    CK(hipFuncSetAttribute((const void*)panel_dataflow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PDF_LDS_BYTES));
+    auto rows_of = [&](int i) { return std::min(n - 1, (i + 1) * 256) - i * 256; };
+    for (int first : {0, 17}) {
+      ChainArgs ca{A, ld, n, n - 1, first, 0, 0, status, inv16, flags, {0}};
+      while (first + ca.nsteps + 1 < np && rows_of(first + ca.nsteps) == 256 && rows_of(first + ca.nsteps + 1) % 64 == 0 &&
+             n - (first + ca.nsteps + 1) * 256 > 0) {
+        const int ms = n - (first + ca.nsteps + 1) * 256;
+        ca.tick[ca.nsteps + 1] = ca.tick[ca.nsteps] + step_grid(ms, rows_of(first + ca.nsteps + 1));
+        ca.nsteps++;
+      }
+      reset();
+      CK(hipMemset(flags, 0, (size_t)(np + 2) * PDF_FLAG_WORDS * 4));
+      // panel `first` must be factored for the first step (its trailing data are whatever the matrix holds: timing only)
+      hipLaunchKernelGGL(panel_dataflow_kernel, dim3(4 + (n - first * 256 - 256 + 63) / 64), dim3(256), PDF_LDS_BYTES, 0, A, ld, n, n - 1, first * 256, 256,
+                         0, status, inv16, flags + (size_t)first * PDF_FLAG_WORDS);
+      CK(hipDeviceSynchronize());
+      CK(hipEventRecord(e0, 0));
+      hipLaunchKernelGGL(chain_kernel, dim3(ca.tick[ca.nsteps]), dim3(256), STEP_LDS_BYTES, 0, ca);
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      printf("chain_kernel steps %d..%d (%d workgroups): %.1f us\n", first, first + ca.nsteps - 1, ca.tick[ca.nsteps], ms * 1e3);
+      std::vector<unsigned int> hf((size_t)(np + 2) * PDF_FLAG_WORDS);
+      CK(hipMemcpy(hf.data(), flags, hf.size() * 4, hipMemcpyDeviceToHost));
+      auto st = [&](int region, int b, int slot) { return *(unsigned long long*)&hf[(size_t)region * PDF_FLAG_WORDS + 512 + 64 * b + 2 * slot]; };
+      const unsigned long long t0 = st(first + 1, 0, 19);
+      for (int sidx = std::max(0, ca.nsteps - 12); sidx < ca.nsteps; sidx++) {
+        const int reg = first + sidx + 1;
+        auto us = [&](int b, int slot) { return (double)(long long)(st(reg, b, slot) - t0) / 100.0; };
+        printf("  step %2d (m=%4d): wg0 entry %.1f rows %.1f gathered %.1f potrf %.1f pub %.1f | wg1 w0 %.1f potrf %.1f pub %.1f | wg2 pub %.1f | wg3 pub %.1f\n",
+               first + sidx, n - (first + sidx + 1) * 256, us(0, 19), us(0, 0), us(0, 20), us(0, 21), us(0, 23), us(1, 1), us(1, 21), us(1, 23), us(2, 23),
+               us(3, 23));
       }
     }
   }
