@@ -243,14 +243,17 @@ __global__ __launch_bounds__(256, 2) void step_kernel(StepArgs a) {
 }
 
 // ---------------------------------------------------------------- a run of consecutive steps as ONE launch
-// Steps i0 .. i0 + nsteps - 1 of a front (every one with a full 256-row finished panel and a next panel of whole 64-blocks),
-// tickets in step order.  A workgroup of step i + 1 additionally waits for what the launch boundary used to guarantee: the
-// 128-column blocks of panel i + 1 it multiplies with (counted by the row-panel workgroups of step i) and the tile of step
-// i that holds the entries it updates.  Every dependency points to a lower ticket, and a ticket is drawn when a workgroup
-// starts, so a waiting workgroup only ever waits for workgroups that are resident or done.  What it buys: no drain / launch
-// gap (8-10 us) per 256 columns, and the head tiles of step i + 1 start when THEIR columns are final instead of after the
-// slowest row-panel workgroup -- the dependency chain of a step shrinks to four tile stages plus one head tile.
-#define CHAIN_MAX_STEPS 224
+// Steps i0 .. i0 + nsteps - 1 of a front (every one with a full 256-row finished panel and a next panel of whole 64-blocks).
+// Ticket k runs task tasks[k] = (step, logical workgroup of that step); a workgroup of step s + 1 additionally waits for what a
+// launch boundary used to guarantee: the 128-column blocks of panel s + 1 it multiplies with (counted by the row-panel
+// workgroups of step s) and the tile of step s that holds the entries it updates.  The task list (chain_schedule below,
+// built once per front on the host) is a topological order of those dependencies, and a ticket is drawn when a workgroup
+// starts, so a waiting workgroup only ever waits for workgroups that are resident or done.
+// What the order buys.  Right-looking step by step, the early steps have 2000+ update tiles each and the late steps almost
+// none, so the late steps run at the speed of their dependency chain (four tile stages + a head tile, ~85 us per 256 columns)
+// with the matrix cores idle.  The schedule instead gives every step about the same number of update tiles: tiles of the
+// early steps that lie far from the diagonal are deferred (earliest deadline first: a tile row must be complete when it
+// becomes the next panel) and fill the late steps; the chain then runs under the update work from the first panel to the last.
 struct ChainArgs {
   double* A;
   int ld, n, nf;
@@ -259,7 +262,7 @@ struct ChainArgs {
   int* status;
   double* inv16;        // 16 x 256 doubles per step
   unsigned int* flags;  // region of panel p at flags + p * PDF_FLAG_WORDS; the ticket counter is word 0 of panel i0 + 1
-  int tick[CHAIN_MAX_STEPS + 1];  // first ticket of every step, and the total
+  const int2* tasks;    // (step - i0, logical workgroup of that step) per ticket
 };
 
 __global__ __launch_bounds__(256, 2) void chain_kernel(ChainArgs ca) {
@@ -267,15 +270,78 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(ChainArgs ca) {
   __shared__ int s_bid, s_ok;
   if (threadIdx.x == 0) s_bid = (int)atomicAdd(&ca.flags[(size_t)(ca.i0 + 1) * PDF_FLAG_WORDS], 1u);
   __syncthreads();
-  const int ticket = s_bid;
-  int s = 0;
-  while (s + 1 < ca.nsteps && ticket >= ca.tick[s + 1]) s++;
-  const int i = ca.i0 + s;
+  const int2 task = ca.tasks[s_bid];
+  const int s = task.x, i = ca.i0 + s;
   const int kbn = min(ca.nf, (i + 2) * 256) - (i + 1) * 256;
   StepArgs a{ca.A, ca.ld, ca.n, ca.nf, 256 * i, 256, kbn, ca.front_id, ca.status, ca.inv16 + (size_t)s * 4096,
              ca.flags + (size_t)(i + 1) * PDF_FLAG_WORDS, nullptr};
   const ChainLink c{s > 0 ? ca.flags + (size_t)i * PDF_FLAG_WORDS : nullptr, s + 1 < ca.nsteps};
-  step_body(a, ticket - ca.tick[s], c, sm, &s_ok);
+  step_body(a, task.y, c, sm, &s_ok);
+}
+
+}  // namespace lmgpu
+
+// ---- host side: the ticket order of a chained launch
+#include <algorithm>
+#include <vector>
+namespace lmgpu {
+
+// n, nf: front size and frontal rows; steps i0 .. i0 + nsteps - 1.  Per step s the logical workgroups are laid out as in
+// step_body: [head tiles][diagonal workgroups][update tiles, tile rows 2.. row-major][row-panel workgroups].
+// Tile rows are numbered chain-absolutely: tile row ti of step s is R = 2 s + ti; as an update-tile row (ti >= 2) it is touched
+// by the steps 0 .. last(R) = (R - 2) / 2 and must be complete at the end of block last(R), because the head tiles of the
+// next step read it.  Block s of the list:
+//   head tiles + diagonal workgroups of step s,
+//   FAR rows (R >= far_row), first unit           -- a unit = the tiles of one step in one tile row
+//   NEAR rows, their unit of step s (right-looking: always up to date),
+//   FAR rows, second unit,
+//   row-panel workgroups of step s.
+// A far row idles through the first half of its life and then takes two units per block ("as late as two per block allows":
+// completed(R, s) >= last(R) + 1 - 2 (last(R) - s)): the bottom rows of the matrix, which the chain reaches last, keep
+// update work for the late steps, whose own tiles no longer fill the machine.  The two units of a row in one block depend on
+// each other and are placed at the two ends of the block's tile list so that the first is (almost) done when the second is
+// dispatched.  Order of dependencies: a unit (s', R) is listed after (s' - 1, R) and in a block s >= s', i.e. after the
+// row-panel workgroups of step s' - 1; head tiles of step s + 1 come after every unit of the rows they read (mandatory below).
+// far_pct = 100: no far rows, plain step order.
+inline std::vector<int2> chain_schedule(int n, int nf, int i0, int nsteps, int far_pct = 100) {
+  struct StepGeo { int T, S, nTA, nd, nTB, ntrsm; };
+  std::vector<StepGeo> g(nsteps);
+  for (int s = 0; s < nsteps; s++) {
+    const int i = i0 + s, m = n - (i + 1) * 256, kbn = std::min(nf, (i + 2) * 256) - (i + 1) * 256;
+    StepGeo& G = g[s];
+    G.T = (m + 127) / 128;
+    G.S = (m + 63) / 64;
+    G.nTA = step_ta_workgroups(G.S);
+    G.nd = kbn / 64;
+    G.nTB = G.T * (G.T + 1) / 2 - (G.T >= 2 ? 2 * G.T - 1 : G.T);
+    G.ntrsm = (m - kbn + 63) / 64;
+  }
+  const int T0 = g[0].T;
+  const int far_row = std::max(4, (int)((long)T0 * far_pct / 100));
+  std::vector<int> next_step(T0 + 2, 0);  // per tile row: the next step whose unit is to be listed
+  std::vector<int2> tasks;
+  auto last_of = [&](int R) { return std::min(nsteps - 1, (R - 2) / 2); };
+  auto emit_unit = [&](int R) {  // the tiles of step next_step[R] in tile row R
+    const int sp = next_step[R]++, ti = R - 2 * sp, T = g[sp].T;
+    int off = g[sp].nTA + g[sp].nd;
+    for (int r = 2; r < ti; r++) off += T - r;
+    for (int tj = ti; tj < T; tj++) tasks.push_back(int2{sp, off + (tj - ti)});
+  };
+  auto pending = [&](int R, int s) { return next_step[R] <= std::min(s, last_of(R)); };  // a unit of row R that block s may list
+  auto far_need = [&](int R, int s) { return last_of(R) + 1 - 2 * (last_of(R) - s); };   // units a far row must have after block s
+  for (int s = 0; s < nsteps; s++) {
+    for (int t = 0; t < g[s].nTA + g[s].nd; t++) tasks.push_back(int2{s, t});
+    const bool last_block = s + 1 == nsteps;
+    for (int R = std::max(far_row, 2 * s + 2); R < T0; R++)
+      if (pending(R, s) && next_step[R] < far_need(R, s)) emit_unit(R);
+    for (int R = 2 * s + 2; R < std::min(far_row, T0); R++)
+      while (pending(R, s)) emit_unit(R);
+    for (int R = std::max(far_row, 2 * s + 2); R < T0; R++)
+      while (pending(R, s) && (next_step[R] < far_need(R, s) || R <= 2 * s + 3 || last_block)) emit_unit(R);
+    const int first_trsm = g[s].nTA + g[s].nd + g[s].nTB;
+    for (int t = 0; t < g[s].ntrsm; t++) tasks.push_back(int2{s, first_trsm + t});
+  }
+  return tasks;
 }
 
 }  // namespace lmgpu

@@ -24,6 +24,7 @@
 #include <limits>
 #include <mutex>
 #include <string>
+#include <map>
 #include <vector>
 
 #include "../../include/lmgpu.h"
@@ -199,6 +200,9 @@ struct lmgpu_handle {
   double* inv16 = nullptr;                     // 16 x (16x16) inverses of the current outer panel's diagonal tiles
   bool two_launch_panel = false;               // LMGPU_PANEL_2L=1: diag_potrf + panel_trsm for every outer panel (A/B)
   bool no_fuse = false;                        // LMGPU_NO_FUSE=1: trailing update and next panel as separate launches (A/B)
+  struct ChainPlan { int i0 = -1, nsteps = 0, ntasks = 0; int2* d_tasks = nullptr; double flop = 0; };
+  std::map<int, ChainPlan> chain_plans;        // per HBM front: ticket order of its chained launch (built at first use)
+  int chain_far_pct = 50;                      // LMGPU_CHAIN_FAR: tile rows beyond this percentage of the front are scheduled late (chain_schedule)
   bool no_chain = false;                       // LMGPU_NO_CHAIN=1: one launch per fused step instead of one per run of steps (A/B)
   unsigned int* d_pflags = nullptr;            // hand-off flags of panel_dataflow_kernel, PDF_FLAG_WORDS per outer panel
   int pflags_panels = 0;
@@ -716,19 +720,29 @@ int do_eliminate(lmgpu_handle* h, double lambda) {
         const int k0 = i * NBO, kb = rows_of(i), r0 = k0 + kb, m = F.n - r0;
         if (m <= 0) break;
         if (chainable(i) && chainable(i + 1)) {
-          ChainArgs ca{A, ld, F.n, F.nf, i, 0, F.id, h->d_status, h->inv16, h->d_pflags, {0}};
-          double flop = 0;
-          while (ca.nsteps < CHAIN_MAX_STEPS && chainable(i + ca.nsteps)) {
-            const int is = i + ca.nsteps, ms = F.n - (is + 1) * NBO;
-            ca.tick[ca.nsteps + 1] = ca.tick[ca.nsteps] + step_grid(ms, rows_of(is + 1));
-            flop += 2.0 * NBO * ((double)ms * (ms + 1) / 2.0) + panel_flop(is + 1);
-            ca.nsteps++;
+          // the run of chainable steps starting here: one launch, ticket order built once per front (chain_schedule)
+          lmgpu_handle::ChainPlan& cp = h->chain_plans[fi];
+          if (cp.i0 != i) {
+            if (cp.d_tasks) HIPCHECK(hipFree(cp.d_tasks));
+            cp = lmgpu_handle::ChainPlan{};
+            cp.i0 = i;
+            while (chainable(i + cp.nsteps)) {
+              const int is = i + cp.nsteps, ms = F.n - (is + 1) * NBO;
+              cp.flop += 2.0 * NBO * ((double)ms * (ms + 1) / 2.0) + panel_flop(is + 1);
+              cp.nsteps++;
+            }
+            const std::vector<int2> tasks = chain_schedule(F.n, F.nf, i, cp.nsteps, h->chain_far_pct);
+            cp.ntasks = (int)tasks.size();
+            HIPCHECK(hipMalloc((void**)&cp.d_tasks, tasks.size() * sizeof(int2)));
+            HIPCHECK(hipMemcpyAsync(cp.d_tasks, tasks.data(), tasks.size() * sizeof(int2), hipMemcpyHostToDevice, s));
+            HIPCHECK(hipStreamSynchronize(s));  // `tasks` is a local
           }
+          ChainArgs ca{A, ld, F.n, F.nf, i, cp.nsteps, F.id, h->d_status, h->inv16, h->d_pflags, cp.d_tasks};
           close_run();
           const int ktc = h->kt.begin(LMGPU_KT_SYRK, s);
-          hipLaunchKernelGGL(chain_kernel, dim3(ca.tick[ca.nsteps]), dim3(256), STEP_LDS_BYTES, s, ca);
-          h->kt.end(ktc, s, flop, 1);
-          i += ca.nsteps - 1;
+          hipLaunchKernelGGL(chain_kernel, dim3(cp.ntasks), dim3(256), STEP_LDS_BYTES, s, ca);
+          h->kt.end(ktc, s, cp.flop, 1);
+          i += cp.nsteps - 1;
           continue;
         }
         const bool fuse = fusable(i);
@@ -1233,6 +1247,7 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
   h->two_launch_panel = getenv("LMGPU_PANEL_2L") != nullptr;
   h->no_fuse = getenv("LMGPU_NO_FUSE") != nullptr;
   h->no_chain = getenv("LMGPU_NO_CHAIN") != nullptr;
+  if (const char* e = getenv("LMGPU_CHAIN_FAR")) h->chain_far_pct = std::max(10, std::min(100, atoi(e)));
   h->overlap_gather = getenv("LMGPU_OVERLAP") != nullptr;
   *out = h;
   if (h->device >= 0) {
@@ -1293,6 +1308,7 @@ int lmgpu_destroy(lmgpu_handle* h) {
       if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     for (hipEvent_t e : h->kt.pool) (void)hipEventDestroy(e);
     fr(h->bs_inv); fr(h->bs_x); fr(h->bs_flags); fr(h->inv16); fr(h->d_pflags);
+    for (auto& kv : h->chain_plans) fr(kv.second.d_tasks);
     fr(h->d_gpblk); fr(h->d_gpent); fr(h->d_gvblk); fr(h->d_gvent); fr(h->d_gcorner);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
@@ -2186,6 +2202,86 @@ int lmgpu_local_group_create(int32_t world_size, lmgpu_local_group** out) {
   *out = g;
   return LMGPU_OK;
 }
+// Host-only check of the ticket order of a chained launch (kernels_step.hpp: chain_schedule): every logical workgroup of every
+// step exactly once, and every dependency step_body waits for at an earlier ticket.  0 = valid, else the 1-based ticket at fault.
+int lmgpu_selftest_chain_schedule(int n, int nf, int i0, int nsteps, int far_pct) {
+  if (nsteps < 1 || n <= nf || nf < (i0 + nsteps + 1) * 256 - 255) return -1;
+  const std::vector<int2> tasks = chain_schedule(n, nf, i0, nsteps, far_pct);
+  struct Geo { int T, S, nHead, nTA, nd, nTB, ntrsm, grid; };
+  std::vector<Geo> g(nsteps);
+  std::vector<std::vector<int>> pos(nsteps);
+  long total = 0;
+  for (int s = 0; s < nsteps; s++) {
+    const int i = i0 + s, m = n - (i + 1) * 256, kbn = std::min(nf, (i + 2) * 256) - (i + 1) * 256;
+    if (m <= 0 || kbn <= 0 || kbn % 64) return -1;
+    Geo& G = g[s];
+    G.T = (m + 127) / 128;
+    G.S = (m + 63) / 64;
+    G.nHead = 4 * step_head_units(G.S);
+    G.nTA = step_ta_workgroups(G.S);
+    G.nd = kbn / 64;
+    G.nTB = G.T * (G.T + 1) / 2 - (G.T >= 2 ? 2 * G.T - 1 : G.T);
+    G.ntrsm = (m - kbn + 63) / 64;
+    G.grid = step_grid(m, kbn);
+    if (G.grid != G.nTA + G.nd + G.nTB + G.ntrsm) return -1;
+    pos[s].assign(G.grid, -1);
+    total += G.grid;
+  }
+  if ((long)tasks.size() != total) return -2;
+  for (size_t k = 0; k < tasks.size(); k++) {
+    const int s = tasks[k].x, t = tasks[k].y;
+    if (s < 0 || s >= nsteps || t < 0 || t >= g[s].grid || pos[s][t] >= 0) return (int)k + 1;
+    pos[s][t] = (int)k;
+  }
+  auto tb_index = [&](int s, int ti, int tj) {  // logical workgroup of update tile (ti, tj), ti >= 2
+    int off = g[s].nTA + g[s].nd;
+    for (int r = 2; r < ti; r++) off += g[s].T - r;
+    return off + (tj - ti);
+  };
+  for (int s = 0; s < nsteps; s++) {
+    const Geo& G = g[s];
+    int last_prev_trsm = -1, last_ta = -1, last_diag = -1;
+    if (s > 0)
+      for (int t = 0; t < g[s - 1].ntrsm; t++) last_prev_trsm = std::max(last_prev_trsm, pos[s - 1][g[s - 1].nTA + g[s - 1].nd + g[s - 1].nTB + t]);
+    for (int t = 0; t < G.nTA; t++) last_ta = std::max(last_ta, pos[s][t]);
+    for (int t = 0; t < G.nd; t++) last_diag = std::max(last_diag, pos[s][G.nTA + t]);
+    for (int t = 0; t < G.grid; t++) {
+      const int me = pos[s][t];
+      int ti = -1, tj = -1;  // 128-tile whose entries this workgroup updates (none for the panel roles)
+      if (t < G.nTA) {
+        int si, sj;
+        if (t < G.nHead) {
+          const int u = t >> 2;
+          sj = (u >= 6) ? 3 : ((u >= 3) ? 2 : (u >= 1 ? 1 : 0));
+          si = u - sj * (sj + 1) / 2;
+        } else {
+          sj = 4 + ((t - G.nHead) >> 2);
+          si = (t - G.nHead) & 3;
+        }
+        ti = si >> 1;
+        tj = sj >> 1;
+      } else if (t < G.nTA + G.nd) {
+        if (me < last_ta) return me + 1;  // diagonal workgroups read the head tiles
+      } else if (t < G.nTA + G.nd + G.nTB) {
+        int rem = t - G.nTA - G.nd;
+        ti = 2;
+        while (rem >= G.T - ti) {
+          rem -= G.T - ti;
+          ti++;
+        }
+        tj = ti + rem;
+      } else {
+        if (me < last_ta || me < last_diag) return me + 1;  // row-panel workgroups read head tiles and diagonal tiles
+      }
+      if (ti >= 0 && s > 0) {
+        if (me < last_prev_trsm) return me + 1;
+        if (me < pos[s - 1][tb_index(s - 1, ti + 2, tj + 2)]) return me + 1;
+      }
+    }
+  }
+  return 0;
+}
+
 int lmgpu_local_group_destroy(lmgpu_local_group* g) {
   delete g;
   return LMGPU_OK;

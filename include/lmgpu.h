@@ -229,6 +229,12 @@ int lmgpu_comm_init(lmgpu_handle* h, const char id128[128]);
 typedef struct lmgpu_local_group lmgpu_local_group;
 int lmgpu_local_group_create(int32_t world_size, lmgpu_local_group** out);
 int lmgpu_local_group_destroy(lmgpu_local_group* g);
+
+/* Host-only self-test (no GPU work): the ticket order the library gives the chained factorisation launch of a dense front
+ * with n columns (nf frontal) for the steps i0 .. i0 + nsteps - 1 (tile rows beyond far_pct percent scheduled late) is a permutation of all logical workgroups in which every
+ * in-launch dependency points to an earlier ticket.  0 = valid.  No reference counterpart (the reference factors a front with
+ * one Eigen LLT call, gtsam/base/cholesky.cpp:108-159); it exists so that the CPU test-suite can check the scheduler. */
+int lmgpu_selftest_chain_schedule(int n, int nf, int i0, int nsteps, int far_pct);
 int lmgpu_comm_init_local(lmgpu_handle* h, lmgpu_local_group* g);
 
 /* ---- micro-benchmarks used by bench.py for roofline peaks (device-only, no graph needed) ---- */

@@ -44,10 +44,10 @@ def test_launch_forms_agree_on_a_large_root(monkeypatch):
     params = LevenbergMarquardtParams()
 
     def run(env):
-        for k in ("LMGPU_NO_FUSE", "LMGPU_PANEL_2L", "LMGPU_NO_CHAIN"):
+        for k in ("LMGPU_NO_FUSE", "LMGPU_PANEL_2L", "LMGPU_NO_CHAIN", "LMGPU_CHAIN_FAR"):
             monkeypatch.delenv(k, raising=False)
         for k in env:
-            monkeypatch.setenv(k, "1")
+            monkeypatch.setenv(k, "100" if k == "LMGPU_CHAIN_FAR" else "1")  # CHAIN_FAR=100: plain step order in the chained launch
         opt = LevenbergMarquardtOptimizer(graph, initial, ordering, params, device=0)  # the switches are read at creation
         e0 = opt.error()
         trace = []
@@ -60,7 +60,7 @@ def test_launch_forms_agree_on_a_large_root(monkeypatch):
 
     base = run([])
     assert base[1][-1][0] < 0.05 * base[0]
-    for env in (["LMGPU_NO_CHAIN"], ["LMGPU_NO_FUSE"], ["LMGPU_PANEL_2L"], ["LMGPU_NO_FUSE", "LMGPU_PANEL_2L"]):
+    for env in (["LMGPU_CHAIN_FAR"], ["LMGPU_NO_CHAIN"], ["LMGPU_NO_FUSE"], ["LMGPU_PANEL_2L"], ["LMGPU_NO_FUSE", "LMGPU_PANEL_2L"]):
         other = run(env)
         assert other[0] == base[0]
         for a, b in zip(other[1], base[1]):

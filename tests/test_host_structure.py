@@ -94,3 +94,23 @@ def test_fronts_match_oracle_pose2_grid_all_orderings():
     graph, initial = _pose2_grid()
     for ordering in (oh.colamd(graph), oh.metis(graph), Ordering.Natural(graph), Ordering.Natural(graph)[::-1]):
         _structure_matches(graph, initial, ordering)
+
+
+@pytest.mark.parametrize("far_pct", [100, 70, 55, 30, 10])
+def test_chained_launch_ticket_order_is_a_topological_order(far_pct):
+    """The chained factorisation launch of a dense front (kernels_step.hpp) hands its logical workgroups out by ticket; a
+    workgroup spins for workgroups it depends on, so every dependency must hold an earlier ticket or the launch could hang.
+    The library checks its own schedule on the host (no GPU): every workgroup of every step exactly once, dependencies
+    earlier.  Front shapes: the C4 root (9001 x 9001), the 600-camera root, separator-heavy and small fronts."""
+    lib = _lib.load()
+    checked = 0
+    for n, nf in [(9001, 9000), (5401, 5400), (2000, 1500), (1081, 1080), (30000, 29000), (10000, 4000), (777, 770), (4097, 4096)]:
+        n_panels = (nf + 255) // 256
+        rows = lambda i: min(nf, (i + 1) * 256) - i * 256
+        steps = [i for i in range(n_panels - 1) if rows(i) == 256 and rows(i + 1) % 64 == 0 and n - (i + 1) * 256 > 0]
+        for first, count in ((0, len(steps)), (1, len(steps) - 1), (0, 2)):
+            if count >= 2 and first + count <= len(steps):
+                assert lib.lmgpu_selftest_chain_schedule(n, nf, steps[first], count, far_pct) == 0, (n, nf, first, count)
+                checked += 1
+    assert checked >= 12
+    assert lib.lmgpu_selftest_chain_schedule(100, 200, 0, 2, far_pct) != 0  # nonsense geometry is refused, not "valid"

@@ -173,13 +173,13 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute((const void*)panel_dataflow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PDF_LDS_BYTES));
     auto rows_of = [&](int i) { return std::min(n - 1, (i + 1) * 256) - i * 256; };
     for (int first : {0, 17}) {
-      ChainArgs ca{A, ld, n, n - 1, first, 0, 0, status, inv16, flags, {0}};
-      while (first + ca.nsteps + 1 < np && rows_of(first + ca.nsteps) == 256 && rows_of(first + ca.nsteps + 1) % 64 == 0 &&
-             n - (first + ca.nsteps + 1) * 256 > 0) {
-        const int ms = n - (first + ca.nsteps + 1) * 256;
-        ca.tick[ca.nsteps + 1] = ca.tick[ca.nsteps] + step_grid(ms, rows_of(first + ca.nsteps + 1));
-        ca.nsteps++;
-      }
+      int nsteps = 0;
+      while (first + nsteps + 1 < np && rows_of(first + nsteps) == 256 && rows_of(first + nsteps + 1) % 64 == 0 && n - (first + nsteps + 1) * 256 > 0) nsteps++;
+      const std::vector<int2> tasks = chain_schedule(n, n - 1, first, nsteps, argc > 2 ? atoi(argv[2]) : 50);
+      int2* d_tasks;
+      CK(hipMalloc((void**)&d_tasks, tasks.size() * sizeof(int2)));
+      CK(hipMemcpy(d_tasks, tasks.data(), tasks.size() * sizeof(int2), hipMemcpyHostToDevice));
+      ChainArgs ca{A, ld, n, n - 1, first, nsteps, 0, status, inv16, flags, d_tasks};
       reset();
       CK(hipMemset(flags, 0, (size_t)(np + 2) * PDF_FLAG_WORDS * 4));
       // panel `first` must be factored for the first step (its trailing data are whatever the matrix holds: timing only)
@@ -187,12 +187,12 @@ int main(int argc, char** argv) {
                          0, status, inv16, flags + (size_t)first * PDF_FLAG_WORDS);
       CK(hipDeviceSynchronize());
       CK(hipEventRecord(e0, 0));
-      hipLaunchKernelGGL(chain_kernel, dim3(ca.tick[ca.nsteps]), dim3(256), STEP_LDS_BYTES, 0, ca);
+      hipLaunchKernelGGL(chain_kernel, dim3((int)tasks.size()), dim3(256), STEP_LDS_BYTES, 0, ca);
       CK(hipEventRecord(e1, 0));
       CK(hipEventSynchronize(e1));
       float ms;
       CK(hipEventElapsedTime(&ms, e0, e1));
-      printf("chain_kernel steps %d..%d (%d workgroups): %.1f us\n", first, first + ca.nsteps - 1, ca.tick[ca.nsteps], ms * 1e3);
+      printf("chain_kernel steps %d..%d (%d workgroups): %.1f us\n", first, first + ca.nsteps - 1, (int)tasks.size(), ms * 1e3);
       std::vector<unsigned int> hf((size_t)(np + 2) * PDF_FLAG_WORDS);
       CK(hipMemcpy(hf.data(), flags, hf.size() * 4, hipMemcpyDeviceToHost));
       auto st = [&](int region, int b, int slot) { return *(unsigned long long*)&hf[(size_t)region * PDF_FLAG_WORDS + 512 + 64 * b + 2 * slot]; };
