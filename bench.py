@@ -177,14 +177,21 @@ def main():
             "setup_s": t_setup,
         }
         if kt is not None:
-            syrk, lin = kt["syrk"], kt["linearize"]
+            lin = kt["linearize"]
+            # the dense camera front: all its fused steps are ONE chain_kernel launch; without chaining (LMGPU_NO_CHAIN, split root)
+            # the same work is one step_kernel launch per 256 columns
+            chained = kt["chain"]["launches"] > 0
+            syrk = kt["chain"] if chained else kt["syrk"]
             pmc = pmc_traffic()
             if syrk["launches"] > 0 and syrk["ms"] > 0:
                 tf = syrk["work"] / (syrk["ms"] * 1e-3) / 1e12
-                out["roofline"] = {"kernel": "step_kernel (v_mfma_f64_16x16x4_f64: trailing update of the dense camera front with outer panel i "
-                                             "+ factorisation of panel i+1 in the same launch)",
+                kname = "chain_kernel" if chained else "step_kernel"
+                out["roofline"] = {"kernel": kname + (" (v_mfma_f64_16x16x4_f64: every trailing update of the dense camera front and the factorisation of "
+                                                      "its 256-column panels, tile-level dataflow inside one launch)" if chained else
+                                                      " (v_mfma_f64_16x16x4_f64: trailing update of the dense camera front with outer panel i "
+                                                      "+ factorisation of panel i+1 in the same launch)"),
                                    "bound": "mfma", "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": tf / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc.get("step_kernel"),
+                                   "frac": tf / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc.get(kname),
                                    "traffic_unit": "HBM bytes per launch (FETCH_SIZE x 2 gfx950 correction + WRITE_SIZE; profiles/r01/pmc_summary.json)",
                                    "launches": syrk["launches"], "avg_launch_us": 1e3 * syrk["ms"] / syrk["launches"],
                                    "flop_per_launch": syrk["work"] / syrk["launches"]}

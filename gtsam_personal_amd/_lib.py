@@ -87,7 +87,7 @@ SYMBOLS = {
     "lmgpu_peak_hbm_copy": (ct.c_int, [ct.c_int32, ct.c_int64, ct.c_int32, _D]),
 }
 
-KT_NAMES = ("linearize", "lds_front", "hbm_assemble", "panel", "syrk", "backsub_hbm", "backsub_lds", "linear_error", "retract_error", "allreduce")
+KT_NAMES = ("linearize", "lds_front", "hbm_assemble", "panel", "syrk", "backsub_hbm", "backsub_lds", "linear_error", "retract_error", "allreduce", "chain")
 
 _lib = None
 

@@ -739,7 +739,7 @@ int do_eliminate(lmgpu_handle* h, double lambda) {
           }
           ChainArgs ca{A, ld, F.n, F.nf, i, cp.nsteps, F.id, h->d_status, h->inv16, h->d_pflags, cp.d_tasks};
           close_run();
-          const int ktc = h->kt.begin(LMGPU_KT_SYRK, s);
+          const int ktc = h->kt.begin(LMGPU_KT_CHAIN, s);
           hipLaunchKernelGGL(chain_kernel, dim3(cp.ntasks), dim3(256), STEP_LDS_BYTES, s, ca);
           h->kt.end(ktc, s, cp.flop, 1);
           i += cp.nsteps - 1;

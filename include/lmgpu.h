@@ -196,13 +196,14 @@ enum lmgpu_kernel_category {
   LMGPU_KT_LDS_FRONT = 1,   /* lds_front_kernel (assemble + partial Cholesky of one small front per workgroup) */
   LMGPU_KT_HBM_ASSEMBLE = 2,/* memset + factor / child extend-add / Schur gather + damping of an HBM front */
   LMGPU_KT_PANEL = 3,       /* panel factorisations launched on their own: panel_dataflow_kernel, diag_potrf_kernel + panel_trsm_kernel */
-  LMGPU_KT_SYRK = 4,        /* step_kernel = trailing update (v_mfma_f64_16x16x4_f64) + the next panel in the same launch; syrk_mfma_kernel */
+  LMGPU_KT_SYRK = 4,        /* step_kernel = trailing update (v_mfma_f64_16x16x4_f64) + the next panel in the same launch (steps outside a chained launch); syrk_mfma_kernel */
   LMGPU_KT_BACKSUB_HBM = 5,
   LMGPU_KT_BACKSUB_LDS = 6,
   LMGPU_KT_LINEAR_ERROR = 7,
   LMGPU_KT_RETRACT_ERROR = 8,
   LMGPU_KT_ALLREDUCE = 9,
-  LMGPU_KT_NUM = 10
+  LMGPU_KT_CHAIN = 10,      /* chain_kernel = all fused steps of a dense front (updates + panel factorisations) as ONE launch */
+  LMGPU_KT_NUM = 11
 };
 int lmgpu_set_kernel_timing(lmgpu_handle* h, int32_t on);
 int lmgpu_get_kernel_times(const lmgpu_handle* h, double* ms /*[LMGPU_KT_NUM]*/, double* work /*[LMGPU_KT_NUM]*/, int64_t* launches /*[LMGPU_KT_NUM]*/);
