@@ -223,6 +223,48 @@ def test_hbm_front_with_odd_dimensions_and_separator():
     _check_lm(opt, orc, params)
 
 
+def _two_level_dense_pose2(n_a, n_b1, n_b2, seed=5):
+    """dense cluster A (all pairs) whose poses also see every pose of B1; B = B1 u B2 is a dense cluster of its own.  Ordered
+    A, B1, B2 the clique of A has B1 as its separator and is NOT merged into its parent (B2 is missing from the separator)."""
+    rng = np.random.default_rng(seed)
+    n = n_a + n_b1 + n_b2
+    truth = np.stack([rng.uniform(-20, 20, n), rng.uniform(-20, 20, n), rng.uniform(-3, 3, n)], axis=1)
+    graph, initial = NonlinearFactorGraph(), Values()
+    for i in range(n):
+        initial.insert_pose2(i, truth[i, 0] + rng.normal(0, 0.05), truth[i, 1] + rng.normal(0, 0.05), truth[i, 2] + rng.normal(0, 0.02))
+    model = noiseModel.Diagonal.Sigmas([0.3, 0.3, 0.1])
+
+    def add(a, b):
+        xa, ya, ta = truth[a]
+        xb, yb, tb = truth[b]
+        c, s = np.cos(ta), np.sin(ta)
+        graph.add_BetweenFactorPose2(a, b, [c * (xb - xa) + s * (yb - ya), -s * (xb - xa) + c * (yb - ya), np.arctan2(np.sin(tb - ta), np.cos(tb - ta))], model)
+    for a in range(n_a):
+        for b in range(a + 1, n_a + n_b1):
+            add(a, b)
+    for a in range(n_a, n):
+        for b in range(a + 1, n):
+            add(a, b)
+    graph.add_PriorFactorPose2(n - 1, list(truth[n - 1]), noiseModel.Diagonal.Sigmas([0.05, 0.05, 0.02]))
+    return graph, initial, Ordering(list(range(n)))
+
+
+def test_chained_front_with_wide_separator():
+    """A dense front BELOW the root: 1200 frontal columns (5 outer panels) and a 150-column separator, so its first three
+    steps go as one chained launch (kernels_step.hpp) whose update tiles, column-block counters and deferred tile rows
+    cover separator columns and a ragged last 128-block (1351 = 10 x 128 + 71); its parent is a second dense front.
+    [R S d] of every front, delta and the LM trajectory against the oracle."""
+    graph, initial, ordering = _two_level_dense_pose2(400, 50, 50)
+    opt, orc, params = _pair(graph, initial, ordering)
+    big = max(range(opt.num_fronts()), key=lambda i: opt.front_info(i)["nf"])
+    info = opt.front_info(big)
+    assert info["cls"] == 1 and info["nf"] == 1200 and info["n"] == 1351
+    opt.linearize()
+    orc.linearize()
+    _check_solve(opt, orc, 1e-3)
+    _check_lm(opt, orc, params)
+
+
 def test_pose3_slam_example_file():
     """examples/Data/pose3example.txt (g2o 3D; committed fixture) as in examples/Pose3SLAMExample_g2o.cpp:42-48"""
     graph, initial = load3D(os.path.join(GOLD, "pose3example.txt"))
