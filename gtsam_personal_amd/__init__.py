@@ -6,4 +6,5 @@ graph / optimizer interface (graph.py, optimizer.py) and the data formats either
 (datasets.py, synthetic.py).  Importing the package does not load the GPU library; constructing a
 LevenbergMarquardtOptimizer does, and fails loudly if liblmgpu.so has not been built."""
 from .graph import (CAM_BUNDLER, POINT3, POSE2, POSE3, C, L, NonlinearFactorGraph, Ordering, P, Values, X, noiseModel, symbol)  # noqa: F401
-from .optimizer import DoglegOptimizer, DoglegParams, GaussNewtonOptimizer, GaussNewtonParams, LevenbergMarquardtOptimizer, LevenbergMarquardtParams  # noqa: F401
+from .optimizer import (DoglegOptimizer, DoglegParams, GaussNewtonOptimizer, GaussNewtonParams, LevenbergMarquardtOptimizer,  # noqa: F401
+                        LevenbergMarquardtParams, Marginals)

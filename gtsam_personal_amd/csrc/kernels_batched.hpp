@@ -33,12 +33,13 @@ __global__ __launch_bounds__(256) void med_assemble_children_kernel(MedLevel L, 
 }
 
 __global__ __launch_bounds__(256) void med_damp_kernel(MedLevel L, const int32_t* __restrict__ fxoff, double* __restrict__ pool, double lambda,
-                                                        const double* __restrict__ dampw) {
+                                                        const double* __restrict__ dampw, const double* __restrict__ gex) {
   const int fi = L.list[blockIdx.y];
   const FrontDesc F = L.fronts[fi];
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= F.nf) return;
   pool[L.f_off[fi] + (size_t)i * L.f_ld[fi] + i] += lambda * dampw[fxoff[F.fx_begin + i]];
+  if (gex) pool[L.f_off[fi] + (size_t)i * L.f_ld[fi] + F.n - 1] += gex[fxoff[F.fx_begin + i]];
 }
 
 // the whole frontal block [0, nf) x [0, nf) of each front: one workgroup per front

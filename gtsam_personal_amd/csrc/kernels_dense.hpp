@@ -85,10 +85,12 @@ __global__ __launch_bounds__(256) void hbm_assemble_children_kernel(FrontDesc F,
 }
 
 __global__ __launch_bounds__(256) void hbm_damp_kernel(FrontDesc F, int64_t f_off, int ld, const int32_t* __restrict__ fxoff,
-                                                        double* __restrict__ pool, double lambda, const double* __restrict__ dampw) {
+                                                        double* __restrict__ pool, double lambda, const double* __restrict__ dampw,
+                                                        const double* __restrict__ gex) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= F.nf) return;
   pool[f_off + (size_t)i * ld + i] += lambda * dampw[fxoff[F.fx_begin + i]];
+  if (gex) pool[f_off + (size_t)i * ld + F.n - 1] += gex[fxoff[F.fx_begin + i]];
 }
 
 // ---------------------------------------------------------------- trailing update on the matrix cores

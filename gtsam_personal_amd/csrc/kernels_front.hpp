@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void lds_front_kernel(const int32_t* __restric
                                                          const ChildRef* __restrict__ childs, const int32_t* __restrict__ cmap,
                                                          const int32_t* __restrict__ fxoff, double* __restrict__ pool, double lambda,
                                                          const double* __restrict__ dampw, int* __restrict__ status, int nmax, int srows,
-                                                         double* __restrict__ gcorner, int jcap) {
+                                                         double* __restrict__ gcorner, int jcap, const double* __restrict__ gex) {
   extern __shared__ double S[];
   double* corner_g = S + (size_t)srows * nmax;  // GATHER: the (rhs, rhs) entry lives here
   double* Jb = corner_g + 8;
@@ -198,7 +198,10 @@ __global__ __launch_bounds__(256) void lds_front_kernel(const int32_t* __restric
     __syncthreads();
   }
   // ---- damping on the frontal diagonal
-  for (int i = tid; i < nf; i += nt) S[i * n + i] += lambda * dampw[fxoff[F.fx_begin + i]];
+  for (int i = tid; i < nf; i += nt) {
+    S[i * n + i] += lambda * dampw[fxoff[F.fx_begin + i]];
+    if (gex) S[i * n + n - 1] += gex[fxoff[F.fx_begin + i]];  // extra gradient term eta += g (marginal covariances: unit vectors)
+  }
   // ---- partial Cholesky (right-looking, row k of R at a time)
   bool failed = false;
   for (int k = 0; k < nf; k++) {

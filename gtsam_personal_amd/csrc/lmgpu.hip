@@ -262,6 +262,8 @@ struct lmgpu_handle {
   std::vector<LevelWork> levels;
   int ntot = 0, nstore = 0;
   bool dampw_is_ones = false;
+  double* gex = nullptr;         // ntot doubles: extra gradient vector for solves with a prescribed right-hand side (marginals)
+  double* gex_active = nullptr;  // == gex while such a solve is being assembled, else nullptr
 
   // ---- LM
   lmgpu_lm_state lm{};
@@ -516,12 +518,14 @@ int do_eliminate(lmgpu_handle* h, double lambda) {
         hipLaunchKernelGGL(lds_front_kernel<false>, dim3(cnt), dim3(threads), lds, s,
                            (const int32_t*)(h->d_lists + L.list_begin + L.bin_begin[b]), (const FrontDesc*)h->d_fronts,
                            (const FrontFac*)h->d_ffac, (const FacDesc*)h->d_fd, (const ChildRef*)h->d_childs, (const int32_t*)h->d_cmap,
-                           (const int32_t*)h->d_fxoff, h->pool, lambda, (const double*)h->dampw, h->d_status, nmax, srows, h->d_gcorner, jcap);
+                           (const int32_t*)h->d_fxoff, h->pool, lambda, (const double*)h->dampw, h->d_status, nmax, srows, h->d_gcorner, jcap,
+                           (const double*)h->gex_active);
       else
         hipLaunchKernelGGL(lds_front_kernel<true>, dim3(cnt), dim3(threads), lds, s,
                            (const int32_t*)(h->d_lists + L.list_begin + L.bin_begin[b]), (const FrontDesc*)h->d_fronts,
                            (const FrontFac*)h->d_ffac, (const FacDesc*)h->d_fd, (const ChildRef*)h->d_childs, (const int32_t*)h->d_cmap,
-                           (const int32_t*)h->d_fxoff, h->pool, lambda, (const double*)h->dampw, h->d_status, nmax, srows, h->d_gcorner, jcap);
+                           (const int32_t*)h->d_fxoff, h->pool, lambda, (const double*)h->dampw, h->d_status, nmax, srows, h->d_gcorner, jcap,
+                           (const double*)h->gex_active);
       h->kt.end(kt, s);
     }
     if (L.med_count > 0) {  // medium fronts of this level: six launches for all of them
@@ -536,7 +540,7 @@ int do_eliminate(lmgpu_handle* h, double lambda) {
         hipLaunchKernelGGL(med_assemble_children_kernel, dim3(L.med_max_child, cnt), dim3(256), 0, s, ML, (const ChildRef*)h->d_childs,
                            (const int32_t*)h->d_cmap, h->pool);
       hipLaunchKernelGGL(med_damp_kernel, dim3((L.med_max_nf + 255) / 256, cnt), dim3(256), 0, s, ML, (const int32_t*)h->d_fxoff, h->pool, lambda,
-                         (const double*)h->dampw);
+                         (const double*)h->dampw, (const double*)h->gex_active);
       h->kt.end(ktm, s);
       ktm = h->kt.begin(LMGPU_KT_PANEL, s);
       hipLaunchKernelGGL(med_diag_potrf_kernel, dim3(cnt), dim3(256), DIAG_LDS_BYTES, s, ML, h->pool, h->d_status, h->inv16_med);
@@ -597,7 +601,7 @@ int do_eliminate(lmgpu_handle* h, double lambda) {
                            (const int32_t*)h->d_cmap, h->pool);
       if (own_terms)
         hipLaunchKernelGGL(hbm_damp_kernel, dim3((F.nf + 255) / 256), dim3(256), 0, sa, F, aoff, ld, (const int32_t*)h->d_fxoff, h->pool, lambda,
-                           (const double*)h->dampw);
+                           (const double*)h->dampw, (const double*)h->gex_active);
       // leaf children in Schur form: deterministic gather instead of atomics; rows [c0, c1) of the chunk table
       auto gather_chunks = [&](int c0, int c1, bool whole) {
         const int s0 = whole ? 0 : G.cs[c0], s1 = whole ? G.pblk_short : G.cs[c1];
@@ -1296,7 +1300,7 @@ int lmgpu_destroy(lmgpu_handle* h) {
       for (int t = 0; t < 4; t++) fr(h->vals[w][t]);
     for (int t = 0; t < 4; t++) fr(h->type_xoff[t]);
     for (int t = 0; t < 4; t++) fr(h->saved[t]);
-    fr(h->delta); fr(h->dampw); fr(h->hdiag); fr(h->ebuf0); fr(h->ebuf1); fr(h->partial); fr(h->dscal); fr(h->ywork); fr(h->d_status);
+    fr(h->gex); fr(h->delta); fr(h->dampw); fr(h->hdiag); fr(h->ebuf0); fr(h->ebuf1); fr(h->partial); fr(h->dscal); fr(h->ywork); fr(h->d_status);
     fr(h->d_fd); fr(h->d_fronts); fr(h->d_ffac); fr(h->d_childs); fr(h->d_cmap); fr(h->d_fxoff); fr(h->d_sxoff); fr(h->d_lists); fr(h->d_hbm_small); fr(h->d_med_list); fr(h->inv16_med); fr(h->bt_ebuf); fr(h->bt_vec); fr(h->d_f_ld); fr(h->d_f_off);
     fr(h->d_scalar_var); fr(h->d_scalar_col); fr(h->d_vi_ptr); fr(h->d_vi_fac); fr(h->d_vi_pos);
     for (Bucket& b : h->buckets) {
@@ -1963,6 +1967,54 @@ int lmgpu_solve(lmgpu_handle* h, double lambda, int32_t diagonal_damping, double
   if (lin_err0) *lin_err0 = h->h_scal[1];
   if (lin_err1) *lin_err1 = h->h_scal[2];
   return rc;
+}
+
+// b := 0 in every stored [A b]: the linear system keeps its matrix A^T A and loses its gradient
+__global__ __launch_bounds__(256) void zero_rhs_kernel(const FacDesc* __restrict__ fd, int nfac, double* __restrict__ pool) {
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= nfac) return;
+  const FacDesc d = fd[f];
+  double* b = pool + d.joff + (size_t)(d.d0 + d.d1) * d.rows;
+  for (int r = 0; r < d.rows; r++) b[r] = 0.0;
+}
+__global__ void set_one_kernel(double* p) { *p = 1.0; }
+
+int lmgpu_marginal_covariance(lmgpu_handle* h, int32_t slot, double* cov) {
+  if (!h || !cov || !h->finalized || !h->have_values || slot < 0 || slot >= h->plan.n_vars) return LMGPU_INVALID;
+  if (h->cfg.world_size > 1) {
+    h->err = "marginal covariances are computed on one GPU";
+    return LMGPU_INVALID;
+  }
+  int rc = need_device(h);
+  if (rc) return rc;
+  // Marginals::Marginals (gtsam/nonlinear/Marginals.cpp:29-78): linearize at the solution, eliminate into a Bayes tree
+  // (here: the same two kernels as every LM step, lambda = 0);  marginalCovariance (:124-127) = inverse of the marginal
+  // information (:109-121) = the variable's diagonal block of (A^T A)^-1.  Column k of that block is the variable's part of
+  // the solution of  A^T A x = e_k,  i.e. one elimination + back-substitution with the gradient replaced by a unit vector.
+  if ((rc = do_linearize(h))) return rc;
+  hipStream_t s = h->stream;
+  if (h->nfac > 0) hipLaunchKernelGGL(zero_rhs_kernel, dim3((h->nfac + 255) / 256), dim3(256), 0, s, (const FacDesc*)h->d_fd, h->nfac, h->pool);
+  if (!h->gex) HIPCHECK(hipMalloc((void**)&h->gex, h->ntot * sizeof(double)));
+  if ((rc = fill_dampw(h, 0, 0.0, 0.0))) return rc;
+  const int d = h->plan.dims[slot], x0 = h->plan.xoff[slot];
+  std::vector<double> col(d);
+  h->gex_active = h->gex;
+  for (int k = 0; k < d && rc == LMGPU_OK; k++) {
+    HIPCHECK(hipMemsetAsync(h->gex, 0, h->ntot * sizeof(double), s));
+    hipLaunchKernelGGL(set_one_kernel, dim3(1), dim3(1), 0, s, h->gex + x0 + k);
+    rc = do_solve(h, 0.0);
+    if (rc == LMGPU_OK) {
+      HIPCHECK(hipMemcpy(col.data(), h->delta + x0, d * sizeof(double), hipMemcpyDeviceToHost));
+      for (int i = 0; i < d; i++) cov[(size_t)i * d + k] = col[i];
+    }
+  }
+  h->gex_active = nullptr;
+  h->linearized = false;  // the stored right-hand sides are gone: the next solve linearizes again
+  h->solved = false;
+  if (rc != LMGPU_OK) return rc;  // LMGPU_INDETERMINATE like Marginals' IndeterminantLinearSystemException
+  for (int i = 0; i < d; i++)
+    for (int j = i + 1; j < d; j++) cov[(size_t)i * d + j] = cov[(size_t)j * d + i] = 0.5 * (cov[(size_t)i * d + j] + cov[(size_t)j * d + i]);
+  return LMGPU_OK;
 }
 
 int lmgpu_retract(lmgpu_handle* h, const double* delta_packed) {

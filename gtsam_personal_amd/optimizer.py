@@ -353,3 +353,28 @@ class DoglegOptimizer(LevenbergMarquardtOptimizer):
         cp = self.params._c()
         self._check(self.lib.lmgpu_dl_optimize(self._h, ct.byref(cp), ct.byref(self.state)))
         return self.values()
+
+
+class Marginals:
+    """Marginals(graph, solution, ordering): marginal covariances of single variables at `solution`
+    (gtsam/nonlinear/Marginals.h; constructor Marginals.cpp:28-43: linearize the graph at the solution and eliminate it;
+    marginalCovariance :124-127, marginalInformation :109-121).  Cholesky factorization only (the reference's default).
+    The elimination ordering is a boundary input as for the optimizers (the reference's default here is COLAMD; the result
+    does not depend on it).  Raises IndeterminantLinearSystemException-like LmgpuError where the reference throws."""
+
+    def __init__(self, graph: NonlinearFactorGraph, solution: Values, ordering, device: int = 0):
+        self._opt = LevenbergMarquardtOptimizer(graph, solution, ordering, LevenbergMarquardtParams(), device=device)
+
+    def marginalCovariance(self, key) -> np.ndarray:
+        o = self._opt
+        slot = o._slot[int(key)]
+        d = int(o._xoff[slot + 1] - o._xoff[slot])
+        out = np.zeros((d, d))
+        o._check(o.lib.lmgpu_marginal_covariance(o._h, slot, _dp(out)))
+        return out
+
+    def marginalInformation(self, key) -> np.ndarray:
+        return np.linalg.inv(self.marginalCovariance(key))
+
+    def close(self):
+        self._opt.close()

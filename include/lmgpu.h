@@ -231,6 +231,15 @@ typedef struct lmgpu_local_group lmgpu_local_group;
 int lmgpu_local_group_create(int32_t world_size, lmgpu_local_group** out);
 int lmgpu_local_group_destroy(lmgpu_local_group* g);
 
+/* Marginals(graph, values).marginalCovariance(variable)  (gtsam/nonlinear/Marginals.cpp:28-33 constructor: linearize at the
+ * solution and eliminate into a Bayes tree; :124-127 marginalCovariance = inverse of the marginal information :109-121):
+ * the dim x dim covariance (row-major) of the variable in `slot` at the handle's current values, i.e. its diagonal block of
+ * (A^T A)^-1.  Computed with the path's own two kernels: per column one elimination (lambda = 0) + back-substitution of the
+ * linearized system whose gradient is replaced by a unit vector.  The stored linearization is consumed (the next
+ * lmgpu_solve needs lmgpu_linearize again).  LMGPU_INDETERMINATE where the reference throws
+ * IndeterminantLinearSystemException (singular information matrix).  One GPU only (world_size == 1). */
+int lmgpu_marginal_covariance(lmgpu_handle* h, int32_t slot, double* cov /* dim x dim */);
+
 /* Host-only self-test (no GPU work): the ticket order the library gives the chained factorisation launch of a dense front
  * with n columns (nf frontal) for the steps i0 .. i0 + nsteps - 1 (tile rows beyond far_pct percent scheduled late) is a permutation of all logical workgroups in which every
  * in-launch dependency points to an earlier ticket.  0 = valid.  No reference counterpart (the reference factors a front with

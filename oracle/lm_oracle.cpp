@@ -1238,6 +1238,68 @@ int orc_solve(void* h, double lambda, int diagonal_damping, double min_diag, dou
   return 0;
 }
 
+// Marginals::marginalCovariance (gtsam/nonlinear/Marginals.cpp:124-127) of one variable at the current values:
+// the constructor linearizes the graph at the solution (:28-33); marginalInformation (:109-121) is the information matrix of
+// BayesTree::marginalFactor(variable), i.e. the Schur complement of the whole information matrix A^T A onto the variable, and
+// marginalCovariance its inverse -- the variable's diagonal block of (A^T A)^-1.  The reference reaches it through Bayes-tree
+// shortcuts; this restatement assembles the information matrix densely and inverts it by Cholesky, which is the same
+// quantity for every ordering (sizes the oracle is used at: total dimension up to a few thousand).
+// out: dim x dim row-major.  Returns 0 ok, 1 singular information matrix (the reference throws IndeterminantLinearSystemException).
+int orc_marginal_covariance(void* h, uint64_t key, double* out) {
+  auto* p = (Problem*)h;
+  linearize(*p);
+  std::map<Key, int> off;
+  int n = 0;
+  for (auto& kv : p->values) {
+    off[kv.first] = n;
+    n += kVarDim[kv.second.type];
+  }
+  if (!off.count(key)) return 2;
+  std::vector<double> L((size_t)n * n, 0.0);  // information matrix, then its Cholesky factor (lower, row-major)
+  for (auto& f : p->linear) {
+    if (f.hessian) return 3;
+    std::vector<int> col;  // global column of every Jacobian column
+    for (size_t k = 0; k < f.keys.size(); k++)
+      for (int c = 0; c < f.dims[k]; c++) col.push_back(off.at(f.keys[k]) + c);
+    for (size_t a = 0; a < col.size(); a++)
+      for (size_t b = 0; b < col.size(); b++) {
+        double sum = 0;
+        for (int i = 0; i < f.Ab.r; i++) sum += f.Ab(i, (int)a) * f.Ab(i, (int)b);
+        L[(size_t)col[a] * n + col[b]] += sum;
+      }
+  }
+  for (int j = 0; j < n; j++) {
+    double d = L[(size_t)j * n + j];
+    for (int k = 0; k < j; k++) d -= L[(size_t)j * n + k] * L[(size_t)j * n + k];
+    if (!(d > 0.0)) return 1;
+    d = std::sqrt(d);
+    L[(size_t)j * n + j] = d;
+    for (int i = j + 1; i < n; i++) {
+      double v = L[(size_t)i * n + j];
+      for (int k = 0; k < j; k++) v -= L[(size_t)i * n + k] * L[(size_t)j * n + k];
+      L[(size_t)i * n + j] = v / d;
+    }
+  }
+  const int x0 = off.at(key), dim = kVarDim[p->values.at(key).type];
+  std::vector<double> x(n);
+  for (int c = 0; c < dim; c++) {  // column c of the block: L L^T x = e_{x0 + c}
+    std::fill(x.begin(), x.end(), 0.0);
+    x[x0 + c] = 1.0;
+    for (int i = 0; i < n; i++) {
+      double v = x[i];
+      for (int k = 0; k < i; k++) v -= L[(size_t)i * n + k] * x[k];
+      x[i] = v / L[(size_t)i * n + i];
+    }
+    for (int i = n - 1; i >= 0; i--) {
+      double v = x[i];
+      for (int k = i + 1; k < n; k++) v -= L[(size_t)k * n + i] * x[k];
+      x[i] = v / L[(size_t)i * n + i];
+    }
+    for (int r = 0; r < dim; r++) out[(size_t)r * dim + c] = x[x0 + r];
+  }
+  return 0;
+}
+
 int orc_hessian_diagonal(void* h, double* out) {
   auto* p = (Problem*)h;
   auto d = hessian_diagonal(*p);

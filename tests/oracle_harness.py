@@ -48,6 +48,7 @@ def lib():
         L.orc_set_factor_robust.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.c_double]
         L.orc_robust.argtypes = [ct.c_int, ct.c_double, ct.c_double, _D]
         L.orc_get_values.argtypes = [ct.c_void_p, _D]
+        L.orc_marginal_covariance.argtypes = [ct.c_void_p, ct.c_uint64, _D]
         L.orc_error.argtypes = [ct.c_void_p]
         L.orc_linearize.argtypes = [ct.c_void_p]
         L.orc_get_jacobian.argtypes = [ct.c_void_p, ct.c_int, _D, _I, _I]
@@ -226,6 +227,13 @@ class OracleProblem:
         xu, xn = np.empty(self.ntot), np.empty(self.ntot)
         assert self.L.orc_dl_points(self.h, dp(xu), dp(xn)) == 0
         return xu, xn
+
+    def marginal_covariance(self, key, dim):
+        """Marginals(graph, values).marginalCovariance(key) at the oracle's current values; None if the information matrix is singular"""
+        out = np.empty((dim, dim))
+        rc = self.L.orc_marginal_covariance(self.h, int(key), dp(out))
+        assert rc in (0, 1), rc
+        return out if rc == 0 else None
 
     def get_delta(self):
         d = np.empty(self.ntot)

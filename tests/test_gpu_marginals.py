@@ -1,0 +1,86 @@
+"""Marginals on the device path (lmgpu_marginal_covariance: per column one elimination + back-substitution of the linearized
+system with a unit gradient) against the oracle's restatement of Marginals::marginalCovariance (dense inverse of the
+information matrix, pinned in tests/test_oracle_golden.py to the reference's own output for the odometry example)."""
+import numpy as np
+import pytest
+
+import oracle_harness as oh
+from gtsam_personal_amd import (LevenbergMarquardtOptimizer, LevenbergMarquardtParams, Marginals, NonlinearFactorGraph, Ordering, Values, _lib,
+                                noiseModel)
+from gtsam_personal_amd.synthetic import make_bal
+from test_oracle_golden import ODOMETRY_EXACT, ODOMETRY_PRINTED, _odometry_example
+
+pytestmark = pytest.mark.gpu
+
+
+def test_odometry_example_known_answers_on_gpu():
+    """doc/Code/OdometryMarginals.cpp / OdometryOutput3.txt: x1, x2, x3 covariances as the reference prints them"""
+    graph, values = _odometry_example()
+    for ordering in ([1, 2, 3], [3, 1, 2]):
+        m = Marginals(graph, values, Ordering(ordering))
+        for k in (1, 2, 3):
+            cov = m.marginalCovariance(k)
+            assert np.allclose(cov, np.array(ODOMETRY_PRINTED[k]), atol=6e-3), (k, cov)
+            assert np.allclose(cov, np.array(ODOMETRY_EXACT[k]), rtol=1e-9, atol=1e-12), (k, cov)
+            assert np.allclose(m.marginalInformation(k) @ cov, np.eye(3), atol=1e-9)
+        m.close()
+
+
+def test_bal_marginals_match_oracle_after_optimization():
+    """cameras (9 x 9, in the HBM root) and points (3 x 3, LDS leaf fronts gathered in Schur form) of an optimized BAL problem;
+    the optimizer's handle keeps working after the marginals consumed its linearization"""
+    graph, initial, _, ordering = make_bal(n_cam=24, n_pt=400, obs_per_point=6, seed=9)
+    opt = LevenbergMarquardtOptimizer(graph, initial, ordering, LevenbergMarquardtParams(), device=0)
+    opt.optimize()
+    result = opt.values()
+    orc = oh.OracleProblem(graph, result, ordering)
+    m = Marginals(graph, result, ordering)
+    keys = list(ordering)
+    for k in [keys[0], keys[7], keys[399], keys[400], keys[411], keys[-1]]:
+        d = 9 if k in keys[400:] else 3
+        ref = orc.marginal_covariance(k, d)
+        cov = m.marginalCovariance(k)
+        assert ref is not None and cov.shape == (d, d)
+        assert np.allclose(cov, cov.T, rtol=0, atol=1e-14 * np.abs(cov).max())
+        assert np.linalg.norm(cov - ref) <= 1e-6 * np.linalg.norm(ref), (k, np.linalg.norm(cov - ref) / np.linalg.norm(ref))
+    # the same handle afterwards: a plain solve needs (and gets) a fresh linearization
+    h = m._opt
+    h.linearize()
+    dk, d, e0, e1 = h.solve(1e-3)
+    orc.linearize()
+    rc, do, o0, o1 = orc.solve(1e-3)
+    assert rc == 0 and abs(e1 - o1) <= 1e-6 * max(1.0, abs(o1))
+    m.close()
+
+
+def test_pose3_graph_marginals_match_oracle_colamd():
+    """first 300 poses of sphere2500 (Pose3 between factors + prior), COLAMD ordering when the reference build is present:
+    LDS, medium and HBM fronts with separators all carry the unit right-hand side"""
+    import os
+    from gtsam_personal_amd.datasets import chain_initial_pose3, load3D
+    graph, _ = load3D(os.path.join(os.path.dirname(__file__), "golden", "sphere2500_head.txt"))
+    vals = chain_initial_pose3(graph)
+    graph.add_PriorFactorPose3(0, np.eye(3), np.zeros(3), noiseModel.Diagonal.Variances([1e-6, 1e-6, 1e-6, 1e-4, 1e-4, 1e-4]))
+    ordering = oh.colamd(graph) if oh.have_ref() else Ordering.Natural(graph)
+    orc = oh.OracleProblem(graph, vals, ordering)
+    m = Marginals(graph, vals, ordering)
+    keys = sorted(int(k) for k in ordering)
+    for k in (keys[0], keys[57], keys[150], keys[-1]):
+        ref, cov = orc.marginal_covariance(k, 6), m.marginalCovariance(k)
+        assert ref is not None
+        assert np.linalg.norm(cov - ref) <= 1e-6 * np.linalg.norm(ref), (k, np.linalg.norm(cov - ref) / np.linalg.norm(ref))
+    m.close()
+
+
+def test_gauge_freedom_reports_indeterminate():
+    """two poses tied by one odometry factor and no prior: the information matrix is singular (here exactly: unit noise and
+    axis-aligned poses make every Jacobian entry a small integer, so the second pivot block is exactly zero); the reference's
+    Marginals throws IndeterminantLinearSystemException from the elimination in its constructor"""
+    graph, values = NonlinearFactorGraph(), Values()
+    graph.add_BetweenFactorPose2(1, 2, [2.0, 0.0, 0.0], noiseModel.Diagonal.Sigmas([1.0, 1.0, 1.0]))
+    values.insert_pose2(1, 0.0, 0.0, 0.0)
+    values.insert_pose2(2, 2.0, 0.0, 0.0)
+    m = Marginals(graph, values, Ordering([1, 2]))
+    with pytest.raises(_lib.IndeterminantLinearSystemException):
+        m.marginalCovariance(2)
+    m.close()

@@ -665,3 +665,67 @@ def test_pinhole_projection_known_answers():
     orc.linearize()
     for i in range(4):
         assert np.allclose(-orc.jacobian(i)[:, -1], expect[i], atol=1e-9)
+
+
+# ---------------------------------------------------------------- Marginals
+def _odometry_example():
+    """doc/Code/OdometryExample.cpp + OdometryMarginals.cpp: prior on x1, two odometry factors; the solution is the
+    measurements themselves, (0,0,0), (2,0,0), (4,0,0)."""
+    from gtsam_personal_amd import NonlinearFactorGraph, Values, noiseModel
+    graph, values = NonlinearFactorGraph(), Values()
+    graph.add_PriorFactorPose2(1, [0.0, 0.0, 0.0], noiseModel.Diagonal.Sigmas([0.3, 0.3, 0.1]))
+    odo = noiseModel.Diagonal.Sigmas([0.2, 0.2, 0.1])
+    graph.add_BetweenFactorPose2(1, 2, [2.0, 0.0, 0.0], odo)
+    graph.add_BetweenFactorPose2(2, 3, [2.0, 0.0, 0.0], odo)
+    for k, x in ((1, 0.0), (2, 2.0), (3, 4.0)):
+        values.insert_pose2(k, x, 0.0, 0.0)
+    return graph, values
+
+
+# the reference's own output for this example (doc/Code/OdometryOutput3.txt, printed with 2 significant digits)
+ODOMETRY_PRINTED = {1: [[0.09, 0, 0], [0, 0.09, 0], [0, 0, 0.01]],
+                    2: [[0.13, 0, 0], [0, 0.17, 0.02], [0, 0.02, 0.02]],
+                    3: [[0.17, 0, 0], [0, 0.37, 0.06], [0, 0.06, 0.03]]}
+# the same numbers exactly: uncertainty of the prior propagated through the odometry chain (x, y, theta of the body frame;
+# a heading error of variance 0.01 moves the next pose sideways by 2 m per unit angle)
+ODOMETRY_EXACT = {1: [[0.09, 0, 0], [0, 0.09, 0], [0, 0, 0.01]],
+                  2: [[0.13, 0, 0], [0, 0.09 + 0.04 + 4 * 0.01, 2 * 0.01], [0, 2 * 0.01, 0.02]],
+                  3: [[0.17, 0, 0], [0, 0.09 + 0.04 + 16 * 0.01 + 0.04 + 4 * 0.01, 4 * 0.01 + 2 * 0.01], [0, 0.06, 0.03]]}
+
+
+def test_marginal_covariance_odometry_example_matches_reference_output():
+    from gtsam_personal_amd import Ordering
+    graph, values = _odometry_example()
+    for ordering in ([1, 2, 3], [3, 1, 2]):
+        orc = oh.OracleProblem(graph, values, Ordering(ordering))
+        for k in (1, 2, 3):
+            cov = orc.marginal_covariance(k, 3)
+            assert np.allclose(cov, np.array(ODOMETRY_PRINTED[k]), atol=6e-3), (k, cov)   # the reference prints 2 digits
+            assert np.allclose(cov, np.array(ODOMETRY_EXACT[k]), atol=1e-12), (k, cov)
+            assert np.allclose(cov, cov.T, atol=1e-15)
+
+
+def test_marginal_covariance_is_block_of_dense_inverse():
+    """against numpy on the oracle's own Jacobians: a Pose2 ring (chain + loop closure) anchored by a prior"""
+    from gtsam_personal_amd import NonlinearFactorGraph, Ordering, Values, noiseModel
+    rng = np.random.default_rng(2)
+    graph, values = NonlinearFactorGraph(), Values()
+    n = 6
+    for i in range(n):
+        values.insert_pose2(i, float(i) + rng.normal(0, 0.1), rng.normal(0, 0.1), rng.normal(0, 0.1))
+    m = noiseModel.Diagonal.Sigmas([0.2, 0.3, 0.05])
+    pairs = [(i, i + 1) for i in range(n - 1)] + [(0, n - 1)]
+    for a, b in pairs:
+        graph.add_BetweenFactorPose2(a, b, [float(b - a), 0.0, 0.0], m)
+    graph.add_PriorFactorPose2(0, [0.0, 0.0, 0.0], noiseModel.Diagonal.Sigmas([0.1, 0.1, 0.02]))
+    orc = oh.OracleProblem(graph, values, Ordering(list(range(n))))
+    orc.linearize()
+    H = np.zeros((3 * n, 3 * n))
+    for g, (a, b) in enumerate(pairs + [(0, None)]):
+        J = orc.jacobian(g)
+        cols = [3 * a, 3 * a + 1, 3 * a + 2] + ([3 * b, 3 * b + 1, 3 * b + 2] if b is not None else [])
+        assert J.shape[1] == len(cols) + 1
+        H[np.ix_(cols, cols)] += J[:, :-1].T @ J[:, :-1]
+    C = np.linalg.inv(H)
+    for k in range(n):
+        assert np.allclose(orc.marginal_covariance(k, 3), C[3 * k:3 * k + 3, 3 * k:3 * k + 3], rtol=1e-9, atol=1e-12)
