@@ -31,7 +31,7 @@ struct BucketDev {
 };
 
 struct ValuesDev {
-  const double* v[4];  // POSE2 [n][3], POSE3 [n][12], POINT3 [n][3], CAM [n][15]
+  const double* v[5];  // POSE2 [n][3], POSE3 [n][12], POINT3 [n][3], CAM [n][15], POINT2 [n][2]
 };
 
 // whiten Jl (col-major M x COLS) in place
@@ -295,6 +295,46 @@ __device__ __forceinline__ void eval_between_pose2(const double* m, const double
   e[0] = d.x; e[1] = d.y; e[2] = atan2(d.s, d.c);
 }
 
+// BearingRangeFactor<Pose2, Point2>  gtsam/sam/BearingRangeFactor.h:33-77 (ExpressionFactor: error = -Local(value, measured),
+// Jacobians of the value, gtsam/nonlinear/ExpressionFactor.h:104-115): Pose2::bearing gtsam/geometry/Pose2.cpp:260-271 over
+// transformTo :222-229 and Rot2::relativeBearing gtsam/geometry/Rot2.cpp:134-145; Pose2::range Pose2.cpp:285-299 over norm2
+// gtsam/geometry/Point2.cpp:27-36.  m = (bearing angle, range); v0 = pose (x, y, theta); v1 = landmark (x, y).
+template <bool JAC>
+__device__ __forceinline__ void eval_bearing_range_2d(const double* m, const double* v0, const double* v1, double* e, double* H1, double* H2) {
+  const double c = cos(v0[2]), sn = sin(v0[2]);
+  const double dx = v1[0] - v0[0], dy = v1[1] - v0[1];
+  const double qx = c * dx + sn * dy, qy = -sn * dx + c * dy;
+  const double d2 = qx * qx + qy * qy, n = sqrt(d2);
+  double hb0 = 0.0, hb1 = 0.0, cb = 1.0, sb = 0.0;
+  if (fabs(n) > 1e-5) {
+    hb0 = -qy / d2;
+    hb1 = qx / d2;
+    cb = qx / n;
+    sb = qy / n;
+  }
+  const double r = sqrt(dx * dx + dy * dy);
+  double hr0 = 1.0, hr1 = 1.0;
+  if (fabs(r) > 1e-10) {
+    hr0 = dx / r;
+    hr1 = dy / r;
+  }
+  if (JAC) {
+    H1[0] = -hb0;
+    H1[1] = -hb1;
+    H1[2] = hb0 * qy - hb1 * qx;
+    H1[3] = hr0 * -c + hr1 * -sn;
+    H1[4] = hr0 * sn + hr1 * -c;
+    H1[5] = 0.0;
+    H2[0] = hb0 * c + hb1 * -sn;
+    H2[1] = hb0 * sn + hb1 * c;
+    H2[2] = hr0;
+    H2[3] = hr1;
+  }
+  const double cm = cos(m[0]), sm = sin(m[0]);
+  e[0] = -atan2(cb * sm - sb * cm, cb * cm + sb * sm);
+  e[1] = r - m[1];
+}
+
 template <int D>
 __device__ __forceinline__ void set_identity(double* H) {
 #pragma unroll
@@ -404,6 +444,7 @@ __global__ __launch_bounds__(128) void generic_factor_kernel(BucketDev b, Values
   if (TYPE == 5) eval_prior_point3<JAC>(m, v0, e, H1);
   if (TYPE == 6) eval_prior_cam<JAC>(m, v0, e, H1);
   if (TYPE == 7) eval_projection<JAC>(m, v0, v1, e, H1, H2);
+  if (TYPE == 9) eval_bearing_range_2d<JAC>(m, v0, v1, e, H1, H2);
   if (TYPE == 8) {
     // GenericProjectionFactor with body_P_sensor (ProjectionFactor.h:142-149): camera pose = pose o sensor; H1 = H1_cam Ad(sensor^-1)
     const P3 sensor = load_pose3(m + 7);
@@ -575,6 +616,10 @@ __global__ __launch_bounds__(256) void retract_kernel(int type, int n, const dou
     const double* v = cur + (size_t)i * 3;
     double* o = out + (size_t)i * 3;
     o[0] = v[0] + d[0]; o[1] = v[1] + d[1]; o[2] = v[2] + d[2];
+  } else if (type == 4) {  // Point2: vector space
+    const double* v = cur + (size_t)i * 2;
+    double* o = out + (size_t)i * 2;
+    o[0] = v[0] + d[0]; o[1] = v[1] + d[1];
   } else {  // PinholeCamera::retract gtsam/geometry/PinholeCamera.h:197-203
     const double* v = cur + (size_t)i * 15;
     double* o = out + (size_t)i * 15;

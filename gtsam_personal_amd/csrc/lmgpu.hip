@@ -209,10 +209,10 @@ struct lmgpu_handle {
   unsigned int* bs_flags = nullptr;
   double* pool = nullptr;
   size_t pool_doubles = 0;
-  double* vals[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
-  double* saved[4] = {nullptr, nullptr, nullptr, nullptr};
+  double* vals[2][kNumVarTypes] = {{nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr}};
+  double* saved[kNumVarTypes] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   int cur = 0;
-  int32_t* type_xoff[4] = {nullptr, nullptr, nullptr, nullptr};
+  int32_t* type_xoff[kNumVarTypes] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   double *delta = nullptr, *dampw = nullptr, *hdiag = nullptr, *ebuf0 = nullptr, *ebuf1 = nullptr, *partial = nullptr, *dscal = nullptr,
          *ywork = nullptr;
   int* d_status = nullptr;
@@ -307,7 +307,7 @@ int need_comm(lmgpu_handle* h) {
 
 ValuesDev values_dev(lmgpu_handle* h, int which) {
   ValuesDev v;
-  for (int t = 0; t < 4; t++) v.v[t] = h->vals[which][t];
+  for (int t = 0; t < kNumVarTypes; t++) v.v[t] = h->vals[which][t];
   return v;
 }
 
@@ -369,6 +369,9 @@ void launch_factors(lmgpu_handle* h, int which) {
         break;
       case LMGPU_F_PROJECTION_BPS:
         hipLaunchKernelGGL((generic_factor_kernel<8, 2, 6, 3, 19, 1, 12, 2, 3, JAC>), dim3(g128), dim3(128), 0, s, d, vals, h->ebuf0);
+        break;
+      case LMGPU_F_BEARING_RANGE_2D:
+        hipLaunchKernelGGL((generic_factor_kernel<9, 2, 3, 2, 2, 0, 3, 4, 2, JAC>), dim3(g128), dim3(128), 0, s, d, vals, h->ebuf0);
         break;
     }
   }
@@ -884,7 +887,7 @@ int do_solve(lmgpu_handle* h, double lambda) {
 }
 
 int do_retract(lmgpu_handle* h, int from, int to) {
-  for (int t = 0; t < 4; t++) {
+  for (int t = 0; t < kNumVarTypes; t++) {
     const int n = h->plan.type_count[t];
     if (n == 0) continue;
     hipLaunchKernelGGL(retract_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, t, n, (const double*)h->vals[from][t], h->vals[to][t],
@@ -1297,9 +1300,9 @@ int lmgpu_destroy(lmgpu_handle* h) {
     };
     fr(h->pool);
     for (int w = 0; w < 2; w++)
-      for (int t = 0; t < 4; t++) fr(h->vals[w][t]);
-    for (int t = 0; t < 4; t++) fr(h->type_xoff[t]);
-    for (int t = 0; t < 4; t++) fr(h->saved[t]);
+      for (int t = 0; t < kNumVarTypes; t++) fr(h->vals[w][t]);
+    for (int t = 0; t < kNumVarTypes; t++) fr(h->type_xoff[t]);
+    for (int t = 0; t < kNumVarTypes; t++) fr(h->saved[t]);
     fr(h->gex); fr(h->delta); fr(h->dampw); fr(h->hdiag); fr(h->ebuf0); fr(h->ebuf1); fr(h->partial); fr(h->dscal); fr(h->ywork); fr(h->d_status);
     fr(h->d_fd); fr(h->d_fronts); fr(h->d_ffac); fr(h->d_childs); fr(h->d_cmap); fr(h->d_fxoff); fr(h->d_sxoff); fr(h->d_lists); fr(h->d_hbm_small); fr(h->d_med_list); fr(h->inv16_med); fr(h->bt_ebuf); fr(h->bt_vec); fr(h->d_f_ld); fr(h->d_f_off);
     fr(h->d_scalar_var); fr(h->d_scalar_col); fr(h->d_vi_ptr); fr(h->d_vi_fac); fr(h->d_vi_pos);
@@ -1806,7 +1809,7 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
     }
   }
   // values, per type
-  for (int t = 0; t < 4; t++) {
+  for (int t = 0; t < kNumVarTypes; t++) {
     const size_t bytes = std::max<size_t>(1, (size_t)P.type_count[t] * kVarStore[t]) * sizeof(double);
     HIPCHECK(hipMalloc((void**)&h->vals[0][t], bytes));
     HIPCHECK(hipMalloc((void**)&h->vals[1][t], bytes));
@@ -1880,7 +1883,7 @@ int lmgpu_set_values(lmgpu_handle* h, const double* packed) {
   int rc = need_device(h);
   if (rc) return rc;
   const Plan& P = h->plan;
-  for (int t = 0; t < 4; t++) {
+  for (int t = 0; t < kNumVarTypes; t++) {
     if (P.type_count[t] == 0) continue;
     std::vector<double> buf((size_t)P.type_count[t] * kVarStore[t]);
     for (int s = 0; s < P.n_vars; s++)
@@ -1898,7 +1901,7 @@ int lmgpu_get_values(lmgpu_handle* h, double* packed) {
   if (rc) return rc;
   const Plan& P = h->plan;
   HIPCHECK(hipStreamSynchronize(h->stream));
-  for (int t = 0; t < 4; t++) {
+  for (int t = 0; t < kNumVarTypes; t++) {
     if (P.type_count[t] == 0) continue;
     std::vector<double> buf((size_t)P.type_count[t] * kVarStore[t]);
     HIPCHECK(hipMemcpy(buf.data(), h->vals[h->cur][t], buf.size() * sizeof(double), hipMemcpyDeviceToHost));
@@ -1913,7 +1916,7 @@ int lmgpu_save_values(lmgpu_handle* h) {
   if (!h || !h->finalized || !h->have_values) return LMGPU_INVALID;
   int rc = need_device(h);
   if (rc) return rc;
-  for (int t = 0; t < 4; t++) {
+  for (int t = 0; t < kNumVarTypes; t++) {
     const size_t bytes = std::max<size_t>(1, (size_t)h->plan.type_count[t] * kVarStore[t]) * sizeof(double);
     if (!h->saved[t]) HIPCHECK(hipMalloc((void**)&h->saved[t], bytes));
     HIPCHECK(hipMemcpyAsync(h->saved[t], h->vals[h->cur][t], bytes, hipMemcpyDeviceToDevice, h->stream));
@@ -1926,7 +1929,7 @@ int lmgpu_restore_values(lmgpu_handle* h) {
   if (!h || !h->finalized || !h->saved[0]) return LMGPU_INVALID;
   int rc = need_device(h);
   if (rc) return rc;
-  for (int t = 0; t < 4; t++) {
+  for (int t = 0; t < kNumVarTypes; t++) {
     const size_t bytes = std::max<size_t>(1, (size_t)h->plan.type_count[t] * kVarStore[t]) * sizeof(double);
     HIPCHECK(hipMemcpyAsync(h->vals[h->cur][t], h->saved[t], bytes, hipMemcpyDeviceToDevice, h->stream));
   }

@@ -19,10 +19,10 @@ std::string Plan::build(int32_t lds_limit_n) {
   xoff.assign(n + 1, 0);
   voff.assign(n + 1, 0);
   tidx.resize(n);
-  for (int t = 0; t < 4; t++) type_count[t] = 0;
+  for (int t = 0; t < kNumVarTypes; t++) type_count[t] = 0;
   for (int32_t s = 0; s < n; s++) {
     const int t = types[s];
-    if (t < 0 || t > 3) return "bad variable type";
+    if (t < 0 || t >= kNumVarTypes) return "bad variable type";
     dims[s] = kVarDim[t];
     xoff[s + 1] = xoff[s] + dims[s];
     voff[s + 1] = voff[s] + kVarStore[t];

@@ -9,14 +9,15 @@
 
 namespace lmgpu {
 
-static const int kVarDim[4] = {3, 6, 3, 9};
-static const int kVarStore[4] = {3, 12, 3, 15};
-static const int kFactorArity[9] = {2, 2, 2, 1, 1, 1, 1, 2, 2};
-static const int kFactorRows[9] = {2, 3, 6, 3, 6, 3, 9, 2, 2};
-static const int kFactorMeas[9] = {2, 3, 12, 3, 12, 3, 15, 7, 19};
+static const int kNumVarTypes = 5;
+static const int kVarDim[5] = {3, 6, 3, 9, 2};
+static const int kVarStore[5] = {3, 12, 3, 15, 2};
+static const int kFactorArity[10] = {2, 2, 2, 1, 1, 1, 1, 2, 2, 2};
+static const int kFactorRows[10] = {2, 3, 6, 3, 6, 3, 9, 2, 2, 2};
+static const int kFactorMeas[10] = {2, 3, 12, 3, 12, 3, 15, 7, 19, 2};
 // variable types each factor type expects (for validation)
-static const int kFactorVar0[9] = {3, 0, 1, 0, 1, 2, 3, 1, 1};
-static const int kFactorVar1[9] = {2, 0, 1, -1, -1, -1, -1, 2, 2};
+static const int kFactorVar0[10] = {3, 0, 1, 0, 1, 2, 3, 1, 1, 0};
+static const int kFactorVar1[10] = {2, 0, 1, -1, -1, -1, -1, 2, 2, 4};
 
 struct FactorRef {
   int32_t bucket;   // bucket index
@@ -49,7 +50,7 @@ struct Plan {
   std::vector<int32_t> xoff;    // scalar offset of slot in packed tangent vectors (size n_vars+1)
   std::vector<int32_t> voff;    // double offset of slot in packed values (size n_vars+1)
   std::vector<int32_t> tidx;    // index of the slot within its type's device array
-  int32_t type_count[4] = {0, 0, 0, 0};
+  int32_t type_count[kNumVarTypes] = {0, 0, 0, 0, 0};
   std::vector<FactorRef> factors;  // sorted by graph_index
   // outputs
   std::vector<int32_t> etree_parent;  // per slot, -1 for roots

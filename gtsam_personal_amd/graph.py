@@ -15,16 +15,18 @@ from __future__ import annotations
 import numpy as np
 
 # ---- enums shared with include/lmgpu.h
-POSE2, POSE3, POINT3, CAM_BUNDLER = 0, 1, 2, 3
-VAR_DIM = (3, 6, 3, 9)
-VAR_STORE = (3, 12, 3, 17)      # host packed value (camera keeps u0, v0)
-VAR_STORE_DEV = (3, 12, 3, 15)  # C-ABI packed value
+POSE2, POSE3, POINT3, CAM_BUNDLER, POINT2 = 0, 1, 2, 3, 4
+VAR_DIM = (3, 6, 3, 9, 2)
+VAR_STORE = (3, 12, 3, 17, 2)      # host packed value (camera keeps u0, v0)
+VAR_STORE_DEV = (3, 12, 3, 15, 2)  # C-ABI packed value
 
-F_SFM, F_BETWEEN_POSE2, F_BETWEEN_POSE3, F_PRIOR_POSE2, F_PRIOR_POSE3, F_PRIOR_POINT3, F_PRIOR_CAM, F_PROJECTION, F_PROJECTION_BPS = range(9)
-FACTOR_ARITY = (2, 2, 2, 1, 1, 1, 1, 2, 2)
-FACTOR_ROWS = (2, 3, 6, 3, 6, 3, 9, 2, 2)
-FACTOR_MEAS = (2, 3, 12, 3, 12, 3, 17, 7, 19)  # host measurement doubles (PRIOR_CAM carries u0, v0)
-FACTOR_VARS = ((CAM_BUNDLER, POINT3), (POSE2, POSE2), (POSE3, POSE3), (POSE2,), (POSE3,), (POINT3,), (CAM_BUNDLER,), (POSE3, POINT3), (POSE3, POINT3))
+(F_SFM, F_BETWEEN_POSE2, F_BETWEEN_POSE3, F_PRIOR_POSE2, F_PRIOR_POSE3, F_PRIOR_POINT3, F_PRIOR_CAM, F_PROJECTION, F_PROJECTION_BPS,
+ F_BEARING_RANGE_2D) = range(10)
+FACTOR_ARITY = (2, 2, 2, 1, 1, 1, 1, 2, 2, 2)
+FACTOR_ROWS = (2, 3, 6, 3, 6, 3, 9, 2, 2, 2)
+FACTOR_MEAS = (2, 3, 12, 3, 12, 3, 17, 7, 19, 2)  # host measurement doubles (PRIOR_CAM carries u0, v0)
+FACTOR_VARS = ((CAM_BUNDLER, POINT3), (POSE2, POSE2), (POSE3, POSE3), (POSE2,), (POSE3,), (POINT3,), (CAM_BUNDLER,), (POSE3, POINT3), (POSE3, POINT3),
+               (POSE2, POINT2))
 
 N_UNIT, N_ISO, N_DIAG, N_GAUSS = 0, 1, 2, 3
 
@@ -213,6 +215,9 @@ class Values:
     def insert_point3(self, key, p):
         self.insert(key, POINT3, p)
 
+    def insert_point2(self, key, p):
+        self.insert(key, POINT2, p)
+
     def insert_camera(self, key, R, t, f, k1, k2, u0=0.0, v0=0.0):
         self.insert(key, CAM_BUNDLER, camera_pack(R, t, f, k1, k2, u0, v0))
 
@@ -311,6 +316,11 @@ class NonlinearFactorGraph:
 
     def add_BetweenFactorPose3(self, key1, key2, measured_R, measured_t, model):
         self._add(F_BETWEEN_POSE3, [[key1, key2]], pose3_pack(measured_R, measured_t), model)
+
+    def add_BearingRangeFactor2D(self, poseKey, pointKey, measuredBearing, measuredRange, model):
+        """BearingRangeFactor<Pose2, Point2>(poseKey, pointKey, Rot2::fromAngle(measuredBearing), measuredRange, model)
+        (gtsam/sam/BearingRangeFactor.h:51-55); bearing in radians"""
+        self._add(F_BEARING_RANGE_2D, [[poseKey, pointKey]], [measuredBearing, measuredRange], model)
 
     def add_PriorFactorPose2(self, key, prior, model):
         self._add(F_PRIOR_POSE2, [[key]], prior, model)

@@ -42,8 +42,9 @@ enum lmgpu_status {
  *   CAM_BUNDLER dim 9  store 15  (R 9, t 3, f, k1, k2)  PinholeCamera<Cal3Bundler>; tangent (omega, v, f, k1, k2).
  *               The constant principal point (u0, v0) of Cal3Bundler is folded into the measurement by the host
  *               (z' = z - (u0, v0)); Cal3Bundler::retract keeps it constant (gtsam/geometry/Cal3Bundler.h:134-136).
+ *   POINT2      dim 2  store 2                           planar landmark (gtsam/geometry/Point2.h), vector retract
  */
-enum lmgpu_var_type { LMGPU_POSE2 = 0, LMGPU_POSE3 = 1, LMGPU_POINT3 = 2, LMGPU_CAM_BUNDLER = 3, LMGPU_NUM_VAR_TYPES = 4 };
+enum lmgpu_var_type { LMGPU_POSE2 = 0, LMGPU_POSE3 = 1, LMGPU_POINT3 = 2, LMGPU_CAM_BUNDLER = 3, LMGPU_POINT2 = 4, LMGPU_NUM_VAR_TYPES = 5 };
 
 /* Factor types ("buckets" are keyed by (factor type, noise kind) = fixed block shape).
  *   type             arity rows  measurement doubles
@@ -57,6 +58,9 @@ enum lmgpu_var_type { LMGPU_POSE2 = 0, LMGPU_POSE3 = 1, LMGPU_POINT3 = 2, LMGPU_
  *   PROJECTION       2     2     7   (z, fx, fy, s, u0, v0)    GenericProjectionFactor<Pose3,Point3,Cal3_S2>  gtsam/slam/ProjectionFactor.h:138-165
  *   PROJECTION_BPS   2     2     19  (z, K, body_P_sensor R t) the same with body_P_sensor (ProjectionFactor.h:142-149: camera =
  *                                                              pose.compose(body_P_sensor), H1 chained with AdjointMap(body_P_sensor^-1))
+ *   BEARING_RANGE_2D 2     2     2   (bearing angle, range)    BearingRangeFactor<Pose2,Point2>  gtsam/sam/BearingRangeFactor.h:33-77:
+ *                                                              error = (wrap(bearing - measured), range - measured) with Pose2::bearing /
+ *                                                              Pose2::range and their Jacobians, gtsam/geometry/Pose2.cpp:283-330
  */
 enum lmgpu_factor_type {
   LMGPU_F_SFM = 0,
@@ -68,7 +72,8 @@ enum lmgpu_factor_type {
   LMGPU_F_PRIOR_CAM = 6,
   LMGPU_F_PROJECTION = 7,
   LMGPU_F_PROJECTION_BPS = 8,
-  LMGPU_NUM_FACTOR_TYPES = 9
+  LMGPU_F_BEARING_RANGE_2D = 9,
+  LMGPU_NUM_FACTOR_TYPES = 10
 };
 
 /* Noise models (gtsam/linear/NoiseModel.cpp).  Per-factor noise data, `rows` = factor rows:

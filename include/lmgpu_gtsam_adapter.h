@@ -60,6 +60,7 @@ class GpuLevenbergMarquardtOptimizer : public LevenbergMarquardtOptimizer {
       else if (dynamic_cast<const GenericValue<Pose3>*>(&v)) t = LMGPU_POSE3;
       else if (dynamic_cast<const GenericValue<Point3>*>(&v)) t = LMGPU_POINT3;
       else if (dynamic_cast<const GenericValue<Camera>*>(&v)) t = LMGPU_CAM_BUNDLER;
+      else if (dynamic_cast<const GenericValue<Point2>*>(&v)) t = LMGPU_POINT2;
       else throw std::invalid_argument("GpuLevenbergMarquardtOptimizer: unsupported variable type");
       slotType_.push_back(t);
     }
@@ -109,7 +110,8 @@ class GpuLevenbergMarquardtOptimizer : public LevenbergMarquardtOptimizer {
       } else if (auto f2 = std::dynamic_pointer_cast<BetweenFactor<Pose2>>(graph[i])) {
         type = LMGPU_F_BETWEEN_POSE2; m = {f2->measured().x(), f2->measured().y(), f2->measured().theta()};
       } else {
-        // PriorFactor<T>, GenericProjectionFactor<Pose3,Point3,Cal3_S2>: same pattern (measurement packing in lmgpu.h)
+        // PriorFactor<T>, GenericProjectionFactor<Pose3,Point3,Cal3_S2>, BearingRangeFactor<Pose2,Point2> (measured().bearing().theta(),
+        // measured().range()): same pattern (measurement packing in lmgpu.h)
         throw std::invalid_argument("GpuLevenbergMarquardtOptimizer: factor type not bound in this sketch");
       }
       B& b = buckets[std::make_tuple(type, kind, rkind, rk)];
@@ -165,6 +167,7 @@ class GpuLevenbergMarquardtOptimizer : public LevenbergMarquardtOptimizer {
         case LMGPU_POSE2: { const Pose2& p = v.at<Pose2>(k); packed[o] = p.x(); packed[o + 1] = p.y(); packed[o + 2] = p.theta(); o += 3; break; }
         case LMGPU_POSE3: packPose3(v.at<Pose3>(k), &packed[o]); o += 12; break;
         case LMGPU_POINT3: { const Point3& p = v.at<Point3>(k); packed[o] = p.x(); packed[o + 1] = p.y(); packed[o + 2] = p.z(); o += 3; break; }
+        case LMGPU_POINT2: { const Point2& p = v.at<Point2>(k); packed[o] = p.x(); packed[o + 1] = p.y(); o += 2; break; }
         default: { const Camera& c = v.at<Camera>(k); packPose3(c.pose(), &packed[o]); packed[o + 12] = c.calibration().fx(); packed[o + 13] = c.calibration().k1(); packed[o + 14] = c.calibration().k2(); o += 15; }
       }
     }
@@ -181,6 +184,7 @@ class GpuLevenbergMarquardtOptimizer : public LevenbergMarquardtOptimizer {
         case LMGPU_POSE2: out.insert(k, Pose2(p[0], p[1], p[2])); o += 3; break;
         case LMGPU_POSE3: out.insert(k, pose3(p)); o += 12; break;
         case LMGPU_POINT3: out.insert(k, Point3(p[0], p[1], p[2])); o += 3; break;
+        case LMGPU_POINT2: out.insert(k, Point2(p[0], p[1])); o += 2; break;
         default: { const Cal3Bundler& K0 = like.at<Camera>(k).calibration(); out.insert(k, Camera(pose3(p), Cal3Bundler(p[12], p[13], p[14], K0.px(), K0.py()))); o += 15; }
       }
     }

@@ -42,9 +42,9 @@ struct Mat {
   double operator()(int i, int j) const { return a[(size_t)j * r + i]; }
 };
 
-enum VarType { POSE2 = 0, POSE3 = 1, POINT3 = 2, CAM_BUNDLER = 3 };
-static const int kVarDim[4] = {3, 6, 3, 9};
-static const int kVarStore[4] = {3, 12, 3, 17};  // packed value doubles (oracle keeps u0,v0 with the camera)
+enum VarType { POSE2 = 0, POSE3 = 1, POINT3 = 2, CAM_BUNDLER = 3, POINT2 = 4 };
+static const int kVarDim[5] = {3, 6, 3, 9, 2};
+static const int kVarStore[5] = {3, 12, 3, 17, 2};  // packed value doubles (oracle keeps u0,v0 with the camera)
 
 enum FactorType {
   F_SFM = 0,            // GeneralSFMFactor<PinholeCamera<Cal3Bundler>,Point3>  (cam, point), meas 2
@@ -55,11 +55,12 @@ enum FactorType {
   F_PRIOR_POINT3 = 5,
   F_PRIOR_CAM = 6,      // PriorFactor<PinholeCamera<Cal3Bundler>>  meas 17
   F_PROJECTION = 7,     // GenericProjectionFactor<Pose3,Point3,Cal3_S2> meas 2 + K(fx,fy,s,u0,v0)
-  F_PROJECTION_BPS = 8  // the same with body_P_sensor: meas 2 + K 5 + sensor pose (R row-major 9, t 3)
+  F_PROJECTION_BPS = 8, // the same with body_P_sensor: meas 2 + K 5 + sensor pose (R row-major 9, t 3)
+  F_BEARING_RANGE_2D = 9  // BearingRangeFactor<Pose2,Point2>  (pose, landmark), meas 2 (bearing angle, range)
 };
-static const int kFactorArity[9] = {2, 2, 2, 1, 1, 1, 1, 2, 2};
-static const int kFactorRows[9] = {2, 3, 6, 3, 6, 3, 9, 2, 2};
-static const int kFactorMeas[9] = {2, 3, 12, 3, 12, 3, 17, 7, 19};
+static const int kFactorArity[10] = {2, 2, 2, 1, 1, 1, 1, 2, 2, 2};
+static const int kFactorRows[10] = {2, 3, 6, 3, 6, 3, 9, 2, 2, 2};
+static const int kFactorMeas[10] = {2, 3, 12, 3, 12, 3, 17, 7, 19, 2};
 
 enum NoiseKind { N_UNIT = 0, N_ISO = 1, N_DIAG = 2, N_GAUSS = 3 };
 
@@ -147,6 +148,9 @@ static Value retract(const Value& x, const double* d) {
     }
     case POINT3:
       for (int i = 0; i < 3; i++) r.v[i] = x.v[i] + d[i];
+      break;
+    case POINT2:
+      for (int i = 0; i < 2; i++) r.v[i] = x.v[i] + d[i];
       break;
     case CAM_BUNDLER: {
       // PinholeCamera::retract gtsam/geometry/PinholeCamera.h:197-203; Cal3Bundler.h:134-136
@@ -281,6 +285,52 @@ static void evaluate_error(const Factor& f, const Values& vals, double* e, doubl
       Pose2 z = pose2_from(f.meas[0], f.meas[1], f.meas[2]);
       Pose2 d = compose(inverse(z), h);
       e[0] = d.x; e[1] = d.y; e[2] = pose2_theta(d);
+      return;
+    }
+    case F_BEARING_RANGE_2D: {
+      // BearingRangeFactor<Pose2,Point2> gtsam/sam/BearingRangeFactor.h:33-77 = ExpressionFactorN over BearingRange::Measure;
+      // unwhitenedError = -Local(value, measured) (gtsam/nonlinear/ExpressionFactor.h:104-115) with the Jacobians of the value:
+      // Pose2::bearing gtsam/geometry/Pose2.cpp:260-271 (transformTo :222-229, Rot2::unrotate, Rot2::relativeBearing
+      // gtsam/geometry/Rot2.cpp:134-145) and Pose2::range Pose2.cpp:285-299 (norm2 gtsam/geometry/Point2.cpp:27-36).
+      // (The reference orders the factor's keys by Key value; the oracle keeps (pose, landmark) -- the blocks are the same.)
+      const Value& a = vals.at(f.keys[0]);
+      const Value& l = vals.at(f.keys[1]);
+      const double c = std::cos(a.v[2]), sn = std::sin(a.v[2]);
+      const double dx = l.v[0] - a.v[0], dy = l.v[1] - a.v[1];
+      const double qx = c * dx + sn * dy, qy = -sn * dx + c * dy;  // transformTo
+      const double d2 = qx * qx + qy * qy, n = std::sqrt(d2);
+      double Hb[2] = {0.0, 0.0}, cb = 1.0, sb = 0.0;  // relativeBearing
+      if (std::abs(n) > 1e-5) {
+        Hb[0] = -qy / d2;
+        Hb[1] = qx / d2;
+        cb = qx / n;
+        sb = qy / n;
+      }
+      // bearing row: Hb * [-1 0 qy; 0 -1 -qx]  and  Hb * R^T
+      const double r = std::sqrt(dx * dx + dy * dy);
+      double Hr[2] = {1.0, 1.0};
+      if (std::abs(r) > 1e-10) {
+        Hr[0] = dx / r;
+        Hr[1] = dy / r;
+      }
+      if (H1) {
+        H1[0] = -Hb[0];
+        H1[1] = -Hb[1];
+        H1[2] = Hb[0] * qy - Hb[1] * qx;
+        H1[3] = Hr[0] * -c + Hr[1] * -sn;
+        H1[4] = Hr[0] * sn + Hr[1] * -c;
+        H1[5] = 0.0;
+      }
+      if (H2) {
+        H2[0] = Hb[0] * c + Hb[1] * -sn;
+        H2[1] = Hb[0] * sn + Hb[1] * c;
+        H2[2] = Hr[0];
+        H2[3] = Hr[1];
+      }
+      // -Local(value, measured): Rot2 Local = Logmap(value^-1 * measured) = theta of (cb, sb)^-1 * (cm, sm)
+      const double cm = std::cos(f.meas[0]), sm = std::sin(f.meas[0]);
+      e[0] = -std::atan2(cb * sm - sb * cm, cb * cm + sb * sm);
+      e[1] = r - f.meas[1];
       return;
     }
     case F_PRIOR_POSE2: {
@@ -1125,7 +1175,7 @@ void orc_destroy(void* h) { delete (Problem*)h; }
 
 int orc_add_variable(void* h, uint64_t key, int type, const double* value) {
   auto* p = (Problem*)h;
-  if (type < 0 || type > 3) return 2;
+  if (type < 0 || type > 4) return 2;
   Value v;
   v.type = type;
   std::memset(v.v, 0, sizeof(v.v));
@@ -1136,7 +1186,7 @@ int orc_add_variable(void* h, uint64_t key, int type, const double* value) {
 
 int orc_add_factor(void* h, int type, const uint64_t* keys, const double* meas, int noise_kind, const double* noise) {
   auto* p = (Problem*)h;
-  if (type < 0 || type > 8) return 2;
+  if (type < 0 || type > 9) return 2;
   Factor f;
   f.type = type;
   f.keys[0] = keys[0];

@@ -8,7 +8,7 @@ import oracle_harness as oh
 from gtsam_personal_amd import (LevenbergMarquardtOptimizer, LevenbergMarquardtParams, Marginals, NonlinearFactorGraph, Ordering, Values, _lib,
                                 noiseModel)
 from gtsam_personal_amd.synthetic import make_bal
-from test_oracle_golden import ODOMETRY_EXACT, ODOMETRY_PRINTED, _odometry_example
+from test_oracle_golden import ODOMETRY_EXACT, ODOMETRY_PRINTED, PLANAR_SLAM_EXPECTED, _odometry_example, _planar_slam_example
 
 pytestmark = pytest.mark.gpu
 
@@ -84,3 +84,33 @@ def test_gauge_freedom_reports_indeterminate():
     with pytest.raises(_lib.IndeterminantLinearSystemException):
         m.marginalCovariance(2)
     m.close()
+
+
+def test_planar_slam_marginals_known_answers_on_gpu():
+    """tests/testMarginals.cpp:40-126: the five marginal covariances of the planar SLAM example (BearingRangeFactor<Pose2, Point2>,
+    Point2 landmarks), asserted by the reference to 1e-8"""
+    graph, soln, keys = _planar_slam_example()
+    for ordering in ([keys[3], keys[4], keys[0], keys[1], keys[2]], list(keys)):
+        m = Marginals(graph, soln, Ordering(ordering))
+        for k, expected in zip(keys, PLANAR_SLAM_EXPECTED):
+            cov = m.marginalCovariance(k)
+            assert np.allclose(cov, np.array(expected), rtol=0, atol=1e-8), (k, cov)
+        m.close()
+
+
+def test_planar_slam_lm_matches_oracle():
+    """the same graph from a perturbed start: linearize / solve / LM trajectory of the bearing-range factors against the oracle"""
+    from test_gpu_parity import _check_linearize, _check_lm, _check_solve, _pair
+    graph, soln, keys = _planar_slam_example()
+    rng = np.random.default_rng(4)
+    initial = Values()
+    for k in keys[:3]:
+        initial.insert_pose2(k, *(soln.at(k) + rng.normal(0, [0.2, 0.2, 0.1])))
+    for k in keys[3:]:
+        initial.insert_point2(k, soln.at(k) + rng.normal(0, 0.3, 2))
+    opt, orc, params = _pair(graph, initial, Ordering([keys[3], keys[4], keys[0], keys[1], keys[2]]))
+    assert abs(opt.graph_error() - orc.error()) <= 1e-10 * orc.error()
+    _check_linearize(opt, orc, graph)
+    _check_solve(opt, orc, 1e-3)
+    _check_lm(opt, orc, params)
+    assert opt.error() < 1e-10

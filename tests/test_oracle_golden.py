@@ -729,3 +729,92 @@ def test_marginal_covariance_is_block_of_dense_inverse():
     C = np.linalg.inv(H)
     for k in range(n):
         assert np.allclose(orc.marginal_covariance(k, 3), C[3 * k:3 * k + 3, 3 * k:3 * k + 3], rtol=1e-9, atol=1e-12)
+
+
+def _planar_slam_example():
+    """tests/testMarginals.cpp:40-93 (PlanarSLAMSelfContained_advanced): prior on x1, two odometry factors, three
+    BearingRangeFactor<Pose2, Point2> to two landmarks; linearization point = the noise-free solution."""
+    from gtsam_personal_amd import NonlinearFactorGraph, Values, noiseModel, symbol
+    x1, x2, x3, l1, l2 = symbol("x", 1), symbol("x", 2), symbol("x", 3), symbol("l", 1), symbol("l", 2)
+    graph, soln = NonlinearFactorGraph(), Values()
+    graph.add_PriorFactorPose2(x1, [0.0, 0.0, 0.0], noiseModel.Diagonal.Sigmas([0.3, 0.3, 0.1]))
+    odo = noiseModel.Diagonal.Sigmas([0.2, 0.2, 0.1])
+    graph.add_BetweenFactorPose2(x1, x2, [2.0, 0.0, 0.0], odo)
+    graph.add_BetweenFactorPose2(x2, x3, [2.0, 0.0, 0.0], odo)
+    meas = noiseModel.Diagonal.Sigmas([0.1, 0.2])
+    graph.add_BearingRangeFactor2D(x1, l1, np.deg2rad(45.0), np.sqrt(8.0), meas)
+    graph.add_BearingRangeFactor2D(x2, l1, np.deg2rad(90.0), 2.0, meas)
+    graph.add_BearingRangeFactor2D(x3, l2, np.deg2rad(90.0), 2.0, meas)
+    soln.insert_pose2(x1, 0.0, 0.0, 0.0)
+    soln.insert_pose2(x2, 2.0, 0.0, 0.0)
+    soln.insert_pose2(x3, 4.0, 0.0, 0.0)
+    soln.insert_point2(l1, [2.0, 2.0])
+    soln.insert_point2(l2, [4.0, 2.0])
+    return graph, soln, (x1, x2, x3, l1, l2)
+
+
+# tests/testMarginals.cpp:96-118 (asserted there with tolerance 1e-8)
+PLANAR_SLAM_EXPECTED = [
+    [[0.09, -7.1942452e-18, -1.27897692e-17], [-7.1942452e-18, 0.09, 1.27897692e-17], [-1.27897692e-17, 1.27897692e-17, 0.01]],
+    [[0.120967742, -0.00129032258, 0.00451612903], [-0.00129032258, 0.158387097, 0.0206451613], [0.00451612903, 0.0206451613, 0.0177419355]],
+    [[0.160967742, 0.00774193548, 0.00451612903], [0.00774193548, 0.351935484, 0.0561290323], [0.00451612903, 0.0561290323, 0.0277419355]],
+    [[0.168709677, -0.0477419355], [-0.0477419355, 0.163548387]],
+    [[0.293870968, -0.104516129], [-0.104516129, 0.391935484]],
+]
+
+
+def test_marginals_planar_slam_known_answers():
+    from gtsam_personal_amd import Ordering
+    graph, soln, keys = _planar_slam_example()
+    orc = oh.OracleProblem(graph, soln, Ordering([keys[3], keys[4], keys[0], keys[1], keys[2]]))
+    assert orc.error() < 1e-20  # the measurements are exact at the linearization point
+    for k, expected in zip(keys, PLANAR_SLAM_EXPECTED):
+        expected = np.array(expected)
+        cov = orc.marginal_covariance(k, expected.shape[0])
+        assert np.allclose(cov, expected, rtol=0, atol=1e-8), (k, cov)
+
+
+def test_bearing_range_factor_values_from_pose2_tests():
+    """gtsam/geometry/tests/testPose2.cpp:606-721: bearings 0 / 45 deg / 45 deg shifted / 45 deg rotated and ranges 1, sqrt 2,
+    sqrt 2, 2 for the poses x1 = (0,0,0), x2 = (1,1,0), x3 = (1,1,pi/4) and landmarks l1..l4; the factor's Jacobians against
+    central differences of its own error (what the reference's test does with numericalDerivative)."""
+    from gtsam_personal_amd import NonlinearFactorGraph, Ordering, Values, noiseModel
+    cases = [((0.0, 0.0, 0.0), (1.0, 0.0), 0.0, 1.0), ((0.0, 0.0, 0.0), (1.0, 1.0), np.pi / 4, np.sqrt(2.0)),
+             ((1.0, 1.0, 0.0), (2.0, 2.0), np.pi / 4, np.sqrt(2.0)), ((1.0, 1.0, np.pi / 4), (1.0, 3.0), np.pi / 4, 2.0)]
+    for pose, lm, bearing, rng_ in cases:
+        def problem(p, l, zb=0.3, zr=0.5):
+            g, v = NonlinearFactorGraph(), Values()
+            g.add_BearingRangeFactor2D(1, 2, zb, zr, noiseModel.Diagonal.Sigmas([1.0, 1.0]))
+            v.insert_pose2(1, *p)
+            v.insert_point2(2, l)
+            return oh.OracleProblem(g, v, Ordering([1, 2]))
+        # error = (bearing - z_bearing wrapped, range - z_range): with z = the expected values the error vanishes
+        assert problem(pose, lm, bearing, rng_).error() < 1e-24
+        # with a different measurement the error is the wrapped difference
+        orc = problem(pose, lm)
+        eb = np.arctan2(np.sin(bearing - 0.3), np.cos(bearing - 0.3))
+        assert abs(orc.error() - 0.5 * (eb ** 2 + (rng_ - 0.5) ** 2)) < 1e-12
+        orc.linearize()
+        J = orc.jacobian(0)  # 2 x (3 + 2 + 1), unit noise: [H1 H2 b]
+        assert J.shape == (2, 6)
+        assert np.allclose(J[:, 5], -np.array([eb, rng_ - 0.5]), atol=1e-12)
+        h = 1e-6
+
+        def err(p, l):
+            c, s = np.cos(p[2]), np.sin(p[2])
+            q = np.array([c * (l[0] - p[0]) + s * (l[1] - p[1]), -s * (l[0] - p[0]) + c * (l[1] - p[1])])
+            return np.array([np.arctan2(q[1], q[0]), np.hypot(q[0], q[1])])
+        for j in range(3):  # pose tangent: retract = compose with (dx, dy, dtheta) in the body frame
+            d = np.zeros(3)
+            d[j] = h
+            c, s = np.cos(pose[2]), np.sin(pose[2])
+
+            def moved(sign):
+                return (pose[0] + sign * (c * d[0] - s * d[1]), pose[1] + sign * (s * d[0] + c * d[1]), pose[2] + sign * d[2])
+            num = (err(moved(+1), lm) - err(moved(-1), lm)) / (2 * h)
+            assert np.allclose(J[:, j], num, atol=1e-8), (pose, lm, j)
+        for j in range(2):
+            d = np.zeros(2)
+            d[j] = h
+            num = (err(pose, (lm[0] + d[0], lm[1] + d[1])) - err(pose, (lm[0] - d[0], lm[1] - d[1]))) / (2 * h)
+            assert np.allclose(J[:, 3 + j], num, atol=1e-8), (pose, lm, j)
