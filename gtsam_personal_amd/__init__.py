@@ -7,4 +7,4 @@ graph / optimizer interface (graph.py, optimizer.py) and the data formats either
 LevenbergMarquardtOptimizer does, and fails loudly if liblmgpu.so has not been built."""
 from .graph import (CAM_BUNDLER, POINT3, POSE2, POSE3, C, L, NonlinearFactorGraph, Ordering, P, Values, X, noiseModel, symbol)  # noqa: F401
 from .optimizer import (DoglegOptimizer, DoglegParams, GaussNewtonOptimizer, GaussNewtonParams, LevenbergMarquardtOptimizer,  # noqa: F401
-                        LevenbergMarquardtParams, Marginals)
+                        LevenbergMarquardtParams, JointMarginal, Marginals)

@@ -82,6 +82,7 @@ SYMBOLS = {
     "lmgpu_local_group_create": (ct.c_int, [ct.c_int32, ct.POINTER(ct.c_void_p)]),
     "lmgpu_local_group_destroy": (ct.c_int, [ct.c_void_p]),
     "lmgpu_marginal_covariance": (ct.c_int, [_H, ct.c_int32, _D]),
+    "lmgpu_joint_marginal_covariance": (ct.c_int, [_H, ct.c_int32, _I, _D]),
     "lmgpu_selftest_chain_schedule": (ct.c_int, [ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_int]),
     "lmgpu_comm_init_local": (ct.c_int, [_H, ct.c_void_p]),
     "lmgpu_peak_mfma_f64": (ct.c_int, [ct.c_int32, ct.c_int32, _D]),

@@ -1982,43 +1982,57 @@ __global__ __launch_bounds__(256) void zero_rhs_kernel(const FacDesc* __restrict
 }
 __global__ void set_one_kernel(double* p) { *p = 1.0; }
 
-int lmgpu_marginal_covariance(lmgpu_handle* h, int32_t slot, double* cov) {
-  if (!h || !cov || !h->finalized || !h->have_values || slot < 0 || slot >= h->plan.n_vars) return LMGPU_INVALID;
+int lmgpu_joint_marginal_covariance(lmgpu_handle* h, int32_t nslots, const int32_t* slots, double* cov) {
+  if (!h || !cov || !slots || nslots < 1 || !h->finalized || !h->have_values) return LMGPU_INVALID;
+  for (int a = 0; a < nslots; a++) {
+    if (slots[a] < 0 || slots[a] >= h->plan.n_vars) return LMGPU_INVALID;
+    for (int b = 0; b < a; b++)
+      if (slots[b] == slots[a]) return LMGPU_INVALID;
+  }
   if (h->cfg.world_size > 1) {
     h->err = "marginal covariances are computed on one GPU";
     return LMGPU_INVALID;
   }
   int rc = need_device(h);
   if (rc) return rc;
-  // Marginals::Marginals (gtsam/nonlinear/Marginals.cpp:29-78): linearize at the solution, eliminate into a Bayes tree
+  // Marginals::Marginals (gtsam/nonlinear/Marginals.cpp:28-43): linearize at the solution, eliminate into a Bayes tree
   // (here: the same two kernels as every LM step, lambda = 0);  marginalCovariance (:124-127) = inverse of the marginal
-  // information (:109-121) = the variable's diagonal block of (A^T A)^-1.  Column k of that block is the variable's part of
-  // the solution of  A^T A x = e_k,  i.e. one elimination + back-substitution with the gradient replaced by a unit vector.
+  // information (:109-121) = the variable's diagonal block of (A^T A)^-1;  jointMarginalCovariance (:130-137) = the blocks of
+  // (A^T A)^-1 for several variables.  Column k of those blocks is the variables' part of the solution of  A^T A x = e_k,
+  // i.e. one elimination + back-substitution with the gradient replaced by a unit vector.
   if ((rc = do_linearize(h))) return rc;
   hipStream_t s = h->stream;
   if (h->nfac > 0) hipLaunchKernelGGL(zero_rhs_kernel, dim3((h->nfac + 255) / 256), dim3(256), 0, s, (const FacDesc*)h->d_fd, h->nfac, h->pool);
   if (!h->gex) HIPCHECK(hipMalloc((void**)&h->gex, h->ntot * sizeof(double)));
   if ((rc = fill_dampw(h, 0, 0.0, 0.0))) return rc;
-  const int d = h->plan.dims[slot], x0 = h->plan.xoff[slot];
-  std::vector<double> col(d);
+  std::vector<int> boff(nslots + 1, 0);  // block offsets inside the joint matrix, in the order of `slots`
+  for (int a = 0; a < nslots; a++) boff[a + 1] = boff[a] + h->plan.dims[slots[a]];
+  const int D = boff[nslots];
+  std::vector<double> col(h->ntot);
   h->gex_active = h->gex;
-  for (int k = 0; k < d && rc == LMGPU_OK; k++) {
-    HIPCHECK(hipMemsetAsync(h->gex, 0, h->ntot * sizeof(double), s));
-    hipLaunchKernelGGL(set_one_kernel, dim3(1), dim3(1), 0, s, h->gex + x0 + k);
-    rc = do_solve(h, 0.0);
-    if (rc == LMGPU_OK) {
-      HIPCHECK(hipMemcpy(col.data(), h->delta + x0, d * sizeof(double), hipMemcpyDeviceToHost));
-      for (int i = 0; i < d; i++) cov[(size_t)i * d + k] = col[i];
+  for (int a = 0; a < nslots && rc == LMGPU_OK; a++) {
+    for (int k = 0; k < h->plan.dims[slots[a]] && rc == LMGPU_OK; k++) {
+      HIPCHECK(hipMemsetAsync(h->gex, 0, h->ntot * sizeof(double), s));
+      hipLaunchKernelGGL(set_one_kernel, dim3(1), dim3(1), 0, s, h->gex + h->plan.xoff[slots[a]] + k);
+      rc = do_solve(h, 0.0);
+      if (rc != LMGPU_OK) break;
+      for (int b = 0; b < nslots; b++) {
+        const int db = h->plan.dims[slots[b]];
+        HIPCHECK(hipMemcpy(col.data(), h->delta + h->plan.xoff[slots[b]], db * sizeof(double), hipMemcpyDeviceToHost));
+        for (int i = 0; i < db; i++) cov[(size_t)(boff[b] + i) * D + boff[a] + k] = col[i];
+      }
     }
   }
   h->gex_active = nullptr;
   h->linearized = false;  // the stored right-hand sides are gone: the next solve linearizes again
   h->solved = false;
   if (rc != LMGPU_OK) return rc;  // LMGPU_INDETERMINATE like Marginals' IndeterminantLinearSystemException
-  for (int i = 0; i < d; i++)
-    for (int j = i + 1; j < d; j++) cov[(size_t)i * d + j] = cov[(size_t)j * d + i] = 0.5 * (cov[(size_t)i * d + j] + cov[(size_t)j * d + i]);
+  for (int i = 0; i < D; i++)
+    for (int j = i + 1; j < D; j++) cov[(size_t)i * D + j] = cov[(size_t)j * D + i] = 0.5 * (cov[(size_t)i * D + j] + cov[(size_t)j * D + i]);
   return LMGPU_OK;
 }
+
+int lmgpu_marginal_covariance(lmgpu_handle* h, int32_t slot, double* cov) { return lmgpu_joint_marginal_covariance(h, 1, &slot, cov); }
 
 int lmgpu_retract(lmgpu_handle* h, const double* delta_packed) {
   if (!h || !h->finalized || !h->have_values) return LMGPU_INVALID;

@@ -376,5 +376,38 @@ class Marginals:
     def marginalInformation(self, key) -> np.ndarray:
         return np.linalg.inv(self.marginalCovariance(key))
 
+    def jointMarginalCovariance(self, keys) -> "JointMarginal":
+        """Marginals::jointMarginalCovariance (Marginals.cpp:130-137): blocks ordered by Key like JointMarginal::fullMatrix"""
+        o = self._opt
+        keys = sorted(int(k) for k in keys)
+        slots = np.array([o._slot[k] for k in keys], dtype=np.int32)
+        dims = [int(o._xoff[s + 1] - o._xoff[s]) for s in slots]
+        out = np.zeros((sum(dims), sum(dims)))
+        o._check(o.lib.lmgpu_joint_marginal_covariance(o._h, len(slots), _ip(slots), _dp(out)))
+        return JointMarginal(keys, dims, out)
+
+    def jointMarginalInformation(self, keys) -> "JointMarginal":
+        j = self.jointMarginalCovariance(keys)
+        return JointMarginal(j.keys, j.dims, np.linalg.inv(j.fullMatrix()))
+
     def close(self):
         self._opt.close()
+
+
+class JointMarginal:
+    """JointMarginal (gtsam/nonlinear/Marginals.h:141-191): at(iVariable, jVariable) = block (i, j); fullMatrix() with the
+    blocks ordered by Key"""
+
+    def __init__(self, keys, dims, full):
+        self.keys, self.dims, self._full = list(keys), list(dims), full
+        off = np.concatenate([[0], np.cumsum(dims)])
+        self._range = {k: (int(off[i]), int(off[i + 1])) for i, k in enumerate(keys)}
+
+    def at(self, iVariable, jVariable) -> np.ndarray:
+        (a0, a1), (b0, b1) = self._range[int(iVariable)], self._range[int(jVariable)]
+        return self._full[a0:a1, b0:b1].copy()
+
+    __call__ = at
+
+    def fullMatrix(self) -> np.ndarray:
+        return self._full.copy()

@@ -244,6 +244,10 @@ int lmgpu_local_group_destroy(lmgpu_local_group* g);
  * lmgpu_solve needs lmgpu_linearize again).  LMGPU_INDETERMINATE where the reference throws
  * IndeterminantLinearSystemException (singular information matrix).  One GPU only (world_size == 1). */
 int lmgpu_marginal_covariance(lmgpu_handle* h, int32_t slot, double* cov /* dim x dim */);
+/* Marginals::jointMarginalCovariance(variables) (gtsam/nonlinear/Marginals.cpp:130-137): the blocks of (A^T A)^-1 for the
+ * variables in `slots` (distinct), as one D x D row-major matrix, D = sum of their dims, block order = order of `slots`
+ * (the reference's JointMarginal::fullMatrix orders the blocks by Key; the caller chooses here).  Cost: D unit-gradient solves. */
+int lmgpu_joint_marginal_covariance(lmgpu_handle* h, int32_t nslots, const int32_t* slots, double* cov /* D x D */);
 
 /* Host-only self-test (no GPU work): the ticket order the library gives the chained factorisation launch of a dense front
  * with n columns (nf frontal) for the steps i0 .. i0 + nsteps - 1 (tile rows beyond far_pct percent scheduled late) is a permutation of all logical workgroups in which every

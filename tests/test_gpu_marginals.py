@@ -8,7 +8,8 @@ import oracle_harness as oh
 from gtsam_personal_amd import (LevenbergMarquardtOptimizer, LevenbergMarquardtParams, Marginals, NonlinearFactorGraph, Ordering, Values, _lib,
                                 noiseModel)
 from gtsam_personal_amd.synthetic import make_bal
-from test_oracle_golden import ODOMETRY_EXACT, ODOMETRY_PRINTED, PLANAR_SLAM_EXPECTED, _odometry_example, _planar_slam_example
+from test_oracle_golden import (ODOMETRY_EXACT, ODOMETRY_PRINTED, PLANAR_SLAM_EXPECTED, PLANAR_SLAM_JOINT_L2_X1_X3, _odometry_example,
+                                _planar_slam_example)
 
 pytestmark = pytest.mark.gpu
 
@@ -114,3 +115,25 @@ def test_planar_slam_lm_matches_oracle():
     _check_solve(opt, orc, 1e-3)
     _check_lm(opt, orc, params)
     assert opt.error() < 1e-10
+
+
+def test_planar_slam_joint_marginals_known_answers_on_gpu():
+    """tests/testMarginals.cpp:128-176: jointMarginalCovariance of (x1, l2, x3) and of (l2, x1): blocks in Key order (l2, x1, x3),
+    asserted by the reference to 1e-6; the single-variable joint equals the marginal"""
+    graph, soln, keys = _planar_slam_example()
+    x1, x2, x3, l1, l2 = keys
+    m = Marginals(graph, soln, Ordering([l1, l2, x1, x2, x3]))
+    joint = m.jointMarginalCovariance([x1, l2, x3])
+    assert joint.keys == [l2, x1, x3] and joint.dims == [2, 3, 3]
+    assert np.allclose(joint.fullMatrix(), PLANAR_SLAM_JOINT_L2_X1_X3, rtol=0, atol=1e-6)
+    assert np.allclose(joint(l2, l2), PLANAR_SLAM_JOINT_L2_X1_X3[0:2, 0:2], atol=1e-6)
+    assert np.allclose(joint(x1, l2), PLANAR_SLAM_JOINT_L2_X1_X3[2:5, 0:2], atol=1e-6)
+    assert np.allclose(joint(x3, x1), PLANAR_SLAM_JOINT_L2_X1_X3[5:8, 2:5], atol=1e-6)
+    joint2 = m.jointMarginalCovariance([l2, x1])
+    assert np.allclose(joint2.fullMatrix(), PLANAR_SLAM_JOINT_L2_X1_X3[0:5, 0:5], atol=1e-6)
+    joint1 = m.jointMarginalCovariance([x1])
+    assert np.allclose(joint1(x1, x1), m.marginalCovariance(x1), atol=1e-12)
+    # consistency with the single-variable marginals and with the information form
+    assert np.allclose(joint(x3, x3), m.marginalCovariance(x3), atol=1e-12)
+    assert np.allclose(m.jointMarginalInformation([l2, x1]).fullMatrix() @ joint2.fullMatrix(), np.eye(5), atol=1e-9)
+    m.close()

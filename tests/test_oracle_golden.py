@@ -818,3 +818,15 @@ def test_bearing_range_factor_values_from_pose2_tests():
             d[j] = h
             num = (err(pose, (lm[0] + d[0], lm[1] + d[1])) - err(pose, (lm[0] - d[0], lm[1] - d[1]))) / (2 * h)
             assert np.allclose(J[:, 3 + j], num, atol=1e-8), (pose, lm, j)
+
+
+# tests/testMarginals.cpp:130-140: joint marginal of (l2, x1, x3) in Key order, asserted there with tolerance 1e-6
+PLANAR_SLAM_JOINT_L2_X1_X3 = np.array([
+    [0.293871159514111, -0.104516127560770, 0.090000180000270, -0.000000000000000, -0.020000000000000, 0.151935669757191, -0.104516127560770, -0.050967744878460],
+    [-0.104516127560770, 0.391935664055174, 0.000000000000000, 0.090000180000270, 0.040000000000000, 0.007741936219615, 0.351935664055174, 0.056129031890193],
+    [0.090000180000270, 0.000000000000000, 0.090000180000270, -0.000000000000000, 0.000000000000000, 0.090000180000270, 0.000000000000000, 0.000000000000000],
+    [-0.000000000000000, 0.090000180000270, -0.000000000000000, 0.090000180000270, 0.000000000000000, -0.000000000000000, 0.090000180000270, 0.000000000000000],
+    [-0.020000000000000, 0.040000000000000, 0.000000000000000, 0.000000000000000, 0.010000000000000, 0.000000000000000, 0.040000000000000, 0.010000000000000],
+    [0.151935669757191, 0.007741936219615, 0.090000180000270, -0.000000000000000, 0.000000000000000, 0.160967924878730, 0.007741936219615, 0.004516127560770],
+    [-0.104516127560770, 0.351935664055174, 0.000000000000000, 0.090000180000270, 0.040000000000000, 0.007741936219615, 0.351935664055174, 0.056129031890193],
+    [-0.050967744878460, 0.056129031890193, 0.000000000000000, 0.000000000000000, 0.010000000000000, 0.004516127560770, 0.056129031890193, 0.027741936219615]])
