@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .graph import NonlinearFactorGraph, P, Values, noiseModel, symbol
+from .graph import L, NonlinearFactorGraph, P, Values, noiseModel, symbol
 
 
 # ---------------------------------------------------------------- small host geometry (loader-side only)
@@ -144,17 +144,27 @@ def _noise2d(v, smart, fmt):
     return noiseModel.Gaussian.Covariance(M, smart)
 
 
-def load2D(filename, noise_format="auto", smart=True):
-    """(graph, initial) with Pose2 vertices keyed by their integer id (gtsam/slam/dataset.cpp:505-569; noise_format as the reference's
-    NoiseFormat: "auto" (default), "g2o", "toro", "graph", "cov"; readG2o passes "g2o")."""
+def load2D(filename, noise_format="auto", smart=True, max_index=0):
+    """(graph, initial): Pose2 vertices keyed by their integer id, Point2 landmarks by L(id) (gtsam/slam/dataset.cpp:505-569;
+    noise_format as the reference's NoiseFormat: "auto" (default), "g2o", "toro", "graph", "cov"; readG2o passes "g2o").
+    Tags: VERTEX2 / VERTEX_SE2 / VERTEX, VERTEX_XY (:192-205), EDGE2 / EDGE / EDGE_SE2 / ODOMETRY (:338-377), and the
+    bearing-range measurements BR and LANDMARK (:450-502: a LANDMARK line's (x, y) sighting becomes bearing = atan2(y, x),
+    range = |(x, y)| with sigmas (sqrt(v1 / 10), sqrt(v1)) when its covariance is isotropic, else (1, 1)).  max_index as the
+    reference's maxIndex: vertices above it are dropped, edges if either id is, bearing-range factors if the pose id is."""
     graph, initial = NonlinearFactorGraph(), Values()
     lines = [ln.split() for ln in open(filename) if ln.strip()]
     for t in lines:
         if t[0] in ("VERTEX2", "VERTEX_SE2", "VERTEX"):
-            initial.insert_pose2(int(t[1]), float(t[2]), float(t[3]), float(t[4]))
+            if not max_index or int(t[1]) <= max_index:
+                initial.insert_pose2(int(t[1]), float(t[2]), float(t[3]), float(t[4]))
+        elif t[0] == "VERTEX_XY":
+            if not max_index or int(t[1]) <= max_index:
+                initial.insert_point2(L(int(t[1])), [float(t[2]), float(t[3])])
     for t in lines:
         if t[0] in ("EDGE2", "EDGE", "EDGE_SE2", "ODOMETRY"):
             id1, id2 = int(t[1]), int(t[2])
+            if max_index and (id1 > max_index or id2 > max_index):
+                continue
             x, y, yaw = float(t[3]), float(t[4]), float(t[5])
             graph.add_BetweenFactorPose2(id1, id2, [x, y, yaw], _noise2d(t[6:12], smart, noise_format))
             if not initial.exists(id1):
@@ -163,6 +173,28 @@ def load2D(filename, noise_format="auto", smart=True):
                 a = initial.at(id1)
                 c, s = np.cos(a[2]), np.sin(a[2])
                 initial.insert_pose2(id2, a[0] + c * x - s * y, a[1] + s * x + c * y, np.arctan2(np.sin(a[2] + yaw), np.cos(a[2] + yaw)))
+        elif t[0] in ("BR", "LANDMARK"):
+            id1, id2 = int(t[1]), int(t[2])
+            if t[0] == "BR":
+                bearing, rng, bearing_std, range_std = (float(x) for x in t[3:7])
+            else:
+                lmx, lmy, v1, _v2, v3 = (float(x) for x in t[3:8])
+                bearing, rng = np.arctan2(lmy, lmx), np.sqrt(lmx * lmx + lmy * lmy)
+                if abs(v1 - v3) < 1e-4:
+                    bearing_std, range_std = np.sqrt(v1 / 10.0), np.sqrt(v1)
+                else:
+                    bearing_std, range_std = 1.0, 1.0
+            if max_index and id1 > max_index:
+                continue
+            key2 = L(id2)
+            graph.add_BearingRangeFactor2D(id1, key2, bearing, rng, noiseModel.Diagonal.Sigmas([bearing_std, range_std]))
+            if not initial.exists(id1):
+                initial.insert_pose2(id1, 0.0, 0.0, 0.0)
+            if not initial.exists(key2):  # pose.transformFrom(bearing * Point2(range, 0))
+                a = initial.at(id1)
+                lx, ly = rng * np.cos(bearing), rng * np.sin(bearing)
+                c, s = np.cos(a[2]), np.sin(a[2])
+                initial.insert_point2(key2, [a[0] + c * lx - s * ly, a[1] + s * lx + c * ly])
     return graph, initial
 
 
@@ -274,9 +306,9 @@ def _rot3_to_quat(R):
 
 
 def writeG2o(graph: NonlinearFactorGraph, estimate: Values, filename):
-    """gtsam/slam/dataset.cpp:636-735: VERTEX_SE2 / VERTEX_SE3:QUAT / VERTEX_TRACKXYZ then EDGE_SE2 / EDGE_SE3:QUAT with the upper
+    """gtsam/slam/dataset.cpp:636-735: VERTEX_SE2 / VERTEX_SE3:QUAT / VERTEX_XY / VERTEX_TRACKXYZ then EDGE_SE2 / EDGE_SE3:QUAT with the upper
     triangle of the information matrix (3D: reordered to g2o's t,R convention); ids = Symbol(key).index()."""
-    from .graph import F_BETWEEN_POSE2, F_BETWEEN_POSE3, POINT3, POSE2, POSE3
+    from .graph import F_BETWEEN_POSE2, F_BETWEEN_POSE3, POINT2, POINT3, POSE2, POSE3
     index = lambda key: int(key) & ((1 << 56) - 1)  # noqa: E731  Symbol(key).index()
     keys = sorted(estimate.keys())
     with open(filename, "w") as o:
@@ -289,6 +321,10 @@ def writeG2o(graph: NonlinearFactorGraph, estimate: Values, filename):
                 v = estimate.at(k)
                 w, x, y, z = _rot3_to_quat(v[:9])
                 o.write(f"VERTEX_SE3:QUAT {index(k)} {_g(v[9])} {_g(v[10])} {_g(v[11])} {_g(x)} {_g(y)} {_g(z)} {_g(w)}\n")
+        for k in keys:
+            if estimate.type(k) == POINT2:  # 2D landmarks, dataset.cpp:660-665
+                v = estimate.at(k)
+                o.write(f"VERTEX_XY {index(k)} {_g(v[0])} {_g(v[1])}\n")
         for k in keys:
             if estimate.type(k) == POINT3:
                 v = estimate.at(k)

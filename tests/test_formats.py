@@ -132,3 +132,43 @@ def test_read_bal_dubrovnik_known_answers():
     z, depth = project_bundler(np.asarray(R)[None], np.asarray(t)[None], np.array([f]), np.array([k1]), np.array([k2]), np.asarray(tr["p"])[None])
     assert depth[0] > 0
     assert np.abs(z[0] - np.array(tr["measurements"][0][1])).max() < 12
+
+
+def test_load2d_victoria_park_counts_and_landmarks():
+    """gtsam/slam/tests/testDataset.cpp:131-145 (load2DVictoriaPark): 10608 factors / 7120 values; restricted to maxIndex = 5:
+    5 factors, 6 values, and the last factor's second key is L(5).  The file has ODOMETRY and LANDMARK lines only."""
+    from gtsam_personal_amd.graph import F_BEARING_RANGE_2D, F_BETWEEN_POSE2, POINT2, POSE2, L
+    path = os.path.join(GOLD, "victoria_park.txt")
+    graph, initial = load2D(path)
+    assert graph.size() == 10608 and initial.size() == 7120
+    types = [initial.type(k) for k in initial.keys()]
+    assert types.count(POSE2) == 6969 and types.count(POINT2) == 151
+    counts = {ft: len(gi) for ft, _, gi, *_ in graph.buckets()}
+    assert counts[F_BETWEEN_POSE2] == 6968 and counts[F_BEARING_RANGE_2D] == 3640
+    graph2, initial2 = load2D(path, max_index=5)
+    assert graph2.size() == 5 and initial2.size() == 6
+    last = [(fk, ft) for ft, _, gi, fkeys, *_ in graph2.buckets() for g, fk in zip(gi.tolist(), fkeys) if g == 4]
+    assert len(last) == 1 and last[0][1] == F_BEARING_RANGE_2D and int(last[0][0][1]) == L(5)
+    # the first LANDMARK line: "LANDMARK 4 5 11.5387 -3.2007 0.4 0 0.4" -> bearing / range and sigmas (sqrt(0.04), sqrt(0.4))
+    for ft, kind, gi, fkeys, meas, noise, models in graph2.buckets():
+        if ft == F_BEARING_RANGE_2D:
+            assert np.allclose(meas[0], [np.arctan2(-3.2007, 11.5387), np.hypot(11.5387, -3.2007)], atol=1e-12)
+            assert np.allclose(models[0].data, [np.sqrt(0.04), np.sqrt(0.4)], atol=1e-12)
+    # the landmark was not in the file as a vertex: it is initialised from the sighting, pose.transformFrom(bearing * (range, 0))
+    p4, l5 = initial2.at(4), initial2.at(L(5))
+    c, s = np.cos(p4[2]), np.sin(p4[2])
+    assert np.allclose(l5, [p4[0] + c * 11.5387 - s * -3.2007, p4[1] + s * 11.5387 + c * -3.2007], atol=1e-9)
+
+
+def test_writeg2o_roundtrips_planar_landmarks(tmp_path):
+    from gtsam_personal_amd.graph import L
+    graph, initial = load2D(os.path.join(GOLD, "victoria_park.txt"), max_index=40)
+    out = tmp_path / "vp.g2o"
+    writeG2o(graph, initial, str(out))
+    text = out.read_text().splitlines()
+    assert sum(ln.startswith("VERTEX_XY ") for ln in text) == sum(1 for k in initial.keys() if len(initial.at(k)) == 2)
+    assert sum(ln.startswith("VERTEX_SE2 ") for ln in text) == sum(1 for k in initial.keys() if len(initial.at(k)) == 3)
+    _, again = load2D(str(out), "g2o")
+    for k in initial.keys():
+        kk = k if len(initial.at(k)) == 3 else L(int(k) & ((1 << 56) - 1))
+        assert np.allclose(again.at(kk), initial.at(k), rtol=1e-5, atol=1e-6)

@@ -77,3 +77,17 @@ def test_city10000_full(which):
     graph.add_PriorFactorPose2(0, initial.at(0), noiseModel.Diagonal.Variances([1e-6, 1e-6, 1e-8]))  # Pose2SLAMExample_g2o.cpp:60-66
     ordering = oh.colamd(graph) if which == "colamd" else oh.metis(graph)
     _compare(graph, initial, ordering, 1e-5, 2, range(0, graph.size(), 211))
+
+
+@pytest.mark.parametrize("which", ["colamd", "metis"])
+def test_victoria_park_full(which):
+    """examples/Data/victoria_park.txt at full size (6 969 Pose2, 151 Point2 landmarks, 6 968 odometry and 3 640
+    BearingRangeFactor<Pose2, Point2> built from its LANDMARK lines, gtsam/slam/tests/testDataset.cpp:131-145): the planar
+    landmark SLAM shape -- long odometry chain, landmarks observed from hundreds of poses each."""
+    if not oh.have_ref():
+        pytest.skip("oracle/_ref not present")
+    graph, initial = load2D(os.path.join(GOLD, "victoria_park.txt"))
+    assert graph.size() == 10608 and initial.size() == 7120
+    graph.add_PriorFactorPose2(0, initial.at(0), noiseModel.Diagonal.Variances([1e-6, 1e-6, 1e-8]))
+    ordering = oh.colamd(graph) if which == "colamd" else oh.metis(graph)
+    _compare(graph, initial, ordering, 1e-5, 2, range(0, graph.size(), 173))

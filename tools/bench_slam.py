@@ -64,3 +64,8 @@ g, init = readG2o(os.path.join(GOLD, "city10000.g2o"))
 g.add_PriorFactorPose2(0, init.at(0), noiseModel.Diagonal.Variances([1e-6, 1e-6, 1e-8]))
 run("city10000 / METIS", g, init, oh.metis(g))
 run("city10000 / COLAMD", g, init, oh.colamd(g))
+from gtsam_personal_amd.datasets import load2D  # noqa: E402
+g, init = load2D(os.path.join(GOLD, "victoria_park.txt"))
+g.add_PriorFactorPose2(0, init.at(0), noiseModel.Diagonal.Variances([1e-6, 1e-6, 1e-8]))
+run("victoria_park / METIS", g, init, oh.metis(g))
+run("victoria_park / COLAMD", g, init, oh.colamd(g))
