@@ -32,13 +32,13 @@ __global__ __launch_bounds__(256) void med_assemble_children_kernel(MedLevel L, 
   assemble_child_body(F, L.f_off[fi], L.f_ld[fi], childs, cmap, pool, blockIdx.x, smap);
 }
 
-__global__ __launch_bounds__(256) void med_damp_kernel(MedLevel L, const int32_t* __restrict__ fxoff, double* __restrict__ pool, double lambda,
+__global__ __launch_bounds__(256) void med_damp_kernel(MedLevel L, const int32_t* __restrict__ fxoff, double* __restrict__ pool, double lambda_v, const double* __restrict__ lambda_p,
                                                         const double* __restrict__ dampw, const double* __restrict__ gex) {
   const int fi = L.list[blockIdx.y];
   const FrontDesc F = L.fronts[fi];
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= F.nf) return;
-  pool[L.f_off[fi] + (size_t)i * L.f_ld[fi] + i] += lambda * dampw[fxoff[F.fx_begin + i]];
+  pool[L.f_off[fi] + (size_t)i * L.f_ld[fi] + i] += (lambda_p ? *lambda_p : lambda_v) * dampw[fxoff[F.fx_begin + i]];
   if (gex) pool[L.f_off[fi] + (size_t)i * L.f_ld[fi] + F.n - 1] += gex[fxoff[F.fx_begin + i]];
 }
 

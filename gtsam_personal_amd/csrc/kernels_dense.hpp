@@ -85,11 +85,11 @@ __global__ __launch_bounds__(256) void hbm_assemble_children_kernel(FrontDesc F,
 }
 
 __global__ __launch_bounds__(256) void hbm_damp_kernel(FrontDesc F, int64_t f_off, int ld, const int32_t* __restrict__ fxoff,
-                                                        double* __restrict__ pool, double lambda, const double* __restrict__ dampw,
+                                                        double* __restrict__ pool, double lambda_v, const double* __restrict__ lambda_p, const double* __restrict__ dampw,
                                                         const double* __restrict__ gex) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= F.nf) return;
-  pool[f_off + (size_t)i * ld + i] += lambda * dampw[fxoff[F.fx_begin + i]];
+  pool[f_off + (size_t)i * ld + i] += (lambda_p ? *lambda_p : lambda_v) * dampw[fxoff[F.fx_begin + i]];
   if (gex) pool[f_off + (size_t)i * ld + F.n - 1] += gex[fxoff[F.fx_begin + i]];
 }
 

@@ -70,7 +70,7 @@ template <bool GATHER>
 __global__ __launch_bounds__(256) void lds_front_kernel(const int32_t* __restrict__ list, const FrontDesc* __restrict__ fronts,
                                                          const FrontFac* __restrict__ ffac, const FacDesc* __restrict__ fd,
                                                          const ChildRef* __restrict__ childs, const int32_t* __restrict__ cmap,
-                                                         const int32_t* __restrict__ fxoff, double* __restrict__ pool, double lambda,
+                                                         const int32_t* __restrict__ fxoff, double* __restrict__ pool, double lambda_v, const double* __restrict__ lambda_p,
                                                          const double* __restrict__ dampw, int* __restrict__ status, int nmax, int srows,
                                                          double* __restrict__ gcorner, int jcap, const double* __restrict__ gex) {
   extern __shared__ double S[];
@@ -198,6 +198,8 @@ __global__ __launch_bounds__(256) void lds_front_kernel(const int32_t* __restric
     __syncthreads();
   }
   // ---- damping on the frontal diagonal
+  // lambda_p != nullptr: the value lives in device memory so that a captured launch sequence can be replayed with a new one
+  const double lambda = lambda_p ? *lambda_p : lambda_v;
   for (int i = tid; i < nf; i += nt) {
     S[i * n + i] += lambda * dampw[fxoff[F.fx_begin + i]];
     if (gex) S[i * n + n - 1] += gex[fxoff[F.fx_begin + i]];  // extra gradient term eta += g (marginal covariances: unit vectors)

@@ -203,6 +203,10 @@ struct lmgpu_handle {
   struct ChainPlan { int i0 = -1, nsteps = 0, ntasks = 0; int2* d_tasks = nullptr; double flop = 0; };
   std::map<int, ChainPlan> chain_plans;        // per HBM front: ticket order of its chained launch (built at first use)
   int chain_far_pct = 50;                      // LMGPU_CHAIN_FAR: tile rows beyond this percentage of the front are scheduled late (chain_schedule)
+  double* d_lambda = nullptr;   // damping parameter of the solve being queued (device memory: see do_solve_enqueue)
+  bool use_graph = false;       // replay the solve's launch sequence as a hipGraph (deep trees; LMGPU_GRAPH=0/1 overrides)
+  int eager_solves = 0;
+  hipGraphExec_t solve_graph[2] = {nullptr, nullptr};  // [1]: with the extra gradient vector of the marginal solves
   bool no_chain = false;                       // LMGPU_NO_CHAIN=1: one launch per fused step instead of one per run of steps (A/B)
   unsigned int* d_pflags = nullptr;            // hand-off flags of panel_dataflow_kernel, PDF_FLAG_WORDS per outer panel
   int pflags_panels = 0;
@@ -478,7 +482,7 @@ int fill_dampw(lmgpu_handle* h, int diagonal, double min_diag, double max_diag) 
 }
 
 // ---- numeric elimination of all (active) fronts, level by level (a10-a13)
-int do_eliminate(lmgpu_handle* h, double lambda) {
+int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  // lambda by value (eager) or in device memory (graph replay)
   hipStream_t s = h->stream;
   HIPCHECK(hipMemsetAsync(h->d_status, 0x7f, sizeof(int), s));
   {  // HBM fronts are accumulated into by their children (atomics) before their own level runs: clear them all first
@@ -521,13 +525,13 @@ int do_eliminate(lmgpu_handle* h, double lambda) {
         hipLaunchKernelGGL(lds_front_kernel<false>, dim3(cnt), dim3(threads), lds, s,
                            (const int32_t*)(h->d_lists + L.list_begin + L.bin_begin[b]), (const FrontDesc*)h->d_fronts,
                            (const FrontFac*)h->d_ffac, (const FacDesc*)h->d_fd, (const ChildRef*)h->d_childs, (const int32_t*)h->d_cmap,
-                           (const int32_t*)h->d_fxoff, h->pool, lambda, (const double*)h->dampw, h->d_status, nmax, srows, h->d_gcorner, jcap,
+                           (const int32_t*)h->d_fxoff, h->pool, lambda_v, lambda_p, (const double*)h->dampw, h->d_status, nmax, srows, h->d_gcorner, jcap,
                            (const double*)h->gex_active);
       else
         hipLaunchKernelGGL(lds_front_kernel<true>, dim3(cnt), dim3(threads), lds, s,
                            (const int32_t*)(h->d_lists + L.list_begin + L.bin_begin[b]), (const FrontDesc*)h->d_fronts,
                            (const FrontFac*)h->d_ffac, (const FacDesc*)h->d_fd, (const ChildRef*)h->d_childs, (const int32_t*)h->d_cmap,
-                           (const int32_t*)h->d_fxoff, h->pool, lambda, (const double*)h->dampw, h->d_status, nmax, srows, h->d_gcorner, jcap,
+                           (const int32_t*)h->d_fxoff, h->pool, lambda_v, lambda_p, (const double*)h->dampw, h->d_status, nmax, srows, h->d_gcorner, jcap,
                            (const double*)h->gex_active);
       h->kt.end(kt, s);
     }
@@ -542,8 +546,8 @@ int do_eliminate(lmgpu_handle* h, double lambda) {
       if (L.med_max_child > 0)
         hipLaunchKernelGGL(med_assemble_children_kernel, dim3(L.med_max_child, cnt), dim3(256), 0, s, ML, (const ChildRef*)h->d_childs,
                            (const int32_t*)h->d_cmap, h->pool);
-      hipLaunchKernelGGL(med_damp_kernel, dim3((L.med_max_nf + 255) / 256, cnt), dim3(256), 0, s, ML, (const int32_t*)h->d_fxoff, h->pool, lambda,
-                         (const double*)h->dampw, (const double*)h->gex_active);
+      hipLaunchKernelGGL(med_damp_kernel, dim3((L.med_max_nf + 255) / 256, cnt), dim3(256), 0, s, ML, (const int32_t*)h->d_fxoff, h->pool, lambda_v,
+                         lambda_p, (const double*)h->dampw, (const double*)h->gex_active);
       h->kt.end(ktm, s);
       ktm = h->kt.begin(LMGPU_KT_PANEL, s);
       hipLaunchKernelGGL(med_diag_potrf_kernel, dim3(cnt), dim3(256), DIAG_LDS_BYTES, s, ML, h->pool, h->d_status, h->inv16_med);
@@ -603,8 +607,8 @@ int do_eliminate(lmgpu_handle* h, double lambda) {
         hipLaunchKernelGGL(hbm_assemble_children_kernel, dim3(F.child_count), dim3(256), 0, sa, F, aoff, ld, (const ChildRef*)h->d_childs,
                            (const int32_t*)h->d_cmap, h->pool);
       if (own_terms)
-        hipLaunchKernelGGL(hbm_damp_kernel, dim3((F.nf + 255) / 256), dim3(256), 0, sa, F, aoff, ld, (const int32_t*)h->d_fxoff, h->pool, lambda,
-                           (const double*)h->dampw, (const double*)h->gex_active);
+        hipLaunchKernelGGL(hbm_damp_kernel, dim3((F.nf + 255) / 256), dim3(256), 0, sa, F, aoff, ld, (const int32_t*)h->d_fxoff, h->pool, lambda_v,
+                           lambda_p, (const double*)h->dampw, (const double*)h->gex_active);
       // leaf children in Schur form: deterministic gather instead of atomics; rows [c0, c1) of the chunk table
       auto gather_chunks = [&](int c0, int c1, bool whole) {
         const int s0 = whole ? 0 : G.cs[c0], s1 = whole ? G.pblk_short : G.cs[c1];
@@ -843,15 +847,17 @@ int do_backsub(lmgpu_handle* h) {
 // returns LMGPU_OK / LMGPU_INDETERMINATE with the linear errors in h_scal[1], h_scal[2].  tryLambda queues the retraction and
 // the new error behind the solve BEFORE it waits (one host round trip per inner iteration instead of two); their result is
 // simply not used when the solve failed or the linearised cost went up.
-int do_solve_enqueue(lmgpu_handle* h, double lambda) {
+__global__ void set_scalar_kernel(double* p, double v) { *p = v; }
+
+// everything of one damped solve that is queued on the stream
+int solve_sequence(lmgpu_handle* h, bool phase_events, double lambda_v, const double* lambda_p) {
   hipStream_t s = h->stream;
-  (void)hipEventRecord(h->ev[1], s);
-  int rc = do_eliminate(h, lambda);
+  int rc = do_eliminate(h, lambda_v, lambda_p);
   if (rc) return rc;
-  (void)hipEventRecord(h->ev[2], s);
+  if (phase_events) (void)hipEventRecord(h->ev[2], s);
   rc = do_backsub(h);
   if (rc) return rc;
-  (void)hipEventRecord(h->ev[3], s);
+  if (phase_events) (void)hipEventRecord(h->ev[3], s);
   const int kt = h->kt.begin(LMGPU_KT_LINEAR_ERROR, s);
   if (h->nfac > 0)
     hipLaunchKernelGGL(linear_error_kernel, dim3((h->nfac + 255) / 256), dim3(256), 0, s, (const FacDesc*)h->d_fd, h->nfac,
@@ -862,6 +868,49 @@ int do_solve_enqueue(lmgpu_handle* h, double lambda) {
   rc = allreduce_scalars(h, 1, 2);
   if (rc) return rc;
   { const int rcs = allreduce_min_int(h, h->d_status, s); if (rcs) return rcs; }
+  return LMGPU_OK;
+}
+
+// Deep clique trees (general SLAM graphs: 20-130 levels, several launches per level) are bound by launch latency: 265 launches
+// of 3.5 ms total kernel time took 6.8 ms per solve on victoria_park / COLAMD.  The launch sequence of a solve depends only on
+// the structure, so after the first (eager) solve it is captured into a hipGraph once and replayed; the only per-solve
+// input, lambda, lives in device memory.  Not with kernel timers on (their events sit between the launches), with several
+// ranks (collectives and host-side rendezvous inside the sequence), or for shallow trees (nothing to gain; the per-phase
+// events of the eager path stay available there).
+static bool graph_eligible(const lmgpu_handle* h) {
+  return h->use_graph && !h->kt.on && h->cfg.world_size == 1 && !h->comm && !h->lgroup && !(h->cfg.flags & LMGPU_FLAG_SPLIT_ROOT) &&
+         h->eager_solves >= 1;
+}
+
+int do_solve_enqueue(lmgpu_handle* h, double lambda) {
+  hipStream_t s = h->stream;
+  (void)hipEventRecord(h->ev[1], s);
+  int rc;
+  if (graph_eligible(h)) {
+    hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, s, h->d_lambda, lambda);  // the replay reads lambda from device memory
+    hipGraphExec_t& exec = h->solve_graph[h->gex_active ? 1 : 0];
+    if (!exec) {
+      hipGraph_t graph = nullptr;
+      HIPCHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      rc = solve_sequence(h, false, 0.0, h->d_lambda);
+      const hipError_t ec = hipStreamEndCapture(s, &graph);
+      if (rc) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+      }
+      HIPCHECK(ec);
+      HIPCHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(graph);
+    }
+    HIPCHECK(hipGraphLaunch(exec, s));
+    // no phase boundaries inside a replay: the whole sequence is booked as elimination time
+    (void)hipEventRecord(h->ev[2], s);
+    (void)hipEventRecord(h->ev[3], s);
+  } else {
+    rc = solve_sequence(h, true, lambda, nullptr);
+    if (rc) return rc;
+    h->eager_solves++;
+  }
   (void)hipEventRecord(h->ev[4], s);
   HIPCHECK(hipMemcpyAsync(h->h_scal + 1, h->dscal + 1, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHECK(hipMemcpyAsync(h->h_status, h->d_status, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1276,6 +1325,8 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
     for (int i = 0; i < 8; i++) HIPCHECK(hipEventCreate(&h->ev[i]));
     HIPCHECK(hipHostMalloc((void**)&h->h_scal, 8 * sizeof(double), hipHostMallocDefault));
     HIPCHECK(hipHostMalloc((void**)&h->h_status, sizeof(int), hipHostMallocDefault));
+    HIPCHECK(hipMalloc((void**)&h->d_lambda, sizeof(double)));
+    HIPCHECK(hipMemset(h->d_lambda, 0, sizeof(double)));
     HIPCHECK(hipFuncSetAttribute((const void*)lds_front_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra + 64));
     HIPCHECK(hipFuncSetAttribute((const void*)lds_front_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra + 64));
     HIPCHECK(hipFuncSetAttribute((const void*)syrk_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSyrkLds));
@@ -1321,6 +1372,9 @@ int lmgpu_destroy(lmgpu_handle* h) {
     if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
     if (h->asm_stream) (void)hipStreamDestroy(h->asm_stream);
     if (h->ready_ev) (void)hipEventDestroy(h->ready_ev);
+    for (int g = 0; g < 2; g++)
+      if (h->solve_graph[g]) (void)hipGraphExecDestroy(h->solve_graph[g]);
+    if (h->d_lambda) (void)hipFree(h->d_lambda);
     fr(h->partial2); fr(h->dscal2);
     if (h->asm_ev) (void)hipEventDestroy(h->asm_ev);
     for (hipEvent_t e : h->chunk_ev) (void)hipEventDestroy(e);
@@ -1731,6 +1785,9 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
   h->finalized = true;
   if (h->device < 0) return LMGPU_OK;  // structure-only handle: symbolic analysis available, no compute
 
+  // deep trees are launch-bound: replay the solve as a graph (LMGPU_GRAPH=0 / 1 overrides the depth rule)
+  h->use_graph = (int)h->levels.size() >= 12;
+  if (const char* e = getenv("LMGPU_GRAPH")) h->use_graph = atoi(e) != 0;
   // ---- device upload
   HIPCHECK(hipSetDevice(h->device));
   HIPCHECK(hipMalloc((void**)&h->pool, h->pool_doubles * sizeof(double)));
