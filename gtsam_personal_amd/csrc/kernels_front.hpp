@@ -204,9 +204,69 @@ __global__ __launch_bounds__(256) void lds_front_kernel(const int32_t* __restric
     S[i * n + i] += lambda * dampw[fxoff[F.fx_begin + i]];
     if (gex) S[i * n + n - 1] += gex[fxoff[F.fx_begin + i]];  // extra gradient term eta += g (marginal covariances: unit vectors)
   }
-  // ---- partial Cholesky (right-looking, row k of R at a time)
+  // ---- partial Cholesky
   bool failed = false;
-  for (int k = 0; k < nf; k++) {
+  // Fronts with many frontal columns (upper levels of general sparse graphs: n ~ 100, nf ~ 20-60) take the pivots FOUR at a
+  // time: the four pivot rows are finished against each other (little work between the barriers), then the trailing matrix
+  // receives one rank-4 update on the matrix cores, 16x16 tile by tile (v_mfma_f64_16x16x4_f64: operands and the tile from
+  // LDS).  Row by row, every trailing entry is read-modify-written in LDS once per pivot -- ~0.75 us per pivot at n = 139 from
+  // LDS bandwidth alone, 100-200 us per front, which is what a narrow tree level costs.  Same arithmetic up to the order of
+  // the four subtractions.
+  const bool blocked = !gather && nf >= 8 && nw == 4;
+  if (blocked) {
+    typedef double d4_t __attribute__((ext_vector_type(4)));
+    const int kk = lane >> 4, cc = lane & 15;
+    for (int k0 = 0; k0 < nf; k0 += 4) {
+      const int kb = min(4, nf - k0);
+      for (int q = 0; q < kb; q++) {
+        const int k = k0 + q;
+        __syncthreads();  // previous update of row k complete
+        double piv = S[k * n + k];
+        if (!(piv > 0.0)) {
+          if (piv <= 0.0) failed = true;
+          piv = (piv == piv && piv != 0.0) ? fabs(piv) : 1.0;
+        }
+        const double r = sqrt(piv), inv = 1.0 / r;
+        for (int j = k + 1 + tid; j < n; j += nt) S[k * n + j] *= inv;
+        __syncthreads();  // row k scaled; every thread has read the pivot
+        if (tid == 0) S[k * n + k] = r;
+        const int i = k + 1 + wave;  // the other rows of the panel: one wave each
+        if (i < k0 + kb) {
+          const double rki = S[k * n + i];
+          for (int j = i + lane; j < n; j += 64) S[i * n + j] -= rki * S[k * n + j];
+        }
+      }
+      __syncthreads();
+      const int t0 = k0 + kb, m = n - t0;
+      if (m <= 0) continue;
+      const int T = (m + 15) >> 4, ntile = T * (T + 1) / 2;
+      for (int t = wave; t < ntile; t += nw) {
+        int ti = 0, rem = t;
+        while (rem >= T - ti) {
+          rem -= T - ti;
+          ti++;
+        }
+        const int row0 = t0 + 16 * ti, col0 = t0 + 16 * (ti + rem);
+        // A[i = cc][k = kk] = -R[k0 + kk][row0 + cc],  B[k = kk][j = cc] = R[k0 + kk][col0 + cc]
+        const bool kv = kk < kb;
+        const double a = (kv && row0 + cc < n) ? -S[(k0 + kk) * n + row0 + cc] : 0.0;
+        const double b = (kv && col0 + cc < n) ? S[(k0 + kk) * n + col0 + cc] : 0.0;
+        d4_t c;
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+          const int row = row0 + kk + 4 * rr, col = col0 + cc;
+          c[rr] = (row < n && col < n) ? S[row * n + col] : 0.0;
+        }
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+          const int row = row0 + kk + 4 * rr, col = col0 + cc;
+          if (row < n && col < n && col >= row) S[row * n + col] = c[rr];
+        }
+      }
+    }
+  }
+  for (int k = blocked ? nf : 0; k < nf; k++) {
     __syncthreads();  // previous trailing update (or assembly) complete
     double piv = S[k * n + k];
     if (!(piv > 0.0)) {
@@ -281,28 +341,76 @@ __global__ __launch_bounds__(256) void lds_backsub_kernel(const int32_t* __restr
   const int n = F.n, nf = F.nf, ns = n - nf - 1;
   const double* RSd = pool + F.rsd_off;
   double* rhs = rhs_s[w];
-  // rhs_i = d_i - sum_j S_ij x_S[j]
-  for (int i = 0; i < nf; i++) {
-    double s = 0;
-    for (int j = lane; j < ns; j += 64) s += RSd[(size_t)i * F.ld_rsd + nf + j] * delta[sxoff[F.sx_begin + j]];
+  // One wave per front; every memory round trip that does not depend on the solve is taken off its chain: the separator part of
+  // delta is gathered once into registers, the rows of S are read four at a time, and the next row of R is in flight while the
+  // current unknown is computed (a version that walked R serially in one lane cost 40-90 us per narrow tree level).
+  // rhs_i = d_i - sum_j S_ij x_S[j]          (n <= 139  =>  at most three 64-column chunks per row)
+  double xs[3];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0) rhs[i] = RSd[(size_t)i * F.ld_rsd + n - 1] - s;
+  for (int q = 0; q < 3; q++) {
+    const int j = lane + 64 * q;
+    xs[q] = (j < ns) ? delta[sxoff[F.sx_begin + j]] : 0.0;
+  }
+  for (int i0 = 0; i0 < nf; i0 += 4) {
+    double acc[4] = {0.0, 0.0, 0.0, 0.0}, dv[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = i0 + u;
+      if (i < nf) {
+        const double* row = RSd + (size_t)i * F.ld_rsd;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          const int j = lane + 64 * q;
+          if (j < ns) acc[u] += row[nf + j] * xs[q];
+        }
+        dv[u] = row[n - 1];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc[u] += __shfl_xor(acc[u], o);
+      if (lane == 0 && i0 + u < nf) rhs[i0 + u] = dv[u] - acc[u];
+    }
   }
   __builtin_amdgcn_wave_barrier();
-  // R x = rhs (upper, backward), serial in lane 0 (nf is small for LDS fronts)
-  if (lane == 0) {
-    bool bad = false;
-    for (int i = nf - 1; i >= 0; i--) {
-      double s = rhs[i];
-      for (int j = i + 1; j < nf; j++) s -= RSd[(size_t)i * F.ld_rsd + j] * rhs[j];
-      s /= RSd[(size_t)i * F.ld_rsd + i];
-      rhs[i] = s;
-      if (s != s) bad = true;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  // R x = rhs (upper, backward): lanes along the row, the finished unknowns in LDS
+  bool bad = false;
+  double rc[3], dc = 1.0;
+  auto load_row = [&](int i, double(&r)[3], double& d) {
+    const double* row = RSd + (size_t)max(i, 0) * F.ld_rsd;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      const int j = i + 1 + lane + 64 * q;
+      r[q] = (i >= 0 && j < nf) ? row[j] : 0.0;
     }
-    for (int i = 0; i < nf; i++) delta[fxoff[F.fx_begin + i]] = rhs[i];
-    if (bad) atomicMin(status, F.id);  // NaN -> IndeterminantLinearSystemException (linearAlgorithms-inst.h:99)
+    d = (i >= 0) ? row[max(i, 0)] : 1.0;
+  };
+  load_row(nf - 1, rc, dc);
+  for (int i = nf - 1; i >= 0; i--) {
+    double rn[3], dn;
+    load_row(i - 1, rn, dn);
+    double sum = 0.0;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      const int j = i + 1 + lane + 64 * q;
+      if (j < nf) sum += rc[q] * rhs[j];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const double x = (rhs[i] - sum) / dc;
+    if (x != x) bad = true;
+    __builtin_amdgcn_wave_barrier();  // every lane has read rhs[i] before it is overwritten
+    if (lane == 0) rhs[i] = x;
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < 3; q++) rc[q] = rn[q];
+    dc = dn;
   }
+  for (int i = lane; i < nf; i += 64) delta[fxoff[F.fx_begin + i]] = rhs[i];
+  if (bad && lane == 0) atomicMin(status, F.id);  // NaN -> IndeterminantLinearSystemException (linearAlgorithms-inst.h:99)
 }
 
 }  // namespace lmgpu
