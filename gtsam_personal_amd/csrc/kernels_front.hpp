@@ -413,4 +413,110 @@ __global__ __launch_bounds__(256) void lds_backsub_kernel(const int32_t* __restr
   if (bad && lane == 0) atomicMin(status, F.id);  // NaN -> IndeterminantLinearSystemException (linearAlgorithms-inst.h:99)
 }
 
+// The same for tree levels that hold fronts with many frontal columns (the narrow upper levels of general sparse graphs): one
+// WORKGROUP per front.  The rows of S are spread over the four waves (16 row reads in flight), R is staged in LDS by all
+// threads while that happens, and wave 0 then solves out of LDS -- no memory round trip is left on the chain of nf unknowns.
+// Dynamic LDS: nfcap * nfcap doubles; a front with nf > nfcap reads R from memory instead (rows prefetched one ahead).
+__global__ __launch_bounds__(256) void lds_backsub_wide_kernel(const int32_t* __restrict__ list, int nlist, const FrontDesc* __restrict__ fronts,
+                                                                const int32_t* __restrict__ fxoff, const int32_t* __restrict__ sxoff,
+                                                                const double* __restrict__ pool, double* __restrict__ delta,
+                                                                int* __restrict__ status, int nfcap) {
+  extern __shared__ double Rl[];  // [nf][nf] row-major, upper part used
+  __shared__ double rhs[160];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x;
+  const FrontDesc F = fronts[list[blockIdx.x]];
+  const int n = F.n, nf = F.nf, ns = n - nf - 1;
+  const double* RSd = pool + F.rsd_off;
+  const bool staged = nf <= nfcap;
+  double xs[3];
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    const int j = lane + 64 * q;
+    xs[q] = (j < ns) ? delta[sxoff[F.sx_begin + j]] : 0.0;
+  }
+  if (staged)
+    for (int idx = tid; idx < nf * nf; idx += 256) {
+      const int i = idx / nf, j = idx - i * nf;
+      if (j >= i) Rl[idx] = RSd[(size_t)i * F.ld_rsd + j];
+    }
+  for (int i0 = 4 * w; i0 < nf; i0 += 16) {
+    double acc[4] = {0.0, 0.0, 0.0, 0.0}, dv[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = i0 + u;
+      if (i < nf) {
+        const double* row = RSd + (size_t)i * F.ld_rsd;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          const int j = lane + 64 * q;
+          if (j < ns) acc[u] += row[nf + j] * xs[q];
+        }
+        dv[u] = row[n - 1];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc[u] += __shfl_xor(acc[u], o);
+      if (lane == 0 && i0 + u < nf) rhs[i0 + u] = dv[u] - acc[u];
+    }
+  }
+  __syncthreads();
+  if (w != 0) return;
+  bool bad = false;
+  if (staged) {
+    for (int i = nf - 1; i >= 0; i--) {
+      double sum = 0.0;
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const int j = i + 1 + lane + 64 * q;
+        if (j < nf) sum += Rl[i * nf + j] * rhs[j];
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+      const double x = (rhs[i] - sum) / Rl[i * nf + i];
+      if (x != x) bad = true;
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) rhs[i] = x;
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  } else {
+    double rc[3], dc = 1.0;
+    auto load_row = [&](int i, double(&r)[3], double& d) {
+      const double* row = RSd + (size_t)max(i, 0) * F.ld_rsd;
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const int j = i + 1 + lane + 64 * q;
+        r[q] = (i >= 0 && j < nf) ? row[j] : 0.0;
+      }
+      d = (i >= 0) ? row[max(i, 0)] : 1.0;
+    };
+    load_row(nf - 1, rc, dc);
+    for (int i = nf - 1; i >= 0; i--) {
+      double rn[3], dn;
+      load_row(i - 1, rn, dn);
+      double sum = 0.0;
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const int j = i + 1 + lane + 64 * q;
+        if (j < nf) sum += rc[q] * rhs[j];
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+      const double x = (rhs[i] - sum) / dc;
+      if (x != x) bad = true;
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) rhs[i] = x;
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int q = 0; q < 3; q++) rc[q] = rn[q];
+      dc = dn;
+    }
+  }
+  for (int i = lane; i < nf; i += 64) delta[fxoff[F.fx_begin + i]] = rhs[i];
+  if (bad && lane == 0) atomicMin(status, F.id);
+}
+
 }  // namespace lmgpu

@@ -77,6 +77,7 @@ struct Bucket {
 struct LevelWork {
   // LDS fronts of this level, grouped by LDS-size bin: [bin_begin[b], bin_begin[b+1]) inside the level's list
   int list_begin = 0, list_count = 0;
+  int lds_nf_max = 0;  // largest frontal dimension among the level's LDS fronts
   int bin_begin[16] = {0};
   int bin_srows[16] = {0};  // rows of the front kept in LDS for the bin's launch
   int bin_jcap[16] = {0};   // doubles of Jacobian staging per workgroup (largest front of the bin, 96 .. LDSF_JCAP)
@@ -832,9 +833,16 @@ int do_backsub(lmgpu_handle* h) {
     }
     if (L.list_count > 0) {
       const int kt = h->kt.begin(LMGPU_KT_BACKSUB_LDS, s);
-      hipLaunchKernelGGL(lds_backsub_kernel, dim3((L.list_count + 3) / 4), dim3(256), 0, s, (const int32_t*)(h->d_lists + L.list_begin),
-                         L.list_count, (const FrontDesc*)h->d_fronts, (const int32_t*)h->d_fxoff, (const int32_t*)h->d_sxoff,
-                         (const double*)h->pool, h->delta, h->d_status);
+      if (L.lds_nf_max > 12) {  // fronts with many frontal columns: one workgroup each, R staged in LDS
+        const int nfcap = std::min(L.lds_nf_max, 96);
+        hipLaunchKernelGGL(lds_backsub_wide_kernel, dim3(L.list_count), dim3(256), (size_t)nfcap * nfcap * sizeof(double), s,
+                           (const int32_t*)(h->d_lists + L.list_begin), L.list_count, (const FrontDesc*)h->d_fronts, (const int32_t*)h->d_fxoff,
+                           (const int32_t*)h->d_sxoff, (const double*)h->pool, h->delta, h->d_status, nfcap);
+      } else {
+        hipLaunchKernelGGL(lds_backsub_kernel, dim3((L.list_count + 3) / 4), dim3(256), 0, s, (const int32_t*)(h->d_lists + L.list_begin),
+                           L.list_count, (const FrontDesc*)h->d_fronts, (const int32_t*)h->d_fxoff, (const int32_t*)h->d_sxoff,
+                           (const double*)h->pool, h->delta, h->d_status);
+      }
       h->kt.end(kt, s);
     }
   }
@@ -1330,6 +1338,7 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
     HIPCHECK(hipFuncSetAttribute((const void*)lds_front_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra + 64));
     HIPCHECK(hipFuncSetAttribute((const void*)lds_front_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra + 64));
     HIPCHECK(hipFuncSetAttribute((const void*)syrk_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSyrkLds));
+    HIPCHECK(hipFuncSetAttribute((const void*)lds_backsub_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 96 * 8));
     HIPCHECK(hipFuncSetAttribute((const void*)diag_potrf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
     HIPCHECK(hipFuncSetAttribute((const void*)panel_dataflow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PDF_LDS_BYTES));
     HIPCHECK(hipFuncSetAttribute((const void*)step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STEP_LDS_BYTES));
@@ -1776,7 +1785,10 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
         jc = std::max(jc, std::min(tot, LDSF_JCAP));
       }
       L.bin_jcap[b] = (jc + 7) & ~7;
-      for (int fi : byLevelBin[l][b]) lists.push_back(fi);
+      for (int fi : byLevelBin[l][b]) {
+        lists.push_back(fi);
+        L.lds_nf_max = std::max(L.lds_nf_max, (int)P.fronts[fi].nf);
+      }
       c += (int)byLevelBin[l][b].size();
     }
     L.bin_begin[kNumBins] = c;
