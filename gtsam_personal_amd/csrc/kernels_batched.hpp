@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void med_assemble_children_kernel(MedLevel L, 
   const int fi = L.list[blockIdx.y];
   const FrontDesc F = L.fronts[fi];
   if ((int)blockIdx.x >= F.child_count) return;
-  assemble_child_body(F, L.f_off[fi], L.f_ld[fi], childs, cmap, pool, blockIdx.x, smap);
+  assemble_child_body(F, L.f_off[fi], L.f_ld[fi], childs, cmap, pool, blockIdx.x, smap, blockIdx.z, gridDim.z);
 }
 
 __global__ __launch_bounds__(256) void med_damp_kernel(MedLevel L, const int32_t* __restrict__ fxoff, double* __restrict__ pool, double lambda_v, const double* __restrict__ lambda_p,

@@ -55,9 +55,12 @@ __global__ __launch_bounds__(64) void hbm_assemble_factors_kernel(FrontDesc F, i
   assemble_factor_body(F, f_off, ld, ffac, fd, pool, blockIdx.x);
 }
 
-// one block per child: extend-add of its update matrix
+// `nsplit` blocks per child (block `split` takes every nsplit-th group of four rows): extend-add of its update matrix.  The
+// upper levels of a general sparse graph have a handful of children with 300-400-column update matrices each: with one block
+// per child a level's extend-add ran on one or two CUs (160-220 us).
 __device__ __forceinline__ void assemble_child_body(const FrontDesc& F, int64_t f_off, int ld, const ChildRef* __restrict__ childs,
-                                                    const int32_t* __restrict__ cmap, double* __restrict__ pool, int bx, int32_t* smap) {
+                                                    const int32_t* __restrict__ cmap, double* __restrict__ pool, int bx, int32_t* smap,
+                                                    int split, int nsplit) {
   const ChildRef c = childs[F.child_begin + bx];
   const double* U = pool + c.u_off;
   const int32_t* map = cmap + c.map_begin;
@@ -67,7 +70,7 @@ __device__ __forceinline__ void assemble_child_body(const FrontDesc& F, int64_t 
     for (int i = threadIdx.x; i < c.m; i += 256) smap[i] = map[i];
     __syncthreads();
   }
-  for (int i = threadIdx.x >> 6; i < c.m; i += 4) {  // one wave per row: row i of U is contiguous
+  for (int i = 4 * split + (threadIdx.x >> 6); i < c.m; i += 4 * nsplit) {  // one wave per row: row i of U is contiguous
     const int gi = small ? smap[i] : map[i];
     const double* Ui = U + (size_t)i * c.ld;
     for (int j = i + (threadIdx.x & 63); j < c.m; j += 64) {
@@ -81,7 +84,7 @@ __device__ __forceinline__ void assemble_child_body(const FrontDesc& F, int64_t 
 __global__ __launch_bounds__(256) void hbm_assemble_children_kernel(FrontDesc F, int64_t f_off, int ld, const ChildRef* __restrict__ childs,
                                                                     const int32_t* __restrict__ cmap, double* __restrict__ pool) {
   __shared__ int32_t smap[160];
-  assemble_child_body(F, f_off, ld, childs, cmap, pool, blockIdx.x, smap);
+  assemble_child_body(F, f_off, ld, childs, cmap, pool, blockIdx.x, smap, blockIdx.y, gridDim.y);
 }
 
 __global__ __launch_bounds__(256) void hbm_damp_kernel(FrontDesc F, int64_t f_off, int ld, const int32_t* __restrict__ fxoff,

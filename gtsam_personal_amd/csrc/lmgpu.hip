@@ -143,6 +143,7 @@ const int kNumBins = 12;  // 0..5: LDS fronts by size; 6..11: the same sizes for
 const int kLdsLimitN = 139;
 const int kLdsFrontExtra = LDSF_EXTRA_BYTES;
 const int NB = 64;    // potrf / trsm step
+const int kChildSplit = 8;  // workgroups per child in the extend-add of HBM fronts
 const int NBO = 256;  // outer panel: rows eliminated per trailing update of the HBM front
 const int kSyrkLds = 2 * 2 * SYRK_KC * SYRK_LDW * 8;
 
@@ -545,7 +546,7 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
         hipLaunchKernelGGL(med_assemble_factors_kernel, dim3(L.med_max_fac, cnt), dim3(64), 0, s, ML, (const FrontFac*)h->d_ffac,
                            (const FacDesc*)h->d_fd, h->pool);
       if (L.med_max_child > 0)
-        hipLaunchKernelGGL(med_assemble_children_kernel, dim3(L.med_max_child, cnt), dim3(256), 0, s, ML, (const ChildRef*)h->d_childs,
+        hipLaunchKernelGGL(med_assemble_children_kernel, dim3(L.med_max_child, cnt, kChildSplit), dim3(256), 0, s, ML, (const ChildRef*)h->d_childs,
                            (const int32_t*)h->d_cmap, h->pool);
       hipLaunchKernelGGL(med_damp_kernel, dim3((L.med_max_nf + 255) / 256, cnt), dim3(256), 0, s, ML, (const int32_t*)h->d_fxoff, h->pool, lambda_v,
                          lambda_p, (const double*)h->dampw, (const double*)h->gex_active);
@@ -605,7 +606,7 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
         hipLaunchKernelGGL(hbm_assemble_factors_kernel, dim3(F.fac_count), dim3(64), 0, sa, F, aoff, ld, (const FrontFac*)h->d_ffac,
                            (const FacDesc*)h->d_fd, h->pool);
       if (F.child_count > 0)
-        hipLaunchKernelGGL(hbm_assemble_children_kernel, dim3(F.child_count), dim3(256), 0, sa, F, aoff, ld, (const ChildRef*)h->d_childs,
+        hipLaunchKernelGGL(hbm_assemble_children_kernel, dim3(F.child_count, kChildSplit), dim3(256), 0, sa, F, aoff, ld, (const ChildRef*)h->d_childs,
                            (const int32_t*)h->d_cmap, h->pool);
       if (own_terms)
         hipLaunchKernelGGL(hbm_damp_kernel, dim3((F.nf + 255) / 256), dim3(256), 0, sa, F, aoff, ld, (const int32_t*)h->d_fxoff, h->pool, lambda_v,
