@@ -247,13 +247,39 @@ __global__ __launch_bounds__(256) void hbm_backsolve_small_kernel(const int32_t*
   const double* A = pool + f_off[fi];
   const int ld = f_ld[fi], n = F.n, nf = F.nf, ns = n - nf - 1;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  for (int i = wave; i < nf; i += 4) {
-    const double* row = A + (size_t)i * ld;
-    double s = 0;
-    for (int j = lane; j < ns; j += 64) s += row[nf + j] * delta[sxoff[F.sx_begin + j]];
+  if (ns <= BSS_MAX_NF) {
+    // the separator part of delta once into LDS (it was gathered again for every row), four rows per wave in flight
+    // (one row at a time made this loop nf / 4 dependent memory round trips: 170 us for a 546-column front)
+    __shared__ double xS[BSS_MAX_NF];
+    for (int j = tid; j < ns; j += 256) xS[j] = delta[sxoff[F.sx_begin + j]];
+    __syncthreads();
+    for (int i0 = 4 * wave; i0 < nf; i0 += 16) {
+      double acc[4] = {0.0, 0.0, 0.0, 0.0}, dv[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0) y[i] = row[n - 1] - s;
+      for (int u = 0; u < 4; u++) {
+        const int i = i0 + u;
+        if (i < nf) {
+          const double* row = A + (size_t)i * ld;
+          for (int j = lane; j < ns; j += 64) acc[u] += row[nf + j] * xS[j];
+          dv[u] = row[n - 1];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[u] += __shfl_xor(acc[u], o);
+        if (lane == 0 && i0 + u < nf) y[i0 + u] = dv[u] - acc[u];
+      }
+    }
+  } else {
+    for (int i = wave; i < nf; i += 4) {
+      const double* row = A + (size_t)i * ld;
+      double s = 0;
+      for (int j = lane; j < ns; j += 64) s += row[nf + j] * delta[sxoff[F.sx_begin + j]];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+      if (lane == 0) y[i] = row[n - 1] - s;
+    }
   }
   __syncthreads();
   const int nblk = (nf + 63) >> 6;
