@@ -519,4 +519,114 @@ __global__ __launch_bounds__(256) void lds_backsub_wide_kernel(const int32_t* __
   if (bad && lane == 0) atomicMin(status, F.id);
 }
 
+// The LDS fronts of SEVERAL consecutive tree levels in one launch (deep clique trees: a level's launch does ~10-25 us of work
+// and costs about as much again in launch latency).  list[seg_begin, seg_end) holds the levels bottom-up; ticket t takes
+// list[seg_end - 1 - t], so parents hold lower tickets than their children.  A front whose parent lies in the same segment
+// waits for the parent's flag (pos_of[parent] inside the segment; a parent outside was finished by an earlier launch);
+// the parent raised it after its delta was stored, and it had waited for its own parent, so every ancestor is visible.
+// Same per-front work as lds_backsub_wide_kernel.  Hand-off and progress as in kernels_potrf.hpp (release / acquire at
+// agent scope, tickets drawn at workgroup start, bounded spin).
+__global__ __launch_bounds__(256) void lds_backsub_merged_kernel(const int32_t* __restrict__ list, int seg_begin, int seg_end,
+                                                                  const FrontDesc* __restrict__ fronts, const int32_t* __restrict__ fxoff,
+                                                                  const int32_t* __restrict__ sxoff, const double* __restrict__ pool,
+                                                                  double* __restrict__ delta, int* __restrict__ status,
+                                                                  const int32_t* __restrict__ parent_of, const int32_t* __restrict__ pos_of,
+                                                                  unsigned int* __restrict__ done, unsigned int* __restrict__ ticket, int nfcap) {
+  extern __shared__ double Rl[];
+  __shared__ double rhs[160];
+  __shared__ int s_ticket, s_ok;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x;
+  if (tid == 0) s_ticket = (int)atomicAdd(ticket, 1u);
+  __syncthreads();
+  const int fi = list[seg_end - 1 - s_ticket];
+  const FrontDesc F = fronts[fi];
+  const int n = F.n, nf = F.nf, ns = n - nf - 1;
+  const double* RSd = pool + F.rsd_off;
+  const bool staged = nf <= nfcap;
+  // R does not depend on the parent: stage it before waiting
+  if (staged)
+    for (int idx = tid; idx < nf * nf; idx += 256) {
+      const int i = idx / nf, j = idx - i * nf;
+      if (j >= i) Rl[idx] = RSd[(size_t)i * F.ld_rsd + j];
+    }
+  if (tid == 0) {
+    int ok = 1;
+    const int par = parent_of[fi];
+    if (par >= 0) {
+      const int pp = pos_of[par];
+      if (pp >= seg_begin && pp < seg_end) {
+        long spins = 0;
+        while (__hip_atomic_load(&done[par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > 2000000L) {
+            ok = 0;
+            break;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+    }
+    s_ok = ok;
+  }
+  __syncthreads();
+  if (!s_ok && tid == 0) atomicMin(status, F.id);  // never expected: spin bound hit
+  double xs[3];
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    const int j = lane + 64 * q;
+    xs[q] = (j < ns) ? delta[sxoff[F.sx_begin + j]] : 0.0;
+  }
+  for (int i0 = 4 * w; i0 < nf; i0 += 16) {
+    double acc[4] = {0.0, 0.0, 0.0, 0.0}, dv[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = i0 + u;
+      if (i < nf) {
+        const double* row = RSd + (size_t)i * F.ld_rsd;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          const int j = lane + 64 * q;
+          if (j < ns) acc[u] += row[nf + j] * xs[q];
+        }
+        dv[u] = row[n - 1];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc[u] += __shfl_xor(acc[u], o);
+      if (lane == 0 && i0 + u < nf) rhs[i0 + u] = dv[u] - acc[u];
+    }
+  }
+  __syncthreads();
+  if (w != 0) return;
+  bool bad = false;
+  for (int i = nf - 1; i >= 0; i--) {
+    double sum = 0.0;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      const int j = i + 1 + lane + 64 * q;
+      if (j < nf) sum += (staged ? Rl[i * nf + j] : RSd[(size_t)i * F.ld_rsd + j]) * rhs[j];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const double x = (rhs[i] - sum) / (staged ? Rl[i * nf + i] : RSd[(size_t)i * F.ld_rsd + i]);
+    if (x != x) bad = true;
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) rhs[i] = x;
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  for (int i = lane; i < nf; i += 64) delta[fxoff[F.fx_begin + i]] = rhs[i];
+  if (bad && lane == 0) atomicMin(status, F.id);
+  // publish: every lane's stores of delta have been performed, then one release + flag
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(&done[fi], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 }  // namespace lmgpu

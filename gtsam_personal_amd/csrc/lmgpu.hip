@@ -206,6 +206,9 @@ struct lmgpu_handle {
   std::map<int, ChainPlan> chain_plans;        // per HBM front: ticket order of its chained launch (built at first use)
   int chain_far_pct = 50;                      // LMGPU_CHAIN_FAR: tile rows beyond this percentage of the front are scheduled late (chain_schedule)
   double* d_lambda = nullptr;   // damping parameter of the solve being queued (device memory: see do_solve_enqueue)
+  bool merge_backsub = false;   // LDS fronts of consecutive levels in one dataflow launch (deep trees; LMGPU_MERGE_BACKSUB=0/1)
+  int32_t *d_bs_parent = nullptr, *d_bs_pos = nullptr;  // per front: parent front if it is an LDS front (else -1); position in d_lists (-1: HBM)
+  unsigned int* d_bs_done = nullptr;                    // per front flag + one ticket counter per level
   bool use_graph = false;       // replay the solve's launch sequence as a hipGraph (deep trees; LMGPU_GRAPH=0/1 overrides)
   int eager_solves = 0;
   hipGraphExec_t solve_graph[2] = {nullptr, nullptr};  // [1]: with the extra gradient vector of the marginal solves
@@ -805,8 +808,47 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
 int do_backsub(lmgpu_handle* h) {
   hipStream_t s = h->stream;
   if (h->cfg.world_size > 1) HIPCHECK(hipMemsetAsync(h->delta, 0, h->ntot * sizeof(double), s));
+  // deep trees: the LDS fronts of consecutive levels without HBM fronts in between go as ONE dataflow launch
+  const bool merge = h->merge_backsub && h->cfg.world_size == 1 && !(h->cfg.flags & LMGPU_FLAG_SPLIT_ROOT);
+  const int NFR = (int)h->h_fronts.size();
+  if (merge) HIPCHECK(hipMemsetAsync(h->d_bs_done, 0, (size_t)(NFR + h->levels.size() + 1) * sizeof(unsigned int), s));
+  int seg_hi = -1, seg_lo = -1;  // levels of the pending segment (top, bottom)
+  auto run_level = [&](const LevelWork& L) {  // one level as a launch of its own
+    if (L.lds_nf_max > 12) {
+      const int nfcap = std::min(L.lds_nf_max, 96);
+      hipLaunchKernelGGL(lds_backsub_wide_kernel, dim3(L.list_count), dim3(256), (size_t)nfcap * nfcap * sizeof(double), s,
+                         (const int32_t*)(h->d_lists + L.list_begin), L.list_count, (const FrontDesc*)h->d_fronts, (const int32_t*)h->d_fxoff,
+                         (const int32_t*)h->d_sxoff, (const double*)h->pool, h->delta, h->d_status, nfcap);
+    } else {
+      hipLaunchKernelGGL(lds_backsub_kernel, dim3((L.list_count + 3) / 4), dim3(256), 0, s, (const int32_t*)(h->d_lists + L.list_begin),
+                         L.list_count, (const FrontDesc*)h->d_fronts, (const int32_t*)h->d_fxoff, (const int32_t*)h->d_sxoff,
+                         (const double*)h->pool, h->delta, h->d_status);
+    }
+  };
+  auto flush_segment = [&]() -> int {
+    if (seg_hi < 0) return LMGPU_OK;
+    const int kt = h->kt.begin(LMGPU_KT_BACKSUB_LDS, s);
+    if (seg_hi == seg_lo) {
+      run_level(h->levels[seg_hi]);
+    } else {
+      const int b = h->levels[seg_lo].list_begin, e = h->levels[seg_hi].list_begin + h->levels[seg_hi].list_count;
+      int nfmax = 0;
+      for (int l = seg_lo; l <= seg_hi; l++) nfmax = std::max(nfmax, h->levels[l].lds_nf_max);
+      const int nfcap = std::min(nfmax, 96);
+      hipLaunchKernelGGL(lds_backsub_merged_kernel, dim3(e - b), dim3(256), (size_t)nfcap * nfcap * sizeof(double), s, (const int32_t*)h->d_lists, b, e,
+                         (const FrontDesc*)h->d_fronts, (const int32_t*)h->d_fxoff, (const int32_t*)h->d_sxoff, (const double*)h->pool, h->delta,
+                         h->d_status, (const int32_t*)h->d_bs_parent, (const int32_t*)h->d_bs_pos, h->d_bs_done, h->d_bs_done + NFR + seg_hi, nfcap);
+    }
+    h->kt.end(kt, s);
+    seg_hi = seg_lo = -1;
+    return LMGPU_OK;
+  };
   for (int li = (int)h->levels.size() - 1; li >= 0; li--) {
     const LevelWork& L = h->levels[li];
+    if (merge && !L.hbm.empty()) {  // this level's HBM fronts need every ancestor: finish the pending LDS levels first
+      const int rcf = flush_segment();
+      if (rcf) return rcf;
+    }
     if (L.small_count > 0) {  // the smaller HBM fronts of the level: one workgroup each, one launch
       const int kt = h->kt.begin(LMGPU_KT_BACKSUB_HBM, s);
       hipLaunchKernelGGL(hbm_backsolve_small_kernel, dim3(L.small_count), dim3(256), 0, s, (const int32_t*)(h->d_hbm_small + L.small_begin),
@@ -832,18 +874,18 @@ int do_backsub(lmgpu_handle* h) {
                          h->d_status);
       h->kt.end(kt, s);
     }
-    if (L.list_count > 0) {
-      const int kt = h->kt.begin(LMGPU_KT_BACKSUB_LDS, s);
-      if (L.lds_nf_max > 12) {  // fronts with many frontal columns: one workgroup each, R staged in LDS
-        const int nfcap = std::min(L.lds_nf_max, 96);
-        hipLaunchKernelGGL(lds_backsub_wide_kernel, dim3(L.list_count), dim3(256), (size_t)nfcap * nfcap * sizeof(double), s,
-                           (const int32_t*)(h->d_lists + L.list_begin), L.list_count, (const FrontDesc*)h->d_fronts, (const int32_t*)h->d_fxoff,
-                           (const int32_t*)h->d_sxoff, (const double*)h->pool, h->delta, h->d_status, nfcap);
-      } else {
-        hipLaunchKernelGGL(lds_backsub_kernel, dim3((L.list_count + 3) / 4), dim3(256), 0, s, (const int32_t*)(h->d_lists + L.list_begin),
-                           L.list_count, (const FrontDesc*)h->d_fronts, (const int32_t*)h->d_fxoff, (const int32_t*)h->d_sxoff,
-                           (const double*)h->pool, h->delta, h->d_status);
+    if (merge) {  // accumulated; flushed before the next HBM front or at the end
+      if (L.list_count > 0) {
+        if (seg_hi < 0) seg_hi = li;
+        seg_lo = li;
       }
+      if (li == 0 || !h->levels[li - 1].hbm.empty()) {
+        const int rcf = flush_segment();
+        if (rcf) return rcf;
+      }
+    } else if (L.list_count > 0) {
+      const int kt = h->kt.begin(LMGPU_KT_BACKSUB_LDS, s);
+      run_level(L);
       h->kt.end(kt, s);
     }
   }
@@ -1340,6 +1382,7 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
     HIPCHECK(hipFuncSetAttribute((const void*)lds_front_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra + 64));
     HIPCHECK(hipFuncSetAttribute((const void*)syrk_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSyrkLds));
     HIPCHECK(hipFuncSetAttribute((const void*)lds_backsub_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 96 * 8));
+    HIPCHECK(hipFuncSetAttribute((const void*)lds_backsub_merged_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 96 * 8));
     HIPCHECK(hipFuncSetAttribute((const void*)diag_potrf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
     HIPCHECK(hipFuncSetAttribute((const void*)panel_dataflow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PDF_LDS_BYTES));
     HIPCHECK(hipFuncSetAttribute((const void*)step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STEP_LDS_BYTES));
@@ -1375,7 +1418,7 @@ int lmgpu_destroy(lmgpu_handle* h) {
     for (int i = 0; i < 8; i++)
       if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     for (hipEvent_t e : h->kt.pool) (void)hipEventDestroy(e);
-    fr(h->bs_inv); fr(h->bs_x); fr(h->bs_flags); fr(h->inv16); fr(h->d_pflags);
+    fr(h->bs_inv); fr(h->bs_x); fr(h->bs_flags); fr(h->inv16); fr(h->d_pflags); fr(h->d_bs_parent); fr(h->d_bs_pos); fr(h->d_bs_done);
     for (auto& kv : h->chain_plans) fr(kv.second.d_tasks);
     fr(h->d_gpblk); fr(h->d_gpent); fr(h->d_gvblk); fr(h->d_gvent); fr(h->d_gcorner);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1800,6 +1843,8 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
 
   // deep trees are launch-bound: replay the solve as a graph (LMGPU_GRAPH=0 / 1 overrides the depth rule)
   h->use_graph = (int)h->levels.size() >= 12;
+  h->merge_backsub = (int)h->levels.size() >= 12;
+  if (const char* e = getenv("LMGPU_MERGE_BACKSUB")) h->merge_backsub = atoi(e) != 0;
   if (const char* e = getenv("LMGPU_GRAPH")) h->use_graph = atoi(e) != 0;
   // ---- device upload
   HIPCHECK(hipSetDevice(h->device));
@@ -1813,6 +1858,17 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
   if ((rc = upload(h, &h->d_fxoff, fxoff))) return rc;
   if ((rc = upload(h, &h->d_sxoff, sxoff))) return rc;
   if ((rc = upload(h, &h->d_lists, lists))) return rc;
+  {
+    std::vector<int32_t> bs_parent(NF, -1), bs_pos(NF, -1);
+    for (size_t q = 0; q < lists.size(); q++) bs_pos[lists[q]] = (int32_t)q;
+    for (int fi = 0; fi < NF; fi++) {
+      const int par = P.fronts[fi].parent;
+      if (par >= 0 && P.fronts[par].cls == 0) bs_parent[fi] = par;
+    }
+    if ((rc = upload(h, &h->d_bs_parent, bs_parent))) return rc;
+    if ((rc = upload(h, &h->d_bs_pos, bs_pos))) return rc;
+    HIPCHECK(hipMalloc((void**)&h->d_bs_done, (size_t)(NF + h->levels.size() + 1) * sizeof(unsigned int)));
+  }
   h->n_lds_fronts = (int)lists.size();
   {
     std::vector<int32_t> small;
