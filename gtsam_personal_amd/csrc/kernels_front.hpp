@@ -65,6 +65,19 @@ struct LFac {
 // lets ~7 workgroups share a CU instead of 2.
 #define LDSF_JCAP 704
 #define LDSF_MAXB 32
+// Packed descriptor of a gather leaf (one record per workgroup of a launch, `stride` bytes apart): everything the workgroup
+// otherwise collects through list -> front -> front-factor -> factor descriptor (four dependent reads) and
+// front -> fxoff -> damping weight (two more), laid out by the host once:
+//   [0]   FrontDesc
+//   [80]  int32 nstage (0: take the general path), tot (doubles of Jacobians), contig, pad
+//   [96]  int32 xo[8]: delta offsets of the frontal scalars (records are only built for nf <= 8)
+//   [128] LFac[nstage] with their LDS offsets filled in
+#define LEAFPACK_HDR 80
+#define LEAFPACK_XO 96
+#define LEAFPACK_FAC 128
+#define LEAFPACK_MAXNF 8
+static_assert(sizeof(FrontDesc) == LEAFPACK_HDR, "leaf records embed a FrontDesc");
+static_assert(sizeof(LFac) == 32, "leaf records embed LFac entries");
 #define LDSF_EXTRA_BYTES (LDSF_JCAP * 8 + LDSF_MAXB * 32 + 16)
 template <bool GATHER>
 __global__ __launch_bounds__(256) void lds_front_kernel(const int32_t* __restrict__ list, const FrontDesc* __restrict__ fronts,
@@ -72,14 +85,24 @@ __global__ __launch_bounds__(256) void lds_front_kernel(const int32_t* __restric
                                                          const ChildRef* __restrict__ childs, const int32_t* __restrict__ cmap,
                                                          const int32_t* __restrict__ fxoff, double* __restrict__ pool, double lambda_v, const double* __restrict__ lambda_p,
                                                          const double* __restrict__ dampw, int* __restrict__ status, int nmax, int srows,
-                                                         double* __restrict__ gcorner, int jcap, const double* __restrict__ gex) {
+                                                         double* __restrict__ gcorner, int jcap, const double* __restrict__ gex,
+                                                         const char* __restrict__ pack, int pack_stride) {
   extern __shared__ double S[];
   double* corner_g = S + (size_t)srows * nmax;  // GATHER: the (rhs, rhs) entry lives here
   double* Jb = corner_g + 8;
   LFac* LF = (LFac*)(Jb + jcap);  // jcap <= LDSF_JCAP doubles of staged Jacobians: the launch's largest front (fewer for small ones => more fronts per CU)
   int* meta = (int*)(LF + LDSF_MAXB);
-  const FrontDesc F = fronts[list[blockIdx.x]];
+  const char* pk = (GATHER && pack) ? pack + (size_t)blockIdx.x * pack_stride : nullptr;
+  const FrontDesc F = pk ? *(const FrontDesc*)pk : fronts[list[blockIdx.x]];
+  const int pk_n = pk ? ((const int*)(pk + LEAFPACK_HDR))[0] : 0;  // > 0: factor descriptors, staging offsets and damping offsets come from the record
+  const int pk_tot = pk_n ? ((const int*)(pk + LEAFPACK_HDR))[1] : 0, pk_contig = pk_n ? ((const int*)(pk + LEAFPACK_HDR))[2] : 0;
   const int n = F.n, nf = F.nf, tid = threadIdx.x, nt = blockDim.x;
+  double damp_pre = 0.0, gex_pre = 0.0;
+  if (pk_n && tid < nf) {
+    const int xo = ((const int*)(pk + LEAFPACK_XO))[tid];
+    damp_pre = dampw[xo];
+    if (gex) gex_pre = gex[xo];
+  }
   const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
   // gather mode (par_ld < 0): the parent assembles this leaf's update itself from [R S d] (kernels_schur.hpp); only the
   // frontal rows and the (rhs, rhs) corner of the trailing block are needed here
@@ -92,6 +115,14 @@ __global__ __launch_bounds__(256) void lds_front_kernel(const int32_t* __restric
   //      dependent HBM reads (list -> front -> factor -> Jacobian) of a batch are in flight together.
   for (int k0 = 0; k0 < F.fac_count;) {
     __syncthreads();
+    int B, tot, contig;
+    if (pk_n) {  // one batch, laid out by the host
+      for (int b = tid; b < pk_n; b += nt) LF[b] = ((const LFac*)(pk + LEAFPACK_FAC))[b];
+      B = pk_n;
+      tot = pk_tot;
+      contig = pk_contig;
+      __syncthreads();
+    } else {
     const int cand = min(LDSF_MAXB, F.fac_count - k0);
     for (int b = tid; b < cand; b += nt) {
       const FrontFac ff = ffac[F.fac_begin + k0 + b];
@@ -123,10 +154,12 @@ __global__ __launch_bounds__(256) void lds_front_kernel(const int32_t* __restric
       meta[2] = contig ? 1 : 0;
     }
     __syncthreads();
-    const int B = meta[0];
-    if (meta[2]) {  // one flat copy: every load independent of the others
+    B = meta[0];
+    tot = meta[1];
+    contig = meta[2];
+    }
+    if (contig) {  // one flat copy: every load independent of the others
       const double* J = pool + LF[0].joff;
-      const int tot = meta[1];
       for (int i = tid; i < tot; i += nt) Jb[i] = J[i];
     } else {
       for (int b = wave; b < B; b += nw) {
@@ -200,9 +233,16 @@ __global__ __launch_bounds__(256) void lds_front_kernel(const int32_t* __restric
   // ---- damping on the frontal diagonal
   // lambda_p != nullptr: the value lives in device memory so that a captured launch sequence can be replayed with a new one
   const double lambda = lambda_p ? *lambda_p : lambda_v;
-  for (int i = tid; i < nf; i += nt) {
-    S[i * n + i] += lambda * dampw[fxoff[F.fx_begin + i]];
-    if (gex) S[i * n + n - 1] += gex[fxoff[F.fx_begin + i]];  // extra gradient term eta += g (marginal covariances: unit vectors)
+  if (pk_n) {  // nf <= LEAFPACK_MAXNF <= nt: the weights were fetched with the record
+    if (tid < nf) {
+      S[tid * n + tid] += lambda * damp_pre;
+      if (gex) S[tid * n + n - 1] += gex_pre;
+    }
+  } else {
+    for (int i = tid; i < nf; i += nt) {
+      S[i * n + i] += lambda * dampw[fxoff[F.fx_begin + i]];
+      if (gex) S[i * n + n - 1] += gex[fxoff[F.fx_begin + i]];  // extra gradient term eta += g (marginal covariances: unit vectors)
+    }
   }
   // ---- partial Cholesky
   bool failed = false;

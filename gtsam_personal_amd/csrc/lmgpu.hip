@@ -81,6 +81,8 @@ struct LevelWork {
   int bin_begin[16] = {0};
   int bin_srows[16] = {0};  // rows of the front kept in LDS for the bin's launch
   int bin_jcap[16] = {0};   // doubles of Jacobian staging per workgroup (largest front of the bin, 96 .. LDSF_JCAP)
+  int64_t pack_off[16] = {0};  // gather bins: byte offset of the launch's packed leaf records in d_leafpack, and their stride (0: none)
+  int pack_stride[16] = {0};
   std::vector<int> hbm;  // HBM fronts of this level
   int small_begin = 0, small_count = 0;  // those with nf <= BSS_MAX_NF, in d_hbm_small: back-substituted in one launch per level
   // "medium" HBM fronts (one outer panel, no gather leaves, not replicated): eliminated with batched launches (kernels_batched.hpp)
@@ -208,6 +210,7 @@ struct lmgpu_handle {
   double* d_lambda = nullptr;   // damping parameter of the solve being queued (device memory: see do_solve_enqueue)
   bool merge_backsub = false;   // LDS fronts of consecutive levels in one dataflow launch (deep trees; LMGPU_MERGE_BACKSUB=0/1)
   int32_t *d_bs_parent = nullptr, *d_bs_pos = nullptr;  // per front: parent front if it is an LDS front (else -1); position in d_lists (-1: HBM)
+  char* d_leafpack = nullptr;                           // packed descriptors of the gather leaves (kernels_front.hpp, LEAFPACK_*)
   unsigned int* d_bs_done = nullptr;                    // per front flag + one ticket counter per level
   bool use_graph = false;       // replay the solve's launch sequence as a hipGraph (deep trees; LMGPU_GRAPH=0/1 overrides)
   int eager_solves = 0;
@@ -531,13 +534,14 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
                            (const int32_t*)(h->d_lists + L.list_begin + L.bin_begin[b]), (const FrontDesc*)h->d_fronts,
                            (const FrontFac*)h->d_ffac, (const FacDesc*)h->d_fd, (const ChildRef*)h->d_childs, (const int32_t*)h->d_cmap,
                            (const int32_t*)h->d_fxoff, h->pool, lambda_v, lambda_p, (const double*)h->dampw, h->d_status, nmax, srows, h->d_gcorner, jcap,
-                           (const double*)h->gex_active);
+                           (const double*)h->gex_active, (const char*)nullptr, 0);
       else
         hipLaunchKernelGGL(lds_front_kernel<true>, dim3(cnt), dim3(threads), lds, s,
                            (const int32_t*)(h->d_lists + L.list_begin + L.bin_begin[b]), (const FrontDesc*)h->d_fronts,
                            (const FrontFac*)h->d_ffac, (const FacDesc*)h->d_fd, (const ChildRef*)h->d_childs, (const int32_t*)h->d_cmap,
                            (const int32_t*)h->d_fxoff, h->pool, lambda_v, lambda_p, (const double*)h->dampw, h->d_status, nmax, srows, h->d_gcorner, jcap,
-                           (const double*)h->gex_active);
+                           (const double*)h->gex_active, (const char*)(h->d_leafpack && L.pack_stride[b] ? h->d_leafpack + L.pack_off[b] : nullptr),
+                           L.pack_stride[b]);
       h->kt.end(kt, s);
     }
     if (L.med_count > 0) {  // medium fronts of this level: six launches for all of them
@@ -1418,7 +1422,7 @@ int lmgpu_destroy(lmgpu_handle* h) {
     for (int i = 0; i < 8; i++)
       if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     for (hipEvent_t e : h->kt.pool) (void)hipEventDestroy(e);
-    fr(h->bs_inv); fr(h->bs_x); fr(h->bs_flags); fr(h->inv16); fr(h->d_pflags); fr(h->d_bs_parent); fr(h->d_bs_pos); fr(h->d_bs_done);
+    fr(h->bs_inv); fr(h->bs_x); fr(h->bs_flags); fr(h->inv16); fr(h->d_pflags); fr(h->d_bs_parent); fr(h->d_bs_pos); fr(h->d_bs_done); fr(h->d_leafpack);
     for (auto& kv : h->chain_plans) fr(kv.second.d_tasks);
     fr(h->d_gpblk); fr(h->d_gpent); fr(h->d_gvblk); fr(h->d_gvent); fr(h->d_gcorner);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1850,6 +1854,58 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
   HIPCHECK(hipSetDevice(h->device));
   HIPCHECK(hipMalloc((void**)&h->pool, h->pool_doubles * sizeof(double)));
   int rc;
+  if (!getenv("LMGPU_NO_LEAFPACK")) {  // packed records of the gather leaves, launch by launch
+    std::vector<char> packs;
+    for (LevelWork& L : h->levels)
+      for (int b = 6; b < kNumBins; b++) {
+        const int cnt = L.bin_begin[b + 1] - L.bin_begin[b];
+        if (cnt == 0) continue;
+        int maxfac = 0;
+        for (int q = 0; q < cnt; q++) maxfac = std::max(maxfac, std::min((int)LDSF_MAXB, h->h_fronts[lists[L.list_begin + L.bin_begin[b] + q]].fac_count));
+        const int stride = LEAFPACK_FAC + 32 * std::max(1, maxfac);
+        packs.resize((packs.size() + 127) & ~size_t(127));
+        L.pack_off[b] = (int64_t)packs.size();
+        L.pack_stride[b] = stride;
+        packs.resize(packs.size() + (size_t)cnt * stride, 0);
+        for (int q = 0; q < cnt; q++) {
+          const FrontDesc& F = h->h_fronts[lists[L.list_begin + L.bin_begin[b] + q]];
+          char* rec = packs.data() + L.pack_off[b] + (size_t)q * stride;
+          std::memcpy(rec, &F, sizeof(FrontDesc));
+          int32_t* hdr = (int32_t*)(rec + LEAFPACK_HDR);
+          hdr[0] = hdr[1] = hdr[2] = hdr[3] = 0;
+          if (F.nf > LEAFPACK_MAXNF || F.fac_count < 1 || F.fac_count > LDSF_MAXB) continue;
+          LFac* lf = (LFac*)(rec + LEAFPACK_FAC);
+          int o = 0;
+          bool contig = true;
+          for (int k = 0; k < F.fac_count; k++) {
+            const FrontFac& ff = ffac[F.fac_begin + k];
+            const FacDesc& d = fd[ff.fac];
+            lf[k].joff = d.joff;
+            lf[k].c0 = ff.c0;
+            lf[k].c1 = ff.c1;
+            lf[k].rows = d.rows;
+            lf[k].d0 = d.d0;
+            lf[k].d1 = d.d1;
+            lf[k].pad = 0;
+            lf[k].off = o;
+            lf[k].sz = d.rows * (d.d0 + d.d1 + 1);
+            if (k > 0 && lf[k].joff != lf[0].joff + o) contig = false;
+            o += lf[k].sz;
+          }
+          if (o > L.bin_jcap[b]) continue;  // more than one staging batch: the general path
+          hdr[0] = F.fac_count;
+          hdr[1] = o;
+          hdr[2] = contig ? 1 : 0;
+          int32_t* xo = (int32_t*)(rec + LEAFPACK_XO);
+          for (int i = 0; i < F.nf; i++) xo[i] = fxoff[F.fx_begin + i];
+        }
+      }
+    if (!packs.empty() && h->device >= 0) {
+      HIPCHECK(hipSetDevice(h->device));
+      HIPCHECK(hipMalloc((void**)&h->d_leafpack, packs.size()));
+      HIPCHECK(hipMemcpy(h->d_leafpack, packs.data(), packs.size(), hipMemcpyHostToDevice));
+    }
+  }
   if ((rc = upload(h, &h->d_fd, fd))) return rc;
   if ((rc = upload(h, &h->d_fronts, h->h_fronts))) return rc;
   if ((rc = upload(h, &h->d_ffac, ffac))) return rc;
