@@ -65,12 +65,12 @@ struct LFac {
 // lets ~7 workgroups share a CU instead of 2.
 #define LDSF_JCAP 704
 #define LDSF_MAXB 32
-// Packed descriptor of a gather leaf (one record per workgroup of a launch, `stride` bytes apart): everything the workgroup
+// Packed descriptor of an LDS front (one record per workgroup of a launch, `stride` bytes apart): everything the workgroup
 // otherwise collects through list -> front -> front-factor -> factor descriptor (four dependent reads) and
 // front -> fxoff -> damping weight (two more), laid out by the host once:
 //   [0]   FrontDesc
-//   [80]  int32 nstage (0: take the general path), tot (doubles of Jacobians), contig, pad
-//   [96]  int32 xo[8]: delta offsets of the frontal scalars (records are only built for nf <= 8)
+//   [80]  int32 nstage (0: take the general path), tot (doubles of Jacobians), contig, has_xo
+//   [96]  int32 xo[8]: delta offsets of the frontal scalars (has_xo: nf <= 8)
 //   [128] LFac[nstage] with their LDS offsets filled in
 #define LEAFPACK_HDR 80
 #define LEAFPACK_XO 96
@@ -92,13 +92,14 @@ __global__ __launch_bounds__(256) void lds_front_kernel(const int32_t* __restric
   double* Jb = corner_g + 8;
   LFac* LF = (LFac*)(Jb + jcap);  // jcap <= LDSF_JCAP doubles of staged Jacobians: the launch's largest front (fewer for small ones => more fronts per CU)
   int* meta = (int*)(LF + LDSF_MAXB);
-  const char* pk = (GATHER && pack) ? pack + (size_t)blockIdx.x * pack_stride : nullptr;
+  const char* pk = pack ? pack + (size_t)blockIdx.x * pack_stride : nullptr;
   const FrontDesc F = pk ? *(const FrontDesc*)pk : fronts[list[blockIdx.x]];
   const int pk_n = pk ? ((const int*)(pk + LEAFPACK_HDR))[0] : 0;  // > 0: factor descriptors, staging offsets and damping offsets come from the record
   const int pk_tot = pk_n ? ((const int*)(pk + LEAFPACK_HDR))[1] : 0, pk_contig = pk_n ? ((const int*)(pk + LEAFPACK_HDR))[2] : 0;
   const int n = F.n, nf = F.nf, tid = threadIdx.x, nt = blockDim.x;
+  const bool pk_xo = pk_n && ((const int*)(pk + LEAFPACK_HDR))[3] != 0;  // the record also carries the frontal delta offsets (nf <= 8)
   double damp_pre = 0.0, gex_pre = 0.0;
-  if (pk_n && tid < nf) {
+  if (pk_xo && tid < nf) {
     const int xo = ((const int*)(pk + LEAFPACK_XO))[tid];
     damp_pre = dampw[xo];
     if (gex) gex_pre = gex[xo];
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(256) void lds_front_kernel(const int32_t* __restric
   // ---- damping on the frontal diagonal
   // lambda_p != nullptr: the value lives in device memory so that a captured launch sequence can be replayed with a new one
   const double lambda = lambda_p ? *lambda_p : lambda_v;
-  if (pk_n) {  // nf <= LEAFPACK_MAXNF <= nt: the weights were fetched with the record
+  if (pk_xo) {  // nf <= LEAFPACK_MAXNF <= nt: the weights were fetched with the record
     if (tid < nf) {
       S[tid * n + tid] += lambda * damp_pre;
       if (gex) S[tid * n + n - 1] += gex_pre;

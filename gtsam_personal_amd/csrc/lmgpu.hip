@@ -81,7 +81,7 @@ struct LevelWork {
   int bin_begin[16] = {0};
   int bin_srows[16] = {0};  // rows of the front kept in LDS for the bin's launch
   int bin_jcap[16] = {0};   // doubles of Jacobian staging per workgroup (largest front of the bin, 96 .. LDSF_JCAP)
-  int64_t pack_off[16] = {0};  // gather bins: byte offset of the launch's packed leaf records in d_leafpack, and their stride (0: none)
+  int64_t pack_off[16] = {0};  // byte offset of the launch's packed leaf records in d_leafpack, and their stride (0: none)
   int pack_stride[16] = {0};
   std::vector<int> hbm;  // HBM fronts of this level
   int small_begin = 0, small_count = 0;  // those with nf <= BSS_MAX_NF, in d_hbm_small: back-substituted in one launch per level
@@ -210,7 +210,7 @@ struct lmgpu_handle {
   double* d_lambda = nullptr;   // damping parameter of the solve being queued (device memory: see do_solve_enqueue)
   bool merge_backsub = false;   // LDS fronts of consecutive levels in one dataflow launch (deep trees; LMGPU_MERGE_BACKSUB=0/1)
   int32_t *d_bs_parent = nullptr, *d_bs_pos = nullptr;  // per front: parent front if it is an LDS front (else -1); position in d_lists (-1: HBM)
-  char* d_leafpack = nullptr;                           // packed descriptors of the gather leaves (kernels_front.hpp, LEAFPACK_*)
+  char* d_leafpack = nullptr;                           // packed descriptors of the LDS fronts (kernels_front.hpp, LEAFPACK_*)
   unsigned int* d_bs_done = nullptr;                    // per front flag + one ticket counter per level
   bool use_graph = false;       // replay the solve's launch sequence as a hipGraph (deep trees; LMGPU_GRAPH=0/1 overrides)
   int eager_solves = 0;
@@ -534,7 +534,8 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
                            (const int32_t*)(h->d_lists + L.list_begin + L.bin_begin[b]), (const FrontDesc*)h->d_fronts,
                            (const FrontFac*)h->d_ffac, (const FacDesc*)h->d_fd, (const ChildRef*)h->d_childs, (const int32_t*)h->d_cmap,
                            (const int32_t*)h->d_fxoff, h->pool, lambda_v, lambda_p, (const double*)h->dampw, h->d_status, nmax, srows, h->d_gcorner, jcap,
-                           (const double*)h->gex_active, (const char*)nullptr, 0);
+                           (const double*)h->gex_active, (const char*)(h->d_leafpack && L.pack_stride[b] ? h->d_leafpack + L.pack_off[b] : nullptr),
+                           L.pack_stride[b]);
       else
         hipLaunchKernelGGL(lds_front_kernel<true>, dim3(cnt), dim3(threads), lds, s,
                            (const int32_t*)(h->d_lists + L.list_begin + L.bin_begin[b]), (const FrontDesc*)h->d_fronts,
@@ -1854,10 +1855,10 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
   HIPCHECK(hipSetDevice(h->device));
   HIPCHECK(hipMalloc((void**)&h->pool, h->pool_doubles * sizeof(double)));
   int rc;
-  if (!getenv("LMGPU_NO_LEAFPACK")) {  // packed records of the gather leaves, launch by launch
+  if (!getenv("LMGPU_NO_LEAFPACK")) {  // packed records of the LDS fronts, launch by launch
     std::vector<char> packs;
     for (LevelWork& L : h->levels)
-      for (int b = 6; b < kNumBins; b++) {
+      for (int b = 0; b < kNumBins; b++) {
         const int cnt = L.bin_begin[b + 1] - L.bin_begin[b];
         if (cnt == 0) continue;
         int maxfac = 0;
@@ -1873,7 +1874,7 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
           std::memcpy(rec, &F, sizeof(FrontDesc));
           int32_t* hdr = (int32_t*)(rec + LEAFPACK_HDR);
           hdr[0] = hdr[1] = hdr[2] = hdr[3] = 0;
-          if (F.nf > LEAFPACK_MAXNF || F.fac_count < 1 || F.fac_count > LDSF_MAXB) continue;
+          if (F.fac_count < 1 || F.fac_count > LDSF_MAXB) continue;
           LFac* lf = (LFac*)(rec + LEAFPACK_FAC);
           int o = 0;
           bool contig = true;
@@ -1896,8 +1897,11 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
           hdr[0] = F.fac_count;
           hdr[1] = o;
           hdr[2] = contig ? 1 : 0;
-          int32_t* xo = (int32_t*)(rec + LEAFPACK_XO);
-          for (int i = 0; i < F.nf; i++) xo[i] = fxoff[F.fx_begin + i];
+          if (F.nf <= LEAFPACK_MAXNF) {
+            hdr[3] = 1;
+            int32_t* xo = (int32_t*)(rec + LEAFPACK_XO);
+            for (int i = 0; i < F.nf; i++) xo[i] = fxoff[F.fx_begin + i];
+          }
         }
       }
     if (!packs.empty() && h->device >= 0) {
