@@ -530,9 +530,20 @@ __global__ __launch_bounds__(256) void linear_error_kernel(const FacDesc* __rest
     const double* src = pool + j0;
     double* dst = stage[wave];
     const int pitch = sz0 | 1;  // odd pitch: lanes spread over the banks
-    for (int i = lane; i < cnt * sz0; i += 64) {
-      const int q = i / sz0;
-      dst[q * pitch + (i - q * sz0)] = src[i];
+    // eight loads in flight, then their stores (left as one load -> wait -> store per iteration by the compiler otherwise)
+    const int total = cnt * sz0;
+    for (int i0 = lane; i0 < total; i0 += 512) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = (i0 + 64 * u < total) ? src[i0 + 64 * u] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = i0 + 64 * u;
+        if (i < total) {
+          const int q = i / sz0;
+          dst[q * pitch + (i - q * sz0)] = v[u];
+        }
+      }
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
