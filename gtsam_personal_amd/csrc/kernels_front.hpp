@@ -161,7 +161,14 @@ __global__ __launch_bounds__(256) void lds_front_kernel(const int32_t* __restric
     }
     if (contig) {  // one flat copy: every load independent of the others
       const double* J = pool + LF[0].joff;
-      for (int i = tid; i < tot; i += nt) Jb[i] = J[i];
+      for (int i0 = tid; i0 < tot; i0 += 8 * nt) {  // eight loads in flight per thread, then their stores
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = (i0 + u * nt < tot) ? J[i0 + u * nt] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+          if (i0 + u * nt < tot) Jb[i0 + u * nt] = v[u];
+      }
     } else {
       for (int b = wave; b < B; b += nw) {
         const double* J = pool + LF[b].joff;
