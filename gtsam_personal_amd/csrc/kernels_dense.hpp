@@ -350,6 +350,54 @@ __global__ __launch_bounds__(64) void hbm_invert_diag_kernel(const double* __res
   for (int idx = j; idx < NB * NB; idx += NB) out[idx] = X[idx / NB][idx % NB];
 }
 
+// The same inverses from what the factorisation left behind: the 16x16 inverses of the diagonal tiles (inv16, by-product of the
+// register Cholesky, kernels_potrf.hpp; 16 per 256-row panel, panel p at inv16 + p * 4096).  Block back-substitution on the
+// matrix cores, one wave per 64x64 block:  X_hh = I_h;  X_gh = -I_g (sum_{k = g+1..h} R_gk X_kh)  for g < h -- 64 MFMAs instead of
+// 2048 dependent LDS round trips per column (82 -> a few us for the 141 blocks of the C4 root).
+__global__ __launch_bounds__(64) void hbm_invert_diag64_from16_kernel(const double* __restrict__ A, int ld, int nf, const double* __restrict__ inv16,
+                                                                       double* __restrict__ inv) {
+  typedef double d4_t __attribute__((ext_vector_type(4)));
+  __shared__ double Rl[64][65];
+  __shared__ double Xl[64][65];
+  __shared__ double Il[4][16][17];
+  const int bb = blockIdx.x, r0 = 64 * bb, nb = min(64, nf - r0), lane = threadIdx.x, kk = lane >> 4, cc = lane & 15;
+  for (int idx = lane; idx < 64 * 64; idx += 64) {
+    const int p = idx >> 6, q = idx & 63;
+    double v = (p == q) ? 1.0 : 0.0;
+    if (p < nb && q < nb && q >= p) v = A[(size_t)(r0 + p) * ld + r0 + q];
+    Rl[p][q] = v;
+    Xl[p][q] = 0.0;
+  }
+  const double* I16 = inv16 + (size_t)(bb >> 2) * 4096 + (size_t)(4 * (bb & 3)) * 256;
+  for (int idx = lane; idx < 4 * 256; idx += 64) Il[idx >> 8][(idx >> 4) & 15][idx & 15] = I16[idx];
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int h = 0; h < 4; h++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) Xl[16 * h + kk + 4 * r][16 * h + cc] = Il[h][kk + 4 * r][cc];
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int g = h - 1; g >= 0; g--) {
+      d4_t m = d4_t{0, 0, 0, 0};
+#pragma unroll
+      for (int k = g + 1; k <= h; k++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) m = __builtin_amdgcn_mfma_f64_16x16x4f64(Rl[16 * g + cc][16 * k + 4 * r + kk], Xl[16 * k + 4 * r + kk][16 * h + cc], m, 0, 0, 0);
+      d4_t x = d4_t{0, 0, 0, 0};
+#pragma unroll
+      for (int r = 0; r < 4; r++) x = __builtin_amdgcn_mfma_f64_16x16x4f64(-Il[g][cc][4 * r + kk], m[r], x, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; r++) Xl[16 * g + kk + 4 * r][16 * h + cc] = x[r];
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+  double* out = inv + (size_t)bb * 4096;
+  for (int idx = lane; idx < 64 * 64; idx += 64) out[idx] = Xl[idx >> 6][idx & 63];
+}
+
 // R x = y, R = rows 0..nf-1 of the front (upper).  Workgroup b owns row block b:  it folds x_j (j > b) into its right-hand side
 // as the blocks are published, then x_b = inv(R_bb) rhs and publishes x_b.  Hand-off: 8-byte agent-scope atomics for the payload and the flag on both sides
 // (cdna_hip_programming.md Guideline 16, "8-B agent atomics both sides"), bounded spin.

@@ -274,6 +274,7 @@ struct lmgpu_handle {
   std::vector<LevelWork> levels;
   int ntot = 0, nstore = 0;
   bool dampw_is_ones = false;
+  int inv16_owner = -1;  // HBM front whose panels' 16x16 inverses inv16 currently holds
   double* gex = nullptr;         // ntot doubles: extra gradient vector for solves with a prescribed right-hand side (marginals)
   double* gex_active = nullptr;  // == gex while such a solve is being assembled, else nullptr
 
@@ -716,14 +717,16 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
         const int ktp = h->kt.begin(LMGPU_KT_PANEL, s);
         if (dataflow_ok(i)) {
           hipLaunchKernelGGL(panel_dataflow_kernel, dim3(kb / 64 + (cols + 63) / 64), dim3(256), PDF_LDS_BYTES, s, A, ld, F.n, F.nf, k0, kb, F.id,
-                             h->d_status, h->inv16, h->d_pflags + (size_t)i * PDF_FLAG_WORDS);
+                             h->d_status, h->inv16 + (size_t)i * 4096, h->d_pflags + (size_t)i * PDF_FLAG_WORDS);
         } else {
-          hipLaunchKernelGGL(diag_potrf_kernel, dim3(1), dim3(256), DIAG_LDS_BYTES, s, A, ld, F.nf, k0, kb, F.id, h->d_status, h->inv16);
-          if (cols > 0) hipLaunchKernelGGL(panel_trsm_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, A, ld, F.n, k0, kb, (const double*)h->inv16);
+          hipLaunchKernelGGL(diag_potrf_kernel, dim3(1), dim3(256), DIAG_LDS_BYTES, s, A, ld, F.nf, k0, kb, F.id, h->d_status, h->inv16 + (size_t)i * 4096);
+          if (cols > 0)
+            hipLaunchKernelGGL(panel_trsm_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, A, ld, F.n, k0, kb, (const double*)(h->inv16 + (size_t)i * 4096));
         }
         h->kt.end(ktp, s, panel_flop(i));
       };
       panel_alone(0);
+      h->inv16_owner = fi;  // the per-panel 16x16 inverses now belong to this front (read again by its back-substitution)
       int kt_run = -1, run_launches = 0;  // one event pair around a run of consecutive step launches
       double run_flop = 0;
       auto close_run = [&]() {
@@ -783,7 +786,7 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
         const double upd_flop = 2.0 * kb * ((double)m * (m + 1) / 2.0);
         if (fuse) {
           const int kbn = rows_of(i + 1);
-          StepArgs a{A, ld, F.n, F.nf, k0, kb, kbn, F.id, h->d_status, h->inv16, h->d_pflags + (size_t)(i + 1) * PDF_FLAG_WORDS,
+          StepArgs a{A, ld, F.n, F.nf, k0, kb, kbn, F.id, h->d_status, h->inv16 + (size_t)(i + 1) * 4096, h->d_pflags + (size_t)(i + 1) * PDF_FLAG_WORDS,
                      fold_in_step ? (const double*)Asm : nullptr};
           const int grid = step_grid(m, kbn);
           if (run_launches == 0) kt_run = h->kt.begin(LMGPU_KT_SYRK, s);
@@ -873,7 +876,11 @@ int do_backsub(lmgpu_handle* h) {
       // inverse of the diagonal blocks (all in parallel), then ONE dataflow launch: workgroup b waits for x_j (j > b) flags
       HIPCHECK(hipMemsetAsync(h->bs_flags, 0, (nblk + 1) * sizeof(unsigned int), s));  // flags + ticket
       HIPCHECK(hipMemsetAsync(h->bs_x, 0xff, (size_t)nblk * NB * sizeof(double), s));  // sentinel: "not published yet"
-      hipLaunchKernelGGL((hbm_invert_diag_kernel<NB>), dim3(nblk), dim3(NB), 0, s, (const double*)(h->pool + off), ld, F.nf, h->bs_inv);
+      if (h->inv16_owner == fi && !getenv("LMGPU_NO_INV16_REUSE"))
+        hipLaunchKernelGGL(hbm_invert_diag64_from16_kernel, dim3(nblk), dim3(64), 0, s, (const double*)(h->pool + off), ld, F.nf,
+                           (const double*)h->inv16, h->bs_inv);
+      else
+        hipLaunchKernelGGL((hbm_invert_diag_kernel<NB>), dim3(nblk), dim3(NB), 0, s, (const double*)(h->pool + off), ld, F.nf, h->bs_inv);
       hipLaunchKernelGGL((hbm_backsolve_dataflow_kernel<NB>), dim3(nblk), dim3(256), 0, s, F, off, ld, (const int32_t*)h->d_fxoff,
                          (const double*)h->pool, (const double*)h->bs_inv, (const double*)h->ywork, h->bs_x, h->bs_flags, h->delta,
                          h->d_status);
@@ -2052,7 +2059,7 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
       if (h->front_active[fi] && P.fronts[fi].cls == 1) max_nf = std::max(max_nf, P.fronts[fi].nf);
     const int max_blk = (max_nf + NB - 1) / NB;
     HIPCHECK(hipMalloc((void**)&h->bs_inv, (size_t)max_blk * NB * NB * sizeof(double)));
-    HIPCHECK(hipMalloc((void**)&h->inv16, (size_t)((P.max_front_n + NBO - 1) / NBO + 1) * 16 * 256 * sizeof(double)));  // per step of a chained launch
+    HIPCHECK(hipMalloc((void**)&h->inv16, (size_t)((P.max_front_n + NBO - 1) / NBO + 2) * 16 * 256 * sizeof(double)));  // 16 blocks per outer panel
     h->pflags_panels = (P.max_front_n + NBO - 1) / NBO + 1;
     HIPCHECK(hipMalloc((void**)&h->d_pflags, (size_t)h->pflags_panels * PDF_FLAG_WORDS * sizeof(unsigned int)));
     HIPCHECK(hipMalloc((void**)&h->bs_x, (size_t)max_blk * NB * sizeof(double)));
