@@ -66,8 +66,8 @@ def pmc_traffic():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cams", type=int, default=1000)
     ap.add_argument("--points", type=int, default=100000)
     ap.add_argument("--obs", type=int, default=10)
