@@ -1,6 +1,6 @@
-"""Multi-panel HBM front (64 cameras -> 577 x 577 root, 3 outer panels of 256 rows): the dense path against the oracle,
-in the default single-stream mode and (development aid) in the experimental two-stream look-ahead mode selected with
-LMGPU_LOOKAHEAD=1 in the environment of the test process."""
+"""Multi-panel dense fronts (64 cameras -> 577 x 577 root with 3 outer panels, up to 600 cameras -> 5401 x 5401): the dense
+path (dataflow panels, fused steps, the chained launch and its ticket schedule) against the oracle and, beyond the oracle's
+reach, its launch forms against each other (LMGPU_CHAIN_FAR / LMGPU_NO_CHAIN / LMGPU_NO_FUSE / LMGPU_PANEL_2L)."""
 import os
 
 import numpy as np
