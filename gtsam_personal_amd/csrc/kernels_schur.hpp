@@ -56,9 +56,16 @@ __device__ __forceinline__ long long readlane_ll(long long v, int src /* wave-un
 // added in a fixed order; waves take fixed contiguous chunks of the list.
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void schur_pairs_kernel(const GPairBlock* __restrict__ blocks, const GPairEntry* __restrict__ entries,
-                                                                  double* __restrict__ pool, int64_t f_off, int ld) {
+                                                                  double* __restrict__ pool, int64_t f_off, int ld, int nblocks) {
   __shared__ double part[WAVES][4][64];
-  const GPairBlock B = blocks[blockIdx.x];
+  // XCD-aware order: workgroup ids go round-robin over the eight XCDs, so id -> (id % 8) * ceil(N / 8) + id / 8 gives every XCD
+  // a contiguous range of the (row-major sorted) destination blocks: the blocks of one camera row re-read that camera's S
+  // blocks nine times between them, which only hits in L2 if they run on the same XCD
+  // (the grid is nblocks rounded up to a multiple of eight, so that the map is onto)
+  const int per_xcd = (nblocks + 7) >> 3;
+  const int logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (logical >= nblocks) return;
+  const GPairBlock B = blocks[logical];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int kk = lane >> 4, cc = lane & 15;
   const bool va = cc < B.da, vb = cc < B.db;

@@ -626,11 +626,12 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
         const int l0 = whole ? 0 : G.cl[c0], l1 = whole ? G.pblk_long : G.cl[c1];
         const int v0 = whole ? 0 : G.cv[c0], v1 = whole ? G.vblk_count : G.cv[c1];
         if (s1 > s0)
-          hipLaunchKernelGGL((schur_pairs_kernel<1>), dim3(s1 - s0), dim3(64), 0, sa, (const GPairBlock*)(h->d_gpblk + G.pblk_begin + s0),
-                             (const GPairEntry*)h->d_gpent, h->pool, aoff, ld);
+          hipLaunchKernelGGL((schur_pairs_kernel<1>), dim3((s1 - s0 + 7) & ~7), dim3(64), 0, sa, (const GPairBlock*)(h->d_gpblk + G.pblk_begin + s0),
+                             (const GPairEntry*)h->d_gpent, h->pool, aoff, ld, s1 - s0);
         if (l1 > l0)
-          hipLaunchKernelGGL((schur_pairs_kernel<4>), dim3(l1 - l0), dim3(256), 0, sa,
-                             (const GPairBlock*)(h->d_gpblk + G.pblk_begin + G.pblk_short + l0), (const GPairEntry*)h->d_gpent, h->pool, aoff, ld);
+          hipLaunchKernelGGL((schur_pairs_kernel<4>), dim3((l1 - l0 + 7) & ~7), dim3(256), 0, sa,
+                             (const GPairBlock*)(h->d_gpblk + G.pblk_begin + G.pblk_short + l0), (const GPairEntry*)h->d_gpent, h->pool, aoff, ld,
+                             l1 - l0);
         if (v1 > v0)
           hipLaunchKernelGGL(schur_factor_kernel, dim3(v1 - v0), dim3(64 * SCHUR_FW), 0, sa, (const GVarBlock*)(h->d_gvblk + G.vblk_begin + v0),
                              (const GVarEntry*)h->d_gvent, h->pool, aoff, ld, F.n);
