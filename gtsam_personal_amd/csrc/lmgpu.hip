@@ -215,6 +215,7 @@ struct lmgpu_handle {
   bool use_graph = false;       // replay the solve's launch sequence as a hipGraph (deep trees; LMGPU_GRAPH=0/1 overrides)
   int eager_solves = 0;
   hipGraphExec_t solve_graph[2] = {nullptr, nullptr};  // [1]: with the extra gradient vector of the marginal solves
+  bool no_tail = false;                        // LMGPU_NO_TAIL=1: the end of a front as separate update / panel launches (A/B)
   bool no_chain = false;                       // LMGPU_NO_CHAIN=1: one launch per fused step instead of one per run of steps (A/B)
   unsigned int* d_pflags = nullptr;            // hand-off flags of panel_dataflow_kernel, PDF_FLAG_WORDS per outer panel
   int pflags_panels = 0;
@@ -769,6 +770,15 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
           h->kt.end(ktc, s, cp.flop, 1);
           i += cp.nsteps - 1;
           continue;
+        }
+        // the end of the front as one small launch: update with panel i, factor the last (partial) panel, update what follows
+        if (!split && !h->no_tail && i + 2 == np && kb <= TAIL_MAX_KP && m <= TAIL_MAX_M && rows_of(i + 1) < 64) {
+          close_run();
+          const int ktt = h->kt.begin(LMGPU_KT_PANEL, s);
+          hipLaunchKernelGGL(front_tail_kernel, dim3(1), dim3(256), TAIL_LDS_BYTES, s, A, ld, F.n, F.nf, k0, kb, F.id, h->d_status,
+                             h->inv16 + (size_t)(i + 1) * 4096);
+          h->kt.end(ktt, s, 2.0 * kb * ((double)m * (m + 1) / 2.0) + panel_flop(i + 1));
+          break;
         }
         const bool fuse = fusable(i);
         // rows of panel i+1 (and, for i = np-1, of the separator part): a fused step folds them in itself (its 64x64 head tiles
@@ -1367,6 +1377,7 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
   h->two_launch_panel = getenv("LMGPU_PANEL_2L") != nullptr;
   h->no_fuse = getenv("LMGPU_NO_FUSE") != nullptr;
   h->no_chain = getenv("LMGPU_NO_CHAIN") != nullptr;
+  h->no_tail = getenv("LMGPU_NO_TAIL") != nullptr;
   if (const char* e = getenv("LMGPU_CHAIN_FAR")) h->chain_far_pct = std::max(10, std::min(100, atoi(e)));
   h->overlap_gather = getenv("LMGPU_OVERLAP") != nullptr;
   *out = h;
@@ -1400,6 +1411,7 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
     HIPCHECK(hipFuncSetAttribute((const void*)panel_dataflow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PDF_LDS_BYTES));
     HIPCHECK(hipFuncSetAttribute((const void*)step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STEP_LDS_BYTES));
     HIPCHECK(hipFuncSetAttribute((const void*)chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STEP_LDS_BYTES));
+    HIPCHECK(hipFuncSetAttribute((const void*)front_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS_BYTES));
     HIPCHECK(hipFuncSetAttribute((const void*)med_diag_potrf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
     HIPCHECK(hipFuncSetAttribute((const void*)med_syrk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSyrkLds));
   }
