@@ -56,7 +56,7 @@ __device__ __forceinline__ long long readlane_ll(long long v, int src /* wave-un
 // added in a fixed order; waves take fixed contiguous chunks of the list.
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void schur_pairs_kernel(const GPairBlock* __restrict__ blocks, const GPairEntry* __restrict__ entries,
-                                                                  double* __restrict__ pool, int64_t f_off, int ld, int nblocks) {
+                                                                  double* __restrict__ pool, int64_t f_off, int ld, int nblocks, int write_mode) {
   __shared__ double part[WAVES][4][64];
   // XCD-aware order: workgroup ids go round-robin over the eight XCDs, so id -> (id % 8) * ceil(N / 8) + id / 8 gives every XCD
   // a contiguous range of the (row-major sorted) destination blocks: the blocks of one camera row re-read that camera's S
@@ -115,11 +115,14 @@ __global__ __launch_bounds__(64 * WAVES) void schur_pairs_kernel(const GPairBloc
   const bool diag = (B.pa == B.pb);
   // destination read-modify-write: the four loads of a lane in flight together (clamped address where the slot is unused).
   // (Issuing them before the list walk was measured slower: 1.41 vs 1.26 ms per C4 assembly.)
-  double cur[4];
+  // write_mode: this gather is the FIRST contribution to the front (no clear beforehand): the block is written, not added to
+  double cur[4] = {0.0, 0.0, 0.0, 0.0};
+  if (!write_mode) {
 #pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int i = min(kk + 4 * r, B.da - 1), j = min(cc, B.db - 1);
-    cur[r] = A[(size_t)(B.pa + i) * ld + B.pb + j];
+    for (int r = 0; r < 4; r++) {
+      const int i = min(kk + 4 * r, B.da - 1), j = min(cc, B.db - 1);
+      cur[r] = A[(size_t)(B.pa + i) * ld + B.pb + j];
+    }
   }
 #pragma unroll
   for (int r = 0; r < 4; r++) {
@@ -194,5 +197,19 @@ __global__ __launch_bounds__(64 * SCHUR_FW) void schur_factor_kernel(const GVarB
 }
 
 __global__ void add_scalar_kernel(double* __restrict__ dst, const double* __restrict__ src) { *dst += *src; }
+
+// upper blocks of a front that no gather list covers (write-mode gather: nothing else initialises them)
+struct GZeroBlock {
+  int32_t pa, pb;
+  int16_t da, db;
+};
+__global__ __launch_bounds__(128) void zero_blocks_kernel(const GZeroBlock* __restrict__ blocks, double* __restrict__ pool, int64_t f_off, int ld) {
+  const GZeroBlock B = blocks[blockIdx.x];
+  double* A = pool + f_off;
+  for (int idx = threadIdx.x; idx < B.da * B.db; idx += 128) {
+    const int i = idx / B.db, j = idx - i * B.db;
+    if (B.pa != B.pb || i <= j) A[(size_t)(B.pa + i) * ld + B.pb + j] = 0.0;
+  }
+}
 
 }  // namespace lmgpu

@@ -251,6 +251,10 @@ struct lmgpu_handle {
     // blocks are sorted by destination row: [cs[c], cs[c+1]) = short pair blocks whose rows lie in row chunk c (256 rows),
     // likewise cl (long pair blocks) and cv (variable blocks); offsets relative to the three list starts
     std::vector<int> cs, cl, cv;
+    // write mode: every contribution to the front's upper triangle before the gather comes from the gather itself (all children are
+    // gather leaves), so the gather writes its blocks and only the blocks no list covers are cleared: [zero_begin, +zero_count)
+    bool write_ok = false;
+    int zero_begin = 0, zero_count = 0;
   };
   // LMGPU_OVERLAP=1: gather the root's row chunks on a second stream beside its factorisation.  Measured r01 (C4): 13.5 ms per
   // step instead of 10.4 -- two resident workgroups of the update kernel hold every VGPR of a SIMD (2 x 256), so the gather
@@ -261,6 +265,9 @@ struct lmgpu_handle {
   double *partial2 = nullptr, *dscal2 = nullptr;
   std::vector<GatherRange> gather;  // per front (only HBM fronts have non-empty ranges)
   GPairBlock* d_gpblk = nullptr;
+  GZeroBlock* d_gzero = nullptr;
+  int n_hbm_fronts = 0;          // number of HBM-class fronts on this rank (selects the clearing regime in do_eliminate)
+  bool no_gather_write = false;  // LMGPU_NO_GATHER_WRITE=1: clear the front and add (A/B)
   GPairEntry* d_gpent = nullptr;
   GVarBlock* d_gvblk = nullptr;
   GVarEntry* d_gvent = nullptr;
@@ -492,6 +499,13 @@ int fill_dampw(lmgpu_handle* h, int diagonal, double min_diag, double max_diag) 
 }
 
 // ---- numeric elimination of all (active) fronts, level by level (a10-a13)
+// The front's first contribution is its own Schur gather (all children are gather leaves, single rank): no clear, the gather writes.
+// Only in the per-front clearing regime (few large HBM fronts); the span memset of general sparse graphs covers everything anyway.
+static bool gather_writes(const lmgpu_handle* h, int fi) {
+  const lmgpu_handle::GatherRange& G = h->gather[fi];
+  return G.write_ok && G.leaf_count > 0 && !h->no_gather_write && h->s_off[fi] < 0 && !h->overlap_gather && h->n_hbm_fronts <= 4;
+}
+
 int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  // lambda by value (eager) or in device memory (graph replay)
   hipStream_t s = h->stream;
   HIPCHECK(hipMemsetAsync(h->d_status, 0x7f, sizeof(int), s));
@@ -514,6 +528,7 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
     } else {
       for (const LevelWork& L : h->levels)
         for (int fi : L.hbm) {
+          if (gather_writes(h, fi)) continue;  // its upper triangle is written by the gather and a list of uncovered blocks
           const size_t bytes = (size_t)h->h_fronts[fi].n * h->f_ld[fi] * sizeof(double);
           HIPCHECK(hipMemsetAsync(h->pool + h->f_off[fi], 0, bytes, s));
           if (h->s_off[fi] >= 0) HIPCHECK(hipMemsetAsync(h->pool + h->s_off[fi], 0, bytes, s));
@@ -612,13 +627,24 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
         count = (size_t)rows * ld - r0c;
       };
       int kt = h->kt.begin(LMGPU_KT_HBM_ASSEMBLE, sa);
-      if (F.fac_count > 0 && own_terms)
+      const bool gwrite = gather_writes(h, fi);
+      if (gwrite && G.zero_count > 0)
+        hipLaunchKernelGGL(zero_blocks_kernel, dim3(G.zero_count), dim3(128), 0, sa, (const GZeroBlock*)(h->d_gzero + G.zero_begin), h->pool, aoff, ld);
+      if (F.fac_count > 0 && own_terms && !gwrite)
         hipLaunchKernelGGL(hbm_assemble_factors_kernel, dim3(F.fac_count), dim3(64), 0, sa, F, aoff, ld, (const FrontFac*)h->d_ffac,
                            (const FacDesc*)h->d_fd, h->pool);
       if (F.child_count > 0)
         hipLaunchKernelGGL(hbm_assemble_children_kernel, dim3(F.child_count, kChildSplit), dim3(256), 0, sa, F, aoff, ld, (const ChildRef*)h->d_childs,
                            (const int32_t*)h->d_cmap, h->pool);
-      if (own_terms)
+      auto own_additive_terms = [&]() {  // the front's own factors and the damping (added: after whatever initialises the entries)
+        if (F.fac_count > 0 && own_terms)
+          hipLaunchKernelGGL(hbm_assemble_factors_kernel, dim3(F.fac_count), dim3(64), 0, sa, F, aoff, ld, (const FrontFac*)h->d_ffac,
+                             (const FacDesc*)h->d_fd, h->pool);
+        if (own_terms)
+          hipLaunchKernelGGL(hbm_damp_kernel, dim3((F.nf + 255) / 256), dim3(256), 0, sa, F, aoff, ld, (const int32_t*)h->d_fxoff, h->pool, lambda_v,
+                             lambda_p, (const double*)h->dampw, (const double*)h->gex_active);
+      };
+      if (!gwrite && own_terms)
         hipLaunchKernelGGL(hbm_damp_kernel, dim3((F.nf + 255) / 256), dim3(256), 0, sa, F, aoff, ld, (const int32_t*)h->d_fxoff, h->pool, lambda_v,
                            lambda_p, (const double*)h->dampw, (const double*)h->gex_active);
       // leaf children in Schur form: deterministic gather instead of atomics; rows [c0, c1) of the chunk table
@@ -628,11 +654,11 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
         const int v0 = whole ? 0 : G.cv[c0], v1 = whole ? G.vblk_count : G.cv[c1];
         if (s1 > s0)
           hipLaunchKernelGGL((schur_pairs_kernel<1>), dim3((s1 - s0 + 7) & ~7), dim3(64), 0, sa, (const GPairBlock*)(h->d_gpblk + G.pblk_begin + s0),
-                             (const GPairEntry*)h->d_gpent, h->pool, aoff, ld, s1 - s0);
+                             (const GPairEntry*)h->d_gpent, h->pool, aoff, ld, s1 - s0, gwrite ? 1 : 0);
         if (l1 > l0)
           hipLaunchKernelGGL((schur_pairs_kernel<4>), dim3((l1 - l0 + 7) & ~7), dim3(256), 0, sa,
                              (const GPairBlock*)(h->d_gpblk + G.pblk_begin + G.pblk_short + l0), (const GPairEntry*)h->d_gpent, h->pool, aoff, ld,
-                             l1 - l0);
+                             l1 - l0, gwrite ? 1 : 0);
         if (v1 > v0)
           hipLaunchKernelGGL(schur_factor_kernel, dim3(v1 - v0), dim3(64 * SCHUR_FW), 0, sa, (const GVarBlock*)(h->d_gvblk + G.vblk_begin + v0),
                              (const GVarEntry*)h->d_gvent, h->pool, aoff, ld, F.n);
@@ -644,6 +670,7 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
       };
       if (!pipelined) {
         gather_chunks(0, nchunks, true);
+        if (gwrite) own_additive_terms();
         h->kt.end(kt, sa);
         if (multi && h->comm && split) {  // RCCL: all chunks queued on the communication stream, one event each
           HIPCHECK(hipEventRecord(h->asm_ev, s));
@@ -1378,6 +1405,7 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
   h->no_fuse = getenv("LMGPU_NO_FUSE") != nullptr;
   h->no_chain = getenv("LMGPU_NO_CHAIN") != nullptr;
   h->no_tail = getenv("LMGPU_NO_TAIL") != nullptr;
+  h->no_gather_write = getenv("LMGPU_NO_GATHER_WRITE") != nullptr;
   if (const char* e = getenv("LMGPU_CHAIN_FAR")) h->chain_far_pct = std::max(10, std::min(100, atoi(e)));
   h->overlap_gather = getenv("LMGPU_OVERLAP") != nullptr;
   *out = h;
@@ -1443,7 +1471,7 @@ int lmgpu_destroy(lmgpu_handle* h) {
     for (int i = 0; i < 8; i++)
       if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     for (hipEvent_t e : h->kt.pool) (void)hipEventDestroy(e);
-    fr(h->bs_inv); fr(h->bs_x); fr(h->bs_flags); fr(h->inv16); fr(h->d_pflags); fr(h->d_bs_parent); fr(h->d_bs_pos); fr(h->d_bs_done); fr(h->d_leafpack);
+    fr(h->bs_inv); fr(h->bs_x); fr(h->bs_flags); fr(h->inv16); fr(h->d_pflags); fr(h->d_bs_parent); fr(h->d_bs_pos); fr(h->d_bs_done); fr(h->d_leafpack); fr(h->d_gzero);
     for (auto& kv : h->chain_plans) fr(kv.second.d_tasks);
     fr(h->d_gpblk); fr(h->d_gpent); fr(h->d_gvblk); fr(h->d_gvent); fr(h->d_gcorner);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1622,6 +1650,7 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
   };
   int n_gleaf = 0;
   std::vector<GPairTmp> gp_tmp;
+  std::vector<GZeroBlock> gzero;
   std::vector<GVarTmp> gv_tmp;
   std::vector<GPairBlock> gpblk;
   std::vector<GPairEntry> gpent;
@@ -1696,6 +1725,7 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
     F.fac_count = (int)ffac.size() - F.fac_begin;
     // children present on this rank: map child's separator scalars (+ rhs) to this front's columns
     F.child_begin = (int)childs.size();
+    bool has_scatter_child = false;
     for (int32_t c : fr.children) {
       if (!h->front_active[c]) continue;
       const Front& ch = P.fronts[c];
@@ -1736,6 +1766,7 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
         continue;
       }
       if (CF.u_off < 0) {  // direct scatter child: tell it where its parent is
+        has_scatter_child = true;
         CF.par_off = h->s_off[fi] >= 0 ? h->s_off[fi] : h->f_off[fi];
         CF.par_ld = h->f_ld[fi];
         CF.par_map = map_begin;
@@ -1791,6 +1822,28 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
         starts(G.cs, G.pblk_short, [&](int i) { return gpblk[G.pblk_begin + i].pa; });
         starts(G.cl, G.pblk_long, [&](int i) { return gpblk[G.pblk_begin + G.pblk_short + i].pa; });
         starts(G.cv, G.vblk_count, [&](int i) { return gvblk[G.vblk_begin + i].pv; });
+      }
+      if (F.child_count == 0 && !has_scatter_child) {  // no child adds to this front before its own level: the gather can be the first writer
+        G.write_ok = true;
+        G.zero_begin = (int)gzero.size();
+        struct VB { int c, d; };
+        std::vector<VB> vb;
+        for (size_t k = 0; k < fr.vars.size(); k++) vb.push_back({fr.col_off[k], P.dims[fr.vars[k]]});
+        vb.push_back({fr.n - 1, 1});
+        size_t gi = 0;  // gpblk of this front is sorted by key among shorts, longs appended: collect the covered keys
+        std::vector<int64_t> covered;
+        covered.reserve(G.pblk_short + G.pblk_long);
+        for (int q = 0; q < G.pblk_short + G.pblk_long; q++)
+          covered.push_back(((int64_t)gpblk[G.pblk_begin + q].pa << 32) | (uint32_t)gpblk[G.pblk_begin + q].pb);
+        std::sort(covered.begin(), covered.end());
+        (void)gi;
+        for (size_t x = 0; x < vb.size(); x++)
+          for (size_t y = x; y < vb.size(); y++) {
+            const int64_t key = ((int64_t)vb[x].c << 32) | (uint32_t)vb[y].c;
+            if (!std::binary_search(covered.begin(), covered.end(), key))
+              gzero.push_back(GZeroBlock{vb[x].c, vb[y].c, (int16_t)vb[x].d, (int16_t)vb[y].d});
+          }
+        G.zero_count = (int)gzero.size() - G.zero_begin;
       }
       std::vector<GPairTmp>().swap(gp_tmp);
       std::vector<GVarTmp>().swap(gv_tmp);
@@ -1866,6 +1919,8 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
   h->finalized = true;
   if (h->device < 0) return LMGPU_OK;  // structure-only handle: symbolic analysis available, no compute
 
+  h->n_hbm_fronts = 0;
+  for (const LevelWork& L : h->levels) h->n_hbm_fronts += (int)L.hbm.size();
   // deep trees are launch-bound: replay the solve as a graph (LMGPU_GRAPH=0 / 1 overrides the depth rule)
   h->use_graph = (int)h->levels.size() >= 12;
   h->merge_backsub = (int)h->levels.size() >= 12;
@@ -1874,6 +1929,8 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
   // ---- device upload
   HIPCHECK(hipSetDevice(h->device));
   HIPCHECK(hipMalloc((void**)&h->pool, h->pool_doubles * sizeof(double)));
+  // once: entries the kernels read but never write (lower triangles inside diagonal tiles, padding columns) must be finite
+  HIPCHECK(hipMemset(h->pool, 0, h->pool_doubles * sizeof(double)));
   int rc;
   if (!getenv("LMGPU_NO_LEAFPACK")) {  // packed records of the LDS fronts, launch by launch
     std::vector<char> packs;
@@ -1985,6 +2042,7 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
     if ((rc = upload(h, &h->d_f_ld, h->f_ld))) return rc;
   }
   if ((rc = upload(h, &h->d_gpblk, gpblk))) return rc;
+  if ((rc = upload(h, &h->d_gzero, gzero))) return rc;
   if ((rc = upload(h, &h->d_gpent, gpent))) return rc;
   if ((rc = upload(h, &h->d_gvblk, gvblk))) return rc;
   if ((rc = upload(h, &h->d_gvent, gvent))) return rc;
