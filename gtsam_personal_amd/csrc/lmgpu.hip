@@ -501,9 +501,14 @@ int fill_dampw(lmgpu_handle* h, int diagonal, double min_diag, double max_diag) 
 // ---- numeric elimination of all (active) fronts, level by level (a10-a13)
 // The front's first contribution is its own Schur gather (all children are gather leaves, single rank): no clear, the gather writes.
 // Only in the per-front clearing regime (few large HBM fronts); the span memset of general sparse graphs covers everything anyway.
+// With several ranks the same holds for the rank's partial-assembly buffer (the working matrix still starts from zero): after the
+// all-reduce it holds the sums of the previous solve, which this rank's gather overwrites where it has entries and the list of
+// blocks it does not cover clears.
 static bool gather_writes(const lmgpu_handle* h, int fi) {
   const lmgpu_handle::GatherRange& G = h->gather[fi];
-  return G.write_ok && G.leaf_count > 0 && !h->no_gather_write && h->s_off[fi] < 0 && !h->overlap_gather && h->n_hbm_fronts <= 4;
+  if (!(G.write_ok && G.leaf_count > 0 && !h->no_gather_write && !h->overlap_gather && h->n_hbm_fronts <= 4)) return false;
+  if (h->s_off[fi] < 0) return true;
+  return (h->h_fronts[fi].pad & 1) != 0 && (h->comm || h->lgroup);  // the partial-assembly buffer is in use (`split` below)
 }
 
 int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  // lambda by value (eager) or in device memory (graph replay)
@@ -528,10 +533,12 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
     } else {
       for (const LevelWork& L : h->levels)
         for (int fi : L.hbm) {
-          if (gather_writes(h, fi)) continue;  // its upper triangle is written by the gather and a list of uncovered blocks
+          // gather_writes: the upper triangle of the buffer the front is assembled into is written by the gather and a list of
+          // uncovered blocks -- the front itself on one rank, the partial-assembly buffer with several
+          const bool gw = gather_writes(h, fi);
           const size_t bytes = (size_t)h->h_fronts[fi].n * h->f_ld[fi] * sizeof(double);
-          HIPCHECK(hipMemsetAsync(h->pool + h->f_off[fi], 0, bytes, s));
-          if (h->s_off[fi] >= 0) HIPCHECK(hipMemsetAsync(h->pool + h->s_off[fi], 0, bytes, s));
+          if (!gw || h->s_off[fi] >= 0) HIPCHECK(hipMemsetAsync(h->pool + h->f_off[fi], 0, bytes, s));
+          if (!gw && h->s_off[fi] >= 0) HIPCHECK(hipMemsetAsync(h->pool + h->s_off[fi], 0, bytes, s));
         }
     }
     h->kt.end(kt0, s);
