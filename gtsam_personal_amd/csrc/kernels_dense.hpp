@@ -1,8 +1,9 @@
 // HBM fronts: fronts too large for one workgroup's LDS live in HBM (row-major upper, leading dimension ld = n rounded up to 16)
 // and are processed by a blocked right-looking partial Cholesky with outer panels of 256 rows:
 //   panel 0                     -> panel_dataflow_kernel (kernels_potrf.hpp)
-//   per outer panel i           -> step_kernel (kernels_step.hpp) = trailing update with panel i (syrk_tile below, K = 256)
-//                                  + factorisation of panel i+1 inside the same launch
+//   all following panels        -> chain_kernel (kernels_step.hpp): per outer panel i the trailing update with panel i (syrk_tile
+//                                  below, K = 256) + the factorisation of panel i+1, all steps of the front in ONE launch
+//                                  (step_kernel: one step per launch, for runs that cannot be chained)
 // so the big trailing matrix is read-modified-written once per 256 eliminated rows.
 // This is choleskyPartial (gtsam/base/cholesky.cpp:108-159: LLT(A); S = R^-T B; C -= S^T S; pivot-exponent test)
 // in blocked form; the root of a BAL problem (all cameras, 9001 x 9001) spends most of the solve here.

@@ -1,12 +1,12 @@
-// One launch per outer panel i of an HBM front:   trailing update with panel i   +   factorisation of panel i+1.
-// Logical workgroup ids (ticket order = start order) are laid out as
-//   [ trailing tiles of tile rows 0 and 1  = the rows of panel i+1 ]  [ diagonal workgroups of panel i+1 ]
-//   [ all other trailing tiles ]                                       [ row-panel (trsm) workgroups of panel i+1 ]
-// The first group publishes a per-column-tile counter when a tile is stored; the diagonal workgroups start on it and run
-// their potrf chain BESIDE the bulk of the trailing update (they occupy 4 of the 512 workgroup slots); the row-panel
-// workgroups are dispatched last and fill the tail of the update.  The dependency chain of the whole factorisation is
-// then  update_i -> (tail) -> update_{i+1}  instead of  update_i -> panel_{i+1} -> update_{i+1}  (look-ahead without a
-// second stream).  Every inter-workgroup hand-off is the release/acquire protocol of kernels_potrf.hpp.
+// A step of the blocked Cholesky of an HBM front = trailing update with outer panel i + factorisation of panel i+1, as dataflow
+// between workgroups.  Logical workgroups of a step (step_body):
+//   [ head tiles: the rows of panel i+1, 32x32 quadrants for strips 0..3, 64x64 sub-tiles beyond ]  [ diagonal workgroups of panel i+1 ]
+//   [ all other trailing tiles, 128x128 ]                                                           [ row-panel (trsm) workgroups of panel i+1 ]
+// The head tiles publish per-strip counters; the diagonal workgroups start on them and run their potrf chain BESIDE the bulk
+// of the trailing update (look-ahead without a second stream); the row-panel workgroups finish the panel.
+// step_kernel = one step per launch.  chain_kernel = all fused steps of a front in one launch, ticket order from
+// chain_schedule (host, below) -- see the comment there for what the order buys.  front_tail_kernel (kernels_potrf.hpp) ends the
+// front when the remainder is small.  Every inter-workgroup hand-off is the release/acquire protocol of kernels_potrf.hpp.
 #pragma once
 #include "kernels_dense.hpp"
 #include "kernels_potrf.hpp"
