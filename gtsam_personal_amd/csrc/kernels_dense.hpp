@@ -429,15 +429,20 @@ __global__ __launch_bounds__(256) void hbm_backsolve_dataflow_kernel(FrontDesc F
 #pragma unroll
     for (int k = 0; k < 16; k++) ibv[k] = ib[k];
   }
-  for (int j = nblk - 1; j > b; j--) {
+  // this thread's 16 entries of R[b rows, j cols], one block AHEAD of the poll: vector memory operations of a wave retire in
+  // order, so a poll issued behind 16 strided row reads could not return before them (they were ~1 us of every hop)
+  auto load_rv = [&](int j, double(&r)[16]) {
     const int c0 = j * NB, ncol = min(NB, F.nf - c0);
-    // prefetch this thread's 16 entries of R[b rows, j cols] while the producer is still working
-    double rv[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
       const int c = quarter * 16 + k;
-      rv[k] = (row < nb && c < ncol) ? arow[c0 + c] : 0.0;
+      r[k] = (j > b && row < nb && c < ncol) ? arow[c0 + c] : 0.0;
     }
+  };
+  double rv[16], rv_next[16];
+  load_rv(nblk - 1, rv);
+  for (int j = nblk - 1; j > b; j--) {
+    const int c0 = j * NB, ncol = min(NB, F.nf - c0);
     // the data is the flag: xbuf is preset to a sentinel bit pattern (all ones, a NaN no computation produces: the producer
     // canonicalises its NaNs); wave 0 polls its 64 values until none is the sentinel -- one round trip per hop instead of two
     if (tid < NB) {
@@ -457,6 +462,7 @@ __global__ __launch_bounds__(256) void hbm_backsolve_dataflow_kernel(FrontDesc F
       }
       xs[tid] = v;
     }
+    load_rv(j - 1, rv_next);  // behind the poll in program order: in flight while x_j is folded in and x_{j-1} is awaited
     __syncthreads();
     if (!ok) break;
     double s = 0;
@@ -465,6 +471,8 @@ __global__ __launch_bounds__(256) void hbm_backsolve_dataflow_kernel(FrontDesc F
     s += __shfl_xor(s, 1);
     s += __shfl_xor(s, 2);
     if (quarter == 0) acc[row] -= s;
+#pragma unroll
+    for (int k = 0; k < 16; k++) rv[k] = rv_next[k];
     __syncthreads();
   }
   if (!ok) {
