@@ -50,6 +50,20 @@ def cpu_baseline(n_cam, n_pt, obs, seed):
                 ms_per_iteration=1e3 * sum(times) / len(times), linearize_ms=1e3 * tm["linearize_s"], eliminate_ms=1e3 * tm["eliminate_s"])
 
 
+def metis_fixture_ordering(args, schur):
+    """The reference computes its ordering once at optimizer construction (LevenbergMarquardtParams.h:112-117); it is a boundary
+    INPUT of the hot path.  The METIS permutation of the bench workloads is carried by a committed fixture
+    (tools/make_c4_fixture.py: Ordering::Metis through the reference's own METIS sources, oracle/_ref)."""
+    import numpy as np
+    tags = {(1000, 100000, 10, 42): "c4_seed42", (100, 10000, 10, 42): "bal100_seed42"}
+    tag = tags.get((args.cams, args.points, args.obs, args.seed))
+    if tag is None:
+        raise SystemExit("--ordering metis: no METIS fixture for this size (tests/golden/*_metis.npz); use --ordering schur")
+    fx = np.load(os.path.join(ROOT, "tests", "golden", f"{tag}_metis.npz"))
+    srt = np.sort(np.array(list(schur), dtype=np.uint64))
+    return [int(k) for k in srt[fx["ordering_perm"]]]
+
+
 def pmc_traffic():
     """HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (counters cannot be collected
     from inside the process): {kernel: bytes}.  tools/pmc_summary.py writes the file; absent file -> traffic null."""
@@ -72,6 +86,10 @@ def main():
     ap.add_argument("--points", type=int, default=100000)
     ap.add_argument("--obs", type=int, default=10)
     ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--ordering", choices=["metis", "schur"], default="metis",
+                    help="elimination ordering: the reference's METIS ordering (BASELINE.json configs[3]; the permutation is a boundary input "
+                         "carried by tests/golden/<tag>_metis.npz, produced once by Ordering::Metis through oracle/_ref) or Schur "
+                         "(points then cameras, timing/timeSFMBAL.h:64-96)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--split-root", action="store_true",
@@ -101,6 +119,10 @@ def main():
 
     t_setup = time.perf_counter()
     graph, initial, _, ordering = make_bal(args.cams, args.points, args.obs, seed=args.seed)
+    ordering_name = "Schur ordering (points then cameras)"
+    if args.ordering == "metis":
+        ordering = metis_fixture_ordering(args, ordering)
+        ordering_name = "METIS ordering (Ordering::Metis of the reference, fixture-carried permutation)"
     params = LevenbergMarquardtParams()
     comm_id = None
     if world > 1:
@@ -163,7 +185,8 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"synthetic BAL {args.cams} cameras / {args.points} points / {n_factors} factors (GeneralSFMFactor<Cal3Bundler> + 2 priors), "
-                                   f"seed {args.seed}, Schur ordering (points then cameras), LM legacy defaults",
+                                   f"seed {args.seed}, {ordering_name}, LM legacy defaults",
+                       "ordering": args.ordering,
                        "cameras": args.cams, "points": args.points, "factors": n_factors, "fronts": opt.num_fronts(),
                        "parallelism": "single GPU" if world == 1 else f"point subtrees sharded over {world} ranks, camera root replicated after ncclAllReduce"},
             "ms_per_linearize": phases["linearize_ms"] / steps,

@@ -2162,7 +2162,6 @@ int lmgpu_set_values(lmgpu_handle* h, const double* packed) {
     HIPCHECK(hipMemcpy(h->vals[h->cur][t], buf.data(), buf.size() * sizeof(double), hipMemcpyHostToDevice));
   }
   h->have_values = true;
-  h->linearized = false;
   return LMGPU_OK;
 }
 
@@ -2204,7 +2203,6 @@ int lmgpu_restore_values(lmgpu_handle* h) {
     const size_t bytes = std::max<size_t>(1, (size_t)h->plan.type_count[t] * kVarStore[t]) * sizeof(double);
     HIPCHECK(hipMemcpyAsync(h->vals[h->cur][t], h->saved[t], bytes, hipMemcpyDeviceToDevice, h->stream));
   }
-  h->linearized = false;
   return LMGPU_OK;
 }
 
@@ -2305,6 +2303,9 @@ int lmgpu_joint_marginal_covariance(lmgpu_handle* h, int32_t nslots, const int32
 
 int lmgpu_marginal_covariance(lmgpu_handle* h, int32_t slot, double* cov) { return lmgpu_joint_marginal_covariance(h, 1, &slot, cov); }
 
+// The stored linearization ([A b] per factor) stays valid across lmgpu_set_values / lmgpu_retract / lmgpu_restore_values, like the
+// GaussianFactorGraph the reference's linearize() returned: tryLambda solves it again with a larger lambda after a rejected step
+// (LevenbergMarquardtOptimizer.cpp:302-305) whatever happened to the Values in between.
 int lmgpu_retract(lmgpu_handle* h, const double* delta_packed) {
   if (!h || !h->finalized || !h->have_values) return LMGPU_INVALID;
   int rc = need_device(h);
@@ -2314,7 +2315,6 @@ int lmgpu_retract(lmgpu_handle* h, const double* delta_packed) {
   if (rc) return rc;
   HIPCHECK(hipStreamSynchronize(h->stream));
   h->cur ^= 1;
-  h->linearized = false;
   return LMGPU_OK;
 }
 

@@ -1,195 +1,404 @@
 // lmgpu_gtsam_adapter.h — reference-side binding of the C ABI in lmgpu.h.
 //
-// Header-only adapter a GTSAM maintainer adds next to gtsam/nonlinear/LevenbergMarquardtOptimizer.h: a subclass that
-// overrides the reference's own extension points (virtual iterate(), LevenbergMarquardtOptimizer.h:103; the pattern is
-// the `IterativeLM` subclass of tests/testNonlinearOptimizer.cpp:507-528) and forwards the hot path to liblmgpu.so.
-// It is NOT compiled in this repository (GTSAM itself is not buildable here); it documents
-// exactly how the entry points of lmgpu.h bind.  Supported factor types are the ones of SURVEY section 8a; any other
-// factor makes the constructor throw, so a caller can fall back to the stock optimizer explicitly.
-// GaussNewtonOptimizer and DoglegOptimizer bind the same way: the same constructor body, and iterate() forwarding to
-// lmgpu_gn_iterate / lmgpu_dl_iterate (the trust radius of DoglegState travels in lmgpu_lm_state::lambda).
+// Header-only adapter a GTSAM maintainer adds next to gtsam/nonlinear/LevenbergMarquardtOptimizer.h: subclasses that override
+// the reference's own extension points and forward the hot path to liblmgpu.so:
+//   iterate()    virtual, gtsam/nonlinear/NonlinearOptimizer.h:136, LM override LevenbergMarquardtOptimizer.h:103
+//   linearize()  virtual, gtsam/nonlinear/LevenbergMarquardtOptimizer.h:113 ("can be overwritten")
+//   solve()      virtual, gtsam/nonlinear/NonlinearOptimizer.h:129-130 (precedent: IterativeLM, tests/testNonlinearOptimizer.cpp:507-528)
+//
+// This file only EXTRACTS numbers from GTSAM objects; slot assignment, bucketing, packing, the call order of the C ABI and
+// the status -> exception mapping are in lmgpu_adapter_core.hpp, which has no GTSAM include and is compiled and tested in the
+// repository (tests/cpp/adapter_harness.cpp).  This file itself cannot be compiled there (GTSAM needs CMake-generated headers,
+// DESIGN.md section 3); it is written against the reference headers cited next to each accessor.
+//
+// Two modes (constructor argument):
+//   WholeIterate (default)  iterate() = lmgpu_iterate: the whole tryLambda loop on device-resident data; values come back
+//                           to the host once per outer iteration.
+//   Piecewise               iterate() is the reference's own (LevenbergMarquardtOptimizer.cpp:273-308); only its two virtual
+//                           calls are replaced: linearize() -> lmgpu_linearize (+ download of the whitened Jacobians as
+//                           JacobianFactors, which tryLambda needs for linear.error), solve() -> lmgpu_solve at state lambda.
 #pragma once
 
 #include <gtsam/geometry/Cal3Bundler.h>
+#include <gtsam/geometry/Cal3_S2.h>
 #include <gtsam/geometry/PinholeCamera.h>
+#include <gtsam/linear/JacobianFactor.h>
 #include <gtsam/linear/linearExceptions.h>
+#include <gtsam/nonlinear/DoglegOptimizer.h>
+#include <gtsam/nonlinear/GaussNewtonOptimizer.h>
 #include <gtsam/nonlinear/LevenbergMarquardtOptimizer.h>
+#include <gtsam/nonlinear/PriorFactor.h>
 #include <gtsam/nonlinear/internal/LevenbergMarquardtState.h>
+#include <gtsam/nonlinear/internal/NonlinearOptimizerState.h>
+#include <gtsam/sam/BearingRangeFactor.h>
 #include <gtsam/slam/BetweenFactor.h>
 #include <gtsam/slam/GeneralSFMFactor.h>
+#include <gtsam/slam/ProjectionFactor.h>
 
-#include <map>
+#include <memory>
 #include <stdexcept>
-#include <tuple>
 #include <vector>
 
-#include "lmgpu.h"
+#include "lmgpu_adapter_core.hpp"
 
 namespace gtsam {
 
-class GpuLevenbergMarquardtOptimizer : public LevenbergMarquardtOptimizer {
-  typedef PinholeCamera<Cal3Bundler> Camera;
-  typedef GeneralSFMFactor<Camera, Point3> SfmFactor;
-  lmgpu_handle* h_ = nullptr;
-  std::vector<Key> slotKey_;          // slot -> key (elimination order)
-  std::vector<int32_t> slotType_;
-  lmgpu_lm_params cp_;
+namespace lmgpu_detail {
 
-  static void check(int rc, lmgpu_handle* h, Key firstKeyOf(int)) { (void)firstKeyOf; if (rc == LMGPU_OK) return;
-    throw std::runtime_error(std::string("lmgpu: ") + lmgpu_last_error(h)); }
+typedef PinholeCamera<Cal3Bundler> Camera;
+typedef GeneralSFMFactor<Camera, Point3> SfmFactor;
+typedef GenericProjectionFactor<Pose3, Point3, Cal3_S2> ProjFactor;
 
-  static void packPose3(const Pose3& p, double* v) {
-    const Matrix3 R = p.rotation().matrix();
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) v[3 * i + j] = R(i, j);
-    v[9] = p.x(); v[10] = p.y(); v[11] = p.z();
+inline void packPose3(const Pose3& p, double* v) {  // R row-major 9, t 3 (lmgpu.h, POSE3)
+  const Matrix3 R = p.rotation().matrix();
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) v[3 * i + j] = R(i, j);
+  v[9] = p.x();
+  v[10] = p.y();
+  v[11] = p.z();
+}
+inline Pose3 unpackPose3(const double* q) {
+  Matrix3 R;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) R(i, j) = q[3 * i + j];
+  return Pose3(Rot3(R), Point3(q[9], q[10], q[11]));
+}
+
+inline int32_t variableType(const Value& v) {  // gtsam/base/GenericValue.h
+  if (dynamic_cast<const GenericValue<Pose2>*>(&v)) return LMGPU_POSE2;
+  if (dynamic_cast<const GenericValue<Pose3>*>(&v)) return LMGPU_POSE3;
+  if (dynamic_cast<const GenericValue<Point3>*>(&v)) return LMGPU_POINT3;
+  if (dynamic_cast<const GenericValue<Camera>*>(&v)) return LMGPU_CAM_BUNDLER;
+  if (dynamic_cast<const GenericValue<Point2>*>(&v)) return LMGPU_POINT2;
+  throw std::invalid_argument("lmgpu adapter: unsupported variable type");
+}
+
+/// noise model -> (kind, data, m-estimator, constant); gtsam/linear/NoiseModel.h (Unit :617-660, Diagonal::invsigmas :361,
+/// Gaussian::R :263, Robust::robust / noise :705-708), gtsam/linear/LossFunctions.h (modelParameter, reweightScheme :82)
+struct Noise {
+  int32_t kind = LMGPU_N_UNIT, robust = LMGPU_ROBUST_NONE;
+  double robustK = 0.0;
+  std::vector<double> data;
+};
+inline Noise extractNoise(SharedNoiseModel model) {
+  Noise out;
+  if (auto rob = std::dynamic_pointer_cast<noiseModel::Robust>(model)) {
+    const auto est = rob->robust();
+    if (est->reweightScheme() != noiseModel::mEstimator::Base::Block)
+      throw std::invalid_argument("lmgpu adapter: only the Block reweighting scheme is bound");
+    using namespace noiseModel::mEstimator;
+    if (auto e1 = std::dynamic_pointer_cast<Huber>(est)) { out.robust = LMGPU_ROBUST_HUBER; out.robustK = e1->modelParameter(); }
+    else if (auto e2 = std::dynamic_pointer_cast<Cauchy>(est)) { out.robust = LMGPU_ROBUST_CAUCHY; out.robustK = e2->modelParameter(); }
+    else if (auto e3 = std::dynamic_pointer_cast<Tukey>(est)) { out.robust = LMGPU_ROBUST_TUKEY; out.robustK = e3->modelParameter(); }
+    else if (auto e4 = std::dynamic_pointer_cast<GemanMcClure>(est)) { out.robust = LMGPU_ROBUST_GEMAN_MCCLURE; out.robustK = e4->modelParameter(); }
+    else if (auto e5 = std::dynamic_pointer_cast<Welsch>(est)) { out.robust = LMGPU_ROBUST_WELSCH; out.robustK = e5->modelParameter(); }
+    else if (auto e6 = std::dynamic_pointer_cast<Fair>(est)) { out.robust = LMGPU_ROBUST_FAIR; out.robustK = e6->modelParameter(); }
+    else if (auto e7 = std::dynamic_pointer_cast<DCS>(est)) { out.robust = LMGPU_ROBUST_DCS; out.robustK = e7->modelParameter(); }
+    else if (auto e8 = std::dynamic_pointer_cast<L2WithDeadZone>(est)) { out.robust = LMGPU_ROBUST_L2_WITH_DEAD_ZONE; out.robustK = e8->modelParameter(); }
+    else throw std::invalid_argument("lmgpu adapter: m-estimator not bound");
+    model = rob->noise();
   }
+  if (!model || model->isUnit()) return out;
+  if (model->isConstrained()) throw std::invalid_argument("lmgpu adapter: constrained noise models take the QR path (not bound)");
+  if (auto d = std::dynamic_pointer_cast<noiseModel::Diagonal>(model)) {  // Isotropic is a Diagonal
+    out.kind = LMGPU_N_DIAG;
+    const Vector& s = d->invsigmas();
+    out.data.assign(s.data(), s.data() + s.size());
+  } else if (auto g = std::dynamic_pointer_cast<noiseModel::Gaussian>(model)) {
+    out.kind = LMGPU_N_GAUSS;
+    const Matrix R = g->R();
+    for (int r = 0; r < R.rows(); r++)
+      for (int c = 0; c < R.cols(); c++) out.data.push_back(R(r, c));
+  } else {
+    throw std::invalid_argument("lmgpu adapter: unsupported noise model");
+  }
+  return out;
+}
 
+/// one nonlinear factor -> (factor type, measurement doubles) in the packing lmgpu.h documents; false if the type is not bound
+inline bool extractFactor(const NonlinearFactor::shared_ptr& f, const Values& initial, int32_t* type, std::vector<double>* m) {
+  if (auto s = std::dynamic_pointer_cast<SfmFactor>(f)) {  // gtsam/slam/GeneralSFMFactor.h:70-206
+    *type = LMGPU_F_SFM;
+    const Cal3Bundler& K = initial.at<Camera>(s->key1()).calibration();
+    *m = {s->measured().x() - K.px(), s->measured().y() - K.py()};  // fold the constant principal point (lmgpu.h, CAM_BUNDLER)
+  } else if (auto b3 = std::dynamic_pointer_cast<BetweenFactor<Pose3>>(f)) {  // gtsam/slam/BetweenFactor.h
+    *type = LMGPU_F_BETWEEN_POSE3;
+    m->resize(12);
+    packPose3(b3->measured(), m->data());
+  } else if (auto b2 = std::dynamic_pointer_cast<BetweenFactor<Pose2>>(f)) {
+    *type = LMGPU_F_BETWEEN_POSE2;
+    *m = {b2->measured().x(), b2->measured().y(), b2->measured().theta()};
+  } else if (auto p2 = std::dynamic_pointer_cast<PriorFactor<Pose2>>(f)) {  // gtsam/nonlinear/PriorFactor.h:104 prior()
+    *type = LMGPU_F_PRIOR_POSE2;
+    *m = {p2->prior().x(), p2->prior().y(), p2->prior().theta()};
+  } else if (auto p3 = std::dynamic_pointer_cast<PriorFactor<Pose3>>(f)) {
+    *type = LMGPU_F_PRIOR_POSE3;
+    m->resize(12);
+    packPose3(p3->prior(), m->data());
+  } else if (auto pp = std::dynamic_pointer_cast<PriorFactor<Point3>>(f)) {
+    *type = LMGPU_F_PRIOR_POINT3;
+    *m = {pp->prior().x(), pp->prior().y(), pp->prior().z()};
+  } else if (auto pc = std::dynamic_pointer_cast<PriorFactor<Camera>>(f)) {  // graph.addPrior(C(0), camera, ...) SFMExample_bal.cpp:67
+    *type = LMGPU_F_PRIOR_CAM;
+    m->resize(15);
+    packPose3(pc->prior().pose(), m->data());
+    (*m)[12] = pc->prior().calibration().fx();
+    (*m)[13] = pc->prior().calibration().k1();
+    (*m)[14] = pc->prior().calibration().k2();
+  } else if (auto pr = std::dynamic_pointer_cast<ProjFactor>(f)) {  // gtsam/slam/ProjectionFactor.h:169-187
+    if (pr->throwCheirality()) {
+      // the reference lets CheiralityException escape from linearize in this configuration; the device path zeroes the factor
+      // like the default build of GeneralSFMFactor does.  Bind only the non-throwing form.
+      throw std::invalid_argument("lmgpu adapter: GenericProjectionFactor with throwCheirality is not bound");
+    }
+    const Cal3_S2& K = *pr->calibration();
+    *m = {pr->measured().x(), pr->measured().y(), K.fx(), K.fy(), K.skew(), K.px(), K.py()};
+    if (pr->body_P_sensor()) {
+      *type = LMGPU_F_PROJECTION_BPS;
+      m->resize(19);
+      packPose3(*pr->body_P_sensor(), m->data() + 7);
+    } else {
+      *type = LMGPU_F_PROJECTION;
+    }
+  } else if (auto br = std::dynamic_pointer_cast<BearingRangeFactor<Pose2, Point2>>(f)) {  // gtsam/sam/BearingRangeFactor.h:33-77
+    *type = LMGPU_F_BEARING_RANGE_2D;
+    *m = {br->measured().bearing().theta(), br->measured().range()};  // ExpressionFactor::measured :82, BearingRange.h:73-76
+  } else {
+    return false;
+  }
+  return true;
+}
+
+/// shared by the three optimizers: the device-resident problem + Values / VectorValues marshalling
+class Device {
  public:
-  GpuLevenbergMarquardtOptimizer(const NonlinearFactorGraph& graph, const Values& initial, const LevenbergMarquardtParams& params, int device = 0)
-      : LevenbergMarquardtOptimizer(graph, initial, params) {
-    // 1. variables in elimination order (params_.ordering was fixed by the base class, LevenbergMarquardtParams.h:112-117)
-    const Ordering& ordering = *params_.ordering;
-    std::map<Key, int32_t> slot;
-    std::vector<uint64_t> keys;
-    for (Key k : ordering) {
-      slot[k] = (int32_t)keys.size();
-      keys.push_back(k);
-      const Value& v = initial.at(k);
-      int32_t t;
-      if (dynamic_cast<const GenericValue<Pose2>*>(&v)) t = LMGPU_POSE2;
-      else if (dynamic_cast<const GenericValue<Pose3>*>(&v)) t = LMGPU_POSE3;
-      else if (dynamic_cast<const GenericValue<Point3>*>(&v)) t = LMGPU_POINT3;
-      else if (dynamic_cast<const GenericValue<Camera>*>(&v)) t = LMGPU_CAM_BUNDLER;
-      else if (dynamic_cast<const GenericValue<Point2>*>(&v)) t = LMGPU_POINT2;
-      else throw std::invalid_argument("GpuLevenbergMarquardtOptimizer: unsupported variable type");
-      slotType_.push_back(t);
-    }
-    slotKey_.assign(keys.begin(), keys.end());
-    lmgpu_config cfg{device, 0, 1, 0};
-    if (lmgpu_create(&cfg, &h_) != LMGPU_OK) throw std::runtime_error("lmgpu_create failed (no HIP device?)");
-    lmgpu_set_variables(h_, (int32_t)keys.size(), keys.data(), slotType_.data());
-
-    // 2. factors, bucketed by (type, noise kind); graph index = position in the NonlinearFactorGraph
-    struct B { std::vector<int32_t> gi, slots; std::vector<double> meas, noise; };
-    std::map<std::tuple<int, int, int, double>, B> buckets;  // (factor type, noise kind, m-estimator, its constant)
+  Device(const NonlinearFactorGraph& graph, const Values& initial, const Ordering& ordering, int device) : p_(device) {
+    std::vector<uint64_t> keys(ordering.begin(), ordering.end());
+    std::vector<int32_t> types;
+    types.reserve(keys.size());
+    for (Key k : ordering) types.push_back(variableType(initial.at(k)));
+    p_.setVariables(keys, types);
     for (size_t i = 0; i < graph.size(); i++) {
-      if (!graph[i]) continue;
+      if (!graph[i]) continue;  // NonlinearFactorGraph::linearize keeps null factors null (NonlinearFactorGraph.cpp:214-233)
       auto nm = std::dynamic_pointer_cast<NoiseModelFactor>(graph[i]);
-      if (!nm) throw std::invalid_argument("GpuLevenbergMarquardtOptimizer: unsupported factor");
-      // noise: Unit / Diagonal (inverse sigmas) / Gaussian (R row-major)
-      int kind = LMGPU_N_UNIT; std::vector<double> nz;
-      auto model = nm->noiseModel();
-      // noiseModel::Robust: unwrap into (m-estimator id, constant) + the Gaussian model underneath (lmgpu_add_factor_bucket_robust);
-      // only the default Block reweighting scheme is bound
-      int rkind = LMGPU_ROBUST_NONE; double rk = 0.0;
-      if (auto rob = std::dynamic_pointer_cast<noiseModel::Robust>(model)) {
-        const auto est = rob->robust();
-        if (auto e1 = std::dynamic_pointer_cast<noiseModel::mEstimator::Huber>(est)) { rkind = LMGPU_ROBUST_HUBER; rk = e1->modelParameter(); }
-        else if (auto e2 = std::dynamic_pointer_cast<noiseModel::mEstimator::Cauchy>(est)) { rkind = LMGPU_ROBUST_CAUCHY; rk = e2->modelParameter(); }
-        else if (auto e3 = std::dynamic_pointer_cast<noiseModel::mEstimator::Tukey>(est)) { rkind = LMGPU_ROBUST_TUKEY; rk = e3->modelParameter(); }
-        else if (auto e4 = std::dynamic_pointer_cast<noiseModel::mEstimator::GemanMcClure>(est)) { rkind = LMGPU_ROBUST_GEMAN_MCCLURE; rk = e4->modelParameter(); }
-        else if (auto e5 = std::dynamic_pointer_cast<noiseModel::mEstimator::Welsch>(est)) { rkind = LMGPU_ROBUST_WELSCH; rk = e5->modelParameter(); }
-        else if (auto e6 = std::dynamic_pointer_cast<noiseModel::mEstimator::Fair>(est)) { rkind = LMGPU_ROBUST_FAIR; rk = e6->modelParameter(); }
-        else if (auto e7 = std::dynamic_pointer_cast<noiseModel::mEstimator::DCS>(est)) { rkind = LMGPU_ROBUST_DCS; rk = e7->modelParameter(); }
-        else if (auto e8 = std::dynamic_pointer_cast<noiseModel::mEstimator::L2WithDeadZone>(est)) { rkind = LMGPU_ROBUST_L2_WITH_DEAD_ZONE; rk = e8->modelParameter(); }
-        else throw std::invalid_argument("GpuLevenbergMarquardtOptimizer: m-estimator not bound");
-        model = rob->noise();
-      }
-      if (model && !model->isUnit()) {
-        if (auto d = std::dynamic_pointer_cast<noiseModel::Diagonal>(model)) { kind = LMGPU_N_DIAG; const Vector s = d->invsigmas(); nz.assign(s.data(), s.data() + s.size()); }
-        else if (auto g = std::dynamic_pointer_cast<noiseModel::Gaussian>(model)) { kind = LMGPU_N_GAUSS; const Matrix R = g->R(); for (int r = 0; r < R.rows(); r++) for (int c = 0; c < R.cols(); c++) nz.push_back(R(r, c)); }
-        else throw std::invalid_argument("GpuLevenbergMarquardtOptimizer: unsupported noise model (constrained)");
-      }
-      int type; std::vector<double> m;
-      if (auto f = std::dynamic_pointer_cast<SfmFactor>(graph[i])) {
-        type = LMGPU_F_SFM;
-        const Cal3Bundler& K = initial.at<Camera>(f->key1()).calibration();
-        m = {f->measured().x() - K.px(), f->measured().y() - K.py()};  // fold the constant principal point (lmgpu.h)
-      } else if (auto f3 = std::dynamic_pointer_cast<BetweenFactor<Pose3>>(graph[i])) {
-        type = LMGPU_F_BETWEEN_POSE3; m.resize(12); packPose3(f3->measured(), m.data());
-      } else if (auto f2 = std::dynamic_pointer_cast<BetweenFactor<Pose2>>(graph[i])) {
-        type = LMGPU_F_BETWEEN_POSE2; m = {f2->measured().x(), f2->measured().y(), f2->measured().theta()};
-      } else {
-        // PriorFactor<T>, GenericProjectionFactor<Pose3,Point3,Cal3_S2>, BearingRangeFactor<Pose2,Point2> (measured().bearing().theta(),
-        // measured().range()): same pattern (measurement packing in lmgpu.h)
-        throw std::invalid_argument("GpuLevenbergMarquardtOptimizer: factor type not bound in this sketch");
-      }
-      B& b = buckets[std::make_tuple(type, kind, rkind, rk)];
-      b.gi.push_back((int32_t)i);
-      for (Key k : nm->keys()) b.slots.push_back(slot.at(k));
-      b.meas.insert(b.meas.end(), m.begin(), m.end());
-      b.noise.insert(b.noise.end(), nz.begin(), nz.end());
+      if (!nm) throw std::invalid_argument("lmgpu adapter: only NoiseModelFactors are bound");
+      int32_t type;
+      std::vector<double> meas;
+      if (!extractFactor(graph[i], initial, &type, &meas)) throw std::invalid_argument("lmgpu adapter: factor type not bound");
+      const Noise nz = extractNoise(nm->noiseModel());
+      std::vector<uint64_t> fk(nm->keys().begin(), nm->keys().end());
+      p_.addFactor(type, (int32_t)i, fk.data(), meas.data(), nz.kind, nz.data.empty() ? nullptr : nz.data.data(), nz.robust, nz.robustK);
     }
-    for (auto& kv : buckets)
-      if (lmgpu_add_factor_bucket_robust(h_, std::get<0>(kv.first), (int32_t)kv.second.gi.size(), kv.second.gi.data(), kv.second.slots.data(),
-                                         kv.second.meas.data(), std::get<1>(kv.first), kv.second.noise.empty() ? nullptr : kv.second.noise.data(),
-                                         std::get<2>(kv.first), std::get<3>(kv.first)) != LMGPU_OK)
-        throw std::runtime_error(lmgpu_last_error(h_));
-    if (lmgpu_finalize_structure(h_) != LMGPU_OK) throw std::runtime_error(lmgpu_last_error(h_));
-    uploadValues(initial);
-    cp_ = lmgpu_lm_params{(int32_t)params.maxIterations, params.relativeErrorTol, params.absoluteErrorTol, params.errorTol, params.lambdaInitial,
-                          params.lambdaFactor, params.lambdaUpperBound, params.lambdaLowerBound, params.minModelFidelity,
-                          params.diagonalDamping, params.useFixedLambdaFactor, params.minDiagonal, params.maxDiagonal};
-  }
-  ~GpuLevenbergMarquardtOptimizer() override { if (h_) lmgpu_destroy(h_); }
-
-  /// drop-in for LevenbergMarquardtOptimizer::iterate() (LevenbergMarquardtOptimizer.cpp:273-308)
-  GaussianFactorGraph::shared_ptr iterate() override {
-    auto cur = static_cast<const internal::LevenbergMarquardtState*>(state_.get());
-    lmgpu_lm_state st{cur->error, cur->lambda, cur->currentFactor, (int32_t)cur->iterations, cur->totalNumberInnerIterations};
-    const int rc = lmgpu_iterate(h_, &cp_, &st);
-    if (rc != LMGPU_OK) throw std::runtime_error(lmgpu_last_error(h_));
-    // new state: values come back from the device only when the caller asks for them (values()) — here eagerly:
-    state_.reset(new internal::LevenbergMarquardtState(downloadValues(cur->values), st.error, st.lambda, st.currentFactor,
-                                                       (unsigned)st.iterations, (unsigned)st.totalNumberInnerIterations));
-    return GaussianFactorGraph::shared_ptr();  // in-tree callers ignore the returned linear graph
+    p_.finalize();
+    upload(initial);
   }
 
-  /// drop-in for NonlinearOptimizer::solve() (NonlinearOptimizer.cpp:132-178) on the last linearization
-  VectorValues solveDamped(double lambda) {
-    std::vector<double> d((size_t)lmgpu_total_dim(h_));
-    double e0, e1;
-    const int rc = lmgpu_solve(h_, lambda, params_.diagonalDamping, params_.minDiagonal, params_.maxDiagonal, d.data(), &e0, &e1);
-    if (rc == LMGPU_INDETERMINATE) throw IndeterminantLinearSystemException(slotKey_[lmgpu_last_failed_slot(h_)]);
-    if (rc != LMGPU_OK) throw std::runtime_error(lmgpu_last_error(h_));
-    VectorValues out; size_t o = 0;
-    static const int dim[4] = {3, 6, 3, 9};
-    for (size_t s = 0; s < slotKey_.size(); s++) { out.insert(slotKey_[s], Eigen::Map<Vector>(d.data() + o, dim[slotType_[s]])); o += dim[slotType_[s]]; }
+  lmgpu_adapter::Problem& problem() { return p_; }
+  const lmgpu_adapter::Problem& problem() const { return p_; }
+
+  void upload(const Values& v) const {
+    std::vector<double> packed((size_t)p_.totalStore());
+    for (size_t s = 0; s < p_.numVariables(); s++) {
+      const Key k = p_.keyOfSlot((int)s);
+      double* o = &packed[p_.valueOffset((int)s)];
+      switch (p_.typeOfSlot((int)s)) {
+        case LMGPU_POSE2: { const Pose2& q = v.at<Pose2>(k); o[0] = q.x(); o[1] = q.y(); o[2] = q.theta(); break; }
+        case LMGPU_POSE3: packPose3(v.at<Pose3>(k), o); break;
+        case LMGPU_POINT3: { const Point3& q = v.at<Point3>(k); o[0] = q.x(); o[1] = q.y(); o[2] = q.z(); break; }
+        case LMGPU_POINT2: { const Point2& q = v.at<Point2>(k); o[0] = q.x(); o[1] = q.y(); break; }
+        default: {
+          const Camera& c = v.at<Camera>(k);
+          packPose3(c.pose(), o);
+          o[12] = c.calibration().fx(); o[13] = c.calibration().k1(); o[14] = c.calibration().k2();
+        }
+      }
+    }
+    const_cast<lmgpu_adapter::Problem&>(p_).setValues(packed);
+  }
+
+  /// `like` supplies what does not travel: the constant principal point of every Cal3Bundler
+  Values download(const Values& like) const {
+    const std::vector<double> packed = p_.getValues();
+    Values out;
+    for (size_t s = 0; s < p_.numVariables(); s++) {
+      const Key k = p_.keyOfSlot((int)s);
+      const double* q = &packed[p_.valueOffset((int)s)];
+      switch (p_.typeOfSlot((int)s)) {
+        case LMGPU_POSE2: out.insert(k, Pose2(q[0], q[1], q[2])); break;
+        case LMGPU_POSE3: out.insert(k, unpackPose3(q)); break;
+        case LMGPU_POINT3: out.insert(k, Point3(q[0], q[1], q[2])); break;
+        case LMGPU_POINT2: out.insert(k, Point2(q[0], q[1])); break;
+        default: {
+          const Cal3Bundler& K0 = like.at<Camera>(k).calibration();
+          out.insert(k, Camera(unpackPose3(q), Cal3Bundler(q[12], q[13], q[14], K0.px(), K0.py())));
+        }
+      }
+    }
+    return out;
+  }
+
+  VectorValues toVectorValues(const std::vector<double>& packed) const {
+    VectorValues out;
+    for (size_t s = 0; s < p_.numVariables(); s++) {
+      const int d = lmgpu_adapter::varDim(p_.typeOfSlot((int)s));
+      out.insert(p_.keyOfSlot((int)s), Vector(Eigen::Map<const Vector>(packed.data() + p_.deltaOffset((int)s), d)));
+    }
+    return out;
+  }
+
+  /// lmgpu_solve with the reference's exception: IndeterminantLinearSystemException(first frontal key of the failing clique)
+  VectorValues solve(double lambda, const LevenbergMarquardtParams* lm) const {
+    try {
+      const lmgpu_adapter::SolveResult r = lm ? p_.solve(lambda, lm->diagonalDamping, lm->minDiagonal, lm->maxDiagonal) : p_.solve(lambda, false, 0.0, 0.0);
+      return toVectorValues(r.delta);
+    } catch (const lmgpu_adapter::Indeterminate& e) {
+      throw IndeterminantLinearSystemException(e.key);
+    }
+  }
+
+  /// the device-resident linearization as the GaussianFactorGraph NonlinearFactorGraph::linearize returns: one JacobianFactor
+  /// per factor, already whitened (unit noise model), index-preserving
+  GaussianFactorGraph::shared_ptr downloadLinearGraph(const NonlinearFactorGraph& graph) const {
+    auto out = std::make_shared<GaussianFactorGraph>();
+    out->reserve(graph.size());
+    for (size_t i = 0; i < graph.size(); i++) {
+      if (!graph[i]) { out->push_back(GaussianFactor::shared_ptr()); continue; }
+      int32_t rows = 0, cols = 0;
+      const std::vector<double> Ab = p_.jacobian((int32_t)i, &rows, &cols);
+      Eigen::Map<const Matrix> M(Ab.data(), rows, cols);  // column-major
+      std::vector<std::pair<Key, Matrix>> terms;
+      int c0 = 0;
+      for (Key k : graph[i]->keys()) {
+        const int d = lmgpu_adapter::varDim(p_.typeOfSlot(p_.slotOf(k)));
+        terms.emplace_back(k, M.middleCols(c0, d));
+        c0 += d;
+      }
+      out->push_back(std::make_shared<JacobianFactor>(terms, Vector(M.col(cols - 1))));
+    }
     return out;
   }
 
  private:
-  void uploadValues(const Values& v) {
-    std::vector<double> packed((size_t)lmgpu_total_store(h_)); size_t o = 0;
-    for (size_t s = 0; s < slotKey_.size(); s++) {
-      const Key k = slotKey_[s];
-      switch (slotType_[s]) {
-        case LMGPU_POSE2: { const Pose2& p = v.at<Pose2>(k); packed[o] = p.x(); packed[o + 1] = p.y(); packed[o + 2] = p.theta(); o += 3; break; }
-        case LMGPU_POSE3: packPose3(v.at<Pose3>(k), &packed[o]); o += 12; break;
-        case LMGPU_POINT3: { const Point3& p = v.at<Point3>(k); packed[o] = p.x(); packed[o + 1] = p.y(); packed[o + 2] = p.z(); o += 3; break; }
-        case LMGPU_POINT2: { const Point2& p = v.at<Point2>(k); packed[o] = p.x(); packed[o + 1] = p.y(); o += 2; break; }
-        default: { const Camera& c = v.at<Camera>(k); packPose3(c.pose(), &packed[o]); packed[o + 12] = c.calibration().fx(); packed[o + 13] = c.calibration().k1(); packed[o + 14] = c.calibration().k2(); o += 15; }
-      }
+  lmgpu_adapter::Problem p_;
+};
+
+inline lmgpu_lm_params toC(const LevenbergMarquardtParams& p) {  // gtsam/nonlinear/LevenbergMarquardtParams.h:35-157
+  return lmgpu_lm_params{(int32_t)p.maxIterations, p.relativeErrorTol, p.absoluteErrorTol, p.errorTol, p.lambdaInitial, p.lambdaFactor,
+                         p.lambdaUpperBound, p.lambdaLowerBound, p.minModelFidelity, p.diagonalDamping ? 1 : 0, p.useFixedLambdaFactor ? 1 : 0,
+                         p.minDiagonal, p.maxDiagonal};
+}
+
+}  // namespace lmgpu_detail
+
+/// drop-in for LevenbergMarquardtOptimizer: same constructor arguments, same optimize() / iterate() / lambda() / values().
+/// Unsupported factors, constrained noise, Scalar-scheme or custom m-estimators make the constructor throw
+/// std::invalid_argument, so that a caller keeps the stock optimizer explicitly — there is no silent fallback.
+class GpuLevenbergMarquardtOptimizer : public LevenbergMarquardtOptimizer {
+ public:
+  enum Mode { WholeIterate, Piecewise };
+
+  GpuLevenbergMarquardtOptimizer(const NonlinearFactorGraph& graph, const Values& initial,
+                                 const LevenbergMarquardtParams& params = LevenbergMarquardtParams(), int device = 0, Mode mode = WholeIterate)
+      : LevenbergMarquardtOptimizer(graph, initial, params),  // fixes params_.ordering (LevenbergMarquardtParams.h:112-117), initial error
+        dev_(graph, initial, *params_.ordering, device), cp_(lmgpu_detail::toC(params_)), mode_(mode) {}
+
+  /// LevenbergMarquardtOptimizer::iterate() (LevenbergMarquardtOptimizer.cpp:273-308)
+  GaussianFactorGraph::shared_ptr iterate() override {
+    if (mode_ == Piecewise) return LevenbergMarquardtOptimizer::iterate();  // calls linearize() / solve() below
+    auto cur = static_cast<const internal::LevenbergMarquardtState*>(state_.get());
+    lmgpu_lm_state st{cur->error, cur->lambda, cur->currentFactor, (int32_t)cur->iterations, cur->totalNumberInnerIterations};
+    try {
+      dev_.problem().iterate(cp_, &st);
+    } catch (const lmgpu_adapter::Indeterminate& e) {
+      throw IndeterminantLinearSystemException(e.key);
     }
-    if (lmgpu_set_values(h_, packed.data()) != LMGPU_OK) throw std::runtime_error(lmgpu_last_error(h_));
+    state_.reset(new internal::LevenbergMarquardtState(dev_.download(cur->values), st.error, st.lambda, st.currentFactor,
+                                                       (unsigned)st.iterations, (unsigned)st.totalNumberInnerIterations));
+    // in-tree callers ignore the returned linear graph; lastLinearGraph() downloads it on request
+    return std::make_shared<GaussianFactorGraph>();
   }
-  Values downloadValues(const Values& like) {
-    std::vector<double> packed((size_t)lmgpu_total_store(h_));
-    if (lmgpu_get_values(h_, packed.data()) != LMGPU_OK) throw std::runtime_error(lmgpu_last_error(h_));
-    Values out; size_t o = 0;
-    for (size_t s = 0; s < slotKey_.size(); s++) {
-      const Key k = slotKey_[s]; const double* p = &packed[o];
-      auto pose3 = [&](const double* q) { Matrix3 R; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R(i, j) = q[3 * i + j]; return Pose3(Rot3(R), Point3(q[9], q[10], q[11])); };
-      switch (slotType_[s]) {
-        case LMGPU_POSE2: out.insert(k, Pose2(p[0], p[1], p[2])); o += 3; break;
-        case LMGPU_POSE3: out.insert(k, pose3(p)); o += 12; break;
-        case LMGPU_POINT3: out.insert(k, Point3(p[0], p[1], p[2])); o += 3; break;
-        case LMGPU_POINT2: out.insert(k, Point2(p[0], p[1])); o += 2; break;
-        default: { const Cal3Bundler& K0 = like.at<Camera>(k).calibration(); out.insert(k, Camera(pose3(p), Cal3Bundler(p[12], p[13], p[14], K0.px(), K0.py()))); o += 15; }
-      }
+
+  /// LevenbergMarquardtOptimizer::linearize() (LevenbergMarquardtOptimizer.h:113): graph_.linearize(state_->values) on the device
+  GaussianFactorGraph::shared_ptr linearize() const override {
+    dev_.upload(state_->values);
+    dev_.problem().linearize();
+    return dev_.downloadLinearGraph(graph_);
+  }
+
+  /// NonlinearOptimizer::solve() (NonlinearOptimizer.h:129-130).  tryLambda hands over buildDampedSystem(linear) — the
+  /// linearization lmgpu_linearize left on the device plus lambda priors — so the damped system is rebuilt on the device from
+  /// the state's lambda instead of being parsed out of `damped`.
+  VectorValues solve(const GaussianFactorGraph& /*damped*/, const NonlinearOptimizerParams& /*params*/) const override {
+    return dev_.solve(static_cast<const internal::LevenbergMarquardtState*>(state_.get())->lambda, &params_);
+  }
+
+  /// the whitened Jacobians of the last linearization as a GaussianFactorGraph (what iterate() returns in the reference)
+  GaussianFactorGraph::shared_ptr lastLinearGraph() const { return dev_.downloadLinearGraph(graph_); }
+
+ private:
+  mutable lmgpu_detail::Device dev_;
+  lmgpu_lm_params cp_;
+  Mode mode_;
+};
+
+/// drop-in for GaussNewtonOptimizer (gtsam/nonlinear/GaussNewtonOptimizer.cpp:44-66): iterate() = lmgpu_gn_iterate
+class GpuGaussNewtonOptimizer : public GaussNewtonOptimizer {
+ public:
+  GpuGaussNewtonOptimizer(const NonlinearFactorGraph& graph, const Values& initial, const GaussNewtonParams& params = GaussNewtonParams(),
+                          int device = 0)
+      : GaussNewtonOptimizer(graph, initial, params), dev_(graph, initial, *params_.ordering, device) {}
+
+  GaussianFactorGraph::shared_ptr iterate() override {
+    lmgpu_lm_state st{state_->error, 0.0, 0.0, (int32_t)state_->iterations, 0};
+    try {
+      dev_.problem().gnIterate(&st);
+    } catch (const lmgpu_adapter::Indeterminate& e) {
+      throw IndeterminantLinearSystemException(e.key);
     }
-    return out;
+    state_.reset(new internal::NonlinearOptimizerState(dev_.download(state_->values), st.error, (unsigned)st.iterations));
+    return std::make_shared<GaussianFactorGraph>();
   }
+
+  VectorValues solve(const GaussianFactorGraph& /*linear*/, const NonlinearOptimizerParams& /*params*/) const override {
+    return dev_.solve(0.0, nullptr);
+  }
+
+ private:
+  mutable lmgpu_detail::Device dev_;
+};
+
+/// DoglegOptimizer's state type (internal::DoglegState) is private to DoglegOptimizer.cpp:54-62, so a subclass cannot replace
+/// state_; the Dogleg binding is therefore a NonlinearOptimizer of its own with the same interface (getDelta(), iterate()).
+class GpuDoglegOptimizer : public NonlinearOptimizer {
+  struct State : public internal::NonlinearOptimizerState {
+    double delta;
+    State(const Values& v, double e, double d, unsigned it = 0) : internal::NonlinearOptimizerState(v, e, it), delta(d) {}
+  };
+
+ public:
+  GpuDoglegOptimizer(const NonlinearFactorGraph& graph, const Values& initial, const DoglegParams& params = DoglegParams(), int device = 0)
+      : NonlinearOptimizer(graph, std::unique_ptr<internal::NonlinearOptimizerState>(new State(initial, graph.error(initial), params.deltaInitial))),
+        params_(params) {
+    if (!params_.ordering) params_.ordering = Ordering::Create(params_.orderingType, graph);  // DoglegOptimizer.cpp:127-131
+    dev_.reset(new lmgpu_detail::Device(graph, initial, *params_.ordering, device));
+  }
+  double getDelta() const { return static_cast<const State*>(state_.get())->delta; }
+
+  GaussianFactorGraph::shared_ptr iterate() override {  // DoglegOptimizer.cpp:84-126
+    lmgpu_lm_state st{state_->error, getDelta(), 0.0, (int32_t)state_->iterations, 0};
+    try {
+      dev_->problem().dlIterate(&st);  // trust radius travels in lambda (lmgpu.h)
+    } catch (const lmgpu_adapter::Indeterminate& e) {
+      throw IndeterminantLinearSystemException(e.key);
+    }
+    state_.reset(new State(dev_->download(state_->values), st.error, st.lambda, (unsigned)st.iterations));
+    return std::make_shared<GaussianFactorGraph>();
+  }
+
+ protected:
+  const NonlinearOptimizerParams& _params() const override { return params_; }
+  DoglegParams params_;
+  std::unique_ptr<lmgpu_detail::Device> dev_;
 };
 
 }  // namespace gtsam

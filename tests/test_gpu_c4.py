@@ -1,0 +1,90 @@
+"""The headline workload at ITS size and under BOTH orderings BASELINE.json configs[3] can mean (METIS as named there, Schur as
+timing/timeSFMBAL.h:64-96 uses): synthetic BAL 1 000 cameras / 100 000 points / 1 000 002 factors, seed 42, one
+LevenbergMarquardtOptimizer::iterate() on the GPU against a committed fixture the CPU oracle produced ONCE in the build
+container (tools/make_c4_fixture.py; the oracle needs minutes and gigabytes at this size, so it does not run on the GPU box).
+The same checks at 1/10 scale (100 cameras / 10 000 points) where the fixture can also be cross-checked live.
+
+Tolerances (north_star): variable ordering / indexing bit-exact (clique count, key order of the root and of sampled point
+cliques), final cost and update vector within 1e-6 relative."""
+import os
+
+import numpy as np
+import pytest
+
+from gtsam_personal_amd import LevenbergMarquardtOptimizer, LevenbergMarquardtParams
+from gtsam_personal_amd.synthetic import make_bal
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+CASES = {"bal100_seed42": (100, 10000, 10, 42), "c4_seed42": (1000, 100000, 10, 42)}
+
+
+def fixture_ordering(fx, schur):
+    """the ordering a fixture was made with: Schur = the generator's own (points then cameras); otherwise the permutation the
+    fixture carries (ordering = sorted(keys)[perm])"""
+    if "ordering_perm" not in fx:
+        return list(schur)
+    srt = np.sort(np.array(list(schur), dtype=np.uint64))
+    return [int(k) for k in srt[fx["ordering_perm"]]]
+
+
+def rel(a, b):
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+@pytest.mark.parametrize("ordering_name", ["schur", "metis"])
+@pytest.mark.parametrize("tag", ["bal100_seed42", "c4_seed42"])
+def test_headline_workload_matches_oracle_fixture(tag, ordering_name):
+    fx = np.load(os.path.join(GOLD, f"{tag}_{ordering_name}.npz"))
+    n_cam, n_pt, obs, seed = CASES[tag]
+    graph, initial, _, schur = make_bal(n_cam, n_pt, obs, seed=seed)
+    ordering = fixture_ordering(fx, schur)
+    params = LevenbergMarquardtParams()
+    opt = LevenbergMarquardtOptimizer(graph, initial, ordering, params, device=0)
+    # ---- structure: bit-exact
+    assert opt.num_fronts() == int(fx["num_cliques"])
+    root = opt.num_fronts() - 1
+    info = opt.front_info(root)
+    assert (info["nf"], info["n"]) == tuple(int(x) for x in fx["root_shape"])
+    rkeys, _ = opt.front(root, numeric=False)
+    assert rkeys == [int(k) for k in fx["root_keys"]]
+    for j, ci in enumerate(fx["leaf_ids"].tolist()):
+        fk, _ = opt.front(ci, numeric=False)
+        assert fk == [int(k) for k in fx[f"leaf{j}_keys"]], ci
+        meta = fx[f"leaf{j}_meta"]
+        fi = opt.front_info(ci)
+        assert fi["n_frontal_keys"] == int(meta[1]) and fi["parent"] == int(meta[2])
+    # ---- initial error
+    e0 = opt.error()
+    assert abs(e0 - float(fx["error_initial"])) <= 1e-9 * float(fx["error_initial"])
+    # ---- the first damped solve (lambdaInitial): update vector, [R S d]
+    opt.linearize()
+    dk, d, l0, l1 = opt.solve(params.lambdaInitial)
+    assert abs(np.linalg.norm(d) - float(fx["delta_norm"])) <= 1e-6 * float(fx["delta_norm"])
+    cam = np.stack([dk[int(k)] for k in fx["cam_keys"]])
+    assert rel(cam, fx["cam_delta"]) < 1e-6, rel(cam, fx["cam_delta"])
+    pts = np.stack([dk[int(k)] for k in fx["pt_keys"]])
+    assert rel(pts, fx["pt_delta"]) < 1e-6, rel(pts, fx["pt_delta"])
+    assert np.allclose(pts, fx["pt_delta"], rtol=1e-5, atol=1e-6 * np.abs(fx["pt_delta"]).max())
+    _, R = opt.front(root)
+    got = R[fx["root_rows"], fx["root_cols"]]
+    want = fx["root_vals"]
+    scale = np.abs(fx["root_diag"])[fx["root_rows"]]  # an entry of row r is judged against the size of that row's pivot
+    assert (np.abs(got - want) <= 1e-6 * np.maximum(np.abs(want), scale)).all(), float(np.max(np.abs(got - want) / np.maximum(np.abs(want), scale)))
+    assert np.allclose(np.diag(R[:, :info["nf"]]), fx["root_diag"], rtol=1e-6, atol=0)
+    del R
+    for j, ci in enumerate(fx["leaf_ids"].tolist()):
+        _, Rl = opt.front(ci)
+        want = fx[f"leaf{j}_rsd"]
+        assert np.allclose(Rl, want, rtol=1e-6, atol=1e-7 * max(1.0, np.abs(want).max())), ci
+    # ---- the whole iterate(): accepted at the first lambda, same new error and lambda
+    opt.iterate()
+    assert opt.iterations() == int(fx["iterations"]) and opt.getInnerIterations() == int(fx["inner"])
+    assert abs(opt.error() - float(fx["error_after"])) <= 1e-6 * float(fx["error_after"])
+    assert abs(opt.lambda_() - float(fx["lambda_after"])) <= 1e-12 * float(fx["lambda_after"])
+    # the quadratic model the accept test uses: linear error at delta is what the trace's model fidelity implies
+    tr = fx["trace"][-1]
+    fidelity = (e0 - opt.error()) / (l0 - l1)
+    assert abs(fidelity - tr[2]) <= 1e-6 * abs(tr[2])
+    opt.close()
