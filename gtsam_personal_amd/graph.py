@@ -305,6 +305,21 @@ class NonlinearFactorGraph:
         self._n += n
         self._final = None
 
+    def push_back(self, other: "NonlinearFactorGraph"):
+        """FactorGraph::push_back(const FactorGraph&) (gtsam/inference/FactorGraph.h): append the factors of `other` in its graph order"""
+        rec = [None] * other.size()
+        for ftype, _, gi, keys, meas, _, models in other.buckets():
+            for i, g in enumerate(gi.tolist()):
+                rec[g] = (ftype, keys[i], meas[i], models[i])
+        for ftype, keys, meas, model in rec:
+            self._add(ftype, [keys], [meas], model)
+
+    def resize(self, n):
+        """FactorGraph::resize(0) as the incremental examples use it to start the next batch of new factors"""
+        if n != 0:
+            raise NotImplementedError("only resize(0)")
+        self.__init__()
+
     # -- reference-named adders (single factor or a batch with one shared model)
     def add_GeneralSFMFactor(self, measured, model, cameraKey, landmarkKey):
         """GeneralSFMFactor<PinholeCamera<Cal3Bundler>, Point3>(measured, model, cameraKey, landmarkKey)"""

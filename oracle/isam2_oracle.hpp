@@ -1,0 +1,415 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (included by lm_oracle.cpp; see its header).
+//
+// CPU restatement of the reference's incremental smoother for the path of BASELINE config 5 (ISAM2 with Gauss-Newton
+// optimisation, Cholesky factorisation, COLAMD ordering): pointer-based and literal like the reference.
+//   ISAM2::update                      gtsam/nonlinear/ISAM2.cpp:404-480      (UpdateImpl: gtsam/nonlinear/ISAM2-impl.h:113-508)
+//   ISAM2::recalculate                 gtsam/nonlinear/ISAM2.cpp:117-175      (batch :178-247, incremental :250-362)
+//   ISAM2::relinearizeAffectedFactors  gtsam/nonlinear/ISAM2.cpp:66-114
+//   BayesTree::removeTop / removePath / removeClique   gtsam/inference/BayesTree-inst.h:440-508
+//   orphan subtrees as symbolic factors  gtsam/inference/BayesTree.h:283-304, ClusterTree-inst.h:228-236, Scatter.cpp:53-55
+//   Ordering::ColamdConstrained        gtsam/inference/Ordering.cpp:50-125, 193-210 (ccolamd itself through a callback: the
+//                                       test harness binds it to oracle/_ref/libccolamd_ref.so = the reference's own C source)
+//   ISAM2::updateDelta / calculateEstimate  gtsam/nonlinear/ISAM2.cpp:701-781; wildfire back-substitution
+//                                       gtsam/nonlinear/ISAM2Clique.cpp:56-77, 151-268, ISAM2-impl.cpp:34-77
+// Not restated (not reached by the configs): Dogleg optimisation, QR, factor removal, marginalizeLeaves, fixed variables,
+// partial relinearization check, per-type threshold maps.
+#pragma once
+
+namespace orc {
+
+// int cb(n_rows, n_cols, col_ptr[n_cols + 1], row_idx[nnz], cmember[n_cols], perm_out[n_cols]): 1 on success.  The callee calls
+// ccolamd with GTSAM's knobs (dense row / column detection off, Ordering.cpp:94-97).
+typedef int (*ccolamd_fn)(int, int, const int*, const int*, const int*, int*);
+
+struct IClique {
+  std::vector<Key> keys;  // frontals then separator (Scatter order)
+  std::vector<int> dims;
+  int nFrontal = 0;
+  Mat RSd;         // conditional_
+  GFactor cached;  // cachedFactor_: the separator Hessian this clique passed to its parent (ISAM2Clique.cpp:35-46)
+  std::vector<std::shared_ptr<IClique>> children;
+  std::weak_ptr<IClique> parent;
+};
+typedef std::shared_ptr<IClique> ICliquePtr;
+
+struct ISAM2Result {
+  int variablesRelinearized = 0, variablesReeliminated = 0, factorsRecalculated = 0, cliques = 0, batch = 0;
+};
+
+// one entry of the linear graph handed to the elimination: a (cached) linear factor, or an orphan subtree standing in as a
+// symbolic factor on its separator keys (BayesTreeOrphanWrapper)
+struct IFactor {
+  const GFactor* g = nullptr;
+  ICliquePtr orphan;
+  std::vector<Key> keys;
+};
+
+struct ISAM2 {
+  // ISAM2Params (gtsam/nonlinear/ISAM2Params.h:133-246): GaussNewton(wildfireThreshold), relinearizeThreshold (double),
+  // relinearizeSkip, enableRelinearization; cacheLinearizedFactors = true
+  double wildfireThreshold = 0.001, relinearizeThreshold = 0.1;
+  int relinearizeSkip = 10;
+  bool enableRelinearization = true;
+  ccolamd_fn ccolamd = nullptr;
+
+  Values theta;
+  VariableIndex variableIndex;
+  VectorValues delta;
+  std::set<Key> deltaReplacedMask;
+  std::vector<Factor> nonlinearFactors;
+  std::vector<GFactor> linearFactors;
+  std::vector<ICliquePtr> roots;
+  std::map<Key, ICliquePtr> nodes;
+  int update_count = 0;
+  // pending input of the next update()
+  std::vector<Factor> newFactors;
+  Values newTheta;
+  ISAM2Result last;
+};
+
+// Ordering::ColamdConstrained(variableIndex, groups) gtsam/inference/Ordering.cpp:193-210 -> :50-125
+static std::vector<Key> colamd_constrained(const ISAM2& S, const VariableIndex& vi, size_t nFactors, const std::map<Key, int>& groups) {
+  const size_t nVars = vi.size();
+  if (nVars == 0) return {};
+  if (nVars == 1) return {vi.begin()->first};
+  std::vector<int> cmember(nVars, 0), p(nVars + 1, 0), A;
+  std::vector<Key> keys(nVars);
+  std::map<Key, size_t> keyIndices;
+  size_t index = 0;
+  for (auto& kf : vi) {
+    for (size_t f : kf.second) A.push_back((int)f);
+    p[index + 1] = (int)A.size();
+    keys[index] = kf.first;
+    keyIndices[kf.first] = index;
+    ++index;
+  }
+  for (auto& g : groups) cmember[keyIndices.at(g.first)] = g.second;
+  std::vector<int> perm(nVars);
+  if (!S.ccolamd || S.ccolamd((int)nFactors, (int)nVars, p.data(), A.data(), cmember.data(), perm.data()) != 1)
+    throw std::runtime_error("ccolamd failed");
+  std::vector<Key> result(nVars);
+  for (size_t j = 0; j < nVars; ++j) result[j] = keys[perm[j]];
+  return result;
+}
+
+// BayesTree::removeClique gtsam/inference/BayesTree-inst.h:440-460
+static void isam2_remove_clique(ISAM2& S, ICliquePtr clique) {
+  ICliquePtr parent = clique->parent.lock();
+  if (!parent) {
+    auto it = std::find(S.roots.begin(), S.roots.end(), clique);
+    if (it != S.roots.end()) S.roots.erase(it);
+  } else {
+    auto it = std::find(parent->children.begin(), parent->children.end(), clique);
+    assert(it != parent->children.end());
+    parent->children.erase(it);
+  }
+  for (auto& child : clique->children) child->parent.reset();
+  for (int k = 0; k < clique->nFrontal; k++) S.nodes.erase(clique->keys[k]);
+}
+
+// BayesTree::removePath :464-486
+static void isam2_remove_path(ISAM2& S, ICliquePtr clique, std::vector<ICliquePtr>* bn, std::list<ICliquePtr>* orphans) {
+  if (!clique) return;
+  orphans->remove(clique);
+  ICliquePtr parent = clique->parent.lock();  // taken before removeClique, which does not touch the clique's own parent pointer
+  isam2_remove_clique(S, clique);
+  isam2_remove_path(S, parent, bn, orphans);
+  orphans->insert(orphans->begin(), clique->children.begin(), clique->children.end());
+  clique->children.clear();
+  bn->push_back(clique);
+}
+
+// ISAM2Clique::findAll gtsam/nonlinear/ISAM2Clique.cpp:304-325
+static void isam2_find_all(const ICliquePtr& c, const std::set<Key>& markedMask, std::set<Key>* keys) {
+  bool found = false;
+  for (size_t k = c->nFrontal; k < c->keys.size(); k++)
+    if (markedMask.count(c->keys[k])) {
+      found = true;
+      break;
+    }
+  if (found)
+    for (int k = 0; k < c->nFrontal; k++) keys->insert(c->keys[k]);
+  for (auto& child : c->children) isam2_find_all(child, markedMask, keys);
+}
+
+// GaussianConditional::solve for one clique (gtsam/linear/GaussianConditional.cpp): x_F = R^-1 (d - S x_S)
+static std::vector<double> isam2_solve_clique(const IClique& c, const VectorValues& x) {
+  const int nf = c.RSd.r, n = c.RSd.c;
+  std::vector<double> rhs(nf);
+  for (int i = 0; i < nf; i++) rhs[i] = c.RSd(i, n - 1);
+  int col = nf;
+  for (size_t k = c.nFrontal; k < c.keys.size(); k++) {
+    const auto& xs = x.at(c.keys[k]);
+    for (int d = 0; d < c.dims[k]; d++, col++)
+      for (int i = 0; i < nf; i++) rhs[i] -= c.RSd(i, col) * xs[d];
+  }
+  for (int i = nf - 1; i >= 0; i--) {
+    double s = rhs[i];
+    for (int j = i + 1; j < nf; j++) s -= c.RSd(i, j) * rhs[j];
+    rhs[i] = s / c.RSd(i, i);
+  }
+  for (int i = 0; i < nf; i++)
+    if (std::isnan(rhs[i])) throw Indeterminate(c.keys.front());
+  return rhs;
+}
+
+// DeltaImpl::UpdateGaussNewtonDelta gtsam/nonlinear/ISAM2-impl.cpp:47-77 with optimizeWildfireNonRecursive
+// (ISAM2Clique.cpp:236-268; optimizeWildfireNode :211-234, isDirty :56-77, valuesChanged :151-158)
+static void isam2_update_delta(ISAM2& S, bool forceFullSolve) {
+  const double threshold = forceFullSolve ? 0.0 : S.wildfireThreshold;
+  std::vector<ICliquePtr> stack;
+  for (auto& root : S.roots) {
+    std::set<Key> changed;  // one per root (optimizeWildfireNonRecursive's local)
+    stack.clear();
+    stack.push_back(root);
+    while (!stack.empty()) {
+      ICliquePtr c = stack.back();
+      stack.pop_back();
+      bool dirty = true;
+      if (threshold > 0.0) {
+        dirty = S.deltaReplacedMask.count(c->keys.front()) > 0;
+        if (!dirty)
+          for (size_t k = c->nFrontal; k < c->keys.size(); k++)
+            if (changed.count(c->keys[k])) {
+              dirty = true;
+              break;
+            }
+      }
+      if (!dirty) continue;
+      const std::vector<double> sol = isam2_solve_clique(*c, S.delta);
+      bool valuesChanged = true;
+      if (threshold > 0.0 && !S.deltaReplacedMask.count(c->keys.front())) {
+        double maxdiff = 0;
+        int o = 0;
+        for (int k = 0; k < c->nFrontal; k++)
+          for (int d = 0; d < c->dims[k]; d++, o++) maxdiff = std::max(maxdiff, std::abs(S.delta.at(c->keys[k])[d] - sol[o]));
+        valuesChanged = maxdiff >= threshold;
+      }
+      if (valuesChanged) {  // otherwise restoreFromOriginals: the old values stay
+        int o = 0;
+        for (int k = 0; k < c->nFrontal; k++) {
+          auto& v = S.delta[c->keys[k]];
+          v.assign(sol.begin() + o, sol.begin() + o + c->dims[k]);
+          o += c->dims[k];
+          changed.insert(c->keys[k]);
+        }
+      }
+      for (auto& child : c->children) stack.push_back(child);
+    }
+  }
+  S.deltaReplacedMask.clear();
+}
+
+// the elimination of a junction tree into ISAM2 cliques: EliminatableClusterTree::eliminate with ISAM2Clique::setEliminationResult
+// (gtsam/inference/ClusterTree-inst.h:219-266, 286-318; gtsam/nonlinear/ISAM2Clique.cpp:35-46)
+static ICliquePtr isam2_eliminate_node(ISAM2& S, const std::shared_ptr<JNode>& node, const std::vector<IFactor>& graph,
+                                       const std::map<Key, int>& keyDim, GFactor* sepOut) {
+  auto cq = std::make_shared<IClique>();
+  std::vector<GFactor> childFactors(node->children.size());
+  for (size_t i = 0; i < node->children.size(); i++) {  // pre-order visitor: children in junction-tree order
+    ICliquePtr ch = isam2_eliminate_node(S, node->children[i], graph, keyDim, &childFactors[i]);
+    cq->children.push_back(ch);
+    ch->parent = cq;
+  }
+  std::vector<const GFactor*> gathered;
+  for (size_t f : node->factors)
+    if (graph[f].g) gathered.push_back(graph[f].g);
+  for (auto& cf : childFactors)
+    if (!cf.empty()) gathered.push_back(&cf);
+  for (size_t f : node->factors)  // orphan subtrees hang below the clique that eliminates their separator
+    if (graph[f].orphan) {
+      cq->children.push_back(graph[f].orphan);
+      graph[f].orphan->parent = cq;
+    }
+  Clique tmp;
+  GFactor sep;
+  eliminate_clique(gathered, node->orderedFrontalKeys, keyDim, tmp, sep);
+  cq->keys = tmp.keys;
+  cq->dims = tmp.dims;
+  cq->nFrontal = tmp.nFrontal;
+  cq->RSd = tmp.RSd;
+  cq->cached = sep;
+  for (int k = 0; k < cq->nFrontal; k++) S.nodes[cq->keys[k]] = cq;
+  *sepOut = sep;
+  return cq;
+}
+
+static void isam2_eliminate(ISAM2& S, const std::vector<IFactor>& graph, const VariableIndex& vi, const std::vector<Key>& ordering) {
+  std::vector<std::vector<Key>> fkeys;
+  for (auto& f : graph) fkeys.push_back(f.keys);
+  std::map<Key, int> keyDim;
+  for (auto& kv : S.theta) keyDim[kv.first] = kVarDim[kv.second.type];
+  auto eroots = build_etree(fkeys, vi, ordering);
+  for (auto& r : eroots) {
+    std::shared_ptr<JNode> jr;
+    jt_visit(r, fkeys, jr);
+    GFactor rem;
+    S.roots.push_back(isam2_eliminate_node(S, jr, graph, keyDim, &rem));
+  }
+}
+
+static int isam2_count_cliques(const ICliquePtr& c) {
+  int n = 1;
+  for (auto& ch : c->children) n += isam2_count_cliques(ch);
+  return n;
+}
+
+// ISAM2::update gtsam/nonlinear/ISAM2.cpp:419-480 (default ISAM2UpdateParams except force_relinearize)
+static ISAM2Result isam2_update(ISAM2& S, bool force_relinearize) {
+  S.update_count += 1;
+  ISAM2Result result;
+  std::vector<Factor> newFactors;
+  newFactors.swap(S.newFactors);
+  Values newTheta;
+  newTheta.swap(S.newTheta);
+  // addVariables :365-384
+  for (auto& kv : newTheta) {
+    if (S.theta.count(kv.first)) throw std::invalid_argument("ISAM2: variable already exists");
+    S.theta[kv.first] = kv.second;
+    S.delta[kv.first] = std::vector<double>(kVarDim[kv.second.type], 0.0);
+  }
+  const bool relinNeeded = force_relinearize || (S.enableRelinearization && S.relinearizeSkip > 0 && S.update_count % S.relinearizeSkip == 0);
+  if (relinNeeded) isam2_update_delta(S, false);
+  // 1. pushBackFactors (ISAM2-impl.h:145-175): indices continue the list (findUnusedFactorSlots = false)
+  const size_t firstNew = S.nonlinearFactors.size();
+  for (auto& f : newFactors) S.nonlinearFactors.push_back(f);
+  // 3. markedKeys = keys of the new factors (:199-228); observedKeys = the same (no unused keys without removals)
+  std::set<Key> markedKeys;
+  for (auto& f : newFactors)
+    for (int k = 0; k < kFactorArity[f.type]; k++) markedKeys.insert(f.keys[k]);
+  const std::vector<Key> observedKeys(markedKeys.begin(), markedKeys.end());
+  std::set<Key> relinKeys;
+  if (relinNeeded) {
+    // 4. CheckRelinearizationFull (:353-383): max |delta_j| >= threshold
+    for (auto& kd : S.delta) {
+      double m = 0;
+      for (double x : kd.second) m = std::max(m, std::abs(x));
+      if (m >= S.relinearizeThreshold) relinKeys.insert(kd.first);
+    }
+    markedKeys.insert(relinKeys.begin(), relinKeys.end());
+    if (!relinKeys.empty()) {
+      // 5. findFluid (:431-451), 6. theta.retractMasked(delta, relinKeys)
+      for (auto& root : S.roots) isam2_find_all(root, relinKeys, &markedKeys);
+      for (Key k : relinKeys) S.theta[k] = retract(S.theta.at(k), S.delta.at(k).data());
+    }
+    result.variablesRelinearized = (int)markedKeys.size();
+  }
+  // 7. linearizeNewFactors (:454-468) + augmentVariableIndex
+  for (size_t i = firstNew; i < S.nonlinearFactors.size(); i++) {
+    S.linearFactors.push_back(linearize_factor(S.nonlinearFactors[i], S.theta));
+    for (int k = 0; k < kFactorArity[S.nonlinearFactors[i].type]; k++) S.variableIndex[S.nonlinearFactors[i].keys[k]].push_back(i);
+  }
+  // 8. recalculate (ISAM2.cpp:117-175)
+  if (!markedKeys.empty() || !observedKeys.empty()) {
+    std::vector<ICliquePtr> affectedBayesNet;
+    std::list<ICliquePtr> orphans;
+    for (Key j : markedKeys) {  // removeTop BayesTree-inst.h:491-508
+      auto node = S.nodes.find(j);
+      if (node != S.nodes.end()) isam2_remove_path(S, node->second, &affectedBayesNet, &orphans);
+    }
+    std::vector<Key> affectedKeys;
+    for (auto& c : affectedBayesNet)
+      for (int k = 0; k < c->nFrontal; k++) affectedKeys.push_back(c->keys[k]);
+    std::set<Key> affectedKeysSet;
+    if ((double)affectedKeys.size() >= (double)S.theta.size() * 0.65) {
+      // ---- recalculateBatch :178-247
+      result.batch = 1;
+      for (auto& kv : S.variableIndex) affectedKeysSet.insert(kv.first);
+      std::vector<Key> order;
+      if (S.theta.size() > observedKeys.size()) {
+        std::map<Key, int> groups;
+        for (Key var : observedKeys) groups[var] = 1;
+        order = colamd_constrained(S, S.variableIndex, S.nonlinearFactors.size(), groups);
+      } else {
+        order = colamd_constrained(S, S.variableIndex, S.nonlinearFactors.size(), {});
+      }
+      for (size_t i = 0; i < S.nonlinearFactors.size(); i++) S.linearFactors[i] = linearize_factor(S.nonlinearFactors[i], S.theta);
+      std::vector<IFactor> graph(S.linearFactors.size());
+      for (size_t i = 0; i < graph.size(); i++) {
+        graph[i].g = &S.linearFactors[i];
+        graph[i].keys = S.linearFactors[i].keys;
+      }
+      S.roots.clear();
+      S.nodes.clear();
+      isam2_eliminate(S, graph, S.variableIndex, order);
+      result.variablesReeliminated = (int)affectedKeysSet.size();
+      result.factorsRecalculated = (int)S.nonlinearFactors.size();
+    } else {
+      // ---- recalculateIncremental :250-362
+      std::vector<Key> affectedAndNewKeys = affectedKeys;
+      affectedAndNewKeys.insert(affectedAndNewKeys.end(), observedKeys.begin(), observedKeys.end());
+      // relinearizeAffectedFactors :66-114
+      std::set<size_t> candidates;
+      for (Key key : affectedAndNewKeys)
+        for (size_t f : S.variableIndex.at(key)) candidates.insert(f);
+      const std::set<Key> inSet(affectedAndNewKeys.begin(), affectedAndNewKeys.end());
+      std::vector<IFactor> factors;
+      for (size_t idx : candidates) {
+        bool inside = true, useCachedLinear = true;
+        const Factor& nf = S.nonlinearFactors[idx];
+        for (int k = 0; k < kFactorArity[nf.type]; k++) {
+          if (!inSet.count(nf.keys[k])) {
+            inside = false;
+            break;
+          }
+          if (relinKeys.count(nf.keys[k])) useCachedLinear = false;
+        }
+        if (!inside) continue;
+        if (!useCachedLinear) S.linearFactors[idx] = linearize_factor(nf, S.theta);
+        IFactor f;
+        f.g = &S.linearFactors[idx];
+        f.keys = S.linearFactors[idx].keys;
+        factors.push_back(f);
+      }
+      result.variablesReeliminated = (int)affectedAndNewKeys.size();
+      result.factorsRecalculated = (int)factors.size();
+      for (auto& orphan : orphans) {  // GetCachedBoundaryFactors ISAM2-impl.h:499-509
+        IFactor f;
+        f.g = &orphan->cached;
+        f.keys = orphan->cached.keys;
+        factors.push_back(f);
+      }
+      for (auto& orphan : orphans) {  // BayesTreeOrphanWrapper: keys = the orphan's separator
+        IFactor f;
+        f.orphan = orphan;
+        f.keys.assign(orphan->keys.begin() + orphan->nFrontal, orphan->keys.end());
+        factors.push_back(f);
+      }
+      affectedKeysSet.insert(markedKeys.begin(), markedKeys.end());
+      affectedKeysSet.insert(affectedKeys.begin(), affectedKeys.end());
+      VariableIndex affectedFactorsVarIndex;
+      for (size_t i = 0; i < factors.size(); i++)
+        for (Key k : factors[i].keys) affectedFactorsVarIndex[k].push_back(i);
+      std::map<Key, int> constraintGroups;
+      const int group = observedKeys.size() < affectedFactorsVarIndex.size() ? 1 : 0;
+      for (Key var : observedKeys) constraintGroups.emplace(var, group);
+      for (auto it = constraintGroups.begin(); it != constraintGroups.end();) {
+        if (!affectedKeysSet.count(it->first)) it = constraintGroups.erase(it);
+        else ++it;
+      }
+      const std::vector<Key> ordering = colamd_constrained(S, affectedFactorsVarIndex, factors.size(), constraintGroups);
+      isam2_eliminate(S, factors, affectedFactorsVarIndex, ordering);
+    }
+    S.deltaReplacedMask.insert(affectedKeysSet.begin(), affectedKeysSet.end());
+  }
+  result.cliques = 0;
+  for (auto& r : S.roots) result.cliques += isam2_count_cliques(r);
+  S.last = result;
+  return result;
+}
+
+// ISAM2::calculateEstimate :748-754 (getDelta :776-779)
+static Values isam2_calculate_estimate(ISAM2& S, bool best) {
+  if (best) isam2_update_delta(S, true);  // calculateBestEstimate :763-766
+  else if (!S.deltaReplacedMask.empty()) isam2_update_delta(S, false);
+  Values out;
+  for (auto& kv : S.theta) out[kv.first] = retract(kv.second, S.delta.at(kv.first).data());
+  return out;
+}
+
+static void isam2_collect(const ICliquePtr& c, std::vector<ICliquePtr>* out) {
+  out->push_back(c);
+  for (auto& ch : c->children) isam2_collect(ch, out);
+}
+
+}  // namespace orc

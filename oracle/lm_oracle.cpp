@@ -21,8 +21,10 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <list>
 #include <map>
 #include <memory>
+#include <set>
 #include <stdexcept>
 #include <vector>
 
@@ -1167,6 +1169,8 @@ static double now_s() {
 }  // namespace orc
 
 // =================================================================== C interface (ctypes)
+#include "isam2_oracle.hpp"
+
 using namespace orc;
 extern "C" {
 
@@ -1688,3 +1692,142 @@ int orc_factor_evaluate(void* h, int i, double* e, double* H1, double* H2) {
   return 0;
 }
 }
+
+// =================================================================== ISAM2 (isam2_oracle.hpp)
+namespace orc {
+struct ISAM2Handle {
+  ISAM2 S;
+  std::vector<ICliquePtr> snap;      // depth-first snapshot of the Bayes tree for the taps below
+  std::vector<int> snapParent;
+};
+}  // namespace orc
+
+extern "C" {
+
+void* orc_isam2_create(double relinearizeThreshold, int relinearizeSkip, int enableRelinearization, double wildfireThreshold,
+                       orc::ccolamd_fn cb) {
+  auto* h = new ISAM2Handle();
+  h->S.relinearizeThreshold = relinearizeThreshold;
+  h->S.relinearizeSkip = relinearizeSkip;
+  h->S.enableRelinearization = enableRelinearization != 0;
+  h->S.wildfireThreshold = wildfireThreshold;
+  h->S.ccolamd = cb;
+  return h;
+}
+void orc_isam2_destroy(void* h) { delete (ISAM2Handle*)h; }
+
+int orc_isam2_add_variable(void* h, uint64_t key, int type, const double* value) {
+  auto& S = ((ISAM2Handle*)h)->S;
+  if (type < 0 || type > 4) return 2;
+  Value v;
+  v.type = type;
+  std::memset(v.v, 0, sizeof(v.v));
+  std::memcpy(v.v, value, kVarStore[type] * sizeof(double));
+  S.newTheta[key] = v;
+  return 0;
+}
+
+int orc_isam2_add_factor(void* h, int type, const uint64_t* keys, const double* meas, int noise_kind, const double* noise) {
+  auto& S = ((ISAM2Handle*)h)->S;
+  if (type < 0 || type > 9) return 2;
+  Factor f;
+  f.type = type;
+  f.keys[0] = keys[0];
+  f.keys[1] = kFactorArity[type] > 1 ? keys[1] : 0;
+  std::memset(f.meas, 0, sizeof(f.meas));
+  std::memcpy(f.meas, meas, kFactorMeas[type] * sizeof(double));
+  f.noise_kind = noise_kind;
+  const int m = kFactorRows[type];
+  if (noise_kind == N_ISO) f.noise.assign(noise, noise + 1);
+  if (noise_kind == N_DIAG) f.noise.assign(noise, noise + m);
+  if (noise_kind == N_GAUSS) f.noise.assign(noise, noise + m * m);
+  S.newFactors.push_back(f);
+  return 0;
+}
+
+// result5: variablesRelinearized, variablesReeliminated, factorsRecalculated, cliques, batch.  1 = indeterminate system
+int orc_isam2_update(void* h, int force_relinearize, int* result5) {
+  auto& S = ((ISAM2Handle*)h)->S;
+  try {
+    const ISAM2Result r = isam2_update(S, force_relinearize != 0);
+    if (result5) {
+      result5[0] = r.variablesRelinearized;
+      result5[1] = r.variablesReeliminated;
+      result5[2] = r.factorsRecalculated;
+      result5[3] = r.cliques;
+      result5[4] = r.batch;
+    }
+  } catch (const Indeterminate&) {
+    return 1;
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "orc_isam2_update: %s\n", e.what());
+    return 2;
+  }
+  return 0;
+}
+
+int orc_isam2_num_variables(void* h) { return (int)((ISAM2Handle*)h)->S.theta.size(); }
+int orc_isam2_num_factors(void* h) { return (int)((ISAM2Handle*)h)->S.nonlinearFactors.size(); }
+
+// which: 0 = calculateEstimate, 1 = calculateBestEstimate, 2 = getLinearizationPoint.  Variables ascending by key;
+// types_out / packed_out (kVarStore doubles each) may be null.
+int orc_isam2_values(void* h, int which, uint64_t* keys_out, int* types_out, double* packed_out) {
+  auto& S = ((ISAM2Handle*)h)->S;
+  try {
+    const Values v = which == 2 ? S.theta : isam2_calculate_estimate(S, which == 1);
+    for (auto& kv : v) {
+      if (keys_out) *keys_out++ = kv.first;
+      if (types_out) *types_out++ = kv.second.type;
+      if (packed_out) {
+        std::memcpy(packed_out, kv.second.v, kVarStore[kv.second.type] * sizeof(double));
+        packed_out += kVarStore[kv.second.type];
+      }
+    }
+  } catch (const Indeterminate&) {
+    return 1;
+  }
+  return 0;
+}
+
+// getDelta(), ascending by key
+int orc_isam2_delta(void* h, double* out) {
+  auto& S = ((ISAM2Handle*)h)->S;
+  if (!S.deltaReplacedMask.empty()) isam2_update_delta(S, false);
+  for (auto& kv : S.delta)
+    for (double x : kv.second) *out++ = x;
+  return 0;
+}
+
+// depth-first snapshot of the Bayes tree (roots in order, children in order); returns the number of cliques
+int orc_isam2_snapshot(void* hh) {
+  auto* h = (ISAM2Handle*)hh;
+  h->snap.clear();
+  h->snapParent.clear();
+  for (auto& r : h->S.roots) isam2_collect(r, &h->snap);
+  for (auto& c : h->snap) {
+    int par = -1;
+    if (auto p = c->parent.lock())
+      par = (int)(std::find(h->snap.begin(), h->snap.end(), p) - h->snap.begin());
+    h->snapParent.push_back(par);
+  }
+  return (int)h->snap.size();
+}
+// info5: nkeys, nfrontal keys, nf (rows), n (cols), parent (index in the snapshot, -1 root)
+int orc_isam2_clique_info(void* hh, int i, int* info5) {
+  auto* h = (ISAM2Handle*)hh;
+  const IClique& c = *h->snap.at(i);
+  info5[0] = (int)c.keys.size();
+  info5[1] = c.nFrontal;
+  info5[2] = c.RSd.r;
+  info5[3] = c.RSd.c;
+  info5[4] = h->snapParent.at(i);
+  return 0;
+}
+int orc_isam2_clique_get(void* hh, int i, uint64_t* keys, double* RSd_colmajor) {
+  const IClique& c = *((ISAM2Handle*)hh)->snap.at(i);
+  if (keys) std::memcpy(keys, c.keys.data(), c.keys.size() * sizeof(uint64_t));
+  if (RSd_colmajor) std::memcpy(RSd_colmajor, c.RSd.a.data(), c.RSd.a.size() * sizeof(double));
+  return 0;
+}
+
+}  // extern "C"

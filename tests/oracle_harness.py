@@ -366,3 +366,152 @@ def metis_from_factor_keys(factor_keys):
         return keys
     perm, _ = metis_from_adjacency(xadj, adj)
     return [keys[i] for i in perm]
+
+
+# ---------------------------------------------------------------- ISAM2 (oracle/isam2_oracle.hpp)
+CCOLAMD_FN = ct.CFUNCTYPE(ct.c_int, ct.c_int, ct.c_int, _I, _I, _I, _I)
+
+
+def ccolamd_csc(n_rows, n_cols, col_ptr, row_idx, cmember):
+    """ccolamd of the reference (oracle/_ref) with GTSAM's knobs (gtsam/inference/Ordering.cpp:86-108): dense-row / dense-column
+    detection off; returns the column permutation"""
+    L = ct.CDLL(os.path.join(REF_DIR, "libccolamd_ref.so"))
+    L.ccolamd_recommended.restype = ct.c_size_t
+    L.ccolamd_recommended.argtypes = [ct.c_int, ct.c_int, ct.c_int]
+    nnz = int(col_ptr[n_cols])
+    Alen = L.ccolamd_recommended(nnz, n_rows, n_cols)
+    A = np.zeros(Alen, dtype=np.int32)
+    A[:nnz] = row_idx[:nnz]
+    p = np.array(col_ptr[:n_cols + 1], dtype=np.int32)
+    knobs = (ct.c_double * 20)()
+    L.ccolamd_set_defaults(knobs)
+    knobs[0] = -1
+    knobs[1] = -1
+    stats = (ct.c_int * 20)()
+    cm = np.array(cmember[:n_cols], dtype=np.int32)
+    rv = L.ccolamd(ct.c_int(n_rows), ct.c_int(n_cols), ct.c_int(Alen), ip(A), ip(p), knobs, stats, ip(cm))
+    if rv != 1:
+        raise RuntimeError(f"ccolamd failed with return value {rv}")
+    return p[:n_cols].copy()
+
+
+def _ccolamd_callback(n_rows, n_cols, col_ptr, row_idx, cmember, perm_out):
+    try:
+        cp = np.ctypeslib.as_array(col_ptr, shape=(n_cols + 1,))
+        ri = np.ctypeslib.as_array(row_idx, shape=(max(1, int(cp[n_cols])),))
+        cm = np.ctypeslib.as_array(cmember, shape=(n_cols,))
+        perm = ccolamd_csc(n_rows, n_cols, cp, ri, cm)
+        out = np.ctypeslib.as_array(perm_out, shape=(n_cols,))
+        out[:] = perm
+        return 1
+    except Exception:  # noqa: BLE001 -- a Python exception must not unwind through the C caller
+        import traceback
+        traceback.print_exc()
+        return 0
+
+
+CCOLAMD_CALLBACK = CCOLAMD_FN(_ccolamd_callback)
+
+
+class OracleISAM2:
+    """ISAM2 (gtsam/nonlinear/ISAM2.h) restated on the CPU; Gauss-Newton optimisation params, Cholesky, COLAMD"""
+
+    def __init__(self, relinearizeThreshold=0.1, relinearizeSkip=10, enableRelinearization=True, wildfireThreshold=0.001):
+        self.L = lib()
+        L = self.L
+        L.orc_isam2_create.restype = ct.c_void_p
+        L.orc_isam2_create.argtypes = [ct.c_double, ct.c_int, ct.c_int, ct.c_double, CCOLAMD_FN]
+        L.orc_isam2_destroy.argtypes = [ct.c_void_p]
+        L.orc_isam2_add_variable.argtypes = [ct.c_void_p, ct.c_uint64, ct.c_int, _D]
+        L.orc_isam2_add_factor.argtypes = [ct.c_void_p, ct.c_int, _U, _D, ct.c_int, _D]
+        L.orc_isam2_update.argtypes = [ct.c_void_p, ct.c_int, _I]
+        L.orc_isam2_num_variables.argtypes = [ct.c_void_p]
+        L.orc_isam2_values.argtypes = [ct.c_void_p, ct.c_int, _U, _I, _D]
+        L.orc_isam2_delta.argtypes = [ct.c_void_p, _D]
+        L.orc_isam2_snapshot.argtypes = [ct.c_void_p]
+        L.orc_isam2_clique_info.argtypes = [ct.c_void_p, ct.c_int, _I]
+        L.orc_isam2_clique_get.argtypes = [ct.c_void_p, ct.c_int, _U, _D]
+        self.h = ct.c_void_p(L.orc_isam2_create(relinearizeThreshold, relinearizeSkip, int(enableRelinearization), wildfireThreshold,
+                                                CCOLAMD_CALLBACK))
+
+    def __del__(self):
+        try:
+            self.L.orc_isam2_destroy(self.h)
+        except Exception:
+            pass
+
+    def update(self, newFactors: NonlinearFactorGraph = None, newTheta: Values = None, force_relinearize=False):
+        """ISAM2::update(newFactors, newTheta); returns dict(variablesRelinearized, variablesReeliminated, factorsRecalculated, cliques, batch)"""
+        if newTheta is not None:
+            for k in newTheta.keys():
+                v = np.ascontiguousarray(newTheta.at(k), dtype=np.float64)
+                assert self.L.orc_isam2_add_variable(self.h, k, newTheta.type(k), dp(v)) == 0
+        if newFactors is not None and newFactors.size():
+            rec = [None] * newFactors.size()
+            for ftype, kind, gi, keys, meas, noise, models in newFactors.buckets():
+                for i, g in enumerate(gi.tolist()):
+                    rec[g] = (ftype, keys[i], meas[i], models[i])
+            for ftype, keys, meas, model in rec:
+                assert not getattr(model, "robust_kind", 0)
+                kk = np.zeros(2, dtype=np.uint64)
+                kk[:FACTOR_ARITY[ftype]] = keys
+                m = np.ascontiguousarray(meas, dtype=np.float64)
+                if model.kind == N_UNIT:
+                    nd = None
+                elif model.kind == N_ISO:
+                    nd = dp(np.array([float(model.data)]))
+                else:
+                    nd = dp(np.ascontiguousarray(model.data, dtype=np.float64).reshape(-1))
+                assert self.L.orc_isam2_add_factor(self.h, ftype, up(kk), dp(m), model.kind, nd) == 0
+        res = np.zeros(5, dtype=np.int32)
+        rc = self.L.orc_isam2_update(self.h, int(force_relinearize), ip(res))
+        assert rc == 0, rc
+        return dict(variablesRelinearized=int(res[0]), variablesReeliminated=int(res[1]), factorsRecalculated=int(res[2]), cliques=int(res[3]),
+                    batch=int(res[4]))
+
+    def _values(self, which):
+        n = self.L.orc_isam2_num_variables(self.h)
+        keys = np.zeros(n, dtype=np.uint64)
+        types = np.zeros(n, dtype=np.int32)
+        assert self.L.orc_isam2_values(self.h, which, up(keys), ip(types), None) == 0
+        packed = np.zeros(int(sum(VAR_STORE[t] for t in types)))
+        assert self.L.orc_isam2_values(self.h, which, None, None, dp(packed)) == 0
+        out, o = Values(), 0
+        for k, t in zip(keys.tolist(), types.tolist()):
+            out.insert(k, t, packed[o:o + VAR_STORE[t]])
+            o += VAR_STORE[t]
+        return out
+
+    def calculateEstimate(self):
+        return self._values(0)
+
+    def calculateBestEstimate(self):
+        return self._values(1)
+
+    def getLinearizationPoint(self):
+        return self._values(2)
+
+    def getDelta(self):
+        """{key: vector}"""
+        lin = self._values(2)
+        tot = sum(VAR_DIM[lin.type(k)] for k in lin.keys())
+        d = np.zeros(tot)
+        self.L.orc_isam2_delta(self.h, dp(d))
+        out, o = {}, 0
+        for k in lin.keys():
+            n = VAR_DIM[lin.type(k)]
+            out[k] = d[o:o + n].copy()
+            o += n
+        return out
+
+    def cliques(self):
+        """[(keys, n_frontal_keys, RSd (nf, n), parent index)] depth-first from the roots"""
+        out = []
+        for i in range(self.L.orc_isam2_snapshot(self.h)):
+            info = np.zeros(5, dtype=np.int32)
+            self.L.orc_isam2_clique_info(self.h, i, ip(info))
+            keys = np.zeros(info[0], dtype=np.uint64)
+            rsd = np.empty(info[2] * info[3])
+            self.L.orc_isam2_clique_get(self.h, i, up(keys), dp(rsd))
+            out.append(([int(k) for k in keys], int(info[1]), rsd.reshape(info[3], info[2]).T.copy(), int(info[4])))
+        return out
