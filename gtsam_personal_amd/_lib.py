@@ -34,6 +34,21 @@ class lmgpu_lm_state(ct.Structure):
                 ("totalNumberInnerIterations", ct.c_int32)]
 
 
+class lmgpu_isam2_params(ct.Structure):
+    _fields_ = [("relinearizeThreshold", ct.c_double), ("relinearizeSkip", ct.c_int32), ("enableRelinearization", ct.c_int32),
+                ("wildfireThreshold", ct.c_double)]
+
+
+class lmgpu_isam2_result(ct.Structure):
+    _fields_ = [("variablesRelinearized", ct.c_int32), ("variablesReeliminated", ct.c_int32), ("factorsRecalculated", ct.c_int32),
+                ("cliques", ct.c_int32), ("batch", ct.c_int32)]
+
+
+# lmgpu_ccolamd_fn: int fn(user, n_rows, n_cols, col_ptr, row_idx, cmember, perm_out)
+CCOLAMD_FN = ct.CFUNCTYPE(ct.c_int, ct.c_void_p, ct.c_int32, ct.c_int32, ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32),
+                          ct.POINTER(ct.c_int32))
+
+
 class lmgpu_timings(ct.Structure):
     _fields_ = [("linearize_ms", ct.c_double), ("eliminate_ms", ct.c_double), ("backsub_ms", ct.c_double), ("linear_error_ms", ct.c_double),
                 ("retract_error_ms", ct.c_double), ("total_ms", ct.c_double), ("inner_iterations", ct.c_int32)]
@@ -85,6 +100,20 @@ SYMBOLS = {
     "lmgpu_joint_marginal_covariance": (ct.c_int, [_H, ct.c_int32, _I, _D]),
     "lmgpu_selftest_chain_schedule": (ct.c_int, [ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_int]),
     "lmgpu_comm_init_local": (ct.c_int, [_H, ct.c_void_p]),
+    "lmgpu_isam2_create": (ct.c_int, [ct.POINTER(lmgpu_config), ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.POINTER(_H)]),
+    "lmgpu_isam2_destroy": (ct.c_int, [_H]),
+    "lmgpu_isam2_last_error": (ct.c_char_p, [_H]),
+    "lmgpu_isam2_last_failed_key": (ct.c_uint64, [_H]),
+    "lmgpu_isam2_add_variables": (ct.c_int, [_H, ct.c_int32, ct.POINTER(ct.c_uint64), _I, _D]),
+    "lmgpu_isam2_add_factors": (ct.c_int, [_H, ct.c_int32, ct.c_int32, ct.POINTER(ct.c_uint64), _D, ct.c_int32, _D]),
+    "lmgpu_isam2_update": (ct.c_int, [_H, ct.c_int32, ct.c_void_p]),
+    "lmgpu_isam2_num_variables": (ct.c_int, [_H]),
+    "lmgpu_isam2_num_factors": (ct.c_int, [_H]),
+    "lmgpu_isam2_get_values": (ct.c_int, [_H, ct.c_int32, ct.POINTER(ct.c_uint64), _I, _D]),
+    "lmgpu_isam2_get_delta": (ct.c_int, [_H, _D]),
+    "lmgpu_isam2_num_cliques": (ct.c_int, [_H]),
+    "lmgpu_isam2_clique_info": (ct.c_int, [_H, ct.c_int32, _I]),
+    "lmgpu_isam2_get_clique": (ct.c_int, [_H, ct.c_int32, ct.POINTER(ct.c_uint64), _D]),
     "lmgpu_peak_mfma_f64": (ct.c_int, [ct.c_int32, ct.c_int32, _D]),
     "lmgpu_peak_hbm_copy": (ct.c_int, [ct.c_int32, ct.c_int64, ct.c_int32, _D]),
 }

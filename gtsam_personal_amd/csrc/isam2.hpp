@@ -1,0 +1,1083 @@
+// ISAM2 on the device (BASELINE config 5): incremental relinearization of the affected factor subset +
+// partial re-elimination of the top of a DEVICE-RESIDENT Bayes tree + wildfire back-substitution.  Included by lmgpu.hip.
+//
+// What runs where (same split as the batch path: symbolic bookkeeping on the host, every number on the device):
+//   host    ISAM2::update's bookkeeping (gtsam/nonlinear/ISAM2.cpp:419-480, ISAM2-impl.h:113-508): new variables / factors, marked
+//           and relinearization keys, findFluid, BayesTree::removeTop (gtsam/inference/BayesTree-inst.h:440-508), the constrained
+//           COLAMD call (a boundary input: lmgpu_ccolamd_fn, bound by the reference side to its own ccolamd), elimination tree and
+//           junction tree of the affected part (plan.cpp: symbolic_multifrontal, n-ary factors = relinearized factors, cached
+//           boundary factors, orphan subtrees' separators, ISAM2.cpp:250-362)
+//   device  theta, delta, the linearization cache ([A b] per factor = linearFactors_), [R S d] and the cached separator factor of
+//           every clique (ISAM2Clique::cachedFactor_); kernels: the bucket factor kernels on an index list (relinearizeAffectedFactors
+//           :66-114, linearizeNewFactors), retract on an index list (retractMasked :465), lds_front_kernel per level of the new
+//           cliques (own Jacobians + cached boundary factors / children as extend-add), isam2_wildfire_kernel per tree depth
+//           (optimizeWildfireNonRecursive, ISAM2Clique.cpp:211-268).
+// Storage: one pool of doubles (offsets, so it can grow): Jacobian regions per factor bucket, [R S d] + update matrix per clique
+// with exact-size free lists (clique shapes repeat in SLAM).
+// Limits of this round (fail loudly): Gauss-Newton params, Cholesky, no factor removal / marginalization / fixed variables;
+// cliques of more than 139 scalar columns (the LDS front kernel's limit) are rejected.
+#pragma once
+
+#include <list>
+#include <set>
+#include <type_traits>
+
+struct lmgpu_isam2 {
+  lmgpu_config cfg{};
+  lmgpu_isam2_params prm{};
+  lmgpu_ccolamd_fn ccolamd = nullptr;
+  void* user = nullptr;
+  int device = -1;
+  std::string err;
+  uint64_t failed_key = 0;
+  hipStream_t stream = nullptr;
+
+  struct Var {
+    uint64_t key;
+    int32_t type, tidx, xoff;
+  };
+  std::vector<Var> vars;
+  std::map<uint64_t, int32_t> vid_of;  // ascending by key = the order of the reference's Values / VectorValues / VariableIndex
+  int type_count[kNumVarTypes] = {0, 0, 0, 0, 0}, type_cap[kNumVarTypes] = {0, 0, 0, 0, 0};
+  double* theta[kNumVarTypes] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  double* est[kNumVarTypes] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int32_t* d_type_xoff[kNumVarTypes] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int ntot = 0, ntot_cap = 0;
+  double *delta = nullptr, *ones = nullptr;
+  unsigned char *d_replaced = nullptr, *d_changed = nullptr;  // per scalar of delta
+
+  struct Fac {
+    int32_t type, bucket, lidx, v[2];
+  };
+  std::vector<Fac> facs;
+  struct Bkt {
+    int type = 0, noise_kind = 0, rows = 0, cols = 0, ml = 0, nl = 0, ar = 0;
+    int n = 0, cap = 0;
+    int64_t joff = -1;  // pool offset of the bucket's Jacobians (cap x rows x cols)
+    int32_t* d_vidx = nullptr;
+    double *d_meas = nullptr, *d_noise = nullptr;
+  };
+  std::vector<Bkt> bkts;
+  std::vector<std::vector<int32_t>> vindex;  // VariableIndex: per variable the factor indices, ascending
+
+  struct Clq {
+    std::vector<int32_t> vars;  // vids: frontals (elimination order), then separators ascending by key (Scatter order)
+    int32_t nfv = 0, nf = 0, n = 0;
+    int64_t rsd_off = -1, u_off = -1;
+    std::vector<int32_t> children;
+    int32_t parent = -1;
+    bool alive = false;
+  };
+  std::vector<Clq> clq;
+  std::vector<int32_t> free_clq, roots, node_of;  // node_of: per variable the clique it is frontal in (-1: none yet)
+  std::vector<char> replaced;                     // deltaReplacedMask_, per variable
+  bool any_replaced = false;
+
+  double* pool = nullptr;
+  size_t pool_cap = 0, pool_top = 0;
+  std::map<size_t, std::vector<int64_t>> freelist;
+
+  // pending input of the next update
+  struct NewVar {
+    uint64_t key;
+    int32_t type;
+    double v[15];
+  };
+  std::vector<NewVar> new_vars;
+  struct NewFac {
+    int32_t type, noise_kind;
+    uint64_t k[2];
+    std::vector<double> meas, noise;
+  };
+  std::vector<NewFac> new_facs;
+  int update_count = 0;
+
+  // device scratch
+  int *d_status = nullptr, *h_status = nullptr;
+  bool tree_dirty = true;
+  FrontDesc* d_tree = nullptr;  // one descriptor per clique slot (wildfire)
+  int32_t *d_tree_fx = nullptr, *d_tree_sx = nullptr, *d_tree_list = nullptr;
+  std::vector<std::pair<int, int>> tree_levels;  // (begin, count) in d_tree_list per depth
+  size_t tree_cap[4] = {0, 0, 0, 0};
+  // taps
+  std::vector<int32_t> snap;
+};
+
+namespace {
+
+#define ISCHECK(expr)                                                 \
+  do {                                                                \
+    hipError_t _e = (expr);                                           \
+    if (_e != hipSuccess) {                                           \
+      S->err = std::string(#expr) + ": " + hipGetErrorString(_e);     \
+      return LMGPU_HIP_ERROR;                                         \
+    }                                                                 \
+  } while (0)
+
+// reallocate a device array to exactly `newcap` elements, keeping its `used` leading elements
+template <typename T>
+int is_realloc(lmgpu_isam2* S, T** p, size_t newcap, size_t used) {
+  T* q = nullptr;
+  ISCHECK(hipMalloc((void**)&q, std::max<size_t>(1, newcap) * sizeof(T)));
+  if (*p && used) ISCHECK(hipMemcpyAsync(q, *p, used * sizeof(T), hipMemcpyDeviceToDevice, S->stream));
+  ISCHECK(hipStreamSynchronize(S->stream));
+  if (*p) (void)hipFree(*p);
+  *p = q;
+  return LMGPU_OK;
+}
+inline size_t is_next_cap(size_t cap, size_t need) { return std::max<size_t>(need, std::max<size_t>(64, cap * 2)); }
+
+int is_pool_alloc(lmgpu_isam2* S, size_t n, int64_t* off) {
+  n = std::max<size_t>(n, 1);
+  auto it = S->freelist.find(n);
+  if (it != S->freelist.end() && !it->second.empty()) {
+    *off = it->second.back();
+    it->second.pop_back();
+    return LMGPU_OK;
+  }
+  if (S->pool_top + n + 64 > S->pool_cap) {
+    const size_t cap = is_next_cap(S->pool_cap, std::max<size_t>(S->pool_top + n + 64, 1 << 16));
+    const int rc = is_realloc(S, &S->pool, cap, S->pool_top);
+    if (rc) return rc;
+    ISCHECK(hipMemsetAsync(S->pool + S->pool_top, 0, (cap - S->pool_top) * sizeof(double), S->stream));
+    S->pool_cap = cap;
+  }
+  *off = (int64_t)S->pool_top;
+  S->pool_top += n;
+  return LMGPU_OK;
+}
+void is_pool_free(lmgpu_isam2* S, int64_t off, size_t n) {
+  if (off >= 0) S->freelist[std::max<size_t>(n, 1)].push_back(off);
+}
+
+int is_new_clique(lmgpu_isam2* S) {
+  int id;
+  if (!S->free_clq.empty()) {
+    id = S->free_clq.back();
+    S->free_clq.pop_back();
+    S->clq[id] = lmgpu_isam2::Clq();
+  } else {
+    id = (int)S->clq.size();
+    S->clq.emplace_back();
+  }
+  S->clq[id].alive = true;
+  return id;
+}
+void is_release_clique(lmgpu_isam2* S, int id) {
+  lmgpu_isam2::Clq& c = S->clq[id];
+  is_pool_free(S, c.rsd_off, (size_t)c.nf * c.n);
+  is_pool_free(S, c.u_off, (size_t)(c.n - c.nf) * (c.n - c.nf));
+  c.alive = false;
+  c.children.clear();
+  c.vars.clear();
+  S->free_clq.push_back(id);
+}
+
+// BayesTree::removeClique gtsam/inference/BayesTree-inst.h:440-460 (the clique's storage is released by the caller once its
+// conditional has been read for the affected keys)
+void is_remove_clique(lmgpu_isam2* S, int id) {
+  lmgpu_isam2::Clq& c = S->clq[id];
+  if (c.parent < 0) {
+    auto it = std::find(S->roots.begin(), S->roots.end(), id);
+    if (it != S->roots.end()) S->roots.erase(it);
+  } else {
+    auto& pc = S->clq[c.parent].children;
+    pc.erase(std::find(pc.begin(), pc.end(), id));
+  }
+  for (int ch : c.children) S->clq[ch].parent = -1;
+  for (int k = 0; k < c.nfv; k++) S->node_of[c.vars[k]] = -1;
+}
+// BayesTree::removePath :464-486
+void is_remove_path(lmgpu_isam2* S, int id, std::vector<int>* bn, std::list<int>* orphans) {
+  if (id < 0) return;
+  orphans->remove(id);
+  const int parent = S->clq[id].parent;
+  is_remove_clique(S, id);
+  is_remove_path(S, parent, bn, orphans);
+  orphans->insert(orphans->begin(), S->clq[id].children.begin(), S->clq[id].children.end());
+  S->clq[id].children.clear();
+  bn->push_back(id);
+}
+
+// launch the factor kernels of bucket b on the index list sel (device), count entries: Jacobians into the linearization cache
+void is_linearize_sel(lmgpu_isam2* S, const lmgpu_isam2::Bkt& b, const int32_t* d_sel, int count) {
+  if (count <= 0) return;
+  BucketDev d;
+  d.type = b.type;
+  d.n = count;
+  d.noise_kind = b.noise_kind;
+  d.vidx = b.d_vidx;
+  d.meas = b.d_meas;
+  d.noise = b.d_noise;
+  d.J = S->pool + b.joff;
+  d.epos = nullptr;
+  d.robust = 0;
+  d.rk = 0.0;
+  d.sel = d_sel;
+  ValuesDev vals;
+  for (int t = 0; t < kNumVarTypes; t++) vals.v[t] = S->theta[t];
+  const int g256 = (count + 255) / 256, g128 = (count + 127) / 128;
+  hipStream_t s = S->stream;
+  double* nob = nullptr;
+  switch (b.type) {
+    case LMGPU_F_SFM: hipLaunchKernelGGL(sfm_linearize_sel_kernel, dim3(g256), dim3(256), 0, s, d, vals); break;
+    case LMGPU_F_BETWEEN_POSE2: hipLaunchKernelGGL((generic_factor_kernel<1, 3, 3, 3, 3, 0, 3, 0, 3, true>), dim3(g128), dim3(128), 0, s, d, vals, nob); break;
+    case LMGPU_F_BETWEEN_POSE3: hipLaunchKernelGGL((generic_factor_kernel<2, 6, 6, 6, 12, 1, 12, 1, 12, true>), dim3(g128), dim3(128), 0, s, d, vals, nob); break;
+    case LMGPU_F_PRIOR_POSE2: hipLaunchKernelGGL((generic_factor_kernel<3, 3, 3, 0, 3, 0, 3, -1, 0, true>), dim3(g128), dim3(128), 0, s, d, vals, nob); break;
+    case LMGPU_F_PRIOR_POSE3: hipLaunchKernelGGL((generic_factor_kernel<4, 6, 6, 0, 12, 1, 12, -1, 0, true>), dim3(g128), dim3(128), 0, s, d, vals, nob); break;
+    case LMGPU_F_PRIOR_POINT3: hipLaunchKernelGGL((generic_factor_kernel<5, 3, 3, 0, 3, 2, 3, -1, 0, true>), dim3(g128), dim3(128), 0, s, d, vals, nob); break;
+    case LMGPU_F_PRIOR_CAM: hipLaunchKernelGGL((generic_factor_kernel<6, 9, 9, 0, 15, 3, 15, -1, 0, true>), dim3(g128), dim3(128), 0, s, d, vals, nob); break;
+    case LMGPU_F_PROJECTION: hipLaunchKernelGGL((generic_factor_kernel<7, 2, 6, 3, 7, 1, 12, 2, 3, true>), dim3(g128), dim3(128), 0, s, d, vals, nob); break;
+    case LMGPU_F_PROJECTION_BPS: hipLaunchKernelGGL((generic_factor_kernel<8, 2, 6, 3, 19, 1, 12, 2, 3, true>), dim3(g128), dim3(128), 0, s, d, vals, nob); break;
+    case LMGPU_F_BEARING_RANGE_2D: hipLaunchKernelGGL((generic_factor_kernel<9, 2, 3, 2, 2, 0, 3, 4, 2, true>), dim3(g128), dim3(128), 0, s, d, vals, nob); break;
+  }
+}
+
+}  // namespace
+
+// One workgroup per clique of one tree depth: ISAM2Clique::optimizeWildfireNode (gtsam/nonlinear/ISAM2Clique.cpp:211-234).
+//   dirty   = the clique was re-eliminated (replaced flag of its first frontal scalar) or a separator scalar changed (isDirty :56-77)
+//   solve   = x_F = R^-1 (d - S x_S)   (fastBackSubstitute -> GaussianConditional::solve)
+//   keep    = replaced or max |x_F_old - x_F_new| >= threshold (valuesChanged :151-158): write x_F, flag the frontal scalars as changed;
+//             otherwise the old values stay (restoreFromOriginals).   threshold <= 0: every clique is solved (full back-substitution).
+// The parents' flags are complete before a depth is launched (launch order on one stream).
+__global__ __launch_bounds__(256) void isam2_wildfire_kernel(const int32_t* __restrict__ list, int nlist, const lmgpu::FrontDesc* __restrict__ tree,
+                                                              const int32_t* __restrict__ fxoff, const int32_t* __restrict__ sxoff,
+                                                              const double* __restrict__ pool, double* __restrict__ delta,
+                                                              const unsigned char* __restrict__ replaced, unsigned char* __restrict__ changed,
+                                                              double threshold, int* __restrict__ status) {
+  __shared__ double rhs[160];
+  __shared__ int flag;
+  __shared__ double red[256];
+  const lmgpu::FrontDesc F = tree[list[blockIdx.x]];
+  const int n = F.n, nf = F.nf, ns = n - nf - 1, tid = threadIdx.x;
+  const bool is_replaced = replaced[fxoff[F.fx_begin]] != 0;
+  if (tid == 0) flag = (threshold <= 0.0 || is_replaced) ? 1 : 0;
+  __syncthreads();
+  if (!(threshold <= 0.0 || is_replaced)) {
+    for (int j = tid; j < ns; j += 256)
+      if (changed[sxoff[F.sx_begin + j]]) flag = 1;  // benign race: every writer stores 1
+    __syncthreads();
+  }
+  if (!flag) return;
+  const double* RSd = pool + F.rsd_off;
+  for (int i = tid; i < nf; i += 256) {
+    const double* row = RSd + (size_t)i * F.ld_rsd;
+    double acc = row[n - 1];
+    for (int j = 0; j < ns; j++) acc -= row[nf + j] * delta[sxoff[F.sx_begin + j]];
+    rhs[i] = acc;
+  }
+  __syncthreads();
+  for (int i = nf - 1; i >= 0; i--) {  // R x = rhs, upper, backward
+    if (tid == 0) rhs[i] = rhs[i] / RSd[(size_t)i * F.ld_rsd + i];
+    __syncthreads();
+    const double xi = rhs[i];
+    for (int j = tid; j < i; j += 256) rhs[j] -= RSd[(size_t)j * F.ld_rsd + i] * xi;
+    __syncthreads();
+  }
+  double md = 0.0;
+  bool bad = false;
+  for (int i = tid; i < nf; i += 256) {
+    md = fmax(md, fabs(delta[fxoff[F.fx_begin + i]] - rhs[i]));
+    if (rhs[i] != rhs[i]) bad = true;
+  }
+  red[tid] = md;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] = fmax(red[tid], red[tid + o]);
+    __syncthreads();
+  }
+  if (bad) atomicMin(status, F.id);  // NaN: IndeterminantLinearSystemException (ISAM2Clique.cpp:124-126)
+  const bool keep = threshold <= 0.0 || is_replaced || red[0] >= threshold;
+  if (keep)
+    for (int i = tid; i < nf; i += 256) {
+      const int xo = fxoff[F.fx_begin + i];
+      delta[xo] = rhs[i];
+      changed[xo] = 1;
+    }
+}
+
+namespace {
+
+// rebuild the device copy of the tree (descriptors, offsets, depth lists) after an update changed it
+int is_sync_tree(lmgpu_isam2* S) {
+  if (!S->tree_dirty) return LMGPU_OK;
+  const int NC = (int)S->clq.size();
+  std::vector<FrontDesc> td(std::max(1, NC));
+  std::vector<int32_t> fx, sx, list;
+  for (int id = 0; id < NC; id++) {
+    const lmgpu_isam2::Clq& c = S->clq[id];
+    FrontDesc F{};
+    if (c.alive) {
+      F.n = c.n;
+      F.nf = c.nf;
+      F.rsd_off = c.rsd_off;
+      F.ld_rsd = c.n;
+      F.id = id;
+      F.fx_begin = (int)fx.size();
+      for (int k = 0; k < c.nfv; k++)
+        for (int d = 0; d < kVarDim[S->vars[c.vars[k]].type]; d++) fx.push_back(S->vars[c.vars[k]].xoff + d);
+      F.sx_begin = (int)sx.size();
+      for (size_t k = c.nfv; k < c.vars.size(); k++)
+        for (int d = 0; d < kVarDim[S->vars[c.vars[k]].type]; d++) sx.push_back(S->vars[c.vars[k]].xoff + d);
+    }
+    td[id] = F;
+  }
+  S->tree_levels.clear();
+  std::vector<int32_t> cur = S->roots, next;
+  while (!cur.empty()) {
+    S->tree_levels.emplace_back((int)list.size(), (int)cur.size());
+    next.clear();
+    for (int id : cur) {
+      list.push_back(id);
+      for (int ch : S->clq[id].children) next.push_back(ch);
+    }
+    cur.swap(next);
+  }
+  int rc;
+  auto fit = [&](auto** p, size_t* cap, size_t need) -> int {
+    if (need <= *cap) return LMGPU_OK;
+    *cap = is_next_cap(*cap, need);
+    return is_realloc(S, p, *cap, 0);
+  };
+  if ((rc = fit(&S->d_tree, &S->tree_cap[0], td.size()))) return rc;
+  if ((rc = fit(&S->d_tree_fx, &S->tree_cap[1], fx.size()))) return rc;
+  if ((rc = fit(&S->d_tree_sx, &S->tree_cap[2], sx.size()))) return rc;
+  if ((rc = fit(&S->d_tree_list, &S->tree_cap[3], list.size()))) return rc;
+  ISCHECK(hipMemcpy(S->d_tree, td.data(), td.size() * sizeof(FrontDesc), hipMemcpyHostToDevice));
+  if (!fx.empty()) ISCHECK(hipMemcpy(S->d_tree_fx, fx.data(), fx.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (!sx.empty()) ISCHECK(hipMemcpy(S->d_tree_sx, sx.data(), sx.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (!list.empty()) ISCHECK(hipMemcpy(S->d_tree_list, list.data(), list.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  S->tree_dirty = false;
+  return LMGPU_OK;
+}
+
+// ISAM2::updateDelta (gtsam/nonlinear/ISAM2.cpp:701-719) -> DeltaImpl::UpdateGaussNewtonDelta (ISAM2-impl.cpp:47-77)
+int is_update_delta(lmgpu_isam2* S, bool force_full) {
+  int rc = is_sync_tree(S);
+  if (rc) return rc;
+  if (S->ntot == 0) return LMGPU_OK;
+  const double thr = force_full ? 0.0 : S->prm.wildfireThreshold;
+  ISCHECK(hipMemsetAsync(S->d_changed, 0, (size_t)S->ntot, S->stream));
+  ISCHECK(hipMemsetAsync(S->d_status, 0x7f, sizeof(int), S->stream));
+  for (auto& lv : S->tree_levels)
+    hipLaunchKernelGGL(isam2_wildfire_kernel, dim3(lv.second), dim3(256), 0, S->stream, (const int32_t*)(S->d_tree_list + lv.first), lv.second,
+                       (const FrontDesc*)S->d_tree, (const int32_t*)S->d_tree_fx, (const int32_t*)S->d_tree_sx, (const double*)S->pool, S->delta,
+                       (const unsigned char*)S->d_replaced, S->d_changed, thr, S->d_status);
+  ISCHECK(hipMemsetAsync(S->d_replaced, 0, (size_t)S->ntot, S->stream));
+  ISCHECK(hipMemcpyAsync(S->h_status, S->d_status, sizeof(int), hipMemcpyDeviceToHost, S->stream));
+  ISCHECK(hipStreamSynchronize(S->stream));
+  std::fill(S->replaced.begin(), S->replaced.end(), 0);
+  S->any_replaced = false;
+  if (*S->h_status < (int)S->clq.size()) {
+    S->failed_key = S->vars[S->clq[*S->h_status].vars[0]].key;
+    S->err = "indeterminate linear system in back-substitution";
+    return LMGPU_INDETERMINATE;
+  }
+  return LMGPU_OK;
+}
+
+// Ordering::ColamdConstrained (gtsam/inference/Ordering.cpp:50-125, 193-210) on a VariableIndex given as (variables ascending by
+// key, their factor lists); groups: vid -> group.  Returns the elimination order as positions into `vids`.
+int is_colamd(lmgpu_isam2* S, const std::vector<int32_t>& vids, const std::vector<std::vector<int32_t>>& cols, int n_factors,
+              const std::map<int32_t, int>& groups, std::vector<int32_t>* perm) {
+  const int nVars = (int)vids.size();
+  perm->assign(nVars, 0);
+  if (nVars <= 1) return LMGPU_OK;
+  std::vector<int32_t> p(nVars + 1, 0), A, cmember(nVars, 0);
+  for (int j = 0; j < nVars; j++) {
+    for (int32_t f : cols[j]) A.push_back(f);
+    p[j + 1] = (int32_t)A.size();
+    auto g = groups.find(vids[j]);
+    if (g != groups.end()) cmember[j] = g->second;
+  }
+  if (!S->ccolamd || S->ccolamd(S->user, n_factors, nVars, p.data(), A.data(), cmember.data(), perm->data()) != 1) {
+    S->err = "the ccolamd callback failed";
+    return LMGPU_INVALID;
+  }
+  return LMGPU_OK;
+}
+
+// one entry of the linear graph handed to the partial elimination
+struct IsGF {
+  int kind;  // 0: linear factor of nonlinear factor `id`; 1: cached boundary factor of orphan clique `id`; 2: the orphan subtree itself
+  int32_t id;
+  std::vector<int32_t> vids;
+};
+
+// eliminate `gfs` over the variables `vids` (ascending by key) in the order `perm`: new cliques on the device, attached to the tree
+int is_eliminate(lmgpu_isam2* S, const std::vector<IsGF>& gfs, const std::vector<int32_t>& vids, const std::vector<int32_t>& perm) {
+  const int n = (int)vids.size();
+  if (n == 0) return LMGPU_OK;
+  // slot = position in the elimination order; keyrank = rank by key (vids is ascending by key)
+  std::vector<int32_t> keyrank(n), vid_of_slot(n);
+  for (int j = 0; j < n; j++) {
+    keyrank[j] = perm[j];
+    vid_of_slot[j] = vids[perm[j]];
+  }
+  std::map<int32_t, int32_t> slot_of_vid;
+  for (int j = 0; j < n; j++) slot_of_vid[vid_of_slot[j]] = j;
+  std::vector<std::vector<int32_t>> fvars(gfs.size());
+  for (size_t i = 0; i < gfs.size(); i++)
+    for (int32_t v : gfs[i].vids) fvars[i].push_back(slot_of_vid.at(v));
+  SymbolicFronts sf;
+  const std::string e = symbolic_multifrontal(n, keyrank, fvars, &sf);
+  if (!e.empty()) {
+    S->err = e;
+    return LMGPU_INVALID;
+  }
+  const int NF = (int)sf.fronts.size();
+  std::vector<int> cid(NF);
+  std::vector<FrontDesc> fds(NF);
+  std::vector<FrontFac> ffac;
+  std::vector<FacDesc> fd;
+  std::vector<ChildRef> childs;
+  std::vector<int32_t> cmap, fxoff;
+  int max_level = 0;
+  std::map<int32_t, int32_t> colof;  // vid -> column offset inside the current front
+  int rc;
+  for (int fi = 0; fi < NF; fi++) {
+    const SymbolicFronts::F& fr = sf.fronts[fi];
+    const int id = is_new_clique(S);
+    cid[fi] = id;
+    lmgpu_isam2::Clq& c = S->clq[id];
+    for (int32_t s : fr.frontals) c.vars.push_back(vid_of_slot[s]);
+    c.nfv = (int)fr.frontals.size();
+    for (int32_t s : fr.sep) c.vars.push_back(vid_of_slot[s]);
+    colof.clear();
+    int off = 0;
+    for (size_t k = 0; k < c.vars.size(); k++) {
+      colof[c.vars[k]] = off;
+      off += kVarDim[S->vars[c.vars[k]].type];
+      if ((int)k == c.nfv - 1) c.nf = off;
+    }
+    c.n = off + 1;
+    if (c.n > kLdsLimitN) {
+      S->err = "ISAM2: a clique of " + std::to_string(c.n) + " scalar columns exceeds the incremental path's limit of " + std::to_string(kLdsLimitN);
+      return LMGPU_INVALID;
+    }
+    if ((rc = is_pool_alloc(S, (size_t)c.nf * c.n, &c.rsd_off))) return rc;
+    if ((rc = is_pool_alloc(S, (size_t)(c.n - c.nf) * (c.n - c.nf), &c.u_off))) return rc;
+    for (int k = 0; k < c.nfv; k++) S->node_of[c.vars[k]] = id;
+    FrontDesc& F = fds[fi];
+    F = FrontDesc{};
+    F.n = c.n;
+    F.nf = c.nf;
+    F.rsd_off = c.rsd_off;
+    F.u_off = c.u_off;
+    F.ld_rsd = c.n;
+    F.ld_u = c.n - c.nf;
+    F.id = fi;
+    F.fac_begin = (int)ffac.size();
+    F.child_begin = (int)childs.size();
+    auto add_child = [&](const lmgpu_isam2::Clq& ch) {  // its cached factor (update matrix) is extend-added through a column map
+      ChildRef cr{};
+      cr.u_off = ch.u_off;
+      cr.ld = ch.n - ch.nf;
+      cr.m = ch.n - ch.nf;
+      cr.map_begin = (int)cmap.size();
+      for (size_t k = ch.nfv; k < ch.vars.size(); k++)
+        for (int d = 0; d < kVarDim[S->vars[ch.vars[k]].type]; d++) cmap.push_back(colof.at(ch.vars[k]) + d);
+      cmap.push_back(c.n - 1);
+      childs.push_back(cr);
+    };
+    for (int32_t g : fr.factors) {  // own factors in the reference's order: Jacobians, cached boundary factors; orphans become children
+      const IsGF& gf = gfs[g];
+      if (gf.kind == 0) {
+        const lmgpu_isam2::Fac& f = S->facs[gf.id];
+        const lmgpu_isam2::Bkt& b = S->bkts[f.bucket];
+        FacDesc d{};
+        d.joff = b.joff + (int64_t)f.lidx * b.rows * b.cols;
+        d.rows = (int16_t)b.rows;
+        d.d0 = (int16_t)kVarDim[S->vars[f.v[0]].type];
+        d.d1 = (int16_t)(f.v[1] >= 0 ? kVarDim[S->vars[f.v[1]].type] : 0);
+        d.x0 = S->vars[f.v[0]].xoff;
+        d.x1 = f.v[1] >= 0 ? S->vars[f.v[1]].xoff : -1;
+        FrontFac ff;
+        ff.fac = (int32_t)fd.size();
+        ff.c0 = colof.at(f.v[0]);
+        ff.c1 = f.v[1] >= 0 ? colof.at(f.v[1]) : 0;
+        fd.push_back(d);
+        ffac.push_back(ff);
+      } else if (gf.kind == 1) {
+        add_child(S->clq[gf.id]);
+      }
+    }
+    F.fac_count = (int)ffac.size() - F.fac_begin;
+    for (int32_t chf : fr.children) {  // junction-tree children first (pre-order visitor), in order
+      add_child(S->clq[cid[chf]]);
+      c.children.push_back(cid[chf]);
+      S->clq[cid[chf]].parent = id;
+    }
+    for (int32_t g : fr.factors)  // then the orphan subtrees whose separator this clique eliminates (ClusterTree-inst.h:228-236)
+      if (gfs[g].kind == 2) {
+        c.children.push_back(gfs[g].id);
+        S->clq[gfs[g].id].parent = id;
+      }
+    F.child_count = (int)childs.size() - F.child_begin;
+    F.fx_begin = (int)fxoff.size();
+    for (int k = 0; k < c.nfv; k++)
+      for (int d = 0; d < kVarDim[S->vars[c.vars[k]].type]; d++) fxoff.push_back(S->vars[c.vars[k]].xoff + d);
+    max_level = std::max(max_level, (int)fr.level);
+  }
+  for (int32_t r : sf.roots) S->roots.push_back(cid[r]);
+  // ---- device: one lds_front_kernel launch per level of the new cliques
+  FrontDesc* d_fds = nullptr;
+  FrontFac* d_ffac = nullptr;
+  FacDesc* d_fd = nullptr;
+  ChildRef* d_childs = nullptr;
+  int32_t *d_cmap = nullptr, *d_fxoff = nullptr, *d_list = nullptr;
+  std::vector<int32_t> list;
+  std::vector<std::pair<int, int>> lv(max_level + 1, {0, 0});
+  for (int l = 0; l <= max_level; l++) {
+    lv[l].first = (int)list.size();
+    for (int fi = 0; fi < NF; fi++)
+      if (sf.fronts[fi].level == l) list.push_back(fi);
+    lv[l].second = (int)list.size() - lv[l].first;
+  }
+  auto up = [&](auto** dst, const auto& src) -> int {
+    typedef typename std::remove_reference<decltype(src[0])>::type T;
+    ISCHECK(hipMalloc((void**)dst, std::max<size_t>(1, src.size()) * sizeof(T)));
+    if (!src.empty()) ISCHECK(hipMemcpyAsync(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, S->stream));
+    return LMGPU_OK;
+  };
+  if ((rc = up(&d_fds, fds)) || (rc = up(&d_ffac, ffac)) || (rc = up(&d_fd, fd)) || (rc = up(&d_childs, childs)) || (rc = up(&d_cmap, cmap)) ||
+      (rc = up(&d_fxoff, fxoff)) || (rc = up(&d_list, list)))
+    return rc;
+  ISCHECK(hipMemsetAsync(S->d_status, 0x7f, sizeof(int), S->stream));
+  for (int l = 0; l <= max_level; l++) {
+    if (lv[l].second == 0) continue;
+    int nmax = 1, jc = 96;
+    for (int q = 0; q < lv[l].second; q++) {
+      const int fi = list[lv[l].first + q];
+      nmax = std::max(nmax, fds[fi].n);
+      int tot = 0;
+      for (int k = 0; k < fds[fi].fac_count; k++) {
+        const FacDesc& d = fd[ffac[fds[fi].fac_begin + k].fac];
+        tot += d.rows * (d.d0 + d.d1 + 1);
+      }
+      jc = std::max(jc, std::min(tot, LDSF_JCAP));
+    }
+    const int jcap = (jc + 7) & ~7;
+    const int threads = nmax <= 24 ? 64 : (nmax <= 48 ? 128 : 256);
+    const size_t lds = kLdsFrontExtra - (size_t)(LDSF_JCAP - jcap) * 8 + 64 + (size_t)nmax * nmax * sizeof(double);
+    hipLaunchKernelGGL(lds_front_kernel<false>, dim3(lv[l].second), dim3(threads), lds, S->stream, (const int32_t*)(d_list + lv[l].first),
+                       (const FrontDesc*)d_fds, (const FrontFac*)d_ffac, (const FacDesc*)d_fd, (const ChildRef*)d_childs, (const int32_t*)d_cmap,
+                       (const int32_t*)d_fxoff, S->pool, 0.0, (const double*)nullptr, (const double*)S->ones, S->d_status, nmax, nmax, (double*)nullptr, jcap,
+                       (const double*)nullptr, (const char*)nullptr, 0);
+  }
+  ISCHECK(hipMemcpyAsync(S->h_status, S->d_status, sizeof(int), hipMemcpyDeviceToHost, S->stream));
+  ISCHECK(hipStreamSynchronize(S->stream));
+  (void)hipFree(d_fds);
+  (void)hipFree(d_ffac);
+  (void)hipFree(d_fd);
+  (void)hipFree(d_childs);
+  (void)hipFree(d_cmap);
+  (void)hipFree(d_fxoff);
+  (void)hipFree(d_list);
+  ISCHECK(hipGetLastError());
+  if (*S->h_status < NF) {  // EliminateCholesky failed: IndeterminantLinearSystemException(first frontal key), HessianFactor.cpp:475-482
+    S->failed_key = S->vars[S->clq[cid[*S->h_status]].vars[0]].key;
+    S->err = "indeterminate linear system";
+    return LMGPU_INDETERMINATE;
+  }
+  return LMGPU_OK;
+}
+
+int is_count_subtree(const lmgpu_isam2* S, int id) {
+  int n = 1;
+  for (int ch : S->clq[id].children) n += is_count_subtree(S, ch);
+  return n;
+}
+
+// upload an index list and run `fn(device list, count)`
+template <typename Fn>
+int is_with_list(lmgpu_isam2* S, const std::vector<int32_t>& v, Fn fn) {
+  if (v.empty()) return LMGPU_OK;
+  int32_t* d = nullptr;
+  ISCHECK(hipMalloc((void**)&d, v.size() * sizeof(int32_t)));
+  ISCHECK(hipMemcpyAsync(d, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice, S->stream));
+  fn((const int32_t*)d, (int)v.size());
+  ISCHECK(hipStreamSynchronize(S->stream));
+  (void)hipFree(d);
+  return LMGPU_OK;
+}
+
+// ISAM2::update (gtsam/nonlinear/ISAM2.cpp:419-480), default ISAM2UpdateParams except force_relinearize
+int is_update(lmgpu_isam2* S, bool force_relinearize, lmgpu_isam2_result* result) {
+  S->update_count += 1;
+  lmgpu_isam2_result res{};
+  int rc;
+  // ---- addVariables :365-384
+  for (const lmgpu_isam2::NewVar& nv : S->new_vars)
+    if (S->vid_of.count(nv.key)) {
+      S->err = "ISAM2: variable already exists";
+      return LMGPU_INVALID;
+    }
+  std::vector<lmgpu_isam2::NewVar> new_vars;
+  new_vars.swap(S->new_vars);
+  std::vector<lmgpu_isam2::NewFac> new_facs;
+  new_facs.swap(S->new_facs);
+  if (!new_vars.empty()) {
+    int add[kNumVarTypes] = {0, 0, 0, 0, 0}, addtot = 0;
+    for (auto& nv : new_vars) {
+      add[nv.type]++;
+      addtot += kVarDim[nv.type];
+    }
+    for (int t = 0; t < kNumVarTypes; t++) {
+      const size_t need = (size_t)(S->type_count[t] + add[t]);
+      if (!add[t] || need <= (size_t)S->type_cap[t]) continue;
+      const size_t ncap = is_next_cap((size_t)S->type_cap[t], need);
+      if ((rc = is_realloc(S, &S->theta[t], ncap * kVarStore[t], (size_t)S->type_count[t] * kVarStore[t]))) return rc;
+      if ((rc = is_realloc(S, &S->est[t], ncap * kVarStore[t], 0))) return rc;
+      if ((rc = is_realloc(S, &S->d_type_xoff[t], ncap, (size_t)S->type_count[t]))) return rc;
+      S->type_cap[t] = (int)ncap;
+    }
+    if (S->ntot + addtot > S->ntot_cap) {
+      const size_t ncap = is_next_cap((size_t)S->ntot_cap, (size_t)(S->ntot + addtot));
+      if ((rc = is_realloc(S, &S->delta, ncap, (size_t)S->ntot))) return rc;
+      if ((rc = is_realloc(S, &S->ones, ncap, 0))) return rc;
+      if ((rc = is_realloc(S, &S->d_replaced, ncap, (size_t)S->ntot))) return rc;
+      if ((rc = is_realloc(S, &S->d_changed, ncap, 0))) return rc;
+      std::vector<double> one(ncap, 1.0);
+      ISCHECK(hipMemcpy(S->ones, one.data(), ncap * sizeof(double), hipMemcpyHostToDevice));
+      ISCHECK(hipMemsetAsync(S->d_replaced + S->ntot, 0, ncap - S->ntot, S->stream));
+      S->ntot_cap = (int)ncap;
+    }
+    for (auto& nv : new_vars) {
+      lmgpu_isam2::Var v{nv.key, nv.type, S->type_count[nv.type]++, S->ntot};
+      const int vid = (int)S->vars.size();
+      S->vars.push_back(v);
+      S->vid_of[nv.key] = vid;
+      S->vindex.emplace_back();
+      S->node_of.push_back(-1);
+      S->replaced.push_back(0);
+      ISCHECK(hipMemcpyAsync(S->theta[nv.type] + (size_t)v.tidx * kVarStore[nv.type], nv.v, kVarStore[nv.type] * sizeof(double),
+                             hipMemcpyHostToDevice, S->stream));
+      ISCHECK(hipMemcpyAsync(S->d_type_xoff[nv.type] + v.tidx, &S->vars.back().xoff, sizeof(int32_t), hipMemcpyHostToDevice, S->stream));
+      ISCHECK(hipMemsetAsync(S->delta + S->ntot, 0, kVarDim[nv.type] * sizeof(double), S->stream));  // delta_.insert(zeroVectors)
+      S->ntot += kVarDim[nv.type];
+    }
+    ISCHECK(hipStreamSynchronize(S->stream));  // the sources above are host locals
+  }
+  const bool relinNeeded = force_relinearize || (S->prm.enableRelinearization && S->prm.relinearizeSkip > 0 && S->update_count % S->prm.relinearizeSkip == 0);
+  if (relinNeeded && (rc = is_update_delta(S, false))) return rc;
+  // ---- 1. pushBackFactors (ISAM2-impl.h:145-175): indices continue the list
+  const int firstNew = (int)S->facs.size();
+  std::set<uint64_t> markedKeys;
+  std::map<int, std::vector<int32_t>> new_by_bucket;  // bucket -> new local indices
+  for (const lmgpu_isam2::NewFac& nf : new_facs) {
+    const int ar = kFactorArity[nf.type];
+    lmgpu_isam2::Fac f{nf.type, -1, -1, {-1, -1}};
+    for (int k = 0; k < ar; k++) {
+      auto it = S->vid_of.find(nf.k[k]);
+      if (it == S->vid_of.end()) {
+        S->err = "ISAM2: a new factor references a variable that has no value";
+        return LMGPU_INVALID;
+      }
+      const int want = (k == 0) ? kFactorVar0[nf.type] : kFactorVar1[nf.type];
+      if (S->vars[it->second].type != want) {
+        S->err = "factor/variable type mismatch";
+        return LMGPU_INVALID;
+      }
+      f.v[k] = it->second;
+      markedKeys.insert(nf.k[k]);  // 3. markedKeys = keys of the new factors (:199-228)
+    }
+    int bi = -1;
+    for (size_t b = 0; b < S->bkts.size(); b++)
+      if (S->bkts[b].type == nf.type && S->bkts[b].noise_kind == nf.noise_kind) bi = (int)b;
+    if (bi < 0) {
+      lmgpu_isam2::Bkt b;
+      b.type = nf.type;
+      b.noise_kind = nf.noise_kind;
+      b.rows = kFactorRows[nf.type];
+      b.ar = ar;
+      b.ml = kFactorMeas[nf.type];
+      b.nl = nf.noise_kind == LMGPU_N_DIAG ? b.rows : (nf.noise_kind == LMGPU_N_GAUSS ? b.rows * b.rows : 0);
+      b.cols = 1;
+      for (int k = 0; k < ar; k++) b.cols += kVarDim[(k == 0) ? kFactorVar0[nf.type] : kFactorVar1[nf.type]];
+      bi = (int)S->bkts.size();
+      S->bkts.push_back(b);
+    }
+    lmgpu_isam2::Bkt& b = S->bkts[bi];
+    if (b.n + 1 > b.cap) {  // grow the bucket: descriptor arrays and its Jacobian region in the pool
+      const size_t ncap = std::max<size_t>(64, (size_t)b.cap * 2);
+      if ((rc = is_realloc(S, &b.d_vidx, ncap * b.ar, (size_t)b.n * b.ar))) return rc;
+      if ((rc = is_realloc(S, &b.d_meas, ncap * b.ml, (size_t)b.n * b.ml))) return rc;
+      if ((rc = is_realloc(S, &b.d_noise, ncap * std::max(1, b.nl), (size_t)b.n * b.nl))) return rc;
+      int64_t noff;
+      if ((rc = is_pool_alloc(S, ncap * b.rows * b.cols, &noff))) return rc;
+      if (b.joff >= 0) {
+        ISCHECK(hipMemcpyAsync(S->pool + noff, S->pool + b.joff, (size_t)b.n * b.rows * b.cols * sizeof(double), hipMemcpyDeviceToDevice, S->stream));
+        ISCHECK(hipStreamSynchronize(S->stream));
+        is_pool_free(S, b.joff, (size_t)b.cap * b.rows * b.cols);
+      }
+      b.joff = noff;
+      b.cap = (int)ncap;
+    }
+    int32_t vi2[2] = {S->vars[f.v[0]].tidx, ar > 1 ? S->vars[f.v[1]].tidx : 0};
+    ISCHECK(hipMemcpy(b.d_vidx + (size_t)b.n * b.ar, vi2, b.ar * sizeof(int32_t), hipMemcpyHostToDevice));
+    ISCHECK(hipMemcpy(b.d_meas + (size_t)b.n * b.ml, nf.meas.data(), b.ml * sizeof(double), hipMemcpyHostToDevice));
+    if (b.nl) ISCHECK(hipMemcpy(b.d_noise + (size_t)b.n * b.nl, nf.noise.data(), b.nl * sizeof(double), hipMemcpyHostToDevice));
+    f.bucket = bi;
+    f.lidx = b.n++;
+    new_by_bucket[bi].push_back(f.lidx);
+    S->facs.push_back(f);
+  }
+  std::vector<int32_t> observed;  // observedKeys = markedKeys at this point (no unused keys without removals), ascending by key
+  for (uint64_t k : markedKeys) observed.push_back(S->vid_of.at(k));
+  std::set<int32_t> relin;  // relinKeys as vids
+  if (relinNeeded) {
+    // ---- 4. CheckRelinearizationFull (:353-383) on the delta just updated
+    std::vector<double> hdelta((size_t)S->ntot);
+    if (S->ntot) ISCHECK(hipMemcpy(hdelta.data(), S->delta, (size_t)S->ntot * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t v = 0; v < S->vars.size(); v++) {
+      double m = 0;
+      for (int d = 0; d < kVarDim[S->vars[v].type]; d++) m = std::max(m, std::fabs(hdelta[S->vars[v].xoff + d]));
+      if (m >= S->prm.relinearizeThreshold) {
+        relin.insert((int32_t)v);
+        markedKeys.insert(S->vars[v].key);
+      }
+    }
+    if (!relin.empty()) {
+      // ---- 5. findFluid (:431-451): cliques whose separator holds a relinearized variable
+      for (const lmgpu_isam2::Clq& c : S->clq) {
+        if (!c.alive) continue;
+        bool found = false;
+        for (size_t k = c.nfv; k < c.vars.size() && !found; k++) found = relin.count(c.vars[k]) > 0;
+        if (found)
+          for (int k = 0; k < c.nfv; k++) markedKeys.insert(S->vars[c.vars[k]].key);
+      }
+      // ---- 6. theta_.retractMasked(delta_, relinKeys) on the device
+      std::vector<int32_t> sel[kNumVarTypes];
+      for (int32_t v : relin) sel[S->vars[v].type].push_back(S->vars[v].tidx);
+      for (int t = 0; t < kNumVarTypes; t++)
+        if ((rc = is_with_list(S, sel[t], [&](const int32_t* d, int cnt) {
+               hipLaunchKernelGGL(retract_kernel, dim3((cnt + 255) / 256), dim3(256), 0, S->stream, t, cnt, (const double*)S->theta[t], S->theta[t],
+                                  (const int32_t*)S->d_type_xoff[t], (const double*)S->delta, d);
+             })))
+          return rc;
+    }
+    res.variablesRelinearized = (int32_t)markedKeys.size();
+  }
+  // ---- 7. linearizeNewFactors (:454-468) + augmentVariableIndex
+  for (auto& kv : new_by_bucket)
+    if ((rc = is_with_list(S, kv.second, [&](const int32_t* d, int cnt) { is_linearize_sel(S, S->bkts[kv.first], d, cnt); }))) return rc;
+  for (int i = firstNew; i < (int)S->facs.size(); i++)
+    for (int k = 0; k < kFactorArity[S->facs[i].type]; k++) S->vindex[S->facs[i].v[k]].push_back(i);
+  // ---- 8. recalculate (ISAM2.cpp:117-175)
+  if (!markedKeys.empty()) {
+    std::vector<int> bn;
+    std::list<int> orphans;
+    for (uint64_t k : markedKeys) {  // removeTop
+      const int node = S->node_of[S->vid_of.at(k)];
+      if (node >= 0) is_remove_path(S, node, &bn, &orphans);
+    }
+    std::vector<int32_t> affected;  // affectedKeys: frontals of the removed conditionals
+    for (int id : bn)
+      for (int k = 0; k < S->clq[id].nfv; k++) affected.push_back(S->clq[id].vars[k]);
+    for (int id : bn) is_release_clique(S, id);
+    S->tree_dirty = true;
+    std::set<int32_t> affectedSet;
+    if ((double)affected.size() >= (double)S->vars.size() * 0.65) {
+      // ---- recalculateBatch :178-247: reorder, relinearize and re-eliminate everything
+      res.batch = 1;
+      for (int id = 0; id < (int)S->clq.size(); id++)
+        if (S->clq[id].alive) is_release_clique(S, id);
+      S->roots.clear();
+      std::fill(S->node_of.begin(), S->node_of.end(), -1);
+      std::vector<int32_t> vids;
+      for (auto& kv : S->vid_of) vids.push_back(kv.second);
+      std::vector<std::vector<int32_t>> cols;
+      for (int32_t v : vids) cols.push_back(S->vindex[v]);
+      std::map<int32_t, int> groups;
+      if (S->vars.size() > observed.size())
+        for (int32_t v : observed) groups[v] = 1;
+      std::vector<int32_t> perm;
+      if ((rc = is_colamd(S, vids, cols, (int)S->facs.size(), groups, &perm))) return rc;
+      for (size_t b = 0; b < S->bkts.size(); b++) {
+        std::vector<int32_t> all(S->bkts[b].n);
+        for (int i = 0; i < S->bkts[b].n; i++) all[i] = i;
+        if ((rc = is_with_list(S, all, [&](const int32_t* d, int cnt) { is_linearize_sel(S, S->bkts[b], d, cnt); }))) return rc;
+      }
+      std::vector<IsGF> gfs(S->facs.size());
+      for (size_t i = 0; i < S->facs.size(); i++) {
+        gfs[i].kind = 0;
+        gfs[i].id = (int32_t)i;
+        for (int k = 0; k < kFactorArity[S->facs[i].type]; k++) gfs[i].vids.push_back(S->facs[i].v[k]);
+      }
+      if ((rc = is_eliminate(S, gfs, vids, perm))) return rc;
+      for (int32_t v : vids) affectedSet.insert(v);
+      res.variablesReeliminated = (int32_t)vids.size();
+      res.factorsRecalculated = (int32_t)S->facs.size();
+    } else {
+      // ---- recalculateIncremental :250-362
+      std::vector<int32_t> affectedAndNew = affected;
+      affectedAndNew.insert(affectedAndNew.end(), observed.begin(), observed.end());
+      const std::set<int32_t> inSet(affectedAndNew.begin(), affectedAndNew.end());
+      std::set<int32_t> candidates;  // relinearizeAffectedFactors :66-114
+      for (int32_t v : affectedAndNew)
+        for (int32_t f : S->vindex[v]) candidates.insert(f);
+      std::vector<IsGF> gfs;
+      std::map<int, std::vector<int32_t>> relin_by_bucket;
+      for (int32_t idx : candidates) {
+        const lmgpu_isam2::Fac& f = S->facs[idx];
+        bool inside = true, useCached = true;
+        for (int k = 0; k < kFactorArity[f.type]; k++) {
+          if (!inSet.count(f.v[k])) {
+            inside = false;
+            break;
+          }
+          if (relin.count(f.v[k])) useCached = false;
+        }
+        if (!inside) continue;
+        if (!useCached) relin_by_bucket[f.bucket].push_back(f.lidx);
+        IsGF g;
+        g.kind = 0;
+        g.id = idx;
+        for (int k = 0; k < kFactorArity[f.type]; k++) g.vids.push_back(f.v[k]);
+        gfs.push_back(std::move(g));
+      }
+      for (auto& kv : relin_by_bucket)
+        if ((rc = is_with_list(S, kv.second, [&](const int32_t* d, int cnt) { is_linearize_sel(S, S->bkts[kv.first], d, cnt); }))) return rc;
+      res.variablesReeliminated = (int32_t)affectedAndNew.size();
+      res.factorsRecalculated = (int32_t)gfs.size();
+      for (int kind = 1; kind <= 2; kind++)  // GetCachedBoundaryFactors (ISAM2-impl.h:499-509), then the orphan wrappers
+        for (int o : orphans) {
+          IsGF g;
+          g.kind = kind;
+          g.id = o;
+          g.vids.assign(S->clq[o].vars.begin() + S->clq[o].nfv, S->clq[o].vars.end());
+          gfs.push_back(std::move(g));
+        }
+      for (uint64_t k : markedKeys) affectedSet.insert(S->vid_of.at(k));
+      for (int32_t v : affected) affectedSet.insert(v);
+      // VariableIndex of `gfs`, ascending by key
+      std::map<uint64_t, std::vector<int32_t>> vi;
+      for (size_t i = 0; i < gfs.size(); i++)
+        for (int32_t v : gfs[i].vids) vi[S->vars[v].key].push_back((int32_t)i);
+      std::vector<int32_t> vids;
+      std::vector<std::vector<int32_t>> cols;
+      for (auto& kv : vi) {
+        vids.push_back(S->vid_of.at(kv.first));
+        cols.push_back(kv.second);
+      }
+      std::map<int32_t, int> groups;
+      const int group = observed.size() < vids.size() ? 1 : 0;
+      for (int32_t v : observed)
+        if (affectedSet.count(v)) groups.emplace(v, group);
+      std::vector<int32_t> perm;
+      if ((rc = is_colamd(S, vids, cols, (int)gfs.size(), groups, &perm))) return rc;
+      if ((rc = is_eliminate(S, gfs, vids, perm))) return rc;
+    }
+    // deltaReplacedMask_ |= affectedKeysSet
+    std::vector<unsigned char> one(8, 1);
+    for (int32_t v : affectedSet) {
+      S->replaced[v] = 1;
+      ISCHECK(hipMemcpyAsync(S->d_replaced + S->vars[v].xoff, one.data(), kVarDim[S->vars[v].type], hipMemcpyHostToDevice, S->stream));
+    }
+    ISCHECK(hipStreamSynchronize(S->stream));
+    S->any_replaced = S->any_replaced || !affectedSet.empty();
+  }
+  res.cliques = 0;
+  for (int r : S->roots) res.cliques += is_count_subtree(S, r);
+  if (result) *result = res;
+  return LMGPU_OK;
+}
+
+}  // namespace
+
+// =============================================================================================== C ABI (ISAM2)
+extern "C" {
+
+int lmgpu_isam2_create(const lmgpu_config* cfg, const lmgpu_isam2_params* prm, lmgpu_ccolamd_fn ccolamd, void* user, lmgpu_isam2** out) {
+  if (!cfg || !prm || !out || !ccolamd) return LMGPU_INVALID;
+  lmgpu_isam2* S = new lmgpu_isam2();
+  S->cfg = *cfg;
+  S->prm = *prm;
+  S->ccolamd = ccolamd;
+  S->user = user;
+  S->device = cfg->device;
+  *out = S;
+  if (S->device < 0) {
+    S->err = "no HIP device bound to this handle; the incremental path has no CPU fallback";
+    return LMGPU_HIP_ERROR;
+  }
+  ISCHECK(hipSetDevice(S->device));
+  ISCHECK(hipStreamCreate(&S->stream));
+  ISCHECK(hipMalloc((void**)&S->d_status, sizeof(int)));
+  ISCHECK(hipHostMalloc((void**)&S->h_status, sizeof(int)));
+  ISCHECK(hipFuncSetAttribute((const void*)lds_front_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra + 64));
+  return LMGPU_OK;
+}
+
+int lmgpu_isam2_destroy(lmgpu_isam2* S) {
+  if (!S) return LMGPU_INVALID;
+  if (S->device >= 0) {
+    (void)hipSetDevice(S->device);
+    for (int t = 0; t < kNumVarTypes; t++) {
+      if (S->theta[t]) (void)hipFree(S->theta[t]);
+      if (S->est[t]) (void)hipFree(S->est[t]);
+      if (S->d_type_xoff[t]) (void)hipFree(S->d_type_xoff[t]);
+    }
+    for (auto& b : S->bkts) {
+      if (b.d_vidx) (void)hipFree(b.d_vidx);
+      if (b.d_meas) (void)hipFree(b.d_meas);
+      if (b.d_noise) (void)hipFree(b.d_noise);
+    }
+    for (void* p : {(void*)S->delta, (void*)S->ones, (void*)S->d_replaced, (void*)S->d_changed, (void*)S->pool, (void*)S->d_status, (void*)S->d_tree,
+                    (void*)S->d_tree_fx, (void*)S->d_tree_sx, (void*)S->d_tree_list})
+      if (p) (void)hipFree(p);
+    if (S->h_status) (void)hipHostFree(S->h_status);
+    if (S->stream) (void)hipStreamDestroy(S->stream);
+  }
+  delete S;
+  return LMGPU_OK;
+}
+
+const char* lmgpu_isam2_last_error(const lmgpu_isam2* S) { return S ? S->err.c_str() : "null handle"; }
+uint64_t lmgpu_isam2_last_failed_key(const lmgpu_isam2* S) { return S ? S->failed_key : 0; }
+
+int lmgpu_isam2_add_variables(lmgpu_isam2* S, int32_t n, const uint64_t* keys, const int32_t* types, const double* packed_values) {
+  if (!S || n < 0 || (n && (!keys || !types || !packed_values))) return LMGPU_INVALID;
+  const double* p = packed_values;
+  for (int i = 0; i < n; i++) {
+    if (types[i] < 0 || types[i] >= LMGPU_NUM_VAR_TYPES) {
+      S->err = "bad variable type";
+      return LMGPU_INVALID;
+    }
+    lmgpu_isam2::NewVar nv{};
+    nv.key = keys[i];
+    nv.type = types[i];
+    std::memcpy(nv.v, p, kVarStore[types[i]] * sizeof(double));
+    p += kVarStore[types[i]];
+    S->new_vars.push_back(nv);
+  }
+  return LMGPU_OK;
+}
+
+int lmgpu_isam2_add_factors(lmgpu_isam2* S, int32_t factor_type, int32_t n, const uint64_t* keys, const double* meas, int32_t noise_kind,
+                            const double* noise) {
+  if (!S || factor_type < 0 || factor_type >= LMGPU_NUM_FACTOR_TYPES || n < 0) return LMGPU_INVALID;
+  if (noise_kind != LMGPU_N_UNIT && noise_kind != LMGPU_N_DIAG && noise_kind != LMGPU_N_GAUSS) return LMGPU_INVALID;
+  if (n == 0) return LMGPU_OK;
+  if (!keys || !meas || (noise_kind != LMGPU_N_UNIT && !noise)) return LMGPU_INVALID;
+  const int ar = kFactorArity[factor_type], rows = kFactorRows[factor_type], ml = kFactorMeas[factor_type];
+  const int nl = noise_kind == LMGPU_N_DIAG ? rows : (noise_kind == LMGPU_N_GAUSS ? rows * rows : 0);
+  for (int i = 0; i < n; i++) {
+    lmgpu_isam2::NewFac f;
+    f.type = factor_type;
+    f.noise_kind = noise_kind;
+    f.k[0] = keys[(size_t)i * ar];
+    f.k[1] = ar > 1 ? keys[(size_t)i * ar + 1] : 0;
+    f.meas.assign(meas + (size_t)i * ml, meas + (size_t)(i + 1) * ml);
+    if (nl) f.noise.assign(noise + (size_t)i * nl, noise + (size_t)(i + 1) * nl);
+    S->new_facs.push_back(std::move(f));
+  }
+  return LMGPU_OK;
+}
+
+int lmgpu_isam2_update(lmgpu_isam2* S, int32_t force_relinearize, lmgpu_isam2_result* out) {
+  if (!S) return LMGPU_INVALID;
+  if (S->device < 0) {
+    S->err = "no HIP device bound to this handle; the incremental path has no CPU fallback";
+    return LMGPU_HIP_ERROR;
+  }
+  ISCHECK(hipSetDevice(S->device));
+  return is_update(S, force_relinearize != 0, out);
+}
+
+int lmgpu_isam2_num_variables(const lmgpu_isam2* S) { return S ? (int)S->vars.size() : -1; }
+int lmgpu_isam2_num_factors(const lmgpu_isam2* S) { return S ? (int)S->facs.size() : -1; }
+
+int lmgpu_isam2_get_values(lmgpu_isam2* S, int32_t which, uint64_t* keys_out, int32_t* types_out, double* packed_out) {
+  if (!S || which < 0 || which > 2) return LMGPU_INVALID;
+  if (S->device < 0) return LMGPU_HIP_ERROR;
+  ISCHECK(hipSetDevice(S->device));
+  int rc;
+  if (which == 1) {  // calculateBestEstimate: full back-substitution (ISAM2.cpp:763-766)
+    if ((rc = is_update_delta(S, true))) return rc;
+  } else if (which == 0 && S->any_replaced) {  // getDelta (:776-779)
+    if ((rc = is_update_delta(S, false))) return rc;
+  }
+  std::vector<std::vector<double>> host(kNumVarTypes);
+  for (int t = 0; t < kNumVarTypes; t++) {
+    const int n = S->type_count[t];
+    if (n == 0) continue;
+    const double* src = S->theta[t];
+    if (which != 2) {  // theta_.retract(delta_)
+      hipLaunchKernelGGL(retract_kernel, dim3((n + 255) / 256), dim3(256), 0, S->stream, t, n, (const double*)S->theta[t], S->est[t],
+                         (const int32_t*)S->d_type_xoff[t], (const double*)S->delta, (const int32_t*)nullptr);
+      src = S->est[t];
+    }
+    host[t].resize((size_t)n * kVarStore[t]);
+    ISCHECK(hipMemcpyAsync(host[t].data(), src, host[t].size() * sizeof(double), hipMemcpyDeviceToHost, S->stream));
+  }
+  ISCHECK(hipStreamSynchronize(S->stream));
+  for (auto& kv : S->vid_of) {  // ascending by key
+    const lmgpu_isam2::Var& v = S->vars[kv.second];
+    if (keys_out) *keys_out++ = v.key;
+    if (types_out) *types_out++ = v.type;
+    if (packed_out) {
+      std::memcpy(packed_out, &host[v.type][(size_t)v.tidx * kVarStore[v.type]], kVarStore[v.type] * sizeof(double));
+      packed_out += kVarStore[v.type];
+    }
+  }
+  return LMGPU_OK;
+}
+
+int lmgpu_isam2_get_delta(lmgpu_isam2* S, double* packed) {
+  if (!S || !packed) return LMGPU_INVALID;
+  if (S->device < 0) return LMGPU_HIP_ERROR;
+  ISCHECK(hipSetDevice(S->device));
+  int rc;
+  if (S->any_replaced && (rc = is_update_delta(S, false))) return rc;
+  std::vector<double> h((size_t)S->ntot);
+  if (S->ntot) ISCHECK(hipMemcpy(h.data(), S->delta, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+  for (auto& kv : S->vid_of) {
+    const lmgpu_isam2::Var& v = S->vars[kv.second];
+    for (int d = 0; d < kVarDim[v.type]; d++) *packed++ = h[v.xoff + d];
+  }
+  return LMGPU_OK;
+}
+
+static void is_collect(const lmgpu_isam2* S, int id, std::vector<int32_t>* out) {
+  out->push_back(id);
+  for (int ch : S->clq[id].children) is_collect(S, ch, out);
+}
+
+int lmgpu_isam2_num_cliques(lmgpu_isam2* S) {
+  if (!S) return -1;
+  S->snap.clear();
+  for (int r : S->roots) is_collect(S, r, &S->snap);
+  return (int)S->snap.size();
+}
+
+int lmgpu_isam2_clique_info(const lmgpu_isam2* S, int32_t i, int32_t* info5) {
+  if (!S || !info5 || i < 0 || i >= (int)S->snap.size()) return LMGPU_INVALID;
+  const lmgpu_isam2::Clq& c = S->clq[S->snap[i]];
+  info5[0] = (int32_t)c.vars.size();
+  info5[1] = c.nfv;
+  info5[2] = c.nf;
+  info5[3] = c.n;
+  info5[4] = -1;
+  if (c.parent >= 0) info5[4] = (int32_t)(std::find(S->snap.begin(), S->snap.end(), c.parent) - S->snap.begin());
+  return LMGPU_OK;
+}
+
+int lmgpu_isam2_get_clique(lmgpu_isam2* S, int32_t i, uint64_t* keys, double* RSd_colmajor) {
+  if (!S || i < 0 || i >= (int)S->snap.size()) return LMGPU_INVALID;
+  const lmgpu_isam2::Clq& c = S->clq[S->snap[i]];
+  if (keys)
+    for (size_t k = 0; k < c.vars.size(); k++) keys[k] = S->vars[c.vars[k]].key;
+  if (RSd_colmajor) {
+    if (S->device < 0) return LMGPU_HIP_ERROR;
+    std::vector<double> rm((size_t)c.nf * c.n);
+    ISCHECK(hipMemcpy(rm.data(), S->pool + c.rsd_off, rm.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int r = 0; r < c.nf; r++)
+      for (int j = 0; j < c.n; j++) RSd_colmajor[(size_t)j * c.nf + r] = rm[(size_t)r * c.n + j];
+  }
+  return LMGPU_OK;
+}
+
+}  // extern "C"

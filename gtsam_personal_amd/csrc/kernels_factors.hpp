@@ -28,6 +28,8 @@ struct BucketDev {
   const int32_t* epos;    // n : position in the error buffer (= rank of the factor by graph index)
   int32_t robust;         // lmgpu_robust_kind: noiseModel::Robust around the Gaussian model (0 = none)
   double rk;              // its tuning constant
+  const int32_t* sel;     // null: all n factors of the bucket; else n indices into the bucket (ISAM2 relinearizes a subset,
+                          // gtsam/nonlinear/ISAM2.cpp:66-114)
 };
 
 struct ValuesDev {
@@ -226,6 +228,43 @@ __global__ __launch_bounds__(256) void sfm_linearize_kernel(BucketDev b, ValuesD
   }
 }
 
+// the same for a SUBSET of the bucket (b.sel): one lane per selected factor, direct stores (the subset is not contiguous)
+__global__ __launch_bounds__(256) void sfm_linearize_sel_kernel(BucketDev b, ValuesDev vals) {
+  const int fi = blockIdx.x * 256 + threadIdx.x;
+  if (fi >= b.n) return;
+  const int f = b.sel[fi];
+  const int ci = b.vidx[2 * f], pi_ = b.vidx[2 * f + 1];
+  double cam[15], pt[3], Jl[26];
+  const double* cp = vals.v[3] + (size_t)ci * 15;
+#pragma unroll
+  for (int i = 0; i < 15; i++) cam[i] = cp[i];
+  const double* pp = vals.v[2] + (size_t)pi_ * 3;
+  pt[0] = pp[0]; pt[1] = pp[1]; pt[2] = pp[2];
+  double pix[2], H1[18], H2[6];
+  if (sfm_project<true>(cam, pt, pix, H1, H2)) {
+#pragma unroll
+    for (int c = 0; c < 9; c++) {
+      Jl[2 * c] = H1[c];
+      Jl[2 * c + 1] = H1[9 + c];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      Jl[18 + 2 * c] = H2[c];
+      Jl[18 + 2 * c + 1] = H2[3 + c];
+    }
+    Jl[24] = b.meas[2 * f] - pix[0];
+    Jl[25] = b.meas[2 * f + 1] - pix[1];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 26; i++) Jl[i] = 0.0;
+  }
+  if (b.noise_kind != 0) whiten_block<2, 13>(Jl, b.noise_kind, b.noise + (size_t)f * (b.noise_kind == 2 ? 2 : 4));
+  if (b.robust) robust_reweight<2, 13>(Jl, b.robust, b.rk);
+  double* out = b.J + (size_t)f * 26;
+#pragma unroll
+  for (int i = 0; i < 26; i++) out[i] = Jl[i];
+}
+
 __global__ __launch_bounds__(256) void sfm_error_kernel(BucketDev b, ValuesDev vals, double* __restrict__ ebuf) {
   const int f = blockIdx.x * 256 + threadIdx.x;
   if (f >= b.n) return;
@@ -420,8 +459,9 @@ __device__ __forceinline__ void eval_projection(const double* m, const double* v
 // Generic bucket kernel.  TYPE selects the evaluator; M rows, D0/D1 tangent dims, S0/S1 stored doubles, T0/T1 value types.
 template <int TYPE, int M, int D0, int D1, int ML, int T0, int S0, int T1, int S1, bool JAC>
 __global__ __launch_bounds__(128) void generic_factor_kernel(BucketDev b, ValuesDev vals, double* __restrict__ ebuf) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= b.n) return;
+  const int fi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (fi >= b.n) return;
+  const int f = b.sel ? b.sel[fi] : fi;
   constexpr int AR = (D1 > 0) ? 2 : 1;
   constexpr int COLS = D0 + D1 + 1;
   double m[ML], v0[S0], v1[S1 > 0 ? S1 : 1];
@@ -610,10 +650,13 @@ __global__ __launch_bounds__(256) void reduce_stage2(const double* __restrict__ 
 
 // ---------------------------------------------------------------- retract (a15)
 // Values::retract gtsam/nonlinear/Values.cpp:53-64; one thread per variable of a type.
-__global__ __launch_bounds__(256) void retract_kernel(int type, int n, const double* __restrict__ cur, double* __restrict__ out,
-                                                       const int32_t* __restrict__ xoff, const double* __restrict__ delta) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+// sel (may be null): the n variables to retract as indices into the type array (ISAM2's retractMasked, gtsam/nonlinear/ISAM2.cpp:465);
+// cur == out is allowed (every lane reads its variable before it writes it).
+__global__ __launch_bounds__(256) void retract_kernel(int type, int n, const double* cur, double* out, const int32_t* __restrict__ xoff,
+                                                       const double* __restrict__ delta, const int32_t* __restrict__ sel = nullptr) {
+  const int li = blockIdx.x * 256 + threadIdx.x;
+  if (li >= n) return;
+  const int i = sel ? sel[li] : li;
   const double* d = delta + xoff[i];
   if (type == 0) {  // Pose2: compose(Pose2(d0,d1,d2))  gtsam/geometry/Pose2.cpp:100-110
     const double* v = cur + (size_t)i * 3;

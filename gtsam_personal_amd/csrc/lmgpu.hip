@@ -344,6 +344,7 @@ BucketDev bucket_dev(lmgpu_handle* h, const Bucket& b) {
   d.noise = b.d_noise;
   d.J = h->pool + b.joff;
   d.epos = b.d_epos;
+  d.sel = nullptr;
   return d;
 }
 
@@ -1048,7 +1049,7 @@ int do_retract(lmgpu_handle* h, int from, int to) {
     const int n = h->plan.type_count[t];
     if (n == 0) continue;
     hipLaunchKernelGGL(retract_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, t, n, (const double*)h->vals[from][t], h->vals[to][t],
-                       (const int32_t*)h->type_xoff[t], (const double*)h->delta);
+                       (const int32_t*)h->type_xoff[t], (const double*)h->delta, (const int32_t*)nullptr);
   }
   HIPCHECK(hipGetLastError());
   return LMGPU_OK;
@@ -2698,3 +2699,5 @@ int lmgpu_peak_hbm_copy(int32_t device, int64_t bytes, int32_t iters, double* gb
 }
 
 }  // extern "C"
+
+#include "isam2.hpp"

@@ -11,49 +11,25 @@
 
 namespace lmgpu {
 
-std::string Plan::build(int32_t lds_limit_n) {
-  const int32_t n = n_vars;
+// The symbolic multifrontal analysis for factors of ANY arity (variables 0 .. n-1 in elimination order, factors in index order):
+// elimination tree, junction tree with the reference's clique-merge rule, fronts in post-order.  Plan::build feeds it the
+// unary / binary factors of a nonlinear graph; the incremental path (csrc/isam2.hpp) feeds it the affected factors, the
+// cached boundary factors and the orphan subtrees' separators (gtsam/nonlinear/ISAM2.cpp:250-362).
+std::string symbolic_multifrontal(int32_t n, const std::vector<int32_t>& keyrank, const std::vector<std::vector<int32_t>>& fvars,
+                                  SymbolicFronts* out) {
   const int32_t none = -1;
-  if (n <= 0) return "no variables";
-  dims.resize(n);
-  xoff.assign(n + 1, 0);
-  voff.assign(n + 1, 0);
-  tidx.resize(n);
-  for (int t = 0; t < kNumVarTypes; t++) type_count[t] = 0;
-  for (int32_t s = 0; s < n; s++) {
-    const int t = types[s];
-    if (t < 0 || t >= kNumVarTypes) return "bad variable type";
-    dims[s] = kVarDim[t];
-    xoff[s + 1] = xoff[s] + dims[s];
-    voff[s + 1] = voff[s] + kVarStore[t];
-    tidx[s] = type_count[t]++;
-  }
-  // rank of each slot's Key (separators are sorted by Key, Scatter.cpp:69-72)
-  std::vector<int32_t> bykey(n), keyrank(n);
-  std::iota(bykey.begin(), bykey.end(), 0);
-  std::sort(bykey.begin(), bykey.end(), [&](int32_t a, int32_t b) { return keys[a] < keys[b]; });
-  for (int32_t r = 0; r < n; r++) {
-    if (r > 0 && keys[bykey[r]] == keys[bykey[r - 1]]) return "duplicate variable key";
-    keyrank[bykey[r]] = r;
-  }
-
-  // factors sorted by graph index (VariableIndex lists factor indices ascending)
-  std::sort(factors.begin(), factors.end(), [](const FactorRef& a, const FactorRef& b) { return a.graph_index < b.graph_index; });
-  const int32_t m = (int32_t)factors.size();
+  const int32_t m = (int32_t)fvars.size();
   std::vector<std::vector<int32_t>> vi(n);
-  for (int32_t i = 0; i < m; i++) {
-    const FactorRef& f = factors[i];
-    for (int k = 0; k < 2; k++) {
-      if (f.slots[k] < 0) continue;
-      if (f.slots[k] >= n) return "factor references unknown slot";
-      if (k == 1 && f.slots[1] == f.slots[0]) return "factor with repeated variable";
-      vi[f.slots[k]].push_back(i);
+  for (int32_t i = 0; i < m; i++)
+    for (int32_t v : fvars[i]) {
+      if (v < 0 || v >= n) return "factor references unknown variable";
+      vi[v].push_back(i);
     }
-  }
   for (int32_t s = 0; s < n; s++)
     if (vi[s].empty()) return "EliminationTree: given ordering contains variables that are not involved in the factor graph";
 
   // ---- elimination tree (EliminationTree-inst.h:94-134); `anc` only accelerates the root walk ----
+  std::vector<int32_t>& etree_parent = out->etree_parent;
   etree_parent.assign(n, none);
   std::vector<int32_t> anc(n, none), prevCol(m, none);
   std::vector<std::vector<int32_t>> echildren(n), efactors(n);
@@ -99,13 +75,11 @@ std::string Plan::build(int32_t lds_limit_n) {
     std::vector<int32_t>& s = sep[j];
     s.clear();
     for (int32_t f : efactors[j])
-      for (int k = 0; k < 2; k++) {
-        int32_t v = factors[f].slots[k];
-        if (v >= 0 && v != j && mark[v] != j) {
+      for (int32_t v : fvars[f])
+        if (v != j && mark[v] != j) {
           mark[v] = j;
           s.push_back(v);
         }
-      }
     for (int32_t c : echildren[j])
       for (int32_t v : sep[c])
         if (v != j && mark[v] != j) {
@@ -162,9 +136,8 @@ std::string Plan::build(int32_t lds_limit_n) {
   }
 
   // ---- fronts in post-order over the junction tree ----
-  fronts.clear();
-  roots.clear();
-  front_of_var.assign(n, -1);
+  out->fronts.clear();
+  out->roots.clear();
   std::vector<int32_t> front_id(n, -1);
   for (int32_t r : eroots) {
     stack.emplace_back(r, 0);
@@ -175,38 +148,99 @@ std::string Plan::build(int32_t lds_limit_n) {
         const int32_t c = jchildren[j][top.second++];
         stack.emplace_back(c, 0);
       } else {
-        Front fr;
-        fr.n_frontal_vars = (int32_t)jfront[j].size();
-        fr.vars = jfront[j];
-        fr.vars.insert(fr.vars.end(), sep[j].begin(), sep[j].end());
-        fr.col_off.resize(fr.vars.size() + 1);
-        int32_t off = 0;
-        for (size_t k = 0; k < fr.vars.size(); k++) {
-          fr.col_off[k] = off;
-          off += dims[fr.vars[k]];
-          if ((int32_t)k == fr.n_frontal_vars - 1) fr.nf = off;
-        }
-        fr.col_off[fr.vars.size()] = off;
-        fr.n = off + 1;
+        SymbolicFronts::F fr;
+        fr.frontals = jfront[j];
+        fr.sep = sep[j];
         fr.factors = jfactors[j];
         int32_t lvl = 0;
         for (int32_t c : jchildren[j]) {
           fr.children.push_back(front_id[c]);
-          lvl = std::max(lvl, fronts[front_id[c]].level + 1);
+          lvl = std::max(lvl, out->fronts[front_id[c]].level + 1);
         }
         fr.level = lvl;
-        fr.cls = (fr.n <= lds_limit_n) ? 0 : 1;
-        const int32_t id = (int32_t)fronts.size();
-        for (int32_t c : fr.children) fronts[c].parent = id;
-        for (int32_t k = 0; k < fr.n_frontal_vars; k++) front_of_var[fr.vars[k]] = id;
+        const int32_t id = (int32_t)out->fronts.size();
+        for (int32_t c : fr.children) out->fronts[c].parent = id;
         front_id[j] = id;
-        max_front_n = std::max(max_front_n, fr.n);
-        n_levels = std::max(n_levels, lvl + 1);
-        fronts.push_back(std::move(fr));
+        out->fronts.push_back(std::move(fr));
         stack.pop_back();
       }
     }
-    roots.push_back(front_id[r]);
+    out->roots.push_back(front_id[r]);
+  }
+  return "";
+}
+
+std::string Plan::build(int32_t lds_limit_n) {
+  const int32_t n = n_vars;
+  if (n <= 0) return "no variables";
+  dims.resize(n);
+  xoff.assign(n + 1, 0);
+  voff.assign(n + 1, 0);
+  tidx.resize(n);
+  for (int t = 0; t < kNumVarTypes; t++) type_count[t] = 0;
+  for (int32_t s = 0; s < n; s++) {
+    const int t = types[s];
+    if (t < 0 || t >= kNumVarTypes) return "bad variable type";
+    dims[s] = kVarDim[t];
+    xoff[s + 1] = xoff[s] + dims[s];
+    voff[s + 1] = voff[s] + kVarStore[t];
+    tidx[s] = type_count[t]++;
+  }
+  // rank of each slot's Key (separators are sorted by Key, Scatter.cpp:69-72)
+  std::vector<int32_t> bykey(n), keyrank(n);
+  std::iota(bykey.begin(), bykey.end(), 0);
+  std::sort(bykey.begin(), bykey.end(), [&](int32_t a, int32_t b) { return keys[a] < keys[b]; });
+  for (int32_t r = 0; r < n; r++) {
+    if (r > 0 && keys[bykey[r]] == keys[bykey[r - 1]]) return "duplicate variable key";
+    keyrank[bykey[r]] = r;
+  }
+
+  // factors sorted by graph index (VariableIndex lists factor indices ascending)
+  std::sort(factors.begin(), factors.end(), [](const FactorRef& a, const FactorRef& b) { return a.graph_index < b.graph_index; });
+  const int32_t m = (int32_t)factors.size();
+  std::vector<std::vector<int32_t>> fvars(m);
+  for (int32_t i = 0; i < m; i++) {
+    const FactorRef& f = factors[i];
+    for (int k = 0; k < 2; k++) {
+      if (f.slots[k] < 0) continue;
+      if (f.slots[k] >= n) return "factor references unknown slot";
+      if (k == 1 && f.slots[1] == f.slots[0]) return "factor with repeated variable";
+      fvars[i].push_back(f.slots[k]);
+    }
+  }
+  SymbolicFronts sf;
+  const std::string e = symbolic_multifrontal(n, keyrank, fvars, &sf);
+  if (!e.empty()) return e;
+  etree_parent = sf.etree_parent;
+
+  // ---- fronts in post-order over the junction tree ----
+  fronts.clear();
+  roots = sf.roots;
+  front_of_var.assign(n, -1);
+  for (size_t id = 0; id < sf.fronts.size(); id++) {
+    SymbolicFronts::F& sfr = sf.fronts[id];
+    Front fr;
+    fr.n_frontal_vars = (int32_t)sfr.frontals.size();
+    fr.vars = sfr.frontals;
+    fr.vars.insert(fr.vars.end(), sfr.sep.begin(), sfr.sep.end());
+    fr.col_off.resize(fr.vars.size() + 1);
+    int32_t off = 0;
+    for (size_t k = 0; k < fr.vars.size(); k++) {
+      fr.col_off[k] = off;
+      off += dims[fr.vars[k]];
+      if ((int32_t)k == fr.n_frontal_vars - 1) fr.nf = off;
+    }
+    fr.col_off[fr.vars.size()] = off;
+    fr.n = off + 1;
+    fr.factors.swap(sfr.factors);
+    fr.children.swap(sfr.children);
+    fr.parent = sfr.parent;
+    fr.level = sfr.level;
+    fr.cls = (fr.n <= lds_limit_n) ? 0 : 1;
+    for (int32_t k = 0; k < fr.n_frontal_vars; k++) front_of_var[fr.vars[k]] = (int32_t)id;
+    max_front_n = std::max(max_front_n, fr.n);
+    n_levels = std::max(n_levels, fr.level + 1);
+    fronts.push_back(std::move(fr));
   }
   return "";
 }

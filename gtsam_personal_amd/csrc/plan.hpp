@@ -41,6 +41,21 @@ struct Front {
   int32_t cls = 0;               // 0: assembled + factored in LDS by one workgroup; 1: lives in HBM, multi-kernel dense path
 };
 
+// result of symbolic_multifrontal: fronts in post-order (children before parents)
+struct SymbolicFronts {
+  struct F {
+    std::vector<int32_t> frontals;  // in the reference's orderedFrontalKeys order
+    std::vector<int32_t> sep;       // sorted by key rank
+    std::vector<int32_t> factors;   // own factors first, then merged children's (reference order)
+    std::vector<int32_t> children;  // front indices, reference child order
+    int32_t parent = -1, level = 0;
+  };
+  std::vector<F> fronts;
+  std::vector<int32_t> roots, etree_parent;
+};
+std::string symbolic_multifrontal(int32_t n, const std::vector<int32_t>& keyrank, const std::vector<std::vector<int32_t>>& fvars,
+                                  SymbolicFronts* out);
+
 struct Plan {
   // inputs
   int32_t n_vars = 0;

@@ -1,0 +1,179 @@
+"""ISAM2 mirror over the C ABI (include/lmgpu.h, lmgpu_isam2_*): same names and argument meaning as the reference interface
+  ISAM2Params / ISAM2GaussNewtonParams   gtsam/nonlinear/ISAM2Params.h:35-60, 133-246
+  ISAM2::update / calculateEstimate / calculateBestEstimate / getLinearizationPoint / getDelta   gtsam/nonlinear/ISAM2.h:146-260
+  ISAM2Result                             gtsam/nonlinear/ISAM2Result.h:60-93
+All numerics run in liblmgpu.so on the GPU; this file only marshals arrays.  The fill-reducing ordering is the caller's: pass
+`ccolamd`, a callable (n_rows, n_cols, col_ptr, row_idx, cmember) -> permutation that runs the CCOLAMD the reference side links
+(Ordering::ColamdConstrained, gtsam/inference/Ordering.cpp:50-125, with its knobs)."""
+from __future__ import annotations
+
+import ctypes as ct
+
+import numpy as np
+
+from . import _lib
+from .graph import FACTOR_ARITY, F_PRIOR_CAM, F_SFM, N_UNIT, VAR_DIM, VAR_STORE, VAR_STORE_DEV, NonlinearFactorGraph, Values
+
+
+class ISAM2GaussNewtonParams:
+    def __init__(self, wildfireThreshold=0.001):
+        self.wildfireThreshold = wildfireThreshold
+
+
+class ISAM2Params:
+    """ISAM2Params(optimizationParams, relinearizeThreshold, relinearizeSkip, enableRelinearization) — ISAM2Params.h:211-246"""
+
+    def __init__(self, optimizationParams=None, relinearizeThreshold=0.1, relinearizeSkip=10, enableRelinearization=True):
+        self.optimizationParams = optimizationParams or ISAM2GaussNewtonParams()
+        self.relinearizeThreshold = relinearizeThreshold
+        self.relinearizeSkip = relinearizeSkip
+        self.enableRelinearization = enableRelinearization
+
+
+class ISAM2Result:
+    def __init__(self, r):
+        self.variablesRelinearized = r.variablesRelinearized
+        self.variablesReeliminated = r.variablesReeliminated
+        self.factorsRecalculated = r.factorsRecalculated
+        self.cliques = r.cliques
+        self.batch = bool(r.batch)
+
+    def as_dict(self):
+        return dict(variablesRelinearized=self.variablesRelinearized, variablesReeliminated=self.variablesReeliminated,
+                    factorsRecalculated=self.factorsRecalculated, cliques=self.cliques, batch=int(self.batch))
+
+
+class ISAM2:
+    def __init__(self, params: ISAM2Params | None = None, ccolamd=None, device: int = 0):
+        if ccolamd is None:
+            raise ValueError("ISAM2 needs the caller's constrained COLAMD (ccolamd=...): the ordering is a boundary input")
+        self.params = params or ISAM2Params()
+        self.lib = _lib.load()
+        self._ccolamd = ccolamd
+
+        def _cb(user, n_rows, n_cols, col_ptr, row_idx, cmember, perm_out):
+            try:
+                cp = np.ctypeslib.as_array(col_ptr, shape=(n_cols + 1,))
+                ri = np.ctypeslib.as_array(row_idx, shape=(max(1, int(cp[n_cols])),))
+                cm = np.ctypeslib.as_array(cmember, shape=(n_cols,))
+                np.ctypeslib.as_array(perm_out, shape=(n_cols,))[:] = self._ccolamd(n_rows, n_cols, cp, ri, cm)
+                return 1
+            except Exception:  # noqa: BLE001 -- must not unwind through the C caller
+                import traceback
+                traceback.print_exc()
+                return 0
+
+        self._cb = _lib.CCOLAMD_FN(_cb)  # keep alive
+        p = self.params
+        cp = _lib.lmgpu_isam2_params(float(p.relinearizeThreshold), int(p.relinearizeSkip), int(bool(p.enableRelinearization)),
+                                     float(p.optimizationParams.wildfireThreshold))
+        cfg = _lib.lmgpu_config(device, 0, 1, 0)
+        self._h = ct.c_void_p()
+        rc = self.lib.lmgpu_isam2_create(ct.byref(cfg), ct.byref(cp), ct.cast(self._cb, ct.c_void_p), None, ct.byref(self._h))
+        self._check(rc)
+        self._u0v0 = {}  # constant principal points of Cal3Bundler cameras (do not travel, see lmgpu.h CAM_BUNDLER)
+
+    def _check(self, rc):
+        if rc == _lib.LMGPU_OK:
+            return
+        msg = self.lib.lmgpu_isam2_last_error(self._h) if self._h else b""
+        if rc == _lib.LMGPU_INDETERMINATE:
+            raise _lib.IndeterminantLinearSystemException(int(self.lib.lmgpu_isam2_last_failed_key(self._h)))
+        raise _lib.LmgpuError(f"lmgpu status {rc}: {msg.decode() if msg else ''}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.lmgpu_isam2_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def update(self, newFactors: NonlinearFactorGraph | None = None, newTheta: Values | None = None, force_relinearize=False) -> ISAM2Result:
+        """ISAM2::update(newFactors, newTheta) (gtsam/nonlinear/ISAM2.h:146-156; no factor removal / constraints)"""
+        U64 = ct.POINTER(ct.c_uint64)
+        if newTheta is not None and newTheta.size():
+            keys = np.array(newTheta.keys(), dtype=np.uint64)
+            types = np.array([newTheta.type(k) for k in newTheta.keys()], dtype=np.int32)
+            packed = np.concatenate([newTheta.at(k)[:VAR_STORE_DEV[newTheta.type(k)]] for k in newTheta.keys()]).astype(np.float64)
+            for k in newTheta.keys():
+                if newTheta.type(k) == 3:
+                    self._u0v0[k] = newTheta.at(k)[15:17].copy()
+            self._check(self.lib.lmgpu_isam2_add_variables(self._h, len(keys), keys.ctypes.data_as(U64), types.ctypes.data_as(_lib._I),
+                                                           packed.ctypes.data_as(_lib._D)))
+        if newFactors is not None and newFactors.size():
+            rec = [None] * newFactors.size()
+            for ftype, kind, gi, keys, meas, noise, models in newFactors.buckets():
+                for i, g in enumerate(gi.tolist()):
+                    if models[i].robust_kind:
+                        raise NotImplementedError("robust noise models are not bound in the incremental path")
+                    rec[g] = (ftype, kind, keys[i], meas[i], None if kind == N_UNIT else noise[i])
+            for ftype, kind, keys, meas, noise in rec:  # one call per factor keeps the graph order across buckets
+                m = np.array(meas, dtype=np.float64)
+                if ftype == F_SFM:
+                    m = m - self._u0v0[int(keys[0])]
+                if ftype == F_PRIOR_CAM:
+                    m = m[:15]
+                kk = np.ascontiguousarray(keys[:FACTOR_ARITY[ftype]], dtype=np.uint64)
+                nz = None if noise is None else np.ascontiguousarray(noise, dtype=np.float64)
+                self._check(self.lib.lmgpu_isam2_add_factors(self._h, ftype, 1, kk.ctypes.data_as(U64), np.ascontiguousarray(m).ctypes.data_as(_lib._D),
+                                                             kind, None if nz is None else nz.ctypes.data_as(_lib._D)))
+        res = _lib.lmgpu_isam2_result()
+        self._check(self.lib.lmgpu_isam2_update(self._h, int(force_relinearize), ct.byref(res)))
+        return ISAM2Result(res)
+
+    def _values(self, which) -> Values:
+        n = self.lib.lmgpu_isam2_num_variables(self._h)
+        keys = np.zeros(n, dtype=np.uint64)
+        types = np.zeros(n, dtype=np.int32)
+        self._check(self.lib.lmgpu_isam2_get_values(self._h, 2, keys.ctypes.data_as(ct.POINTER(ct.c_uint64)), types.ctypes.data_as(_lib._I), None))
+        packed = np.zeros(int(sum(VAR_STORE_DEV[t] for t in types)))
+        self._check(self.lib.lmgpu_isam2_get_values(self._h, which, None, None, packed.ctypes.data_as(_lib._D)))
+        out, o = Values(), 0
+        for k, t in zip(keys.tolist(), types.tolist()):
+            v = np.zeros(VAR_STORE[t])
+            v[:VAR_STORE_DEV[t]] = packed[o:o + VAR_STORE_DEV[t]]
+            if t == 3:
+                v[15:17] = self._u0v0[k]
+            out.insert(k, t, v)
+            o += VAR_STORE_DEV[t]
+        return out
+
+    def calculateEstimate(self) -> Values:
+        return self._values(0)
+
+    def calculateBestEstimate(self) -> Values:
+        return self._values(1)
+
+    def getLinearizationPoint(self) -> Values:
+        return self._values(2)
+
+    def getDelta(self):
+        """{key: vector} (VectorValues)"""
+        lin = self._values(2)
+        d = np.zeros(sum(VAR_DIM[lin.type(k)] for k in lin.keys()))
+        self._check(self.lib.lmgpu_isam2_get_delta(self._h, d.ctypes.data_as(_lib._D)))
+        out, o = {}, 0
+        for k in lin.keys():
+            n = VAR_DIM[lin.type(k)]
+            out[k] = d[o:o + n].copy()
+            o += n
+        return out
+
+    def size(self):
+        return self.lib.lmgpu_isam2_num_variables(self._h)
+
+    def cliques(self):
+        """parity tap: [(keys, n_frontal_keys, RSd (nf, n), parent index)] depth-first from the roots"""
+        out = []
+        for i in range(self.lib.lmgpu_isam2_num_cliques(self._h)):
+            info = np.zeros(5, dtype=np.int32)
+            self._check(self.lib.lmgpu_isam2_clique_info(self._h, i, info.ctypes.data_as(_lib._I)))
+            keys = np.zeros(info[0], dtype=np.uint64)
+            rsd = np.empty(info[2] * info[3])
+            self._check(self.lib.lmgpu_isam2_get_clique(self._h, i, keys.ctypes.data_as(ct.POINTER(ct.c_uint64)), rsd.ctypes.data_as(_lib._D)))
+            out.append(([int(k) for k in keys], int(info[1]), rsd.reshape(info[3], info[2]).T.copy(), int(info[4])))
+        return out

@@ -256,6 +256,55 @@ int lmgpu_joint_marginal_covariance(lmgpu_handle* h, int32_t nslots, const int32
 int lmgpu_selftest_chain_schedule(int n, int nf, int i0, int nsteps, int far_pct);
 int lmgpu_comm_init_local(lmgpu_handle* h, lmgpu_local_group* g);
 
+/* ---- ISAM2 (gtsam/nonlinear/ISAM2.h): incremental smoothing on a device-resident Bayes tree (BASELINE config 5) ----
+ * ISAM2::update(newFactors, newTheta) (gtsam/nonlinear/ISAM2.cpp:419-480) = lmgpu_isam2_add_variables + lmgpu_isam2_add_factors
+ * (the pending input) + lmgpu_isam2_update: add the variables, (every relinearizeSkip-th update) refresh delta, mark and
+ * relinearize the variables whose delta exceeds relinearizeThreshold, relinearize the affected factor subset on the device,
+ * remove the top of the Bayes tree, re-eliminate it with the cached boundary factors of the orphaned subtrees under a constrained
+ * COLAMD ordering (:250-362; batch fallback when >= 65 % of the variables are affected, :156-159), and keep the tree on the device.
+ * ISAM2Params honoured: ISAM2GaussNewtonParams::wildfireThreshold, relinearizeThreshold (one double), relinearizeSkip,
+ * enableRelinearization (gtsam/nonlinear/ISAM2Params.h:133-246); Cholesky factorisation; cacheLinearizedFactors semantics.
+ * Not bound: Dogleg, QR, factor removal, marginalizeLeaves, fixed variables, per-type thresholds (LMGPU_INVALID / not offered).
+ *
+ * The fill-reducing ordering is a boundary input like in the batch path, but here it is needed per update: the caller hands over
+ * ITS ccolamd (the reference side: the one Ordering::ColamdConstrained calls, gtsam/inference/Ordering.cpp:50-125) as a callback:
+ *   int fn(user, n_rows, n_cols, col_ptr[n_cols + 1], row_idx[nnz], cmember[n_cols], perm_out[n_cols]) -> 1 on success,
+ * to be run with GTSAM's knobs (CCOLAMD_DENSE_ROW = CCOLAMD_DENSE_COL = -1, Ordering.cpp:94-97); perm_out[j] = the column eliminated j-th. */
+typedef struct lmgpu_isam2 lmgpu_isam2;
+typedef int (*lmgpu_ccolamd_fn)(void* user, int32_t n_rows, int32_t n_cols, const int32_t* col_ptr, const int32_t* row_idx, const int32_t* cmember,
+                                int32_t* perm_out);
+typedef struct lmgpu_isam2_params {
+  double relinearizeThreshold;  /* default 0.1 */
+  int32_t relinearizeSkip;      /* default 10 */
+  int32_t enableRelinearization; /* default 1 */
+  double wildfireThreshold;     /* ISAM2GaussNewtonParams, default 0.001 */
+} lmgpu_isam2_params;
+/* ISAM2Result subset (gtsam/nonlinear/ISAM2Result.h:60-93) + whether the batch fallback ran */
+typedef struct lmgpu_isam2_result {
+  int32_t variablesRelinearized, variablesReeliminated, factorsRecalculated, cliques, batch;
+} lmgpu_isam2_result;
+int lmgpu_isam2_create(const lmgpu_config* cfg, const lmgpu_isam2_params* params, lmgpu_ccolamd_fn ccolamd, void* user, lmgpu_isam2** out);
+int lmgpu_isam2_destroy(lmgpu_isam2* s);
+const char* lmgpu_isam2_last_error(const lmgpu_isam2* s);
+uint64_t lmgpu_isam2_last_failed_key(const lmgpu_isam2* s); /* LMGPU_INDETERMINATE: first frontal key of the failing clique */
+/* newTheta of the next update: packed values like lmgpu_set_values (store doubles per type, in the order given) */
+int lmgpu_isam2_add_variables(lmgpu_isam2* s, int32_t n, const uint64_t* keys, const int32_t* types, const double* packed_values);
+/* newFactors of the next update, appended in call order (= their order in the NonlinearFactorGraph); keys: n x arity Keys */
+int lmgpu_isam2_add_factors(lmgpu_isam2* s, int32_t factor_type, int32_t n, const uint64_t* keys, const double* meas, int32_t noise_kind,
+                            const double* noise);
+int lmgpu_isam2_update(lmgpu_isam2* s, int32_t force_relinearize, lmgpu_isam2_result* out);
+int lmgpu_isam2_num_variables(const lmgpu_isam2* s);
+int lmgpu_isam2_num_factors(const lmgpu_isam2* s);
+/* which: 0 = calculateEstimate (ISAM2.cpp:748-754), 1 = calculateBestEstimate (:763-766), 2 = getLinearizationPoint.
+ * Variables ascending by Key (the reference's Values order); any of the outputs may be NULL. */
+int lmgpu_isam2_get_values(lmgpu_isam2* s, int32_t which, uint64_t* keys_out, int32_t* types_out, double* packed_out);
+int lmgpu_isam2_get_delta(lmgpu_isam2* s, double* packed); /* getDelta (:776-779), ascending by Key */
+/* parity taps: the Bayes tree depth-first from the roots (children in order).  lmgpu_isam2_num_cliques takes the snapshot the
+ * other two index; info5: n_keys, n_frontal_keys, nf, n, parent (index in the snapshot, -1 root); RSd column-major nf x n */
+int lmgpu_isam2_num_cliques(lmgpu_isam2* s);
+int lmgpu_isam2_clique_info(const lmgpu_isam2* s, int32_t i, int32_t* info5);
+int lmgpu_isam2_get_clique(lmgpu_isam2* s, int32_t i, uint64_t* keys, double* RSd_colmajor);
+
 /* ---- micro-benchmarks used by bench.py for roofline peaks (device-only, no graph needed) ---- */
 int lmgpu_peak_mfma_f64(int32_t device, int32_t iters, double* tflops);
 int lmgpu_peak_hbm_copy(int32_t device, int64_t bytes, int32_t iters, double* gbps);

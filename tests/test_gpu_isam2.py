@@ -1,0 +1,91 @@
+"""BASELINE config 5: ISAM2 (incremental relinearize + partial re-eliminate) on the device against the CPU oracle, update by
+update, on the reference's own incremental workloads (tests/isam2_examples.py): VisualISAM2Example's 8-pose / 8-point
+sequence (examples/VisualISAM2Example.cpp:88-131, relinearizeThreshold 0.01, relinearizeSkip 1, an extra update() per frame) and
+createSlamlikeISAM2 (tests/testGaussianISAM2.cpp:44-168) with and without relinearization.
+
+Per update: identical bookkeeping (variables relinearized / re-eliminated, factors recalculated, clique count, batch-or-incremental),
+identical Bayes tree (cliques depth-first: keys in Scatter order, frontal counts, parents) = bit-exact ordering / indexing; [R S d]
+of every clique, the linearization point, delta and calculateEstimate() within 1e-6 relative."""
+import numpy as np
+import pytest
+
+import oracle_harness as oh
+from gtsam_personal_amd import ISAM2, ISAM2GaussNewtonParams, ISAM2Params
+from gtsam_personal_amd.graph import symbol
+from isam2_examples import create_points, slamlike_steps, visual_steps
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not oh.have_ref(), reason="oracle/_ref (CCOLAMD of the reference) not built")]
+
+
+def ccolamd(n_rows, n_cols, col_ptr, row_idx, cmember):
+    return oh.ccolamd_csc(n_rows, n_cols, col_ptr, row_idx, cmember)
+
+
+def compare_state(isam, orc, tol=1e-6):
+    cg, co = isam.cliques(), orc.cliques()
+    assert len(cg) == len(co)
+    for i, ((kg, nfg, Rg, pg), (ko, nfo, Ro, po)) in enumerate(zip(cg, co)):
+        assert kg == ko and nfg == nfo and pg == po, (i, kg, ko)
+        assert Rg.shape == Ro.shape
+        assert np.allclose(Rg, Ro, rtol=tol, atol=1e-7 * max(1.0, np.abs(Ro).max())), i
+    lg, lo = isam.getLinearizationPoint(), orc.getLinearizationPoint()
+    assert lg.keys() == lo.keys()
+    for k in lo.keys():
+        assert np.allclose(lg.at(k), lo.at(k), rtol=tol, atol=1e-9), k
+    dg, do = isam.getDelta(), orc.getDelta()
+    for k in do:
+        assert np.allclose(dg[k], do[k], rtol=tol, atol=1e-8), (k, dg[k], do[k])
+    eg, eo = isam.calculateEstimate(), orc.calculateEstimate()
+    for k in eo.keys():
+        assert np.allclose(eg.at(k), eo.at(k), rtol=tol, atol=1e-8), k
+
+
+def run_sequence(steps, params, check_every_step=True):
+    p = params
+    isam = ISAM2(p, ccolamd=ccolamd, device=0)
+    orc = oh.OracleISAM2(p.relinearizeThreshold, p.relinearizeSkip, p.enableRelinearization, p.optimizationParams.wildfireThreshold)
+    for i, (g, v) in enumerate(steps):
+        rg = isam.update(g, v).as_dict()
+        ro = orc.update(g, v)
+        assert rg == ro, (i, rg, ro)
+        if check_every_step:
+            compare_state(isam, orc)
+    compare_state(isam, orc)
+    return isam, orc
+
+
+def test_visual_isam2_example_step_by_step():
+    params = ISAM2Params(relinearizeThreshold=0.01, relinearizeSkip=1)
+    isam, orc = run_sequence(visual_steps(), params)
+    result = isam.calculateEstimate()
+    assert len(result.keys()) == 16
+    for j, p in enumerate(create_points()):  # tests/testVisualISAM2.cpp:112-117
+        assert np.allclose(result.at(symbol("l", j))[:3], p, rtol=0, atol=0.01), j
+    best, best_o = isam.calculateBestEstimate(), orc.calculateBestEstimate()
+    for k in best_o.keys():
+        assert np.allclose(best.at(k), best_o.at(k), rtol=1e-6, atol=1e-8), k
+    isam.close()
+
+
+@pytest.mark.parametrize("params", [
+    ISAM2Params(ISAM2GaussNewtonParams(0.001), 0.0, 0, False),   # tests/testGaussianISAM2.cpp:303: relinearization off
+    ISAM2Params(),                                                # defaults: threshold 0.1, every 10th update
+    ISAM2Params(ISAM2GaussNewtonParams(0.001), 0.01, 1, True),   # relinearize eagerly
+    ISAM2Params(ISAM2GaussNewtonParams(0.0), 0.05, 2, True),     # wildfire off: full back-substitution
+], ids=["norelin", "defaults", "eager", "fullsolve"])
+def test_slamlike_step_by_step(params):
+    isam, _ = run_sequence(slamlike_steps(), params)
+    isam.close()
+
+
+def test_forced_relinearization_and_bare_updates():
+    steps = slamlike_steps()
+    p = ISAM2Params()
+    isam = ISAM2(p, ccolamd=ccolamd, device=0)
+    orc = oh.OracleISAM2(p.relinearizeThreshold, p.relinearizeSkip, p.enableRelinearization, p.optimizationParams.wildfireThreshold)
+    for g, v in steps:
+        assert isam.update(g, v).as_dict() == orc.update(g, v)
+    for _ in range(3):
+        assert isam.update(force_relinearize=True).as_dict() == orc.update(force_relinearize=True)
+        compare_state(isam, orc)
+    isam.close()
