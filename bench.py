@@ -99,8 +99,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        # one process per GPU: N > 1 runs under torch.distributed.run (the driver's launch line); a bare `--gpus N` would silently
+        # measure one GPU
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with `python -m torch.distributed.run --nnodes=1 "
+                         f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port <P> bench.py --gpus {args.gpus} ...`")
     # RCCL prints a version banner on stdout when the first communicator is created; the contract is ONE JSON line on
     # stdout, so everything before the final print goes to stderr at file-descriptor level
     saved_stdout = None

@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256) void hbm_backsolve_dataflow_kernel(FrontDesc F
     __syncthreads();
   }
   if (!ok) {
-    if (tid == 0) atomicMin(status, F.id);  // never expected: spin bound hit
+    if (tid == 0) atomicExch(status + 1, 1 + F.id);  // never expected: spin bound hit (a fault, reported apart from pivot failures)
     // still publish something so that waiters terminate
   }
   // x_b = inv(R_bb) acc   (thread (row, quarter): 16 columns of the row; the inverse was fetched before the first hop)

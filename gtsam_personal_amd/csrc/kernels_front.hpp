@@ -617,7 +617,7 @@ __global__ __launch_bounds__(256) void lds_backsub_merged_kernel(const int32_t* 
     s_ok = ok;
   }
   __syncthreads();
-  if (!s_ok && tid == 0) atomicMin(status, F.id);  // never expected: spin bound hit
+  if (!s_ok && tid == 0) atomicExch(status + 1, 1 + F.id);  // never expected: spin bound hit (a fault, reported apart from pivot failures)
   double xs[3];
 #pragma unroll
   for (int q = 0; q < 3; q++) {

@@ -691,7 +691,7 @@ __device__ __forceinline__ void panel_role(double* A, int ld, int n, int nf, int
       }
     }
   }
-  if (!healthy && tid == 0) atomicMin(status, front_id);  // never expected: spin bound hit
+  if (!healthy && tid == 0) atomicExch(status + 1, 1 + front_id);  // never expected: spin bound hit (a fault, reported apart from pivot failures)
   if (!diagwg) {
     if (publish_strips) pdf_publish(&flags[PDF_PR0 + ((b - nblk) >> 1)], tid == 0);
     return;

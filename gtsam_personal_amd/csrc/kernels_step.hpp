@@ -202,7 +202,7 @@ __device__ __forceinline__ void step_body(const StepArgs& a, int t, const ChainL
       si = (t - nHead) & 3;
     }
     const bool ok = chain_wait_tile(c, T, S, si >> 1, sj >> 1, s_ok);
-    if (!ok && threadIdx.x == 0) atomicMin(a.status, a.front_id);
+    if (!ok && threadIdx.x == 0) atomicExch(a.status + 1, 1 + a.front_id);  // hand-off timed out: a fault, reported apart from pivot failures
     if (t < nHead)
       syrk_quadrant32(a.A, a.ld, a.n, a.p0, a.kp, r0, si, sj, t & 3, a.S);
     else
@@ -225,7 +225,7 @@ __device__ __forceinline__ void step_body(const StepArgs& a, int t, const ChainL
     }
     const int tj = ti + rem;
     const bool ok = chain_wait_tile(c, T, S, ti, tj, s_ok);
-    if (!ok && threadIdx.x == 0) atomicMin(a.status, a.front_id);
+    if (!ok && threadIdx.x == 0) atomicExch(a.status + 1, 1 + a.front_id);  // hand-off timed out: a fault, reported apart from pivot failures
     syrk_tile(a.A, a.ld, a.n, a.p0, a.kp, r0, a.n, ti, tj, sm);
     if (c.publish) pdf_publish(&a.flags[PDF_TD0 + ti * T - ti * (ti - 1) / 2 + (tj - ti)], threadIdx.x == 0);
     return;

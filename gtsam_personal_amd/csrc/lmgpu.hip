@@ -180,6 +180,14 @@ __global__ void local_sum_kernel(double* __restrict__ dst, const double* __restr
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] += src[i];
 }
 __global__ void local_min_kernel(int* __restrict__ dst, const int* __restrict__ src) { *dst = min(*dst, *src); }
+// damping weights of diagonal damping: w = sqrt(clamp(diag, min, max))^2 -- the square of what the reference's prior carries
+// (value.cwiseMax(minDiagonal).cwiseMin(maxDiagonal).cwiseSqrt(), LevenbergMarquardtOptimizer.cpp:294-298; the prior squares it again)
+__global__ void clamp_diag_kernel(int n, const double* __restrict__ diag, double* __restrict__ w, double lo, double hi) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double s = sqrt(fmin(fmax(diag[i], lo), hi));
+  w[i] = s * s;
+}
 
 struct lmgpu_handle {
   lmgpu_config cfg;
@@ -256,13 +264,6 @@ struct lmgpu_handle {
     bool write_ok = false;
     int zero_begin = 0, zero_count = 0;
   };
-  // LMGPU_OVERLAP=1: gather the root's row chunks on a second stream beside its factorisation.  Measured r01 (C4): 13.5 ms per
-  // step instead of 10.4 -- two resident workgroups of the update kernel hold every VGPR of a SIMD (2 x 256), so the gather
-  // waves only get in between workgroups and every panel then waits for its chunk.  Off; kept for A/B.
-  bool overlap_gather = false;
-  hipStream_t asm_stream = nullptr;  // pipelined assembly of a gathered HBM front, chunk by chunk beside its factorisation
-  hipEvent_t ready_ev = nullptr;
-  double *partial2 = nullptr, *dscal2 = nullptr;
   std::vector<GatherRange> gather;  // per front (only HBM fronts have non-empty ranges)
   GPairBlock* d_gpblk = nullptr;
   GZeroBlock* d_gzero = nullptr;
@@ -483,18 +484,11 @@ int fill_dampw(lmgpu_handle* h, int diagonal, double min_diag, double max_diag) 
     }
     return LMGPU_OK;
   }
-  // hessianDiagonal, clamped (LevenbergMarquardtOptimizer.cpp:291-298: sqrt then squared by the prior = clamp(diag))
+  // hessianDiagonal, clamped (LevenbergMarquardtOptimizer.cpp:291-298: sqrt then squared by the prior = clamp(diag)); an
+  // element-wise kernel on the stream, nothing crosses PCIe
   int rc = launch_hessian_diag(h);
   if (rc) return rc;
-  std::vector<double> d(h->ntot);
-  HIPCHECK(hipMemcpyAsync(d.data(), h->hdiag, d.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCHECK(hipStreamSynchronize(h->stream));
-  for (auto& x : d) {
-    const double s = std::sqrt(std::min(std::max(x, min_diag), max_diag));
-    x = s * s;
-  }
-  HIPCHECK(hipMemcpyAsync(h->dampw, d.data(), d.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIPCHECK(hipStreamSynchronize(h->stream));
+  hipLaunchKernelGGL(clamp_diag_kernel, dim3((h->ntot + 255) / 256), dim3(256), 0, h->stream, h->ntot, (const double*)h->hdiag, h->dampw, min_diag, max_diag);
   h->dampw_is_ones = false;
   return LMGPU_OK;
 }
@@ -507,7 +501,7 @@ int fill_dampw(lmgpu_handle* h, int diagonal, double min_diag, double max_diag) 
 // blocks it does not cover clears.
 static bool gather_writes(const lmgpu_handle* h, int fi) {
   const lmgpu_handle::GatherRange& G = h->gather[fi];
-  if (!(G.write_ok && G.leaf_count > 0 && !h->no_gather_write && !h->overlap_gather && h->n_hbm_fronts <= 4)) return false;
+  if (!(G.write_ok && G.leaf_count > 0 && !h->no_gather_write && h->n_hbm_fronts <= 4)) return false;
   if (h->s_off[fi] < 0) return true;
   return (h->h_fronts[fi].pad & 1) != 0 && (h->comm || h->lgroup);  // the partial-assembly buffer is in use (`split` below)
 }
@@ -515,6 +509,7 @@ static bool gather_writes(const lmgpu_handle* h, int fi) {
 int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  // lambda by value (eager) or in device memory (graph replay)
   hipStream_t s = h->stream;
   HIPCHECK(hipMemsetAsync(h->d_status, 0x7f, sizeof(int), s));
+  HIPCHECK(hipMemsetAsync(h->d_status + 1, 0, sizeof(int), s));  // [1]: a dataflow hand-off timed out (1 + front id)
   {  // HBM fronts are accumulated into by their children (atomics) before their own level runs: clear them all first
     const int kt0 = h->kt.begin(LMGPU_KT_HBM_ASSEMBLE, s);
     int n_hbm = 0;
@@ -609,19 +604,13 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
       // `split`: the assembled contributions go to a buffer of their own (aoff) and reach the working matrix A (which starts
       // from zero and collects the trailing updates) in 256-row chunks, each just before its panel is factored.
       //   multi-rank   : the chunks are summed over the ranks (RCCL on the communication stream / the in-process group)
-      //   `pipelined`  : the chunks are GATHERED one after the other on the assembly stream while the factorisation of the
-      //                  earlier panels runs on the main stream (the gather is memory-bound, the update MFMA-bound, and the
-      //                  tail of the factorisation leaves most CUs idle)
+      // (gathering the chunks on a second stream beside the factorisation was measured in round 1 -- 13.5 vs 10.4 ms per step: two
+      //  resident workgroups of the update kernel hold every VGPR of a SIMD, the gather waves only get in between -- and removed)
       const bool multi = replicated && (h->comm || h->lgroup);
-      const bool pipelined = h->overlap_gather && h->s_off[fi] >= 0 && G.leaf_count > 0 && !h->lgroup && (int)G.cs.size() == nchunks + 1;
-      const bool split = h->s_off[fi] >= 0 && (multi || pipelined);
+      const bool split = h->s_off[fi] >= 0 && multi;
       const int64_t aoff = split ? h->s_off[fi] : off;
       double* Asm = h->pool + aoff;
-      hipStream_t sa = pipelined ? h->asm_stream : s;
-      if (pipelined) {
-        HIPCHECK(hipEventRecord(h->ready_ev, s));
-        HIPCHECK(hipStreamWaitEvent(sa, h->ready_ev, 0));
-      }
+      hipStream_t sa = s;
       if (split)
         while ((int)h->chunk_ev.size() < 2 * nchunks) {
           hipEvent_t e;
@@ -671,45 +660,28 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
           hipLaunchKernelGGL(schur_factor_kernel, dim3(v1 - v0), dim3(64 * SCHUR_FW), 0, sa, (const GVarBlock*)(h->d_gvblk + G.vblk_begin + v0),
                              (const GVarEntry*)h->d_gvent, h->pool, aoff, ld, F.n);
         if (G.leaf_count > 0 && (whole || c1 == nchunks)) {  // the (rhs, rhs) corner lives in the last chunk
-          double* scal = pipelined ? h->dscal2 : h->dscal + 4;
-          reduce_to(h, h->d_gcorner + G.leaf_begin, G.leaf_count, scal, sa, pipelined ? h->partial2 : nullptr);
+          double* scal = h->dscal + 4;
+          reduce_to(h, h->d_gcorner + G.leaf_begin, G.leaf_count, scal, sa, nullptr);
           hipLaunchKernelGGL(add_scalar_kernel, dim3(1), dim3(1), 0, sa, Asm + (size_t)(F.n - 1) * ld + F.n - 1, (const double*)scal);
         }
       };
-      if (!pipelined) {
-        gather_chunks(0, nchunks, true);
-        if (gwrite) own_additive_terms();
-        h->kt.end(kt, sa);
-        if (multi && h->comm && split) {  // RCCL: all chunks queued on the communication stream, one event each
-          HIPCHECK(hipEventRecord(h->asm_ev, s));
-          HIPCHECK(hipStreamWaitEvent(h->comm_stream, h->asm_ev, 0));
-          for (int c = 0; c < nchunks; c++) {
-            size_t cb, cn;
-            chunk_range(c, cb, cn);
-            NCCLCHECK(ncclAllReduce(Asm + cb, Asm + cb, cn, ncclDouble, ncclSum, h->comm, h->comm_stream));
-            HIPCHECK(hipEventRecord(h->chunk_ev[c], h->comm_stream));
-          }
-        }
-      } else {
+      gather_chunks(0, nchunks, true);
+      if (gwrite) own_additive_terms();
+      h->kt.end(kt, sa);
+      if (multi && h->comm && split) {  // RCCL: all chunks queued on the communication stream, one event each
+        HIPCHECK(hipEventRecord(h->asm_ev, s));
+        HIPCHECK(hipStreamWaitEvent(h->comm_stream, h->asm_ev, 0));
         for (int c = 0; c < nchunks; c++) {
-          gather_chunks(c, c + 1, false);
-          if (c + 1 == nchunks) h->kt.end(kt, sa);
-          if (multi && h->comm) {  // gathered chunk -> summed over the ranks -> event
-            size_t cb, cn;
-            chunk_range(c, cb, cn);
-            HIPCHECK(hipEventRecord(h->chunk_ev[nchunks + c], sa));
-            HIPCHECK(hipStreamWaitEvent(h->comm_stream, h->chunk_ev[nchunks + c], 0));
-            NCCLCHECK(ncclAllReduce(Asm + cb, Asm + cb, cn, ncclDouble, ncclSum, h->comm, h->comm_stream));
-            HIPCHECK(hipEventRecord(h->chunk_ev[c], h->comm_stream));
-          } else {
-            HIPCHECK(hipEventRecord(h->chunk_ev[c], sa));
-          }
+          size_t cb, cn;
+          chunk_range(c, cb, cn);
+          NCCLCHECK(ncclAllReduce(Asm + cb, Asm + cb, cn, ncclDouble, ncclSum, h->comm, h->comm_stream));
+          HIPCHECK(hipEventRecord(h->chunk_ev[c], h->comm_stream));
         }
       }
       // chunk c is complete (gathered / reduced) for everything queued on the main stream after this call
       auto wait_chunk = [&](int c) -> int {
         if (!split || c >= nchunks) return LMGPU_OK;
-        if (pipelined || h->comm) {
+        if (h->comm) {
           HIPCHECK(hipStreamWaitEvent(s, h->chunk_ev[c], 0));
         } else {  // in-process group: synchronous
           size_t cb, cn;
@@ -1022,7 +994,7 @@ int do_solve_enqueue(lmgpu_handle* h, double lambda) {
   }
   (void)hipEventRecord(h->ev[4], s);
   HIPCHECK(hipMemcpyAsync(h->h_scal + 1, h->dscal + 1, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
-  HIPCHECK(hipMemcpyAsync(h->h_status, h->d_status, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHECK(hipMemcpyAsync(h->h_status, h->d_status, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
   return LMGPU_OK;
 }
 
@@ -1030,6 +1002,10 @@ int do_solve_finish(lmgpu_handle* h) {
   HIPCHECK(hipStreamSynchronize(h->stream));
   h->kt.resolve();
   h->solved = true;
+  if (h->h_status[1] != 0) {  // a bounded spin of an in-launch hand-off ran out: a scheduling / protocol fault, NOT an ill-conditioned system
+    h->err = "in-launch dataflow hand-off timed out in front " + std::to_string(h->h_status[1] - 1) + " (spin bound hit)";
+    return LMGPU_HIP_ERROR;
+  }
   if (*h->h_status < (int)h->h_fronts.size()) {
     const Front& fr = h->plan.fronts[*h->h_status];
     h->failed_slot = fr.vars[0];
@@ -1415,7 +1391,6 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
   h->no_tail = getenv("LMGPU_NO_TAIL") != nullptr;
   h->no_gather_write = getenv("LMGPU_NO_GATHER_WRITE") != nullptr;
   if (const char* e = getenv("LMGPU_CHAIN_FAR")) h->chain_far_pct = std::max(10, std::min(100, atoi(e)));
-  h->overlap_gather = getenv("LMGPU_OVERLAP") != nullptr;
   *out = h;
   if (h->device >= 0) {
     HIPCHECK(hipSetDevice(h->device));
@@ -1426,16 +1401,10 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
       HIPCHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
       HIPCHECK(hipStreamCreateWithPriority(&h->comm_stream, hipStreamNonBlocking, prio_hi));
     }
-    {  // the assembly chunks are short and each gates a panel of the factorisation: highest dispatch priority
-      int prio_lo = 0, prio_hi = 0;
-      HIPCHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-      HIPCHECK(hipStreamCreateWithPriority(&h->asm_stream, hipStreamNonBlocking, prio_hi));
-    }
-    HIPCHECK(hipEventCreateWithFlags(&h->ready_ev, hipEventDisableTiming));
     HIPCHECK(hipEventCreateWithFlags(&h->asm_ev, hipEventDisableTiming));
     for (int i = 0; i < 8; i++) HIPCHECK(hipEventCreate(&h->ev[i]));
     HIPCHECK(hipHostMalloc((void**)&h->h_scal, 8 * sizeof(double), hipHostMallocDefault));
-    HIPCHECK(hipHostMalloc((void**)&h->h_status, sizeof(int), hipHostMallocDefault));
+    HIPCHECK(hipHostMalloc((void**)&h->h_status, 2 * sizeof(int), hipHostMallocDefault));
     HIPCHECK(hipMalloc((void**)&h->d_lambda, sizeof(double)));
     HIPCHECK(hipMemset(h->d_lambda, 0, sizeof(double)));
     HIPCHECK(hipFuncSetAttribute((const void*)lds_front_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra + 64));
@@ -1484,12 +1453,9 @@ int lmgpu_destroy(lmgpu_handle* h) {
     fr(h->d_gpblk); fr(h->d_gpent); fr(h->d_gvblk); fr(h->d_gvent); fr(h->d_gcorner);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
-    if (h->asm_stream) (void)hipStreamDestroy(h->asm_stream);
-    if (h->ready_ev) (void)hipEventDestroy(h->ready_ev);
     for (int g = 0; g < 2; g++)
       if (h->solve_graph[g]) (void)hipGraphExecDestroy(h->solve_graph[g]);
     if (h->d_lambda) (void)hipFree(h->d_lambda);
-    fr(h->partial2); fr(h->dscal2);
     if (h->asm_ev) (void)hipEventDestroy(h->asm_ev);
     for (hipEvent_t e : h->chunk_ev) (void)hipEventDestroy(e);
   }
@@ -1709,13 +1675,9 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
       F.ld_u = ld;
       F.u_off = off + (int64_t)fr.nf * ld + fr.nf;
       off += (int64_t)fr.n * ld;
-      bool gathered = false;  // will this front gather leaf children (kernels_schur.hpp)?
-      for (int32_t c : fr.children)
-        if (h->front_active[c] && P.fronts[c].cls == 0 && P.fronts[c].children.empty() && !getenv("LMGPU_NO_GATHER")) gathered = true;
       // the assembled contributions get a buffer of their own beside the working matrix when they arrive in row chunks while
-      // the factorisation is already running: replicated fronts (chunks all-reduced over the ranks) and multi-panel fronts
-      // that gather their leaves (chunks gathered on a second stream)
-      if ((F.pad & 1) || (gathered && fr.nf > NBO && h->overlap_gather)) {
+      // the factorisation is already running: replicated fronts (chunks all-reduced over the ranks)
+      if (F.pad & 1) {
         h->s_off[fi] = off;
         off += (int64_t)fr.n * ld;
       }
@@ -2127,11 +2089,9 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
   HIPCHECK(hipMalloc((void**)&h->ebuf0, std::max(1, h->nfac) * sizeof(double)));
   HIPCHECK(hipMalloc((void**)&h->ebuf1, std::max(1, h->nfac) * sizeof(double)));
   HIPCHECK(hipMalloc((void**)&h->partial, 256 * sizeof(double)));
-  HIPCHECK(hipMalloc((void**)&h->partial2, 256 * sizeof(double)));
-  HIPCHECK(hipMalloc((void**)&h->dscal2, 8 * sizeof(double)));
   HIPCHECK(hipMalloc((void**)&h->dscal, 8 * sizeof(double)));
   HIPCHECK(hipMalloc((void**)&h->ywork, std::max(1, P.max_front_n) * sizeof(double)));
-  HIPCHECK(hipMalloc((void**)&h->d_status, sizeof(int)));
+  HIPCHECK(hipMalloc((void**)&h->d_status, 2 * sizeof(int)));
   {
     int max_nf = 1;
     for (int fi = 0; fi < NF; fi++)
@@ -2424,6 +2384,7 @@ int lmgpu_optimize(lmgpu_handle* h, const lmgpu_lm_params* p, lmgpu_lm_state* in
   if (rc) return rc;
   if ((rc = need_comm(h))) return rc;
   // NonlinearOptimizer::defaultOptimize (gtsam/nonlinear/NonlinearOptimizer.cpp:62-117)
+  if (inout) h->lm = *inout;  // the caller owns the LevenbergMarquardtState, as in lmgpu_iterate
   double currentError = h->lm.error;
   if (currentError <= p->errorTol || h->lm.iterations >= p->maxIterations) {
     if (inout) *inout = h->lm;
@@ -2433,7 +2394,10 @@ int lmgpu_optimize(lmgpu_handle* h, const lmgpu_lm_params* p, lmgpu_lm_state* in
   do {
     currentError = newError;
     rc = lm_iterate(h, p);
-    if (rc) return rc;
+    if (rc) {
+      if (inout) *inout = h->lm;  // the state reached so far, also on an error return
+      return rc;
+    }
     newError = h->lm.error;
   } while (h->lm.iterations < p->maxIterations &&
            !check_convergence(p->relativeErrorTol, p->absoluteErrorTol, p->errorTol, currentError, newError) && std::isfinite(currentError));
