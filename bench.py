@@ -27,27 +27,52 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet FP64 matrix peak (not listed i
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def cpu_baseline(n_cam, n_pt, obs, seed):
-    """the CPU oracle (a port of the reference's algorithm, 1 thread) timed on a bounded sample of the workload"""
+def cpu_baseline(n_cam, n_pt, obs, seed, full_tag=None):
+    """the CPU oracle (a port of the reference's algorithm) timed on a bounded sample of the workload, single thread and with all the
+    host cores this process may use (subtree-parallel elimination + parallel linearize: what the reference does with TBB,
+    gtsam/base/treeTraversal/parallelTraversalTasks.h:78-93, NonlinearFactorGraph.cpp:246-261); beside it the oracle's time on the
+    FULL workload, measured once in the build container when the parity fixture was made (tests/golden/<tag>_timing.json)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_harness as oh  # the oracle is only ever the baseline / the checker
     from gtsam_personal_amd import LevenbergMarquardtParams
     from gtsam_personal_amd.synthetic import make_bal
     graph, initial, _, ordering = make_bal(n_cam, n_pt, obs, seed=seed)
-    orc = oh.OracleProblem(graph, initial, ordering)
     params = LevenbergMarquardtParams()
-    orc.lm_init(params)
-    times = []
-    t_all = time.perf_counter()
-    while len(times) < 3 and (time.perf_counter() - t_all) < 25.0:
-        t0 = time.perf_counter()
-        orc.lm_iterate(params)
-        times.append(time.perf_counter() - t0)
-    tm = orc.timings()
-    return dict(value=len(times) / sum(times), unit="LM iterations/s", cores=1, kind="port",
-                sample=f"synthetic BAL {n_cam} cameras / {n_pt} points / {graph.size()} factors (1/10 of the GPU workload per dimension), "
-                       f"{len(times)} LM iterations, oracle/liblm_oracle.so single thread",
-                ms_per_iteration=1e3 * sum(times) / len(times), linearize_ms=1e3 * tm["linearize_s"], eliminate_ms=1e3 * tm["eliminate_s"])
+
+    def leg(threads, budget_s):
+        oh.set_threads(threads)
+        orc = oh.OracleProblem(graph, initial, ordering)
+        orc.lm_init(params)
+        times = []
+        t_all = time.perf_counter()
+        while len(times) < 3 and (time.perf_counter() - t_all) < budget_s:
+            t0 = time.perf_counter()
+            orc.lm_iterate(params)
+            times.append(time.perf_counter() - t0)
+        tm = orc.timings()
+        return len(times) / sum(times), times, tm
+
+    cores = max(1, min(len(os.sched_getaffinity(0)), 16))
+    v1, t1, tm1 = leg(1, 12.0)
+    vn, tn, tmn = leg(cores, 12.0) if cores > 1 else (v1, t1, tm1)
+    oh.set_threads(1)
+    out = dict(value=vn, unit="LM iterations/s", cores=cores, kind="port",
+               sample=f"synthetic BAL {n_cam} cameras / {n_pt} points / {graph.size()} factors (1/10 of the GPU workload per dimension), "
+                      f"{len(tn)} LM iterations, oracle/liblm_oracle.so with {cores} threads (subtree-parallel elimination, parallel linearize)",
+               ms_per_iteration=1e3 * sum(tn) / len(tn), linearize_ms=1e3 * tmn["linearize_s"], eliminate_ms=1e3 * tmn["eliminate_s"],
+               single_thread={"value": v1, "cores": 1, "ms_per_iteration": 1e3 * sum(t1) / len(t1), "linearize_ms": 1e3 * tm1["linearize_s"],
+                              "eliminate_ms": 1e3 * tm1["eliminate_s"]})
+    if full_tag:
+        try:
+            with open(os.path.join(ROOT, "tests", "golden", f"{full_tag}_timing.json")) as f:
+                tj = json.load(f)
+            out["same_workload"] = {"what": tj["what"], "workload": tj["workload"],
+                                    "runs": [{"ordering": r["ordering"], "value": 1.0 / r["iterate_s"], "unit": "LM iterations/s", "cores": 1,
+                                              "ms_per_iteration": 1e3 * r["iterate_s"], "linearize_ms": 1e3 * r["linearize_s"],
+                                              "eliminate_ms": 1e3 * r["eliminate_s"]} for r in tj["runs"]]}
+        except OSError:
+            pass
+    return out
 
 
 def metis_fixture_ordering(args, schur):
@@ -241,7 +266,8 @@ def main():
             if "roofline_linearize" in out and v.value > 0:
                 out["roofline_linearize"]["frac_of_measured_copy"] = out["roofline_linearize"]["achieved"] / v.value
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(max(2, args.cams // 10), max(10, args.points // 10), args.obs, args.seed)
+            full_tag = {(1000, 100000, 10, 42): "c4_seed42", (100, 10000, 10, 42): "bal100_seed42"}.get((args.cams, args.points, args.obs, args.seed))
+            out["cpu_baseline"] = cpu_baseline(max(2, args.cams // 10), max(10, args.points // 10), args.obs, args.seed, full_tag)
         sys.stdout.flush()
         if saved_stdout is not None:
             os.dup2(saved_stdout, 1)

@@ -15,17 +15,22 @@
 //
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
 #include <algorithm>
+#include <atomic>
 #include <cassert>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <list>
+#include <malloc.h>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <set>
 #include <stdexcept>
+#include <thread>
 #include <vector>
 
 #include "geometry.hpp"
@@ -710,7 +715,9 @@ static void eliminate_clique(const std::vector<const GFactor*>& gathered, const 
   }
   offs.push_back(n);
   n += 1;
-  Mat info(n, n);
+  static thread_local Mat info;  // reused per thread: a fresh (n x n) allocation per clique is page-fault bound (BAL: 70 KB x 100 000)
+  info.r = info.c = n;
+  info.a.assign((size_t)n * n, 0.0);
   for (auto* g : gathered) update_hessian(*g, keys, offs, info);
   int nf = 0;
   for (size_t i = 0; i < frontals.size(); i++) nf += dims[i];
@@ -734,18 +741,61 @@ static void eliminate_clique(const std::vector<const GFactor*>& gathered, const 
     for (int i = 0; i <= j; i++) separator.info(i, j) = info(nf + i, nf + j);
 }
 
+static double now_s();
+// all-cores leg of the CPU baseline (orc_set_threads > 1): the subtrees below a clique with many children are eliminated by a
+// pool of threads, each into a Bayes tree of its own, and spliced into the result in child order afterwards -- the same cliques
+// in the same post-order.  This is the reference's TBB subtree parallelism (gtsam/base/treeTraversal/parallelTraversalTasks.h:78-93,
+// threshold gtsam/inference/ClusterTree-inst.h:299-300); the dense work inside a clique stays single-threaded, as Eigen's LLT is there.
+static int g_threads = 1;
+
 static int eliminate_tree(const std::shared_ptr<JNode>& node, const std::vector<const GFactor*>& graph,
                           const std::map<Key, int>& keyDim, BayesTree& bt, GFactor& sepOut) {
   // post-order: children first (gtsam/inference/ClusterTree-inst.h:219-266)
   std::vector<GFactor> childFactors(node->children.size());
   std::vector<int> childIdx;
-  for (size_t i = 0; i < node->children.size(); i++) childIdx.push_back(eliminate_tree(node->children[i], graph, keyDim, bt, childFactors[i]));
+  if (g_threads > 1 && node->children.size() >= 64) {
+    const size_t nc = node->children.size();
+    std::vector<BayesTree> local(nc);
+    std::vector<int> localRoot(nc, -1);
+    std::atomic<size_t> next(0);
+    std::exception_ptr failure;
+    std::mutex mu;
+    auto work = [&]() {
+      for (;;) {
+        const size_t i = next.fetch_add(1);
+        if (i >= nc) return;
+        try {
+          localRoot[i] = eliminate_tree(node->children[i], graph, keyDim, local[i], childFactors[i]);
+        } catch (...) {
+          std::lock_guard<std::mutex> lk(mu);
+          if (!failure) failure = std::current_exception();
+        }
+      }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < g_threads; t++) pool.emplace_back(work);
+    for (auto& t : pool) t.join();
+    if (failure) std::rethrow_exception(failure);
+    for (size_t i = 0; i < nc; i++) {  // splice in child order: indices shift by the cliques already there
+      const int base = (int)bt.cliques.size();
+      for (Clique& c : local[i].cliques) {
+        for (int& ch : c.children) ch += base;
+        if (c.parent >= 0) c.parent += base;
+        bt.cliques.push_back(std::move(c));
+      }
+      childIdx.push_back(base + localRoot[i]);
+    }
+  } else {
+    for (size_t i = 0; i < node->children.size(); i++) childIdx.push_back(eliminate_tree(node->children[i], graph, keyDim, bt, childFactors[i]));
+  }
   std::vector<const GFactor*> gathered;
   for (size_t f : node->factors) gathered.push_back(graph[f]);
   for (auto& cf : childFactors)
     if (!cf.empty()) gathered.push_back(&cf);
   Clique cq;
+  const double tq = (getenv("ORC_TRACE") && node->children.size() >= 64) ? now_s() : 0.0;
   eliminate_clique(gathered, node->orderedFrontalKeys, keyDim, cq, sepOut);
+  if (tq > 0.0) std::fprintf(stderr, "clique with %zu children: own elimination %.3f s\n", node->children.size(), now_s() - tq);
   cq.children = childIdx;
   int me = (int)bt.cliques.size();
   bt.cliques.push_back(std::move(cq));
@@ -817,6 +867,21 @@ static double graph_error(const Problem& p, const Values& v) {
 
 static void linearize(Problem& p) {
   p.linear.clear();
+  if (g_threads > 1 && p.factors.size() >= 4096) {  // NonlinearFactorGraph::linearize with TBB: parallel_for over the factors (:246-261)
+    p.linear.resize(p.factors.size());
+    std::atomic<size_t> next(0);
+    auto work = [&]() {
+      for (;;) {
+        const size_t b = next.fetch_add(1024);
+        if (b >= p.factors.size()) return;
+        for (size_t i = b; i < std::min(p.factors.size(), b + 1024); i++) p.linear[i] = linearize_factor(p.factors[i], p.values);
+      }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < g_threads; t++) pool.emplace_back(work);
+    for (auto& t : pool) t.join();
+    return;
+  }
   p.linear.reserve(p.factors.size());
   for (auto& f : p.factors) p.linear.push_back(linearize_factor(f, p.values));
 }
@@ -895,14 +960,21 @@ static void solve_damped(Problem& p, double lambda, const VectorValues* sqrtHess
   for (auto& kv : p.values) keyDim[kv.first] = kVarDim[kv.second.type];
   double t0 = now_s();
   auto roots = build_etree(fkeys, vi, p.ordering);
+  const double ta = now_s();
+  double tj = 0, te = 0;
   p.bt = BayesTree();
   for (auto& r : roots) {
     std::shared_ptr<JNode> jr;
+    double tq = now_s();
     jt_visit(r, fkeys, jr);
+    tj += now_s() - tq;
+    tq = now_s();
     GFactor rem;
     int idx = eliminate_tree(jr, damped, keyDim, p.bt, rem);
+    te += now_s() - tq;
     p.bt.roots.push_back(idx);
   }
+  if (getenv("ORC_TRACE")) std::fprintf(stderr, "etree %.3f jt %.3f elim %.3f\n", ta - t0, tj, te);
   double t1 = now_s();
   p.delta.clear();
   backsub(p.bt, p.delta);
@@ -1225,6 +1297,18 @@ int orc_set_ordering(void* h, int n, const uint64_t* keys) {
   auto* p = (Problem*)h;
   p->ordering.assign(keys, keys + n);
   return 0;
+}
+
+// threads of the all-cores baseline leg (1 = the plain single-thread restatement); returns the value in effect
+int orc_set_threads(int n) {
+  g_threads = std::max(1, n);
+  if (g_threads > 1) {
+    // every clique allocates its (n x n) separator factor; with glibc's default arena growth that is one mprotect / page-fault
+    // storm per thread, serialised in the kernel (measured: no speed-up at 8 threads).  Keep freed memory and grow in large steps.
+    mallopt(M_TOP_PAD, 1 << 30);
+    mallopt(M_TRIM_THRESHOLD, 0x7fffffff);
+  }
+  return g_threads;
 }
 
 int orc_num_variables(void* h) { return (int)((Problem*)h)->values.size(); }

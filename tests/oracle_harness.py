@@ -88,8 +88,14 @@ def lib():
         L.orc_rot3_expmap.argtypes = [_D, _D]
         L.orc_rot3_logmap.argtypes = [_D, _D]
         L.orc_factor_evaluate.argtypes = [ct.c_void_p, ct.c_int, _D, _D, _D]
+        L.orc_set_threads.argtypes = [ct.c_int]
         _lib = L
     return _lib
+
+
+def set_threads(n):
+    """threads of the oracle's all-cores leg (subtree-parallel elimination + parallel linearize, like the reference with TBB)"""
+    return lib().orc_set_threads(int(n))
 
 
 def dp(a):
