@@ -89,6 +89,82 @@ def metis_fixture_ordering(args, schur):
     return [int(k) for k in srt[fx["ordering_perm"]]]
 
 
+def slam_workload(name):
+    """BASELINE configs[2] / configs[0] at the reference's own size: examples/Pose3SLAMExample_g2o.cpp on sphere2500 (2 500 Pose3,
+    4 949 BetweenFactor<Pose3>, odometry-chained initial estimate because the file carries no vertices, prior on pose 0 with
+    Diagonal::Variances(1e-6 x3, 1e-4 x3), :42-48) and examples/Pose2SLAMExample_g2o.cpp on city10000 (10 000 Pose2, 20 687 factors,
+    prior Variances(1e-6, 1e-6, 1e-8), :55-67)"""
+    import numpy as np
+    from gtsam_personal_amd import noiseModel
+    from gtsam_personal_amd.datasets import chain_initial_pose3, load3D, readG2o
+    gold = os.path.join(ROOT, "tests", "golden")
+    if name == "sphere2500":
+        graph, _ = load3D(os.path.join(gold, "sphere2500.txt"))
+        initial = chain_initial_pose3(graph)
+        graph.add_PriorFactorPose3(0, np.eye(3), np.zeros(3), noiseModel.Diagonal.Variances([1e-6, 1e-6, 1e-6, 1e-4, 1e-4, 1e-4]))
+    elif name == "city10000":
+        graph, initial = readG2o(os.path.join(gold, "city10000.g2o"))
+        graph.add_PriorFactorPose2(0, initial.at(0), noiseModel.Diagonal.Variances([1e-6, 1e-6, 1e-8]))
+    else:
+        raise SystemExit(name)
+    return graph, initial
+
+
+def slam_bench(args):
+    """side line for the general sparse configs (deep clique trees): LM iterations/s of one iterate() from the initial estimate, with
+    the bound that applies to them stated: tree depth x per-level latency (a level is one dependent launch sequence)"""
+    import numpy as np
+    import torch
+    from gtsam_personal_amd import LevenbergMarquardtOptimizer, LevenbergMarquardtParams
+    graph, initial = slam_workload(args.workload)
+    oname = "colamd" if args.ordering == "schur" else args.ordering  # COLAMD is the examples' default ordering type
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "slam_orderings.npz"))
+    keys = np.array(sorted(graph.keys()), dtype=np.uint64)
+    ordering = [int(k) for k in keys[fx[f"{args.workload}_{oname}"]]]
+    params = LevenbergMarquardtParams()
+    opt = LevenbergMarquardtOptimizer(graph, initial, ordering, params, device=0)
+    opt.save_values()
+    st = opt.copy_state()
+    for _ in range(args.warmup):
+        opt.restore_values(st)
+        opt.iterate()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    inner = 0
+    for _ in range(args.steps):
+        opt.restore_values(st)
+        opt.iterate()
+        inner += opt.timings()["inner_iterations"]
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    opt.set_kernel_timing(True)
+    opt.restore_values(st)
+    opt.iterate()
+    kt = opt.kernel_times()
+    nf = opt.num_fronts()
+    infos = [opt.front_info(i) for i in range(nf)]
+    levels = max(fi["level"] for fi in infos) + 1
+    # algorithmic bytes of one solve: every Jacobian read once, every [R S d] written once and read once by the back-substitution
+    from gtsam_personal_amd.graph import FACTOR_ROWS, FACTOR_VARS, VAR_DIM
+    jac = sum(len(gi) * FACTOR_ROWS[ft] * (sum(VAR_DIM[t] for t in FACTOR_VARS[ft]) + 1) * 8 for ft, _, gi, _, _, _, _ in graph.buckets())
+    rsd = sum(fi["nf"] * fi["n"] * 8 for fi in infos)
+    solve_ms = sum(v["ms"] for k, v in kt.items() if k not in ("linearize", "retract_error"))
+    out = {"metric": "LM iterations/sec", "value": args.steps / elapsed, "unit": "LM iterations/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "f64", "data": "reference dataset file (tests/golden)",
+           "config": {"workload": f"{args.workload} ({graph.size()} factors, {len(ordering)} variables), {oname.upper()} ordering of the reference "
+                                  f"(fixture-carried), one LM iterate from the initial estimate", "fronts": nf, "tree_levels": levels,
+                      "inner_iterations_per_step": inner / args.steps},
+           "kernel_ms_one_iterate": {k: v["ms"] for k, v in kt.items() if v["ms"] > 0},
+           "kernel_launches_one_iterate": {k: v["launches"] for k, v in kt.items() if v["launches"] > 0},
+           "roofline": {"kernel": "the whole damped solve (all fronts + back-substitution; no single dominant kernel)", "bound": "hbm",
+                        "achieved": (jac + 2 * rsd) / (solve_ms * 1e-3) / 1e9 if solve_ms > 0 else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": (jac + 2 * rsd) / (solve_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if solve_ms > 0 else None, "traffic": None,
+                        "note": f"latency-bound, not bandwidth-bound: {levels} tree levels, each a dependent launch sequence up and down the "
+                                f"tree; the applicable bound is levels x per-level latency (~{1e3 * solve_ms / max(1, 2 * levels * max(1, inner // args.steps or 1)):.0f} us per level and direction measured)"}}
+    print(json.dumps(out), flush=True)
+
+
 def pmc_traffic():
     """HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (counters cannot be collected
     from inside the process): {kernel: bytes}.  tools/pmc_summary.py writes the file; absent file -> traffic null."""
@@ -111,16 +187,25 @@ def main():
     ap.add_argument("--points", type=int, default=100000)
     ap.add_argument("--obs", type=int, default=10)
     ap.add_argument("--seed", type=int, default=42)
-    ap.add_argument("--ordering", choices=["metis", "schur"], default="metis",
+    ap.add_argument("--ordering", choices=["metis", "schur", "colamd"], default="metis",
                     help="elimination ordering: the reference's METIS ordering (BASELINE.json configs[3]; the permutation is a boundary input "
                          "carried by tests/golden/<tag>_metis.npz, produced once by Ordering::Metis through oracle/_ref) or Schur "
                          "(points then cameras, timing/timeSFMBAL.h:64-96)")
+    ap.add_argument("--workload", choices=["bal", "sphere2500", "city10000"], default="bal",
+                    help="bal = the headline synthetic BAL graph (BASELINE configs[3]); sphere2500 / city10000 = the general sparse configs at the "
+                         "reference's size (single GPU side line; --ordering colamd|metis)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--split-root", action="store_true",
                     help="1-GPU rehearsal of the multi-rank data path: one-rank RCCL communicator, chunked all-reduce of the root")
     args = ap.parse_args()
 
+    if args.workload != "bal":
+        if args.gpus != 1:
+            raise SystemExit("--workload sphere2500 / city10000 is a single-GPU side line")
+        return slam_bench(args)
+    if args.ordering == "colamd":
+        raise SystemExit("--ordering colamd is offered for --workload sphere2500 / city10000 (the BAL fixtures carry METIS and Schur)")
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
