@@ -115,6 +115,7 @@ SYMBOLS = {
     "lmgpu_isam2_clique_info": (ct.c_int, [_H, ct.c_int32, _I]),
     "lmgpu_isam2_get_clique": (ct.c_int, [_H, ct.c_int32, ct.POINTER(ct.c_uint64), _D]),
     "lmgpu_peak_mfma_f64": (ct.c_int, [ct.c_int32, ct.c_int32, _D]),
+    "lmgpu_peak_mfma_f64_clock": (ct.c_int, [ct.c_int32, ct.c_int32, ct.c_int32, _D, _D, _D]),
     "lmgpu_peak_hbm_copy": (ct.c_int, [ct.c_int32, ct.c_int64, ct.c_int32, _D]),
 }
 

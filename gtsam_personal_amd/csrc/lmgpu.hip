@@ -2611,6 +2611,33 @@ __global__ __launch_bounds__(256) void peak_mfma_f64_kernel(double* out, int ite
   out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// Diagnostic form of the same loop: NACC independent accumulators per wave and, around the loop, one pair of stamps per workgroup --
+// s_memtime (shader-clock cycles) and s_memrealtime (constant 100 MHz) -- written to a buffer nothing else reads
+// (MI355X_MICROARCH.md, DVFS give-back item 6): the clock the chip HOLDS under this load = d(memtime) / d(memrealtime) x 100 MHz.
+#define PEAK_CLOCK_KERNEL(NAME, NACC)                                                                                   \
+__global__ __launch_bounds__(256) void NAME(double* out, unsigned long long* stamps, int iters) { \
+  double4_t acc[NACC]; \
+  for (int i = 0; i < NACC; i++) acc[i] = double4_t{0, 0, 0, 0}; \
+  const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9; \
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime(); \
+  __builtin_amdgcn_sched_barrier(0); \
+  for (int it = 0; it < iters; it++) { \
+_Pragma("unroll") \
+    for (int i = 0; i < NACC; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0); \
+  } \
+  double s = 0; \
+  for (int i = 0; i < NACC; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3]; \
+  out[blockIdx.x * 256 + threadIdx.x] = s; \
+  __builtin_amdgcn_sched_barrier(0); \
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime(); \
+  if (threadIdx.x == 0) { \
+    stamps[2 * blockIdx.x] = c1 - c0; \
+    stamps[2 * blockIdx.x + 1] = r1 - r0; \
+  } \
+}
+PEAK_CLOCK_KERNEL(peak_mfma_f64_clock_kernel4, 4)
+PEAK_CLOCK_KERNEL(peak_mfma_f64_clock_kernel8, 8)
+
 __global__ __launch_bounds__(256) void peak_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
@@ -2633,6 +2660,59 @@ int lmgpu_peak_mfma_f64(int32_t device, int32_t iters, double* tflops) {
   const double flops = (double)blocks * 4 /*waves*/ * (double)iters * 4 * 2048.0;
   *tflops = flops / (ms * 1e-3) / 1e12;
   (void)hipFree(out);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return LMGPU_OK;
+}
+
+// tflops: the sustained rate of the loop; sclk_mhz: the median in-kernel shader clock while it ran (after ~1 s of back-to-back
+// launches so that the power state has settled); flop_per_clk_simd = tflops / (SIMDs x clock): 32 = one v_mfma_f64_16x16x4_f64
+// (2048 flop) per 64 cycles and SIMD, the rate the 78.6 TFLOP/s datasheet figure assumes AT 2.4 GHz.
+int lmgpu_peak_mfma_f64_clock(int32_t device, int32_t iters, int32_t n_acc, double* tflops, double* sclk_mhz, double* flop_per_clk_simd) {
+  if (hipSetDevice(device) != hipSuccess || (n_acc != 4 && n_acc != 8) || !tflops || !sclk_mhz) return LMGPU_HIP_ERROR;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return LMGPU_HIP_ERROR;
+  const int cus = prop.multiProcessorCount;
+  const int blocks = cus * 8;
+  double* out = nullptr;
+  unsigned long long* stamps = nullptr;
+  if (hipMalloc((void**)&out, (size_t)blocks * 256 * sizeof(double)) != hipSuccess) return LMGPU_HIP_ERROR;
+  if (hipMalloc((void**)&stamps, (size_t)blocks * 2 * sizeof(unsigned long long)) != hipSuccess) return LMGPU_HIP_ERROR;
+  auto launch = [&](int it) {
+    if (n_acc == 4) hipLaunchKernelGGL(peak_mfma_f64_clock_kernel4, dim3(blocks), dim3(256), 0, 0, out, stamps, it);
+    else hipLaunchKernelGGL(peak_mfma_f64_clock_kernel8, dim3(blocks), dim3(256), 0, 0, out, stamps, it);
+  };
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  launch(iters);
+  (void)hipDeviceSynchronize();
+  (void)hipEventRecord(e0, 0);
+  launch(iters);
+  (void)hipEventRecord(e1, 0);
+  (void)hipEventSynchronize(e1);
+  float ms1 = 0;
+  (void)hipEventElapsedTime(&ms1, e0, e1);
+  const int reps = std::max(1, std::min(400, (int)(1000.0 / std::max(0.05f, ms1))));  // ~1 s of back-to-back launches
+  for (int r = 0; r < reps; r++) launch(iters);
+  (void)hipEventRecord(e0, 0);
+  launch(iters);
+  (void)hipEventRecord(e1, 0);
+  (void)hipEventSynchronize(e1);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  std::vector<unsigned long long> h((size_t)blocks * 2);
+  (void)hipMemcpy(h.data(), stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  std::vector<double> clk;
+  for (int b = 0; b < blocks; b++)
+    if (h[2 * b + 1] > 0) clk.push_back((double)h[2 * b] / (double)h[2 * b + 1] * 100.0);
+  std::sort(clk.begin(), clk.end());
+  *sclk_mhz = clk.empty() ? 0.0 : clk[clk.size() / 2];
+  const double flops = (double)blocks * 4 /*waves*/ * (double)iters * n_acc * 2048.0;
+  *tflops = flops / (ms * 1e-3) / 1e12;
+  if (flop_per_clk_simd) *flop_per_clk_simd = (*sclk_mhz > 0) ? (*tflops * 1e12) / ((double)cus * 4 * *sclk_mhz * 1e6) : 0.0;
+  (void)hipFree(out);
+  (void)hipFree(stamps);
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   return LMGPU_OK;
