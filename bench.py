@@ -168,7 +168,7 @@ def slam_bench(args):
 def pmc_traffic():
     """HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (counters cannot be collected
     from inside the process): {kernel: bytes}.  tools/pmc_summary.py writes the file; absent file -> traffic null."""
-    path = os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")
+    path = os.path.join(ROOT, "profiles", "r02", "pmc_summary.json")
     try:
         with open(path) as f:
             d = json.load(f)
@@ -329,7 +329,7 @@ def main():
                                                       "+ factorisation of panel i+1 in the same launch)"),
                                    "bound": "mfma", "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                    "frac": tf / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc.get(kname),
-                                   "traffic_unit": "HBM bytes per launch (FETCH_SIZE x 2 gfx950 correction + WRITE_SIZE; profiles/r01/pmc_summary.json)",
+                                   "traffic_unit": "HBM bytes per launch (FETCH_SIZE x 2 gfx950 correction + WRITE_SIZE; profiles/r02/pmc_summary.json)",
                                    "launches": syrk["launches"], "avg_launch_us": 1e3 * syrk["ms"] / syrk["launches"],
                                    "flop_per_launch": syrk["work"] / syrk["launches"]}
             if lin["launches"] > 0 and lin["ms"] > 0:

@@ -263,6 +263,8 @@ struct ChainArgs {
   double* inv16;        // 16 x 256 doubles per panel: panel p at inv16 + p * 4096
   unsigned int* flags;  // region of panel p at flags + p * PDF_FLAG_WORDS; the ticket counter is word 0 of panel i0 + 1
   const int2* tasks;    // (step - i0, logical workgroup of that step) per ticket
+  const double* S;      // multi-rank: the partial-assembly buffer (summed over the ranks for every row chunk this launch touches: the host
+                        // waits for those chunks' events before the launch) whose rows the head tiles fold in; else nullptr
 };
 
 __global__ __launch_bounds__(256, 2) void chain_kernel(ChainArgs ca) {
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(ChainArgs ca) {
   const int s = task.x, i = ca.i0 + s;
   const int kbn = min(ca.nf, (i + 2) * 256) - (i + 1) * 256;
   StepArgs a{ca.A, ca.ld, ca.n, ca.nf, 256 * i, 256, kbn, ca.front_id, ca.status, ca.inv16 + (size_t)(i + 1) * 4096,
-             ca.flags + (size_t)(i + 1) * PDF_FLAG_WORDS, nullptr};
+             ca.flags + (size_t)(i + 1) * PDF_FLAG_WORDS, ca.S};
   const ChainLink c{s > 0 ? ca.flags + (size_t)i * PDF_FLAG_WORDS : nullptr, s + 1 < ca.nsteps};
   step_body(a, task.y, c, sm, &s_ok);
 }

@@ -180,6 +180,7 @@ __global__ void local_sum_kernel(double* __restrict__ dst, const double* __restr
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] += src[i];
 }
 __global__ void local_min_kernel(int* __restrict__ dst, const int* __restrict__ src) { *dst = min(*dst, *src); }
+
 // damping weights of diagonal damping: w = sqrt(clamp(diag, min, max))^2 -- the square of what the reference's prior carries
 // (value.cwiseMax(minDiagonal).cwiseMin(maxDiagonal).cwiseSqrt(), LevenbergMarquardtOptimizer.cpp:294-298; the prior squares it again)
 __global__ void clamp_diag_kernel(int n, const double* __restrict__ diag, double* __restrict__ w, double lo, double hi) {
@@ -213,7 +214,7 @@ struct lmgpu_handle {
   bool two_launch_panel = false;               // LMGPU_PANEL_2L=1: diag_potrf + panel_trsm for every outer panel (A/B)
   bool no_fuse = false;                        // LMGPU_NO_FUSE=1: trailing update and next panel as separate launches (A/B)
   struct ChainPlan { int i0 = -1, nsteps = 0, ntasks = 0; int2* d_tasks = nullptr; double flop = 0; };
-  std::map<int, ChainPlan> chain_plans;        // per HBM front: ticket order of its chained launch (built at first use)
+  std::map<int, std::vector<ChainPlan>> chain_plans;  // per HBM front: ticket order of its chained launch(es) (built at first use)
   int chain_far_pct = 50;                      // LMGPU_CHAIN_FAR: tile rows beyond this percentage of the front are scheduled late (chain_schedule)
   double* d_lambda = nullptr;   // damping parameter of the solve being queued (device memory: see do_solve_enqueue)
   bool merge_backsub = false;   // LDS fronts of consecutive levels in one dataflow launch (deep trees; LMGPU_MERGE_BACKSUB=0/1)
@@ -746,36 +747,60 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
       };
       // a step that can be fused with the factorisation of the next panel; consecutive ones with full panels go as ONE launch
       auto fusable = [&](int i) { return (i + 1 < np) && dataflow_ok(i + 1) && !h->no_fuse && F.n - i * NBO - rows_of(i) > 0; };
+      // multi-rank (RCCL): the steps still go as chained launches -- their head tiles fold the all-reduced row chunks in -- but in
+      // SEGMENTS of 1, 1, 2, 4, 8, ... steps, each launched behind a stream wait for the event of the last chunk it touches: no
+      // workgroup ever waits for the network inside a launch (nothing to deadlock on), the first panels start after two chunks, and
+      // the communication stream gets further ahead with every segment (one launch per step cost 6.9 vs 6.2 ms for the C4 root in
+      // round 1).  The in-process test communicator sums on the host between the launches and keeps the per-step form.
+      const bool chain_split = split && h->comm != nullptr;
       auto chainable = [&](int i) {
-        return fusable(i) && !split && !h->no_chain && rows_of(i) == NBO && (F.n - (i + 1) * NBO + 127) / 128 <= PDF_MAX_CHAIN_T;
+        return fusable(i) && (!split || chain_split) && !h->no_chain && rows_of(i) == NBO && (F.n - (i + 1) * NBO + 127) / 128 <= PDF_MAX_CHAIN_T;
       };
       for (int i = 0; i < np; i++) {
         const int k0 = i * NBO, kb = rows_of(i), r0 = k0 + kb, m = F.n - r0;
         if (m <= 0) break;
         if (chainable(i) && chainable(i + 1)) {
-          // the run of chainable steps starting here: one launch, ticket order built once per front (chain_schedule)
-          lmgpu_handle::ChainPlan& cp = h->chain_plans[fi];
-          if (cp.i0 != i) {
-            if (cp.d_tasks) HIPCHECK(hipFree(cp.d_tasks));
-            cp = lmgpu_handle::ChainPlan{};
-            cp.i0 = i;
-            while (chainable(i + cp.nsteps)) {
-              const int is = i + cp.nsteps, ms = F.n - (is + 1) * NBO;
-              cp.flop += 2.0 * NBO * ((double)ms * (ms + 1) / 2.0) + panel_flop(is + 1);
-              cp.nsteps++;
+          // the run of chainable steps starting here: one launch (single rank) or a few segment launches (multi-rank), ticket order
+          // built once per front and segment (chain_schedule)
+          int run = 0;
+          while (chainable(i + run)) run++;
+          std::vector<lmgpu_handle::ChainPlan>& plans = h->chain_plans[fi];
+          if (plans.empty() || plans[0].i0 != i) {
+            for (auto& p : plans)
+              if (p.d_tasks) HIPCHECK(hipFree(p.d_tasks));
+            plans.clear();
+            int at = i, seg = 1, nseg = 0;
+            while (at < i + run) {
+              lmgpu_handle::ChainPlan cp;
+              cp.i0 = at;
+              cp.nsteps = chain_split ? std::min(seg, i + run - at) : run;
+              if (chain_split && i + run - (at + cp.nsteps) == 1) cp.nsteps++;  // no one-step remainder
+              for (int q = 0; q < cp.nsteps; q++) {
+                const int is = at + q, ms = F.n - (is + 1) * NBO;
+                cp.flop += 2.0 * NBO * ((double)ms * (ms + 1) / 2.0) + panel_flop(is + 1);
+              }
+              const std::vector<int2> tasks = chain_schedule(F.n, F.nf, cp.i0, cp.nsteps, h->chain_far_pct);
+              cp.ntasks = (int)tasks.size();
+              HIPCHECK(hipMalloc((void**)&cp.d_tasks, tasks.size() * sizeof(int2)));
+              HIPCHECK(hipMemcpyAsync(cp.d_tasks, tasks.data(), tasks.size() * sizeof(int2), hipMemcpyHostToDevice, s));
+              HIPCHECK(hipStreamSynchronize(s));  // `tasks` is a local
+              at += cp.nsteps;
+              if (++nseg >= 2) seg *= 2;
+              plans.push_back(cp);
             }
-            const std::vector<int2> tasks = chain_schedule(F.n, F.nf, i, cp.nsteps, h->chain_far_pct);
-            cp.ntasks = (int)tasks.size();
-            HIPCHECK(hipMalloc((void**)&cp.d_tasks, tasks.size() * sizeof(int2)));
-            HIPCHECK(hipMemcpyAsync(cp.d_tasks, tasks.data(), tasks.size() * sizeof(int2), hipMemcpyHostToDevice, s));
-            HIPCHECK(hipStreamSynchronize(s));  // `tasks` is a local
           }
-          ChainArgs ca{A, ld, F.n, F.nf, i, cp.nsteps, F.id, h->d_status, h->inv16, h->d_pflags, cp.d_tasks};
           close_run();
-          const int ktc = h->kt.begin(LMGPU_KT_CHAIN, s);
-          hipLaunchKernelGGL(chain_kernel, dim3(cp.ntasks), dim3(256), STEP_LDS_BYTES, s, ca);
-          h->kt.end(ktc, s, cp.flop, 1);
-          i += cp.nsteps - 1;
+          for (const lmgpu_handle::ChainPlan& cp : plans) {
+            if (split) {  // every row chunk the segment folds in (cp.i0 + 1 .. cp.i0 + cp.nsteps) is summed over the ranks
+              const int rcw = wait_chunk(cp.i0 + cp.nsteps);
+              if (rcw) return rcw;
+            }
+            ChainArgs ca{A, ld, F.n, F.nf, cp.i0, cp.nsteps, F.id, h->d_status, h->inv16, h->d_pflags, cp.d_tasks, split ? (const double*)Asm : nullptr};
+            const int ktc = h->kt.begin(LMGPU_KT_CHAIN, s);
+            hipLaunchKernelGGL(chain_kernel, dim3(cp.ntasks), dim3(256), STEP_LDS_BYTES, s, ca);
+            h->kt.end(ktc, s, cp.flop, 1);
+          }
+          i += run - 1;
           continue;
         }
         // the end of the front as one small launch: update with panel i, factor the last (partial) panel, update what follows
@@ -929,6 +954,7 @@ int do_backsub(lmgpu_handle* h) {
 // the new error behind the solve BEFORE it waits (one host round trip per inner iteration instead of two); their result is
 // simply not used when the solve failed or the linearised cost went up.
 __global__ void set_scalar_kernel(double* p, double v) { *p = v; }
+
 
 // everything of one damped solve that is queued on the stream
 int solve_sequence(lmgpu_handle* h, bool phase_events, double lambda_v, const double* lambda_p) {
@@ -1449,7 +1475,8 @@ int lmgpu_destroy(lmgpu_handle* h) {
       if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     for (hipEvent_t e : h->kt.pool) (void)hipEventDestroy(e);
     fr(h->bs_inv); fr(h->bs_x); fr(h->bs_flags); fr(h->inv16); fr(h->d_pflags); fr(h->d_bs_parent); fr(h->d_bs_pos); fr(h->d_bs_done); fr(h->d_leafpack); fr(h->d_gzero);
-    for (auto& kv : h->chain_plans) fr(kv.second.d_tasks);
+    for (auto& kv : h->chain_plans)
+      for (auto& cp : kv.second) fr(cp.d_tasks);
     fr(h->d_gpblk); fr(h->d_gpent); fr(h->d_gvblk); fr(h->d_gvent); fr(h->d_gcorner);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
@@ -2101,6 +2128,7 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
     HIPCHECK(hipMalloc((void**)&h->inv16, (size_t)((P.max_front_n + NBO - 1) / NBO + 2) * 16 * 256 * sizeof(double)));  // 16 blocks per outer panel
     h->pflags_panels = (P.max_front_n + NBO - 1) / NBO + 1;
     HIPCHECK(hipMalloc((void**)&h->d_pflags, (size_t)h->pflags_panels * PDF_FLAG_WORDS * sizeof(unsigned int)));
+
     HIPCHECK(hipMalloc((void**)&h->bs_x, (size_t)max_blk * NB * sizeof(double)));
     HIPCHECK(hipMalloc((void**)&h->bs_flags, (size_t)(max_blk + 1) * sizeof(unsigned int)));
   }
