@@ -89,3 +89,51 @@ def test_forced_relinearization_and_bare_updates():
         assert isam.update(force_relinearize=True).as_dict() == orc.update(force_relinearize=True)
         compare_state(isam, orc)
     isam.close()
+
+
+def test_incremental_pose_graph_like_time_incremental():
+    """timing/timeIncremental.cpp:84-170 on the first 400 poses of city10000 (tests/golden/city10000_head.g2o, 431 edges incl. loop
+    closures): one pose per update with the edges that reach back from it, the new pose initialised from the previous estimate composed
+    with the odometry; default ISAM2Params (relinearizeThreshold 0.1, relinearizeSkip 10).  Counts per update, the whole state every
+    40 updates and at the end, against the oracle."""
+    import os
+    from gtsam_personal_amd import NonlinearFactorGraph, Values, noiseModel
+    from gtsam_personal_amd.datasets import readG2o
+    graph, _ = readG2o(os.path.join(os.path.dirname(__file__), "golden", "city10000_head.g2o"))
+    edges = []  # (k1, k2, measured, model) in file order
+    for ftype, kind, gi, keys, meas, noise, models in graph.buckets():
+        for i, g in enumerate(gi.tolist()):
+            edges.append((g, int(keys[i][0]), int(keys[i][1]), meas[i], models[i]))
+    edges.sort()
+    p = ISAM2Params()
+    isam = ISAM2(p, ccolamd=ccolamd, device=0)
+    orc = oh.OracleISAM2(p.relinearizeThreshold, p.relinearizeSkip, p.enableRelinearization, p.optimizationParams.wildfireThreshold)
+
+    def compose(a, d):
+        c, s = np.cos(a[2]), np.sin(a[2])
+        return np.array([a[0] + c * d[0] - s * d[1], a[1] + s * d[0] + c * d[1], a[2] + d[2]])
+
+    nxt, step, n_poses = 0, 1, 1 + max(max(e[1], e[2]) for e in edges)
+    while nxt < len(edges):
+        g, v = NonlinearFactorGraph(), Values()
+        if step == 1:
+            v.insert_pose2(0, 0.0, 0.0, 0.0)
+            g.add_PriorFactorPose2(0, [0.0, 0.0, 0.0], noiseModel.Unit.Create(3))
+        while nxt < len(edges):
+            _, k1, k2, m, model = edges[nxt]
+            if k1 > step or k2 > step:
+                break
+            g.add_BetweenFactorPose2(k1, k2, m, model)
+            if k2 == step and k1 == step - 1:
+                prev = np.zeros(3) if step == 1 else orc.calculateEstimate().at(step - 1)
+                v.insert(step, 0, compose(prev, m))
+            nxt += 1
+        rg = isam.update(g, v).as_dict()
+        ro = orc.update(g, v)
+        assert rg == ro, (step, rg, ro)
+        if step % 40 == 0:
+            compare_state(isam, orc)
+        step += 1
+    assert isam.size() == n_poses
+    compare_state(isam, orc)
+    isam.close()
