@@ -32,6 +32,18 @@ __global__ __launch_bounds__(256) void med_assemble_children_kernel(MedLevel L, 
   assemble_child_body(F, L.f_off[fi], L.f_ld[fi], childs, cmap, pool, blockIdx.x, smap, blockIdx.z, gridDim.z);
 }
 
+// deterministic row-owner assembly (kernels_dense.hpp: assemble_row_body) for all medium fronts of a level: grid (max rows / 4, fronts)
+__global__ __launch_bounds__(256) void med_assemble_rows_kernel(MedLevel L, const int32_t* __restrict__ row_begin, const int32_t* __restrict__ rowptr,
+                                                                const RowSrc* __restrict__ src, const ChildRef* __restrict__ childs,
+                                                                const int32_t* __restrict__ cmap, const FrontFac* __restrict__ ffac,
+                                                                const FacDesc* __restrict__ fd, double* __restrict__ pool) {
+  const int fi = L.list[blockIdx.y];
+  const FrontDesc F = L.fronts[fi];
+  const int R = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (R >= F.n) return;
+  assemble_row_body(F, L.f_off[fi], L.f_ld[fi], rowptr + row_begin[fi], src, childs, cmap, ffac, fd, pool, R, true);
+}
+
 __global__ __launch_bounds__(256) void med_damp_kernel(MedLevel L, const int32_t* __restrict__ fxoff, double* __restrict__ pool, double lambda_v, const double* __restrict__ lambda_p,
                                                         const double* __restrict__ dampw, const double* __restrict__ gex) {
   const int fi = L.list[blockIdx.y];

@@ -88,6 +88,65 @@ __global__ __launch_bounds__(256) void hbm_assemble_children_kernel(FrontDesc F,
   assemble_child_body(F, f_off, ld, childs, cmap, pool, blockIdx.x, smap, blockIdx.y, gridDim.y);
 }
 
+// ---- atomic-free, bitwise-reproducible assembly of an HBM front: one WAVE owns one row of the front
+// Row R of the upper triangle receives every contribution whose smaller front index is R: from a child's update matrix U (row i of
+// the child maps to R) the entries U[min(i,j)][max(i,j)] for every child index j with map[j] >= R, and from an own factor whose
+// local column p maps to R the products sum_r J[r][p] J[r][q] for its columns q with column(q) >= R.  The sources of a row are a
+// list built once by the host (RowSrc: children in child order, then factors in graph order); the wave walks it sequentially, its
+// lanes take the j / q of one source (distinct destinations inside one source: a child's column map is injective) -- so every entry
+// of the front is a sum in a FIXED order with no atomics: two solves give bitwise the same front.  (The FP64 atomicAdd forms above
+// remain for the LMGPU_NO_GATHER development switch only.)
+struct RowSrc {
+  int32_t idx;  // >= 0: child reference (index into childs[]); < 0: own factor, -(index into ffac[]) - 1
+  int32_t i;    // child: row / column index inside its update matrix; factor: local column p of [A b]
+};
+__device__ __forceinline__ void assemble_row_body(const FrontDesc& F, int64_t f_off, int ld, const int32_t* __restrict__ rowptr, const RowSrc* __restrict__ src,
+                                                  const ChildRef* __restrict__ childs, const int32_t* __restrict__ cmap,
+                                                  const FrontFac* __restrict__ ffac, const FacDesc* __restrict__ fd, double* __restrict__ pool,
+                                                  int R, bool with_factors) {
+  const int lane = threadIdx.x & 63;
+  double* Arow = pool + f_off + (size_t)R * ld;
+  for (int e = rowptr[R]; e < rowptr[R + 1]; e++) {
+    const RowSrc sr = src[e];
+    if (sr.idx >= 0) {
+      const ChildRef c = childs[sr.idx];
+      const double* U = pool + c.u_off;
+      const int32_t* map = cmap + c.map_begin;
+      const int i = sr.i;
+      for (int j = lane; j < c.m; j += 64) {
+        const int gj = map[j];
+        if (gj >= R) Arow[gj] += (j >= i) ? U[(size_t)i * c.ld + j] : U[(size_t)j * c.ld + i];
+      }
+    } else if (with_factors) {
+      const FrontFac ff = ffac[-sr.idx - 1];
+      const FacDesc d = fd[ff.fac];
+      const double* J = pool + d.joff;
+      const int m = d.rows, nc = d.d0 + d.d1 + 1, p = sr.i;
+      for (int q = lane; q < nc; q += 64) {
+        const int gq = (q < d.d0) ? ff.c0 + q : (q < d.d0 + d.d1 ? ff.c1 + (q - d.d0) : F.n - 1);
+        if (gq > R || (gq == R && q == p)) {
+          double v = 0;
+          for (int r = 0; r < m; r++) v += J[p * m + r] * J[q * m + r];
+          Arow[gq] += v;
+        }
+      }
+    }
+    // the next source of this row may touch the same entries from other lanes of this wave
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+// grid: ceil(n / 4) blocks of 4 waves
+__global__ __launch_bounds__(256) void hbm_assemble_rows_kernel(FrontDesc F, int64_t f_off, int ld, const int32_t* __restrict__ rowptr,
+                                                                const RowSrc* __restrict__ src, const ChildRef* __restrict__ childs,
+                                                                const int32_t* __restrict__ cmap, const FrontFac* __restrict__ ffac,
+                                                                const FacDesc* __restrict__ fd, double* __restrict__ pool, int with_factors) {
+  const int R = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (R >= F.n) return;
+  assemble_row_body(F, f_off, ld, rowptr, src, childs, cmap, ffac, fd, pool, R, with_factors != 0);
+}
+
 __global__ __launch_bounds__(256) void hbm_damp_kernel(FrontDesc F, int64_t f_off, int ld, const int32_t* __restrict__ fxoff,
                                                         double* __restrict__ pool, double lambda_v, const double* __restrict__ lambda_p, const double* __restrict__ dampw,
                                                         const double* __restrict__ gex) {

@@ -86,7 +86,7 @@ struct LevelWork {
   std::vector<int> hbm;  // HBM fronts of this level
   int small_begin = 0, small_count = 0;  // those with nf <= BSS_MAX_NF, in d_hbm_small: back-substituted in one launch per level
   // "medium" HBM fronts (one outer panel, no gather leaves, not replicated): eliminated with batched launches (kernels_batched.hpp)
-  int med_begin = 0, med_count = 0, med_max_fac = 0, med_max_child = 0, med_max_nf = 0, med_max_cols = 0;
+  int med_begin = 0, med_count = 0, med_max_fac = 0, med_max_child = 0, med_max_nf = 0, med_max_cols = 0, med_max_n = 0;
 };
 
 struct KTimer {
@@ -246,6 +246,12 @@ struct lmgpu_handle {
   ChildRef* d_childs = nullptr;
   int32_t *d_cmap = nullptr, *d_fxoff = nullptr, *d_sxoff = nullptr, *d_lists = nullptr;
   int32_t *d_hbm_small = nullptr, *d_f_ld = nullptr, *d_med_list = nullptr;
+  // deterministic assembly of HBM fronts (kernels_dense.hpp: hbm_assemble_rows_kernel): per front the start of its n + 1 row
+  // pointers in d_rowptr (-1: none), the pointers (offsets into d_rowsrc) and the sources
+  std::vector<int32_t> row_begin;
+  int32_t *d_row_begin = nullptr, *d_rowptr = nullptr;
+  RowSrc* d_rowsrc = nullptr;
+  bool scatter_atomics = false;  // LMGPU_NO_GATHER=1 (development switch): the round-1 FP64-atomic forms
   int n_lds_fronts = 0;                         // all levels' LDS-class fronts are contiguous in d_lists
   double *bt_ebuf = nullptr, *bt_vec = nullptr;  // Dogleg: per-clique / per-row squared residuals; gradient / zero vector
   int bt_ebuf_len = 0;
@@ -571,12 +577,19 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
                         (const int32_t*)h->d_f_ld};
       const unsigned cnt = (unsigned)L.med_count;
       int ktm = h->kt.begin(LMGPU_KT_HBM_ASSEMBLE, s);
-      if (L.med_max_fac > 0)
-        hipLaunchKernelGGL(med_assemble_factors_kernel, dim3(L.med_max_fac, cnt), dim3(64), 0, s, ML, (const FrontFac*)h->d_ffac,
-                           (const FacDesc*)h->d_fd, h->pool);
-      if (L.med_max_child > 0)
-        hipLaunchKernelGGL(med_assemble_children_kernel, dim3(L.med_max_child, cnt, kChildSplit), dim3(256), 0, s, ML, (const ChildRef*)h->d_childs,
-                           (const int32_t*)h->d_cmap, h->pool);
+      if (!h->scatter_atomics) {
+        if (L.med_max_fac > 0 || L.med_max_child > 0)
+          hipLaunchKernelGGL(med_assemble_rows_kernel, dim3((L.med_max_n + 3) / 4, cnt), dim3(256), 0, s, ML, (const int32_t*)h->d_row_begin,
+                             (const int32_t*)h->d_rowptr, (const RowSrc*)h->d_rowsrc, (const ChildRef*)h->d_childs, (const int32_t*)h->d_cmap,
+                             (const FrontFac*)h->d_ffac, (const FacDesc*)h->d_fd, h->pool);
+      } else {
+        if (L.med_max_fac > 0)
+          hipLaunchKernelGGL(med_assemble_factors_kernel, dim3(L.med_max_fac, cnt), dim3(64), 0, s, ML, (const FrontFac*)h->d_ffac,
+                             (const FacDesc*)h->d_fd, h->pool);
+        if (L.med_max_child > 0)
+          hipLaunchKernelGGL(med_assemble_children_kernel, dim3(L.med_max_child, cnt, kChildSplit), dim3(256), 0, s, ML, (const ChildRef*)h->d_childs,
+                             (const int32_t*)h->d_cmap, h->pool);
+      }
       hipLaunchKernelGGL(med_damp_kernel, dim3((L.med_max_nf + 255) / 256, cnt), dim3(256), 0, s, ML, (const int32_t*)h->d_fxoff, h->pool, lambda_v,
                          lambda_p, (const double*)h->dampw, (const double*)h->gex_active);
       h->kt.end(ktm, s);
@@ -628,14 +641,28 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
       const bool gwrite = gather_writes(h, fi);
       if (gwrite && G.zero_count > 0)
         hipLaunchKernelGGL(zero_blocks_kernel, dim3(G.zero_count), dim3(128), 0, sa, (const GZeroBlock*)(h->d_gzero + G.zero_begin), h->pool, aoff, ld);
-      if (F.fac_count > 0 && own_terms && !gwrite)
-        hipLaunchKernelGGL(hbm_assemble_factors_kernel, dim3(F.fac_count), dim3(64), 0, sa, F, aoff, ld, (const FrontFac*)h->d_ffac,
-                           (const FacDesc*)h->d_fd, h->pool);
-      if (F.child_count > 0)
-        hipLaunchKernelGGL(hbm_assemble_children_kernel, dim3(F.child_count, kChildSplit), dim3(256), 0, sa, F, aoff, ld, (const ChildRef*)h->d_childs,
-                           (const int32_t*)h->d_cmap, h->pool);
+      // own factors and children's update matrices: one wave per row of the front walks that row's sources in a fixed order (no
+      // atomics, bitwise reproducible); with_factors = 0 on the ranks that leave the own terms to rank 0
+      auto assemble_rows = [&](bool with_factors) {
+        if (h->row_begin[fi] >= 0 && (F.child_count > 0 || (with_factors && F.fac_count > 0)))
+          hipLaunchKernelGGL(hbm_assemble_rows_kernel, dim3((F.n + 3) / 4), dim3(256), 0, sa, F, aoff, ld, (const int32_t*)(h->d_rowptr + h->row_begin[fi]),
+                             (const RowSrc*)h->d_rowsrc, (const ChildRef*)h->d_childs, (const int32_t*)h->d_cmap, (const FrontFac*)h->d_ffac,
+                             (const FacDesc*)h->d_fd, h->pool, with_factors ? 1 : 0);
+      };
+      if (!h->scatter_atomics) {
+        assemble_rows(own_terms && !gwrite);
+      } else {
+        if (F.fac_count > 0 && own_terms && !gwrite)
+          hipLaunchKernelGGL(hbm_assemble_factors_kernel, dim3(F.fac_count), dim3(64), 0, sa, F, aoff, ld, (const FrontFac*)h->d_ffac,
+                             (const FacDesc*)h->d_fd, h->pool);
+        if (F.child_count > 0)
+          hipLaunchKernelGGL(hbm_assemble_children_kernel, dim3(F.child_count, kChildSplit), dim3(256), 0, sa, F, aoff, ld, (const ChildRef*)h->d_childs,
+                             (const int32_t*)h->d_cmap, h->pool);
+      }
       auto own_additive_terms = [&]() {  // the front's own factors and the damping (added: after whatever initialises the entries)
-        if (F.fac_count > 0 && own_terms)
+        if (F.fac_count > 0 && own_terms && !h->scatter_atomics)
+          assemble_rows(true);  // (a gather-write front has no update-matrix children: only its factors are added here)
+        else if (F.fac_count > 0 && own_terms)
           hipLaunchKernelGGL(hbm_assemble_factors_kernel, dim3(F.fac_count), dim3(64), 0, sa, F, aoff, ld, (const FrontFac*)h->d_ffac,
                              (const FacDesc*)h->d_fd, h->pool);
         if (own_terms)
@@ -1416,6 +1443,7 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
   h->no_chain = getenv("LMGPU_NO_CHAIN") != nullptr;
   h->no_tail = getenv("LMGPU_NO_TAIL") != nullptr;
   h->no_gather_write = getenv("LMGPU_NO_GATHER_WRITE") != nullptr;
+  h->scatter_atomics = getenv("LMGPU_NO_GATHER") != nullptr;
   if (const char* e = getenv("LMGPU_CHAIN_FAR")) h->chain_far_pct = std::max(10, std::min(100, atoi(e)));
   *out = h;
   if (h->device >= 0) {
@@ -1477,7 +1505,7 @@ int lmgpu_destroy(lmgpu_handle* h) {
     fr(h->bs_inv); fr(h->bs_x); fr(h->bs_flags); fr(h->inv16); fr(h->d_pflags); fr(h->d_bs_parent); fr(h->d_bs_pos); fr(h->d_bs_done); fr(h->d_leafpack); fr(h->d_gzero);
     for (auto& kv : h->chain_plans)
       for (auto& cp : kv.second) fr(cp.d_tasks);
-    fr(h->d_gpblk); fr(h->d_gpent); fr(h->d_gvblk); fr(h->d_gvent); fr(h->d_gcorner);
+    fr(h->d_gpblk); fr(h->d_gpent); fr(h->d_gvblk); fr(h->d_gvent); fr(h->d_gcorner); fr(h->d_row_begin); fr(h->d_rowptr); fr(h->d_rowsrc);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
     for (int g = 0; g < 2; g++)
@@ -1659,6 +1687,9 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
   std::vector<GVarEntry> gvent;
   h->gather.assign(NF, lmgpu_handle::GatherRange());
   std::vector<FrontFac> ffac;
+  std::vector<int32_t> rowptr;
+  std::vector<RowSrc> rowsrc;
+  h->row_begin.assign(NF, -1);
   std::vector<ChildRef> childs;
   std::vector<int32_t> cmap, fxoff, sxoff;
   std::vector<int32_t> colof(P.n_vars, -1);
@@ -1681,14 +1712,14 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
       //   leaves (no children): the parent GATHERS -[S d]^T [S d] and the factor terms itself (kernels_schur.hpp), par_ld = -1
       //   others: scattered straight into the parent with FP64 atomics (par_ld > 0, filled in when the parent is laid out)
       const bool direct = fr.parent >= 0 && P.fronts[fr.parent].cls == 1;
-      if (direct) {
+      if (direct && (h->scatter_atomics || fr.children.empty())) {
         F.u_off = -1;
-        if (fr.children.empty() && !getenv("LMGPU_NO_GATHER")) {
+        if (fr.children.empty() && !h->scatter_atomics) {
           F.par_ld = -1;
           F.u_off = off;  // gather leaves also keep [S d] transposed ((n - nf) x nf: every variable's block contiguous)
           off += (int64_t)F.ld_u * fr.nf;
         }
-      } else {
+      } else {  // (a non-leaf LDS child of an HBM front writes its update matrix too: the parent's rows collect it in a fixed order)
         F.u_off = off;
         off += (int64_t)F.ld_u * F.ld_u;
       }
@@ -1777,6 +1808,28 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
       childs.push_back(cr);
     }
     F.child_count = (int)childs.size() - F.child_begin;
+    if (fr.cls == 1 && !h->scatter_atomics && (F.child_count > 0 || F.fac_count > 0)) {  // row -> sources, for the deterministic assembly
+      std::vector<std::vector<RowSrc>> rows(fr.n);
+      for (int k = 0; k < F.child_count; k++) {
+        const ChildRef& c = childs[F.child_begin + k];
+        for (int i = 0; i < c.m; i++) rows[cmap[c.map_begin + i]].push_back(RowSrc{F.child_begin + k, i});
+      }
+      for (int k = 0; k < F.fac_count; k++) {
+        const FrontFac& ff = ffac[F.fac_begin + k];
+        const FacDesc& d = fd[ff.fac];
+        const int nc = d.d0 + d.d1 + 1;
+        for (int p = 0; p < nc; p++) {
+          const int gp = (p < d.d0) ? ff.c0 + p : (p < d.d0 + d.d1 ? ff.c1 + (p - d.d0) : fr.n - 1);
+          rows[gp].push_back(RowSrc{-(F.fac_begin + k) - 1, p});
+        }
+      }
+      h->row_begin[fi] = (int32_t)rowptr.size();
+      for (int R2 = 0; R2 < fr.n; R2++) {
+        rowptr.push_back((int32_t)rowsrc.size());
+        rowsrc.insert(rowsrc.end(), rows[R2].begin(), rows[R2].end());
+      }
+      rowptr.push_back((int32_t)rowsrc.size());
+    }
     if (!gp_tmp.empty() || !gv_tmp.empty()) {
       lmgpu_handle::GatherRange& G = h->gather[fi];
       std::stable_sort(gp_tmp.begin(), gp_tmp.end(), [](const GPairTmp& a, const GPairTmp& b) { return a.key < b.key; });
@@ -2029,6 +2082,7 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
         L.med_max_child = std::max(L.med_max_child, F.child_count);
         L.med_max_nf = std::max(L.med_max_nf, fr.nf);
         L.med_max_cols = std::max(L.med_max_cols, fr.n - fr.nf);
+        L.med_max_n = std::max(L.med_max_n, (int)fr.n);
       }
       L.med_count = (int)med.size() - L.med_begin;
       max_med = std::max(max_med, L.med_count);
@@ -2038,6 +2092,9 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
     if ((rc = upload(h, &h->d_f_off, h->f_off))) return rc;
     if ((rc = upload(h, &h->d_f_ld, h->f_ld))) return rc;
   }
+  if ((rc = upload(h, &h->d_row_begin, h->row_begin))) return rc;
+  if ((rc = upload(h, &h->d_rowptr, rowptr))) return rc;
+  if ((rc = upload(h, &h->d_rowsrc, rowsrc))) return rc;
   if ((rc = upload(h, &h->d_gpblk, gpblk))) return rc;
   if ((rc = upload(h, &h->d_gzero, gzero))) return rc;
   if ((rc = upload(h, &h->d_gpent, gpent))) return rc;

@@ -91,3 +91,28 @@ def test_victoria_park_full(which):
     graph.add_PriorFactorPose2(0, initial.at(0), noiseModel.Diagonal.Variances([1e-6, 1e-6, 1e-8]))
     ordering = oh.colamd(graph) if which == "colamd" else oh.metis(graph)
     _compare(graph, initial, ordering, 1e-5, 2, range(0, graph.size(), 173))
+
+
+@pytest.mark.parametrize("name", ["sphere2500", "city10000"])
+def test_general_sparse_solves_are_bitwise_reproducible(name):
+    """every front is assembled in a fixed order (Schur gather for leaf children, one wave per front row for update matrices and own
+    factors: no FP64 atomics anywhere on the default path), so two solves of the same linearization give bitwise the same update
+    vector and the same [R S d] of the root -- on the general sparse graphs too, not only on BAL"""
+    if name == "sphere2500":
+        graph, _ = load3D(os.path.join(GOLD, "sphere2500.txt"))
+        initial = chain_initial_pose3(graph)
+        graph.add_PriorFactorPose3(0, np.eye(3), np.zeros(3), noiseModel.Diagonal.Variances([1e-6, 1e-6, 1e-6, 1e-4, 1e-4, 1e-4]))
+    else:
+        graph, initial = readG2o(os.path.join(GOLD, "city10000.g2o"))
+        graph.add_PriorFactorPose2(0, initial.at(0), noiseModel.Diagonal.Variances([1e-6, 1e-6, 1e-8]))
+    ordering = oh.colamd(graph)
+    opt = LevenbergMarquardtOptimizer(graph, initial, ordering, LevenbergMarquardtParams(), device=0)
+    opt.linearize()
+    runs = []
+    for _ in range(3):
+        _, d, e0, e1 = opt.solve(1e-3)
+        _, R = opt.front(opt.num_fronts() - 1)
+        runs.append((d.copy(), R.copy(), e0, e1))
+    for d, R, e0, e1 in runs[1:]:
+        assert np.array_equal(d, runs[0][0]) and np.array_equal(R, runs[0][1]) and e0 == runs[0][2] and e1 == runs[0][3]
+    opt.close()
