@@ -26,6 +26,8 @@
 #include <gtsam/linear/linearExceptions.h>
 #include <gtsam/nonlinear/DoglegOptimizer.h>
 #include <gtsam/nonlinear/GaussNewtonOptimizer.h>
+#include <gtsam/nonlinear/ISAM2.h>
+#include <gtsam/3rdparty/CCOLAMD/Include/ccolamd.h>
 #include <gtsam/nonlinear/LevenbergMarquardtOptimizer.h>
 #include <gtsam/nonlinear/PriorFactor.h>
 #include <gtsam/nonlinear/internal/LevenbergMarquardtState.h>
@@ -399,6 +401,130 @@ class GpuDoglegOptimizer : public NonlinearOptimizer {
   const NonlinearOptimizerParams& _params() const override { return params_; }
   DoglegParams params_;
   std::unique_ptr<lmgpu_detail::Device> dev_;
+};
+
+/// ISAM2 on the device (lmgpu_isam2_*): the same update() / calculateEstimate() calls as gtsam::ISAM2 (gtsam/nonlinear/ISAM2.h:146-260)
+/// for the parameter subset the C ABI binds (Gauss-Newton optimisation params, one relinearization threshold, Cholesky).  Not a
+/// subclass: ISAM2 is a BayesTree<ISAM2Clique> whose cliques live on the host; here the tree lives on the device and only the
+/// estimate comes back.  The constrained COLAMD of recalculate() stays on this side: the callback below is the body of
+/// Ordering::ColamdConstrained (gtsam/inference/Ordering.cpp:86-108) on the arrays the library hands over.
+class GpuISAM2 {
+ public:
+  explicit GpuISAM2(const ISAM2Params& params = ISAM2Params(), int device = 0) {
+    if (!std::holds_alternative<ISAM2GaussNewtonParams>(params.optimizationParams) || !std::holds_alternative<double>(params.relinearizeThreshold) ||
+        params.factorization != ISAM2Params::CHOLESKY || params.findUnusedFactorSlots || params.enablePartialRelinearizationCheck)
+      throw std::invalid_argument("GpuISAM2: parameter set not bound (Gauss-Newton, scalar threshold, Cholesky only)");
+    lmgpu_isam2_params p{std::get<double>(params.relinearizeThreshold), params.relinearizeSkip, params.enableRelinearization ? 1 : 0,
+                         std::get<ISAM2GaussNewtonParams>(params.optimizationParams).wildfireThreshold};
+    lmgpu_config cfg{device, 0, 1, 0};
+    if (lmgpu_isam2_create(&cfg, &p, &GpuISAM2::Ccolamd, nullptr, &h_) != LMGPU_OK) {
+      const std::string why = h_ ? lmgpu_isam2_last_error(h_) : "lmgpu_isam2_create failed";
+      if (h_) lmgpu_isam2_destroy(h_);
+      throw std::runtime_error(why);
+    }
+  }
+  ~GpuISAM2() { if (h_) lmgpu_isam2_destroy(h_); }
+  GpuISAM2(const GpuISAM2&) = delete;
+  GpuISAM2& operator=(const GpuISAM2&) = delete;
+
+  /// ISAM2::update(newFactors, newTheta) (ISAM2.cpp:404-480, default ISAM2UpdateParams)
+  lmgpu_isam2_result update(const NonlinearFactorGraph& newFactors = NonlinearFactorGraph(), const Values& newTheta = Values(),
+                            bool force_relinearize = false) {
+    std::vector<uint64_t> keys;
+    std::vector<int32_t> types;
+    std::vector<double> packed;
+    for (const auto& kv : newTheta) {
+      const int32_t t = lmgpu_detail::variableType(kv.value);
+      keys.push_back(kv.key);
+      types.push_back(t);
+      double v[15];
+      packOne(newTheta, kv.key, t, v);
+      packed.insert(packed.end(), v, v + lmgpu_adapter::varStore(t));
+      all_.insert(kv.key, kv.value);  // keeps what does not travel (Cal3Bundler's principal point) and the types for download
+    }
+    check(lmgpu_isam2_add_variables(h_, (int32_t)keys.size(), keys.data(), types.data(), packed.data()));
+    for (size_t i = 0; i < newFactors.size(); i++) {
+      if (!newFactors[i]) continue;
+      auto nm = std::dynamic_pointer_cast<NoiseModelFactor>(newFactors[i]);
+      int32_t type;
+      std::vector<double> meas;
+      if (!nm || !lmgpu_detail::extractFactor(newFactors[i], all_, &type, &meas)) throw std::invalid_argument("GpuISAM2: factor type not bound");
+      const lmgpu_detail::Noise nz = lmgpu_detail::extractNoise(nm->noiseModel());
+      if (nz.robust != LMGPU_ROBUST_NONE) throw std::invalid_argument("GpuISAM2: robust noise models are not bound in the incremental path");
+      std::vector<uint64_t> fk(nm->keys().begin(), nm->keys().end());
+      check(lmgpu_isam2_add_factors(h_, type, 1, fk.data(), meas.data(), nz.kind, nz.data.empty() ? nullptr : nz.data.data()));
+    }
+    lmgpu_isam2_result r{};
+    check(lmgpu_isam2_update(h_, force_relinearize ? 1 : 0, &r));
+    return r;
+  }
+
+  Values calculateEstimate() const { return download(0); }
+  Values calculateBestEstimate() const { return download(1); }
+  Values getLinearizationPoint() const { return download(2); }
+
+ private:
+  static int Ccolamd(void*, int32_t n_rows, int32_t n_cols, const int32_t* col_ptr, const int32_t* row_idx, const int32_t* cmember, int32_t* perm_out) {
+    const size_t Alen = ccolamd_recommended(col_ptr[n_cols], n_rows, n_cols);
+    std::vector<int> A(Alen), p(col_ptr, col_ptr + n_cols + 1), cm(cmember, cmember + n_cols);
+    std::copy(row_idx, row_idx + col_ptr[n_cols], A.begin());
+    double knobs[CCOLAMD_KNOBS];
+    ccolamd_set_defaults(knobs);
+    knobs[CCOLAMD_DENSE_ROW] = -1;
+    knobs[CCOLAMD_DENSE_COL] = -1;
+    int stats[CCOLAMD_STATS];
+    if (ccolamd(n_rows, n_cols, (int)Alen, A.data(), p.data(), knobs, stats, cm.data()) != 1) return 0;
+    std::copy(p.begin(), p.begin() + n_cols, perm_out);
+    return 1;
+  }
+  void check(int rc) const {
+    if (rc == LMGPU_OK) return;
+    if (rc == LMGPU_INDETERMINATE) throw IndeterminantLinearSystemException(lmgpu_isam2_last_failed_key(h_));
+    throw std::runtime_error(lmgpu_isam2_last_error(h_));
+  }
+  static void packOne(const Values& v, Key k, int32_t t, double* o) {
+    switch (t) {
+      case LMGPU_POSE2: { const Pose2& q = v.at<Pose2>(k); o[0] = q.x(); o[1] = q.y(); o[2] = q.theta(); break; }
+      case LMGPU_POSE3: lmgpu_detail::packPose3(v.at<Pose3>(k), o); break;
+      case LMGPU_POINT3: { const Point3& q = v.at<Point3>(k); o[0] = q.x(); o[1] = q.y(); o[2] = q.z(); break; }
+      case LMGPU_POINT2: { const Point2& q = v.at<Point2>(k); o[0] = q.x(); o[1] = q.y(); break; }
+      default: {
+        const lmgpu_detail::Camera& c = v.at<lmgpu_detail::Camera>(k);
+        lmgpu_detail::packPose3(c.pose(), o);
+        o[12] = c.calibration().fx(); o[13] = c.calibration().k1(); o[14] = c.calibration().k2();
+      }
+    }
+  }
+  Values download(int which) const {
+    const int n = lmgpu_isam2_num_variables(h_);
+    std::vector<uint64_t> keys((size_t)n);
+    std::vector<int32_t> types((size_t)n);
+    check(lmgpu_isam2_get_values(h_, 2, keys.data(), types.data(), nullptr));
+    size_t tot = 0;
+    for (int32_t t : types) tot += (size_t)lmgpu_adapter::varStore(t);
+    std::vector<double> packed(tot);
+    check(lmgpu_isam2_get_values(h_, which, nullptr, nullptr, packed.data()));
+    Values out;
+    const double* q = packed.data();
+    for (int i = 0; i < n; i++) {
+      const Key k = keys[(size_t)i];
+      switch (types[(size_t)i]) {
+        case LMGPU_POSE2: out.insert(k, Pose2(q[0], q[1], q[2])); break;
+        case LMGPU_POSE3: out.insert(k, lmgpu_detail::unpackPose3(q)); break;
+        case LMGPU_POINT3: out.insert(k, Point3(q[0], q[1], q[2])); break;
+        case LMGPU_POINT2: out.insert(k, Point2(q[0], q[1])); break;
+        default: {
+          const Cal3Bundler& K0 = all_.at<lmgpu_detail::Camera>(k).calibration();
+          out.insert(k, lmgpu_detail::Camera(lmgpu_detail::unpackPose3(q), Cal3Bundler(q[12], q[13], q[14], K0.px(), K0.py())));
+        }
+      }
+      q += lmgpu_adapter::varStore(types[(size_t)i]);
+    }
+    return out;
+  }
+
+  lmgpu_isam2* h_ = nullptr;
+  Values all_;  // every variable ever added, at its initial value
 };
 
 }  // namespace gtsam

@@ -8,7 +8,9 @@ REF = "/root/reference/examples/Data"
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 # verbatim inputs (sphere2500 / city10000 in full: configs C3 / C1 at the reference's own size)
-for name in ("dubrovnik-3-7-pre.txt", "pose3example.txt", "noisyToyGraph.txt", "sphere2500.txt", "city10000.g2o", "w100.graph", "pose2example.txt"):
+# (victoria_park.txt: the planar landmark-SLAM input of timing/timeIncremental.cpp -- bearing-range factors, 6 969 poses)
+for name in ("dubrovnik-3-7-pre.txt", "pose3example.txt", "noisyToyGraph.txt", "sphere2500.txt", "city10000.g2o", "w100.graph", "pose2example.txt",
+             "victoria_park.txt"):
     shutil.copy(os.path.join(REF, name), os.path.join(HERE, name))
 
 # first 300 poses of sphere2500 (EDGE3 lines whose two ids are < 300)
@@ -28,3 +30,7 @@ with open(os.path.join(REF, "city10000.g2o")) as f, open(os.path.join(HERE, "cit
             o.write(ln)
         if t[0] == "EDGE_SE2" and int(t[1]) < 400 and int(t[2]) < 400:
             o.write(ln)
+
+# Derived fixtures (numbers the oracle / the reference's vendored CCOLAMD + METIS produced; each has its own generator):
+#   c4_seed42_{schur,metis}.npz, bal100_seed42_{schur,metis}.npz, *_timing.json   tools/make_c4_fixture.py
+#   slam_orderings.npz                                                             tools/make_ordering_fixtures.py
