@@ -94,12 +94,9 @@ SYMBOLS = {
     "lmgpu_get_front": (ct.c_int, [_H, ct.c_int32, _I, _D]),
     "lmgpu_comm_unique_id": (ct.c_int, [ct.c_char_p]),
     "lmgpu_comm_init": (ct.c_int, [_H, ct.c_char_p]),
-    "lmgpu_local_group_create": (ct.c_int, [ct.c_int32, ct.POINTER(ct.c_void_p)]),
-    "lmgpu_local_group_destroy": (ct.c_int, [ct.c_void_p]),
     "lmgpu_marginal_covariance": (ct.c_int, [_H, ct.c_int32, _D]),
     "lmgpu_joint_marginal_covariance": (ct.c_int, [_H, ct.c_int32, _I, _D]),
     "lmgpu_selftest_chain_schedule": (ct.c_int, [ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_int]),
-    "lmgpu_comm_init_local": (ct.c_int, [_H, ct.c_void_p]),
     "lmgpu_isam2_create": (ct.c_int, [ct.POINTER(lmgpu_config), ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.POINTER(_H)]),
     "lmgpu_isam2_destroy": (ct.c_int, [_H]),
     "lmgpu_isam2_last_error": (ct.c_char_p, [_H]),
@@ -119,14 +116,35 @@ SYMBOLS = {
     "lmgpu_peak_hbm_copy": (ct.c_int, [ct.c_int32, ct.c_int64, ct.c_int32, _D]),
 }
 
+# test hooks: liblmgpu_test.so only (include/lmgpu.h, LMGPU_TEST_HOOKS)
+TEST_SYMBOLS = {
+    "lmgpu_local_group_create": (ct.c_int, [ct.c_int32, ct.POINTER(ct.c_void_p)]),
+    "lmgpu_local_group_destroy": (ct.c_int, [ct.c_void_p]),
+    "lmgpu_comm_init_local": (ct.c_int, [_H, ct.c_void_p]),
+}
+
 KT_NAMES = ("linearize", "lds_front", "hbm_assemble", "panel", "syrk", "backsub_hbm", "backsub_lds", "linear_error", "retract_error", "allreduce", "chain")
 
 _lib = None
+_lib_test = None
+TEST_LIB_PATH = os.path.join(_HERE, "liblmgpu_test.so")
 
 
-def load():
-    """Load liblmgpu.so once; raises if it has not been built (no fallback)."""
-    global _lib
+def load(test_hooks=False):
+    """Load liblmgpu.so once; raises if it has not been built (no fallback).  test_hooks=True: liblmgpu_test.so, the same library
+    built with the in-process communicator the sharded-loop test needs (never used by the product path)."""
+    global _lib, _lib_test
+    if test_hooks:
+        if _lib_test is None:
+            if not os.path.exists(TEST_LIB_PATH):
+                raise ImportError(f"{TEST_LIB_PATH} not built: run `make -C gtsam_personal_amd/csrc`")
+            lib = ct.CDLL(TEST_LIB_PATH)
+            for name, (res, args) in list(SYMBOLS.items()) + list(TEST_SYMBOLS.items()):
+                fn = getattr(lib, name)
+                fn.restype = res
+                fn.argtypes = args
+            _lib_test = lib
+        return _lib_test
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -2583,6 +2583,7 @@ int lmgpu_comm_init(lmgpu_handle* h, const char id128[128]) {
   return LMGPU_OK;
 }
 
+#ifdef LMGPU_TEST_HOOKS  // in-process stand-in for the communicator: exported by liblmgpu_test.so only
 int lmgpu_local_group_create(int32_t world_size, lmgpu_local_group** out) {
   if (!out || world_size < 1) return LMGPU_INVALID;
   lmgpu_local_group* g = new lmgpu_local_group();
@@ -2592,6 +2593,7 @@ int lmgpu_local_group_create(int32_t world_size, lmgpu_local_group** out) {
   *out = g;
   return LMGPU_OK;
 }
+#endif
 // Host-only check of the ticket order of a chained launch (kernels_step.hpp: chain_schedule): every logical workgroup of every
 // step exactly once, and every dependency step_body waits for at an earlier ticket.  0 = valid, else the 1-based ticket at fault.
 int lmgpu_selftest_chain_schedule(int n, int nf, int i0, int nsteps, int far_pct) {
@@ -2672,6 +2674,7 @@ int lmgpu_selftest_chain_schedule(int n, int nf, int i0, int nsteps, int far_pct
   return 0;
 }
 
+#ifdef LMGPU_TEST_HOOKS
 int lmgpu_local_group_destroy(lmgpu_local_group* g) {
   delete g;
   return LMGPU_OK;
@@ -2681,8 +2684,10 @@ int lmgpu_comm_init_local(lmgpu_handle* h, lmgpu_local_group* g) {
   h->lgroup = g;
   return LMGPU_OK;
 }
+#endif
 
 // ---------------------------------------------------------------- peak micro-benchmarks
+
 __global__ __launch_bounds__(256) void peak_mfma_f64_kernel(double* out, int iters) {
   double4_t acc[4];
   for (int i = 0; i < 4; i++) acc[i] = double4_t{0, 0, 0, 0};

@@ -90,7 +90,7 @@ class LevenbergMarquardtOptimizer:
         if ordering is None:
             raise ValueError("an elimination Ordering is required (Ordering.Schur / Ordering.Natural, or COLAMD/METIS from the caller)")
         self.graph, self.ordering = graph, Ordering(ordering)
-        self.lib = _lib.load()
+        self.lib = _lib.load(test_hooks=local_group is not None)  # the in-process communicator lives in liblmgpu_test.so only
         self._h = ct.c_void_p()
         cfg = _lib.lmgpu_config(device, rank, world_size, 1 if split_root else 0)
         self._check(self.lib.lmgpu_create(ct.byref(cfg), ct.byref(self._h)))

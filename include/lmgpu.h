@@ -229,13 +229,6 @@ int lmgpu_get_front(lmgpu_handle* h, int32_t front, int32_t* slots, double* RSd_
 int lmgpu_comm_unique_id(char id128[128]);
 int lmgpu_comm_init(lmgpu_handle* h, const char id128[128]);
 
-/* In-process stand-in for the RCCL communicator (testing aid): W handles created by W threads of ONE process on one
- * device sum their buffers through a host rendezvous, at exactly the call sites where the RCCL path all-reduces.
- * Lets the sharded LM loop run end to end on a single GPU.  Every rank must drive its handle from its own thread. */
-typedef struct lmgpu_local_group lmgpu_local_group;
-int lmgpu_local_group_create(int32_t world_size, lmgpu_local_group** out);
-int lmgpu_local_group_destroy(lmgpu_local_group* g);
-
 /* Marginals(graph, values).marginalCovariance(variable)  (gtsam/nonlinear/Marginals.cpp:28-33 constructor: linearize at the
  * solution and eliminate into a Bayes tree; :124-127 marginalCovariance = inverse of the marginal information :109-121):
  * the dim x dim covariance (row-major) of the variable in `slot` at the handle's current values, i.e. its diagonal block of
@@ -254,7 +247,6 @@ int lmgpu_joint_marginal_covariance(lmgpu_handle* h, int32_t nslots, const int32
  * in-launch dependency points to an earlier ticket.  0 = valid.  No reference counterpart (the reference factors a front with
  * one Eigen LLT call, gtsam/base/cholesky.cpp:108-159); it exists so that the CPU test-suite can check the scheduler. */
 int lmgpu_selftest_chain_schedule(int n, int nf, int i0, int nsteps, int far_pct);
-int lmgpu_comm_init_local(lmgpu_handle* h, lmgpu_local_group* g);
 
 /* ---- ISAM2 (gtsam/nonlinear/ISAM2.h): incremental smoothing on a device-resident Bayes tree (BASELINE config 5) ----
  * ISAM2::update(newFactors, newTheta) (gtsam/nonlinear/ISAM2.cpp:419-480) = lmgpu_isam2_add_variables + lmgpu_isam2_add_factors
@@ -304,6 +296,17 @@ int lmgpu_isam2_get_delta(lmgpu_isam2* s, double* packed); /* getDelta (:776-779
 int lmgpu_isam2_num_cliques(lmgpu_isam2* s);
 int lmgpu_isam2_clique_info(const lmgpu_isam2* s, int32_t i, int32_t* info5);
 int lmgpu_isam2_get_clique(lmgpu_isam2* s, int32_t i, uint64_t* keys, double* RSd_colmajor);
+
+#ifdef LMGPU_TEST_HOOKS
+/* TEST HOOKS -- exported by liblmgpu_test.so only (csrc/Makefile builds it with -DLMGPU_TEST_HOOKS); the product library has none of them.
+ * In-process stand-in for the RCCL communicator: W handles created by W threads of ONE process on one
+ * device sum their buffers through a host rendezvous, at exactly the call sites where the RCCL path all-reduces.
+ * Lets the sharded LM loop run end to end on a single GPU.  Every rank must drive its handle from its own thread. */
+typedef struct lmgpu_local_group lmgpu_local_group;
+int lmgpu_local_group_create(int32_t world_size, lmgpu_local_group** out);
+int lmgpu_local_group_destroy(lmgpu_local_group* g);
+int lmgpu_comm_init_local(lmgpu_handle* h, lmgpu_local_group* g);
+#endif
 
 /* ---- micro-benchmarks used by bench.py for roofline peaks (device-only, no graph needed) ---- */
 int lmgpu_peak_mfma_f64(int32_t device, int32_t iters, double* tflops);

@@ -20,12 +20,20 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "lmgpu.h")).read()
+    hooks = re.search(r"#ifdef LMGPU_TEST_HOOKS(.*?)#endif", header, re.S)
+    test_declared = set(re.findall(r"\b(lmgpu_[a-z0-9_]+)\s*\(", hooks.group(1)))
+    header = header.replace(hooks.group(0), "")
     declared = set(re.findall(r"\b(lmgpu_[a-z0-9_]+)\s*\(", header))
     declared -= {"lmgpu_handle"}
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    # the test hooks: declared under LMGPU_TEST_HOOKS, exported by liblmgpu_test.so, absent from the product library
+    assert test_declared == set(_lib.TEST_SYMBOLS)
+    for name in test_declared:
+        assert not hasattr(lib, name), name
+        assert hasattr(_lib.load(test_hooks=True), name), name
 
 
 def test_compute_without_device_fails_loudly():
