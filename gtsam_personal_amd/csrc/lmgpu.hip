@@ -300,7 +300,9 @@ struct lmgpu_handle {
   hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   KTimer kt;
 
-  ncclComm_t comm = nullptr;
+  ncclComm_t comm = nullptr;       // scalars / status / Hessian diagonal: issued on the compute stream only
+  ncclComm_t comm_data = nullptr;  // the chunked all-reduce of a replicated front's partial assembly: issued on the communication stream only
+                                   // (a communicator of its own, so that no communicator is ever driven from two streams at once)
   lmgpu_local_group* lgroup = nullptr;  // test-only in-process communicator (lmgpu_comm_init_local)
 };
 
@@ -702,7 +704,7 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
         for (int c = 0; c < nchunks; c++) {
           size_t cb, cn;
           chunk_range(c, cb, cn);
-          NCCLCHECK(ncclAllReduce(Asm + cb, Asm + cb, cn, ncclDouble, ncclSum, h->comm, h->comm_stream));
+          NCCLCHECK(ncclAllReduce(Asm + cb, Asm + cb, cn, ncclDouble, ncclSum, h->comm_data ? h->comm_data : h->comm, h->comm_stream));
           HIPCHECK(hipEventRecord(h->chunk_ev[c], h->comm_stream));
         }
       }
@@ -1482,6 +1484,7 @@ int lmgpu_destroy(lmgpu_handle* h) {
   if (h->device >= 0) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->comm_data) ncclCommDestroy(h->comm_data);
     if (h->comm) ncclCommDestroy(h->comm);
     auto fr = [](void* p) {
       if (p) (void)hipFree(p);
@@ -2580,6 +2583,7 @@ int lmgpu_comm_init(lmgpu_handle* h, const char id128[128]) {
   std::memcpy(&id, id128, 128);
   HIPCHECK(hipSetDevice(h->device));
   NCCLCHECK(ncclCommInitRank(&h->comm, h->cfg.world_size, id, h->cfg.rank));
+  NCCLCHECK(ncclCommSplit(h->comm, 0, h->cfg.rank, &h->comm_data, nullptr));  // collective: every rank calls it right after the init
   return LMGPU_OK;
 }
 
