@@ -287,95 +287,153 @@ __global__ __launch_bounds__(64) void hbm_rhs_init_kernel(FrontDesc F, int64_t f
   if (lane == 0) y[i] = row[n - 1] - s;
 }
 
-// ---------------------------------------------------------------- back-substitution of the smaller HBM fronts
-// One workgroup per front (nf <= BSS_MAX_NF), all such fronts of a tree level in ONE launch:  y = d - S x_S, then 64-row
-// blocks from the last to the first: the diagonal block is solved by one wave (lane i carries y_i; per step one v_readlane
-// and one fma), the rows above fold x_b in with one thread per row.  General sparse graphs (SLAM) have dozens of fronts of a
-// few hundred columns; the per-front launches of the dataflow path (pre-inverted diagonal blocks, 141 hops for a 9000-row
-// root) only pay for large fronts.
-#define BSS_MAX_NF 1024
-__global__ __launch_bounds__(256) void hbm_backsolve_small_kernel(const int32_t* __restrict__ list, const FrontDesc* __restrict__ fronts,
-                                                                   const int64_t* __restrict__ f_off, const int32_t* __restrict__ f_ld,
-                                                                   const int32_t* __restrict__ fxoff, const int32_t* __restrict__ sxoff,
-                                                                   const double* __restrict__ pool, double* __restrict__ delta,
-                                                                   int* __restrict__ status) {
-  __shared__ double y[BSS_MAX_NF];
-  __shared__ double Db[64][65];
-  __shared__ double xs[64];
-  const int fi = list[blockIdx.x];
-  const FrontDesc F = fronts[fi];
-  const double* A = pool + f_off[fi];
-  const int ld = f_ld[fi], n = F.n, nf = F.nf, ns = n - nf - 1;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  if (ns <= BSS_MAX_NF) {
-    // the separator part of delta once into LDS (it was gathered again for every row), four rows per wave in flight
-    // (one row at a time made this loop nf / 4 dependent memory round trips: 170 us for a 546-column front)
-    __shared__ double xS[BSS_MAX_NF];
-    for (int j = tid; j < ns; j += 256) xS[j] = delta[sxoff[F.sx_begin + j]];
-    __syncthreads();
-    for (int i0 = 4 * wave; i0 < nf; i0 += 16) {
-      double acc[4] = {0.0, 0.0, 0.0, 0.0}, dv[4] = {0.0, 0.0, 0.0, 0.0};
+#define BSS_MAX_NF 1024  // fronts up to this many frontal rows take the block kernel below; larger ones the per-front dataflow path
+
+// Sums over the 64 lanes of a wave of R per-lane values at once: each halving step trades half of the values with the lane `o` away,
+// so R values cost R - 1 + log2(64 / R) shuffles instead of 6 R dependent ones (a chain of 96 ds_bpermute pairs for 16 rows was
+// 8 us of every 64-row block).  Returns, in EVERY lane, the total of value number `slot`.
+template <int R>
+__device__ __forceinline__ double wave_reduce_slots(double (&s)[R], int lane, int& slot) {
+  int o = 32;
+  slot = 0;
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int i = i0 + u;
-        if (i < nf) {
-          const double* row = A + (size_t)i * ld;
-          for (int j = lane; j < ns; j += 64) acc[u] += row[nf + j] * xS[j];
-          dv[u] = row[n - 1];
-        }
-      }
+  for (int half = R / 2; half >= 1; half >>= 1, o >>= 1) {
+    const bool hi = (lane & o) != 0;
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc[u] += __shfl_xor(acc[u], o);
-        if (lane == 0 && i0 + u < nf) y[i0 + u] = dv[u] - acc[u];
-      }
+    for (int k = 0; k < half; k++) {
+      const double keep = hi ? s[k + half] : s[k], send = hi ? s[k] : s[k + half];
+      s[k] = keep + __shfl_xor(send, o);
     }
-  } else {
-    for (int i = wave; i < nf; i += 4) {
-      const double* row = A + (size_t)i * ld;
-      double s = 0;
-      for (int j = lane; j < ns; j += 64) s += row[nf + j] * delta[sxoff[F.sx_begin + j]];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-      if (lane == 0) y[i] = row[n - 1] - s;
-    }
+    slot += hi ? half : 0;
   }
+#pragma unroll
+  for (; o >= 1; o >>= 1) s[0] += __shfl_xor(s[0], o);
+  return s[0];
+}
+
+// ---------------------------------------------------------------- back-substitution of the smaller HBM fronts, one workgroup per 64-row block
+// General sparse graphs (SLAM) have a handful of fronts of a few hundred columns on each of their upper levels.  A single workgroup
+// reads such a front at 13-20 GB/s (one CU's worth of requests in flight against a ~3 us round trip on an otherwise idle device),
+// which is what round 1's one-workgroup-per-front kernel was bound by even after its reductions and its solve chain were cleaned up:
+// 131 -> 80 us for a 330-column root, 0.92 of the 3.1 ms of an LM iteration on sphere2500 (profiles/r02/backsolve_bench.txt).
+// Here every 64-row block of every such front of a tree level is a workgroup of its own, all in ONE
+// launch: block b folds the separator part into its right-hand side, then the blocks x_j (j > b) of its own front as their owners
+// publish them, solves its diagonal block and publishes x_b.  Wave w owns rows 16 w .. 16 w + 15 of the block, a lane one column:
+// row reads are whole 512-byte segments, the per-lane partial sums of a row stay in registers over all hops and are reduced ONCE
+// (wave_reduce_slots), and every wave polls x_j itself -- no barrier and no shuffle on a hop.  The data is the flag: xbuf is preset
+// to all ones (a NaN pattern no computation produces; producers canonicalise their NaNs).  Order: a ticket indexes a table in which
+// the blocks of a front appear from the last to the first, so a workgroup only waits for workgroups that started before it.
+struct BsdBlock {
+  int32_t front, b, xoff, pad;  // xoff: where the front's x starts in xbuf (64 entries per block, the last block zero-padded)
+};
+#define BSD_SPIN_LIMIT 4000000L
+__global__ __launch_bounds__(256) void hbm_backsolve_blocks_kernel(const BsdBlock* __restrict__ table, unsigned int* __restrict__ ticket,
+                                                                    const FrontDesc* __restrict__ fronts, const int64_t* __restrict__ f_off,
+                                                                    const int32_t* __restrict__ f_ld, const int32_t* __restrict__ fxoff,
+                                                                    const int32_t* __restrict__ sxoff, const double* __restrict__ pool,
+                                                                    double* __restrict__ delta, double* __restrict__ xbuf, int* __restrict__ status) {
+  __shared__ double Db[64][65];
+  __shared__ double yb[64];
+  __shared__ int s_t;
+  if (threadIdx.x == 0) s_t = (int)atomicAdd(ticket, 1u);
   __syncthreads();
-  const int nblk = (nf + 63) >> 6;
-  for (int b = nblk - 1; b >= 0; b--) {
-    const int r0 = 64 * b, nb = min(64, nf - r0);
-    for (int idx = tid; idx < 64 * 64; idx += 256) {
-      const int p = idx >> 6, q = idx & 63;
-      Db[p][q] = (p < nb && q < nb && q >= p) ? A[(size_t)(r0 + p) * ld + r0 + q] : ((p == q) ? 1.0 : 0.0);
-    }
-    __syncthreads();
-    if (wave == 0) {
-      double yi = (lane < nb) ? y[r0 + lane] : 0.0;
-      const double rd = 1.0 / Db[lane][lane];
-      for (int k = nb - 1; k >= 0; k--) {
-        const double xk = readlane_dyn(yi * rd, k);
-        if (lane == k) yi = xk;
-        if (lane < k) yi -= Db[lane][k] * xk;
+  const BsdBlock B = table[s_t];
+  const FrontDesc F = fronts[B.front];
+  const double* A = pool + f_off[B.front];
+  const int ld = f_ld[B.front], n = F.n, nf = F.nf, ns = n - nf - 1;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int nblk = (nf + 63) >> 6, b = B.b, r0 = 64 * b, nb = min(64, nf - r0);
+  double* xb = xbuf + B.xoff;
+  // (every load is unconditional on a clamped address: the compiler waits for a load issued under a branch at the end of that branch)
+  const double* Arow[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) Arow[k] = A + (size_t)min(r0 + 16 * wave + k, nf - 1) * ld;
+  // the slot (row 16 wave + slot) whose total wave_reduce_slots leaves in this lane, its right-hand side and its delta offset
+  const int myslot = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+  const int myrow = 16 * wave + myslot;
+  const double dv = A[(size_t)min(r0 + myrow, nf - 1) * ld + n - 1];
+  const int fo = fxoff[F.fx_begin + r0 + min(lane, nb - 1)];
+  double dbr[16], tl[16];
+  {
+    const int c = r0 + min(lane, nb - 1);
+#pragma unroll
+    for (int k = 0; k < 16; k++) dbr[k] = Arow[k][c];
+  }
+  auto load_tile = [&](int j, double(&t)[16]) {  // R[rows of this block, columns of block j]; columns past nf are clamped (they meet x = 0)
+    const int c = min(64 * j + lane, nf - 1);
+#pragma unroll
+    for (int k = 0; k < 16; k++) t[k] = Arow[k][c];
+  };
+  load_tile(nblk - 1, tl);  // (b == nblk - 1: loaded and not used)
+  double acc[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) acc[k] = 0.0;
+  // separator part: acc[row] += S[row][j] x_S[j], two chunks of 64 columns in flight
+  for (int c0 = 0; c0 < ns; c0 += 128) {
+    const int j0 = c0 + lane, j1 = c0 + 64 + lane;
+    const int o0 = sxoff[F.sx_begin + min(j0, ns - 1)], o1 = sxoff[F.sx_begin + min(j1, ns - 1)];
+    double v0[16], v1[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) v0[k] = Arow[k][nf + min(j0, ns - 1)];
+#pragma unroll
+    for (int k = 0; k < 16; k++) v1[k] = Arow[k][nf + min(j1, ns - 1)];
+    const double d0 = delta[o0], d1 = delta[o1];
+    const double x0 = (j0 < ns) ? d0 : 0.0, x1 = (j1 < ns) ? d1 : 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) acc[k] += v0[k] * x0 + v1[k] * x1;
+  }
+  // the diagonal block into LDS (identity-padded), long since arrived
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int p = 16 * wave + k;
+    Db[p][lane] = (p < nb && lane < nb && lane >= p) ? dbr[k] : ((p == lane) ? 1.0 : 0.0);
+  }
+  bool dead = false;
+  for (int j = nblk - 1; j > b; j--) {
+    double xj;
+    long spins = 0;
+    for (;;) {
+      xj = __hip_atomic_load(&xb[64 * j + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__double_as_longlong(xj) != -1LL) break;
+      if (dead || ++spins > BSD_SPIN_LIMIT) {
+        dead = true;
+        xj = 0.0;
+        break;
       }
-      xs[lane] = (lane < nb) ? yi : 0.0;
-      if (lane < nb) {
-        delta[fxoff[F.fx_begin + r0 + lane]] = yi;
-        if (yi != yi) atomicMin(status, F.id);  // NaN -> IndeterminantLinearSystemException (linearAlgorithms-inst.h:99)
-      }
+      __builtin_amdgcn_s_sleep(1);
     }
-    __syncthreads();
-    for (int i = tid; i < r0; i += 256) {
-      const double2* row = (const double2*)(A + (size_t)i * ld + r0);  // r0 and ld are multiples of 16 doubles
-      double s = 0;
-#pragma unroll 8
-      for (int c = 0; c < 32; c++) {
-        const double2 v = row[c];
-        s += v.x * xs[2 * c] + v.y * xs[2 * c + 1];
+    double tn[16];
+    load_tile(j - 1, tn);  // behind the poll in program order: in flight while x_j is folded in and x_{j-1} is awaited
+#pragma unroll
+    for (int k = 0; k < 16; k++) acc[k] += tl[k] * xj;
+#pragma unroll
+    for (int k = 0; k < 16; k++) tl[k] = tn[k];
+  }
+  if (__any(dead) && lane == 0) atomicExch(status + 1, 1 + F.id);  // never expected: spin bound hit (a fault, reported apart from pivot failures)
+  int slot;
+  const double tot = wave_reduce_slots<16>(acc, lane, slot);
+  if ((lane & 3) == 0) yb[myrow] = (myrow < nb) ? dv - tot : 0.0;
+  __syncthreads();
+  if (wave == 0) {
+    // lane i carries y_i / R_ii and row i of the block scaled to a unit diagonal: a step is one v_readlane pair and one fma
+    const double rd = 1.0 / Db[lane][lane];
+    double yi = yb[lane] * rd;
+    for (int k0 = 63; k0 >= 0; k0 -= 8) {
+      double cf[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const double c = Db[lane][k0 - u];
+        cf[u] = (lane < k0 - u) ? c * rd : 0.0;
       }
-      y[i] -= s;
+#pragma unroll
+      for (int u = 0; u < 8; u++) yi = fma(-cf[u], readlane_dyn(yi, k0 - u), yi);
     }
-    __syncthreads();
+    const double pub = (lane < nb) ? ((yi != yi) ? __longlong_as_double(0x7ff8000000000000LL) : yi) : 0.0;  // never the sentinel
+    __hip_atomic_store(&xb[r0 + lane], pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane < nb) {
+      delta[fo] = yi;
+      if (yi != yi) atomicMin(status, F.id);  // NaN -> IndeterminantLinearSystemException (linearAlgorithms-inst.h:99)
+    }
   }
 }
 

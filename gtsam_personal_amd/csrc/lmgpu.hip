@@ -85,6 +85,7 @@ struct LevelWork {
   int pack_stride[16] = {0};
   std::vector<int> hbm;  // HBM fronts of this level
   int small_begin = 0, small_count = 0;  // those with nf <= BSS_MAX_NF, in d_hbm_small: back-substituted in one launch per level
+  int bsd_begin = 0, bsd_count = 0;      // their 64-row blocks in d_bsd_table (hbm_backsolve_blocks_kernel: one workgroup per block)
   // "medium" HBM fronts (one outer panel, no gather leaves, not replicated): eliminated with batched launches (kernels_batched.hpp)
   int med_begin = 0, med_count = 0, med_max_fac = 0, med_max_child = 0, med_max_nf = 0, med_max_cols = 0, med_max_n = 0;
 };
@@ -246,6 +247,10 @@ struct lmgpu_handle {
   ChildRef* d_childs = nullptr;
   int32_t *d_cmap = nullptr, *d_fxoff = nullptr, *d_sxoff = nullptr, *d_lists = nullptr;
   int32_t *d_hbm_small = nullptr, *d_f_ld = nullptr, *d_med_list = nullptr;
+  BsdBlock* d_bsd_table = nullptr;      // 64-row blocks of the smaller HBM fronts, per level, each front from its last block to its first
+  double* d_bsd_x = nullptr;            // their published x (64 per block), preset to the all-ones sentinel at the start of a back-substitution
+  unsigned int* d_bsd_ticket = nullptr; // one ticket counter per level
+  size_t bsd_x_count = 0;
   // deterministic assembly of HBM fronts (kernels_dense.hpp: hbm_assemble_rows_kernel): per front the start of its n + 1 row
   // pointers in d_rowptr (-1: none), the pointers (offsets into d_rowsrc) and the sources
   std::vector<int32_t> row_begin;
@@ -892,6 +897,10 @@ int do_backsub(lmgpu_handle* h) {
   const bool merge = h->merge_backsub && h->cfg.world_size == 1 && !(h->cfg.flags & LMGPU_FLAG_SPLIT_ROOT);
   const int NFR = (int)h->h_fronts.size();
   if (merge) HIPCHECK(hipMemsetAsync(h->d_bs_done, 0, (size_t)(NFR + h->levels.size() + 1) * sizeof(unsigned int), s));
+  if (h->bsd_x_count > 0) {
+    HIPCHECK(hipMemsetAsync(h->d_bsd_x, 0xff, h->bsd_x_count * sizeof(double), s));  // "not published yet"
+    HIPCHECK(hipMemsetAsync(h->d_bsd_ticket, 0, h->levels.size() * sizeof(unsigned int), s));
+  }
   int seg_hi = -1, seg_lo = -1;  // levels of the pending segment (top, bottom)
   auto run_level = [&](const LevelWork& L) {  // one level as a launch of its own
     if (L.lds_nf_max > 12) {
@@ -929,11 +938,11 @@ int do_backsub(lmgpu_handle* h) {
       const int rcf = flush_segment();
       if (rcf) return rcf;
     }
-    if (L.small_count > 0) {  // the smaller HBM fronts of the level: one workgroup each, one launch
+    if (L.bsd_count > 0) {  // the smaller HBM fronts of the level: one workgroup per 64-row block, one launch
       const int kt = h->kt.begin(LMGPU_KT_BACKSUB_HBM, s);
-      hipLaunchKernelGGL(hbm_backsolve_small_kernel, dim3(L.small_count), dim3(256), 0, s, (const int32_t*)(h->d_hbm_small + L.small_begin),
-                         (const FrontDesc*)h->d_fronts, (const int64_t*)h->d_f_off, (const int32_t*)h->d_f_ld, (const int32_t*)h->d_fxoff,
-                         (const int32_t*)h->d_sxoff, (const double*)h->pool, h->delta, h->d_status);
+      hipLaunchKernelGGL(hbm_backsolve_blocks_kernel, dim3(L.bsd_count), dim3(256), 0, s, (const BsdBlock*)(h->d_bsd_table + L.bsd_begin),
+                         h->d_bsd_ticket + li, (const FrontDesc*)h->d_fronts, (const int64_t*)h->d_f_off, (const int32_t*)h->d_f_ld,
+                         (const int32_t*)h->d_fxoff, (const int32_t*)h->d_sxoff, (const double*)h->pool, h->delta, h->d_bsd_x, h->d_status);
       h->kt.end(kt, s);
     }
     for (int fi : L.hbm) {
@@ -1505,7 +1514,7 @@ int lmgpu_destroy(lmgpu_handle* h) {
     for (int i = 0; i < 8; i++)
       if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     for (hipEvent_t e : h->kt.pool) (void)hipEventDestroy(e);
-    fr(h->bs_inv); fr(h->bs_x); fr(h->bs_flags); fr(h->inv16); fr(h->d_pflags); fr(h->d_bs_parent); fr(h->d_bs_pos); fr(h->d_bs_done); fr(h->d_leafpack); fr(h->d_gzero);
+    fr(h->bs_inv); fr(h->bs_x); fr(h->bs_flags); fr(h->inv16); fr(h->d_pflags); fr(h->d_bs_parent); fr(h->d_bs_pos); fr(h->d_bs_done); fr(h->d_bsd_table); fr(h->d_bsd_x); fr(h->d_bsd_ticket); fr(h->d_leafpack); fr(h->d_gzero);
     for (auto& kv : h->chain_plans)
       for (auto& cp : kv.second) fr(cp.d_tasks);
     fr(h->d_gpblk); fr(h->d_gpent); fr(h->d_gvblk); fr(h->d_gvent); fr(h->d_gcorner); fr(h->d_row_begin); fr(h->d_rowptr); fr(h->d_rowsrc);
@@ -2069,6 +2078,23 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
       L.small_count = (int)small.size() - L.small_begin;
     }
     if ((rc = upload(h, &h->d_hbm_small, small))) return rc;
+    std::vector<BsdBlock> bsd;
+    int32_t xoff = 0;
+    for (LevelWork& L : h->levels) {
+      L.bsd_begin = (int)bsd.size();
+      for (int q = 0; q < L.small_count; q++) {
+        const int fi = small[L.small_begin + q], nblk = (P.fronts[fi].nf + 63) / 64;
+        for (int b = nblk - 1; b >= 0; b--) bsd.push_back(BsdBlock{fi, b, xoff, 0});
+        xoff += 64 * nblk;
+      }
+      L.bsd_count = (int)bsd.size() - L.bsd_begin;
+    }
+    h->bsd_x_count = (size_t)xoff;
+    if ((rc = upload(h, &h->d_bsd_table, bsd))) return rc;
+    if (xoff > 0) {
+      HIPCHECK(hipMalloc((void**)&h->d_bsd_x, (size_t)xoff * sizeof(double)));
+      HIPCHECK(hipMalloc((void**)&h->d_bsd_ticket, h->levels.size() * sizeof(unsigned int)));
+    }
     std::vector<int32_t> med;
     h->is_med.assign(NF, 0);
     int max_med = 0;
