@@ -5,76 +5,92 @@
 #pragma once
 #include "kernels_dense.hpp"
 #include "kernels_potrf.hpp"
+#include "kernels_step.hpp"
 
 namespace lmgpu {
 
+// One record per medium front, level by level: everything the kernels below need to find their data, so that a workgroup is ONE
+// dependent load away from it (list -> front descriptor -> offsets was three, at ~3 us each on an otherwise idle device).
+struct MedFront {
+  FrontDesc F;
+  int64_t f_off;
+  int32_t ld, row_begin;
+};
 struct MedLevel {
-  const int32_t* list;       // front ids of this level's medium fronts
-  const FrontDesc* fronts;
-  const int64_t* f_off;
-  const int32_t* f_ld;
+  const MedFront* mf;  // this level's records
 };
 
 __global__ __launch_bounds__(64) void med_assemble_factors_kernel(MedLevel L, const FrontFac* __restrict__ ffac, const FacDesc* __restrict__ fd,
                                                                    double* __restrict__ pool) {
-  const int fi = L.list[blockIdx.y];
-  const FrontDesc F = L.fronts[fi];
+  const MedFront M = L.mf[blockIdx.y];
+  const FrontDesc& F = M.F;
   if ((int)blockIdx.x >= F.fac_count) return;
-  assemble_factor_body(F, L.f_off[fi], L.f_ld[fi], ffac, fd, pool, blockIdx.x);
+  assemble_factor_body(F, M.f_off, M.ld, ffac, fd, pool, blockIdx.x);
 }
 
 __global__ __launch_bounds__(256) void med_assemble_children_kernel(MedLevel L, const ChildRef* __restrict__ childs, const int32_t* __restrict__ cmap,
                                                                     double* __restrict__ pool) {
   __shared__ int32_t smap[160];
-  const int fi = L.list[blockIdx.y];
-  const FrontDesc F = L.fronts[fi];
+  const MedFront M = L.mf[blockIdx.y];
+  const FrontDesc& F = M.F;
   if ((int)blockIdx.x >= F.child_count) return;
-  assemble_child_body(F, L.f_off[fi], L.f_ld[fi], childs, cmap, pool, blockIdx.x, smap, blockIdx.z, gridDim.z);
+  assemble_child_body(F, M.f_off, M.ld, childs, cmap, pool, blockIdx.x, smap, blockIdx.z, gridDim.z);
 }
 
 // deterministic row-owner assembly (kernels_dense.hpp: assemble_row_body) for all medium fronts of a level: grid (max rows / 4, fronts)
-__global__ __launch_bounds__(256) void med_assemble_rows_kernel(MedLevel L, const int32_t* __restrict__ row_begin, const int32_t* __restrict__ rowptr,
+__global__ __launch_bounds__(256) void med_assemble_rows_kernel(MedLevel L, const int32_t* __restrict__ rowptr,
                                                                 const RowSrc* __restrict__ src, const ChildRef* __restrict__ childs,
                                                                 const int32_t* __restrict__ cmap, const FrontFac* __restrict__ ffac,
-                                                                const FacDesc* __restrict__ fd, double* __restrict__ pool) {
-  const int fi = L.list[blockIdx.y];
-  const FrontDesc F = L.fronts[fi];
+                                                                const FacDesc* __restrict__ fd, double* __restrict__ pool,
+                                                                const int32_t* __restrict__ fxoff, double lambda_v, const double* __restrict__ lambda_p,
+                                                                const double* __restrict__ dampw, const double* __restrict__ gex) {
+  const MedFront M = L.mf[blockIdx.y];
+  const FrontDesc& F = M.F;
   const int R = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (R >= F.n) return;
-  assemble_row_body(F, L.f_off[fi], L.f_ld[fi], rowptr + row_begin[fi], src, childs, cmap, ffac, fd, pool, R, true);
+  assemble_row_body(F, M.f_off, M.ld, rowptr + M.row_begin, src, childs, cmap, ffac, fd, pool, R, true);
+  // the damping of a frontal row by the wave that owns it (med_damp_kernel was a launch of its own: ~4.5 us per tree level)
+  if (R < F.nf && (threadIdx.x & 63) == 0) {
+    double* Arow = pool + M.f_off + (size_t)R * M.ld;
+    const int xo = fxoff[F.fx_begin + R];
+    Arow[R] += (lambda_p ? *lambda_p : lambda_v) * dampw[xo];
+    if (gex) Arow[F.n - 1] += gex[xo];
+  }
 }
 
 __global__ __launch_bounds__(256) void med_damp_kernel(MedLevel L, const int32_t* __restrict__ fxoff, double* __restrict__ pool, double lambda_v, const double* __restrict__ lambda_p,
                                                         const double* __restrict__ dampw, const double* __restrict__ gex) {
-  const int fi = L.list[blockIdx.y];
-  const FrontDesc F = L.fronts[fi];
+  const MedFront M = L.mf[blockIdx.y];
+  const FrontDesc& F = M.F;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= F.nf) return;
-  pool[L.f_off[fi] + (size_t)i * L.f_ld[fi] + i] += (lambda_p ? *lambda_p : lambda_v) * dampw[fxoff[F.fx_begin + i]];
-  if (gex) pool[L.f_off[fi] + (size_t)i * L.f_ld[fi] + F.n - 1] += gex[fxoff[F.fx_begin + i]];
+  pool[M.f_off + (size_t)i * M.ld + i] += (lambda_p ? *lambda_p : lambda_v) * dampw[fxoff[F.fx_begin + i]];
+  if (gex) pool[M.f_off + (size_t)i * M.ld + F.n - 1] += gex[fxoff[F.fx_begin + i]];
 }
 
 // the whole frontal block [0, nf) x [0, nf) of each front: one workgroup per front
 __global__ __launch_bounds__(256) void med_diag_potrf_kernel(MedLevel L, double* __restrict__ pool, int* __restrict__ status, double* __restrict__ inv16) {
   extern __shared__ __attribute__((aligned(16))) double dsm[];
-  const int fi = L.list[blockIdx.x];
-  const FrontDesc F = L.fronts[fi];
-  diag_potrf_body(pool + L.f_off[fi], L.f_ld[fi], F.nf, 0, F.nf, F.id, status, inv16 + (size_t)blockIdx.x * 16 * 256, dsm);
+  const MedFront M = L.mf[blockIdx.x];
+  diag_potrf_body(pool + M.f_off, M.ld, M.F.nf, 0, M.F.nf, M.F.id, status, inv16 + (size_t)blockIdx.x * 16 * 256, dsm);
 }
 
 __global__ __launch_bounds__(256) void med_panel_trsm_kernel(MedLevel L, double* __restrict__ pool, const double* __restrict__ inv16) {
   __shared__ double I16[16][16][17];
-  const int fi = L.list[blockIdx.y];
-  const FrontDesc F = L.fronts[fi];
-  if ((int)blockIdx.x * 64 >= F.n - F.nf) return;
-  panel_trsm_body(pool + L.f_off[fi], L.f_ld[fi], F.n, 0, F.nf, inv16 + (size_t)blockIdx.y * 16 * 256, I16, blockIdx.x);
+  const MedFront M = L.mf[blockIdx.y];
+  if ((int)blockIdx.x * 64 >= M.F.n - M.F.nf) return;
+  panel_trsm_body(pool + M.f_off, M.ld, M.F.n, 0, M.F.nf, inv16 + (size_t)blockIdx.y * 16 * 256, I16, blockIdx.x);
 }
 
-__global__ __launch_bounds__(256, 2) void med_syrk_kernel(MedLevel L, double* __restrict__ pool) {
-  extern __shared__ double sm[];
-  const int fi = L.list[blockIdx.z];
-  const FrontDesc F = L.fronts[fi];
-  syrk_tile(pool + L.f_off[fi], L.f_ld[fi], F.n, 0, F.nf, F.nf, F.n, blockIdx.y, blockIdx.x, sm);
+// Trailing update of every medium front of a level, one workgroup per 32 x 32 quadrant (kernels_step.hpp: syrk_quadrant32, one
+// 16 x 16 MFMA tile per wave, operands straight from L2).  A 128 x 128 tile per workgroup (syrk_tile) is the right shape for the dense
+// root, where thousands of tiles share 256 CUs; here a front has one to ten of them and each is K / 4 x 16 dependent MFMAs per wave
+// on a single CU (~2.7 us per 16 rows of K: 17-52 us per level of sphere2500) while 250 CUs idle.  grid: (4 x strips, strips, fronts).
+__global__ __launch_bounds__(256) void med_syrk_kernel(MedLevel L, double* __restrict__ pool) {
+  const MedFront M = L.mf[blockIdx.z];
+  const int sj = blockIdx.x >> 2, si = blockIdx.y, S = (M.F.n - M.F.nf + 63) >> 6;
+  if (si > sj || sj >= S) return;
+  syrk_quadrant32(pool + M.f_off, M.ld, M.F.n, 0, M.F.nf, M.F.nf, si, sj, blockIdx.x & 3, nullptr);
 }
 
 }  // namespace lmgpu

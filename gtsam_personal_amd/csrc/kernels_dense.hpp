@@ -323,24 +323,31 @@ __device__ __forceinline__ double wave_reduce_slots(double (&s)[R], int lane, in
 // (wave_reduce_slots), and every wave polls x_j itself -- no barrier and no shuffle on a hop.  The data is the flag: xbuf is preset
 // to all ones (a NaN pattern no computation produces; producers canonicalise their NaNs).  Order: a ticket indexes a table in which
 // the blocks of a front appear from the last to the first, so a workgroup only waits for workgroups that started before it.
-struct BsdBlock {
-  int32_t front, b, xoff, pad;  // xoff: where the front's x starts in xbuf (64 entries per block, the last block zero-padded)
+struct BsdBlock {  // everything a workgroup needs, in one record: it is ONE dependent load away from its data
+  int64_t f_off;
+  int32_t ld, n, nf, fx_begin, sx_begin, id;
+  int32_t b, xoff;  // xoff: where the front's x starts in xbuf (64 entries per block, the last block zero-padded)
 };
 #define BSD_SPIN_LIMIT 4000000L
 __global__ __launch_bounds__(256) void hbm_backsolve_blocks_kernel(const BsdBlock* __restrict__ table, unsigned int* __restrict__ ticket,
-                                                                    const FrontDesc* __restrict__ fronts, const int64_t* __restrict__ f_off,
-                                                                    const int32_t* __restrict__ f_ld, const int32_t* __restrict__ fxoff,
-                                                                    const int32_t* __restrict__ sxoff, const double* __restrict__ pool,
-                                                                    double* __restrict__ delta, double* __restrict__ xbuf, int* __restrict__ status) {
+                                                                    const int32_t* __restrict__ fxoff, const int32_t* __restrict__ sxoff,
+                                                                    const double* __restrict__ pool, double* __restrict__ delta,
+                                                                    double* __restrict__ xbuf, int* __restrict__ status) {
   __shared__ double Db[64][65];
   __shared__ double yb[64];
   __shared__ int s_t;
-  if (threadIdx.x == 0) s_t = (int)atomicAdd(ticket, 1u);
-  __syncthreads();
-  const BsdBlock B = table[s_t];
-  const FrontDesc F = fronts[B.front];
-  const double* A = pool + f_off[B.front];
-  const int ld = f_ld[B.front], n = F.n, nf = F.nf, ns = n - nf - 1;
+  // ticket == nullptr: the whole grid is resident at once (the host checks: at most one workgroup per CU), so no order of dispatch
+  // can leave a waiting workgroup without its producer, and the atomic's round trip is saved
+  int t = blockIdx.x;
+  if (ticket) {
+    if (threadIdx.x == 0) s_t = (int)atomicAdd(ticket, 1u);
+    __syncthreads();
+    t = s_t;
+  }
+  const BsdBlock B = table[t];
+  struct { int32_t fx_begin, sx_begin, id; } F{B.fx_begin, B.sx_begin, B.id};
+  const double* A = pool + B.f_off;
+  const int ld = B.ld, n = B.n, nf = B.nf, ns = n - nf - 1;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int nblk = (nf + 63) >> 6, b = B.b, r0 = 64 * b, nb = min(64, nf - r0);
   double* xb = xbuf + B.xoff;

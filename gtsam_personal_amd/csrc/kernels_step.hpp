@@ -234,6 +234,13 @@ __device__ __forceinline__ void step_body(const StepArgs& a, int t, const ChainL
   panel_role(a.A, a.ld, a.n, a.nf, r0, a.kb_next, nd + t, a.front_id, a.status, a.inv16, a.flags, sm, s_ok, true, c.publish);
 }
 
+// a trailing update of a few tiles (the tail of a front) as 32 x 32 quadrants: grid (4 x strips, strips)
+__global__ __launch_bounds__(256) void syrk_quadrants_kernel(double* __restrict__ A, int ld, int n, int p0, int kp, int r0) {
+  const int sj = blockIdx.x >> 2, si = blockIdx.y;
+  if (si > sj) return;
+  syrk_quadrant32(A, ld, n, p0, kp, r0, si, sj, blockIdx.x & 3, nullptr);
+}
+
 __global__ __launch_bounds__(256, 2) void step_kernel(StepArgs a) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ int s_bid, s_ok;

@@ -247,10 +247,12 @@ struct lmgpu_handle {
   ChildRef* d_childs = nullptr;
   int32_t *d_cmap = nullptr, *d_fxoff = nullptr, *d_sxoff = nullptr, *d_lists = nullptr;
   int32_t *d_hbm_small = nullptr, *d_f_ld = nullptr, *d_med_list = nullptr;
+  MedFront* d_med_fronts = nullptr;     // packed records of the medium fronts, level by level (same order as d_med_list)
   BsdBlock* d_bsd_table = nullptr;      // 64-row blocks of the smaller HBM fronts, per level, each front from its last block to its first
   double* d_bsd_x = nullptr;            // their published x (64 per block), preset to the all-ones sentinel at the start of a back-substitution
   unsigned int* d_bsd_ticket = nullptr; // one ticket counter per level
   size_t bsd_x_count = 0;
+  int num_cus = 0;                      // compute units of the device (a grid of at most this many small workgroups is resident at once)
   // deterministic assembly of HBM fronts (kernels_dense.hpp: hbm_assemble_rows_kernel): per front the start of its n + 1 row
   // pointers in d_rowptr (-1: none), the pointers (offsets into d_rowsrc) and the sources
   std::vector<int32_t> row_begin;
@@ -553,6 +555,9 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
     }
     h->kt.end(kt0, s);
   }
+  // (Running a level's LDS fronts on a second stream beside its dense fronts -- they only depend on the levels below -- was measured
+  //  with the replayed graph: 4.9 vs 2.5 ms per LM iteration on sphere2500; every cross-stream edge of the graph costs more than the
+  //  45 us of LDS-front latency it hides.  Not kept.)
   for (const LevelWork& L : h->levels) {
     for (int b = 0; b < kNumBins; b++) {
       const int cnt = L.bin_begin[b + 1] - L.bin_begin[b];
@@ -580,15 +585,14 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
       h->kt.end(kt, s);
     }
     if (L.med_count > 0) {  // medium fronts of this level: six launches for all of them
-      const MedLevel ML{(const int32_t*)(h->d_med_list + L.med_begin), (const FrontDesc*)h->d_fronts, (const int64_t*)h->d_f_off,
-                        (const int32_t*)h->d_f_ld};
+      const MedLevel ML{(const MedFront*)(h->d_med_fronts + L.med_begin)};
       const unsigned cnt = (unsigned)L.med_count;
       int ktm = h->kt.begin(LMGPU_KT_HBM_ASSEMBLE, s);
       if (!h->scatter_atomics) {
         if (L.med_max_fac > 0 || L.med_max_child > 0)
-          hipLaunchKernelGGL(med_assemble_rows_kernel, dim3((L.med_max_n + 3) / 4, cnt), dim3(256), 0, s, ML, (const int32_t*)h->d_row_begin,
-                             (const int32_t*)h->d_rowptr, (const RowSrc*)h->d_rowsrc, (const ChildRef*)h->d_childs, (const int32_t*)h->d_cmap,
-                             (const FrontFac*)h->d_ffac, (const FacDesc*)h->d_fd, h->pool);
+          hipLaunchKernelGGL(med_assemble_rows_kernel, dim3((L.med_max_n + 3) / 4, cnt), dim3(256), 0, s, ML, (const int32_t*)h->d_rowptr, (const RowSrc*)h->d_rowsrc, (const ChildRef*)h->d_childs, (const int32_t*)h->d_cmap,
+                             (const FrontFac*)h->d_ffac, (const FacDesc*)h->d_fd, h->pool, (const int32_t*)h->d_fxoff, lambda_v, lambda_p,
+                             (const double*)h->dampw, (const double*)h->gex_active);
       } else {
         if (L.med_max_fac > 0)
           hipLaunchKernelGGL(med_assemble_factors_kernel, dim3(L.med_max_fac, cnt), dim3(64), 0, s, ML, (const FrontFac*)h->d_ffac,
@@ -597,8 +601,9 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
           hipLaunchKernelGGL(med_assemble_children_kernel, dim3(L.med_max_child, cnt, kChildSplit), dim3(256), 0, s, ML, (const ChildRef*)h->d_childs,
                              (const int32_t*)h->d_cmap, h->pool);
       }
-      hipLaunchKernelGGL(med_damp_kernel, dim3((L.med_max_nf + 255) / 256, cnt), dim3(256), 0, s, ML, (const int32_t*)h->d_fxoff, h->pool, lambda_v,
-                         lambda_p, (const double*)h->dampw, (const double*)h->gex_active);
+      if (h->scatter_atomics || !(L.med_max_fac > 0 || L.med_max_child > 0))  // (the row-owner assembly damps its own rows)
+        hipLaunchKernelGGL(med_damp_kernel, dim3((L.med_max_nf + 255) / 256, cnt), dim3(256), 0, s, ML, (const int32_t*)h->d_fxoff, h->pool, lambda_v,
+                           lambda_p, (const double*)h->dampw, (const double*)h->gex_active);
       h->kt.end(ktm, s);
       ktm = h->kt.begin(LMGPU_KT_PANEL, s);
       hipLaunchKernelGGL(med_diag_potrf_kernel, dim3(cnt), dim3(256), DIAG_LDS_BYTES, s, ML, h->pool, h->d_status, h->inv16_med);
@@ -606,9 +611,9 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
         hipLaunchKernelGGL(med_panel_trsm_kernel, dim3((L.med_max_cols + 63) / 64, cnt), dim3(256), 0, s, ML, h->pool, (const double*)h->inv16_med);
       h->kt.end(ktm, s);
       if (L.med_max_cols > 0) {
-        const int T = (L.med_max_cols + 127) / 128;
+        const int S = (L.med_max_cols + 63) / 64;
         ktm = h->kt.begin(LMGPU_KT_SYRK, s);
-        hipLaunchKernelGGL(med_syrk_kernel, dim3(T, T, cnt), dim3(256), kSyrkLds, s, ML, h->pool);
+        hipLaunchKernelGGL(med_syrk_kernel, dim3(4 * S, S, cnt), dim3(256), 0, s, ML, h->pool);
         h->kt.end(ktm, s);
       }
     }
@@ -873,7 +878,12 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
         } else {
           close_run();
           const int kts = h->kt.begin(LMGPU_KT_SYRK, s);
-          hipLaunchKernelGGL(syrk_mfma_kernel, dim3(T, T), dim3(256), kSyrkLds, s, A, ld, F.n, k0, kb, r0, F.n);
+          if (m <= 1024) {  // a few tiles: one workgroup per 32 x 32 quadrant instead (each 128-tile is K / 4 x 16 dependent MFMAs on one CU)
+            const int S = (m + 63) / 64;
+            hipLaunchKernelGGL(syrk_quadrants_kernel, dim3(4 * S, S), dim3(256), 0, s, A, ld, F.n, k0, kb, r0);
+          } else {
+            hipLaunchKernelGGL(syrk_mfma_kernel, dim3(T, T), dim3(256), kSyrkLds, s, A, ld, F.n, k0, kb, r0, F.n);
+          }
           h->kt.end(kts, s, upd_flop);
           if (i + 1 < np) panel_alone(i + 1);
         }
@@ -941,8 +951,8 @@ int do_backsub(lmgpu_handle* h) {
     if (L.bsd_count > 0) {  // the smaller HBM fronts of the level: one workgroup per 64-row block, one launch
       const int kt = h->kt.begin(LMGPU_KT_BACKSUB_HBM, s);
       hipLaunchKernelGGL(hbm_backsolve_blocks_kernel, dim3(L.bsd_count), dim3(256), 0, s, (const BsdBlock*)(h->d_bsd_table + L.bsd_begin),
-                         h->d_bsd_ticket + li, (const FrontDesc*)h->d_fronts, (const int64_t*)h->d_f_off, (const int32_t*)h->d_f_ld,
-                         (const int32_t*)h->d_fxoff, (const int32_t*)h->d_sxoff, (const double*)h->pool, h->delta, h->d_bsd_x, h->d_status);
+                         L.bsd_count <= h->num_cus ? (unsigned int*)nullptr : h->d_bsd_ticket + li, (const int32_t*)h->d_fxoff,
+                         (const int32_t*)h->d_sxoff, (const double*)h->pool, h->delta, h->d_bsd_x, h->d_status);
       h->kt.end(kt, s);
     }
     for (int fi : L.hbm) {
@@ -1459,6 +1469,11 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
   *out = h;
   if (h->device >= 0) {
     HIPCHECK(hipSetDevice(h->device));
+    {
+      hipDeviceProp_t prop;
+      HIPCHECK(hipGetDeviceProperties(&prop, h->device));
+      h->num_cus = prop.multiProcessorCount;
+    }
     HIPCHECK(hipStreamCreate(&h->stream));
     // the chunk all-reduces gate the panels of the factorisation that runs beside them: highest dispatch priority
     {
@@ -1483,7 +1498,6 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
     HIPCHECK(hipFuncSetAttribute((const void*)chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STEP_LDS_BYTES));
     HIPCHECK(hipFuncSetAttribute((const void*)front_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS_BYTES));
     HIPCHECK(hipFuncSetAttribute((const void*)med_diag_potrf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
-    HIPCHECK(hipFuncSetAttribute((const void*)med_syrk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSyrkLds));
   }
   return LMGPU_OK;
 }
@@ -1504,7 +1518,7 @@ int lmgpu_destroy(lmgpu_handle* h) {
     for (int t = 0; t < kNumVarTypes; t++) fr(h->type_xoff[t]);
     for (int t = 0; t < kNumVarTypes; t++) fr(h->saved[t]);
     fr(h->gex); fr(h->delta); fr(h->dampw); fr(h->hdiag); fr(h->ebuf0); fr(h->ebuf1); fr(h->partial); fr(h->dscal); fr(h->ywork); fr(h->d_status);
-    fr(h->d_fd); fr(h->d_fronts); fr(h->d_ffac); fr(h->d_childs); fr(h->d_cmap); fr(h->d_fxoff); fr(h->d_sxoff); fr(h->d_lists); fr(h->d_hbm_small); fr(h->d_med_list); fr(h->inv16_med); fr(h->bt_ebuf); fr(h->bt_vec); fr(h->d_f_ld); fr(h->d_f_off);
+    fr(h->d_fd); fr(h->d_fronts); fr(h->d_ffac); fr(h->d_childs); fr(h->d_cmap); fr(h->d_fxoff); fr(h->d_sxoff); fr(h->d_lists); fr(h->d_hbm_small); fr(h->d_med_list); fr(h->d_med_fronts); fr(h->inv16_med); fr(h->bt_ebuf); fr(h->bt_vec); fr(h->d_f_ld); fr(h->d_f_off);
     fr(h->d_scalar_var); fr(h->d_scalar_col); fr(h->d_vi_ptr); fr(h->d_vi_fac); fr(h->d_vi_pos);
     for (Bucket& b : h->buckets) {
       fr(b.d_vidx); fr(b.d_meas); fr(b.d_noise); fr(b.d_epos);
@@ -2084,7 +2098,8 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
       L.bsd_begin = (int)bsd.size();
       for (int q = 0; q < L.small_count; q++) {
         const int fi = small[L.small_begin + q], nblk = (P.fronts[fi].nf + 63) / 64;
-        for (int b = nblk - 1; b >= 0; b--) bsd.push_back(BsdBlock{fi, b, xoff, 0});
+        const FrontDesc& F = h->h_fronts[fi];
+        for (int b = nblk - 1; b >= 0; b--) bsd.push_back(BsdBlock{h->f_off[fi], h->f_ld[fi], F.n, F.nf, F.fx_begin, F.sx_begin, F.id, b, xoff});
         xoff += 64 * nblk;
       }
       L.bsd_count = (int)bsd.size() - L.bsd_begin;
@@ -2122,6 +2137,13 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
     if ((rc = upload(h, &h->d_f_ld, h->f_ld))) return rc;
   }
   if ((rc = upload(h, &h->d_row_begin, h->row_begin))) return rc;
+  {
+    std::vector<MedFront> mfs;
+    for (const LevelWork& L : h->levels)
+      for (int fi : L.hbm)
+        if (h->is_med[fi]) mfs.push_back(MedFront{h->h_fronts[fi], h->f_off[fi], h->f_ld[fi], h->row_begin[fi]});
+    if ((rc = upload(h, &h->d_med_fronts, mfs))) return rc;
+  }
   if ((rc = upload(h, &h->d_rowptr, rowptr))) return rc;
   if ((rc = upload(h, &h->d_rowsrc, rowsrc))) return rc;
   if ((rc = upload(h, &h->d_gpblk, gpblk))) return rc;

@@ -55,7 +55,7 @@ int main() {
     {  // the same front, one workgroup per 64-row block
       const int nblk = (nf + 63) / 64;
       std::vector<BsdBlock> tab;
-      for (int b = nblk - 1; b >= 0; b--) tab.push_back(BsdBlock{0, b, 0, 0});
+      for (int b = nblk - 1; b >= 0; b--) tab.push_back(BsdBlock{0, ld, n, nf, 0, 0, 0, b, 0});
       BsdBlock* dtab; unsigned int* dtick; double* dx;
       (void)hipMalloc((void**)&dtab, tab.size() * sizeof(BsdBlock)); (void)hipMalloc((void**)&dtick, 4); (void)hipMalloc((void**)&dx, nblk * 64 * 8);
       (void)hipMemcpy(dtab, tab.data(), tab.size() * sizeof(BsdBlock), hipMemcpyHostToDevice);
@@ -63,7 +63,7 @@ int main() {
       auto launch2 = [&]() {
         (void)hipMemsetAsync(dtick, 0, 4, 0);
         (void)hipMemsetAsync(dx, 0xff, nblk * 64 * 8, 0);
-        hipLaunchKernelGGL(hbm_backsolve_blocks_kernel, dim3(nblk), dim3(256), 0, 0, dtab, dtick, dF, doff, dld, dfx, dsx, dA, dd, dx, dst);
+        hipLaunchKernelGGL(hbm_backsolve_blocks_kernel, dim3(nblk), dim3(256), 0, 0, dtab, (unsigned int*)nullptr, dfx, dsx, dA, dd, dx, dst);
       };
       launch2();
       (void)hipDeviceSynchronize();
