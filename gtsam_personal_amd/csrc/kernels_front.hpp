@@ -79,8 +79,23 @@ struct LFac {
 static_assert(sizeof(FrontDesc) == LEAFPACK_HDR, "leaf records embed a FrontDesc");
 static_assert(sizeof(LFac) == 32, "leaf records embed LFac entries");
 #define LDSF_EXTRA_BYTES (LDSF_JCAP * 8 + LDSF_MAXB * 32 + 16)
-template <bool GATHER>
-__global__ __launch_bounds__(256) void lds_front_kernel(const int32_t* __restrict__ list, const FrontDesc* __restrict__ fronts,
+// development aid (tools/ldsf_phases.py builds a library of its own with it): 100 MHz wall-clock time per phase of the first workgroup of
+// every launch of at most eight fronts (= the upper levels of a clique tree, where a launch lasts as long as its slowest front)
+#ifdef LDSF_STAMPS
+__device__ unsigned long long ldsf_dbg[16];
+#define LDSF_STAMP(i)                                                  \
+  do {                                                                 \
+    if (gridDim.x <= 8 && blockIdx.x == 0 && threadIdx.x == 0) {       \
+      const unsigned long long now_ = wall_clock64();                  \
+      atomicAdd(&ldsf_dbg[i], now_ - ldsf_last);                       \
+      ldsf_last = now_;                                                \
+    }                                                                  \
+  } while (0)
+#else
+#define LDSF_STAMP(i) do { } while (0)
+#endif
+template <bool GATHER, int MAXT = 256>
+__global__ __launch_bounds__(MAXT) void lds_front_kernel(const int32_t* __restrict__ list, const FrontDesc* __restrict__ fronts,
                                                          const FrontFac* __restrict__ ffac, const FacDesc* __restrict__ fd,
                                                          const ChildRef* __restrict__ childs, const int32_t* __restrict__ cmap,
                                                          const int32_t* __restrict__ fxoff, double* __restrict__ pool, double lambda_v, const double* __restrict__ lambda_p,
@@ -88,6 +103,10 @@ __global__ __launch_bounds__(256) void lds_front_kernel(const int32_t* __restric
                                                          double* __restrict__ gcorner, int jcap, const double* __restrict__ gex,
                                                          const char* __restrict__ pack, int pack_stride) {
   extern __shared__ double S[];
+#ifdef LDSF_STAMPS
+  unsigned long long ldsf_last = wall_clock64();
+  if (gridDim.x <= 8 && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ldsf_dbg[15], 1ull);
+#endif
   double* corner_g = S + (size_t)srows * nmax;  // GATHER: the (rhs, rhs) entry lives here
   double* Jb = corner_g + 8;
   LFac* LF = (LFac*)(Jb + jcap);  // jcap <= LDSF_JCAP doubles of staged Jacobians: the launch's largest front (fewer for small ones => more fronts per CU)
@@ -223,21 +242,49 @@ __global__ __launch_bounds__(256) void lds_front_kernel(const int32_t* __restric
     k0 += B;
   }
   __syncthreads();
-  // ---- children: extend-add of their update matrices (row i of U contiguous: lanes along j)
-  for (int k = 0; k < F.child_count; k++) {
-    const ChildRef c = childs[F.child_begin + k];
-    const double* U = pool + c.u_off;
-    const int32_t* map = cmap + c.map_begin;
-    for (int i = wave; i < c.m; i += nw) {
-      const int gi = map[i];
-      for (int j = i + lane; j < c.m; j += 64) {
-        const int gj = map[j];
-        const int lo = gi < gj ? gi : gj, hi = gi < gj ? gj : gi;
-        S[lo * n + hi] += U[(size_t)i * c.ld + j];
+  LDSF_STAMP(0);  // descriptors, clear, own factors
+  // ---- children: extend-add of their update matrices (row i of U contiguous: lanes along j).  The child's column map is staged
+  //      in LDS once and eight rows per wave are fetched before the first is added -- row by row, every row was a memory round
+  //      trip of its own (25-35 of them per child of ~100 columns: most of the 27-60 us an upper-level front took).  The loads are
+  //      unconditional on clamped addresses (the lower triangle and the padding of U are finite: the pool is cleared once).
+  {
+    int* cm = (int*)Jb;  // jcap >= 96 doubles: room for 139 ints (a child's update matrix is at most as wide as this front)
+    for (int k = 0; k < F.child_count; k++) {
+      const ChildRef c = childs[F.child_begin + k];
+      const double* U = pool + c.u_off;
+      const int32_t* map = cmap + c.map_begin;
+      for (int i = tid; i < c.m; i += nt) cm[i] = map[i];
+      __syncthreads();
+      int gjs[3];
+#pragma unroll
+      for (int q = 0; q < 3; q++) gjs[q] = cm[min(lane + 64 * q, c.m - 1)];
+      for (int i0 = wave; i0 < c.m; i0 += 8 * nw) {
+        double u[8][3];
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+#pragma unroll
+          for (int q = 0; q < 3; q++) u[r][q] = U[(size_t)min(i0 + r * nw, c.m - 1) * c.ld + min(lane + 64 * q, c.m - 1)];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+          const int i = i0 + r * nw;
+          if (i < c.m) {
+            const int gi = cm[i];
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+              const int j = lane + 64 * q;
+              if (j >= i && j < c.m) {
+                const int gj = gjs[q];
+                const int lo = gi < gj ? gi : gj, hi = gi < gj ? gj : gi;
+                S[lo * n + hi] += u[r][q];
+              }
+            }
+          }
+        }
       }
+      __syncthreads();
     }
-    __syncthreads();
   }
+  LDSF_STAMP(1);  // extend-add of the children
   // ---- damping on the frontal diagonal
   // lambda_p != nullptr: the value lives in device memory so that a captured launch sequence can be replayed with a new one
   const double lambda = lambda_p ? *lambda_p : lambda_v;
@@ -252,6 +299,7 @@ __global__ __launch_bounds__(256) void lds_front_kernel(const int32_t* __restric
       if (gex) S[i * n + n - 1] += gex[fxoff[F.fx_begin + i]];  // extra gradient term eta += g (marginal covariances: unit vectors)
     }
   }
+  LDSF_STAMP(2);  // damping
   // ---- partial Cholesky
   bool failed = false;
   // Fronts with many frontal columns (upper levels of general sparse graphs: n ~ 100, nf ~ 20-60) take the pivots FOUR at a
@@ -260,29 +308,70 @@ __global__ __launch_bounds__(256) void lds_front_kernel(const int32_t* __restric
   // LDS).  Row by row, every trailing entry is read-modify-written in LDS once per pivot -- ~0.75 us per pivot at n = 139 from
   // LDS bandwidth alone, 100-200 us per front, which is what a narrow tree level costs.  Same arithmetic up to the order of
   // the four subtractions.
-  const bool blocked = !gather && nf >= 8 && nw == 4;
+  const bool blocked = !gather && nf >= 8 && nw >= 4;
   if (blocked) {
     typedef double d4_t __attribute__((ext_vector_type(4)));
     const int kk = lane >> 4, cc = lane & 15;
     for (int k0 = 0; k0 < nf; k0 += 4) {
       const int kb = min(4, nf - k0);
-      for (int q = 0; q < kb; q++) {
-        const int k = k0 + q;
-        __syncthreads();  // previous update of row k complete
-        double piv = S[k * n + k];
-        if (!(piv > 0.0)) {
-          if (piv <= 0.0) failed = true;
-          piv = (piv == piv && piv != 0.0) ? fabs(piv) : 1.0;
+      // The four pivot rows against each other: every thread factors the kb x kb diagonal block in registers (ten broadcast LDS
+      // reads; the same arithmetic in every thread), then one thread per column solves that column of the four-row panel against
+      // it.  Three barriers per four pivots; pivot by pivot (scale the row, update the rows below it, each behind a barrier of its
+      // own and a dependent sqrt / divide) the panel took ~1.6 us of the ~3 us a group of four costs.  Element by element the
+      // operations and their order are the ones of the row-by-row form.
+      __syncthreads();  // previous trailing update complete
+      double d[4][4], inv[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int c = q; c < 4; c++) d[q][c] = (c < kb) ? S[(k0 + q) * n + k0 + c] : ((q == c) ? 1.0 : 0.0);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        inv[q] = 1.0;
+        if (q < kb) {
+          double piv = d[q][q];
+          if (!(piv > 0.0)) {
+            if (piv <= 0.0) failed = true;  // Eigen LLT: pivot <= 0 -> NumericalIssue (NaN passes, like Eigen)
+            piv = (piv == piv && piv != 0.0) ? fabs(piv) : 1.0;
+          }
+          const double r = sqrt(piv);
+          inv[q] = 1.0 / r;
+          d[q][q] = r;
+#pragma unroll
+          for (int c = q + 1; c < 4; c++) d[q][c] *= inv[q];
+#pragma unroll
+          for (int i = q + 1; i < 4; i++)
+#pragma unroll
+            for (int c = i; c < 4; c++) d[i][c] -= d[q][i] * d[q][c];
         }
-        const double r = sqrt(piv), inv = 1.0 / r;
-        for (int j = k + 1 + tid; j < n; j += nt) S[k * n + j] *= inv;
-        __syncthreads();  // row k scaled; every thread has read the pivot
-        if (tid == 0) S[k * n + k] = r;
-        const int i = k + 1 + wave;  // the other rows of the panel: one wave each
-        if (i < k0 + kb) {
-          const double rki = S[k * n + i];
-          for (int j = i + lane; j < n; j += 64) S[i * n + j] -= rki * S[k * n + j];
+      }
+      __syncthreads();  // every thread has read the block
+      if (tid < 16) {
+        const int q = tid >> 2, c = tid & 3;
+        if (q <= c && c < kb) {
+          double v = 0.0;
+#pragma unroll
+          for (int qq = 0; qq < 4; qq++)
+#pragma unroll
+            for (int cc2 = 0; cc2 < 4; cc2++)
+              if (qq == q && cc2 == c && cc2 >= qq) v = d[qq][cc2];
+          S[(k0 + q) * n + k0 + c] = v;
         }
+      }
+      for (int j = k0 + kb + tid; j < n; j += nt) {
+        double x[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) x[q] = (q < kb) ? S[(k0 + q) * n + j] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          if (q < kb) {
+            x[q] *= inv[q];
+#pragma unroll
+            for (int i = q + 1; i < 4; i++) x[i] -= d[q][i] * x[q];
+          }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          if (q < kb) S[(k0 + q) * n + j] = x[q];
       }
       __syncthreads();
       const int t0 = k0 + kb, m = n - t0;
@@ -334,6 +423,7 @@ __global__ __launch_bounds__(256) void lds_front_kernel(const int32_t* __restric
     }
   }
   __syncthreads();
+  LDSF_STAMP(3);  // partial Cholesky
   if (tid == 0) {
     // pivot-exponent test, gtsam/base/cholesky.cpp:146-158
     if (nf >= 2) {
@@ -375,6 +465,10 @@ __global__ __launch_bounds__(256) void lds_front_kernel(const int32_t* __restric
     for (int i = wave; i < m; i += nw)
       for (int j = i + lane; j < m; j += 64) U[(size_t)i * F.ld_u + j] = S[(nf + i) * n + nf + j];
   }
+#ifdef LDSF_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  LDSF_STAMP(4);  // [R S d] and the update matrix written
+#endif
 }
 
 // back-substitution for LDS-class fronts: x_F = R^-1 (d - S x_S).  One wave per front, 4 fronts per block.

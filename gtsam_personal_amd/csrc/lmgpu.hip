@@ -225,6 +225,7 @@ struct lmgpu_handle {
   bool use_graph = false;       // replay the solve's launch sequence as a hipGraph (deep trees; LMGPU_GRAPH=0/1 overrides)
   int eager_solves = 0;
   hipGraphExec_t solve_graph[2] = {nullptr, nullptr};  // [1]: with the extra gradient vector of the marginal solves
+  bool no_wide16 = false;                      // LMGPU_NO_WIDE16=1: LDS fronts always with four waves (A/B)
   bool no_tail = false;                        // LMGPU_NO_TAIL=1: the end of a front as separate update / panel launches (A/B)
   bool no_chain = false;                       // LMGPU_NO_CHAIN=1: one launch per fused step instead of one per run of steps (A/B)
   unsigned int* d_pflags = nullptr;            // hand-off flags of panel_dataflow_kernel, PDF_FLAG_WORDS per outer panel
@@ -568,7 +569,17 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
       const int jcap = L.bin_jcap[b];
       const size_t lds = kLdsFrontExtra - (size_t)(LDSF_JCAP - jcap) * 8 + 64 + (size_t)srows * nmax * sizeof(double);
       const int kt = h->kt.begin(LMGPU_KT_LDS_FRONT, s);
-      if (b < 6)
+      // a handful of wide fronts (the upper levels of a general sparse tree, where a launch lasts as long as its slowest front and the
+      // device is idle): sixteen waves per front -- the rank-4 trailing updates, the extend-add and the emission all scale with them
+      const bool wide16 = b >= 3 && b < 6 && cnt <= 64 && !h->no_wide16;
+      if (wide16)
+        hipLaunchKernelGGL((lds_front_kernel<false, 1024>), dim3(cnt), dim3(1024), lds, s,
+                           (const int32_t*)(h->d_lists + L.list_begin + L.bin_begin[b]), (const FrontDesc*)h->d_fronts,
+                           (const FrontFac*)h->d_ffac, (const FacDesc*)h->d_fd, (const ChildRef*)h->d_childs, (const int32_t*)h->d_cmap,
+                           (const int32_t*)h->d_fxoff, h->pool, lambda_v, lambda_p, (const double*)h->dampw, h->d_status, nmax, srows, h->d_gcorner, jcap,
+                           (const double*)h->gex_active, (const char*)(h->d_leafpack && L.pack_stride[b] ? h->d_leafpack + L.pack_off[b] : nullptr),
+                           L.pack_stride[b]);
+      else if (b < 6)
         hipLaunchKernelGGL(lds_front_kernel<false>, dim3(cnt), dim3(threads), lds, s,
                            (const int32_t*)(h->d_lists + L.list_begin + L.bin_begin[b]), (const FrontDesc*)h->d_fronts,
                            (const FrontFac*)h->d_ffac, (const FacDesc*)h->d_fd, (const ChildRef*)h->d_childs, (const int32_t*)h->d_cmap,
@@ -1463,6 +1474,7 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
   h->no_fuse = getenv("LMGPU_NO_FUSE") != nullptr;
   h->no_chain = getenv("LMGPU_NO_CHAIN") != nullptr;
   h->no_tail = getenv("LMGPU_NO_TAIL") != nullptr;
+  h->no_wide16 = getenv("LMGPU_NO_WIDE16") != nullptr;
   h->no_gather_write = getenv("LMGPU_NO_GATHER_WRITE") != nullptr;
   h->scatter_atomics = getenv("LMGPU_NO_GATHER") != nullptr;
   if (const char* e = getenv("LMGPU_CHAIN_FAR")) h->chain_far_pct = std::max(10, std::min(100, atoi(e)));
@@ -1488,6 +1500,7 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
     HIPCHECK(hipMalloc((void**)&h->d_lambda, sizeof(double)));
     HIPCHECK(hipMemset(h->d_lambda, 0, sizeof(double)));
     HIPCHECK(hipFuncSetAttribute((const void*)lds_front_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra + 64));
+    HIPCHECK(hipFuncSetAttribute((const void*)lds_front_kernel<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra + 64));
     HIPCHECK(hipFuncSetAttribute((const void*)lds_front_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra + 64));
     HIPCHECK(hipFuncSetAttribute((const void*)syrk_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSyrkLds));
     HIPCHECK(hipFuncSetAttribute((const void*)lds_backsub_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 96 * 8));
@@ -2887,3 +2900,13 @@ int lmgpu_peak_hbm_copy(int32_t device, int64_t bytes, int32_t iters, double* gb
 }  // extern "C"
 
 #include "isam2.hpp"
+
+#ifdef LDSF_STAMPS  // development aid: tools/ldsf_phases.py
+extern "C" int lmgpu_debug_ldsf(unsigned long long* out16, int reset) {
+  if (reset) {
+    unsigned long long z[16] = {0};
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(lmgpu::ldsf_dbg), z, sizeof(z));
+  }
+  return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(lmgpu::ldsf_dbg), 16 * sizeof(unsigned long long));
+}
+#endif

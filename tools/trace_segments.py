@@ -4,18 +4,18 @@ rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # last complete iterate: find last sfm/between linearize kernel as marker
 names = [r["Kernel_Name"] for r in rows]
-marks = [i for i, n in enumerate(names) if "linearize" in n or "factor_kernel" in n]
+marks = [i for i, n in enumerate(names) if "linearize" in n or "generic_factor_kernel" in n]
 # take the segment between the 2 last linearize launches groups
 # groups of consecutive linearize launches = starts of LM iterations; segment number argv[3] counted from the end (default 1 = last)
 back = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 j = marks[-1]
 for _ in range(back - 1):
-    while j > 0 and ("linearize" in names[j - 1] or "factor_kernel" in names[j - 1]): j -= 1
+    while j > 0 and ("linearize" in names[j - 1] or "generic_factor_kernel" in names[j - 1]): j -= 1
     j -= 1
-    while j > 0 and not ("linearize" in names[j] or "factor_kernel" in names[j]): j -= 1
-while j > 0 and ("linearize" in names[j - 1] or "factor_kernel" in names[j - 1]): j -= 1
+    while j > 0 and not ("linearize" in names[j] or "generic_factor_kernel" in names[j]): j -= 1
+while j > 0 and ("linearize" in names[j - 1] or "generic_factor_kernel" in names[j - 1]): j -= 1
 k = j - 1
-while k > 0 and not ("linearize" in names[k] or "factor_kernel" in names[k]): k -= 1
+while k > 0 and not ("linearize" in names[k] or "generic_factor_kernel" in names[k]): k -= 1
 seg = rows[k + 1:j]
 t0 = int(seg[0]["Start_Timestamp"])
 prev_end = t0
