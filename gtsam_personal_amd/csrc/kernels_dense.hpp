@@ -156,6 +156,18 @@ __global__ __launch_bounds__(256) void hbm_damp_kernel(FrontDesc F, int64_t f_of
   if (gex) pool[f_off + (size_t)i * ld + F.n - 1] += gex[fxoff[F.fx_begin + i]];
 }
 
+// Clears a list of ranges of the pool in ONE launch: grid (slices, ranges).  A general sparse graph has dozens of HBM fronts scattered
+// through the pool; a memset node per front cost ~5 us each at the head of every solve (41 of them on city10000).
+struct ZeroRange {
+  int64_t off, count;  // doubles; both multiples of 2
+};
+__global__ __launch_bounds__(256) void zero_ranges_kernel(const ZeroRange* __restrict__ ranges, double* __restrict__ pool) {
+  const ZeroRange r = ranges[blockIdx.y];
+  double2* p = (double2*)(pool + r.off);
+  const int64_t n2 = r.count >> 1;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)gridDim.x * 256) p[i] = double2{0.0, 0.0};
+}
+
 // ---------------------------------------------------------------- trailing update on the matrix cores
 // C[i][j] -= sum_{p < kp} P[p][i] P[p][j]   for r0 <= i < r1, i <= j < n,   P = rows p0 .. p0+kp-1 of A (finished [R S d] rows).
 // Block = 4 waves computing a 128x128 tile (each wave 64x64 = 4x4 MFMA 16x16x4 f64 tiles, 128 accumulator VGPRs).

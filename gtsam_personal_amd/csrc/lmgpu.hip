@@ -253,6 +253,8 @@ struct lmgpu_handle {
   double* d_bsd_x = nullptr;            // their published x (64 per block), preset to the all-ones sentinel at the start of a back-substitution
   unsigned int* d_bsd_ticket = nullptr; // one ticket counter per level
   size_t bsd_x_count = 0;
+  ZeroRange* d_zero_ranges = nullptr;   // the HBM fronts a solve clears first, when they are many and scattered (zero_ranges_kernel)
+  int n_zero_ranges = 0;
   int num_cus = 0;                      // compute units of the device (a grid of at most this many small workgroups is resident at once)
   // deterministic assembly of HBM fronts (kernels_dense.hpp: hbm_assemble_rows_kernel): per front the start of its n + 1 row
   // pointers in d_rowptr (-1: none), the pointers (offsets into d_rowsrc) and the sources
@@ -543,6 +545,23 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
       // many mid-size fronts (general sparse graphs): one memset over their span; what lies between them ([R S d] / update
       // storage of LDS fronts, laid out in the same post-order) is rewritten by this elimination before it is read
       HIPCHECK(hipMemsetAsync(h->pool + lo, 0, (size_t)(hi - lo) * sizeof(double), s));
+    } else if (n_hbm > 4) {
+      // scattered through the pool: one launch over the list of their ranges (built once; f_ld and the pool offsets are multiples of 16)
+      if (!h->d_zero_ranges) {
+        std::vector<ZeroRange> zr;
+        for (const LevelWork& L : h->levels)
+          for (int fi : L.hbm) {
+            const bool gw = gather_writes(h, fi);
+            const int64_t cnt = (int64_t)h->h_fronts[fi].n * h->f_ld[fi];
+            if (!gw || h->s_off[fi] >= 0) zr.push_back(ZeroRange{h->f_off[fi], cnt});
+            if (!gw && h->s_off[fi] >= 0) zr.push_back(ZeroRange{h->s_off[fi], cnt});
+          }
+        h->n_zero_ranges = (int)zr.size();
+        const int rcu = upload(h, &h->d_zero_ranges, zr);
+        if (rcu) return rcu;
+      }
+      if (h->n_zero_ranges > 0)
+        hipLaunchKernelGGL(zero_ranges_kernel, dim3(16, h->n_zero_ranges), dim3(256), 0, s, (const ZeroRange*)h->d_zero_ranges, h->pool);
     } else {
       for (const LevelWork& L : h->levels)
         for (int fi : L.hbm) {
@@ -1541,7 +1560,7 @@ int lmgpu_destroy(lmgpu_handle* h) {
     for (int i = 0; i < 8; i++)
       if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     for (hipEvent_t e : h->kt.pool) (void)hipEventDestroy(e);
-    fr(h->bs_inv); fr(h->bs_x); fr(h->bs_flags); fr(h->inv16); fr(h->d_pflags); fr(h->d_bs_parent); fr(h->d_bs_pos); fr(h->d_bs_done); fr(h->d_bsd_table); fr(h->d_bsd_x); fr(h->d_bsd_ticket); fr(h->d_leafpack); fr(h->d_gzero);
+    fr(h->bs_inv); fr(h->bs_x); fr(h->bs_flags); fr(h->inv16); fr(h->d_pflags); fr(h->d_bs_parent); fr(h->d_bs_pos); fr(h->d_bs_done); fr(h->d_bsd_table); fr(h->d_zero_ranges); fr(h->d_bsd_x); fr(h->d_bsd_ticket); fr(h->d_leafpack); fr(h->d_gzero);
     for (auto& kv : h->chain_plans)
       for (auto& cp : kv.second) fr(cp.d_tasks);
     fr(h->d_gpblk); fr(h->d_gpent); fr(h->d_gvblk); fr(h->d_gvent); fr(h->d_gcorner); fr(h->d_row_begin); fr(h->d_rowptr); fr(h->d_rowsrc);
