@@ -18,6 +18,7 @@
 // cliques of more than 139 scalar columns (the LDS front kernel's limit) are rejected.
 #pragma once
 
+#include <chrono>
 #include <list>
 #include <set>
 #include <type_traits>
@@ -94,6 +95,20 @@ struct lmgpu_isam2 {
 
   // device scratch
   int *d_status = nullptr, *h_status = nullptr;
+  // Per-update staging: everything an update sends to the device goes through ONE pinned host arena and (for tables only the
+  // update's kernels read) a device arena of the same size -- asynchronous copies from memory that stays valid until the next update,
+  // no allocation, no wait.  (One hipMalloc + copy + wait + hipFree per index list and per table, and three blocking copies per new
+  // factor, were most of the 0.4-0.7 ms an update cost.)  Requests beyond the arena get a chunk of their own, freed at the next update.
+  char *h_stage = nullptr, *d_stage = nullptr;
+  size_t stage_cap = 0, stage_used = 0, stage_want = 0;
+  std::vector<std::pair<void*, void*>> stage_extra;  // (pinned host, device)
+  double* h_delta = nullptr;  // pinned copy of delta for CheckRelinearizationFull
+  size_t h_delta_cap = 0;
+  // LMGPU_ISAM2_TRACE=1: wall time per phase of update(), printed when the handle is destroyed (development aid)
+  bool trace = false;
+  double t_phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  std::vector<int> elim_cid;  // cliques of the elimination whose status word is still on the device (checked when the update ends)
+  bool elim_pending = false;
   bool tree_dirty = true;
   FrontDesc* d_tree = nullptr;  // one descriptor per clique slot (wildfire)
   int32_t *d_tree_fx = nullptr, *d_tree_sx = nullptr, *d_tree_list = nullptr;
@@ -126,6 +141,70 @@ int is_realloc(lmgpu_isam2* S, T** p, size_t newcap, size_t used) {
   return LMGPU_OK;
 }
 inline size_t is_next_cap(size_t cap, size_t need) { return std::max<size_t>(need, std::max<size_t>(64, cap * 2)); }
+
+// start of an update: the stream is idle (every entry point ends with a wait), so the arenas can be reused / regrown
+int is_stage_begin(lmgpu_isam2* S) {
+  ISCHECK(hipStreamSynchronize(S->stream));
+  for (auto& e : S->stage_extra) {
+    (void)hipHostFree(e.first);
+    if (e.second) (void)hipFree(e.second);
+  }
+  S->stage_extra.clear();
+  const size_t want = std::max<size_t>(size_t(1) << 20, 2 * S->stage_want);
+  if (want > S->stage_cap) {
+    if (S->h_stage) (void)hipHostFree(S->h_stage);
+    if (S->d_stage) (void)hipFree(S->d_stage);
+    S->h_stage = S->d_stage = nullptr;
+    S->stage_cap = 0;
+    ISCHECK(hipHostMalloc((void**)&S->h_stage, want, hipHostMallocDefault));
+    ISCHECK(hipMalloc((void**)&S->d_stage, want));
+    S->stage_cap = want;
+  }
+  S->stage_used = 0;
+  S->stage_want = 0;
+  return LMGPU_OK;
+}
+// pinned bytes for `bytes` of payload (+ where the device arena mirrors them, if asked for)
+int is_stage_raw(lmgpu_isam2* S, size_t bytes, char** hp, char** dp) {
+  const size_t b = (std::max<size_t>(bytes, 1) + 63) & ~size_t(63);
+  S->stage_want += b;
+  if (S->stage_used + b <= S->stage_cap) {
+    *hp = S->h_stage + S->stage_used;
+    if (dp) *dp = S->d_stage + S->stage_used;
+    S->stage_used += b;
+    return LMGPU_OK;
+  }
+  void *h = nullptr, *d = nullptr;
+  ISCHECK(hipHostMalloc(&h, b, hipHostMallocDefault));
+  if (dp) ISCHECK(hipMalloc(&d, b));
+  S->stage_extra.emplace_back(h, d);
+  *hp = (char*)h;
+  if (dp) *dp = (char*)d;
+  return LMGPU_OK;
+}
+// a table the update's kernels read: host vector -> device arena, asynchronously
+template <typename T>
+int is_stage(lmgpu_isam2* S, const std::vector<T>& src, T** d) {
+  char *hp, *dp;
+  const int rc = is_stage_raw(S, src.size() * sizeof(T), &hp, &dp);
+  if (rc) return rc;
+  if (!src.empty()) {
+    std::memcpy(hp, src.data(), src.size() * sizeof(T));
+    ISCHECK(hipMemcpyAsync(dp, hp, src.size() * sizeof(T), hipMemcpyHostToDevice, S->stream));
+  }
+  *d = (T*)dp;
+  return LMGPU_OK;
+}
+// host data into a persistent device array, asynchronously (the source is copied into the pinned arena first)
+int is_push(lmgpu_isam2* S, void* dst, const void* src, size_t bytes) {
+  if (!bytes) return LMGPU_OK;
+  char* hp;
+  const int rc = is_stage_raw(S, bytes, &hp, nullptr);
+  if (rc) return rc;
+  std::memcpy(hp, src, bytes);
+  ISCHECK(hipMemcpyAsync(dst, hp, bytes, hipMemcpyHostToDevice, S->stream));
+  return LMGPU_OK;
+}
 
 int is_pool_alloc(lmgpu_isam2* S, size_t n, int64_t* off) {
   n = std::max<size_t>(n, 1);
@@ -234,6 +313,14 @@ void is_linearize_sel(lmgpu_isam2* S, const lmgpu_isam2::Bkt& b, const int32_t* 
 }
 
 }  // namespace
+
+// deltaReplacedMask_ |= affected keys (ISAM2.cpp:172): marks = (offset, dimension) pairs of the re-eliminated variables
+__global__ __launch_bounds__(256) void isam2_mark_kernel(const int32_t* __restrict__ marks, int n, unsigned char* __restrict__ replaced) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int xo = marks[2 * i], d = marks[2 * i + 1];
+  for (int k = 0; k < d; k++) replaced[xo + k] = 1;
+}
 
 // One workgroup per clique of one tree depth: ISAM2Clique::optimizeWildfireNode (gtsam/nonlinear/ISAM2Clique.cpp:211-234).
 //   dirty   = the clique was re-eliminated (replaced flag of its first frontal scalar) or a separator scalar changed (isDirty :56-77)
@@ -344,10 +431,10 @@ int is_sync_tree(lmgpu_isam2* S) {
   if ((rc = fit(&S->d_tree_fx, &S->tree_cap[1], fx.size()))) return rc;
   if ((rc = fit(&S->d_tree_sx, &S->tree_cap[2], sx.size()))) return rc;
   if ((rc = fit(&S->d_tree_list, &S->tree_cap[3], list.size()))) return rc;
-  ISCHECK(hipMemcpy(S->d_tree, td.data(), td.size() * sizeof(FrontDesc), hipMemcpyHostToDevice));
-  if (!fx.empty()) ISCHECK(hipMemcpy(S->d_tree_fx, fx.data(), fx.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  if (!sx.empty()) ISCHECK(hipMemcpy(S->d_tree_sx, sx.data(), sx.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  if (!list.empty()) ISCHECK(hipMemcpy(S->d_tree_list, list.data(), list.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  if ((rc = is_push(S, S->d_tree, td.data(), td.size() * sizeof(FrontDesc)))) return rc;
+  if ((rc = is_push(S, S->d_tree_fx, fx.data(), fx.size() * sizeof(int32_t)))) return rc;
+  if ((rc = is_push(S, S->d_tree_sx, sx.data(), sx.size() * sizeof(int32_t)))) return rc;
+  if ((rc = is_push(S, S->d_tree_list, list.data(), list.size() * sizeof(int32_t)))) return rc;
   S->tree_dirty = false;
   return LMGPU_OK;
 }
@@ -366,6 +453,13 @@ int is_update_delta(lmgpu_isam2* S, bool force_full) {
                        (const unsigned char*)S->d_replaced, S->d_changed, thr, S->d_status);
   ISCHECK(hipMemsetAsync(S->d_replaced, 0, (size_t)S->ntot, S->stream));
   ISCHECK(hipMemcpyAsync(S->h_status, S->d_status, sizeof(int), hipMemcpyDeviceToHost, S->stream));
+  if ((size_t)S->ntot > S->h_delta_cap) {
+    if (S->h_delta) (void)hipHostFree(S->h_delta);
+    S->h_delta = nullptr;
+    S->h_delta_cap = is_next_cap(S->h_delta_cap, (size_t)S->ntot);
+    ISCHECK(hipHostMalloc((void**)&S->h_delta, S->h_delta_cap * sizeof(double), hipHostMallocDefault));
+  }
+  ISCHECK(hipMemcpyAsync(S->h_delta, S->delta, (size_t)S->ntot * sizeof(double), hipMemcpyDeviceToHost, S->stream));  // CheckRelinearizationFull reads it
   ISCHECK(hipStreamSynchronize(S->stream));
   std::fill(S->replaced.begin(), S->replaced.end(), 0);
   S->any_replaced = false;
@@ -535,14 +629,8 @@ int is_eliminate(lmgpu_isam2* S, const std::vector<IsGF>& gfs, const std::vector
       if (sf.fronts[fi].level == l) list.push_back(fi);
     lv[l].second = (int)list.size() - lv[l].first;
   }
-  auto up = [&](auto** dst, const auto& src) -> int {
-    typedef typename std::remove_reference<decltype(src[0])>::type T;
-    ISCHECK(hipMalloc((void**)dst, std::max<size_t>(1, src.size()) * sizeof(T)));
-    if (!src.empty()) ISCHECK(hipMemcpyAsync(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, S->stream));
-    return LMGPU_OK;
-  };
-  if ((rc = up(&d_fds, fds)) || (rc = up(&d_ffac, ffac)) || (rc = up(&d_fd, fd)) || (rc = up(&d_childs, childs)) || (rc = up(&d_cmap, cmap)) ||
-      (rc = up(&d_fxoff, fxoff)) || (rc = up(&d_list, list)))
+  if ((rc = is_stage(S, fds, &d_fds)) || (rc = is_stage(S, ffac, &d_ffac)) || (rc = is_stage(S, fd, &d_fd)) || (rc = is_stage(S, childs, &d_childs)) ||
+      (rc = is_stage(S, cmap, &d_cmap)) || (rc = is_stage(S, fxoff, &d_fxoff)) || (rc = is_stage(S, list, &d_list)))
     return rc;
   ISCHECK(hipMemsetAsync(S->d_status, 0x7f, sizeof(int), S->stream));
   for (int l = 0; l <= max_level; l++) {
@@ -566,18 +654,21 @@ int is_eliminate(lmgpu_isam2* S, const std::vector<IsGF>& gfs, const std::vector
                        (const int32_t*)d_fxoff, S->pool, 0.0, (const double*)nullptr, (const double*)S->ones, S->d_status, nmax, nmax, (double*)nullptr, jcap,
                        (const double*)nullptr, (const char*)nullptr, 0);
   }
+  // the status word comes back with the one wait that ends the update (is_finish_elimination)
   ISCHECK(hipMemcpyAsync(S->h_status, S->d_status, sizeof(int), hipMemcpyDeviceToHost, S->stream));
+  S->elim_cid = cid;
+  S->elim_pending = true;
+  return LMGPU_OK;
+}
+
+// the wait that ends an update: EliminateCholesky failed -> IndeterminantLinearSystemException(first frontal key), HessianFactor.cpp:475-482
+int is_finish_elimination(lmgpu_isam2* S) {
   ISCHECK(hipStreamSynchronize(S->stream));
-  (void)hipFree(d_fds);
-  (void)hipFree(d_ffac);
-  (void)hipFree(d_fd);
-  (void)hipFree(d_childs);
-  (void)hipFree(d_cmap);
-  (void)hipFree(d_fxoff);
-  (void)hipFree(d_list);
   ISCHECK(hipGetLastError());
-  if (*S->h_status < NF) {  // EliminateCholesky failed: IndeterminantLinearSystemException(first frontal key), HessianFactor.cpp:475-482
-    S->failed_key = S->vars[S->clq[cid[*S->h_status]].vars[0]].key;
+  if (!S->elim_pending) return LMGPU_OK;
+  S->elim_pending = false;
+  if (*S->h_status < (int)S->elim_cid.size()) {
+    S->failed_key = S->vars[S->clq[S->elim_cid[*S->h_status]].vars[0]].key;
     S->err = "indeterminate linear system";
     return LMGPU_INDETERMINATE;
   }
@@ -595,11 +686,9 @@ template <typename Fn>
 int is_with_list(lmgpu_isam2* S, const std::vector<int32_t>& v, Fn fn) {
   if (v.empty()) return LMGPU_OK;
   int32_t* d = nullptr;
-  ISCHECK(hipMalloc((void**)&d, v.size() * sizeof(int32_t)));
-  ISCHECK(hipMemcpyAsync(d, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice, S->stream));
+  const int rc = is_stage(S, v, &d);
+  if (rc) return rc;
   fn((const int32_t*)d, (int)v.size());
-  ISCHECK(hipStreamSynchronize(S->stream));
-  (void)hipFree(d);
   return LMGPU_OK;
 }
 
@@ -608,6 +697,16 @@ int is_update(lmgpu_isam2* S, bool force_relinearize, lmgpu_isam2_result* result
   S->update_count += 1;
   lmgpu_isam2_result res{};
   int rc;
+  auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_last = S->trace ? now() : 0.0;
+  auto lap = [&](int i) {
+    if (!S->trace) return;
+    const double t = now();
+    S->t_phase[i] += t - t_last;
+    t_last = t;
+  };
+  if ((rc = is_stage_begin(S))) return rc;
+  S->elim_pending = false;
   // ---- addVariables :365-384
   for (const lmgpu_isam2::NewVar& nv : S->new_vars)
     if (S->vid_of.count(nv.key)) {
@@ -644,6 +743,12 @@ int is_update(lmgpu_isam2* S, bool force_relinearize, lmgpu_isam2_result* result
       ISCHECK(hipMemsetAsync(S->d_replaced + S->ntot, 0, ncap - S->ntot, S->stream));
       S->ntot_cap = (int)ncap;
     }
+    // the new variables of a type take consecutive places: one copy per type for the values, one for the delta offsets
+    const int ntot0 = S->ntot;
+    int first_tidx[kNumVarTypes];
+    std::vector<double> vals[kNumVarTypes];
+    std::vector<int32_t> xoffs[kNumVarTypes];
+    for (int t = 0; t < kNumVarTypes; t++) first_tidx[t] = S->type_count[t];
     for (auto& nv : new_vars) {
       lmgpu_isam2::Var v{nv.key, nv.type, S->type_count[nv.type]++, S->ntot};
       const int vid = (int)S->vars.size();
@@ -652,20 +757,31 @@ int is_update(lmgpu_isam2* S, bool force_relinearize, lmgpu_isam2_result* result
       S->vindex.emplace_back();
       S->node_of.push_back(-1);
       S->replaced.push_back(0);
-      ISCHECK(hipMemcpyAsync(S->theta[nv.type] + (size_t)v.tidx * kVarStore[nv.type], nv.v, kVarStore[nv.type] * sizeof(double),
-                             hipMemcpyHostToDevice, S->stream));
-      ISCHECK(hipMemcpyAsync(S->d_type_xoff[nv.type] + v.tidx, &S->vars.back().xoff, sizeof(int32_t), hipMemcpyHostToDevice, S->stream));
-      ISCHECK(hipMemsetAsync(S->delta + S->ntot, 0, kVarDim[nv.type] * sizeof(double), S->stream));  // delta_.insert(zeroVectors)
+      vals[nv.type].insert(vals[nv.type].end(), nv.v, nv.v + kVarStore[nv.type]);
+      xoffs[nv.type].push_back(v.xoff);
       S->ntot += kVarDim[nv.type];
     }
-    ISCHECK(hipStreamSynchronize(S->stream));  // the sources above are host locals
+    for (int t = 0; t < kNumVarTypes; t++) {
+      if (xoffs[t].empty()) continue;
+      if ((rc = is_push(S, S->theta[t] + (size_t)first_tidx[t] * kVarStore[t], vals[t].data(), vals[t].size() * sizeof(double)))) return rc;
+      if ((rc = is_push(S, S->d_type_xoff[t] + first_tidx[t], xoffs[t].data(), xoffs[t].size() * sizeof(int32_t)))) return rc;
+    }
+    ISCHECK(hipMemsetAsync(S->delta + ntot0, 0, (size_t)(S->ntot - ntot0) * sizeof(double), S->stream));  // delta_.insert(zeroVectors)
   }
   const bool relinNeeded = force_relinearize || (S->prm.enableRelinearization && S->prm.relinearizeSkip > 0 && S->update_count % S->prm.relinearizeSkip == 0);
   if (relinNeeded && (rc = is_update_delta(S, false))) return rc;
+  const int relin_ntot = S->ntot;  // scalars of delta the pinned copy holds
+  lap(0);  // new variables + updateDelta (wildfire, one wait)
   // ---- 1. pushBackFactors (ISAM2-impl.h:145-175): indices continue the list
   const int firstNew = (int)S->facs.size();
   std::set<uint64_t> markedKeys;
   std::map<int, std::vector<int32_t>> new_by_bucket;  // bucket -> new local indices
+  struct NewRows {
+    int first = -1;
+    std::vector<int32_t> vidx;
+    std::vector<double> meas, noise;
+  };
+  std::map<int, NewRows> new_rows;  // bucket -> the descriptor rows of its new factors (consecutive local indices), uploaded after the loop
   for (const lmgpu_isam2::NewFac& nf : new_facs) {
     const int ar = kFactorArity[nf.type];
     lmgpu_isam2::Fac f{nf.type, -1, -1, {-1, -1}};
@@ -715,23 +831,34 @@ int is_update(lmgpu_isam2* S, bool force_relinearize, lmgpu_isam2_result* result
       b.joff = noff;
       b.cap = (int)ncap;
     }
-    int32_t vi2[2] = {S->vars[f.v[0]].tidx, ar > 1 ? S->vars[f.v[1]].tidx : 0};
-    ISCHECK(hipMemcpy(b.d_vidx + (size_t)b.n * b.ar, vi2, b.ar * sizeof(int32_t), hipMemcpyHostToDevice));
-    ISCHECK(hipMemcpy(b.d_meas + (size_t)b.n * b.ml, nf.meas.data(), b.ml * sizeof(double), hipMemcpyHostToDevice));
-    if (b.nl) ISCHECK(hipMemcpy(b.d_noise + (size_t)b.n * b.nl, nf.noise.data(), b.nl * sizeof(double), hipMemcpyHostToDevice));
+    NewRows& nr = new_rows[bi];
+    if (nr.first < 0) nr.first = b.n;
+    nr.vidx.push_back(S->vars[f.v[0]].tidx);
+    if (ar > 1) nr.vidx.push_back(S->vars[f.v[1]].tidx);
+    nr.meas.insert(nr.meas.end(), nf.meas.begin(), nf.meas.begin() + b.ml);
+    if (b.nl) nr.noise.insert(nr.noise.end(), nf.noise.begin(), nf.noise.begin() + b.nl);
     f.bucket = bi;
     f.lidx = b.n++;
     new_by_bucket[bi].push_back(f.lidx);
     S->facs.push_back(f);
+  }
+  for (auto& kv : new_rows) {  // (a bucket that grew in the loop moved its old rows only; the new ones arrive here)
+    lmgpu_isam2::Bkt& b = S->bkts[kv.first];
+    const NewRows& nr = kv.second;
+    if ((rc = is_push(S, b.d_vidx + (size_t)nr.first * b.ar, nr.vidx.data(), nr.vidx.size() * sizeof(int32_t)))) return rc;
+    if ((rc = is_push(S, b.d_meas + (size_t)nr.first * b.ml, nr.meas.data(), nr.meas.size() * sizeof(double)))) return rc;
+    if (b.nl && (rc = is_push(S, b.d_noise + (size_t)nr.first * b.nl, nr.noise.data(), nr.noise.size() * sizeof(double)))) return rc;
   }
   std::vector<int32_t> observed;  // observedKeys = markedKeys at this point (no unused keys without removals), ascending by key
   for (uint64_t k : markedKeys) observed.push_back(S->vid_of.at(k));
   std::set<int32_t> relin;  // relinKeys as vids
   if (relinNeeded) {
     // ---- 4. CheckRelinearizationFull (:353-383) on the delta just updated
-    std::vector<double> hdelta((size_t)S->ntot);
-    if (S->ntot) ISCHECK(hipMemcpy(hdelta.data(), S->delta, (size_t)S->ntot * sizeof(double), hipMemcpyDeviceToHost));
+    // (is_update_delta above brought delta to the host with its own wait; variables added by this update are not in it: delta = 0)
+    const double* hdelta = S->h_delta;
+    const int ntot_checked = relin_ntot;
     for (size_t v = 0; v < S->vars.size(); v++) {
+      if (S->vars[v].xoff >= ntot_checked) continue;
       double m = 0;
       for (int d = 0; d < kVarDim[S->vars[v].type]; d++) m = std::max(m, std::fabs(hdelta[S->vars[v].xoff + d]));
       if (m >= S->prm.relinearizeThreshold) {
@@ -765,6 +892,7 @@ int is_update(lmgpu_isam2* S, bool force_relinearize, lmgpu_isam2_result* result
     if ((rc = is_with_list(S, kv.second, [&](const int32_t* d, int cnt) { is_linearize_sel(S, S->bkts[kv.first], d, cnt); }))) return rc;
   for (int i = firstNew; i < (int)S->facs.size(); i++)
     for (int k = 0; k < kFactorArity[S->facs[i].type]; k++) S->vindex[S->facs[i].v[k]].push_back(i);
+  lap(1);  // new factors, relinearization check, retract, linearize
   // ---- 8. recalculate (ISAM2.cpp:117-175)
   if (!markedKeys.empty()) {
     std::vector<int> bn;
@@ -867,22 +995,32 @@ int is_update(lmgpu_isam2* S, bool force_relinearize, lmgpu_isam2_result* result
       for (int32_t v : observed)
         if (affectedSet.count(v)) groups.emplace(v, group);
       std::vector<int32_t> perm;
+      lap(2);  // removeTop, affected factors, variable index
       if ((rc = is_colamd(S, vids, cols, (int)gfs.size(), groups, &perm))) return rc;
+      lap(3);  // constrained COLAMD callback
       if ((rc = is_eliminate(S, gfs, vids, perm))) return rc;
+      lap(4);  // symbolic elimination, tables, launches
     }
     // deltaReplacedMask_ |= affectedKeysSet
-    std::vector<unsigned char> one(8, 1);
+    std::vector<int32_t> marks;  // (xoff, dim) pairs
     for (int32_t v : affectedSet) {
       S->replaced[v] = 1;
-      ISCHECK(hipMemcpyAsync(S->d_replaced + S->vars[v].xoff, one.data(), kVarDim[S->vars[v].type], hipMemcpyHostToDevice, S->stream));
+      marks.push_back(S->vars[v].xoff);
+      marks.push_back(kVarDim[S->vars[v].type]);
     }
-    ISCHECK(hipStreamSynchronize(S->stream));
+    if ((rc = is_with_list(S, marks, [&](const int32_t* d, int cnt) {
+           hipLaunchKernelGGL(isam2_mark_kernel, dim3((cnt / 2 + 255) / 256), dim3(256), 0, S->stream, d, cnt / 2, S->d_replaced);
+         })))
+      return rc;
     S->any_replaced = S->any_replaced || !affectedSet.empty();
   }
   res.cliques = 0;
   for (int r : S->roots) res.cliques += is_count_subtree(S, r);
   if (result) *result = res;
-  return LMGPU_OK;
+  lap(5);
+  rc = is_finish_elimination(S);  // the one wait of an update without relinearization
+  lap(6);
+  return rc;
 }
 
 }  // namespace
@@ -898,6 +1036,7 @@ int lmgpu_isam2_create(const lmgpu_config* cfg, const lmgpu_isam2_params* prm, l
   S->ccolamd = ccolamd;
   S->user = user;
   S->device = cfg->device;
+  S->trace = getenv("LMGPU_ISAM2_TRACE") != nullptr;
   *out = S;
   if (S->device < 0) {
     S->err = "no HIP device bound to this handle; the incremental path has no CPU fallback";
@@ -913,6 +1052,11 @@ int lmgpu_isam2_create(const lmgpu_config* cfg, const lmgpu_isam2_params* prm, l
 
 int lmgpu_isam2_destroy(lmgpu_isam2* S) {
   if (!S) return LMGPU_INVALID;
+  if (S->trace && S->update_count > 0) {
+    static const char* nm[7] = {"new variables + updateDelta", "new factors / relinearization check / linearize", "removeTop + affected factors + variable index",
+                                "constrained COLAMD callback", "symbolic elimination + tables + launches", "marks + clique count", "final wait"};
+    for (int i = 0; i < 7; i++) std::fprintf(stderr, "isam2 update: %-50s %8.1f us per update\n", nm[i], 1e6 * S->t_phase[i] / S->update_count);
+  }
   if (S->device >= 0) {
     (void)hipSetDevice(S->device);
     for (int t = 0; t < kNumVarTypes; t++) {
@@ -929,6 +1073,13 @@ int lmgpu_isam2_destroy(lmgpu_isam2* S) {
                     (void*)S->d_tree_fx, (void*)S->d_tree_sx, (void*)S->d_tree_list})
       if (p) (void)hipFree(p);
     if (S->h_status) (void)hipHostFree(S->h_status);
+    if (S->h_delta) (void)hipHostFree(S->h_delta);
+    if (S->h_stage) (void)hipHostFree(S->h_stage);
+    if (S->d_stage) (void)hipFree(S->d_stage);
+    for (auto& e : S->stage_extra) {
+      (void)hipHostFree(e.first);
+      if (e.second) (void)hipFree(e.second);
+    }
     if (S->stream) (void)hipStreamDestroy(S->stream);
   }
   delete S;
