@@ -18,12 +18,6 @@ namespace lmgpu {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ double readlane_dyn(double v, int src /* wave-uniform */) {
-  const long long b = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), src), hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-
 // ---------------------------------------------------------------- assembly
 // one 64-lane block per own factor: F += [A b]^T [A b]
 __device__ __forceinline__ void assemble_factor_body(const FrontDesc& F, int64_t f_off, int ld, const FrontFac* __restrict__ ffac,

@@ -44,6 +44,12 @@ struct FrontDesc {
   int32_t par_map;   // into cmap[]: this front's update index -> parent column
 };
 
+__device__ __forceinline__ double readlane_dyn(double v, int src /* wave-uniform */) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), src), hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 __device__ __forceinline__ int frexp_exp(double x) {
   int e;
   (void)frexp(x, &e);
@@ -555,110 +561,135 @@ __global__ __launch_bounds__(256) void lds_backsub_kernel(const int32_t* __restr
   if (bad && lane == 0) atomicMin(status, F.id);  // NaN -> IndeterminantLinearSystemException (linearAlgorithms-inst.h:99)
 }
 
-// The same for tree levels that hold fronts with many frontal columns (the narrow upper levels of general sparse graphs): one
-// WORKGROUP per front.  The rows of S are spread over the four waves (16 row reads in flight), R is staged in LDS by all
-// threads while that happens, and wave 0 then solves out of LDS -- no memory round trip is left on the chain of nf unknowns.
-// Dynamic LDS: nfcap * nfcap doubles; a front with nf > nfcap reads R from memory instead (rows prefetched one ahead).
+// ---- back-substitution of an LDS front by one WORKGROUP, the whole [R S d] of the front staged in LDS
+// (tree levels that hold fronts with more than a dozen frontal columns: the upper levels of general sparse graphs)
+//   stage   : a flat, batched copy of the nf x n block -- before anything the front depends on, so that it overlaps the wait for the parent
+//   x_S     : one gather of the separator part of delta (offsets fetched before the wait)
+//   y       : d - S x_S, eight rows per wave and reduction (wave_reduce8 below), everything from LDS
+//   solve   : 64 unknowns at a time by wave 0: lane i carries y_i / R_ii, a step is one v_readlane pair and one fma with the row scaled
+//             to a unit diagonal (coefficients read eight ahead); the rows above a block are folded by all four waves
+// Row by row with a six-shuffle reduction and a divide per unknown (the round-1 form) a front of 30 unknowns took ~10 us after its
+// parent; this form leaves one memory round trip (x_S) and ~2 us of arithmetic on the parent-to-child chain.
+// Dynamic LDS: (max over the launch of nf x (n | 1)) + 2 x 144 doubles.
+#define LDSB_TAIL 288
+__device__ __forceinline__ double ldsb_reduce8(double (&s)[8], int lane, int& slot) {  // as wave_reduce_slots<8> (kernels_dense.hpp)
+  int o = 32;
+  slot = 0;
+#pragma unroll
+  for (int half = 4; half >= 1; half >>= 1, o >>= 1) {
+    const bool hi = (lane & o) != 0;
+#pragma unroll
+    for (int k = 0; k < half; k++) {
+      const double keep = hi ? s[k + half] : s[k], send = hi ? s[k] : s[k + half];
+      s[k] = keep + __shfl_xor(send, o);
+    }
+    slot += hi ? half : 0;
+  }
+#pragma unroll
+  for (; o >= 1; o >>= 1) s[0] += __shfl_xor(s[0], o);
+  return s[0];
+}
+__device__ __forceinline__ void ldsb_stage(const FrontDesc& F, const double* __restrict__ pool, double* Ls, int tid) {
+  const int n = F.n, nf = F.nf, nl = n | 1, total = nf * n;
+  const double* RSd = pool + F.rsd_off;
+  for (int base = 0; base < total; base += 8 * 256) {
+    double v[8];
+    int at[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int idx = min(base + u * 256 + tid, total - 1), i = idx / n, j = idx - i * n;
+      v[u] = RSd[(size_t)i * F.ld_rsd + j];  // unconditional on a clamped index: a batch of loads, not a chain
+      at[u] = i * nl + j;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (base + u * 256 + tid < total) Ls[at[u]] = v[u];
+  }
+}
+// after the front's ancestors are visible.  so = this thread's separator offset (sxoff[sx_begin + min(tid, ns - 1)]), fo = its frontal
+// offset (fxoff[fx_begin + min(tid, nf - 1)]); Ls staged by ldsb_stage (a barrier follows here).  Returns with delta stored by wave 0..3.
+__device__ __forceinline__ void ldsb_solve(const FrontDesc& F, double* Ls, int so, int fo, double* __restrict__ delta, int* __restrict__ status) {
+  const int n = F.n, nf = F.nf, ns = n - nf - 1, nl = n | 1;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  double* xsl = Ls + (size_t)nf * nl;  // [144]
+  double* y = xsl + 144;               // [144]
+  const double xv = delta[so];
+  if (tid < ns) xsl[tid] = xv;
+  __syncthreads();  // Ls and x_S in LDS
+  for (int i0 = w; i0 < nf; i0 += 32) {  // rows i0, i0 + 4, ..., i0 + 28
+    double acc[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const int i = min(i0 + 4 * r, nf - 1);
+      double a = 0.0;
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const int j = lane + 64 * q;
+        if (j < ns) a += Ls[i * nl + nf + j] * xsl[j];
+      }
+      acc[r] = a;
+    }
+    int slot;
+    const double tot = ldsb_reduce8(acc, lane, slot);
+    const int i = i0 + 4 * slot;
+    if ((lane & 7) == 0 && i < nf) y[i] = Ls[i * nl + n - 1] - tot;
+  }
+  __syncthreads();
+  bool bad = false;
+  const int nblk = (nf + 63) >> 6;
+  for (int b = nblk - 1; b >= 0; b--) {
+    const int r0 = 64 * b, nb = min(64, nf - r0);
+    if (w == 0) {
+      const int il = r0 + min(lane, nb - 1);
+      const double rd = (lane < nb) ? 1.0 / Ls[il * nl + il] : 1.0;
+      double yi = (lane < nb) ? y[il] * rd : 0.0;
+      for (int k0 = 63; k0 >= 0; k0 -= 8) {
+        double cf[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int k = k0 - u;
+          const double c = Ls[il * nl + r0 + min(k, nb - 1)];
+          cf[u] = (lane < k && k < nb) ? c * rd : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) yi = fma(-cf[u], readlane_dyn(yi, k0 - u), yi);
+      }
+      if (lane < nb) {
+        y[r0 + lane] = yi;
+        if (yi != yi) bad = true;
+      }
+    }
+    if (b == 0) break;
+    __syncthreads();  // x of this block in y
+    for (int i0 = w; i0 < r0; i0 += 32) {
+      double acc[8];
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+        const int i = min(i0 + 4 * r, r0 - 1);
+        acc[r] = (lane < nb) ? Ls[i * nl + r0 + lane] * y[r0 + lane] : 0.0;
+      }
+      int slot;
+      const double tot = ldsb_reduce8(acc, lane, slot);
+      const int i = i0 + 4 * slot;
+      if ((lane & 7) == 0 && i < r0) y[i] -= tot;
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (tid < nf) delta[fo] = y[tid];
+  if (bad && lane == 0) atomicMin(status, F.id);  // NaN -> IndeterminantLinearSystemException (linearAlgorithms-inst.h:99)
+}
+
 __global__ __launch_bounds__(256) void lds_backsub_wide_kernel(const int32_t* __restrict__ list, int nlist, const FrontDesc* __restrict__ fronts,
                                                                 const int32_t* __restrict__ fxoff, const int32_t* __restrict__ sxoff,
                                                                 const double* __restrict__ pool, double* __restrict__ delta,
-                                                                int* __restrict__ status, int nfcap) {
-  extern __shared__ double Rl[];  // [nf][nf] row-major, upper part used
-  __shared__ double rhs[160];
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x;
+                                                                int* __restrict__ status) {
+  extern __shared__ double Ls[];
   const FrontDesc F = fronts[list[blockIdx.x]];
-  const int n = F.n, nf = F.nf, ns = n - nf - 1;
-  const double* RSd = pool + F.rsd_off;
-  const bool staged = nf <= nfcap;
-  double xs[3];
-#pragma unroll
-  for (int q = 0; q < 3; q++) {
-    const int j = lane + 64 * q;
-    xs[q] = (j < ns) ? delta[sxoff[F.sx_begin + j]] : 0.0;
-  }
-  if (staged)
-    for (int idx = tid; idx < nf * nf; idx += 256) {
-      const int i = idx / nf, j = idx - i * nf;
-      if (j >= i) Rl[idx] = RSd[(size_t)i * F.ld_rsd + j];
-    }
-  for (int i0 = 4 * w; i0 < nf; i0 += 16) {
-    double acc[4] = {0.0, 0.0, 0.0, 0.0}, dv[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int i = i0 + u;
-      if (i < nf) {
-        const double* row = RSd + (size_t)i * F.ld_rsd;
-#pragma unroll
-        for (int q = 0; q < 3; q++) {
-          const int j = lane + 64 * q;
-          if (j < ns) acc[u] += row[nf + j] * xs[q];
-        }
-        dv[u] = row[n - 1];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) acc[u] += __shfl_xor(acc[u], o);
-      if (lane == 0 && i0 + u < nf) rhs[i0 + u] = dv[u] - acc[u];
-    }
-  }
-  __syncthreads();
-  if (w != 0) return;
-  bool bad = false;
-  if (staged) {
-    for (int i = nf - 1; i >= 0; i--) {
-      double sum = 0.0;
-#pragma unroll
-      for (int q = 0; q < 3; q++) {
-        const int j = i + 1 + lane + 64 * q;
-        if (j < nf) sum += Rl[i * nf + j] * rhs[j];
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-      const double x = (rhs[i] - sum) / Rl[i * nf + i];
-      if (x != x) bad = true;
-      __builtin_amdgcn_wave_barrier();
-      if (lane == 0) rhs[i] = x;
-      __builtin_amdgcn_wave_barrier();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-  } else {
-    double rc[3], dc = 1.0;
-    auto load_row = [&](int i, double(&r)[3], double& d) {
-      const double* row = RSd + (size_t)max(i, 0) * F.ld_rsd;
-#pragma unroll
-      for (int q = 0; q < 3; q++) {
-        const int j = i + 1 + lane + 64 * q;
-        r[q] = (i >= 0 && j < nf) ? row[j] : 0.0;
-      }
-      d = (i >= 0) ? row[max(i, 0)] : 1.0;
-    };
-    load_row(nf - 1, rc, dc);
-    for (int i = nf - 1; i >= 0; i--) {
-      double rn[3], dn;
-      load_row(i - 1, rn, dn);
-      double sum = 0.0;
-#pragma unroll
-      for (int q = 0; q < 3; q++) {
-        const int j = i + 1 + lane + 64 * q;
-        if (j < nf) sum += rc[q] * rhs[j];
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-      const double x = (rhs[i] - sum) / dc;
-      if (x != x) bad = true;
-      __builtin_amdgcn_wave_barrier();
-      if (lane == 0) rhs[i] = x;
-      __builtin_amdgcn_wave_barrier();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int q = 0; q < 3; q++) rc[q] = rn[q];
-      dc = dn;
-    }
-  }
-  for (int i = lane; i < nf; i += 64) delta[fxoff[F.fx_begin + i]] = rhs[i];
-  if (bad && lane == 0) atomicMin(status, F.id);
+  const int tid = threadIdx.x, ns = F.n - F.nf - 1;
+  const int so = sxoff[F.sx_begin + max(min(tid, ns - 1), 0)], fo = fxoff[F.fx_begin + min(tid, F.nf - 1)];
+  ldsb_stage(F, pool, Ls, tid);
+  ldsb_solve(F, Ls, ns > 0 ? so : fo, fo, delta, status);
 }
 
 // The LDS fronts of SEVERAL consecutive tree levels in one launch (deep clique trees: a level's launch does ~10-25 us of work
@@ -666,31 +697,25 @@ __global__ __launch_bounds__(256) void lds_backsub_wide_kernel(const int32_t* __
 // list[seg_end - 1 - t], so parents hold lower tickets than their children.  A front whose parent lies in the same segment
 // waits for the parent's flag (pos_of[parent] inside the segment; a parent outside was finished by an earlier launch);
 // the parent raised it after its delta was stored, and it had waited for its own parent, so every ancestor is visible.
-// Same per-front work as lds_backsub_wide_kernel.  Hand-off and progress as in kernels_potrf.hpp (release / acquire at
-// agent scope, tickets drawn at workgroup start, bounded spin).
+// Same per-front work as lds_backsub_wide_kernel, the staging of [R S d] under the wait.  Hand-off and progress as in
+// kernels_potrf.hpp (release / acquire at agent scope, tickets drawn at workgroup start, bounded spin).
 __global__ __launch_bounds__(256) void lds_backsub_merged_kernel(const int32_t* __restrict__ list, int seg_begin, int seg_end,
                                                                   const FrontDesc* __restrict__ fronts, const int32_t* __restrict__ fxoff,
                                                                   const int32_t* __restrict__ sxoff, const double* __restrict__ pool,
                                                                   double* __restrict__ delta, int* __restrict__ status,
                                                                   const int32_t* __restrict__ parent_of, const int32_t* __restrict__ pos_of,
-                                                                  unsigned int* __restrict__ done, unsigned int* __restrict__ ticket, int nfcap) {
-  extern __shared__ double Rl[];
-  __shared__ double rhs[160];
+                                                                  unsigned int* __restrict__ done, unsigned int* __restrict__ ticket) {
+  extern __shared__ double Ls[];
   __shared__ int s_ticket, s_ok;
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
   if (tid == 0) s_ticket = (int)atomicAdd(ticket, 1u);
   __syncthreads();
   const int fi = list[seg_end - 1 - s_ticket];
   const FrontDesc F = fronts[fi];
-  const int n = F.n, nf = F.nf, ns = n - nf - 1;
-  const double* RSd = pool + F.rsd_off;
-  const bool staged = nf <= nfcap;
-  // R does not depend on the parent: stage it before waiting
-  if (staged)
-    for (int idx = tid; idx < nf * nf; idx += 256) {
-      const int i = idx / nf, j = idx - i * nf;
-      if (j >= i) Rl[idx] = RSd[(size_t)i * F.ld_rsd + j];
-    }
+  const int ns = F.n - F.nf - 1;
+  const int so = sxoff[F.sx_begin + max(min(tid, ns - 1), 0)], fo = fxoff[F.fx_begin + min(tid, F.nf - 1)];
+  // [R S d] does not depend on the parent: stage it before waiting
+  ldsb_stage(F, pool, Ls, tid);
   if (tid == 0) {
     int ok = 1;
     const int par = parent_of[fi];
@@ -712,63 +737,16 @@ __global__ __launch_bounds__(256) void lds_backsub_merged_kernel(const int32_t* 
   }
   __syncthreads();
   if (!s_ok && tid == 0) atomicExch(status + 1, 1 + F.id);  // never expected: spin bound hit (a fault, reported apart from pivot failures)
-  double xs[3];
-#pragma unroll
-  for (int q = 0; q < 3; q++) {
-    const int j = lane + 64 * q;
-    xs[q] = (j < ns) ? delta[sxoff[F.sx_begin + j]] : 0.0;
-  }
-  for (int i0 = 4 * w; i0 < nf; i0 += 16) {
-    double acc[4] = {0.0, 0.0, 0.0, 0.0}, dv[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int i = i0 + u;
-      if (i < nf) {
-        const double* row = RSd + (size_t)i * F.ld_rsd;
-#pragma unroll
-        for (int q = 0; q < 3; q++) {
-          const int j = lane + 64 * q;
-          if (j < ns) acc[u] += row[nf + j] * xs[q];
-        }
-        dv[u] = row[n - 1];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) acc[u] += __shfl_xor(acc[u], o);
-      if (lane == 0 && i0 + u < nf) rhs[i0 + u] = dv[u] - acc[u];
-    }
-  }
-  __syncthreads();
-  if (w != 0) return;
-  bool bad = false;
-  for (int i = nf - 1; i >= 0; i--) {
-    double sum = 0.0;
-#pragma unroll
-    for (int q = 0; q < 3; q++) {
-      const int j = i + 1 + lane + 64 * q;
-      if (j < nf) sum += (staged ? Rl[i * nf + j] : RSd[(size_t)i * F.ld_rsd + j]) * rhs[j];
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    const double x = (rhs[i] - sum) / (staged ? Rl[i * nf + i] : RSd[(size_t)i * F.ld_rsd + i]);
-    if (x != x) bad = true;
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) rhs[i] = x;
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  }
-  for (int i = lane; i < nf; i += 64) delta[fxoff[F.fx_begin + i]] = rhs[i];
-  if (bad && lane == 0) atomicMin(status, F.id);
-  // publish: every lane's stores of delta have been performed, then one release + flag
+  ldsb_solve(F, Ls, ns > 0 ? so : fo, fo, delta, status);
+  // publish: every wave's stores of delta have been performed, then one release + flag
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-  if (lane == 0) {
+  __syncthreads();
+  if (tid == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(&done[fi], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  (void)lane;
 }
 
 }  // namespace lmgpu

@@ -78,6 +78,7 @@ struct LevelWork {
   // LDS fronts of this level, grouped by LDS-size bin: [bin_begin[b], bin_begin[b+1]) inside the level's list
   int list_begin = 0, list_count = 0;
   int lds_nf_max = 0;  // largest frontal dimension among the level's LDS fronts
+  int lds_rsd_max = 0; // largest nf x (n | 1) among them: doubles of LDS the workgroup-per-front back-substitution stages
   int bin_begin[16] = {0};
   int bin_srows[16] = {0};  // rows of the front kept in LDS for the bin's launch
   int bin_jcap[16] = {0};   // doubles of Jacobian staging per workgroup (largest front of the bin, 96 .. LDSF_JCAP)
@@ -944,10 +945,9 @@ int do_backsub(lmgpu_handle* h) {
   int seg_hi = -1, seg_lo = -1;  // levels of the pending segment (top, bottom)
   auto run_level = [&](const LevelWork& L) {  // one level as a launch of its own
     if (L.lds_nf_max > 12) {
-      const int nfcap = std::min(L.lds_nf_max, 96);
-      hipLaunchKernelGGL(lds_backsub_wide_kernel, dim3(L.list_count), dim3(256), (size_t)nfcap * nfcap * sizeof(double), s,
+      hipLaunchKernelGGL(lds_backsub_wide_kernel, dim3(L.list_count), dim3(256), (size_t)(L.lds_rsd_max + LDSB_TAIL) * sizeof(double), s,
                          (const int32_t*)(h->d_lists + L.list_begin), L.list_count, (const FrontDesc*)h->d_fronts, (const int32_t*)h->d_fxoff,
-                         (const int32_t*)h->d_sxoff, (const double*)h->pool, h->delta, h->d_status, nfcap);
+                         (const int32_t*)h->d_sxoff, (const double*)h->pool, h->delta, h->d_status);
     } else {
       hipLaunchKernelGGL(lds_backsub_kernel, dim3((L.list_count + 3) / 4), dim3(256), 0, s, (const int32_t*)(h->d_lists + L.list_begin),
                          L.list_count, (const FrontDesc*)h->d_fronts, (const int32_t*)h->d_fxoff, (const int32_t*)h->d_sxoff,
@@ -961,12 +961,11 @@ int do_backsub(lmgpu_handle* h) {
       run_level(h->levels[seg_hi]);
     } else {
       const int b = h->levels[seg_lo].list_begin, e = h->levels[seg_hi].list_begin + h->levels[seg_hi].list_count;
-      int nfmax = 0;
-      for (int l = seg_lo; l <= seg_hi; l++) nfmax = std::max(nfmax, h->levels[l].lds_nf_max);
-      const int nfcap = std::min(nfmax, 96);
-      hipLaunchKernelGGL(lds_backsub_merged_kernel, dim3(e - b), dim3(256), (size_t)nfcap * nfcap * sizeof(double), s, (const int32_t*)h->d_lists, b, e,
+      int rsdmax = 0;
+      for (int l = seg_lo; l <= seg_hi; l++) rsdmax = std::max(rsdmax, h->levels[l].lds_rsd_max);
+      hipLaunchKernelGGL(lds_backsub_merged_kernel, dim3(e - b), dim3(256), (size_t)(rsdmax + LDSB_TAIL) * sizeof(double), s, (const int32_t*)h->d_lists, b, e,
                          (const FrontDesc*)h->d_fronts, (const int32_t*)h->d_fxoff, (const int32_t*)h->d_sxoff, (const double*)h->pool, h->delta,
-                         h->d_status, (const int32_t*)h->d_bs_parent, (const int32_t*)h->d_bs_pos, h->d_bs_done, h->d_bs_done + NFR + seg_hi, nfcap);
+                         h->d_status, (const int32_t*)h->d_bs_parent, (const int32_t*)h->d_bs_pos, h->d_bs_done, h->d_bs_done + NFR + seg_hi);
     }
     h->kt.end(kt, s);
     seg_hi = seg_lo = -1;
@@ -1522,8 +1521,8 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
     HIPCHECK(hipFuncSetAttribute((const void*)lds_front_kernel<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra + 64));
     HIPCHECK(hipFuncSetAttribute((const void*)lds_front_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra + 64));
     HIPCHECK(hipFuncSetAttribute((const void*)syrk_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSyrkLds));
-    HIPCHECK(hipFuncSetAttribute((const void*)lds_backsub_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 96 * 8));
-    HIPCHECK(hipFuncSetAttribute((const void*)lds_backsub_merged_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 96 * 8));
+    HIPCHECK(hipFuncSetAttribute((const void*)lds_backsub_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (kLdsLimitN * kLdsLimitN + LDSB_TAIL) * 8));
+    HIPCHECK(hipFuncSetAttribute((const void*)lds_backsub_merged_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (kLdsLimitN * kLdsLimitN + LDSB_TAIL) * 8));
     HIPCHECK(hipFuncSetAttribute((const void*)diag_potrf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
     HIPCHECK(hipFuncSetAttribute((const void*)panel_dataflow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PDF_LDS_BYTES));
     HIPCHECK(hipFuncSetAttribute((const void*)step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STEP_LDS_BYTES));
@@ -2018,6 +2017,7 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
       for (int fi : byLevelBin[l][b]) {
         lists.push_back(fi);
         L.lds_nf_max = std::max(L.lds_nf_max, (int)P.fronts[fi].nf);
+        L.lds_rsd_max = std::max(L.lds_rsd_max, (int)P.fronts[fi].nf * ((int)P.fronts[fi].n | 1));
       }
       c += (int)byLevelBin[l][b].size();
     }
