@@ -590,12 +590,26 @@ __global__ __launch_bounds__(256) void linear_error_kernel(const FacDesc* __rest
     J = dst + lane * pitch;
   }
   if (!valid) return;
+  // the factor's columns of delta once, all loads in flight together (they sat inside the row loop: one dependent load per product)
+  double dx[12];
+  const bool small = cols <= 12;
+#pragma unroll
+  for (int c = 0; c < 12; c++) {
+    const int at = (c < d.d0) ? d.x0 + c : ((c < cols) ? d.x1 + (c - d.d0) : d.x0);
+    dx[c] = delta[at];
+  }
   double s0 = 0, s1 = 0;
   for (int r = 0; r < m; r++) {
     const double bb = J[cols * m + r];
     double e = -bb;
-    for (int c = 0; c < d.d0; c++) e += J[c * m + r] * delta[d.x0 + c];
-    for (int c = 0; c < d.d1; c++) e += J[(d.d0 + c) * m + r] * delta[d.x1 + c];
+    if (small) {
+#pragma unroll
+      for (int c = 0; c < 12; c++)
+        if (c < cols) e += J[c * m + r] * dx[c];
+    } else {
+      for (int c = 0; c < d.d0; c++) e += J[c * m + r] * delta[d.x0 + c];
+      for (int c = 0; c < d.d1; c++) e += J[(d.d0 + c) * m + r] * delta[d.x1 + c];
+    }
     s0 += bb * bb;
     s1 += e * e;
   }

@@ -250,10 +250,11 @@ __global__ __launch_bounds__(MAXT) void lds_front_kernel(const int32_t* __restri
   __syncthreads();
   LDSF_STAMP(0);  // descriptors, clear, own factors
   // ---- children: extend-add of their update matrices (row i of U contiguous: lanes along j).  The child's column map is staged
-  //      in LDS once and eight rows per wave are fetched before the first is added -- row by row, every row was a memory round
+  //      in LDS once and four (sixteen-wave form: eight) rows per wave are fetched before the first is added -- row by row, every row was a memory round
   //      trip of its own (25-35 of them per child of ~100 columns: most of the 27-60 us an upper-level front took).  The loads are
   //      unconditional on clamped addresses (the lower triangle and the padding of U are finite: the pool is cleared once).
-  {
+  if constexpr (!GATHER) {  // (gather leaves have no children; keeping the block out of that instantiation keeps its 41 VGPRs)
+    constexpr int EAB = (MAXT > 256) ? 8 : 4;  // rows per wave in flight (eight cost the four-wave form occupancy on leaf levels)
     int* cm = (int*)Jb;  // jcap >= 96 doubles: room for 139 ints (a child's update matrix is at most as wide as this front)
     for (int k = 0; k < F.child_count; k++) {
       const ChildRef c = childs[F.child_begin + k];
@@ -264,14 +265,14 @@ __global__ __launch_bounds__(MAXT) void lds_front_kernel(const int32_t* __restri
       int gjs[3];
 #pragma unroll
       for (int q = 0; q < 3; q++) gjs[q] = cm[min(lane + 64 * q, c.m - 1)];
-      for (int i0 = wave; i0 < c.m; i0 += 8 * nw) {
-        double u[8][3];
+      for (int i0 = wave; i0 < c.m; i0 += EAB * nw) {
+        double u[EAB][3];
 #pragma unroll
-        for (int r = 0; r < 8; r++)
+        for (int r = 0; r < EAB; r++)
 #pragma unroll
           for (int q = 0; q < 3; q++) u[r][q] = U[(size_t)min(i0 + r * nw, c.m - 1) * c.ld + min(lane + 64 * q, c.m - 1)];
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
+        for (int r = 0; r < EAB; r++) {
           const int i = i0 + r * nw;
           if (i < c.m) {
             const int gi = cm[i];
@@ -477,11 +478,19 @@ __global__ __launch_bounds__(MAXT) void lds_front_kernel(const int32_t* __restri
 #endif
 }
 
-// back-substitution for LDS-class fronts: x_F = R^-1 (d - S x_S).  One wave per front, 4 fronts per block.
+// back-substitution for LDS-class fronts with at most LDSB_SMALL_NF frontal scalars (leaves and the levels just above them: the host
+// takes the workgroup-per-front kernels below for anything larger): x_F = R^-1 (d - S x_S).  One wave per front, 4 fronts per block.
+// Built around the number of dependent memory round trips (each ~2-3 us, and BAL's 100 000 leaf fronts are ~12 rounds of resident
+// waves): list -> descriptor -> {separator offsets, frontal offsets, the rows of S and d four at a time, lane i's row of R} in ONE
+// batch of unconditional loads on clamped indices -> x_S -> arithmetic -> store.  The nf x nf solve is a register chain: lane i
+// carries y_i / R_ii and its own row of R scaled to a unit diagonal; a step is one v_readlane pair and one fma.
+// (Round 1's form gathered x_S through two dependent loads under a branch per 64 columns and solved row by row with a six-shuffle
+//  reduction, an LDS round trip and a divide per unknown.)
+#define LDSB_SMALL_NF 12
 __global__ __launch_bounds__(256) void lds_backsub_kernel(const int32_t* __restrict__ list, int nlist, const FrontDesc* __restrict__ fronts,
                                                            const int32_t* __restrict__ fxoff, const int32_t* __restrict__ sxoff,
                                                            const double* __restrict__ pool, double* __restrict__ delta, int* __restrict__ status) {
-  __shared__ double rhs_s[4][160];
+  __shared__ double rhs_s[4][16];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int li = blockIdx.x * 4 + w;
   if (li >= nlist) return;
@@ -489,76 +498,75 @@ __global__ __launch_bounds__(256) void lds_backsub_kernel(const int32_t* __restr
   const int n = F.n, nf = F.nf, ns = n - nf - 1;
   const double* RSd = pool + F.rsd_off;
   double* rhs = rhs_s[w];
-  // One wave per front; every memory round trip that does not depend on the solve is taken off its chain: the separator part of
-  // delta is gathered once into registers, the rows of S are read four at a time, and the next row of R is in flight while the
-  // current unknown is computed (a version that walked R serially in one lane cost 40-90 us per narrow tree level).
-  // rhs_i = d_i - sum_j S_ij x_S[j]          (n <= 139  =>  at most three 64-column chunks per row)
-  double xs[3];
+  const int fo = fxoff[F.fx_begin + min(lane, nf - 1)];
+  int so[3] = {0, 0, 0};
+  if (ns > 0) {  // (wave-uniform; a front without separator is a root)
 #pragma unroll
-  for (int q = 0; q < 3; q++) {
-    const int j = lane + 64 * q;
-    xs[q] = (j < ns) ? delta[sxoff[F.sx_begin + j]] : 0.0;
+    for (int q = 0; q < 3; q++) so[q] = sxoff[F.sx_begin + min(lane + 64 * q, ns - 1)];
   }
+  // lane i's row of R (columns 0 .. LDSB_SMALL_NF - 1, clamped): the coefficients of the register solve
+  double rk[LDSB_SMALL_NF];
+  {
+    const double* row = RSd + (size_t)min(lane, nf - 1) * F.ld_rsd;
+#pragma unroll
+    for (int k = 0; k < LDSB_SMALL_NF; k++) rk[k] = row[min(k, nf - 1)];
+  }
+  double xs[3] = {0.0, 0.0, 0.0};
+  // rhs_i = d_i - sum_j S_ij x_S[j], four rows at a time          (n <= 139  =>  at most three 64-column chunks per row)
   for (int i0 = 0; i0 < nf; i0 += 4) {
-    double acc[4] = {0.0, 0.0, 0.0, 0.0}, dv[4] = {0.0, 0.0, 0.0, 0.0};
+    double sv[4][3], dv[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-      const int i = i0 + u;
-      if (i < nf) {
-        const double* row = RSd + (size_t)i * F.ld_rsd;
+      const double* row = RSd + (size_t)min(i0 + u, nf - 1) * F.ld_rsd;
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
-          const int j = lane + 64 * q;
-          if (j < ns) acc[u] += row[nf + j] * xs[q];
-        }
-        dv[u] = row[n - 1];
+      for (int q = 0; q < 3; q++) sv[u][q] = row[nf + max(min(lane + 64 * q, ns - 1), 0)];
+      dv[u] = row[n - 1];
+    }
+    if (i0 == 0 && ns > 0) {  // behind the first batch of rows in program order: both are in flight together
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const double v = delta[so[q]];
+        xs[q] = (lane + 64 * q < ns) ? v : 0.0;
       }
     }
+    double acc[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < 4; u++) acc[u] = sv[u][0] * xs[0] + sv[u][1] * xs[1] + sv[u][2] * xs[2];
+    // four rows reduced together: 2 + 1 + 4 shuffles instead of 24
+    {
+      const bool h5 = (lane & 32) != 0, h4 = (lane & 16) != 0;
+      const double k0 = h5 ? acc[2] : acc[0], s0 = h5 ? acc[0] : acc[2], k1 = h5 ? acc[3] : acc[1], s1 = h5 ? acc[1] : acc[3];
+      const double a0 = k0 + __shfl_xor(s0, 32), a1 = k1 + __shfl_xor(s1, 32);
+      const double kk = h4 ? a1 : a0, ss = h4 ? a0 : a1;
+      double t = kk + __shfl_xor(ss, 16);
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) acc[u] += __shfl_xor(acc[u], o);
-      if (lane == 0 && i0 + u < nf) rhs[i0 + u] = dv[u] - acc[u];
+      for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o);
+      const int slot = (h5 ? 2 : 0) + (h4 ? 1 : 0);
+      // the lane that holds row `slot` also needs that row's d: dv[slot] by selects (dv is indexed statically)
+      const double dsel = h5 ? (h4 ? dv[3] : dv[2]) : (h4 ? dv[1] : dv[0]);
+      if ((lane & 15) == 0 && i0 + slot < nf) rhs[i0 + slot] = dsel - t;
     }
   }
   __builtin_amdgcn_wave_barrier();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  // R x = rhs (upper, backward): lanes along the row, the finished unknowns in LDS
-  bool bad = false;
-  double rc[3], dc = 1.0;
-  auto load_row = [&](int i, double(&r)[3], double& d) {
-    const double* row = RSd + (size_t)max(i, 0) * F.ld_rsd;
+  // R x = rhs in registers
+  double diag = 1.0;
 #pragma unroll
-    for (int q = 0; q < 3; q++) {
-      const int j = i + 1 + lane + 64 * q;
-      r[q] = (i >= 0 && j < nf) ? row[j] : 0.0;
+  for (int k = 0; k < LDSB_SMALL_NF; k++)
+    if (k == lane && k < nf) diag = rk[k];
+  const double rd = 1.0 / diag;
+  double yi = (lane < nf) ? rhs[lane] * rd : 0.0;
+#pragma unroll
+  for (int k = LDSB_SMALL_NF - 1; k >= 1; k--) {
+    if (k < nf) {  // wave-uniform
+      const double c = (lane < k) ? rk[k] * rd : 0.0;
+      yi = fma(-c, readlane_dyn(yi, k), yi);
     }
-    d = (i >= 0) ? row[max(i, 0)] : 1.0;
-  };
-  load_row(nf - 1, rc, dc);
-  for (int i = nf - 1; i >= 0; i--) {
-    double rn[3], dn;
-    load_row(i - 1, rn, dn);
-    double sum = 0.0;
-#pragma unroll
-    for (int q = 0; q < 3; q++) {
-      const int j = i + 1 + lane + 64 * q;
-      if (j < nf) sum += rc[q] * rhs[j];
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    const double x = (rhs[i] - sum) / dc;
-    if (x != x) bad = true;
-    __builtin_amdgcn_wave_barrier();  // every lane has read rhs[i] before it is overwritten
-    if (lane == 0) rhs[i] = x;
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int q = 0; q < 3; q++) rc[q] = rn[q];
-    dc = dn;
   }
-  for (int i = lane; i < nf; i += 64) delta[fxoff[F.fx_begin + i]] = rhs[i];
-  if (bad && lane == 0) atomicMin(status, F.id);  // NaN -> IndeterminantLinearSystemException (linearAlgorithms-inst.h:99)
+  if (lane < nf) {
+    delta[fo] = yi;
+    if (yi != yi) atomicMin(status, F.id);  // NaN -> IndeterminantLinearSystemException (linearAlgorithms-inst.h:99)
+  }
 }
 
 // ---- back-substitution of an LDS front by one WORKGROUP, the whole [R S d] of the front staged in LDS

@@ -944,7 +944,7 @@ int do_backsub(lmgpu_handle* h) {
   }
   int seg_hi = -1, seg_lo = -1;  // levels of the pending segment (top, bottom)
   auto run_level = [&](const LevelWork& L) {  // one level as a launch of its own
-    if (L.lds_nf_max > 12) {
+    if (L.lds_nf_max > LDSB_SMALL_NF) {
       hipLaunchKernelGGL(lds_backsub_wide_kernel, dim3(L.list_count), dim3(256), (size_t)(L.lds_rsd_max + LDSB_TAIL) * sizeof(double), s,
                          (const int32_t*)(h->d_lists + L.list_begin), L.list_count, (const FrontDesc*)h->d_fronts, (const int32_t*)h->d_fxoff,
                          (const int32_t*)h->d_sxoff, (const double*)h->pool, h->delta, h->d_status);
