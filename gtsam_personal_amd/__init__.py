@@ -5,7 +5,7 @@ Only the hot path lives here: csrc/ (HIP kernels + C ABI), the host-side mirror 
 graph / optimizer interface (graph.py, optimizer.py) and the data formats either side of it
 (datasets.py, synthetic.py).  Importing the package does not load the GPU library; constructing a
 LevenbergMarquardtOptimizer does, and fails loudly if liblmgpu.so has not been built."""
-from .graph import (CAM_BUNDLER, POINT3, POSE2, POSE3, C, L, NonlinearFactorGraph, Ordering, P, Values, X, noiseModel, symbol)  # noqa: F401
+from .graph import (CAL3_S2, CAM_BUNDLER, POINT2, POINT3, POSE2, POSE3, C, L, NonlinearFactorGraph, Ordering, P, Values, X, noiseModel, symbol)  # noqa: F401
 from .optimizer import (DoglegOptimizer, DoglegParams, GaussNewtonOptimizer, GaussNewtonParams, LevenbergMarquardtOptimizer,  # noqa: F401
                         LevenbergMarquardtParams, JointMarginal, Marginals)
 from .isam2 import ISAM2, ISAM2GaussNewtonParams, ISAM2Params, ISAM2Result  # noqa: F401

@@ -39,10 +39,10 @@ struct lmgpu_isam2 {
   };
   std::vector<Var> vars;
   std::map<uint64_t, int32_t> vid_of;  // ascending by key = the order of the reference's Values / VectorValues / VariableIndex
-  int type_count[kNumVarTypes] = {0, 0, 0, 0, 0}, type_cap[kNumVarTypes] = {0, 0, 0, 0, 0};
-  double* theta[kNumVarTypes] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  double* est[kNumVarTypes] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  int32_t* d_type_xoff[kNumVarTypes] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int type_count[kNumVarTypes] = {}, type_cap[kNumVarTypes] = {};
+  double* theta[kNumVarTypes] = {};
+  double* est[kNumVarTypes] = {};
+  int32_t* d_type_xoff[kNumVarTypes] = {};
   int ntot = 0, ntot_cap = 0;
   double *delta = nullptr, *ones = nullptr;
   unsigned char *d_replaced = nullptr, *d_changed = nullptr;  // per scalar of delta
@@ -587,7 +587,7 @@ int is_eliminate(lmgpu_isam2* S, const std::vector<IsGF>& gfs, const std::vector
         d.d1 = (int16_t)(f.v[1] >= 0 ? kVarDim[S->vars[f.v[1]].type] : 0);
         d.x0 = S->vars[f.v[0]].xoff;
         d.x1 = f.v[1] >= 0 ? S->vars[f.v[1]].xoff : -1;
-        FrontFac ff;
+        FrontFac ff{};
         ff.fac = (int32_t)fd.size();
         ff.c0 = colof.at(f.v[0]);
         ff.c1 = f.v[1] >= 0 ? colof.at(f.v[1]) : 0;
@@ -718,7 +718,7 @@ int is_update(lmgpu_isam2* S, bool force_relinearize, lmgpu_isam2_result* result
   std::vector<lmgpu_isam2::NewFac> new_facs;
   new_facs.swap(S->new_facs);
   if (!new_vars.empty()) {
-    int add[kNumVarTypes] = {0, 0, 0, 0, 0}, addtot = 0;
+    int add[kNumVarTypes] = {}, addtot = 0;
     for (auto& nv : new_vars) {
       add[nv.type]++;
       addtot += kVarDim[nv.type];
@@ -1113,6 +1113,10 @@ int lmgpu_isam2_add_factors(lmgpu_isam2* S, int32_t factor_type, int32_t n, cons
   if (noise_kind != LMGPU_N_UNIT && noise_kind != LMGPU_N_DIAG && noise_kind != LMGPU_N_GAUSS) return LMGPU_INVALID;
   if (n == 0) return LMGPU_OK;
   if (!keys || !meas || (noise_kind != LMGPU_N_UNIT && !noise)) return LMGPU_INVALID;
+  if (kFactorArity[factor_type] > 2 || factor_type == LMGPU_F_PRIOR_CAL3_S2) {
+    S->err = "the incremental path takes factors of at most two variables (no GeneralSFMFactor2 / Cal3_S2 variables)";
+    return LMGPU_INVALID;
+  }
   const int ar = kFactorArity[factor_type], rows = kFactorRows[factor_type], ml = kFactorMeas[factor_type];
   const int nl = noise_kind == LMGPU_N_DIAG ? rows : (noise_kind == LMGPU_N_GAUSS ? rows * rows : 0);
   for (int i = 0; i < n; i++) {

@@ -26,7 +26,7 @@ __device__ __forceinline__ void assemble_factor_body(const FrontDesc& F, int64_t
   const FacDesc d = fd[ff.fac];
   const double* J = pool + d.joff;
   double* A = pool + f_off;
-  const int n = F.n, m = d.rows, nc = d.d0 + d.d1 + 1;
+  const int n = F.n, m = d.rows, nc = d.d0 + d.d1 + d.d2 + 1;
   const int npair = nc * (nc + 1) / 2;
   for (int pidx = threadIdx.x; pidx < npair; pidx += 64) {
     int p = 0, rem = pidx, rowlen = nc;
@@ -38,8 +38,7 @@ __device__ __forceinline__ void assemble_factor_body(const FrontDesc& F, int64_t
     const int q = p + rem;
     double v = 0;
     for (int r = 0; r < m; r++) v += J[p * m + r] * J[q * m + r];
-    const int gp = (p < d.d0) ? ff.c0 + p : (p < d.d0 + d.d1 ? ff.c1 + (p - d.d0) : n - 1);
-    const int gq = (q < d.d0) ? ff.c0 + q : (q < d.d0 + d.d1 ? ff.c1 + (q - d.d0) : n - 1);
+    const int gp = fac_col(d, ff.c0, ff.c1, ff.c2, p, n), gq = fac_col(d, ff.c0, ff.c1, ff.c2, q, n);
     const int lo = gp < gq ? gp : gq, hi = gp < gq ? gq : gp;
     atomicAdd(&A[(size_t)lo * ld + hi], v);
   }
@@ -115,9 +114,9 @@ __device__ __forceinline__ void assemble_row_body(const FrontDesc& F, int64_t f_
       const FrontFac ff = ffac[-sr.idx - 1];
       const FacDesc d = fd[ff.fac];
       const double* J = pool + d.joff;
-      const int m = d.rows, nc = d.d0 + d.d1 + 1, p = sr.i;
+      const int m = d.rows, nc = d.d0 + d.d1 + d.d2 + 1, p = sr.i;
       for (int q = lane; q < nc; q += 64) {
-        const int gq = (q < d.d0) ? ff.c0 + q : (q < d.d0 + d.d1 ? ff.c1 + (q - d.d0) : F.n - 1);
+        const int gq = fac_col(d, ff.c0, ff.c1, ff.c2, q, F.n);
         if (gq > R || (gq == R && q == p)) {
           double v = 0;
           for (int r = 0; r < m; r++) v += J[p * m + r] * J[q * m + r];

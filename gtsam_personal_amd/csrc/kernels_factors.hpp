@@ -33,7 +33,7 @@ struct BucketDev {
 };
 
 struct ValuesDev {
-  const double* v[5];  // POSE2 [n][3], POSE3 [n][12], POINT3 [n][3], CAM [n][15], POINT2 [n][2]
+  const double* v[6];  // POSE2 [n][3], POSE3 [n][12], POINT3 [n][3], CAM [n][15], POINT2 [n][2], CAL3_S2 [n][5]
 };
 
 // whiten Jl (col-major M x COLS) in place
@@ -456,6 +456,79 @@ __device__ __forceinline__ void eval_projection(const double* m, const double* v
   e[1] = fy * v + v0c - m[1];
 }
 
+template <bool JAC>
+__device__ __forceinline__ void eval_prior_cal3_s2(const double* m, const double* v0, double* e, double* H1) {
+  // PriorFactor<Cal3_S2>: -Local(x, prior) with Cal3_S2::localCoordinates = T2.vector() - vector() (Cal3_S2.h:118-119)
+#pragma unroll
+  for (int i = 0; i < 5; i++) e[i] = -(m[i] - v0[i]);
+  if (JAC) set_identity<5>(H1);
+}
+
+// GeneralSFMFactor2<Cal3_S2> (gtsam/slam/GeneralSFMFactor.h:208-262): one lane per factor, three variables (Pose3, Point3, Cal3_S2).
+// error = PinholeCamera<Cal3_S2>(pose, K).project(point) - z with H1 (2x6), H2 (2x3) as GenericProjectionFactor's (PinholePose chain) and
+// H3 = Cal3_S2::uncalibrate's Dcal = [u 0 v 1 0; 0 v 0 0 1] at the intrinsic point (u, v) (gtsam/geometry/Cal3_S2.cpp:44-50).  A point
+// behind the camera: the reference catches the CheiralityException, zeroes H1..H3 and returns a ZERO error (:251-260).
+// [A1 A2 A3 b] is written column-major, 2 x 15.
+template <bool JAC>
+__global__ __launch_bounds__(128) void sfm2_factor_kernel(BucketDev b, ValuesDev vals, double* __restrict__ ebuf) {
+  const int fi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (fi >= b.n) return;
+  const int f = b.sel ? b.sel[fi] : fi;
+  constexpr int M = 2, COLS = 15;
+  double m[7], v0[12], v1[3];
+  const double* mp = b.meas + (size_t)f * 2;
+  const double* p0 = vals.v[1] + (size_t)b.vidx[3 * f] * 12;
+  const double* p1 = vals.v[2] + (size_t)b.vidx[3 * f + 1] * 3;
+  const double* p2 = vals.v[5] + (size_t)b.vidx[3 * f + 2] * 5;
+  m[0] = mp[0];
+  m[1] = mp[1];
+#pragma unroll
+  for (int i = 0; i < 5; i++) m[2 + i] = p2[i];
+#pragma unroll
+  for (int i = 0; i < 12; i++) v0[i] = p0[i];
+#pragma unroll
+  for (int i = 0; i < 3; i++) v1[i] = p1[i];
+  double e[2], H1[12], H2[6], H3[10];
+  const D3 d{v1[0] - v0[9], v1[1] - v0[10], v1[2] - v0[11]};
+  const double qz = v0[2] * d.x + v0[5] * d.y + v0[8] * d.z;
+  if (qz <= 0) {
+    e[0] = e[1] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) H1[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) H2[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 10; i++) H3[i] = 0.0;
+  } else {
+    eval_projection<JAC>(m, v0, v1, e, H1, H2);
+    const double dz = 1.0 / qz;
+    const double u = (v0[0] * d.x + v0[3] * d.y + v0[6] * d.z) * dz, v = (v0[1] * d.x + v0[4] * d.y + v0[7] * d.z) * dz;
+    H3[0] = u; H3[1] = 0.0; H3[2] = v; H3[3] = 1.0; H3[4] = 0.0;
+    H3[5] = 0.0; H3[6] = v; H3[7] = 0.0; H3[8] = 0.0; H3[9] = 1.0;
+  }
+  const double* nz = b.noise ? b.noise + (size_t)f * (b.noise_kind == 2 ? M : M * M) : nullptr;
+  if (JAC) {
+    double Jl[M * COLS];
+#pragma unroll
+    for (int r = 0; r < M; r++) {
+#pragma unroll
+      for (int c = 0; c < 6; c++) Jl[c * M + r] = H1[r * 6 + c];
+#pragma unroll
+      for (int c = 0; c < 3; c++) Jl[(6 + c) * M + r] = H2[r * 3 + c];
+#pragma unroll
+      for (int c = 0; c < 5; c++) Jl[(9 + c) * M + r] = H3[r * 5 + c];
+      Jl[14 * M + r] = -e[r];
+    }
+    whiten_block<M, COLS>(Jl, b.noise_kind, nz);
+    if (b.robust) robust_reweight<M, COLS>(Jl, b.robust, b.rk);
+    double* out = b.J + (size_t)f * (M * COLS);
+#pragma unroll
+    for (int i = 0; i < M * COLS; i++) out[i] = Jl[i];
+  } else {
+    ebuf[b.epos[f]] = whitened_half_sq<M>(e, b.noise_kind, nz, b.robust, b.rk);
+  }
+}
+
 // Generic bucket kernel.  TYPE selects the evaluator; M rows, D0/D1 tangent dims, S0/S1 stored doubles, T0/T1 value types.
 template <int TYPE, int M, int D0, int D1, int ML, int T0, int S0, int T1, int S1, bool JAC>
 __global__ __launch_bounds__(128) void generic_factor_kernel(BucketDev b, ValuesDev vals, double* __restrict__ ebuf) {
@@ -485,6 +558,7 @@ __global__ __launch_bounds__(128) void generic_factor_kernel(BucketDev b, Values
   if (TYPE == 6) eval_prior_cam<JAC>(m, v0, e, H1);
   if (TYPE == 7) eval_projection<JAC>(m, v0, v1, e, H1, H2);
   if (TYPE == 9) eval_bearing_range_2d<JAC>(m, v0, v1, e, H1, H2);
+  if (TYPE == 11) eval_prior_cal3_s2<JAC>(m, v0, e, H1);
   if (TYPE == 8) {
     // GenericProjectionFactor with body_P_sensor (ProjectionFactor.h:142-149): camera pose = pose o sensor; H1 = H1_cam Ad(sensor^-1)
     const P3 sensor = load_pose3(m + 7);
@@ -546,8 +620,13 @@ __global__ __launch_bounds__(128) void generic_factor_kernel(BucketDev b, Values
 struct FacDesc {
   int64_t joff;   // offset of the factor's [A|b] in the pool
   int32_t x0, x1; // scalar offsets of its variables in delta (x1 = -1 unary)
-  int16_t rows, d0, d1, pad;
+  int16_t rows, d0, d1, d2;  // d2 > 0: a third variable (GeneralSFMFactor2), its offset in x2
+  int32_t x2, pad;
 };
+// local column q of the factor's [A1 A2 A3 b] -> offset of that scalar in delta (q < d0 + d1 + d2)
+__device__ __forceinline__ int fac_xoff(const FacDesc& d, int q) {
+  return q < d.d0 ? d.x0 + q : (q < d.d0 + d.d1 ? d.x1 + (q - d.d0) : d.x2 + (q - d.d0 - d.d1));
+}
 
 // One lane per factor.  When the 64 factors of a wave are of one shape and stored back to back (always, inside a bucket),
 // their [A b] blocks are first copied to LDS as ONE contiguous, coalesced stream (a lane-per-factor read would touch 64
@@ -560,7 +639,7 @@ __global__ __launch_bounds__(256) void linear_error_kernel(const FacDesc* __rest
   const int f = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool valid = f < nfac;
   const FacDesc d = fd[valid ? f : nfac - 1];
-  const int m = d.rows, cols = d.d0 + d.d1, sz = m * (cols + 1);
+  const int m = d.rows, cols = d.d0 + d.d1 + d.d2, sz = m * (cols + 1);
   const long long j0 = __shfl((long long)d.joff, 0, 64);
   const int sz0 = __shfl(sz, 0, 64);
   const int cnt = min(64, nfac - (blockIdx.x * 256 + wave * 64));  // valid lanes of this wave (<= 0: none)
@@ -591,24 +670,20 @@ __global__ __launch_bounds__(256) void linear_error_kernel(const FacDesc* __rest
   }
   if (!valid) return;
   // the factor's columns of delta once, all loads in flight together (they sat inside the row loop: one dependent load per product)
-  double dx[12];
-  const bool small = cols <= 12;
+  double dx[14];
+  const bool small = cols <= 14;
 #pragma unroll
-  for (int c = 0; c < 12; c++) {
-    const int at = (c < d.d0) ? d.x0 + c : ((c < cols) ? d.x1 + (c - d.d0) : d.x0);
-    dx[c] = delta[at];
-  }
+  for (int c = 0; c < 14; c++) dx[c] = delta[(c < cols) ? fac_xoff(d, c) : d.x0];
   double s0 = 0, s1 = 0;
   for (int r = 0; r < m; r++) {
     const double bb = J[cols * m + r];
     double e = -bb;
     if (small) {
 #pragma unroll
-      for (int c = 0; c < 12; c++)
+      for (int c = 0; c < 14; c++)
         if (c < cols) e += J[c * m + r] * dx[c];
     } else {
-      for (int c = 0; c < d.d0; c++) e += J[c * m + r] * delta[d.x0 + c];
-      for (int c = 0; c < d.d1; c++) e += J[(d.d0 + c) * m + r] * delta[d.x1 + c];
+      for (int c = 0; c < cols; c++) e += J[c * m + r] * delta[fac_xoff(d, c)];
     }
     s0 += bb * bb;
     s1 += e * e;
@@ -629,7 +704,7 @@ __global__ __launch_bounds__(256) void hessian_diag_kernel(int ntot, const int32
   double s = 0;
   for (int k = vi_ptr[v]; k < vi_ptr[v + 1]; k++) {
     const FacDesc d = fd[vi_fac[k]];
-    const int col = (vi_pos[k] == 0) ? c : d.d0 + c;
+    const int col = (vi_pos[k] == 0) ? c : (vi_pos[k] == 1 ? d.d0 + c : d.d0 + d.d1 + c);
     const double* J = pool + d.joff + (size_t)col * d.rows;
     for (int r = 0; r < d.rows; r++) s += J[r] * J[r];
   }
@@ -688,6 +763,11 @@ __global__ __launch_bounds__(256) void retract_kernel(int type, int n, const dou
     const double* v = cur + (size_t)i * 2;
     double* o = out + (size_t)i * 2;
     o[0] = v[0] + d[0]; o[1] = v[1] + d[1];
+  } else if (type == 5) {  // Cal3_S2::retract gtsam/geometry/Cal3_S2.h:113-115: vector() + d
+    const double* v = cur + (size_t)i * 5;
+    double* o = out + (size_t)i * 5;
+#pragma unroll
+    for (int k = 0; k < 5; k++) o[k] = v[k] + d[k];
   } else {  // PinholeCamera::retract gtsam/geometry/PinholeCamera.h:197-203
     const double* v = cur + (size_t)i * 15;
     double* o = out + (size_t)i * 15;

@@ -19,8 +19,8 @@
 namespace lmgpu {
 
 struct FrontFac {
-  int32_t fac;     // index into FacDesc[]
-  int32_t c0, c1;  // column offsets of the factor's variables inside the front
+  int32_t fac;         // index into FacDesc[]
+  int32_t c0, c1, c2;  // column offsets of the factor's variables inside the front (c2: third variable of a ternary factor)
 };
 struct ChildRef {
   int64_t u_off;      // pool offset of the child's update matrix
@@ -60,9 +60,15 @@ __device__ __forceinline__ int frexp_exp(double x) {
 struct LFac {
   int64_t joff;
   int32_t c0, c1;
-  int16_t rows, d0, d1, pad;
-  int32_t off, sz;
+  int16_t rows, d0, d1, d2;
+  int32_t c2;
+  int16_t off, sz;  // staging offset (< LDSF_JCAP) and size (rows x columns, < 100) in doubles
 };
+// local column q of a factor's [A1 A2 A3 b] (q <= d0 + d1 + d2; the last one is b) -> column of the front with n columns
+template <typename FD>
+__device__ __forceinline__ int fac_col(const FD& d, int c0, int c1, int c2, int q, int n) {
+  return q < d.d0 ? c0 + q : (q < d.d0 + d.d1 ? c1 + (q - d.d0) : (q < d.d0 + d.d1 + d.d2 ? c2 + (q - d.d0 - d.d1) : n - 1));
+}
 
 // grid: one block per front in `list`; dynamic LDS = srows*nmax (+8) doubles (the front) + LDSF_JCAP doubles (staged
 // Jacobians) + LDSF_MAXB staged factor descriptors + 4 ints.  Lanes run along the contiguous (column) index of the
@@ -157,12 +163,13 @@ __global__ __launch_bounds__(MAXT) void lds_front_kernel(const int32_t* __restri
       l.joff = d.joff;
       l.c0 = ff.c0;
       l.c1 = ff.c1;
+      l.c2 = ff.c2;
       l.rows = d.rows;
       l.d0 = d.d0;
       l.d1 = d.d1;
-      l.pad = 0;
+      l.d2 = d.d2;
       l.off = 0;
-      l.sz = d.rows * (d.d0 + d.d1 + 1);
+      l.sz = (int16_t)(d.rows * (d.d0 + d.d1 + d.d2 + 1));
       LF[b] = l;
     }
     __syncthreads();
@@ -205,8 +212,8 @@ __global__ __launch_bounds__(MAXT) void lds_front_kernel(const int32_t* __restri
     for (int b = 0; b < B; b++) {
       const LFac d = LF[b];
       const double* J = Jb + d.off;
-      const int m = d.rows, nc = d.d0 + d.d1 + 1;
-      if (gather) {
+      const int m = d.rows, nc = d.d0 + d.d1 + d.d2 + 1;
+      if (gather) {  // (gather leaves only carry factors of at most two variables: the host checks)
         // only the frontal rows are kept: pairs (p, q) with p a FRONTAL column of this factor and q any column (q frontal too:
         // once, gq >= gp), all of them in one pass of the workgroup (BAL: 3 x 13); the (b, b) corner by one lane
         const bool f0 = d.c0 < nf, f1 = d.d1 > 0 && d.c1 < nf;
@@ -231,11 +238,11 @@ __global__ __launch_bounds__(MAXT) void lds_front_kernel(const int32_t* __restri
       }
       // thread (p = tid / 16 + k nt/16, q = p + tid % 16 + 16 l): every pair p <= q exactly once, no two threads on one entry
       for (int p = tid >> 4; p < nc; p += (nt >> 4)) {
-        const int gp = (p < d.d0) ? d.c0 + p : (p < d.d0 + d.d1 ? d.c1 + (p - d.d0) : n - 1);
+        const int gp = fac_col(d, d.c0, d.c1, d.c2, p, n);
         for (int q = p + (tid & 15); q < nc; q += 16) {
           double v = 0;
           for (int r = 0; r < m; r++) v += J[p * m + r] * J[q * m + r];
-          const int gq = (q < d.d0) ? d.c0 + q : (q < d.d0 + d.d1 ? d.c1 + (q - d.d0) : n - 1);
+          const int gq = fac_col(d, d.c0, d.c1, d.c2, q, n);
           const int lo = gp < gq ? gp : gq, hi = gp < gq ? gq : gp;
           if (!gather || lo < nf)
             S[lo * n + hi] += v;

@@ -234,10 +234,10 @@ struct lmgpu_handle {
   unsigned int* bs_flags = nullptr;
   double* pool = nullptr;
   size_t pool_doubles = 0;
-  double* vals[2][kNumVarTypes] = {{nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr}};
-  double* saved[kNumVarTypes] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  double* vals[2][kNumVarTypes] = {};
+  double* saved[kNumVarTypes] = {};
   int cur = 0;
-  int32_t* type_xoff[kNumVarTypes] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int32_t* type_xoff[kNumVarTypes] = {};
   double *delta = nullptr, *dampw = nullptr, *hdiag = nullptr, *ebuf0 = nullptr, *ebuf1 = nullptr, *partial = nullptr, *dscal = nullptr,
          *ywork = nullptr;
   int* d_status = nullptr;
@@ -415,6 +415,12 @@ void launch_factors(lmgpu_handle* h, int which) {
         break;
       case LMGPU_F_BEARING_RANGE_2D:
         hipLaunchKernelGGL((generic_factor_kernel<9, 2, 3, 2, 2, 0, 3, 4, 2, JAC>), dim3(g128), dim3(128), 0, s, d, vals, h->ebuf0);
+        break;
+      case LMGPU_F_SFM2:
+        hipLaunchKernelGGL(sfm2_factor_kernel<JAC>, dim3(g128), dim3(128), 0, s, d, vals, h->ebuf0);
+        break;
+      case LMGPU_F_PRIOR_CAL3_S2:
+        hipLaunchKernelGGL((generic_factor_kernel<11, 5, 5, 0, 5, 5, 5, -1, 0, JAC>), dim3(g128), dim3(128), 0, s, d, vals, h->ebuf0);
         break;
     }
   }
@@ -1612,12 +1618,16 @@ int lmgpu_add_factor_bucket_robust(lmgpu_handle* h, int32_t type, int32_t n, con
         h->err = "factor references unknown slot";
         return LMGPU_INVALID;
       }
-      const int want = (k == 0) ? kFactorVar0[type] : kFactorVar1[type];
+      const int want = factor_var_type(type, k);
       if (h->plan.types[s] != want) {
         h->err = "factor/variable type mismatch";
         return LMGPU_INVALID;
       }
     }
+  if (robust_kind != LMGPU_ROBUST_NONE && ar > 2) {
+    h->err = "robust noise models are not wired for three-variable factors";
+    return LMGPU_INVALID;
+  }
   Bucket b;
   b.type = type;
   b.n = n;
@@ -1630,7 +1640,7 @@ int lmgpu_add_factor_bucket_robust(lmgpu_handle* h, int32_t type, int32_t n, con
   const int nl = noise_kind == LMGPU_N_DIAG ? rows : (noise_kind == LMGPU_N_GAUSS ? rows * rows : 0);
   if (nl) b.noise.assign(noise, noise + (size_t)n * nl);
   int cols = 1;
-  for (int k = 0; k < ar; k++) cols += kVarDim[(k == 0) ? kFactorVar0[type] : kFactorVar1[type]];
+  for (int k = 0; k < ar; k++) cols += kVarDim[factor_var_type(type, k)];
   b.rows = rows;
   b.cols = cols;
   const int bi = (int)h->buckets.size();
@@ -1638,8 +1648,7 @@ int lmgpu_add_factor_bucket_robust(lmgpu_handle* h, int32_t type, int32_t n, con
     FactorRef f;
     f.bucket = bi;
     f.idx = i;
-    f.slots[0] = var_slots[i * ar];
-    f.slots[1] = ar > 1 ? var_slots[i * ar + 1] : -1;
+    for (int k = 0; k < kMaxArity; k++) f.slots[k] = k < ar ? var_slots[i * ar + k] : -1;
     f.graph_index = graph_index[i];
     h->plan.factors.push_back(f);
   }
@@ -1722,6 +1731,8 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
     d.d1 = (int16_t)(f.slots[1] >= 0 ? P.dims[f.slots[1]] : 0);
     d.x0 = P.xoff[f.slots[0]];
     d.x1 = f.slots[1] >= 0 ? P.xoff[f.slots[1]] : -1;
+    d.d2 = (int16_t)(f.slots[2] >= 0 ? P.dims[f.slots[2]] : 0);
+    d.x2 = f.slots[2] >= 0 ? P.xoff[f.slots[2]] : -1;
     fd[h->fac_local[i]] = d;
   }
   struct GPairTmp {
@@ -1771,7 +1782,12 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
       const bool direct = fr.parent >= 0 && P.fronts[fr.parent].cls == 1;
       if (direct && (h->scatter_atomics || fr.children.empty())) {
         F.u_off = -1;
-        if (fr.children.empty() && !h->scatter_atomics) {
+        bool binary_only = true;  // the Schur gather reads factors of at most two variables
+        for (int32_t f : fr.factors) binary_only = binary_only && P.factors[f].slots[2] < 0;
+        if (fr.children.empty() && !h->scatter_atomics && !binary_only) {  // such a leaf writes its update matrix like any other child
+          F.u_off = off;
+          off += (int64_t)F.ld_u * F.ld_u;
+        } else if (fr.children.empty() && !h->scatter_atomics) {
           F.par_ld = -1;
           F.u_off = off;  // gather leaves also keep [S d] transposed ((n - nf) x nf: every variable's block contiguous)
           off += (int64_t)F.ld_u * fr.nf;
@@ -1805,6 +1821,7 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
       ff.fac = h->fac_local[f];
       ff.c0 = colof[P.factors[f].slots[0]];
       ff.c1 = P.factors[f].slots[1] >= 0 ? colof[P.factors[f].slots[1]] : 0;
+      ff.c2 = P.factors[f].slots[2] >= 0 ? colof[P.factors[f].slots[2]] : 0;
       ffac.push_back(ff);
     }
     F.fac_count = (int)ffac.size() - F.fac_begin;
@@ -1874,9 +1891,9 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
       for (int k = 0; k < F.fac_count; k++) {
         const FrontFac& ff = ffac[F.fac_begin + k];
         const FacDesc& d = fd[ff.fac];
-        const int nc = d.d0 + d.d1 + 1;
+        const int nc = d.d0 + d.d1 + d.d2 + 1;
         for (int p = 0; p < nc; p++) {
-          const int gp = (p < d.d0) ? ff.c0 + p : (p < d.d0 + d.d1 ? ff.c1 + (p - d.d0) : fr.n - 1);
+          const int gp = (p < d.d0) ? ff.c0 + p : (p < d.d0 + d.d1 ? ff.c1 + (p - d.d0) : (p < d.d0 + d.d1 + d.d2 ? ff.c2 + (p - d.d0 - d.d1) : fr.n - 1));
           rows[gp].push_back(RowSrc{-(F.fac_begin + k) - 1, p});
         }
       }
@@ -2010,7 +2027,7 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
       int jc = 96;
       for (int fi : byLevelBin[l][b]) {
         int tot = 0;
-        for (int32_t f : P.fronts[fi].factors) tot += fd[h->fac_local[f]].rows * (fd[h->fac_local[f]].d0 + fd[h->fac_local[f]].d1 + 1);
+        for (int32_t f : P.fronts[fi].factors) tot += fd[h->fac_local[f]].rows * (fd[h->fac_local[f]].d0 + fd[h->fac_local[f]].d1 + fd[h->fac_local[f]].d2 + 1);
         jc = std::max(jc, std::min(tot, LDSF_JCAP));
       }
       L.bin_jcap[b] = (jc + 7) & ~7;
@@ -2069,12 +2086,13 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
             lf[k].joff = d.joff;
             lf[k].c0 = ff.c0;
             lf[k].c1 = ff.c1;
+            lf[k].c2 = ff.c2;
             lf[k].rows = d.rows;
             lf[k].d0 = d.d0;
             lf[k].d1 = d.d1;
-            lf[k].pad = 0;
-            lf[k].off = o;
-            lf[k].sz = d.rows * (d.d0 + d.d1 + 1);
+            lf[k].d2 = d.d2;
+            lf[k].off = (int16_t)o;
+            lf[k].sz = (int16_t)(d.rows * (d.d0 + d.d1 + d.d2 + 1));
             if (k > 0 && lf[k].joff != lf[0].joff + o) contig = false;
             o += lf[k].sz;
           }
@@ -2232,8 +2250,8 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
     for (int i = 0; i < NFAC; i++) {
       const int l = h->fac_local[i];
       if (l < 0 || l >= h->n_counted) continue;
-      vi[P.factors[i].slots[0]].push_back({l, 0});
-      if (P.factors[i].slots[1] >= 0) vi[P.factors[i].slots[1]].push_back({l, 1});
+      for (int k = 0; k < kMaxArity; k++)
+        if (P.factors[i].slots[k] >= 0) vi[P.factors[i].slots[k]].push_back({l, (int8_t)k});
     }
     for (int s = 0; s < P.n_vars; s++) {
       vi_ptr[s] = (int32_t)vi_fac.size();

@@ -201,10 +201,11 @@ std::string Plan::build(int32_t lds_limit_n) {
   std::vector<std::vector<int32_t>> fvars(m);
   for (int32_t i = 0; i < m; i++) {
     const FactorRef& f = factors[i];
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < kMaxArity; k++) {
       if (f.slots[k] < 0) continue;
       if (f.slots[k] >= n) return "factor references unknown slot";
-      if (k == 1 && f.slots[1] == f.slots[0]) return "factor with repeated variable";
+      for (int q = 0; q < k; q++)
+        if (f.slots[q] == f.slots[k]) return "factor with repeated variable";
       fvars[i].push_back(f.slots[k]);
     }
   }

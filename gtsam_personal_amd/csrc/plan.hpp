@@ -9,20 +9,23 @@
 
 namespace lmgpu {
 
-static const int kNumVarTypes = 5;
-static const int kVarDim[5] = {3, 6, 3, 9, 2};
-static const int kVarStore[5] = {3, 12, 3, 15, 2};
-static const int kFactorArity[10] = {2, 2, 2, 1, 1, 1, 1, 2, 2, 2};
-static const int kFactorRows[10] = {2, 3, 6, 3, 6, 3, 9, 2, 2, 2};
-static const int kFactorMeas[10] = {2, 3, 12, 3, 12, 3, 15, 7, 19, 2};
+static const int kNumVarTypes = 6;
+static const int kVarDim[6] = {3, 6, 3, 9, 2, 5};
+static const int kVarStore[6] = {3, 12, 3, 15, 2, 5};
+static const int kMaxArity = 3;
+static const int kFactorArity[12] = {2, 2, 2, 1, 1, 1, 1, 2, 2, 2, 3, 1};
+static const int kFactorRows[12] = {2, 3, 6, 3, 6, 3, 9, 2, 2, 2, 2, 5};
+static const int kFactorMeas[12] = {2, 3, 12, 3, 12, 3, 15, 7, 19, 2, 2, 5};
 // variable types each factor type expects (for validation)
-static const int kFactorVar0[10] = {3, 0, 1, 0, 1, 2, 3, 1, 1, 0};
-static const int kFactorVar1[10] = {2, 0, 1, -1, -1, -1, -1, 2, 2, 4};
+static const int kFactorVar0[12] = {3, 0, 1, 0, 1, 2, 3, 1, 1, 0, 1, 5};
+static const int kFactorVar1[12] = {2, 0, 1, -1, -1, -1, -1, 2, 2, 4, 2, -1};
+static const int kFactorVar2[12] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 5, -1};
+inline int factor_var_type(int ftype, int k) { return k == 0 ? kFactorVar0[ftype] : (k == 1 ? kFactorVar1[ftype] : kFactorVar2[ftype]); }
 
 struct FactorRef {
   int32_t bucket;   // bucket index
   int32_t idx;      // index inside the bucket
-  int32_t slots[2]; // variable slots (slots[1] = -1 for unary)
+  int32_t slots[3]; // variable slots (-1 beyond the factor's arity)
   int32_t graph_index;
 };
 
@@ -65,7 +68,7 @@ struct Plan {
   std::vector<int32_t> xoff;    // scalar offset of slot in packed tangent vectors (size n_vars+1)
   std::vector<int32_t> voff;    // double offset of slot in packed values (size n_vars+1)
   std::vector<int32_t> tidx;    // index of the slot within its type's device array
-  int32_t type_count[kNumVarTypes] = {0, 0, 0, 0, 0};
+  int32_t type_count[kNumVarTypes] = {};
   std::vector<FactorRef> factors;  // sorted by graph_index
   // outputs
   std::vector<int32_t> etree_parent;  // per slot, -1 for roots

@@ -15,18 +15,18 @@ from __future__ import annotations
 import numpy as np
 
 # ---- enums shared with include/lmgpu.h
-POSE2, POSE3, POINT3, CAM_BUNDLER, POINT2 = 0, 1, 2, 3, 4
-VAR_DIM = (3, 6, 3, 9, 2)
-VAR_STORE = (3, 12, 3, 17, 2)      # host packed value (camera keeps u0, v0)
-VAR_STORE_DEV = (3, 12, 3, 15, 2)  # C-ABI packed value
+POSE2, POSE3, POINT3, CAM_BUNDLER, POINT2, CAL3_S2 = 0, 1, 2, 3, 4, 5
+VAR_DIM = (3, 6, 3, 9, 2, 5)
+VAR_STORE = (3, 12, 3, 17, 2, 5)      # host packed value (camera keeps u0, v0)
+VAR_STORE_DEV = (3, 12, 3, 15, 2, 5)  # C-ABI packed value
 
 (F_SFM, F_BETWEEN_POSE2, F_BETWEEN_POSE3, F_PRIOR_POSE2, F_PRIOR_POSE3, F_PRIOR_POINT3, F_PRIOR_CAM, F_PROJECTION, F_PROJECTION_BPS,
- F_BEARING_RANGE_2D) = range(10)
-FACTOR_ARITY = (2, 2, 2, 1, 1, 1, 1, 2, 2, 2)
-FACTOR_ROWS = (2, 3, 6, 3, 6, 3, 9, 2, 2, 2)
-FACTOR_MEAS = (2, 3, 12, 3, 12, 3, 17, 7, 19, 2)  # host measurement doubles (PRIOR_CAM carries u0, v0)
+ F_BEARING_RANGE_2D, F_SFM2, F_PRIOR_CAL3_S2) = range(12)
+FACTOR_ARITY = (2, 2, 2, 1, 1, 1, 1, 2, 2, 2, 3, 1)
+FACTOR_ROWS = (2, 3, 6, 3, 6, 3, 9, 2, 2, 2, 2, 5)
+FACTOR_MEAS = (2, 3, 12, 3, 12, 3, 17, 7, 19, 2, 2, 5)  # host measurement doubles (PRIOR_CAM carries u0, v0)
 FACTOR_VARS = ((CAM_BUNDLER, POINT3), (POSE2, POSE2), (POSE3, POSE3), (POSE2,), (POSE3,), (POINT3,), (CAM_BUNDLER,), (POSE3, POINT3), (POSE3, POINT3),
-               (POSE2, POINT2))
+               (POSE2, POINT2), (POSE3, POINT3, CAL3_S2), (CAL3_S2,))
 
 N_UNIT, N_ISO, N_DIAG, N_GAUSS = 0, 1, 2, 3
 
@@ -218,6 +218,10 @@ class Values:
     def insert_point2(self, key, p):
         self.insert(key, POINT2, p)
 
+    def insert_cal3_s2(self, key, fx, fy, s, u0, v0):
+        """Cal3_S2 as a variable (self-calibration, examples/SelfCalibrationExample.cpp:55-56)"""
+        self.insert(key, CAL3_S2, [fx, fy, s, u0, v0])
+
     def insert_camera(self, key, R, t, f, k1, k2, u0=0.0, v0=0.0):
         self.insert(key, CAM_BUNDLER, camera_pack(R, t, f, k1, k2, u0, v0))
 
@@ -348,6 +352,14 @@ class NonlinearFactorGraph:
 
     def add_PriorFactorCamera(self, key, packed17, model):
         self._add(F_PRIOR_CAM, [[key]], packed17, model)
+
+    def add_PriorFactorCal3_S2(self, key, K, model):
+        """PriorFactor<Cal3_S2>; K = (fx, fy, s, u0, v0)"""
+        self._add(F_PRIOR_CAL3_S2, [[key]], K, model)
+
+    def add_GeneralSFMFactor2(self, measured, model, poseKey, landmarkKey, calibKey):
+        """GeneralSFMFactor2<Cal3_S2>(measured, model, poseKey, landmarkKey, calibKey)  (gtsam/slam/GeneralSFMFactor.h:236-237)"""
+        self._add(F_SFM2, [[poseKey, landmarkKey, calibKey]], measured, model)
 
     def add_GenericProjectionFactor(self, measured, model, poseKey, pointKey, K, body_P_sensor=None):
         """GenericProjectionFactor<Pose3, Point3, Cal3_S2>; K = (fx, fy, s, u0, v0); body_P_sensor = (R 3x3, t 3) or None

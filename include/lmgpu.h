@@ -43,8 +43,17 @@ enum lmgpu_status {
  *               The constant principal point (u0, v0) of Cal3Bundler is folded into the measurement by the host
  *               (z' = z - (u0, v0)); Cal3Bundler::retract keeps it constant (gtsam/geometry/Cal3Bundler.h:134-136).
  *   POINT2      dim 2  store 2                           planar landmark (gtsam/geometry/Point2.h), vector retract
+ *   CAL3_S2     dim 5  store 5   (fx, fy, s, u0, v0)     Cal3_S2 as a VARIABLE (gtsam/geometry/Cal3_S2.h:106-119: vector retract / local)
  */
-enum lmgpu_var_type { LMGPU_POSE2 = 0, LMGPU_POSE3 = 1, LMGPU_POINT3 = 2, LMGPU_CAM_BUNDLER = 3, LMGPU_POINT2 = 4, LMGPU_NUM_VAR_TYPES = 5 };
+enum lmgpu_var_type {
+  LMGPU_POSE2 = 0,
+  LMGPU_POSE3 = 1,
+  LMGPU_POINT3 = 2,
+  LMGPU_CAM_BUNDLER = 3,
+  LMGPU_POINT2 = 4,
+  LMGPU_CAL3_S2 = 5,
+  LMGPU_NUM_VAR_TYPES = 6
+};
 
 /* Factor types ("buckets" are keyed by (factor type, noise kind) = fixed block shape).
  *   type             arity rows  measurement doubles
@@ -61,6 +70,11 @@ enum lmgpu_var_type { LMGPU_POSE2 = 0, LMGPU_POSE3 = 1, LMGPU_POINT3 = 2, LMGPU_
  *   BEARING_RANGE_2D 2     2     2   (bearing angle, range)    BearingRangeFactor<Pose2,Point2>  gtsam/sam/BearingRangeFactor.h:33-77:
  *                                                              error = (wrap(bearing - measured), range - measured) with Pose2::bearing /
  *                                                              Pose2::range and their Jacobians, gtsam/geometry/Pose2.cpp:283-330
+ *   SFM2             3     2     2   z                         GeneralSFMFactor2<Cal3_S2> (Pose3, Point3, Cal3_S2)  gtsam/slam/GeneralSFMFactor.h:208-262:
+ *                                                              PinholeCamera<Cal3_S2>(pose, K).project(point, H1, H2, H3) - z; a point behind
+ *                                                              the camera gives zero error and zero Jacobians (:251-260)
+ *   PRIOR_CAL3_S2    1     5     5   (fx, fy, s, u0, v0)       PriorFactor<Cal3_S2>
+ * Keys of a factor: `arity` per factor, in the reference's key order.  The incremental path (lmgpu_isam2_*) takes factors of arity <= 2.
  */
 enum lmgpu_factor_type {
   LMGPU_F_SFM = 0,
@@ -73,7 +87,9 @@ enum lmgpu_factor_type {
   LMGPU_F_PROJECTION = 7,
   LMGPU_F_PROJECTION_BPS = 8,
   LMGPU_F_BEARING_RANGE_2D = 9,
-  LMGPU_NUM_FACTOR_TYPES = 10
+  LMGPU_F_SFM2 = 10,
+  LMGPU_F_PRIOR_CAL3_S2 = 11,
+  LMGPU_NUM_FACTOR_TYPES = 12
 };
 
 /* Noise models (gtsam/linear/NoiseModel.cpp).  Per-factor noise data, `rows` = factor rows:

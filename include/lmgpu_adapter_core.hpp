@@ -29,15 +29,16 @@
 namespace lmgpu_adapter {
 
 // ---- shape tables of include/lmgpu.h (variable / factor / noise enums)
-inline int varDim(int32_t t) { static const int d[LMGPU_NUM_VAR_TYPES] = {3, 6, 3, 9, 2}; return d[t]; }
-inline int varStore(int32_t t) { static const int s[LMGPU_NUM_VAR_TYPES] = {3, 12, 3, 15, 2}; return s[t]; }
-inline int factorArity(int32_t f) { static const int a[LMGPU_NUM_FACTOR_TYPES] = {2, 2, 2, 1, 1, 1, 1, 2, 2, 2}; return a[f]; }
-inline int factorRows(int32_t f) { static const int r[LMGPU_NUM_FACTOR_TYPES] = {2, 3, 6, 3, 6, 3, 9, 2, 2, 2}; return r[f]; }
-inline int factorMeas(int32_t f) { static const int m[LMGPU_NUM_FACTOR_TYPES] = {2, 3, 12, 3, 12, 3, 15, 7, 19, 2}; return m[f]; }
+inline int varDim(int32_t t) { static const int d[LMGPU_NUM_VAR_TYPES] = {3, 6, 3, 9, 2, 5}; return d[t]; }
+inline int varStore(int32_t t) { static const int s[LMGPU_NUM_VAR_TYPES] = {3, 12, 3, 15, 2, 5}; return s[t]; }
+inline int factorArity(int32_t f) { static const int a[LMGPU_NUM_FACTOR_TYPES] = {2, 2, 2, 1, 1, 1, 1, 2, 2, 2, 3, 1}; return a[f]; }
+inline int factorRows(int32_t f) { static const int r[LMGPU_NUM_FACTOR_TYPES] = {2, 3, 6, 3, 6, 3, 9, 2, 2, 2, 2, 5}; return r[f]; }
+inline int factorMeas(int32_t f) { static const int m[LMGPU_NUM_FACTOR_TYPES] = {2, 3, 12, 3, 12, 3, 15, 7, 19, 2, 2, 5}; return m[f]; }
 inline int32_t factorVarType(int32_t f, int i) {
-  static const int32_t v[LMGPU_NUM_FACTOR_TYPES][2] = {{LMGPU_CAM_BUNDLER, LMGPU_POINT3}, {LMGPU_POSE2, LMGPU_POSE2}, {LMGPU_POSE3, LMGPU_POSE3},
-                                                       {LMGPU_POSE2, -1}, {LMGPU_POSE3, -1}, {LMGPU_POINT3, -1}, {LMGPU_CAM_BUNDLER, -1},
-                                                       {LMGPU_POSE3, LMGPU_POINT3}, {LMGPU_POSE3, LMGPU_POINT3}, {LMGPU_POSE2, LMGPU_POINT2}};
+  static const int32_t v[LMGPU_NUM_FACTOR_TYPES][3] = {{LMGPU_CAM_BUNDLER, LMGPU_POINT3, -1}, {LMGPU_POSE2, LMGPU_POSE2, -1}, {LMGPU_POSE3, LMGPU_POSE3, -1},
+                                                       {LMGPU_POSE2, -1, -1}, {LMGPU_POSE3, -1, -1}, {LMGPU_POINT3, -1, -1}, {LMGPU_CAM_BUNDLER, -1, -1},
+                                                       {LMGPU_POSE3, LMGPU_POINT3, -1}, {LMGPU_POSE3, LMGPU_POINT3, -1}, {LMGPU_POSE2, LMGPU_POINT2, -1},
+                                                       {LMGPU_POSE3, LMGPU_POINT3, LMGPU_CAL3_S2}, {LMGPU_CAL3_S2, -1, -1}};
   return v[f][i];
 }
 inline int noiseDoubles(int32_t kind, int rows) { return kind == LMGPU_N_UNIT ? 0 : (kind == LMGPU_N_DIAG ? rows : rows * rows); }

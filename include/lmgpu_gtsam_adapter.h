@@ -72,6 +72,7 @@ inline int32_t variableType(const Value& v) {  // gtsam/base/GenericValue.h
   if (dynamic_cast<const GenericValue<Point3>*>(&v)) return LMGPU_POINT3;
   if (dynamic_cast<const GenericValue<Camera>*>(&v)) return LMGPU_CAM_BUNDLER;
   if (dynamic_cast<const GenericValue<Point2>*>(&v)) return LMGPU_POINT2;
+  if (dynamic_cast<const GenericValue<Cal3_S2>*>(&v)) return LMGPU_CAL3_S2;  // self-calibration: the calibration is a variable
   throw std::invalid_argument("lmgpu adapter: unsupported variable type");
 }
 
@@ -162,6 +163,13 @@ inline bool extractFactor(const NonlinearFactor::shared_ptr& f, const Values& in
     } else {
       *type = LMGPU_F_PROJECTION;
     }
+  } else if (auto s2 = std::dynamic_pointer_cast<GeneralSFMFactor2<Cal3_S2>>(f)) {  // gtsam/slam/GeneralSFMFactor.h:208-262 (keys: pose, point, K)
+    *type = LMGPU_F_SFM2;
+    *m = {s2->measured().x(), s2->measured().y()};
+  } else if (auto pk = std::dynamic_pointer_cast<PriorFactor<Cal3_S2>>(f)) {  // graph.addPrior(Symbol('K', 0), K, calNoise) SelfCalibrationExample.cpp:83
+    *type = LMGPU_F_PRIOR_CAL3_S2;
+    const Cal3_S2& K = pk->prior();
+    *m = {K.fx(), K.fy(), K.skew(), K.px(), K.py()};
   } else if (auto br = std::dynamic_pointer_cast<BearingRangeFactor<Pose2, Point2>>(f)) {  // gtsam/sam/BearingRangeFactor.h:33-77
     *type = LMGPU_F_BEARING_RANGE_2D;
     *m = {br->measured().bearing().theta(), br->measured().range()};  // ExpressionFactor::measured :82, BearingRange.h:73-76
@@ -208,6 +216,7 @@ class Device {
         case LMGPU_POSE3: packPose3(v.at<Pose3>(k), o); break;
         case LMGPU_POINT3: { const Point3& q = v.at<Point3>(k); o[0] = q.x(); o[1] = q.y(); o[2] = q.z(); break; }
         case LMGPU_POINT2: { const Point2& q = v.at<Point2>(k); o[0] = q.x(); o[1] = q.y(); break; }
+        case LMGPU_CAL3_S2: { const Cal3_S2& q = v.at<Cal3_S2>(k); o[0] = q.fx(); o[1] = q.fy(); o[2] = q.skew(); o[3] = q.px(); o[4] = q.py(); break; }
         default: {
           const Camera& c = v.at<Camera>(k);
           packPose3(c.pose(), o);
@@ -230,6 +239,7 @@ class Device {
         case LMGPU_POSE3: out.insert(k, unpackPose3(q)); break;
         case LMGPU_POINT3: out.insert(k, Point3(q[0], q[1], q[2])); break;
         case LMGPU_POINT2: out.insert(k, Point2(q[0], q[1])); break;
+        case LMGPU_CAL3_S2: out.insert(k, Cal3_S2(q[0], q[1], q[2], q[3], q[4])); break;
         default: {
           const Cal3Bundler& K0 = like.at<Camera>(k).calibration();
           out.insert(k, Camera(unpackPose3(q), Cal3Bundler(q[12], q[13], q[14], K0.px(), K0.py())));
@@ -488,6 +498,7 @@ class GpuISAM2 {
       case LMGPU_POSE3: lmgpu_detail::packPose3(v.at<Pose3>(k), o); break;
       case LMGPU_POINT3: { const Point3& q = v.at<Point3>(k); o[0] = q.x(); o[1] = q.y(); o[2] = q.z(); break; }
       case LMGPU_POINT2: { const Point2& q = v.at<Point2>(k); o[0] = q.x(); o[1] = q.y(); break; }
+        case LMGPU_CAL3_S2: { const Cal3_S2& q = v.at<Cal3_S2>(k); o[0] = q.fx(); o[1] = q.fy(); o[2] = q.skew(); o[3] = q.px(); o[4] = q.py(); break; }
       default: {
         const lmgpu_detail::Camera& c = v.at<lmgpu_detail::Camera>(k);
         lmgpu_detail::packPose3(c.pose(), o);
@@ -513,6 +524,7 @@ class GpuISAM2 {
         case LMGPU_POSE3: out.insert(k, lmgpu_detail::unpackPose3(q)); break;
         case LMGPU_POINT3: out.insert(k, Point3(q[0], q[1], q[2])); break;
         case LMGPU_POINT2: out.insert(k, Point2(q[0], q[1])); break;
+        case LMGPU_CAL3_S2: out.insert(k, Cal3_S2(q[0], q[1], q[2], q[3], q[4])); break;
         default: {
           const Cal3Bundler& K0 = all_.at<lmgpu_detail::Camera>(k).calibration();
           out.insert(k, lmgpu_detail::Camera(lmgpu_detail::unpackPose3(q), Cal3Bundler(q[12], q[13], q[14], K0.px(), K0.py())));

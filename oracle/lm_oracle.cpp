@@ -49,9 +49,9 @@ struct Mat {
   double operator()(int i, int j) const { return a[(size_t)j * r + i]; }
 };
 
-enum VarType { POSE2 = 0, POSE3 = 1, POINT3 = 2, CAM_BUNDLER = 3, POINT2 = 4 };
-static const int kVarDim[5] = {3, 6, 3, 9, 2};
-static const int kVarStore[5] = {3, 12, 3, 17, 2};  // packed value doubles (oracle keeps u0,v0 with the camera)
+enum VarType { POSE2 = 0, POSE3 = 1, POINT3 = 2, CAM_BUNDLER = 3, POINT2 = 4, CAL3_S2 = 5 };
+static const int kVarDim[6] = {3, 6, 3, 9, 2, 5};
+static const int kVarStore[6] = {3, 12, 3, 17, 2, 5};  // packed value doubles (oracle keeps u0,v0 with the camera); CAL3_S2 = (fx, fy, s, u0, v0)
 
 enum FactorType {
   F_SFM = 0,            // GeneralSFMFactor<PinholeCamera<Cal3Bundler>,Point3>  (cam, point), meas 2
@@ -63,11 +63,14 @@ enum FactorType {
   F_PRIOR_CAM = 6,      // PriorFactor<PinholeCamera<Cal3Bundler>>  meas 17
   F_PROJECTION = 7,     // GenericProjectionFactor<Pose3,Point3,Cal3_S2> meas 2 + K(fx,fy,s,u0,v0)
   F_PROJECTION_BPS = 8, // the same with body_P_sensor: meas 2 + K 5 + sensor pose (R row-major 9, t 3)
-  F_BEARING_RANGE_2D = 9  // BearingRangeFactor<Pose2,Point2>  (pose, landmark), meas 2 (bearing angle, range)
+  F_BEARING_RANGE_2D = 9,  // BearingRangeFactor<Pose2,Point2>  (pose, landmark), meas 2 (bearing angle, range)
+  F_SFM2 = 10,             // GeneralSFMFactor2<Cal3_S2>  (pose, point, calibration), meas 2   gtsam/slam/GeneralSFMFactor.h:208-262
+  F_PRIOR_CAL3_S2 = 11     // PriorFactor<Cal3_S2>  meas 5 (fx, fy, s, u0, v0)
 };
-static const int kFactorArity[10] = {2, 2, 2, 1, 1, 1, 1, 2, 2, 2};
-static const int kFactorRows[10] = {2, 3, 6, 3, 6, 3, 9, 2, 2, 2};
-static const int kFactorMeas[10] = {2, 3, 12, 3, 12, 3, 17, 7, 19, 2};
+static const int kNumFactorTypes = 12;
+static const int kFactorArity[12] = {2, 2, 2, 1, 1, 1, 1, 2, 2, 2, 3, 1};
+static const int kFactorRows[12] = {2, 3, 6, 3, 6, 3, 9, 2, 2, 2, 2, 5};
+static const int kFactorMeas[12] = {2, 3, 12, 3, 12, 3, 17, 7, 19, 2, 2, 5};
 
 enum NoiseKind { N_UNIT = 0, N_ISO = 1, N_DIAG = 2, N_GAUSS = 3 };
 
@@ -78,7 +81,7 @@ struct Value {
 
 struct Factor {
   int type;
-  Key keys[2];
+  Key keys[3];
   double meas[19];
   int noise_kind;
   std::vector<double> noise;  // ISO: sigma ; DIAG: sigmas[m] ; GAUSS: R m x m row-major (sqrt information)
@@ -159,6 +162,9 @@ static Value retract(const Value& x, const double* d) {
     case POINT2:
       for (int i = 0; i < 2; i++) r.v[i] = x.v[i] + d[i];
       break;
+    case CAL3_S2:  // Cal3_S2::retract gtsam/geometry/Cal3_S2.h:113-115: Cal3_S2(vector() + d)
+      for (int i = 0; i < 5; i++) r.v[i] = x.v[i] + d[i];
+      break;
     case CAM_BUNDLER: {
       // PinholeCamera::retract gtsam/geometry/PinholeCamera.h:197-203; Cal3Bundler.h:134-136
       store_pose3(pose3_retract(as_pose3(x.v), d), r.v);
@@ -172,9 +178,57 @@ static Value retract(const Value& x, const double* d) {
 }
 
 // ------------------------------------------------------------------ factors: unwhitened error + Jacobians
-// H1, H2: row-major m x dim (nullptr to skip).  Returns error e (size m).
-static void evaluate_error(const Factor& f, const Values& vals, double* e, double* H1, double* H2) {
+// H1, H2, H3: row-major m x dim (nullptr to skip).  Returns error e (size m).
+static void evaluate_error(const Factor& f, const Values& vals, double* e, double* H1, double* H2, double* H3 = nullptr) {
   switch (f.type) {
+    case F_SFM2: {
+      // GeneralSFMFactor2::evaluateError gtsam/slam/GeneralSFMFactor.h:245-262: PinholeCamera<Cal3_S2>(pose, calib).project(point, H1, H2, H3)
+      // - measured; the CheiralityException is caught: zero Jacobians and a ZERO error (:251-260).  PinholeCamera::project
+      // (gtsam/geometry/PinholeCamera.h:228-240 via PinholeBaseK): pn = project2(pose, point), pi = K.uncalibrate(pn, Dcal, Dpi_pn),
+      // Dpose = Dpi_pn * Dpn_pose, Dpoint = Dpi_pn * Dpn_point.  Cal3_S2::uncalibrate gtsam/geometry/Cal3_S2.cpp:44-50:
+      // Dcal = [x 0 y 1 0; 0 y 0 0 1], Dp = [fx s; 0 fy].
+      const Value& po = vals.at(f.keys[0]);
+      const Value& pt = vals.at(f.keys[1]);
+      const Value& kv = vals.at(f.keys[2]);
+      const Pose3 pose = as_pose3(po.v);
+      const double fx = kv.v[0], fy = kv.v[1], s = kv.v[2], u0 = kv.v[3], v0 = kv.v[4];
+      double pn[2], Dpose[12], Dpoint[6];
+      bool ok = pinhole_project2(pose, V3{pt.v[0], pt.v[1], pt.v[2]}, pn, H1 ? Dpose : nullptr, H2 ? Dpoint : nullptr);
+      if (!ok) {
+        if (H1) std::memset(H1, 0, 12 * sizeof(double));
+        if (H2) std::memset(H2, 0, 6 * sizeof(double));
+        if (H3) std::memset(H3, 0, 10 * sizeof(double));
+        e[0] = e[1] = 0.0;
+        return;
+      }
+      if (H1)
+        for (int j = 0; j < 6; j++) {
+          H1[j] = fx * Dpose[j] + s * Dpose[6 + j];
+          H1[6 + j] = fy * Dpose[6 + j];
+        }
+      if (H2)
+        for (int j = 0; j < 3; j++) {
+          H2[j] = fx * Dpoint[j] + s * Dpoint[3 + j];
+          H2[3 + j] = fy * Dpoint[3 + j];
+        }
+      if (H3) {
+        const double D[10] = {pn[0], 0.0, pn[1], 1.0, 0.0, 0.0, pn[1], 0.0, 0.0, 1.0};
+        std::memcpy(H3, D, sizeof(D));
+      }
+      e[0] = fx * pn[0] + s * pn[1] + u0 - f.meas[0];
+      e[1] = fy * pn[1] + v0 - f.meas[1];
+      return;
+    }
+    case F_PRIOR_CAL3_S2: {
+      // PriorFactor::evaluateError gtsam/nonlinear/PriorFactor.h:98-102 with Cal3_S2::localCoordinates (Cal3_S2.h:118-119): -(prior - x), H = I
+      const Value& a = vals.at(f.keys[0]);
+      for (int i = 0; i < 5; i++) e[i] = -(f.meas[i] - a.v[i]);
+      if (H1) {
+        std::memset(H1, 0, 25 * sizeof(double));
+        for (int i = 0; i < 5; i++) H1[6 * i] = 1.0;
+      }
+      return;
+    }
     case F_SFM: {
       // GeneralSFMFactor::evaluateError gtsam/slam/GeneralSFMFactor.h:127-138
       const Value& cam = vals.at(f.keys[0]);
@@ -473,13 +527,15 @@ static GFactor linearize_factor(const Factor& f, const Values& vals) {
     g.dims.push_back(kVarDim[vals.at(f.keys[j]).type]);
     tot += g.dims.back();
   }
-  double e[9], H1[81], H2[54];
-  evaluate_error(f, vals, e, H1, ar > 1 ? H2 : nullptr);
+  double e[9], H1[81], H2[54], H3[10];
+  evaluate_error(f, vals, e, H1, ar > 1 ? H2 : nullptr, ar > 2 ? H3 : nullptr);
   g.Ab = Mat(m, tot + 1);
   for (int i = 0; i < m; i++) {
     for (int j = 0; j < g.dims[0]; j++) g.Ab(i, j) = H1[i * g.dims[0] + j];
     if (ar > 1)
       for (int j = 0; j < g.dims[1]; j++) g.Ab(i, g.dims[0] + j) = H2[i * g.dims[1] + j];
+    if (ar > 2)
+      for (int j = 0; j < g.dims[2]; j++) g.Ab(i, g.dims[0] + g.dims[1] + j) = H3[i * g.dims[2] + j];
     g.Ab(i, tot) = -e[i];
   }
   whiten_rows(f, m, g.Ab.a.data(), tot + 1, m);
@@ -1251,7 +1307,7 @@ void orc_destroy(void* h) { delete (Problem*)h; }
 
 int orc_add_variable(void* h, uint64_t key, int type, const double* value) {
   auto* p = (Problem*)h;
-  if (type < 0 || type > 4) return 2;
+  if (type < 0 || type > 5) return 2;
   Value v;
   v.type = type;
   std::memset(v.v, 0, sizeof(v.v));
@@ -1262,11 +1318,12 @@ int orc_add_variable(void* h, uint64_t key, int type, const double* value) {
 
 int orc_add_factor(void* h, int type, const uint64_t* keys, const double* meas, int noise_kind, const double* noise) {
   auto* p = (Problem*)h;
-  if (type < 0 || type > 9) return 2;
+  if (type < 0 || type >= kNumFactorTypes) return 2;
   Factor f;
   f.type = type;
   f.keys[0] = keys[0];
   f.keys[1] = kFactorArity[type] > 1 ? keys[1] : 0;
+  f.keys[2] = kFactorArity[type] > 2 ? keys[2] : 0;
   std::memset(f.meas, 0, sizeof(f.meas));
   std::memcpy(f.meas, meas, kFactorMeas[type] * sizeof(double));
   f.noise_kind = noise_kind;
@@ -1775,6 +1832,12 @@ int orc_factor_evaluate(void* h, int i, double* e, double* H1, double* H2) {
   evaluate_error(p->factors.at(i), p->values, e, H1, H2);
   return 0;
 }
+// the same for a three-variable factor
+int orc_factor_evaluate3(void* h, int i, double* e, double* H1, double* H2, double* H3) {
+  auto* p = (Problem*)h;
+  evaluate_error(p->factors.at(i), p->values, e, H1, H2, H3);
+  return 0;
+}
 }
 
 // =================================================================== ISAM2 (isam2_oracle.hpp)
@@ -1802,7 +1865,7 @@ void orc_isam2_destroy(void* h) { delete (ISAM2Handle*)h; }
 
 int orc_isam2_add_variable(void* h, uint64_t key, int type, const double* value) {
   auto& S = ((ISAM2Handle*)h)->S;
-  if (type < 0 || type > 4) return 2;
+  if (type < 0 || type > 5) return 2;
   Value v;
   v.type = type;
   std::memset(v.v, 0, sizeof(v.v));
@@ -1813,11 +1876,12 @@ int orc_isam2_add_variable(void* h, uint64_t key, int type, const double* value)
 
 int orc_isam2_add_factor(void* h, int type, const uint64_t* keys, const double* meas, int noise_kind, const double* noise) {
   auto& S = ((ISAM2Handle*)h)->S;
-  if (type < 0 || type > 9) return 2;
+  if (type < 0 || type >= kNumFactorTypes) return 2;
   Factor f;
   f.type = type;
   f.keys[0] = keys[0];
   f.keys[1] = kFactorArity[type] > 1 ? keys[1] : 0;
+  f.keys[2] = kFactorArity[type] > 2 ? keys[2] : 0;
   std::memset(f.meas, 0, sizeof(f.meas));
   std::memcpy(f.meas, meas, kFactorMeas[type] * sizeof(double));
   f.noise_kind = noise_kind;

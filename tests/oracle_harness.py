@@ -88,6 +88,7 @@ def lib():
         L.orc_rot3_expmap.argtypes = [_D, _D]
         L.orc_rot3_logmap.argtypes = [_D, _D]
         L.orc_factor_evaluate.argtypes = [ct.c_void_p, ct.c_int, _D, _D, _D]
+        L.orc_factor_evaluate3.argtypes = [ct.c_void_p, ct.c_int, _D, _D, _D, _D]
         L.orc_set_threads.argtypes = [ct.c_int]
         _lib = L
     return _lib
@@ -134,7 +135,7 @@ class OracleProblem:
             for i, g in enumerate(gi.tolist()):
                 rec[g] = (ftype, keys[i], meas[i], models[i])
         for ftype, keys, meas, model in rec:
-            kk = np.zeros(2, dtype=np.uint64)
+            kk = np.zeros(3, dtype=np.uint64)
             kk[:FACTOR_ARITY[ftype]] = keys
             m = np.ascontiguousarray(meas, dtype=np.float64)
             if model.kind == N_UNIT:
@@ -459,7 +460,7 @@ class OracleISAM2:
                     rec[g] = (ftype, keys[i], meas[i], models[i])
             for ftype, keys, meas, model in rec:
                 assert not getattr(model, "robust_kind", 0)
-                kk = np.zeros(2, dtype=np.uint64)
+                kk = np.zeros(3, dtype=np.uint64)
                 kk[:FACTOR_ARITY[ftype]] = keys
                 m = np.ascontiguousarray(meas, dtype=np.float64)
                 if model.kind == N_UNIT:

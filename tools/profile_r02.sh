@@ -10,11 +10,9 @@ for w in sphere2500 city10000; do for o in colamd metis; do python bench.py --wo
 echo "bench lines done" >> $O/progress.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --steps 10 --no-cpu-baseline --no-peaks > $O/prof.log 2>&1
 echo "kernel trace done" >> $O/progress.txt
-rocprofv3 --pmc FETCH_SIZE WRITE_SIZE --output-format csv -d $O/pmc_fw -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-peaks > $O/pmc_fw.log 2>&1
-echo "pmc fetch/write done" >> $O/progress.txt
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/pmc_sq -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-peaks > $O/pmc_sq.log 2>&1
-echo "pmc sq done" >> $O/progress.txt
-python tools/pmc_summary.py $O/pmc_fw $O/pmc_sq > $O/pmc_summary.json
 find $O/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
-rm -rf $O/prof $O/pmc_fw $O/pmc_sq
+rm -rf $O/prof
+timeout -k 10 300 python tools/bench_isam2.py > $O/bench_isam2.txt 2>> $O/bench_slam.err
+tools/backsolve_bench > $O/backsolve_bench_now.txt 2>&1
+# PMC passes: tools/pmc_r02.sh (one counter group per run)
 head -c 600 $O/bench_c4.json
