@@ -670,17 +670,17 @@ __global__ __launch_bounds__(256) void linear_error_kernel(const FacDesc* __rest
   }
   if (!valid) return;
   // the factor's columns of delta once, all loads in flight together (they sat inside the row loop: one dependent load per product)
-  double dx[14];
-  const bool small = cols <= 14;
+  double dx[12];
+  const bool small = cols <= 12;  // (every two-variable factor; a three-variable one takes the loop below)
 #pragma unroll
-  for (int c = 0; c < 14; c++) dx[c] = delta[(c < cols) ? fac_xoff(d, c) : d.x0];
+  for (int c = 0; c < 12; c++) dx[c] = delta[(c < d.d0) ? d.x0 + c : ((c < cols && small) ? d.x1 + (c - d.d0) : d.x0)];
   double s0 = 0, s1 = 0;
   for (int r = 0; r < m; r++) {
     const double bb = J[cols * m + r];
     double e = -bb;
     if (small) {
 #pragma unroll
-      for (int c = 0; c < 14; c++)
+      for (int c = 0; c < 12; c++)
         if (c < cols) e += J[c * m + r] * dx[c];
     } else {
       for (int c = 0; c < cols; c++) e += J[c * m + r] * delta[fac_xoff(d, c)];
