@@ -113,7 +113,10 @@ struct lmgpu_isam2 {
   FrontDesc* d_tree = nullptr;  // one descriptor per clique slot (wildfire)
   int32_t *d_tree_fx = nullptr, *d_tree_sx = nullptr, *d_tree_list = nullptr;
   std::vector<std::pair<int, int>> tree_levels;  // (begin, count) in d_tree_list per depth
-  size_t tree_cap[4] = {0, 0, 0, 0};
+  size_t tree_cap[5] = {0, 0, 0, 0, 0};
+  unsigned int* d_tree_done = nullptr;  // per clique slot: its wildfire decision is stored (+ one ticket counter behind them)
+  size_t tree_lds = 0;                  // largest nf x (n | 1) of a clique: doubles of LDS the wildfire kernel stages
+  int tree_count = 0;                   // cliques in d_tree_list
   // taps
   std::vector<int32_t> snap;
 };
@@ -322,66 +325,82 @@ __global__ __launch_bounds__(256) void isam2_mark_kernel(const int32_t* __restri
   for (int k = 0; k < d; k++) replaced[xo + k] = 1;
 }
 
-// One workgroup per clique of one tree depth: ISAM2Clique::optimizeWildfireNode (gtsam/nonlinear/ISAM2Clique.cpp:211-234).
+// The whole Bayes tree in ONE launch: ISAM2Clique::optimizeWildfireNode (gtsam/nonlinear/ISAM2Clique.cpp:211-234) per clique, one
+// workgroup each, parent -> child dataflow inside the launch (tickets in breadth-first order: a parent holds a lower ticket than its
+// children; a clique waits for its parent's flag, which the parent raised after its own decision was stored -- and the parent had
+// waited for ITS parent, so every ancestor is visible).
 //   dirty   = the clique was re-eliminated (replaced flag of its first frontal scalar) or a separator scalar changed (isDirty :56-77)
-//   solve   = x_F = R^-1 (d - S x_S)   (fastBackSubstitute -> GaussianConditional::solve)
+//   solve   = x_F = R^-1 (d - S x_S)   (fastBackSubstitute -> GaussianConditional::solve): [R S d] staged in LDS BEFORE the wait for
+//             the parent, the solve as in lds_backsub_merged_kernel (kernels_front.hpp: ldsb_stage / ldsb_solve_core)
 //   keep    = replaced or max |x_F_old - x_F_new| >= threshold (valuesChanged :151-158): write x_F, flag the frontal scalars as changed;
 //             otherwise the old values stay (restoreFromOriginals).   threshold <= 0: every clique is solved (full back-substitution).
-// The parents' flags are complete before a depth is launched (launch order on one stream).
-__global__ __launch_bounds__(256) void isam2_wildfire_kernel(const int32_t* __restrict__ list, int nlist, const lmgpu::FrontDesc* __restrict__ tree,
+// tree[id].child_begin carries the parent clique (-1: a root).  One launch per tree DEPTH (the first form) was ~15 launches per update
+// of a 400-pose graph whatever had changed.
+__global__ __launch_bounds__(256) void isam2_wildfire_kernel(const int32_t* __restrict__ list, const lmgpu::FrontDesc* __restrict__ tree,
                                                               const int32_t* __restrict__ fxoff, const int32_t* __restrict__ sxoff,
                                                               const double* __restrict__ pool, double* __restrict__ delta,
                                                               const unsigned char* __restrict__ replaced, unsigned char* __restrict__ changed,
-                                                              double threshold, int* __restrict__ status) {
-  __shared__ double rhs[160];
-  __shared__ int flag;
-  __shared__ double red[256];
-  const lmgpu::FrontDesc F = tree[list[blockIdx.x]];
-  const int n = F.n, nf = F.nf, ns = n - nf - 1, tid = threadIdx.x;
+                                                              double threshold, int* __restrict__ status, unsigned int* __restrict__ done,
+                                                              unsigned int* __restrict__ ticket) {
+  extern __shared__ double Ls[];
+  __shared__ int s_ticket, s_ok, flag;
+  __shared__ double red[4];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) s_ticket = (int)atomicAdd(ticket, 1u);
+  __syncthreads();
+  const int id = list[s_ticket];
+  const lmgpu::FrontDesc F = tree[id];
+  const int n = F.n, nf = F.nf, ns = n - nf - 1, par = F.child_begin;
+  const int so = ns > 0 ? sxoff[F.sx_begin + min(tid, ns - 1)] : 0, fo = fxoff[F.fx_begin + min(tid, nf - 1)];
   const bool is_replaced = replaced[fxoff[F.fx_begin]] != 0;
-  if (tid == 0) flag = (threshold <= 0.0 || is_replaced) ? 1 : 0;
-  __syncthreads();
-  if (!(threshold <= 0.0 || is_replaced)) {
-    for (int j = tid; j < ns; j += 256)
-      if (changed[sxoff[F.sx_begin + j]]) flag = 1;  // benign race: every writer stores 1
-    __syncthreads();
-  }
-  if (!flag) return;
-  const double* RSd = pool + F.rsd_off;
-  for (int i = tid; i < nf; i += 256) {
-    const double* row = RSd + (size_t)i * F.ld_rsd;
-    double acc = row[n - 1];
-    for (int j = 0; j < ns; j++) acc -= row[nf + j] * delta[sxoff[F.sx_begin + j]];
-    rhs[i] = acc;
-  }
-  __syncthreads();
-  for (int i = nf - 1; i >= 0; i--) {  // R x = rhs, upper, backward
-    if (tid == 0) rhs[i] = rhs[i] / RSd[(size_t)i * F.ld_rsd + i];
-    __syncthreads();
-    const double xi = rhs[i];
-    for (int j = tid; j < i; j += 256) rhs[j] -= RSd[(size_t)j * F.ld_rsd + i] * xi;
-    __syncthreads();
-  }
-  double md = 0.0;
-  bool bad = false;
-  for (int i = tid; i < nf; i += 256) {
-    md = fmax(md, fabs(delta[fxoff[F.fx_begin + i]] - rhs[i]));
-    if (rhs[i] != rhs[i]) bad = true;
-  }
-  red[tid] = md;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (tid < o) red[tid] = fmax(red[tid], red[tid + o]);
-    __syncthreads();
-  }
-  if (bad) atomicMin(status, F.id);  // NaN: IndeterminantLinearSystemException (ISAM2Clique.cpp:124-126)
-  const bool keep = threshold <= 0.0 || is_replaced || red[0] >= threshold;
-  if (keep)
-    for (int i = tid; i < nf; i += 256) {
-      const int xo = fxoff[F.fx_begin + i];
-      delta[xo] = rhs[i];
-      changed[xo] = 1;
+  lmgpu::ldsb_stage(F, pool, Ls, tid);  // does not depend on the parent
+  if (tid == 0) {
+    int ok = 1;
+    if (par >= 0) {
+      long spins = 0;
+      while (__hip_atomic_load(&done[par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > 4000000L) {
+          ok = 0;
+          break;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
+    s_ok = ok;
+    flag = (threshold <= 0.0 || is_replaced) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_ok && tid == 0) atomicMin(status, -1);  // never expected: spin bound hit (reported as a fault by the host)
+  if (!(threshold <= 0.0 || is_replaced)) {
+    if (tid < ns && changed[so]) flag = 1;  // benign race: every writer stores 1   (ns <= 138 < 256)
+    __syncthreads();
+  }
+  if (flag) {  // workgroup-uniform
+    bool bad;
+    const double* x = lmgpu::ldsb_solve_core(F, Ls, ns > 0 ? so : fo, delta, &bad);
+    double md = 0.0;
+    if (tid < nf) md = fabs(delta[fo] - x[tid]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) md = fmax(md, __shfl_xor(md, o));
+    if (lane == 0) red[w] = md;
+    __syncthreads();
+    const double mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    if (bad && lane == 0) atomicMin(status, F.id);  // NaN: IndeterminantLinearSystemException (ISAM2Clique.cpp:124-126)
+    const bool keep = threshold <= 0.0 || is_replaced || mx >= threshold;
+    if (keep && tid < nf) {
+      delta[fo] = x[tid];
+      changed[fo] = 1;
+    }
+  }
+  // publish: every wave's stores have been performed, then one release + flag
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(&done[id], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 namespace {
@@ -390,6 +409,7 @@ namespace {
 int is_sync_tree(lmgpu_isam2* S) {
   if (!S->tree_dirty) return LMGPU_OK;
   const int NC = (int)S->clq.size();
+  S->tree_lds = 0;
   std::vector<FrontDesc> td(std::max(1, NC));
   std::vector<int32_t> fx, sx, list;
   for (int id = 0; id < NC; id++) {
@@ -401,6 +421,8 @@ int is_sync_tree(lmgpu_isam2* S) {
       F.rsd_off = c.rsd_off;
       F.ld_rsd = c.n;
       F.id = id;
+      F.child_begin = c.parent;  // (the wildfire kernel waits for this clique's flag)
+      S->tree_lds = std::max(S->tree_lds, (size_t)c.nf * (size_t)(c.n | 1));
       F.fx_begin = (int)fx.size();
       for (int k = 0; k < c.nfv; k++)
         for (int d = 0; d < kVarDim[S->vars[c.vars[k]].type]; d++) fx.push_back(S->vars[c.vars[k]].xoff + d);
@@ -411,6 +433,7 @@ int is_sync_tree(lmgpu_isam2* S) {
     td[id] = F;
   }
   S->tree_levels.clear();
+  for (int r : S->roots) td[r].child_begin = -1;
   std::vector<int32_t> cur = S->roots, next;
   while (!cur.empty()) {
     S->tree_levels.emplace_back((int)list.size(), (int)cur.size());
@@ -428,6 +451,8 @@ int is_sync_tree(lmgpu_isam2* S) {
     return is_realloc(S, p, *cap, 0);
   };
   if ((rc = fit(&S->d_tree, &S->tree_cap[0], td.size()))) return rc;
+  if ((rc = fit(&S->d_tree_done, &S->tree_cap[4], td.size() + 1))) return rc;
+  S->tree_count = (int)list.size();
   if ((rc = fit(&S->d_tree_fx, &S->tree_cap[1], fx.size()))) return rc;
   if ((rc = fit(&S->d_tree_sx, &S->tree_cap[2], sx.size()))) return rc;
   if ((rc = fit(&S->d_tree_list, &S->tree_cap[3], list.size()))) return rc;
@@ -447,10 +472,14 @@ int is_update_delta(lmgpu_isam2* S, bool force_full) {
   const double thr = force_full ? 0.0 : S->prm.wildfireThreshold;
   ISCHECK(hipMemsetAsync(S->d_changed, 0, (size_t)S->ntot, S->stream));
   ISCHECK(hipMemsetAsync(S->d_status, 0x7f, sizeof(int), S->stream));
-  for (auto& lv : S->tree_levels)
-    hipLaunchKernelGGL(isam2_wildfire_kernel, dim3(lv.second), dim3(256), 0, S->stream, (const int32_t*)(S->d_tree_list + lv.first), lv.second,
-                       (const FrontDesc*)S->d_tree, (const int32_t*)S->d_tree_fx, (const int32_t*)S->d_tree_sx, (const double*)S->pool, S->delta,
-                       (const unsigned char*)S->d_replaced, S->d_changed, thr, S->d_status);
+  if (S->tree_count > 0) {
+    const size_t nflags = S->clq.size() + 1;
+    ISCHECK(hipMemsetAsync(S->d_tree_done, 0, nflags * sizeof(unsigned int), S->stream));
+    hipLaunchKernelGGL(isam2_wildfire_kernel, dim3(S->tree_count), dim3(256), (S->tree_lds + LDSB_TAIL) * sizeof(double), S->stream,
+                       (const int32_t*)S->d_tree_list, (const FrontDesc*)S->d_tree, (const int32_t*)S->d_tree_fx, (const int32_t*)S->d_tree_sx,
+                       (const double*)S->pool, S->delta, (const unsigned char*)S->d_replaced, S->d_changed, thr, S->d_status, S->d_tree_done,
+                       S->d_tree_done + S->clq.size());
+  }
   ISCHECK(hipMemsetAsync(S->d_replaced, 0, (size_t)S->ntot, S->stream));
   ISCHECK(hipMemcpyAsync(S->h_status, S->d_status, sizeof(int), hipMemcpyDeviceToHost, S->stream));
   if ((size_t)S->ntot > S->h_delta_cap) {
@@ -463,6 +492,10 @@ int is_update_delta(lmgpu_isam2* S, bool force_full) {
   ISCHECK(hipStreamSynchronize(S->stream));
   std::fill(S->replaced.begin(), S->replaced.end(), 0);
   S->any_replaced = false;
+  if (*S->h_status < 0) {
+    S->err = "ISAM2 back-substitution: a parent-to-child hand-off timed out";
+    return LMGPU_HIP_ERROR;
+  }
   if (*S->h_status < (int)S->clq.size()) {
     S->failed_key = S->vars[S->clq[*S->h_status].vars[0]].key;
     S->err = "indeterminate linear system in back-substitution";
@@ -1047,6 +1080,7 @@ int lmgpu_isam2_create(const lmgpu_config* cfg, const lmgpu_isam2_params* prm, l
   ISCHECK(hipMalloc((void**)&S->d_status, sizeof(int)));
   ISCHECK(hipHostMalloc((void**)&S->h_status, sizeof(int)));
   ISCHECK(hipFuncSetAttribute((const void*)lds_front_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra + 64));
+  ISCHECK(hipFuncSetAttribute((const void*)isam2_wildfire_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (kLdsLimitN * kLdsLimitN + LDSB_TAIL) * 8));
   return LMGPU_OK;
 }
 
@@ -1070,7 +1104,7 @@ int lmgpu_isam2_destroy(lmgpu_isam2* S) {
       if (b.d_noise) (void)hipFree(b.d_noise);
     }
     for (void* p : {(void*)S->delta, (void*)S->ones, (void*)S->d_replaced, (void*)S->d_changed, (void*)S->pool, (void*)S->d_status, (void*)S->d_tree,
-                    (void*)S->d_tree_fx, (void*)S->d_tree_sx, (void*)S->d_tree_list})
+                    (void*)S->d_tree_fx, (void*)S->d_tree_sx, (void*)S->d_tree_list, (void*)S->d_tree_done})
       if (p) (void)hipFree(p);
     if (S->h_status) (void)hipHostFree(S->h_status);
     if (S->h_delta) (void)hipHostFree(S->h_delta);

@@ -621,9 +621,10 @@ __device__ __forceinline__ void ldsb_stage(const FrontDesc& F, const double* __r
       if (base + u * 256 + tid < total) Ls[at[u]] = v[u];
   }
 }
-// after the front's ancestors are visible.  so = this thread's separator offset (sxoff[sx_begin + min(tid, ns - 1)]), fo = its frontal
-// offset (fxoff[fx_begin + min(tid, nf - 1)]); Ls staged by ldsb_stage (a barrier follows here).  Returns with delta stored by wave 0..3.
-__device__ __forceinline__ void ldsb_solve(const FrontDesc& F, double* Ls, int so, int fo, double* __restrict__ delta, int* __restrict__ status) {
+// after the front's ancestors are visible.  so = this thread's separator offset (sxoff[sx_begin + min(tid, ns - 1)]); Ls staged by
+// ldsb_stage (a barrier follows here).  Leaves x_F in LDS (the pointer returned, nf entries; a barrier precedes the return) and
+// whether this thread saw a NaN in it.
+__device__ __forceinline__ double* ldsb_solve_core(const FrontDesc& F, double* Ls, int so, const double* __restrict__ delta, bool* bad_out) {
   const int n = F.n, nf = F.nf, ns = n - nf - 1, nl = n | 1;
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   double* xsl = Ls + (size_t)nf * nl;  // [144]
@@ -691,8 +692,15 @@ __device__ __forceinline__ void ldsb_solve(const FrontDesc& F, double* Ls, int s
     __syncthreads();
   }
   __syncthreads();
-  if (tid < nf) delta[fo] = y[tid];
-  if (bad && lane == 0) atomicMin(status, F.id);  // NaN -> IndeterminantLinearSystemException (linearAlgorithms-inst.h:99)
+  *bad_out = bad;
+  return y;
+}
+// the same, stored: fo = this thread's frontal offset (fxoff[fx_begin + min(tid, nf - 1)])
+__device__ __forceinline__ void ldsb_solve(const FrontDesc& F, double* Ls, int so, int fo, double* __restrict__ delta, int* __restrict__ status) {
+  bool bad;
+  const double* y = ldsb_solve_core(F, Ls, so, delta, &bad);
+  if ((int)threadIdx.x < F.nf) delta[fo] = y[threadIdx.x];
+  if (bad && (threadIdx.x & 63) == 0) atomicMin(status, F.id);  // NaN -> IndeterminantLinearSystemException (linearAlgorithms-inst.h:99)
 }
 
 __global__ __launch_bounds__(256) void lds_backsub_wide_kernel(const int32_t* __restrict__ list, int nlist, const FrontDesc* __restrict__ fronts,
