@@ -231,6 +231,17 @@ def main():
     from gtsam_personal_amd import LevenbergMarquardtOptimizer, LevenbergMarquardtParams
     from gtsam_personal_amd.synthetic import make_bal
 
+    # The first process on a freshly started GPU box ran 3 % slower than any later one (112.7 vs 116.2 LM iterations/s; every kernel
+    # slower, the bandwidth-bound linearize by 11 %), whatever the number of warm-up steps: the device memory the solver's pool lands in
+    # is handed out for the first time.  Allocating, clearing and freeing a few GiB once before the solver allocates removes that
+    # (measured: profiles/r02/first_process.txt).  Untimed set-up, reported in the JSON line; BENCH_PRETOUCH_GB=0 switches it off.
+    pre_gb = float(os.environ.get("BENCH_PRETOUCH_GB", "8"))
+    if pre_gb > 0:
+        x = torch.empty(int(pre_gb * (1 << 30)), dtype=torch.uint8, device=f"cuda:{local_rank}")
+        x.zero_()
+        torch.cuda.synchronize()
+        del x
+        torch.cuda.empty_cache()
     t_setup = time.perf_counter()
     graph, initial, _, ordering = make_bal(args.cams, args.points, args.obs, seed=args.seed)
     ordering_name = "Schur ordering (points then cameras)"
@@ -262,7 +273,9 @@ def main():
         opt.restore_values(state0)
         opt.iterate()
     if not args.no_kernel_timing:
-        opt.set_kernel_timing(True)
+        # HIP events around the two roofline kernels only, live in the timed region; the other categories (whose events would cost the
+        # timed region ~0.08 ms of idle device time per step) are measured on one more iteration behind it
+        opt.set_kernel_timing(2)
     phases = dict(linearize_ms=0.0, eliminate_ms=0.0, backsub_ms=0.0, linear_error_ms=0.0, retract_error_ms=0.0)
     inner = 0
     sync()
@@ -282,6 +295,15 @@ def main():
         elapsed = float(t.item())
     kt = opt.kernel_times() if not args.no_kernel_timing else None
     e_final = opt.error()  # error after ONE LM iteration from the initial estimate
+    kt_all, kt_all_inner = None, 1
+    if kt is not None:  # every category, outside the timed region
+        opt.set_kernel_timing(True)
+        opt.restore_values(state0)
+        opt.iterate()
+        kt_all_inner = max(1, opt.timings()["inner_iterations"])
+        kt_all = opt.kernel_times()
+        opt.restore_values(state0)
+        opt.iterate()  # leave the values where e_final was taken
 
     if rank == 0:
         steps = args.steps
@@ -315,6 +337,7 @@ def main():
             "error_initial": e_initial,
             "error_after_one_iteration": e_final,
             "setup_s": t_setup,
+            "device_memory_pretouch_gib": pre_gb,
         }
         if kt is not None:
             lin = kt["linearize"]
@@ -340,7 +363,10 @@ def main():
                 out["roofline_linearize"] = {"kernel": "sfm_linearize_kernel", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                              "frac": gbs / HBM_PEAK_GBPS, "traffic": pmc.get("sfm_linearize_kernel"), "launches": lin["launches"],
                                              "avg_launch_us": 1e3 * lin["ms"] / lin["launches"], "bytes_per_launch": lin["work"] / lin["launches"]}
-            out["kernel_ms_per_step"] = {k: v["ms"] / steps for k, v in kt.items()}
+            # linearize / chain / syrk: the timed region; the other categories: the one fully instrumented iteration behind it
+            live = ("linearize", "chain", "syrk")
+            out["kernel_ms_per_step"] = {k: (v["ms"] / steps if k in live else kt_all[k]["ms"]) for k, v in kt.items()}
+            out["kernel_ms_per_step_note"] = "linearize / chain / syrk: HIP events inside the timed region; others: one more iteration with every category instrumented"
         # measured device peaks for context (not the roofline denominators)
         import ctypes as ct
         from gtsam_personal_amd import _lib

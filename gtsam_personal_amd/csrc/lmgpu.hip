@@ -93,6 +93,7 @@ struct LevelWork {
 
 struct KTimer {
   bool on = false;
+  bool dominant_only = false;  // lmgpu_set_kernel_timing(h, 2): only the roofline kernels (LINEARIZE; CHAIN, or SYRK = the per-step form of the same work) carry events
   std::vector<hipEvent_t> pool;
   struct Rec {
     int cat, e0, e1, launches;
@@ -110,7 +111,7 @@ struct KTimer {
     return used++;
   }
   int begin(int cat, hipStream_t s) {
-    if (!on) return -1;
+    if (!on || (dominant_only && cat != LMGPU_KT_LINEARIZE && cat != LMGPU_KT_CHAIN && cat != LMGPU_KT_SYRK)) return -1;
     const int e = grab();
     (void)hipEventRecord(pool[e], s);
     recs.push_back({cat, e, -1, 1});
@@ -2600,6 +2601,7 @@ int lmgpu_get_timings(const lmgpu_handle* h, lmgpu_timings* out) {
 int lmgpu_set_kernel_timing(lmgpu_handle* h, int32_t on) {
   if (!h) return LMGPU_INVALID;
   h->kt.on = on != 0;
+  h->kt.dominant_only = on == 2;
   h->kt.reset();
   return LMGPU_OK;
 }

@@ -227,6 +227,7 @@ class LevenbergMarquardtOptimizer:
         return s
 
     def set_kernel_timing(self, on=True):
+        """True / 1: every category; 2: only the two roofline kernels (linearize, chain); False: off"""
         self._check(self.lib.lmgpu_set_kernel_timing(self._h, int(on)))
 
     def kernel_times(self):

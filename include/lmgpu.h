@@ -226,6 +226,8 @@ enum lmgpu_kernel_category {
   LMGPU_KT_CHAIN = 10,      /* chain_kernel = all fused steps of a dense front (updates + panel factorisations) as ONE launch */
   LMGPU_KT_NUM = 11
 };
+/* on: 0 off; 1 every category; 2 only LINEARIZE and CHAIN / SYRK (the roofline kernels; SYRK is the per-step form of CHAIN's work): an event between two launches costs a few
+ * microseconds of idle device time, and a throughput measurement should not pay that for the eleven categories it does not report */
 int lmgpu_set_kernel_timing(lmgpu_handle* h, int32_t on);
 int lmgpu_get_kernel_times(const lmgpu_handle* h, double* ms /*[LMGPU_KT_NUM]*/, double* work /*[LMGPU_KT_NUM]*/, int64_t* launches /*[LMGPU_KT_NUM]*/);
 
