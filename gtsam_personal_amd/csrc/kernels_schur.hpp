@@ -55,7 +55,7 @@ __device__ __forceinline__ long long readlane_ll(long long v, int src /* wave-un
 // columns >= the block dims are zero).  Four accumulators take entries e, e+1, e+2, e+3 of every group of four and are
 // added in a fixed order; waves take fixed contiguous chunks of the list.
 template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void schur_pairs_kernel(const GPairBlock* __restrict__ blocks, const GPairEntry* __restrict__ entries,
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void schur_pairs_kernel(const GPairBlock* __restrict__ blocks, const GPairEntry* __restrict__ entries,
                                                                   double* __restrict__ pool, int64_t f_off, int ld, int nblocks, int write_mode) {
   __shared__ double part[WAVES][4][64];
   // XCD-aware order: workgroup ids go round-robin over the eight XCDs, so id -> (id % 8) * ceil(N / 8) + id / 8 gives every XCD
