@@ -228,6 +228,7 @@ struct lmgpu_handle {
   int eager_solves = 0;
   hipGraphExec_t solve_graph[2] = {nullptr, nullptr};  // [1]: with the extra gradient vector of the marginal solves
   bool no_wide16 = false;                      // LMGPU_NO_WIDE16=1: LDS fronts always with four waves (A/B)
+  bool bsd_ticket = false;                     // LMGPU_BSD_TICKET=1: the block back-substitution always draws tickets (tests: the path of levels with more blocks than CUs)
   bool no_tail = false;                        // LMGPU_NO_TAIL=1: the end of a front as separate update / panel launches (A/B)
   bool no_chain = false;                       // LMGPU_NO_CHAIN=1: one launch per fused step instead of one per run of steps (A/B)
   unsigned int* d_pflags = nullptr;            // hand-off flags of panel_dataflow_kernel, PDF_FLAG_WORDS per outer panel
@@ -987,7 +988,7 @@ int do_backsub(lmgpu_handle* h) {
     if (L.bsd_count > 0) {  // the smaller HBM fronts of the level: one workgroup per 64-row block, one launch
       const int kt = h->kt.begin(LMGPU_KT_BACKSUB_HBM, s);
       hipLaunchKernelGGL(hbm_backsolve_blocks_kernel, dim3(L.bsd_count), dim3(256), 0, s, (const BsdBlock*)(h->d_bsd_table + L.bsd_begin),
-                         L.bsd_count <= h->num_cus ? (unsigned int*)nullptr : h->d_bsd_ticket + li, (const int32_t*)h->d_fxoff,
+                         (L.bsd_count <= h->num_cus && !h->bsd_ticket) ? (unsigned int*)nullptr : h->d_bsd_ticket + li, (const int32_t*)h->d_fxoff,
                          (const int32_t*)h->d_sxoff, (const double*)h->pool, h->delta, h->d_bsd_x, h->d_status);
       h->kt.end(kt, s);
     }
@@ -1500,6 +1501,7 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
   h->no_chain = getenv("LMGPU_NO_CHAIN") != nullptr;
   h->no_tail = getenv("LMGPU_NO_TAIL") != nullptr;
   h->no_wide16 = getenv("LMGPU_NO_WIDE16") != nullptr;
+  h->bsd_ticket = getenv("LMGPU_BSD_TICKET") != nullptr;
   h->no_gather_write = getenv("LMGPU_NO_GATHER_WRITE") != nullptr;
   h->scatter_atomics = getenv("LMGPU_NO_GATHER") != nullptr;
   if (const char* e = getenv("LMGPU_CHAIN_FAR")) h->chain_far_pct = std::max(10, std::min(100, atoi(e)));

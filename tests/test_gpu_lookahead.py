@@ -123,3 +123,38 @@ def test_graph_replay_and_merged_backsubstitution_agree_with_eager_launches(monk
         for (d, e1), (d0, e10) in zip(out, base):
             assert np.linalg.norm(d - d0) <= 1e-12 * np.linalg.norm(d0), mode
             assert abs(e1 - e10) <= 1e-12 * max(1.0, abs(e10)), mode
+
+
+def test_deep_tree_launch_forms_agree(monkeypatch):
+    """Round-2 forms of the deep-tree kernels against each other on sphere2500 (20 levels, mid-size fronts of up to 546 columns): the
+    block back-substitution with and without tickets (LMGPU_BSD_TICKET: the path of levels with more 64-row blocks than CUs), LDS fronts
+    with four and with sixteen waves (LMGPU_NO_WIDE16), mid-size fronts batched per level or one by one (LMGPU_NO_MED: the trailing
+    update as 128-tiles / quadrants of the per-front path).  Same arithmetic per entry except where a reduction is cut differently."""
+    from gtsam_personal_amd import noiseModel
+    from gtsam_personal_amd.datasets import chain_initial_pose3, load3D
+    graph, _ = load3D(os.path.join(os.path.dirname(__file__), "golden", "sphere2500.txt"))
+    initial = chain_initial_pose3(graph)
+    graph.add_PriorFactorPose3(0, np.eye(3), np.zeros(3), noiseModel.Diagonal.Variances([1e-6, 1e-6, 1e-6, 1e-4, 1e-4, 1e-4]))
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "slam_orderings.npz"))
+    keys = np.array(sorted(graph.keys()), dtype=np.uint64)
+    ordering = [int(k) for k in keys[fx["sphere2500_metis"]]]
+    results = {}
+    for mode in ("default", "LMGPU_BSD_TICKET", "LMGPU_NO_WIDE16", "LMGPU_NO_MED"):
+        for sw in ("LMGPU_BSD_TICKET", "LMGPU_NO_WIDE16", "LMGPU_NO_MED"):
+            monkeypatch.delenv(sw, raising=False)
+        if mode != "default":
+            monkeypatch.setenv(mode, "1")
+        opt = LevenbergMarquardtOptimizer(graph, initial, ordering, LevenbergMarquardtParams(), device=0)
+        opt.linearize()
+        out = []
+        for lam in (1e-5, 1e-2, 1.0):
+            _, d, e0, e1 = opt.solve(lam)
+            out.append((d.copy(), e1))
+        opt.close()
+        results[mode] = out
+    base = results["default"]
+    for mode, out in results.items():
+        tol = 0.0 if mode == "LMGPU_BSD_TICKET" else 1e-9  # tickets only change which workgroup takes which block
+        for (d, e1), (d0, e10) in zip(out, base):
+            assert np.linalg.norm(d - d0) <= tol * np.linalg.norm(d0), mode
+            assert abs(e1 - e10) <= max(tol, 1e-15) * max(1.0, abs(e10)), mode
