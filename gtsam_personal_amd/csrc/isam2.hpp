@@ -153,7 +153,9 @@ int is_stage_begin(lmgpu_isam2* S) {
     if (e.second) (void)hipFree(e.second);
   }
   S->stage_extra.clear();
-  const size_t want = std::max<size_t>(size_t(1) << 20, 2 * S->stage_want);
+  size_t floor_bytes = size_t(1) << 20;
+  if (const char* e = getenv("LMGPU_ISAM2_STAGE_BYTES")) floor_bytes = (size_t)std::max(64L, atol(e));  // tests: a tiny arena, every request overflows
+  const size_t want = getenv("LMGPU_ISAM2_STAGE_BYTES") ? floor_bytes : std::max<size_t>(floor_bytes, 2 * S->stage_want);
   if (want > S->stage_cap) {
     if (S->h_stage) (void)hipHostFree(S->h_stage);
     if (S->d_stage) (void)hipFree(S->d_stage);

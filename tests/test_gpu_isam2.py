@@ -67,6 +67,14 @@ def test_visual_isam2_example_step_by_step():
     isam.close()
 
 
+def test_updates_with_a_staging_arena_that_always_overflows(monkeypatch):
+    """every table and index list of an update goes through the pinned staging arena (csrc/isam2.hpp); with a 64-byte arena each
+    request takes the overflow path (a chunk of its own, freed at the next update) -- same results"""
+    monkeypatch.setenv("LMGPU_ISAM2_STAGE_BYTES", "64")
+    isam, _ = run_sequence(visual_steps(), ISAM2Params(relinearizeThreshold=0.01, relinearizeSkip=1))
+    isam.close()
+
+
 @pytest.mark.parametrize("params", [
     ISAM2Params(ISAM2GaussNewtonParams(0.001), 0.0, 0, False),   # tests/testGaussianISAM2.cpp:303: relinearization off
     ISAM2Params(),                                                # defaults: threshold 0.1, every 10th update
