@@ -158,3 +158,23 @@ def test_deep_tree_launch_forms_agree(monkeypatch):
         for (d, e1), (d0, e10) in zip(out, base):
             assert np.linalg.norm(d - d0) <= tol * np.linalg.norm(d0), mode
             assert abs(e1 - e10) <= max(tol, 1e-15) * max(1.0, abs(e10)), mode
+
+
+def test_kernel_timers_modes():
+    """lmgpu_set_kernel_timing: 1 = every category, 2 = only the roofline kernels (what bench.py keeps inside its timed region); the
+    timers never change results"""
+    graph, initial, _, ordering = make_bal(n_cam=64, n_pt=1600, obs_per_point=8, seed=17)
+    outs = {}
+    for mode in (0, 1, 2):
+        opt = LevenbergMarquardtOptimizer(graph, initial, ordering, LevenbergMarquardtParams(), device=0)
+        opt.set_kernel_timing(mode)
+        opt.iterate()
+        kt = opt.kernel_times()
+        outs[mode] = (opt.error(), kt)
+        opt.close()
+    assert outs[0][0] == outs[1][0] == outs[2][0]
+    assert all(v["launches"] == 0 for v in outs[0][1].values())
+    assert outs[1][1]["linearize"]["launches"] > 0 and outs[1][1]["lds_front"]["launches"] > 0 and outs[1][1]["backsub_lds"]["launches"] > 0
+    assert outs[2][1]["linearize"]["launches"] > 0 and outs[2][1]["linearize"]["ms"] > 0
+    assert all(v["launches"] == 0 for k, v in outs[2][1].items() if k not in ("linearize", "chain", "syrk"))
+    assert outs[2][1]["chain"]["launches"] + outs[2][1]["syrk"]["launches"] > 0
