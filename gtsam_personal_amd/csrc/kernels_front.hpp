@@ -94,10 +94,17 @@ static_assert(sizeof(LFac) == 32, "leaf records embed LFac entries");
 // development aid (tools/ldsf_phases.py builds a library of its own with it): 100 MHz wall-clock time per phase of the first workgroup of
 // every launch of at most eight fronts (= the upper levels of a clique tree, where a launch lasts as long as its slowest front)
 #ifdef LDSF_STAMPS
+// which workgroups are sampled: the first one of launches of at most eight fronts (upper tree levels) -- or, with LDSF_STAMPS_LEAVES, one
+// in the middle of every launch of more than 1000 fronts (a leaf level under full load)
+#ifdef LDSF_STAMPS_LEAVES
+#define LDSF_SAMPLED (gridDim.x > 1000 && blockIdx.x == gridDim.x / 2)
+#else
+#define LDSF_SAMPLED (gridDim.x <= 8 && blockIdx.x == 0)
+#endif
 __device__ unsigned long long ldsf_dbg[16];
 #define LDSF_STAMP(i)                                                  \
   do {                                                                 \
-    if (gridDim.x <= 8 && blockIdx.x == 0 && threadIdx.x == 0) {       \
+    if (LDSF_SAMPLED && threadIdx.x == 0) {                            \
       const unsigned long long now_ = wall_clock64();                  \
       atomicAdd(&ldsf_dbg[i], now_ - ldsf_last);                       \
       ldsf_last = now_;                                                \
@@ -117,7 +124,7 @@ __global__ __launch_bounds__(MAXT) void lds_front_kernel(const int32_t* __restri
   extern __shared__ double S[];
 #ifdef LDSF_STAMPS
   unsigned long long ldsf_last = wall_clock64();
-  if (gridDim.x <= 8 && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ldsf_dbg[15], 1ull);
+  if (LDSF_SAMPLED && threadIdx.x == 0) atomicAdd(&ldsf_dbg[15], 1ull);
 #endif
   double* corner_g = S + (size_t)srows * nmax;  // GATHER: the (rhs, rhs) entry lives here
   double* Jb = corner_g + 8;
