@@ -65,6 +65,8 @@ struct lmgpu_isam2 {
     std::vector<int32_t> vars;  // vids: frontals (elimination order), then separators ascending by key (Scatter order)
     int32_t nfv = 0, nf = 0, n = 0;
     int64_t rsd_off = -1, u_off = -1;
+    int64_t kids_off = -1;  // pool offset (doubles) of the children's clique ids as int32 (the wildfire kernel pushes them), -1: none
+    int32_t kids_n = 0;
     std::vector<int32_t> children;
     int32_t parent = -1;
     bool alive = false;
@@ -109,14 +111,17 @@ struct lmgpu_isam2 {
   double t_phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   std::vector<int> elim_cid;  // cliques of the elimination whose status word is still on the device (checked when the update ends)
   bool elim_pending = false;
-  bool tree_dirty = true;
-  FrontDesc* d_tree = nullptr;  // one descriptor per clique slot (wildfire)
-  int32_t *d_tree_fx = nullptr, *d_tree_sx = nullptr, *d_tree_list = nullptr;
-  std::vector<std::pair<int, int>> tree_levels;  // (begin, count) in d_tree_list per depth
-  size_t tree_cap[5] = {0, 0, 0, 0, 0};
-  unsigned int* d_tree_done = nullptr;  // per clique slot: its wildfire decision is stored (+ one ticket counter behind them)
-  size_t tree_lds = 0;                  // largest nf x (n | 1) of a clique: doubles of LDS the wildfire kernel stages
-  int tree_count = 0;                   // cliques in d_tree_list
+  // Device copy of the Bayes tree for the wildfire, PATCHED per update (only the cliques an update created or re-parented are
+  // rewritten): one FrontDesc per clique slot (child_begin / child_count = its children as a list of clique ids in the pool), its frontal
+  // and separator delta offsets in fixed-stride rows (kTreeRow ints per slot).
+  std::vector<int32_t> touched;  // clique slots whose descriptor changed since the last patch
+  FrontDesc* d_tree = nullptr;
+  int32_t *d_tree_fx = nullptr, *d_tree_sx = nullptr;
+  size_t tree_slots = 0;         // capacity of the three arrays, in clique slots
+  int32_t* d_queue = nullptr;    // work list of the wildfire kernel (clique ids; -1 = not published; consumers reset what they take)
+  size_t queue_cap = 0;
+  unsigned int* d_wl = nullptr;  // [0] tail, [1] next ticket, [2] items published and not finished
+  size_t tree_lds = 0;           // largest nf x (n | 1) of a clique: doubles of LDS the wildfire kernel stages
   // taps
   std::vector<int32_t> snap;
 };
@@ -251,6 +256,9 @@ void is_release_clique(lmgpu_isam2* S, int id) {
   lmgpu_isam2::Clq& c = S->clq[id];
   is_pool_free(S, c.rsd_off, (size_t)c.nf * c.n);
   is_pool_free(S, c.u_off, (size_t)(c.n - c.nf) * (c.n - c.nf));
+  if (c.kids_off >= 0) is_pool_free(S, c.kids_off, (size_t)(c.kids_n + 1) / 2);
+  c.kids_off = -1;
+  c.kids_n = 0;
   c.alive = false;
   c.children.clear();
   c.vars.clear();
@@ -327,160 +335,223 @@ __global__ __launch_bounds__(256) void isam2_mark_kernel(const int32_t* __restri
   for (int k = 0; k < d; k++) replaced[xo + k] = 1;
 }
 
-// The whole Bayes tree in ONE launch: ISAM2Clique::optimizeWildfireNode (gtsam/nonlinear/ISAM2Clique.cpp:211-234) per clique, one
-// workgroup each, parent -> child dataflow inside the launch (tickets in breadth-first order: a parent holds a lower ticket than its
-// children; a clique waits for its parent's flag, which the parent raised after its own decision was stored -- and the parent had
-// waited for ITS parent, so every ancestor is visible).
+#define ISAM2_TREE_ROW 140  // ints per clique slot for its frontal / separator delta offsets (a clique has at most 139 scalar columns)
+#define ISAM2_WL_GROUPS 64  // persistent workgroups of the wildfire kernel
+
+// rewrites the descriptors of the cliques an update touched: entry i of the blob -> clique slot ids[i]
+__global__ __launch_bounds__(256) void isam2_tree_patch_kernel(const int32_t* __restrict__ ids, const lmgpu::FrontDesc* __restrict__ td,
+                                                                const int32_t* __restrict__ fx, const int32_t* __restrict__ sx,
+                                                                const int32_t* __restrict__ kids, const int32_t* __restrict__ kids_begin,
+                                                                lmgpu::FrontDesc* __restrict__ tree, int32_t* __restrict__ tree_fx,
+                                                                int32_t* __restrict__ tree_sx, double* __restrict__ pool) {
+  const int i = blockIdx.x, id = ids[i], tid = threadIdx.x;
+  const lmgpu::FrontDesc F = td[i];
+  if (tid == 0) tree[id] = F;
+  const int nf = F.nf, ns = F.n - F.nf - 1;
+  if (tid < nf) tree_fx[(size_t)id * ISAM2_TREE_ROW + tid] = fx[(size_t)i * ISAM2_TREE_ROW + tid];
+  if (tid < ns) tree_sx[(size_t)id * ISAM2_TREE_ROW + tid] = sx[(size_t)i * ISAM2_TREE_ROW + tid];
+  int32_t* dst = (int32_t*)(pool + F.child_begin);
+  for (int k = tid; k < F.child_count; k += 256) dst[k] = kids[kids_begin[i] + k];
+}
+
+// ISAM2::updateDelta's top-down walk as a device-side WORK LIST (optimizeWildfireNonRecursive, gtsam/nonlinear/ISAM2-impl.cpp:47-77 ->
+// ISAM2Clique::optimizeWildfireNode, ISAM2Clique.cpp:211-234): the queue starts with the roots; a persistent workgroup takes the next
+// ticket, waits for that queue entry, processes the clique and -- if the clique was dirty, exactly the reference's rule for descending
+// -- appends its children.  Work is O(cliques visited), not O(cliques): the first single-launch form had one workgroup per clique of the
+// tree, whatever had changed (0.25 ms per update after 500 poses of city10000, 0.40 ms after 3 000).
 //   dirty   = the clique was re-eliminated (replaced flag of its first frontal scalar) or a separator scalar changed (isDirty :56-77)
-//   solve   = x_F = R^-1 (d - S x_S)   (fastBackSubstitute -> GaussianConditional::solve): [R S d] staged in LDS BEFORE the wait for
-//             the parent, the solve as in lds_backsub_merged_kernel (kernels_front.hpp: ldsb_stage / ldsb_solve_core)
+//   solve   = x_F = R^-1 (d - S x_S)   ([R S d] staged in LDS, the register solve of the batch path's LDS fronts: ldsb_stage / ldsb_solve_core)
 //   keep    = replaced or max |x_F_old - x_F_new| >= threshold (valuesChanged :151-158): write x_F, flag the frontal scalars as changed;
 //             otherwise the old values stay (restoreFromOriginals).   threshold <= 0: every clique is solved (full back-substitution).
-// tree[id].child_begin carries the parent clique (-1: a root).  One launch per tree DEPTH (the first form) was ~15 launches per update
-// of a 400-pose graph whatever had changed.
-__global__ __launch_bounds__(256) void isam2_wildfire_kernel(const int32_t* __restrict__ list, const lmgpu::FrontDesc* __restrict__ tree,
-                                                              const int32_t* __restrict__ fxoff, const int32_t* __restrict__ sxoff,
-                                                              const double* __restrict__ pool, double* __restrict__ delta,
-                                                              const unsigned char* __restrict__ replaced, unsigned char* __restrict__ changed,
-                                                              double threshold, int* __restrict__ status, unsigned int* __restrict__ done,
-                                                              unsigned int* __restrict__ ticket) {
+// Progress: tickets and queue slots are both handed out in increasing order, an entry is published by a clique that is being processed
+// (counted in wl[2]), and a waiting workgroup leaves when its entry is empty AND wl[2] == 0.  Every spin is bounded.
+// wl: [0] tail (next free queue slot), [1] next ticket, [2] published and unfinished items; the host presets them and the roots.
+__global__ __launch_bounds__(256) void isam2_wildfire_kernel(int32_t* __restrict__ queue, unsigned int* __restrict__ wl,
+                                                              const lmgpu::FrontDesc* __restrict__ tree, const int32_t* __restrict__ tree_fx,
+                                                              const int32_t* __restrict__ tree_sx, const double* __restrict__ pool,
+                                                              double* __restrict__ delta, const unsigned char* __restrict__ replaced,
+                                                              unsigned char* __restrict__ changed, double threshold, int* __restrict__ status) {
   extern __shared__ double Ls[];
-  __shared__ int s_ticket, s_ok, flag;
+  __shared__ int s_id, flag;
   __shared__ double red[4];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  if (tid == 0) s_ticket = (int)atomicAdd(ticket, 1u);
-  __syncthreads();
-  const int id = list[s_ticket];
-  const lmgpu::FrontDesc F = tree[id];
-  const int n = F.n, nf = F.nf, ns = n - nf - 1, par = F.child_begin;
-  const int so = ns > 0 ? sxoff[F.sx_begin + min(tid, ns - 1)] : 0, fo = fxoff[F.fx_begin + min(tid, nf - 1)];
-  const bool is_replaced = replaced[fxoff[F.fx_begin]] != 0;
-  lmgpu::ldsb_stage(F, pool, Ls, tid);  // does not depend on the parent
-  if (tid == 0) {
-    int ok = 1;
-    if (par >= 0) {
+  for (;;) {
+    if (tid == 0) {
+      const unsigned int my = atomicAdd(&wl[1], 1u);
+      int id;
       long spins = 0;
-      while (__hip_atomic_load(&done[par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-        __builtin_amdgcn_s_sleep(1);
+      for (;;) {
+        id = __hip_atomic_load(&queue[my], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (id >= 0) break;
+        if (__hip_atomic_load(&wl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+          id = -2;  // nothing is being processed and nothing is queued: the walk is over
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
         if (++spins > 4000000L) {
-          ok = 0;
+          id = -3;
           break;
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (id >= 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the parent's delta / changed flags
+        __hip_atomic_store(&queue[my], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the slot is clean for the next launch
+      }
+      s_id = id;
     }
-    s_ok = ok;
-    flag = (threshold <= 0.0 || is_replaced) ? 1 : 0;
-  }
-  __syncthreads();
-  if (!s_ok && tid == 0) atomicMin(status, -1);  // never expected: spin bound hit (reported as a fault by the host)
-  if (!(threshold <= 0.0 || is_replaced)) {
-    if (tid < ns && changed[so]) flag = 1;  // benign race: every writer stores 1   (ns <= 138 < 256)
     __syncthreads();
-  }
-  if (flag) {  // workgroup-uniform
-    bool bad;
-    const double* x = lmgpu::ldsb_solve_core(F, Ls, ns > 0 ? so : fo, delta, &bad);
-    double md = 0.0;
-    if (tid < nf) md = fabs(delta[fo] - x[tid]);
+    const int id = s_id;
+    if (id < 0) {
+      if (id == -3 && tid == 0) atomicMin(status, -1);  // never expected: spin bound hit (reported as a fault by the host)
+      return;
+    }
+    const lmgpu::FrontDesc F = tree[id];
+    const int n = F.n, nf = F.nf, ns = n - nf - 1;
+    const int32_t* fxr = tree_fx + (size_t)id * ISAM2_TREE_ROW;
+    const int32_t* sxr = tree_sx + (size_t)id * ISAM2_TREE_ROW;
+    const int so = ns > 0 ? sxr[min(tid, ns - 1)] : 0, fo = fxr[min(tid, nf - 1)];
+    const bool is_replaced = replaced[fxr[0]] != 0;
+    if (tid == 0) flag = (threshold <= 0.0 || is_replaced) ? 1 : 0;
+    __syncthreads();
+    if (!(threshold <= 0.0 || is_replaced)) {
+      if (tid < ns && changed[so]) flag = 1;  // benign race: every writer stores 1   (ns <= 138 < 256)
+      __syncthreads();
+    }
+    const bool dirty = flag != 0;  // workgroup-uniform
+    if (dirty) {
+      lmgpu::ldsb_stage(F, pool, Ls, tid);
+      bool bad;
+      const double* x = lmgpu::ldsb_solve_core(F, Ls, ns > 0 ? so : fo, delta, &bad);
+      double md = 0.0;
+      if (tid < nf) md = fabs(delta[fo] - x[tid]);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) md = fmax(md, __shfl_xor(md, o));
-    if (lane == 0) red[w] = md;
-    __syncthreads();
-    const double mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-    if (bad && lane == 0) atomicMin(status, F.id);  // NaN: IndeterminantLinearSystemException (ISAM2Clique.cpp:124-126)
-    const bool keep = threshold <= 0.0 || is_replaced || mx >= threshold;
-    if (keep && tid < nf) {
-      delta[fo] = x[tid];
-      changed[fo] = 1;
+      for (int o = 32; o > 0; o >>= 1) md = fmax(md, __shfl_xor(md, o));
+      if (lane == 0) red[w] = md;
+      __syncthreads();
+      const double mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+      if (bad && lane == 0) atomicMin(status, F.id);  // NaN: IndeterminantLinearSystemException (ISAM2Clique.cpp:124-126)
+      const bool keep = threshold <= 0.0 || is_replaced || mx >= threshold;
+      if (keep && tid < nf) {
+        delta[fo] = x[tid];
+        changed[fo] = 1;
+      }
     }
-  }
-  // publish: every wave's stores have been performed, then one release + flag
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    // hand over: every wave's stores have been performed, then the children (a dirty clique's only) and the count
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(&done[id], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int nk = dirty ? F.child_count : 0;
+    unsigned int base = 0;
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (nk > 0) {
+        atomicAdd(&wl[2], (unsigned int)nk);
+        base = atomicAdd(&wl[0], (unsigned int)nk);
+      }
+      s_id = (int)base;
+    }
+    __syncthreads();
+    if (nk > 0) {
+      const int32_t* kids = (const int32_t*)(pool + F.child_begin);
+      for (int k = tid; k < nk; k += 256) __hip_atomic_store(&queue[(unsigned int)s_id + k], kids[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) atomicSub(&wl[2], 1u);  // this item is finished (its children, if any, are counted already)
+    __syncthreads();
   }
 }
 
 namespace {
 
-// rebuild the device copy of the tree (descriptors, offsets, depth lists) after an update changed it
-int is_sync_tree(lmgpu_isam2* S) {
-  if (!S->tree_dirty) return LMGPU_OK;
-  const int NC = (int)S->clq.size();
-  S->tree_lds = 0;
-  std::vector<FrontDesc> td(std::max(1, NC));
-  std::vector<int32_t> fx, sx, list;
-  for (int id = 0; id < NC; id++) {
-    const lmgpu_isam2::Clq& c = S->clq[id];
-    FrontDesc F{};
-    if (c.alive) {
-      F.n = c.n;
-      F.nf = c.nf;
-      F.rsd_off = c.rsd_off;
-      F.ld_rsd = c.n;
-      F.id = id;
-      F.child_begin = c.parent;  // (the wildfire kernel waits for this clique's flag)
-      S->tree_lds = std::max(S->tree_lds, (size_t)c.nf * (size_t)(c.n | 1));
-      F.fx_begin = (int)fx.size();
-      for (int k = 0; k < c.nfv; k++)
-        for (int d = 0; d < kVarDim[S->vars[c.vars[k]].type]; d++) fx.push_back(S->vars[c.vars[k]].xoff + d);
-      F.sx_begin = (int)sx.size();
-      for (size_t k = c.nfv; k < c.vars.size(); k++)
-        for (int d = 0; d < kVarDim[S->vars[c.vars[k]].type]; d++) sx.push_back(S->vars[c.vars[k]].xoff + d);
-    }
-    td[id] = F;
-  }
-  S->tree_levels.clear();
-  for (int r : S->roots) td[r].child_begin = -1;
-  std::vector<int32_t> cur = S->roots, next;
-  while (!cur.empty()) {
-    S->tree_levels.emplace_back((int)list.size(), (int)cur.size());
-    next.clear();
-    for (int id : cur) {
-      list.push_back(id);
-      for (int ch : S->clq[id].children) next.push_back(ch);
-    }
-    cur.swap(next);
-  }
+// bring the device copy of the tree up to date: only the cliques the updates since the last call created or re-parented
+int is_patch_tree(lmgpu_isam2* S) {
+  const size_t NC = S->clq.size();
   int rc;
-  auto fit = [&](auto** p, size_t* cap, size_t need) -> int {
-    if (need <= *cap) return LMGPU_OK;
-    *cap = is_next_cap(*cap, need);
-    return is_realloc(S, p, *cap, 0);
-  };
-  if ((rc = fit(&S->d_tree, &S->tree_cap[0], td.size()))) return rc;
-  if ((rc = fit(&S->d_tree_done, &S->tree_cap[4], td.size() + 1))) return rc;
-  S->tree_count = (int)list.size();
-  if ((rc = fit(&S->d_tree_fx, &S->tree_cap[1], fx.size()))) return rc;
-  if ((rc = fit(&S->d_tree_sx, &S->tree_cap[2], sx.size()))) return rc;
-  if ((rc = fit(&S->d_tree_list, &S->tree_cap[3], list.size()))) return rc;
-  if ((rc = is_push(S, S->d_tree, td.data(), td.size() * sizeof(FrontDesc)))) return rc;
-  if ((rc = is_push(S, S->d_tree_fx, fx.data(), fx.size() * sizeof(int32_t)))) return rc;
-  if ((rc = is_push(S, S->d_tree_sx, sx.data(), sx.size() * sizeof(int32_t)))) return rc;
-  if ((rc = is_push(S, S->d_tree_list, list.data(), list.size() * sizeof(int32_t)))) return rc;
-  S->tree_dirty = false;
+  if (NC > S->tree_slots) {  // more clique slots: the arrays grow, their contents are kept
+    const size_t cap = is_next_cap(S->tree_slots, NC);
+    if ((rc = is_realloc(S, &S->d_tree, cap, S->tree_slots))) return rc;
+    if ((rc = is_realloc(S, &S->d_tree_fx, cap * ISAM2_TREE_ROW, S->tree_slots * ISAM2_TREE_ROW))) return rc;
+    if ((rc = is_realloc(S, &S->d_tree_sx, cap * ISAM2_TREE_ROW, S->tree_slots * ISAM2_TREE_ROW))) return rc;
+    S->tree_slots = cap;
+  }
+  if (NC + ISAM2_WL_GROUPS + 1 > S->queue_cap) {  // every clique once + the tickets of the workgroups that find nothing
+    const size_t cap = is_next_cap(S->queue_cap, NC + ISAM2_WL_GROUPS + 1);
+    if ((rc = is_realloc(S, &S->d_queue, cap, 0))) return rc;
+    ISCHECK(hipMemsetAsync(S->d_queue, 0xff, cap * sizeof(int32_t), S->stream));  // all slots "not published"; consumers keep it that way
+    S->queue_cap = cap;
+  }
+  if (!S->d_wl) ISCHECK(hipMalloc((void**)&S->d_wl, 4 * sizeof(unsigned int)));
+  std::sort(S->touched.begin(), S->touched.end());
+  S->touched.erase(std::unique(S->touched.begin(), S->touched.end()), S->touched.end());
+  std::vector<int32_t> ids, fx, sx, kids, kids_begin;
+  std::vector<FrontDesc> td;
+  for (int32_t id : S->touched) {
+    lmgpu_isam2::Clq& c = S->clq[id];
+    if (!c.alive) continue;
+    if (c.kids_off >= 0 && c.kids_n != (int)c.children.size()) {
+      is_pool_free(S, c.kids_off, (size_t)(c.kids_n + 1) / 2);
+      c.kids_off = -1;
+    }
+    c.kids_n = (int)c.children.size();
+    if (c.kids_n > 0 && c.kids_off < 0 && (rc = is_pool_alloc(S, (size_t)(c.kids_n + 1) / 2, &c.kids_off))) return rc;
+    if (c.kids_off > (int64_t)INT32_MAX) {
+      S->err = "ISAM2: pool offset beyond the range of a tree descriptor";
+      return LMGPU_INVALID;
+    }
+    FrontDesc F{};
+    F.n = c.n;
+    F.nf = c.nf;
+    F.rsd_off = c.rsd_off;
+    F.ld_rsd = c.n;
+    F.id = id;
+    F.child_begin = c.kids_n > 0 ? (int32_t)c.kids_off : 0;
+    F.child_count = c.kids_n;
+    S->tree_lds = std::max(S->tree_lds, (size_t)c.nf * (size_t)(c.n | 1));
+    const size_t row = ids.size() * ISAM2_TREE_ROW;
+    fx.resize(row + ISAM2_TREE_ROW, 0);
+    sx.resize(row + ISAM2_TREE_ROW, 0);
+    int o = 0;
+    for (int k = 0; k < c.nfv; k++)
+      for (int d = 0; d < kVarDim[S->vars[c.vars[k]].type]; d++) fx[row + o++] = S->vars[c.vars[k]].xoff + d;
+    o = 0;
+    for (size_t k = c.nfv; k < c.vars.size(); k++)
+      for (int d = 0; d < kVarDim[S->vars[c.vars[k]].type]; d++) sx[row + o++] = S->vars[c.vars[k]].xoff + d;
+    kids_begin.push_back((int32_t)kids.size());
+    kids.insert(kids.end(), c.children.begin(), c.children.end());
+    ids.push_back(id);
+    td.push_back(F);
+  }
+  S->touched.clear();
+  if (ids.empty()) return LMGPU_OK;
+  int32_t *d_ids, *d_fx, *d_sx, *d_kids, *d_kb;
+  FrontDesc* d_td;
+  if ((rc = is_stage(S, ids, &d_ids)) || (rc = is_stage(S, td, &d_td)) || (rc = is_stage(S, fx, &d_fx)) || (rc = is_stage(S, sx, &d_sx)) ||
+      (rc = is_stage(S, kids, &d_kids)) || (rc = is_stage(S, kids_begin, &d_kb)))
+    return rc;
+  hipLaunchKernelGGL(isam2_tree_patch_kernel, dim3((unsigned)ids.size()), dim3(256), 0, S->stream, (const int32_t*)d_ids, (const FrontDesc*)d_td,
+                     (const int32_t*)d_fx, (const int32_t*)d_sx, (const int32_t*)d_kids, (const int32_t*)d_kb, S->d_tree, S->d_tree_fx, S->d_tree_sx,
+                     S->pool);
   return LMGPU_OK;
 }
 
 // ISAM2::updateDelta (gtsam/nonlinear/ISAM2.cpp:701-719) -> DeltaImpl::UpdateGaussNewtonDelta (ISAM2-impl.cpp:47-77)
 int is_update_delta(lmgpu_isam2* S, bool force_full) {
-  int rc = is_sync_tree(S);
+  int rc = is_patch_tree(S);
   if (rc) return rc;
   if (S->ntot == 0) return LMGPU_OK;
   const double thr = force_full ? 0.0 : S->prm.wildfireThreshold;
   ISCHECK(hipMemsetAsync(S->d_changed, 0, (size_t)S->ntot, S->stream));
   ISCHECK(hipMemsetAsync(S->d_status, 0x7f, sizeof(int), S->stream));
-  if (S->tree_count > 0) {
-    const size_t nflags = S->clq.size() + 1;
-    ISCHECK(hipMemsetAsync(S->d_tree_done, 0, nflags * sizeof(unsigned int), S->stream));
-    hipLaunchKernelGGL(isam2_wildfire_kernel, dim3(S->tree_count), dim3(256), (S->tree_lds + LDSB_TAIL) * sizeof(double), S->stream,
-                       (const int32_t*)S->d_tree_list, (const FrontDesc*)S->d_tree, (const int32_t*)S->d_tree_fx, (const int32_t*)S->d_tree_sx,
-                       (const double*)S->pool, S->delta, (const unsigned char*)S->d_replaced, S->d_changed, thr, S->d_status, S->d_tree_done,
-                       S->d_tree_done + S->clq.size());
+  if (!S->roots.empty()) {
+    // the walk starts at every root (ISAM2-impl.cpp:60-66): queue[0 .. r) = roots, tail = r, next ticket = 0, unfinished = r
+    const unsigned int r = (unsigned int)S->roots.size();
+    const unsigned int ctl[4] = {r, 0u, r, 0u};
+    if ((rc = is_push(S, S->d_queue, S->roots.data(), r * sizeof(int32_t)))) return rc;
+    if ((rc = is_push(S, S->d_wl, ctl, sizeof(ctl)))) return rc;
+    hipLaunchKernelGGL(isam2_wildfire_kernel, dim3(ISAM2_WL_GROUPS), dim3(256), (S->tree_lds + LDSB_TAIL) * sizeof(double), S->stream, S->d_queue, S->d_wl,
+                       (const FrontDesc*)S->d_tree, (const int32_t*)S->d_tree_fx, (const int32_t*)S->d_tree_sx, (const double*)S->pool, S->delta,
+                       (const unsigned char*)S->d_replaced, S->d_changed, thr, S->d_status);
   }
   ISCHECK(hipMemsetAsync(S->d_replaced, 0, (size_t)S->ntot, S->stream));
   ISCHECK(hipMemcpyAsync(S->h_status, S->d_status, sizeof(int), hipMemcpyDeviceToHost, S->stream));
@@ -569,6 +640,7 @@ int is_eliminate(lmgpu_isam2* S, const std::vector<IsGF>& gfs, const std::vector
     const SymbolicFronts::F& fr = sf.fronts[fi];
     const int id = is_new_clique(S);
     cid[fi] = id;
+    S->touched.push_back(id);  // its descriptor reaches the device copy of the tree with the next patch
     lmgpu_isam2::Clq& c = S->clq[id];
     for (int32_t s : fr.frontals) c.vars.push_back(vid_of_slot[s]);
     c.nfv = (int)fr.frontals.size();
@@ -940,7 +1012,7 @@ int is_update(lmgpu_isam2* S, bool force_relinearize, lmgpu_isam2_result* result
     for (int id : bn)
       for (int k = 0; k < S->clq[id].nfv; k++) affected.push_back(S->clq[id].vars[k]);
     for (int id : bn) is_release_clique(S, id);
-    S->tree_dirty = true;
+
     std::set<int32_t> affectedSet;
     if ((double)affected.size() >= (double)S->vars.size() * 0.65) {
       // ---- recalculateBatch :178-247: reorder, relinearize and re-eliminate everything
@@ -1106,7 +1178,7 @@ int lmgpu_isam2_destroy(lmgpu_isam2* S) {
       if (b.d_noise) (void)hipFree(b.d_noise);
     }
     for (void* p : {(void*)S->delta, (void*)S->ones, (void*)S->d_replaced, (void*)S->d_changed, (void*)S->pool, (void*)S->d_status, (void*)S->d_tree,
-                    (void*)S->d_tree_fx, (void*)S->d_tree_sx, (void*)S->d_tree_list, (void*)S->d_tree_done})
+                    (void*)S->d_tree_fx, (void*)S->d_tree_sx, (void*)S->d_queue, (void*)S->d_wl})
       if (p) (void)hipFree(p);
     if (S->h_status) (void)hipHostFree(S->h_status);
     if (S->h_delta) (void)hipHostFree(S->h_delta);
