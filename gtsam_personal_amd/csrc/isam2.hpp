@@ -65,6 +65,12 @@ struct lmgpu_isam2 {
     std::vector<int32_t> vars;  // vids: frontals (elimination order), then separators ascending by key (Scatter order)
     int32_t nfv = 0, nf = 0, n = 0;
     int64_t rsd_off = -1, u_off = -1;
+    // ld == 0: an LDS clique -- [R S d] nf x n at rsd_off, the update matrix (n - nf)^2 at u_off, both dense.
+    // ld > 0: a clique of more than 139 scalar columns, eliminated in place in ONE n x ld block of the pool (f_off) by the dense-front
+    //         kernels of the batch path: rsd_off = f_off (rows 0 .. nf-1), u_off = f_off + nf ld + nf (the trailing block), stride ld.
+    int32_t ld = 0;
+    int64_t f_off = -1;
+    int64_t xrow_off = -1;  // ld > 0: pool offset of its delta offsets as int32 [nf frontal | n - nf - 1 separator] (too long for a tree row)
     int64_t kids_off = -1;  // pool offset (doubles) of the children's clique ids as int32 (the wildfire kernel pushes them), -1: none
     int32_t kids_n = 0;
     std::vector<int32_t> children;
@@ -104,6 +110,7 @@ struct lmgpu_isam2 {
   char *h_stage = nullptr, *d_stage = nullptr;
   size_t stage_cap = 0, stage_used = 0, stage_want = 0;
   std::vector<std::pair<void*, void*>> stage_extra;  // (pinned host, device)
+  double* inv16 = nullptr;    // 16 x 256 doubles: the 16 x 16 inverses of the panel being factored (wide cliques)
   double* h_delta = nullptr;  // pinned copy of delta for CheckRelinearizationFull
   size_t h_delta_cap = 0;
   // LMGPU_ISAM2_TRACE=1: wall time per phase of update(), printed when the handle is destroyed (development aid)
@@ -254,8 +261,16 @@ int is_new_clique(lmgpu_isam2* S) {
 }
 void is_release_clique(lmgpu_isam2* S, int id) {
   lmgpu_isam2::Clq& c = S->clq[id];
-  is_pool_free(S, c.rsd_off, (size_t)c.nf * c.n);
-  is_pool_free(S, c.u_off, (size_t)(c.n - c.nf) * (c.n - c.nf));
+  if (c.ld > 0) {
+    is_pool_free(S, c.f_off, (size_t)c.n * c.ld);
+  } else {
+    is_pool_free(S, c.rsd_off, (size_t)c.nf * c.n);
+    is_pool_free(S, c.u_off, (size_t)(c.n - c.nf) * (c.n - c.nf));
+  }
+  if (c.xrow_off >= 0) is_pool_free(S, c.xrow_off, (size_t)c.n / 2 + 1);
+  c.xrow_off = -1;
+  c.ld = 0;
+  c.f_off = -1;
   if (c.kids_off >= 0) is_pool_free(S, c.kids_off, (size_t)(c.kids_n + 1) / 2);
   c.kids_off = -1;
   c.kids_n = 0;
@@ -342,14 +357,19 @@ __global__ __launch_bounds__(256) void isam2_mark_kernel(const int32_t* __restri
 __global__ __launch_bounds__(256) void isam2_tree_patch_kernel(const int32_t* __restrict__ ids, const lmgpu::FrontDesc* __restrict__ td,
                                                                 const int32_t* __restrict__ fx, const int32_t* __restrict__ sx,
                                                                 const int32_t* __restrict__ kids, const int32_t* __restrict__ kids_begin,
-                                                                lmgpu::FrontDesc* __restrict__ tree, int32_t* __restrict__ tree_fx,
-                                                                int32_t* __restrict__ tree_sx, double* __restrict__ pool) {
+                                                                const int32_t* __restrict__ xrow_begin, lmgpu::FrontDesc* __restrict__ tree,
+                                                                int32_t* __restrict__ tree_fx, int32_t* __restrict__ tree_sx, double* __restrict__ pool) {
   const int i = blockIdx.x, id = ids[i], tid = threadIdx.x;
   const lmgpu::FrontDesc F = td[i];
   if (tid == 0) tree[id] = F;
   const int nf = F.nf, ns = F.n - F.nf - 1;
-  if (tid < nf) tree_fx[(size_t)id * ISAM2_TREE_ROW + tid] = fx[(size_t)i * ISAM2_TREE_ROW + tid];
-  if (tid < ns) tree_sx[(size_t)id * ISAM2_TREE_ROW + tid] = sx[(size_t)i * ISAM2_TREE_ROW + tid];
+  if (F.par_ld == 0) {  // an LDS clique: its delta offsets in the fixed-stride rows
+    if (tid < nf) tree_fx[(size_t)id * ISAM2_TREE_ROW + tid] = fx[(size_t)i * ISAM2_TREE_ROW + tid];
+    if (tid < ns) tree_sx[(size_t)id * ISAM2_TREE_ROW + tid] = sx[(size_t)i * ISAM2_TREE_ROW + tid];
+  } else {  // a wide clique: [frontal | separator] offsets in an array of its own in the pool (par_off)
+    int32_t* xr = (int32_t*)(pool + F.par_off);
+    for (int k = tid; k < nf + ns; k += 256) xr[k] = kids[xrow_begin[i] + k];
+  }
   int32_t* dst = (int32_t*)(pool + F.child_begin);
   for (int k = tid; k < F.child_count; k += 256) dst[k] = kids[kids_begin[i] + k];
 }
@@ -407,18 +427,92 @@ __global__ __launch_bounds__(256) void isam2_wildfire_kernel(int32_t* __restrict
     }
     const lmgpu::FrontDesc F = tree[id];
     const int n = F.n, nf = F.nf, ns = n - nf - 1;
-    const int32_t* fxr = tree_fx + (size_t)id * ISAM2_TREE_ROW;
-    const int32_t* sxr = tree_sx + (size_t)id * ISAM2_TREE_ROW;
+    const bool wide = F.par_ld != 0;  // more than 139 scalar columns: offsets in the pool, [R S d] walked from memory
+    const int32_t* fxr = wide ? (const int32_t*)(pool + F.par_off) : tree_fx + (size_t)id * ISAM2_TREE_ROW;
+    const int32_t* sxr = wide ? fxr + nf : tree_sx + (size_t)id * ISAM2_TREE_ROW;
     const int so = ns > 0 ? sxr[min(tid, ns - 1)] : 0, fo = fxr[min(tid, nf - 1)];
     const bool is_replaced = replaced[fxr[0]] != 0;
     if (tid == 0) flag = (threshold <= 0.0 || is_replaced) ? 1 : 0;
     __syncthreads();
     if (!(threshold <= 0.0 || is_replaced)) {
-      if (tid < ns && changed[so]) flag = 1;  // benign race: every writer stores 1   (ns <= 138 < 256)
+      for (int j = tid; j < ns; j += 256)
+        if (changed[sxr[j]]) flag = 1;  // benign race: every writer stores 1
       __syncthreads();
     }
     const bool dirty = flag != 0;  // workgroup-uniform
-    if (dirty) {
+    if (dirty && wide) {
+      // A clique too wide for the LDS staging (rare: loop closures of large graphs): x_S and y in LDS, R / S streamed from memory by this
+      // one workgroup -- y = d - S x_S one wave per row, then 64 unknowns at a time (the diagonal block staged in LDS, the readlane
+      // chain of the LDS path), the rows above each block folded by all waves.
+      double* xs = Ls;               // [ns]
+      double* y = Ls + ns;           // [nf]
+      double* Db = Ls + ns + nf;     // [64][65]
+      const double* A = pool + F.rsd_off;
+      const int ld = F.ld_rsd;
+      for (int j = tid; j < ns; j += 256) xs[j] = delta[sxr[j]];
+      __syncthreads();
+      for (int i = w; i < nf; i += 4) {
+        const double* row = A + (size_t)i * ld;
+        double a = 0.0;
+        for (int j = lane; j < ns; j += 64) a += row[nf + j] * xs[j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+        if (lane == 0) y[i] = row[n - 1] - a;
+      }
+      __syncthreads();
+      bool bad = false;
+      for (int b = (nf + 63) / 64 - 1; b >= 0; b--) {
+        const int r0 = 64 * b, nb = min(64, nf - r0);
+        for (int idx = tid; idx < 64 * 64; idx += 256) {
+          const int p = idx >> 6, q = idx & 63;
+          const double v = A[(size_t)(r0 + min(p, nb - 1)) * ld + r0 + min(q, nb - 1)];
+          Db[p * 65 + q] = (p < nb && q < nb && q >= p) ? v : ((p == q) ? 1.0 : 0.0);
+        }
+        __syncthreads();
+        if (w == 0) {
+          const double rd = 1.0 / Db[lane * 65 + lane];
+          double yi = (lane < nb) ? y[r0 + lane] * rd : 0.0;
+          for (int k0 = 63; k0 >= 0; k0 -= 8) {
+            double cf[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+              const double c = Db[lane * 65 + k0 - u];
+              cf[u] = (lane < k0 - u) ? c * rd : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) yi = fma(-cf[u], lmgpu::readlane_dyn(yi, k0 - u), yi);
+          }
+          if (lane < nb) {
+            y[r0 + lane] = yi;
+            if (yi != yi) bad = true;
+          }
+        }
+        __syncthreads();
+        for (int i = w; i < r0; i += 4) {
+          const double a0 = (lane < nb) ? A[(size_t)i * ld + r0 + lane] * y[r0 + lane] : 0.0;
+          double a = a0;
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+          if (lane == 0) y[i] -= a;
+        }
+        __syncthreads();
+      }
+      double md = 0.0;
+      for (int i = tid; i < nf; i += 256) md = fmax(md, fabs(delta[fxr[i]] - y[i]));
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) md = fmax(md, __shfl_xor(md, o));
+      if (lane == 0) red[w] = md;
+      __syncthreads();
+      const double mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+      if (bad && lane == 0) atomicMin(status, F.id);
+      const bool keep = threshold <= 0.0 || is_replaced || mx >= threshold;
+      if (keep)
+        for (int i = tid; i < nf; i += 256) {
+          const int xo = fxr[i];
+          delta[xo] = y[i];
+          changed[xo] = 1;
+        }
+    } else if (dirty) {
       lmgpu::ldsb_stage(F, pool, Ls, tid);
       bool bad;
       const double* x = lmgpu::ldsb_solve_core(F, Ls, ns > 0 ? so : fo, delta, &bad);
@@ -484,7 +578,7 @@ int is_patch_tree(lmgpu_isam2* S) {
   if (!S->d_wl) ISCHECK(hipMalloc((void**)&S->d_wl, 4 * sizeof(unsigned int)));
   std::sort(S->touched.begin(), S->touched.end());
   S->touched.erase(std::unique(S->touched.begin(), S->touched.end()), S->touched.end());
-  std::vector<int32_t> ids, fx, sx, kids, kids_begin;
+  std::vector<int32_t> ids, fx, sx, kids, kids_begin, xrow_begin;
   std::vector<FrontDesc> td;
   for (int32_t id : S->touched) {
     lmgpu_isam2::Clq& c = S->clq[id];
@@ -503,20 +597,33 @@ int is_patch_tree(lmgpu_isam2* S) {
     F.n = c.n;
     F.nf = c.nf;
     F.rsd_off = c.rsd_off;
-    F.ld_rsd = c.n;
+    F.ld_rsd = c.ld > 0 ? c.ld : c.n;
     F.id = id;
     F.child_begin = c.kids_n > 0 ? (int32_t)c.kids_off : 0;
     F.child_count = c.kids_n;
-    S->tree_lds = std::max(S->tree_lds, (size_t)c.nf * (size_t)(c.n | 1));
+    if (c.ld > 0)  // walked from memory by one workgroup (isam2_wildfire_kernel): x_S, y and one 64 x 64 diagonal block in LDS
+      S->tree_lds = std::max(S->tree_lds, (size_t)c.n + 64 * 65 + 64);
+    else
+      S->tree_lds = std::max(S->tree_lds, (size_t)c.nf * (size_t)(c.n | 1));
     const size_t row = ids.size() * ISAM2_TREE_ROW;
     fx.resize(row + ISAM2_TREE_ROW, 0);
     sx.resize(row + ISAM2_TREE_ROW, 0);
-    int o = 0;
-    for (int k = 0; k < c.nfv; k++)
-      for (int d = 0; d < kVarDim[S->vars[c.vars[k]].type]; d++) fx[row + o++] = S->vars[c.vars[k]].xoff + d;
-    o = 0;
-    for (size_t k = c.nfv; k < c.vars.size(); k++)
-      for (int d = 0; d < kVarDim[S->vars[c.vars[k]].type]; d++) sx[row + o++] = S->vars[c.vars[k]].xoff + d;
+    if (c.ld == 0) {
+      int o = 0;
+      for (int k = 0; k < c.nfv; k++)
+        for (int d = 0; d < kVarDim[S->vars[c.vars[k]].type]; d++) fx[row + o++] = S->vars[c.vars[k]].xoff + d;
+      o = 0;
+      for (size_t k = c.nfv; k < c.vars.size(); k++)
+        for (int d = 0; d < kVarDim[S->vars[c.vars[k]].type]; d++) sx[row + o++] = S->vars[c.vars[k]].xoff + d;
+      xrow_begin.push_back(0);
+    } else {
+      if (c.xrow_off < 0 && (rc = is_pool_alloc(S, (size_t)c.n / 2 + 1, &c.xrow_off))) return rc;
+      F.par_off = c.xrow_off;
+      F.par_ld = 1;
+      xrow_begin.push_back((int32_t)kids.size());
+      for (size_t k = 0; k < c.vars.size(); k++)
+        for (int d = 0; d < kVarDim[S->vars[c.vars[k]].type]; d++) kids.push_back(S->vars[c.vars[k]].xoff + d);
+    }
     kids_begin.push_back((int32_t)kids.size());
     kids.insert(kids.end(), c.children.begin(), c.children.end());
     ids.push_back(id);
@@ -524,14 +631,14 @@ int is_patch_tree(lmgpu_isam2* S) {
   }
   S->touched.clear();
   if (ids.empty()) return LMGPU_OK;
-  int32_t *d_ids, *d_fx, *d_sx, *d_kids, *d_kb;
+  int32_t *d_ids, *d_fx, *d_sx, *d_kids, *d_kb, *d_xb;
   FrontDesc* d_td;
   if ((rc = is_stage(S, ids, &d_ids)) || (rc = is_stage(S, td, &d_td)) || (rc = is_stage(S, fx, &d_fx)) || (rc = is_stage(S, sx, &d_sx)) ||
-      (rc = is_stage(S, kids, &d_kids)) || (rc = is_stage(S, kids_begin, &d_kb)))
+      (rc = is_stage(S, kids, &d_kids)) || (rc = is_stage(S, kids_begin, &d_kb)) || (rc = is_stage(S, xrow_begin, &d_xb)))
     return rc;
   hipLaunchKernelGGL(isam2_tree_patch_kernel, dim3((unsigned)ids.size()), dim3(256), 0, S->stream, (const int32_t*)d_ids, (const FrontDesc*)d_td,
-                     (const int32_t*)d_fx, (const int32_t*)d_sx, (const int32_t*)d_kids, (const int32_t*)d_kb, S->d_tree, S->d_tree_fx, S->d_tree_sx,
-                     S->pool);
+                     (const int32_t*)d_fx, (const int32_t*)d_sx, (const int32_t*)d_kids, (const int32_t*)d_kb, (const int32_t*)d_xb, S->d_tree,
+                     S->d_tree_fx, S->d_tree_sx, S->pool);
   return LMGPU_OK;
 }
 
@@ -654,11 +761,15 @@ int is_eliminate(lmgpu_isam2* S, const std::vector<IsGF>& gfs, const std::vector
     }
     c.n = off + 1;
     if (c.n > kLdsLimitN) {
-      S->err = "ISAM2: a clique of " + std::to_string(c.n) + " scalar columns exceeds the incremental path's limit of " + std::to_string(kLdsLimitN);
-      return LMGPU_INVALID;
+      // wider than an LDS front (loop closures of large graphs): one n x ld block, eliminated in place by the dense-front kernels
+      c.ld = (c.n + 15) & ~15;
+      if ((rc = is_pool_alloc(S, (size_t)c.n * c.ld, &c.f_off))) return rc;
+      c.rsd_off = c.f_off;
+      c.u_off = c.f_off + (int64_t)c.nf * c.ld + c.nf;
+    } else {
+      if ((rc = is_pool_alloc(S, (size_t)c.nf * c.n, &c.rsd_off))) return rc;
+      if ((rc = is_pool_alloc(S, (size_t)(c.n - c.nf) * (c.n - c.nf), &c.u_off))) return rc;
     }
-    if ((rc = is_pool_alloc(S, (size_t)c.nf * c.n, &c.rsd_off))) return rc;
-    if ((rc = is_pool_alloc(S, (size_t)(c.n - c.nf) * (c.n - c.nf), &c.u_off))) return rc;
     for (int k = 0; k < c.nfv; k++) S->node_of[c.vars[k]] = id;
     FrontDesc& F = fds[fi];
     F = FrontDesc{};
@@ -666,15 +777,15 @@ int is_eliminate(lmgpu_isam2* S, const std::vector<IsGF>& gfs, const std::vector
     F.nf = c.nf;
     F.rsd_off = c.rsd_off;
     F.u_off = c.u_off;
-    F.ld_rsd = c.n;
-    F.ld_u = c.n - c.nf;
+    F.ld_rsd = c.ld > 0 ? c.ld : c.n;
+    F.ld_u = c.ld > 0 ? c.ld : c.n - c.nf;
     F.id = fi;
     F.fac_begin = (int)ffac.size();
     F.child_begin = (int)childs.size();
     auto add_child = [&](const lmgpu_isam2::Clq& ch) {  // its cached factor (update matrix) is extend-added through a column map
       ChildRef cr{};
       cr.u_off = ch.u_off;
-      cr.ld = ch.n - ch.nf;
+      cr.ld = ch.ld > 0 ? ch.ld : ch.n - ch.nf;
       cr.m = ch.n - ch.nf;
       cr.map_begin = (int)cmap.size();
       for (size_t k = ch.nfv; k < ch.vars.size(); k++)
@@ -730,17 +841,82 @@ int is_eliminate(lmgpu_isam2* S, const std::vector<IsGF>& gfs, const std::vector
   int32_t *d_cmap = nullptr, *d_fxoff = nullptr, *d_list = nullptr;
   std::vector<int32_t> list;
   std::vector<std::pair<int, int>> lv(max_level + 1, {0, 0});
+  std::vector<std::vector<int32_t>> wide(max_level + 1);  // per level: the fronts of more than 139 columns
   for (int l = 0; l <= max_level; l++) {
     lv[l].first = (int)list.size();
-    for (int fi = 0; fi < NF; fi++)
-      if (sf.fronts[fi].level == l) list.push_back(fi);
+    for (int fi = 0; fi < NF; fi++) {
+      if (sf.fronts[fi].level != l) continue;
+      if (S->clq[cid[fi]].ld > 0)
+        wide[l].push_back(fi);
+      else
+        list.push_back(fi);
+    }
     lv[l].second = (int)list.size() - lv[l].first;
+  }
+  // wide fronts are assembled by one wave per row walking that row's sources in a fixed order (hbm_assemble_rows_kernel, as in the batch path)
+  std::vector<int32_t> rowptr;
+  std::vector<RowSrc> rowsrc;
+  std::map<int32_t, int32_t> row_begin;  // front -> start of its n + 1 row pointers
+  for (int l = 0; l <= max_level; l++)
+    for (int32_t fi : wide[l]) {
+      const FrontDesc& F = fds[fi];
+      std::vector<std::vector<RowSrc>> rows(F.n);
+      for (int k = 0; k < F.child_count; k++) {
+        const ChildRef& c = childs[F.child_begin + k];
+        for (int i = 0; i < c.m; i++) rows[cmap[c.map_begin + i]].push_back(RowSrc{F.child_begin + k, i});
+      }
+      for (int k = 0; k < F.fac_count; k++) {
+        const FrontFac& ff = ffac[F.fac_begin + k];
+        const FacDesc& d = fd[ff.fac];
+        const int nc = d.d0 + d.d1 + 1;
+        for (int p = 0; p < nc; p++) {
+          const int gp = (p < d.d0) ? ff.c0 + p : (p < d.d0 + d.d1 ? ff.c1 + (p - d.d0) : F.n - 1);
+          rows[gp].push_back(RowSrc{-(F.fac_begin + k) - 1, p});
+        }
+      }
+      row_begin[fi] = (int32_t)rowptr.size();
+      for (int r = 0; r < F.n; r++) {
+        rowptr.push_back((int32_t)rowsrc.size());
+        rowsrc.insert(rowsrc.end(), rows[r].begin(), rows[r].end());
+      }
+      rowptr.push_back((int32_t)rowsrc.size());
+    }
+  int32_t* d_rowptr = nullptr;
+  RowSrc* d_rowsrc = nullptr;
+  if (!rowptr.empty()) {
+    if ((rc = is_stage(S, rowptr, &d_rowptr)) || (rc = is_stage(S, rowsrc, &d_rowsrc))) return rc;
+    if (!S->inv16) ISCHECK(hipMalloc((void**)&S->inv16, 16 * 256 * sizeof(double)));
   }
   if ((rc = is_stage(S, fds, &d_fds)) || (rc = is_stage(S, ffac, &d_ffac)) || (rc = is_stage(S, fd, &d_fd)) || (rc = is_stage(S, childs, &d_childs)) ||
       (rc = is_stage(S, cmap, &d_cmap)) || (rc = is_stage(S, fxoff, &d_fxoff)) || (rc = is_stage(S, list, &d_list)))
     return rc;
   ISCHECK(hipMemsetAsync(S->d_status, 0x7f, sizeof(int), S->stream));
   for (int l = 0; l <= max_level; l++) {
+    for (int32_t fi : wide[l]) {  // (the level's LDS fronts and these only depend on the levels below)
+      const FrontDesc& F = fds[fi];
+      const lmgpu_isam2::Clq& c = S->clq[cid[fi]];
+      const int ld = c.ld, n = c.n;
+      double* A = S->pool + c.f_off;
+      ISCHECK(hipMemsetAsync(A, 0, (size_t)n * ld * sizeof(double), S->stream));
+      hipLaunchKernelGGL(hbm_assemble_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, S->stream, F, c.f_off, ld, (const int32_t*)(d_rowptr + row_begin[fi]),
+                         (const RowSrc*)d_rowsrc, (const ChildRef*)d_childs, (const int32_t*)d_cmap, (const FrontFac*)d_ffac, (const FacDesc*)d_fd, S->pool, 1);
+      // right-looking over 256-row outer panels, the two-launch panel form + the trailing update (lmgpu.hip: panel_alone / the unfused step)
+      const int np = (F.nf + NBO - 1) / NBO;
+      for (int i = 0; i < np; i++) {
+        const int k0 = i * NBO, kb = std::min(F.nf, (i + 1) * NBO) - k0, r0 = k0 + kb, cols = n - r0, m = n - r0;
+        hipLaunchKernelGGL(diag_potrf_kernel, dim3(1), dim3(256), DIAG_LDS_BYTES, S->stream, A, ld, F.nf, k0, kb, F.id, S->d_status, S->inv16);
+        if (cols > 0) hipLaunchKernelGGL(panel_trsm_kernel, dim3((cols + 63) / 64), dim3(256), 0, S->stream, A, ld, n, k0, kb, (const double*)S->inv16);
+        if (m > 0) {
+          if (m <= 1024) {
+            const int Sx = (m + 63) / 64;
+            hipLaunchKernelGGL(syrk_quadrants_kernel, dim3(4 * Sx, Sx), dim3(256), 0, S->stream, A, ld, n, k0, kb, r0);
+          } else {
+            const int T = (m + 127) / 128;
+            hipLaunchKernelGGL(syrk_mfma_kernel, dim3(T, T), dim3(256), kSyrkLds, S->stream, A, ld, n, k0, kb, r0, n);
+          }
+        }
+      }
+    }
     if (lv[l].second == 0) continue;
     int nmax = 1, jc = 96;
     for (int q = 0; q < lv[l].second; q++) {
@@ -1155,6 +1331,8 @@ int lmgpu_isam2_create(const lmgpu_config* cfg, const lmgpu_isam2_params* prm, l
   ISCHECK(hipHostMalloc((void**)&S->h_status, sizeof(int)));
   ISCHECK(hipFuncSetAttribute((const void*)lds_front_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra + 64));
   ISCHECK(hipFuncSetAttribute((const void*)isam2_wildfire_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (kLdsLimitN * kLdsLimitN + LDSB_TAIL) * 8));
+  ISCHECK(hipFuncSetAttribute((const void*)diag_potrf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
+  ISCHECK(hipFuncSetAttribute((const void*)syrk_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSyrkLds));
   return LMGPU_OK;
 }
 
@@ -1178,7 +1356,7 @@ int lmgpu_isam2_destroy(lmgpu_isam2* S) {
       if (b.d_noise) (void)hipFree(b.d_noise);
     }
     for (void* p : {(void*)S->delta, (void*)S->ones, (void*)S->d_replaced, (void*)S->d_changed, (void*)S->pool, (void*)S->d_status, (void*)S->d_tree,
-                    (void*)S->d_tree_fx, (void*)S->d_tree_sx, (void*)S->d_queue, (void*)S->d_wl})
+                    (void*)S->d_tree_fx, (void*)S->d_tree_sx, (void*)S->d_queue, (void*)S->d_wl, (void*)S->inv16})
       if (p) (void)hipFree(p);
     if (S->h_status) (void)hipHostFree(S->h_status);
     if (S->h_delta) (void)hipHostFree(S->h_delta);
@@ -1336,9 +1514,11 @@ int lmgpu_isam2_get_clique(lmgpu_isam2* S, int32_t i, uint64_t* keys, double* RS
   if (RSd_colmajor) {
     if (S->device < 0) return LMGPU_HIP_ERROR;
     std::vector<double> rm((size_t)c.nf * c.n);
+    const int ldr = c.ld > 0 ? c.ld : c.n;
+    rm.resize((size_t)c.nf * ldr);
     ISCHECK(hipMemcpy(rm.data(), S->pool + c.rsd_off, rm.size() * sizeof(double), hipMemcpyDeviceToHost));
     for (int r = 0; r < c.nf; r++)
-      for (int j = 0; j < c.n; j++) RSd_colmajor[(size_t)j * c.nf + r] = rm[(size_t)r * c.n + j];
+      for (int j = 0; j < c.n; j++) RSd_colmajor[(size_t)j * c.nf + r] = (j >= r) ? rm[(size_t)r * ldr + j] : 0.0;
   }
   return LMGPU_OK;
 }

@@ -145,3 +145,58 @@ def test_incremental_pose_graph_like_time_incremental():
     assert isam.size() == n_poses
     compare_state(isam, orc)
     isam.close()
+
+
+def dense_pose2_steps(n_poses=60, seed=3):
+    """a graph in which every new pose is tied to EVERY earlier one (one pose per update): the top clique holds all poses, i.e. it
+    outgrows an LDS front (139 scalar columns) at pose 47"""
+    from gtsam_personal_amd import NonlinearFactorGraph, Values, noiseModel
+    rng = np.random.default_rng(seed)
+    truth = [np.array([2.0 * np.cos(0.3 * i) * (1 + 0.05 * i), 2.0 * np.sin(0.3 * i) * (1 + 0.05 * i), 0.3 * i + 1.0]) for i in range(n_poses)]
+
+    def between(a, b):
+        c, s_ = np.cos(a[2]), np.sin(a[2])
+        dx, dy = b[0] - a[0], b[1] - a[1]
+        th = b[2] - a[2]
+        return np.array([c * dx + s_ * dy, -s_ * dx + c * dy, np.arctan2(np.sin(th), np.cos(th))])
+
+    model = noiseModel.Diagonal.Sigmas([0.1, 0.1, 0.05])
+    steps = []
+    for i in range(n_poses):
+        g, v = NonlinearFactorGraph(), Values()
+        if i == 0:
+            g.add_PriorFactorPose2(0, truth[0], noiseModel.Diagonal.Sigmas([0.01, 0.01, 0.01]))
+        for j in range(i):
+            g.add_BetweenFactorPose2(j, i, between(truth[j], truth[i]) + rng.normal(0, 0.01, 3), model)
+        v.insert_pose2(i, *(truth[i] + rng.normal(0, 0.05, 3)))
+        steps.append((g, v))
+    return steps
+
+
+def test_cliques_wider_than_an_lds_front():
+    """a clique of more than 139 scalar columns is eliminated in place by the dense-front kernels of the batch path (assembly by row,
+    256-row panels, trailing updates on the matrix cores) and walked from memory by the wildfire; smaller cliques above and below it
+    extend-add its update matrix as they do any other.  Compared with the oracle update by update like every other sequence."""
+    steps = dense_pose2_steps()
+    isam, orc = run_sequence(steps, ISAM2Params(relinearizeThreshold=0.05, relinearizeSkip=2), check_every_step=False)
+    widest = max(R.shape[1] for _, _, R, _ in isam.cliques())
+    assert widest > 139, widest
+    # a few more updates on top of the wide tree: incremental paths through a wide clique (cached boundary factors, orphans)
+    assert isam.update(force_relinearize=True).as_dict() == orc.update(force_relinearize=True)
+    compare_state(isam, orc)
+    isam.close()
+
+
+def test_full_city10000_incremental_run():
+    """timing/timeIncremental.cpp's workload: all 10 000 poses of city10000, one per update (tools/isam2_long_run.py), the same updates
+    replayed through the oracle: identical Bayes tree (7 939 cliques after the closing batch step, the widest 298 columns -- the
+    dense-front fallback), identical counts of the last update, estimate within 1e-6."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("isam2_long_run", os.path.join(os.path.dirname(__file__), "..", "tools", "isam2_long_run.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.run(10000, check=True, verbose=False)
+    assert res["stopped"] is None, res
+    assert res["updates"] == 9999 and res["same_tree"] and res["last_counts_equal"], res
+    assert res["max_rel_diff"] < 1e-6 and res["widest_clique"] > 139, res
