@@ -78,6 +78,7 @@ struct lmgpu_isam2 {
     bool alive = false;
   };
   std::vector<Clq> clq;
+  int n_alive = 0;  // cliques alive = cliques of the tree once an update has re-attached its orphans (ISAM2Result's clique count)
   std::vector<int32_t> free_clq, roots, node_of;  // node_of: per variable the clique it is frontal in (-1: none yet)
   std::vector<char> replaced;                     // deltaReplacedMask_, per variable
   bool any_replaced = false;
@@ -257,6 +258,7 @@ int is_new_clique(lmgpu_isam2* S) {
     S->clq.emplace_back();
   }
   S->clq[id].alive = true;
+  S->n_alive++;
   return id;
 }
 void is_release_clique(lmgpu_isam2* S, int id) {
@@ -275,6 +277,7 @@ void is_release_clique(lmgpu_isam2* S, int id) {
   c.kids_off = -1;
   c.kids_n = 0;
   c.alive = false;
+  S->n_alive--;
   c.children.clear();
   c.vars.clear();
   S->free_clq.push_back(id);
@@ -958,11 +961,6 @@ int is_finish_elimination(lmgpu_isam2* S) {
   return LMGPU_OK;
 }
 
-int is_count_subtree(const lmgpu_isam2* S, int id) {
-  int n = 1;
-  for (int ch : S->clq[id].children) n += is_count_subtree(S, ch);
-  return n;
-}
 
 // upload an index list and run `fn(device list, count)`
 template <typename Fn>
@@ -1297,8 +1295,7 @@ int is_update(lmgpu_isam2* S, bool force_relinearize, lmgpu_isam2_result* result
       return rc;
     S->any_replaced = S->any_replaced || !affectedSet.empty();
   }
-  res.cliques = 0;
-  for (int r : S->roots) res.cliques += is_count_subtree(S, r);
+  res.cliques = S->n_alive;  // (every alive clique hangs in the tree again by now; counting them by a walk was O(cliques) per update)
   if (result) *result = res;
   lap(5);
   rc = is_finish_elimination(S);  // the one wait of an update without relinearization
