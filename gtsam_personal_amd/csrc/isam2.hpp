@@ -10,12 +10,16 @@
 //   device  theta, delta, the linearization cache ([A b] per factor = linearFactors_), [R S d] and the cached separator factor of
 //           every clique (ISAM2Clique::cachedFactor_); kernels: the bucket factor kernels on an index list (relinearizeAffectedFactors
 //           :66-114, linearizeNewFactors), retract on an index list (retractMasked :465), lds_front_kernel per level of the new
-//           cliques (own Jacobians + cached boundary factors / children as extend-add), isam2_wildfire_kernel per tree depth
-//           (optimizeWildfireNonRecursive, ISAM2Clique.cpp:211-268).
+//           cliques (own Jacobians + cached boundary factors / children as extend-add; cliques of more than 139 scalar columns go
+//           through the dense-front kernels instead: hbm_assemble_rows_kernel, diag_potrf_kernel / panel_trsm_kernel, the MFMA
+//           trailing update), isam2_wildfire_kernel = the top-down walk as a device-side work list over the dirty part of the tree
+//           (optimizeWildfireNonRecursive, ISAM2Clique.cpp:211-268), isam2_tree_patch_kernel = the device copy of the tree, patched.
 // Storage: one pool of doubles (offsets, so it can grow): Jacobian regions per factor bucket, [R S d] + update matrix per clique
-// with exact-size free lists (clique shapes repeat in SLAM).
-// Limits of this round (fail loudly): Gauss-Newton params, Cholesky, no factor removal / marginalization / fixed variables;
-// cliques of more than 139 scalar columns (the LDS front kernel's limit) are rejected.
+// (one dense block for a wide clique) with exact-size free lists (clique shapes repeat in SLAM), the children lists of the cliques.
+// Everything an update sends to the device goes through a pinned staging arena: no allocation, one wait per update (two with
+// relinearization).
+// Limits (fail loudly): Gauss-Newton params, Cholesky, no factor removal / marginalization / fixed variables, factors of at most two
+// variables.
 #pragma once
 
 #include <chrono>
