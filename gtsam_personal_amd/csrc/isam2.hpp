@@ -18,8 +18,7 @@
 // (one dense block for a wide clique) with exact-size free lists (clique shapes repeat in SLAM), the children lists of the cliques.
 // Everything an update sends to the device goes through a pinned staging arena: no allocation, one wait per update (two with
 // relinearization).
-// Limits (fail loudly): Gauss-Newton params, Cholesky, no factor removal / marginalization / fixed variables, factors of at most two
-// variables.
+// Limits (fail loudly): Gauss-Newton params, Cholesky, no factor removal / marginalization / fixed variables.
 #pragma once
 
 #include <chrono>
@@ -52,7 +51,7 @@ struct lmgpu_isam2 {
   unsigned char *d_replaced = nullptr, *d_changed = nullptr;  // per scalar of delta
 
   struct Fac {
-    int32_t type, bucket, lidx, v[2];
+    int32_t type, bucket, lidx, v[3];
   };
   std::vector<Fac> facs;
   struct Bkt {
@@ -100,7 +99,7 @@ struct lmgpu_isam2 {
   std::vector<NewVar> new_vars;
   struct NewFac {
     int32_t type, noise_kind;
-    uint64_t k[2];
+    uint64_t k[3];
     std::vector<double> meas, noise;
   };
   std::vector<NewFac> new_facs;
@@ -344,6 +343,8 @@ void is_linearize_sel(lmgpu_isam2* S, const lmgpu_isam2::Bkt& b, const int32_t* 
     case LMGPU_F_PROJECTION: hipLaunchKernelGGL((generic_factor_kernel<7, 2, 6, 3, 7, 1, 12, 2, 3, true>), dim3(g128), dim3(128), 0, s, d, vals, nob); break;
     case LMGPU_F_PROJECTION_BPS: hipLaunchKernelGGL((generic_factor_kernel<8, 2, 6, 3, 19, 1, 12, 2, 3, true>), dim3(g128), dim3(128), 0, s, d, vals, nob); break;
     case LMGPU_F_BEARING_RANGE_2D: hipLaunchKernelGGL((generic_factor_kernel<9, 2, 3, 2, 2, 0, 3, 4, 2, true>), dim3(g128), dim3(128), 0, s, d, vals, nob); break;
+    case LMGPU_F_SFM2: hipLaunchKernelGGL(sfm2_factor_kernel<true>, dim3(g128), dim3(128), 0, s, d, vals, nob); break;
+    case LMGPU_F_PRIOR_CAL3_S2: hipLaunchKernelGGL((generic_factor_kernel<11, 5, 5, 0, 5, 5, 5, -1, 0, true>), dim3(g128), dim3(128), 0, s, d, vals, nob); break;
   }
 }
 
@@ -812,10 +813,13 @@ int is_eliminate(lmgpu_isam2* S, const std::vector<IsGF>& gfs, const std::vector
         d.d1 = (int16_t)(f.v[1] >= 0 ? kVarDim[S->vars[f.v[1]].type] : 0);
         d.x0 = S->vars[f.v[0]].xoff;
         d.x1 = f.v[1] >= 0 ? S->vars[f.v[1]].xoff : -1;
+        d.d2 = (int16_t)(f.v[2] >= 0 ? kVarDim[S->vars[f.v[2]].type] : 0);
+        d.x2 = f.v[2] >= 0 ? S->vars[f.v[2]].xoff : -1;
         FrontFac ff{};
         ff.fac = (int32_t)fd.size();
         ff.c0 = colof.at(f.v[0]);
         ff.c1 = f.v[1] >= 0 ? colof.at(f.v[1]) : 0;
+        ff.c2 = f.v[2] >= 0 ? colof.at(f.v[2]) : 0;
         fd.push_back(d);
         ffac.push_back(ff);
       } else if (gf.kind == 1) {
@@ -875,9 +879,9 @@ int is_eliminate(lmgpu_isam2* S, const std::vector<IsGF>& gfs, const std::vector
       for (int k = 0; k < F.fac_count; k++) {
         const FrontFac& ff = ffac[F.fac_begin + k];
         const FacDesc& d = fd[ff.fac];
-        const int nc = d.d0 + d.d1 + 1;
+        const int nc = d.d0 + d.d1 + d.d2 + 1;
         for (int p = 0; p < nc; p++) {
-          const int gp = (p < d.d0) ? ff.c0 + p : (p < d.d0 + d.d1 ? ff.c1 + (p - d.d0) : F.n - 1);
+          const int gp = (p < d.d0) ? ff.c0 + p : (p < d.d0 + d.d1 ? ff.c1 + (p - d.d0) : (p < d.d0 + d.d1 + d.d2 ? ff.c2 + (p - d.d0 - d.d1) : F.n - 1));
           rows[gp].push_back(RowSrc{-(F.fac_begin + k) - 1, p});
         }
       }
@@ -932,7 +936,7 @@ int is_eliminate(lmgpu_isam2* S, const std::vector<IsGF>& gfs, const std::vector
       int tot = 0;
       for (int k = 0; k < fds[fi].fac_count; k++) {
         const FacDesc& d = fd[ffac[fds[fi].fac_begin + k].fac];
-        tot += d.rows * (d.d0 + d.d1 + 1);
+        tot += d.rows * (d.d0 + d.d1 + d.d2 + 1);
       }
       jc = std::max(jc, std::min(tot, LDSF_JCAP));
     }
@@ -1069,14 +1073,14 @@ int is_update(lmgpu_isam2* S, bool force_relinearize, lmgpu_isam2_result* result
   std::map<int, NewRows> new_rows;  // bucket -> the descriptor rows of its new factors (consecutive local indices), uploaded after the loop
   for (const lmgpu_isam2::NewFac& nf : new_facs) {
     const int ar = kFactorArity[nf.type];
-    lmgpu_isam2::Fac f{nf.type, -1, -1, {-1, -1}};
+    lmgpu_isam2::Fac f{nf.type, -1, -1, {-1, -1, -1}};
     for (int k = 0; k < ar; k++) {
       auto it = S->vid_of.find(nf.k[k]);
       if (it == S->vid_of.end()) {
         S->err = "ISAM2: a new factor references a variable that has no value";
         return LMGPU_INVALID;
       }
-      const int want = (k == 0) ? kFactorVar0[nf.type] : kFactorVar1[nf.type];
+      const int want = factor_var_type(nf.type, k);
       if (S->vars[it->second].type != want) {
         S->err = "factor/variable type mismatch";
         return LMGPU_INVALID;
@@ -1096,7 +1100,7 @@ int is_update(lmgpu_isam2* S, bool force_relinearize, lmgpu_isam2_result* result
       b.ml = kFactorMeas[nf.type];
       b.nl = nf.noise_kind == LMGPU_N_DIAG ? b.rows : (nf.noise_kind == LMGPU_N_GAUSS ? b.rows * b.rows : 0);
       b.cols = 1;
-      for (int k = 0; k < ar; k++) b.cols += kVarDim[(k == 0) ? kFactorVar0[nf.type] : kFactorVar1[nf.type]];
+      for (int k = 0; k < ar; k++) b.cols += kVarDim[factor_var_type(nf.type, k)];
       bi = (int)S->bkts.size();
       S->bkts.push_back(b);
     }
@@ -1118,8 +1122,7 @@ int is_update(lmgpu_isam2* S, bool force_relinearize, lmgpu_isam2_result* result
     }
     NewRows& nr = new_rows[bi];
     if (nr.first < 0) nr.first = b.n;
-    nr.vidx.push_back(S->vars[f.v[0]].tidx);
-    if (ar > 1) nr.vidx.push_back(S->vars[f.v[1]].tidx);
+    for (int k = 0; k < ar; k++) nr.vidx.push_back(S->vars[f.v[k]].tidx);
     nr.meas.insert(nr.meas.end(), nf.meas.begin(), nf.meas.begin() + b.ml);
     if (b.nl) nr.noise.insert(nr.noise.end(), nf.noise.begin(), nf.noise.begin() + b.nl);
     f.bucket = bi;
@@ -1400,18 +1403,13 @@ int lmgpu_isam2_add_factors(lmgpu_isam2* S, int32_t factor_type, int32_t n, cons
   if (noise_kind != LMGPU_N_UNIT && noise_kind != LMGPU_N_DIAG && noise_kind != LMGPU_N_GAUSS) return LMGPU_INVALID;
   if (n == 0) return LMGPU_OK;
   if (!keys || !meas || (noise_kind != LMGPU_N_UNIT && !noise)) return LMGPU_INVALID;
-  if (kFactorArity[factor_type] > 2 || factor_type == LMGPU_F_PRIOR_CAL3_S2) {
-    S->err = "the incremental path takes factors of at most two variables (no GeneralSFMFactor2 / Cal3_S2 variables)";
-    return LMGPU_INVALID;
-  }
   const int ar = kFactorArity[factor_type], rows = kFactorRows[factor_type], ml = kFactorMeas[factor_type];
   const int nl = noise_kind == LMGPU_N_DIAG ? rows : (noise_kind == LMGPU_N_GAUSS ? rows * rows : 0);
   for (int i = 0; i < n; i++) {
     lmgpu_isam2::NewFac f;
     f.type = factor_type;
     f.noise_kind = noise_kind;
-    f.k[0] = keys[(size_t)i * ar];
-    f.k[1] = ar > 1 ? keys[(size_t)i * ar + 1] : 0;
+    for (int k = 0; k < 3; k++) f.k[k] = k < ar ? keys[(size_t)i * ar + k] : 0;
     f.meas.assign(meas + (size_t)i * ml, meas + (size_t)(i + 1) * ml);
     if (nl) f.noise.assign(noise + (size_t)i * nl, noise + (size_t)(i + 1) * nl);
     S->new_facs.push_back(std::move(f));

@@ -74,7 +74,7 @@ enum lmgpu_var_type {
  *                                                              PinholeCamera<Cal3_S2>(pose, K).project(point, H1, H2, H3) - z; a point behind
  *                                                              the camera gives zero error and zero Jacobians (:251-260)
  *   PRIOR_CAL3_S2    1     5     5   (fx, fy, s, u0, v0)       PriorFactor<Cal3_S2>
- * Keys of a factor: `arity` per factor, in the reference's key order.  The incremental path (lmgpu_isam2_*) takes factors of arity <= 2.
+ * Keys of a factor: `arity` per factor, in the reference's key order.
  */
 enum lmgpu_factor_type {
   LMGPU_F_SFM = 0,

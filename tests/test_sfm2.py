@@ -241,3 +241,43 @@ def test_gpu_self_calibration_dogleg_like_the_example():
     orc.dl_optimize(DoglegParams())
     assert abs(opt.error() - orc.error()) <= 1e-6 * max(1e-3, abs(orc.error()))
     assert np.allclose(res.at(K0), orc.values()[K0], rtol=1e-6, atol=1e-6)
+
+
+def self_calibration_isam2_steps():
+    """VisualISAM2Example's sequence (examples/VisualISAM2Example.cpp:88-131) with the calibration as a variable: the projection factors
+    become GeneralSFMFactor2<Cal3_S2>, K gets the prior of SelfCalibrationExample.cpp:80-83 and a perturbed initial value"""
+    noise = noiseModel.Isotropic.Sigma(2, 1.0)
+    points, poses = create_points(), create_poses()
+    dR, dt = rot3_expmap([-0.1, 0.2, 0.25]), np.array([0.05, -0.10, 0.20])
+    steps = []
+    g, v = NonlinearFactorGraph(), Values()
+    for i, (R, t) in enumerate(poses):
+        for j, p in enumerate(points):
+            g.add_GeneralSFMFactor2(project_cal3_s2(R, t, p, K_TRUE), noise, X(i), L(j), K0)
+        Ri, ti = pose3_compose(R, t, dR, dt)
+        v.insert_pose3(X(i), Ri, ti)
+        if i == 0:
+            g.add_PriorFactorPose3(X(0), R, t, noiseModel.Diagonal.Sigmas([0.1, 0.1, 0.1, 0.3, 0.3, 0.3]))
+            g.add_PriorFactorPoint3(L(0), points[0], noiseModel.Isotropic.Sigma(3, 0.1))
+            g.add_PriorFactorCal3_S2(K0, K_TRUE, noiseModel.Diagonal.Sigmas([5, 5, 0.1, 5, 5]))
+            v.insert_cal3_s2(K0, 52.0, 52.0, 0.0, 49.0, 49.0)
+            for j, p in enumerate(points):
+                v.insert_point3(L(j), p + np.array([-0.25, 0.20, 0.15]))
+        else:
+            steps.append((g, v))
+            steps.append((NonlinearFactorGraph(), Values()))
+            g, v = NonlinearFactorGraph(), Values()
+    return steps
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not oh.have_ref(), reason="oracle/_ref (CCOLAMD of the reference) not built")
+def test_gpu_isam2_with_three_variable_factors():
+    """the incremental path with GeneralSFMFactor2 and a Cal3_S2 variable: update by update against the oracle (bookkeeping, Bayes tree,
+    [R S d], linearization point, delta, estimate), as tests/test_gpu_isam2.py does for the reference's own sequences"""
+    from gtsam_personal_amd import ISAM2Params
+    from test_gpu_isam2 import run_sequence
+    isam, orc = run_sequence(self_calibration_isam2_steps(), ISAM2Params(relinearizeThreshold=0.01, relinearizeSkip=1))
+    est = isam.calculateEstimate()
+    assert np.allclose(est.at(K0)[[0, 2, 3]], np.array(K_TRUE)[[0, 2, 3]], atol=1.0)
+    isam.close()
