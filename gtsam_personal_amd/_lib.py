@@ -44,6 +44,13 @@ class lmgpu_isam2_result(ct.Structure):
                 ("cliques", ct.c_int32), ("batch", ct.c_int32)]
 
 
+class lmgpu_isam2_update_params(ct.Structure):
+    _fields_ = [("n_remove", ct.c_int32), ("removeFactorIndices", ct.POINTER(ct.c_uint64)), ("has_constrained", ct.c_int32),
+                ("n_constrained", ct.c_int32), ("constrainedKeys", ct.POINTER(ct.c_uint64)), ("constrainedGroups", ct.POINTER(ct.c_int32)),
+                ("n_no_relin", ct.c_int32), ("noRelinKeys", ct.POINTER(ct.c_uint64)), ("n_extra_reelim", ct.c_int32),
+                ("extraReelimKeys", ct.POINTER(ct.c_uint64)), ("force_relinearize", ct.c_int32), ("forceFullSolve", ct.c_int32)]
+
+
 # lmgpu_ccolamd_fn: int fn(user, n_rows, n_cols, col_ptr, row_idx, cmember, perm_out)
 CCOLAMD_FN = ct.CFUNCTYPE(ct.c_int, ct.c_void_p, ct.c_int32, ct.c_int32, ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32),
                           ct.POINTER(ct.c_int32))
@@ -104,6 +111,9 @@ SYMBOLS = {
     "lmgpu_isam2_add_variables": (ct.c_int, [_H, ct.c_int32, ct.POINTER(ct.c_uint64), _I, _D]),
     "lmgpu_isam2_add_factors": (ct.c_int, [_H, ct.c_int32, ct.c_int32, ct.POINTER(ct.c_uint64), _D, ct.c_int32, _D]),
     "lmgpu_isam2_update": (ct.c_int, [_H, ct.c_int32, ct.c_void_p]),
+    "lmgpu_isam2_update_with": (ct.c_int, [_H, ct.c_void_p, ct.c_void_p]),
+    "lmgpu_isam2_get_unused_keys": (ct.c_int, [_H, ct.POINTER(ct.c_uint64)]),
+    "lmgpu_isam2_factor_exists": (ct.c_int, [_H, ct.c_int32]),
     "lmgpu_isam2_num_variables": (ct.c_int, [_H]),
     "lmgpu_isam2_num_factors": (ct.c_int, [_H]),
     "lmgpu_isam2_get_values": (ct.c_int, [_H, ct.c_int32, ct.POINTER(ct.c_uint64), _I, _D]),

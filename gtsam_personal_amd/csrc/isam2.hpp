@@ -18,7 +18,10 @@
 // (one dense block for a wide clique) with exact-size free lists (clique shapes repeat in SLAM), the children lists of the cliques.
 // Everything an update sends to the device goes through a pinned staging arena: no allocation, one wait per update (two with
 // relinearization).
-// Limits (fail loudly): Gauss-Newton params, Cholesky, no factor removal / marginalization / fixed variables.
+// ISAM2UpdateParams (gtsam/nonlinear/ISAM2UpdateParams.h:30-90) honoured: removeFactorIndices (a removed factor leaves an empty slot, a
+// variable that lost its last factor leaves the system: pushBackFactors / computeUnusedKeys / removeVariables), constrainedKeys,
+// noRelinKeys, extraReelimKeys, force_relinearize, forceFullSolve.
+// Limits (fail loudly): Gauss-Newton params, Cholesky, no marginalizeLeaves, no newAffectedKeys (smart factors).
 #pragma once
 
 #include <chrono>
@@ -39,9 +42,10 @@ struct lmgpu_isam2 {
   struct Var {
     uint64_t key;
     int32_t type, tidx, xoff;
+    bool dead;  // removed from the system (ISAM2::removeVariables): its id, value slot and delta scalars are not reused
   };
   std::vector<Var> vars;
-  std::map<uint64_t, int32_t> vid_of;  // ascending by key = the order of the reference's Values / VectorValues / VariableIndex
+  std::map<uint64_t, int32_t> vid_of;  // the LIVE variables, ascending by key = the order of the reference's Values / VectorValues / VariableIndex
   int type_count[kNumVarTypes] = {}, type_cap[kNumVarTypes] = {};
   double* theta[kNumVarTypes] = {};
   double* est[kNumVarTypes] = {};
@@ -52,6 +56,7 @@ struct lmgpu_isam2 {
 
   struct Fac {
     int32_t type, bucket, lidx, v[3];
+    bool removed;  // an empty slot of nonlinearFactors_ (NonlinearFactorGraph::remove): the index is not reused
   };
   std::vector<Fac> facs;
   struct Bkt {
@@ -104,6 +109,15 @@ struct lmgpu_isam2 {
   };
   std::vector<NewFac> new_facs;
   int update_count = 0;
+  // ISAM2UpdateParams of one update
+  struct UpParams {
+    std::vector<uint64_t> remove;
+    bool has_constrained = false;
+    std::map<uint64_t, int> constrained;
+    std::vector<uint64_t> no_relin, extra_reelim;
+    bool force_relinearize = false, force_full_solve = false;
+  };
+  std::vector<uint64_t> last_unused;  // ISAM2Result::unusedKeys of the last update
 
   // device scratch
   int *d_status = nullptr, *h_status = nullptr;
@@ -981,8 +995,23 @@ int is_with_list(lmgpu_isam2* S, const std::vector<int32_t>& v, Fn fn) {
   return LMGPU_OK;
 }
 
-// ISAM2::update (gtsam/nonlinear/ISAM2.cpp:419-480), default ISAM2UpdateParams except force_relinearize
-int is_update(lmgpu_isam2* S, bool force_relinearize, lmgpu_isam2_result* result) {
+// ISAM2::update (gtsam/nonlinear/ISAM2.cpp:419-480)
+int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_result* result) {
+  const bool force_relinearize = up.force_relinearize;
+  // what can be refused is refused before anything changes
+  for (uint64_t idx : up.remove)
+    if (idx >= S->facs.size()) {
+      S->err = "ISAM2: removeFactorIndices names a factor that does not exist (factors added by the same update cannot be removed by it)";
+      return LMGPU_INVALID;
+    }
+  for (uint64_t k : up.extra_reelim) {
+    bool known = S->vid_of.count(k) > 0;
+    for (const lmgpu_isam2::NewVar& nv : S->new_vars) known = known || nv.key == k;
+    if (!known) {
+      S->err = "ISAM2: extraReelimKeys names an unknown variable";
+      return LMGPU_INVALID;
+    }
+  }
   S->update_count += 1;
   lmgpu_isam2_result res{};
   int rc;
@@ -1039,7 +1068,7 @@ int is_update(lmgpu_isam2* S, bool force_relinearize, lmgpu_isam2_result* result
     std::vector<int32_t> xoffs[kNumVarTypes];
     for (int t = 0; t < kNumVarTypes; t++) first_tidx[t] = S->type_count[t];
     for (auto& nv : new_vars) {
-      lmgpu_isam2::Var v{nv.key, nv.type, S->type_count[nv.type]++, S->ntot};
+      lmgpu_isam2::Var v{nv.key, nv.type, S->type_count[nv.type]++, S->ntot, false};
       const int vid = (int)S->vars.size();
       S->vars.push_back(v);
       S->vid_of[nv.key] = vid;
@@ -1058,7 +1087,7 @@ int is_update(lmgpu_isam2* S, bool force_relinearize, lmgpu_isam2_result* result
     ISCHECK(hipMemsetAsync(S->delta + ntot0, 0, (size_t)(S->ntot - ntot0) * sizeof(double), S->stream));  // delta_.insert(zeroVectors)
   }
   const bool relinNeeded = force_relinearize || (S->prm.enableRelinearization && S->prm.relinearizeSkip > 0 && S->update_count % S->prm.relinearizeSkip == 0);
-  if (relinNeeded && (rc = is_update_delta(S, false))) return rc;
+  if (relinNeeded && (rc = is_update_delta(S, up.force_full_solve))) return rc;
   const int relin_ntot = S->ntot;  // scalars of delta the pinned copy holds
   lap(0);  // new variables + updateDelta (wildfire, one wait)
   // ---- 1. pushBackFactors (ISAM2-impl.h:145-175): indices continue the list
@@ -1073,7 +1102,7 @@ int is_update(lmgpu_isam2* S, bool force_relinearize, lmgpu_isam2_result* result
   std::map<int, NewRows> new_rows;  // bucket -> the descriptor rows of its new factors (consecutive local indices), uploaded after the loop
   for (const lmgpu_isam2::NewFac& nf : new_facs) {
     const int ar = kFactorArity[nf.type];
-    lmgpu_isam2::Fac f{nf.type, -1, -1, {-1, -1, -1}};
+    lmgpu_isam2::Fac f{nf.type, -1, -1, {-1, -1, -1}, false};
     for (int k = 0; k < ar; k++) {
       auto it = S->vid_of.find(nf.k[k]);
       if (it == S->vid_of.end()) {
@@ -1137,19 +1166,40 @@ int is_update(lmgpu_isam2* S, bool force_relinearize, lmgpu_isam2_result* result
     if ((rc = is_push(S, b.d_meas + (size_t)nr.first * b.ml, nr.meas.data(), nr.meas.size() * sizeof(double)))) return rc;
     if (b.nl && (rc = is_push(S, b.d_noise + (size_t)nr.first * b.nl, nr.noise.data(), nr.noise.size() * sizeof(double)))) return rc;
   }
-  std::vector<int32_t> observed;  // observedKeys = markedKeys at this point (no unused keys without removals), ascending by key
-  for (uint64_t k : markedKeys) observed.push_back(S->vid_of.at(k));
+  // the removals of pushBackFactors (ISAM2-impl.h:157-172): the slot empties, the variable index forgets the factor
+  std::set<uint64_t> keysWithRemoved, newFactorKeys = markedKeys, unusedKeys;
+  for (uint64_t idx : up.remove) {
+    lmgpu_isam2::Fac& f = S->facs[idx];
+    if (f.removed) continue;
+    for (int k = 0; k < kFactorArity[f.type]; k++) {
+      keysWithRemoved.insert(S->vars[f.v[k]].key);
+      std::vector<int32_t>& entries = S->vindex[f.v[k]];
+      entries.erase(std::find(entries.begin(), entries.end(), (int32_t)idx));
+    }
+    f.removed = true;
+  }
+  // computeUnusedKeys (:175-190): keys whose last factor went and which no new factor mentions
+  for (uint64_t k : keysWithRemoved)
+    if (S->vindex[S->vid_of.at(k)].empty() && !newFactorKeys.count(k)) unusedKeys.insert(k);
+  // gatherInvolvedKeys (:199-226) + updateKeys (:228-244)
+  markedKeys.insert(keysWithRemoved.begin(), keysWithRemoved.end());
+  markedKeys.insert(up.extra_reelim.begin(), up.extra_reelim.end());
+  std::vector<int32_t> observed;  // observedKeys = the marked keys that stay in the system, ascending by key
+  for (uint64_t k : markedKeys)
+    if (!unusedKeys.count(k)) observed.push_back(S->vid_of.at(k));
   std::set<int32_t> relin;  // relinKeys as vids
   if (relinNeeded) {
     // ---- 4. CheckRelinearizationFull (:353-383) on the delta just updated
     // (is_update_delta above brought delta to the host with its own wait; variables added by this update are not in it: delta = 0)
     const double* hdelta = S->h_delta;
     const int ntot_checked = relin_ntot;
+    const double threshold = up.force_full_solve ? 0.0 : S->prm.relinearizeThreshold;  // gatherRelinearizeKeys :367-399
+    std::set<uint64_t> noRelin(up.no_relin.begin(), up.no_relin.end());
     for (size_t v = 0; v < S->vars.size(); v++) {
-      if (S->vars[v].xoff >= ntot_checked) continue;
+      if (S->vars[v].dead || S->vars[v].xoff >= ntot_checked) continue;
       double m = 0;
       for (int d = 0; d < kVarDim[S->vars[v].type]; d++) m = std::max(m, std::fabs(hdelta[S->vars[v].xoff + d]));
-      if (m >= S->prm.relinearizeThreshold) {
+      if (m >= threshold && !noRelin.count(S->vars[v].key)) {
         relin.insert((int32_t)v);
         markedKeys.insert(S->vars[v].key);
       }
@@ -1195,7 +1245,7 @@ int is_update(lmgpu_isam2* S, bool force_relinearize, lmgpu_isam2_result* result
     for (int id : bn) is_release_clique(S, id);
 
     std::set<int32_t> affectedSet;
-    if ((double)affected.size() >= (double)S->vars.size() * 0.65) {
+    if ((double)affected.size() >= (double)S->vid_of.size() * 0.65) {
       // ---- recalculateBatch :178-247: reorder, relinearize and re-eliminate everything
       res.batch = 1;
       for (int id = 0; id < (int)S->clq.size(); id++)
@@ -1203,12 +1253,23 @@ int is_update(lmgpu_isam2* S, bool force_relinearize, lmgpu_isam2_result* result
       S->roots.clear();
       std::fill(S->node_of.begin(), S->node_of.end(), -1);
       std::vector<int32_t> vids;
-      for (auto& kv : S->vid_of) vids.push_back(kv.second);
+      for (auto& kv : S->vid_of)
+        if (!unusedKeys.count(kv.first)) vids.push_back(kv.second);
       std::vector<std::vector<int32_t>> cols;
       for (int32_t v : vids) cols.push_back(S->vindex[v]);
       std::map<int32_t, int> groups;
-      if (S->vars.size() > observed.size())
+      if (up.has_constrained) {
+        for (auto& kg : up.constrained) {
+          auto it = S->vid_of.find(kg.first);
+          if (it == S->vid_of.end() || unusedKeys.count(kg.first)) {
+            S->err = "ISAM2: constrainedKeys names a variable that is not in the system";
+            return LMGPU_INVALID;
+          }
+          groups[it->second] = kg.second;
+        }
+      } else if (S->vid_of.size() > observed.size()) {
         for (int32_t v : observed) groups[v] = 1;
+      }
       std::vector<int32_t> perm;
       if ((rc = is_colamd(S, vids, cols, (int)S->facs.size(), groups, &perm))) return rc;
       for (size_t b = 0; b < S->bkts.size(); b++) {
@@ -1220,6 +1281,7 @@ int is_update(lmgpu_isam2* S, bool force_relinearize, lmgpu_isam2_result* result
       for (size_t i = 0; i < S->facs.size(); i++) {
         gfs[i].kind = 0;
         gfs[i].id = (int32_t)i;
+        if (S->facs[i].removed) continue;  // an empty slot: an entry without variables, so that positions stay factor indices
         for (int k = 0; k < kFactorArity[S->facs[i].type]; k++) gfs[i].vids.push_back(S->facs[i].v[k]);
       }
       if ((rc = is_eliminate(S, gfs, vids, perm))) return rc;
@@ -1278,10 +1340,17 @@ int is_update(lmgpu_isam2* S, bool force_relinearize, lmgpu_isam2_result* result
         vids.push_back(S->vid_of.at(kv.first));
         cols.push_back(kv.second);
       }
-      std::map<int32_t, int> groups;
-      const int group = observed.size() < vids.size() ? 1 : 0;
-      for (int32_t v : observed)
-        if (affectedSet.count(v)) groups.emplace(v, group);
+      std::map<int32_t, int> groups;  // constraint groups, minus unused / unaffected keys (ISAM2.cpp:318-340)
+      if (up.has_constrained) {
+        for (auto& kg : up.constrained) {
+          auto it = S->vid_of.find(kg.first);
+          if (it != S->vid_of.end() && !unusedKeys.count(kg.first) && affectedSet.count(it->second)) groups.emplace(it->second, kg.second);
+        }
+      } else {
+        const int group = observed.size() < vids.size() ? 1 : 0;
+        for (int32_t v : observed)
+          if (affectedSet.count(v)) groups.emplace(v, group);
+      }
       std::vector<int32_t> perm;
       lap(2);  // removeTop, affected factors, variable index
       if ((rc = is_colamd(S, vids, cols, (int)gfs.size(), groups, &perm))) return rc;
@@ -1292,6 +1361,7 @@ int is_update(lmgpu_isam2* S, bool force_relinearize, lmgpu_isam2_result* result
     // deltaReplacedMask_ |= affectedKeysSet
     std::vector<int32_t> marks;  // (xoff, dim) pairs
     for (int32_t v : affectedSet) {
+      if (unusedKeys.count(S->vars[v].key)) continue;  // leaves the system below
       S->replaced[v] = 1;
       marks.push_back(S->vars[v].xoff);
       marks.push_back(kVarDim[S->vars[v].type]);
@@ -1302,6 +1372,15 @@ int is_update(lmgpu_isam2* S, bool force_relinearize, lmgpu_isam2_result* result
       return rc;
     S->any_replaced = S->any_replaced || !affectedSet.empty();
   }
+  // ---- removeVariables (ISAM2.cpp:385-398): the variable leaves theta / delta / the variable index; its storage is not reused
+  for (uint64_t k : unusedKeys) {
+    const int32_t v = S->vid_of.at(k);
+    S->vars[v].dead = true;
+    S->replaced[v] = 0;
+    S->node_of[v] = -1;
+    S->vid_of.erase(k);
+  }
+  S->last_unused.assign(unusedKeys.begin(), unusedKeys.end());
   res.cliques = S->n_alive;  // (every alive clique hangs in the tree again by now; counting them by a walk was O(cliques) per update)
   if (result) *result = res;
   lap(5);
@@ -1424,10 +1503,43 @@ int lmgpu_isam2_update(lmgpu_isam2* S, int32_t force_relinearize, lmgpu_isam2_re
     return LMGPU_HIP_ERROR;
   }
   ISCHECK(hipSetDevice(S->device));
-  return is_update(S, force_relinearize != 0, out);
+  lmgpu_isam2::UpParams up;
+  up.force_relinearize = force_relinearize != 0;
+  return is_update(S, up, out);
 }
 
-int lmgpu_isam2_num_variables(const lmgpu_isam2* S) { return S ? (int)S->vars.size() : -1; }
+int lmgpu_isam2_update_with(lmgpu_isam2* S, const lmgpu_isam2_update_params* p, lmgpu_isam2_result* out) {
+  if (!S || !p) return LMGPU_INVALID;
+  if (p->n_remove < 0 || p->n_constrained < 0 || p->n_no_relin < 0 || p->n_extra_reelim < 0 || (p->n_remove && !p->removeFactorIndices) ||
+      (p->n_constrained && (!p->constrainedKeys || !p->constrainedGroups)) || (p->n_no_relin && !p->noRelinKeys) ||
+      (p->n_extra_reelim && !p->extraReelimKeys)) {
+    S->err = "bad ISAM2 update parameters";
+    return LMGPU_INVALID;
+  }
+  if (S->device < 0) {
+    S->err = "no HIP device bound to this handle; the incremental path has no CPU fallback";
+    return LMGPU_HIP_ERROR;
+  }
+  ISCHECK(hipSetDevice(S->device));
+  lmgpu_isam2::UpParams up;
+  up.remove.assign(p->removeFactorIndices, p->removeFactorIndices + p->n_remove);
+  up.has_constrained = p->has_constrained != 0;
+  for (int i = 0; i < p->n_constrained; i++) up.constrained[p->constrainedKeys[i]] = p->constrainedGroups[i];
+  up.no_relin.assign(p->noRelinKeys, p->noRelinKeys + p->n_no_relin);
+  up.extra_reelim.assign(p->extraReelimKeys, p->extraReelimKeys + p->n_extra_reelim);
+  up.force_relinearize = p->force_relinearize != 0;
+  up.force_full_solve = p->forceFullSolve != 0;
+  return is_update(S, up, out);
+}
+
+int lmgpu_isam2_get_unused_keys(const lmgpu_isam2* S, uint64_t* keys_out) {
+  if (!S) return -1;
+  if (keys_out) std::copy(S->last_unused.begin(), S->last_unused.end(), keys_out);
+  return (int)S->last_unused.size();
+}
+int lmgpu_isam2_factor_exists(const lmgpu_isam2* S, int32_t i) { return S && i >= 0 && i < (int)S->facs.size() && !S->facs[i].removed; }
+
+int lmgpu_isam2_num_variables(const lmgpu_isam2* S) { return S ? (int)S->vid_of.size() : -1; }
 int lmgpu_isam2_num_factors(const lmgpu_isam2* S) { return S ? (int)S->facs.size() : -1; }
 
 int lmgpu_isam2_get_values(lmgpu_isam2* S, int32_t which, uint64_t* keys_out, int32_t* types_out, double* packed_out) {

@@ -240,6 +240,14 @@ class Values:
     def exists(self, key):
         return int(key) in self._type
 
+    def erase(self, key):
+        """Values::erase (gtsam/nonlinear/Values.cpp)"""
+        key = int(key)
+        if key not in self._type:
+            raise KeyError(f"key {key} not in Values")
+        del self._type[key]
+        del self._val[key]
+
     def size(self):
         return len(self._type)
 

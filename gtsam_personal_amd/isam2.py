@@ -92,8 +92,11 @@ class ISAM2:
         except Exception:
             pass
 
-    def update(self, newFactors: NonlinearFactorGraph | None = None, newTheta: Values | None = None, force_relinearize=False) -> ISAM2Result:
-        """ISAM2::update(newFactors, newTheta) (gtsam/nonlinear/ISAM2.h:146-156; no factor removal / constraints)"""
+    def update(self, newFactors: NonlinearFactorGraph | None = None, newTheta: Values | None = None, removeFactorIndices=(),
+               constrainedKeys=None, noRelinKeys=None, extraReelimKeys=None, force_relinearize=False, forceFullSolve=False) -> ISAM2Result:
+        """ISAM2::update(newFactors, newTheta, removeFactorIndices, constrainedKeys, noRelinKeys, extraReelimKeys, force_relinearize)
+        (gtsam/nonlinear/ISAM2.h:146-186, ISAM2UpdateParams.h:30-90).  removeFactorIndices: positions in getFactorsUnsafe();
+        constrainedKeys: {key: group} (None = not given); the new factors of this update get the indices size() .. of the list"""
         U64 = ct.POINTER(ct.c_uint64)
         if newTheta is not None and newTheta.size():
             keys = np.array(newTheta.keys(), dtype=np.uint64)
@@ -122,8 +125,31 @@ class ISAM2:
                 self._check(self.lib.lmgpu_isam2_add_factors(self._h, ftype, 1, kk.ctypes.data_as(U64), np.ascontiguousarray(m).ctypes.data_as(_lib._D),
                                                              kind, None if nz is None else nz.ctypes.data_as(_lib._D)))
         res = _lib.lmgpu_isam2_result()
-        self._check(self.lib.lmgpu_isam2_update(self._h, int(force_relinearize), ct.byref(res)))
+        rm = np.asarray(list(removeFactorIndices), dtype=np.uint64)
+        ck = np.asarray(sorted(constrainedKeys) if constrainedKeys else [], dtype=np.uint64)
+        cg = np.asarray([constrainedKeys[int(k)] for k in ck], dtype=np.int32)
+        nr = np.asarray(list(noRelinKeys or []), dtype=np.uint64)
+        ex = np.asarray(list(extraReelimKeys or []), dtype=np.uint64)
+        up = _lib.lmgpu_isam2_update_params(len(rm), rm.ctypes.data_as(U64), int(constrainedKeys is not None), len(ck), ck.ctypes.data_as(U64),
+                                            cg.ctypes.data_as(_lib._I), len(nr), nr.ctypes.data_as(U64), len(ex), ex.ctypes.data_as(U64),
+                                            int(force_relinearize), int(forceFullSolve))
+        self._check(self.lib.lmgpu_isam2_update_with(self._h, ct.byref(up), ct.byref(res)))
         return ISAM2Result(res)
+
+    def unusedKeys(self):
+        """ISAM2Result::unusedKeys of the last update: the variables that left the system with their last factor"""
+        n = self.lib.lmgpu_isam2_get_unused_keys(self._h, None)
+        keys = np.zeros(max(n, 1), dtype=np.uint64)
+        self.lib.lmgpu_isam2_get_unused_keys(self._h, keys.ctypes.data_as(ct.POINTER(ct.c_uint64)))
+        return [int(k) for k in keys[:n]]
+
+    def factor_exists(self, i):
+        """getFactorsUnsafe().exists(i)"""
+        return bool(self.lib.lmgpu_isam2_factor_exists(self._h, int(i)))
+
+    def num_factors(self):
+        """getFactorsUnsafe().size(): slots, removed ones included"""
+        return self.lib.lmgpu_isam2_num_factors(self._h)
 
     def _values(self, which) -> Values:
         n = self.lib.lmgpu_isam2_num_variables(self._h)

@@ -274,7 +274,9 @@ int lmgpu_selftest_chain_schedule(int n, int nf, int i0, int nsteps, int far_pct
  * COLAMD ordering (:250-362; batch fallback when >= 65 % of the variables are affected, :156-159), and keep the tree on the device.
  * ISAM2Params honoured: ISAM2GaussNewtonParams::wildfireThreshold, relinearizeThreshold (one double), relinearizeSkip,
  * enableRelinearization (gtsam/nonlinear/ISAM2Params.h:133-246); Cholesky factorisation; cacheLinearizedFactors semantics.
- * Not bound: Dogleg, QR, factor removal, marginalizeLeaves, fixed variables, per-type thresholds (LMGPU_INVALID / not offered).
+ * ISAM2UpdateParams (gtsam/nonlinear/ISAM2UpdateParams.h:30-90) through lmgpu_isam2_update_with: removeFactorIndices, constrainedKeys,
+ * noRelinKeys, extraReelimKeys, force_relinearize, forceFullSolve.
+ * Not bound: Dogleg, QR, marginalizeLeaves, newAffectedKeys (smart factors), per-type thresholds (not offered).
  *
  * The fill-reducing ordering is a boundary input like in the batch path, but here it is needed per update: the caller hands over
  * ITS ccolamd (the reference side: the one Ordering::ColamdConstrained calls, gtsam/inference/Ordering.cpp:50-125) as a callback:
@@ -303,8 +305,34 @@ int lmgpu_isam2_add_variables(lmgpu_isam2* s, int32_t n, const uint64_t* keys, c
 int lmgpu_isam2_add_factors(lmgpu_isam2* s, int32_t factor_type, int32_t n, const uint64_t* keys, const double* meas, int32_t noise_kind,
                             const double* noise);
 int lmgpu_isam2_update(lmgpu_isam2* s, int32_t force_relinearize, lmgpu_isam2_result* out);
-int lmgpu_isam2_num_variables(const lmgpu_isam2* s);
-int lmgpu_isam2_num_factors(const lmgpu_isam2* s);
+/* ISAM2::update(newFactors, newTheta, const ISAM2UpdateParams&) (gtsam/nonlinear/ISAM2.h:176-186, ISAM2UpdateParams.h:30-90).
+ * removeFactorIndices: positions in the factor list (getFactorsUnsafe(); the factors of update k start at lmgpu_isam2_num_factors()
+ *   before it); a removed factor leaves an empty slot (indices never shift), removing an empty slot is a no-op, an index beyond the
+ *   list (including the factors this very update adds) is LMGPU_INVALID.  A variable that loses its last factor leaves the system
+ *   (ISAM2Result::unusedKeys -> ISAM2::removeVariables, ISAM2.cpp:385-398): see lmgpu_isam2_get_unused_keys.
+ * constrainedKeys (has_constrained != 0: the optional is engaged, even with n_constrained == 0): key -> group for the constrained
+ *   COLAMD call instead of "the observed keys last" (ISAM2.cpp:205-218, 318-340).
+ * noRelinKeys: never relinearized by this update; extraReelimKeys: re-eliminated although no new factor touches them;
+ * forceFullSolve: wildfire threshold 0 and every variable relinearized (the reference's debugging switch). */
+typedef struct lmgpu_isam2_update_params {
+  int32_t n_remove;
+  const uint64_t* removeFactorIndices;
+  int32_t has_constrained, n_constrained;
+  const uint64_t* constrainedKeys;
+  const int32_t* constrainedGroups;
+  int32_t n_no_relin;
+  const uint64_t* noRelinKeys;
+  int32_t n_extra_reelim;
+  const uint64_t* extraReelimKeys;
+  int32_t force_relinearize, forceFullSolve;
+} lmgpu_isam2_update_params;
+int lmgpu_isam2_update_with(lmgpu_isam2* s, const lmgpu_isam2_update_params* params, lmgpu_isam2_result* out);
+/* ISAM2Result::unusedKeys of the last update, ascending; returns their number (keys_out may be NULL) */
+int lmgpu_isam2_get_unused_keys(const lmgpu_isam2* s, uint64_t* keys_out);
+/* 1 when slot i of the factor list holds a factor (getFactorsUnsafe().exists(i)) */
+int lmgpu_isam2_factor_exists(const lmgpu_isam2* s, int32_t i);
+int lmgpu_isam2_num_variables(const lmgpu_isam2* s); /* live variables = theta_.size() */
+int lmgpu_isam2_num_factors(const lmgpu_isam2* s);   /* slots of the factor list, removed ones included */
 /* which: 0 = calculateEstimate (ISAM2.cpp:748-754), 1 = calculateBestEstimate (:763-766), 2 = getLinearizationPoint.
  * Variables ascending by Key (the reference's Values order); any of the outputs may be NULL. */
 int lmgpu_isam2_get_values(lmgpu_isam2* s, int32_t which, uint64_t* keys_out, int32_t* types_out, double* packed_out);

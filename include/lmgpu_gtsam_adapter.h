@@ -437,9 +437,25 @@ class GpuISAM2 {
   GpuISAM2(const GpuISAM2&) = delete;
   GpuISAM2& operator=(const GpuISAM2&) = delete;
 
-  /// ISAM2::update(newFactors, newTheta) (ISAM2.cpp:404-480, default ISAM2UpdateParams)
+  /// ISAM2::update(newFactors, newTheta, removeFactorIndices, constrainedKeys, noRelinKeys, extraReelimKeys, force_relinearize)
+  /// (ISAM2.h:146-156, ISAM2.cpp:400-416)
   lmgpu_isam2_result update(const NonlinearFactorGraph& newFactors = NonlinearFactorGraph(), const Values& newTheta = Values(),
-                            bool force_relinearize = false) {
+                            const FactorIndices& removeFactorIndices = FactorIndices(),
+                            const std::optional<FastMap<Key, int>>& constrainedKeys = {}, const std::optional<FastList<Key>>& noRelinKeys = {},
+                            const std::optional<FastList<Key>>& extraReelimKeys = {}, bool force_relinearize = false) {
+    ISAM2UpdateParams params;
+    params.constrainedKeys = constrainedKeys;
+    params.extraReelimKeys = extraReelimKeys;
+    params.force_relinearize = force_relinearize;
+    params.noRelinKeys = noRelinKeys;
+    params.removeFactorIndices = removeFactorIndices;
+    return update(newFactors, newTheta, params);
+  }
+
+  /// ISAM2::update(newFactors, newTheta, const ISAM2UpdateParams&) (ISAM2.h:176-186, ISAM2.cpp:419-480).  The new factors take the
+  /// indices size() .. of the factor list like ISAM2Result::newFactorsIndices (findUnusedFactorSlots is not bound).
+  lmgpu_isam2_result update(const NonlinearFactorGraph& newFactors, const Values& newTheta, const ISAM2UpdateParams& up) {
+    if (up.newAffectedKeys) throw std::invalid_argument("GpuISAM2: newAffectedKeys (smart factors) is not bound");
     std::vector<uint64_t> keys;
     std::vector<int32_t> types;
     std::vector<double> packed;
@@ -450,6 +466,7 @@ class GpuISAM2 {
       double v[15];
       packOne(newTheta, kv.key, t, v);
       packed.insert(packed.end(), v, v + lmgpu_adapter::varStore(t));
+      if (all_.exists(kv.key)) all_.erase(kv.key);  // a key that left the system (unusedKeys) may come back
       all_.insert(kv.key, kv.value);  // keeps what does not travel (Cal3Bundler's principal point) and the types for download
     }
     check(lmgpu_isam2_add_variables(h_, (int32_t)keys.size(), keys.data(), types.data(), packed.data()));
@@ -464,9 +481,28 @@ class GpuISAM2 {
       std::vector<uint64_t> fk(nm->keys().begin(), nm->keys().end());
       check(lmgpu_isam2_add_factors(h_, type, 1, fk.data(), meas.data(), nz.kind, nz.data.empty() ? nullptr : nz.data.data()));
     }
+    std::vector<uint64_t> rm(up.removeFactorIndices.begin(), up.removeFactorIndices.end()), ck, nr, ex;
+    std::vector<int32_t> cg;
+    if (up.constrainedKeys)
+      for (const auto& kg : *up.constrainedKeys) {
+        ck.push_back(kg.first);
+        cg.push_back(kg.second);
+      }
+    if (up.noRelinKeys) nr.assign(up.noRelinKeys->begin(), up.noRelinKeys->end());
+    if (up.extraReelimKeys) ex.assign(up.extraReelimKeys->begin(), up.extraReelimKeys->end());
+    const lmgpu_isam2_update_params p{(int32_t)rm.size(), rm.data(), up.constrainedKeys ? 1 : 0, (int32_t)ck.size(), ck.data(), cg.data(),
+                                      (int32_t)nr.size(), nr.data(), (int32_t)ex.size(), ex.data(), up.force_relinearize ? 1 : 0,
+                                      up.forceFullSolve ? 1 : 0};
     lmgpu_isam2_result r{};
-    check(lmgpu_isam2_update(h_, force_relinearize ? 1 : 0, &r));
+    check(lmgpu_isam2_update_with(h_, &p, &r));
     return r;
+  }
+
+  /// ISAM2Result::unusedKeys of the last update
+  KeySet unusedKeys() const {
+    std::vector<uint64_t> k((size_t)std::max(1, lmgpu_isam2_get_unused_keys(h_, nullptr)));
+    const int n = lmgpu_isam2_get_unused_keys(h_, k.data());
+    return KeySet(k.begin(), k.begin() + n);
   }
 
   Values calculateEstimate() const { return download(0); }

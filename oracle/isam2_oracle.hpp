@@ -11,8 +11,11 @@
 //                                       test harness binds it to oracle/_ref/libccolamd_ref.so = the reference's own C source)
 //   ISAM2::updateDelta / calculateEstimate  gtsam/nonlinear/ISAM2.cpp:701-781; wildfire back-substitution
 //                                       gtsam/nonlinear/ISAM2Clique.cpp:56-77, 151-268, ISAM2-impl.cpp:34-77
-// Not restated (not reached by the configs): Dogleg optimisation, QR, factor removal, marginalizeLeaves, fixed variables,
-// partial relinearization check, per-type threshold maps.
+//   ISAM2UpdateParams (gtsam/nonlinear/ISAM2UpdateParams.h:30-90): removeFactorIndices (pushBackFactors ISAM2-impl.h:141-173,
+//                                       computeUnusedKeys :175-190, ISAM2::removeVariables ISAM2.cpp:385-398), constrainedKeys,
+//                                       noRelinKeys, extraReelimKeys, force_relinearize, forceFullSolve
+// Not restated (not reached by the configs): Dogleg optimisation, QR, marginalizeLeaves, newAffectedKeys (smart factors),
+// partial relinearization check, per-type threshold maps, findUnusedFactorSlots.
 #pragma once
 
 namespace orc {
@@ -57,6 +60,7 @@ struct ISAM2 {
   VectorValues delta;
   std::set<Key> deltaReplacedMask;
   std::vector<Factor> nonlinearFactors;
+  std::vector<char> removedFactor;  // a removed factor leaves its slot behind (NonlinearFactorGraph::remove resets the pointer): indices stay
   std::vector<GFactor> linearFactors;
   std::vector<ICliquePtr> roots;
   std::map<Key, ICliquePtr> nodes;
@@ -65,6 +69,16 @@ struct ISAM2 {
   std::vector<Factor> newFactors;
   Values newTheta;
   ISAM2Result last;
+  std::vector<Key> lastUnusedKeys;
+};
+
+// gtsam/nonlinear/ISAM2UpdateParams.h:30-90 (without newAffectedKeys)
+struct ISAM2UpdateParams {
+  std::vector<size_t> removeFactorIndices;
+  bool hasConstrainedKeys = false;  // std::optional: an empty map that is GIVEN still replaces the default grouping
+  std::map<Key, int> constrainedKeys;
+  std::vector<Key> noRelinKeys, extraReelimKeys;
+  bool force_relinearize = false, forceFullSolve = false;
 };
 
 // Ordering::ColamdConstrained(variableIndex, groups) gtsam/inference/Ordering.cpp:193-210 -> :50-125
@@ -254,8 +268,8 @@ static int isam2_count_cliques(const ICliquePtr& c) {
   return n;
 }
 
-// ISAM2::update gtsam/nonlinear/ISAM2.cpp:419-480 (default ISAM2UpdateParams except force_relinearize)
-static ISAM2Result isam2_update(ISAM2& S, bool force_relinearize) {
+// ISAM2::update gtsam/nonlinear/ISAM2.cpp:419-480
+static ISAM2Result isam2_update(ISAM2& S, const ISAM2UpdateParams& up) {
   S.update_count += 1;
   ISAM2Result result;
   std::vector<Factor> newFactors;
@@ -268,24 +282,51 @@ static ISAM2Result isam2_update(ISAM2& S, bool force_relinearize) {
     S.theta[kv.first] = kv.second;
     S.delta[kv.first] = std::vector<double>(kVarDim[kv.second.type], 0.0);
   }
-  const bool relinNeeded = force_relinearize || (S.enableRelinearization && S.relinearizeSkip > 0 && S.update_count % S.relinearizeSkip == 0);
-  if (relinNeeded) isam2_update_delta(S, false);
-  // 1. pushBackFactors (ISAM2-impl.h:145-175): indices continue the list (findUnusedFactorSlots = false)
+  const bool relinNeeded = up.force_relinearize || (S.enableRelinearization && S.relinearizeSkip > 0 && S.update_count % S.relinearizeSkip == 0);
+  if (relinNeeded) isam2_update_delta(S, up.forceFullSolve);
+  // 1. pushBackFactors (ISAM2-impl.h:141-173): indices continue the list (findUnusedFactorSlots = false); then the removals
   const size_t firstNew = S.nonlinearFactors.size();
-  for (auto& f : newFactors) S.nonlinearFactors.push_back(f);
-  // 3. markedKeys = keys of the new factors (:199-228); observedKeys = the same (no unused keys without removals)
-  std::set<Key> markedKeys;
+  for (auto& f : newFactors) {
+    S.nonlinearFactors.push_back(f);
+    S.removedFactor.push_back(0);
+  }
+  std::set<Key> keysWithRemovedFactors;
+  for (size_t index : up.removeFactorIndices) {
+    if (index >= firstNew) throw std::invalid_argument("ISAM2: removeFactorIndices out of range");
+    if (S.removedFactor[index]) continue;  // an empty slot: nothing to take out of the variable index
+    const Factor& f = S.nonlinearFactors[index];
+    for (int k = 0; k < kFactorArity[f.type]; k++) {
+      keysWithRemovedFactors.insert(f.keys[k]);
+      auto& entries = S.variableIndex.at(f.keys[k]);  // VariableIndex::remove (VariableIndex-inl.h:52-80): the key keeps its (emptier) list
+      entries.erase(std::find(entries.begin(), entries.end(), index));
+    }
+    S.removedFactor[index] = 1;
+    S.linearFactors[index] = GFactor();
+  }
+  // computeUnusedKeys :175-190: keys whose last factor went and which no new factor mentions
+  std::set<Key> newFactorKeys, unusedKeys;
   for (auto& f : newFactors)
-    for (int k = 0; k < kFactorArity[f.type]; k++) markedKeys.insert(f.keys[k]);
-  const std::vector<Key> observedKeys(markedKeys.begin(), markedKeys.end());
+    for (int k = 0; k < kFactorArity[f.type]; k++) newFactorKeys.insert(f.keys[k]);
+  for (Key key : keysWithRemovedFactors)
+    if (S.variableIndex.at(key).empty() && !newFactorKeys.count(key)) unusedKeys.insert(key);
+  // 3. gatherInvolvedKeys :199-226: keys of the new factors, of the removed factors, extraReelimKeys; updateKeys :228-244:
+  //    observedKeys = the marked keys that stay in the system
+  std::set<Key> markedKeys = newFactorKeys;
+  markedKeys.insert(keysWithRemovedFactors.begin(), keysWithRemovedFactors.end());
+  markedKeys.insert(up.extraReelimKeys.begin(), up.extraReelimKeys.end());
+  std::vector<Key> observedKeys;
+  for (Key k : markedKeys)
+    if (!unusedKeys.count(k)) observedKeys.push_back(k);
   std::set<Key> relinKeys;
   if (relinNeeded) {
-    // 4. CheckRelinearizationFull (:353-383): max |delta_j| >= threshold
+    // 4. gatherRelinearizeKeys :367-399: CheckRelinearizationFull (:353-383, max |delta_j| >= threshold) minus noRelinKeys
+    const double threshold = up.forceFullSolve ? 0.0 : S.relinearizeThreshold;
     for (auto& kd : S.delta) {
       double m = 0;
       for (double x : kd.second) m = std::max(m, std::abs(x));
-      if (m >= S.relinearizeThreshold) relinKeys.insert(kd.first);
+      if (m >= threshold) relinKeys.insert(kd.first);
     }
+    for (Key k : up.noRelinKeys) relinKeys.erase(k);
     markedKeys.insert(relinKeys.begin(), relinKeys.end());
     if (!relinKeys.empty()) {
       // 5. findFluid (:431-451), 6. theta.retractMasked(delta, relinKeys)
@@ -314,24 +355,29 @@ static ISAM2Result isam2_update(ISAM2& S, bool force_relinearize) {
     if ((double)affectedKeys.size() >= (double)S.theta.size() * 0.65) {
       // ---- recalculateBatch :178-247
       result.batch = 1;
-      for (auto& kv : S.variableIndex) affectedKeysSet.insert(kv.first);
+      VariableIndex affectedFactorsVarIndex = S.variableIndex;
+      for (Key key : unusedKeys) affectedFactorsVarIndex.erase(key);
+      for (auto& kv : affectedFactorsVarIndex) affectedKeysSet.insert(kv.first);
       std::vector<Key> order;
-      if (S.theta.size() > observedKeys.size()) {
+      if (up.hasConstrainedKeys) {
+        order = colamd_constrained(S, affectedFactorsVarIndex, S.nonlinearFactors.size(), up.constrainedKeys);
+      } else if (S.theta.size() > observedKeys.size()) {
         std::map<Key, int> groups;
         for (Key var : observedKeys) groups[var] = 1;
-        order = colamd_constrained(S, S.variableIndex, S.nonlinearFactors.size(), groups);
+        order = colamd_constrained(S, affectedFactorsVarIndex, S.nonlinearFactors.size(), groups);
       } else {
-        order = colamd_constrained(S, S.variableIndex, S.nonlinearFactors.size(), {});
+        order = colamd_constrained(S, affectedFactorsVarIndex, S.nonlinearFactors.size(), {});
       }
-      for (size_t i = 0; i < S.nonlinearFactors.size(); i++) S.linearFactors[i] = linearize_factor(S.nonlinearFactors[i], S.theta);
-      std::vector<IFactor> graph(S.linearFactors.size());
-      for (size_t i = 0; i < graph.size(); i++) {
+      std::vector<IFactor> graph(S.linearFactors.size());  // an empty slot stays an entry without keys (the indices are the row ids)
+      for (size_t i = 0; i < S.nonlinearFactors.size(); i++) {
+        if (S.removedFactor[i]) continue;
+        S.linearFactors[i] = linearize_factor(S.nonlinearFactors[i], S.theta);
         graph[i].g = &S.linearFactors[i];
         graph[i].keys = S.linearFactors[i].keys;
       }
       S.roots.clear();
       S.nodes.clear();
-      isam2_eliminate(S, graph, S.variableIndex, order);
+      isam2_eliminate(S, graph, affectedFactorsVarIndex, order);
       result.variablesReeliminated = (int)affectedKeysSet.size();
       result.factorsRecalculated = (int)S.nonlinearFactors.size();
     } else {
@@ -381,10 +427,14 @@ static ISAM2Result isam2_update(ISAM2& S, bool force_relinearize) {
       for (size_t i = 0; i < factors.size(); i++)
         for (Key k : factors[i].keys) affectedFactorsVarIndex[k].push_back(i);
       std::map<Key, int> constraintGroups;
-      const int group = observedKeys.size() < affectedFactorsVarIndex.size() ? 1 : 0;
-      for (Key var : observedKeys) constraintGroups.emplace(var, group);
-      for (auto it = constraintGroups.begin(); it != constraintGroups.end();) {
-        if (!affectedKeysSet.count(it->first)) it = constraintGroups.erase(it);
+      if (up.hasConstrainedKeys) {
+        constraintGroups = up.constrainedKeys;
+      } else {
+        const int group = observedKeys.size() < affectedFactorsVarIndex.size() ? 1 : 0;
+        for (Key var : observedKeys) constraintGroups.emplace(var, group);
+      }
+      for (auto it = constraintGroups.begin(); it != constraintGroups.end();) {  // "Remove unaffected keys from the constraints"
+        if (unusedKeys.count(it->first) || !affectedKeysSet.count(it->first)) it = constraintGroups.erase(it);
         else ++it;
       }
       const std::vector<Key> ordering = colamd_constrained(S, affectedFactorsVarIndex, factors.size(), constraintGroups);
@@ -392,6 +442,15 @@ static ISAM2Result isam2_update(ISAM2& S, bool force_relinearize) {
     }
     S.deltaReplacedMask.insert(affectedKeysSet.begin(), affectedKeysSet.end());
   }
+  // removeVariables ISAM2.cpp:385-398
+  for (Key key : unusedKeys) {
+    S.variableIndex.erase(key);
+    S.delta.erase(key);
+    S.deltaReplacedMask.erase(key);
+    S.nodes.erase(key);
+    S.theta.erase(key);
+  }
+  S.lastUnusedKeys.assign(unusedKeys.begin(), unusedKeys.end());
   result.cliques = 0;
   for (auto& r : S.roots) result.cliques += isam2_count_cliques(r);
   S.last = result;

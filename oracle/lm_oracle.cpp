@@ -1894,10 +1894,10 @@ int orc_isam2_add_factor(void* h, int type, const uint64_t* keys, const double* 
 }
 
 // result5: variablesRelinearized, variablesReeliminated, factorsRecalculated, cliques, batch.  1 = indeterminate system
-int orc_isam2_update(void* h, int force_relinearize, int* result5) {
+static int isam2_update_guarded(void* h, const orc::ISAM2UpdateParams& up, int* result5) {
   auto& S = ((ISAM2Handle*)h)->S;
   try {
-    const ISAM2Result r = isam2_update(S, force_relinearize != 0);
+    const ISAM2Result r = isam2_update(S, up);
     if (result5) {
       result5[0] = r.variablesRelinearized;
       result5[1] = r.variablesReeliminated;
@@ -1912,6 +1912,36 @@ int orc_isam2_update(void* h, int force_relinearize, int* result5) {
     return 2;
   }
   return 0;
+}
+int orc_isam2_update(void* h, int force_relinearize, int* result5) {
+  orc::ISAM2UpdateParams up;
+  up.force_relinearize = force_relinearize != 0;
+  return isam2_update_guarded(h, up, result5);
+}
+// ISAM2::update(newFactors, newTheta, ISAM2UpdateParams) (gtsam/nonlinear/ISAM2.h:146-186): has_constrained = the optional is engaged
+int orc_isam2_update_with(void* h, int n_remove, const uint64_t* remove_idx, int has_constrained, int n_constrained, const uint64_t* ckeys,
+                          const int* cgroups, int n_norelin, const uint64_t* norelin, int n_extra, const uint64_t* extra, int force_relinearize,
+                          int forceFullSolve, int* result5) {
+  orc::ISAM2UpdateParams up;
+  up.removeFactorIndices.assign(remove_idx, remove_idx + n_remove);
+  up.hasConstrainedKeys = has_constrained != 0;
+  for (int i = 0; i < n_constrained; i++) up.constrainedKeys[ckeys[i]] = cgroups[i];
+  up.noRelinKeys.assign(norelin, norelin + n_norelin);
+  up.extraReelimKeys.assign(extra, extra + n_extra);
+  up.force_relinearize = force_relinearize != 0;
+  up.forceFullSolve = forceFullSolve != 0;
+  return isam2_update_guarded(h, up, result5);
+}
+// ISAM2Result::unusedKeys of the last update (ascending); returns their number
+int orc_isam2_unused_keys(void* h, uint64_t* keys_out) {
+  auto& S = ((ISAM2Handle*)h)->S;
+  if (keys_out) std::copy(S.lastUnusedKeys.begin(), S.lastUnusedKeys.end(), keys_out);
+  return (int)S.lastUnusedKeys.size();
+}
+// 1 when slot i of the factor list still holds a factor
+int orc_isam2_factor_exists(void* h, int i) {
+  auto& S = ((ISAM2Handle*)h)->S;
+  return i >= 0 && i < (int)S.nonlinearFactors.size() && !S.removedFactor[i];
 }
 
 int orc_isam2_num_variables(void* h) { return (int)((ISAM2Handle*)h)->S.theta.size(); }

@@ -60,6 +60,17 @@ def slamlike_steps(max_poses=10):
     return steps
 
 
+def constrained_ordering_steps():
+    """TEST(ISAM2, constrained_ordering), tests/testGaussianISAM2.cpp:479-571: the slamlike sequence, from the fourth odometry step on
+    every update is given constrainedKeys {3: 1, 4: 2}.  [(graph, values, constrainedKeys | None)]"""
+    constrained = {3: 1, 4: 2}
+    out = []
+    for n, (g, v) in enumerate(slamlike_steps()):
+        # steps: 0 = prior, 1..5 = odometry i = 0..4 (constrained for i >= 3), 6.. = everything after, all constrained
+        out.append((g, v, constrained if n >= 4 else None))
+    return out
+
+
 def create_points():
     return [np.array(p, dtype=np.float64) for p in ((10, 10, 10), (-10, 10, 10), (-10, -10, 10), (10, -10, 10), (10, 10, -10), (-10, 10, -10),
                                                      (-10, -10, -10), (10, -10, -10))]

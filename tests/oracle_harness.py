@@ -432,6 +432,10 @@ class OracleISAM2:
         L.orc_isam2_add_variable.argtypes = [ct.c_void_p, ct.c_uint64, ct.c_int, _D]
         L.orc_isam2_add_factor.argtypes = [ct.c_void_p, ct.c_int, _U, _D, ct.c_int, _D]
         L.orc_isam2_update.argtypes = [ct.c_void_p, ct.c_int, _I]
+        L.orc_isam2_update_with.argtypes = [ct.c_void_p, ct.c_int, _U, ct.c_int, ct.c_int, _U, _I, ct.c_int, _U, ct.c_int, _U, ct.c_int, ct.c_int, _I]
+        L.orc_isam2_unused_keys.argtypes = [ct.c_void_p, _U]
+        L.orc_isam2_factor_exists.argtypes = [ct.c_void_p, ct.c_int]
+        L.orc_isam2_num_factors.argtypes = [ct.c_void_p]
         L.orc_isam2_num_variables.argtypes = [ct.c_void_p]
         L.orc_isam2_values.argtypes = [ct.c_void_p, ct.c_int, _U, _I, _D]
         L.orc_isam2_delta.argtypes = [ct.c_void_p, _D]
@@ -447,8 +451,10 @@ class OracleISAM2:
         except Exception:
             pass
 
-    def update(self, newFactors: NonlinearFactorGraph = None, newTheta: Values = None, force_relinearize=False):
-        """ISAM2::update(newFactors, newTheta); returns dict(variablesRelinearized, variablesReeliminated, factorsRecalculated, cliques, batch)"""
+    def update(self, newFactors: NonlinearFactorGraph = None, newTheta: Values = None, removeFactorIndices=(), constrainedKeys=None,
+               noRelinKeys=None, extraReelimKeys=None, force_relinearize=False, forceFullSolve=False):
+        """ISAM2::update(newFactors, newTheta, removeFactorIndices, constrainedKeys, noRelinKeys, extraReelimKeys, force_relinearize)
+        (gtsam/nonlinear/ISAM2.h:146-186); returns dict(variablesRelinearized, variablesReeliminated, factorsRecalculated, cliques, batch)"""
         if newTheta is not None:
             for k in newTheta.keys():
                 v = np.ascontiguousarray(newTheta.at(k), dtype=np.float64)
@@ -471,10 +477,30 @@ class OracleISAM2:
                     nd = dp(np.ascontiguousarray(model.data, dtype=np.float64).reshape(-1))
                 assert self.L.orc_isam2_add_factor(self.h, ftype, up(kk), dp(m), model.kind, nd) == 0
         res = np.zeros(5, dtype=np.int32)
-        rc = self.L.orc_isam2_update(self.h, int(force_relinearize), ip(res))
+        rm = np.asarray(list(removeFactorIndices), dtype=np.uint64)
+        ck = np.asarray(sorted(constrainedKeys) if constrainedKeys else [], dtype=np.uint64)
+        cg = np.asarray([constrainedKeys[int(k)] for k in ck], dtype=np.int32)
+        nr = np.asarray(list(noRelinKeys or []), dtype=np.uint64)
+        ex = np.asarray(list(extraReelimKeys or []), dtype=np.uint64)
+        rc = self.L.orc_isam2_update_with(self.h, len(rm), up(rm), int(constrainedKeys is not None), len(ck), up(ck), ip(cg), len(nr), up(nr),
+                                          len(ex), up(ex), int(force_relinearize), int(forceFullSolve), ip(res))
         assert rc == 0, rc
         return dict(variablesRelinearized=int(res[0]), variablesReeliminated=int(res[1]), factorsRecalculated=int(res[2]), cliques=int(res[3]),
                     batch=int(res[4]))
+
+    def unusedKeys(self):
+        """ISAM2Result::unusedKeys of the last update"""
+        n = self.L.orc_isam2_unused_keys(self.h, None)
+        keys = np.zeros(max(n, 1), dtype=np.uint64)
+        self.L.orc_isam2_unused_keys(self.h, up(keys))
+        return [int(k) for k in keys[:n]]
+
+    def factor_exists(self, i):
+        return bool(self.L.orc_isam2_factor_exists(self.h, int(i)))
+
+    def num_factors(self):
+        """slots of getFactorsUnsafe(), removed ones included"""
+        return self.L.orc_isam2_num_factors(self.h)
 
     def _values(self, which):
         n = self.L.orc_isam2_num_variables(self.h)

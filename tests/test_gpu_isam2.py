@@ -12,7 +12,7 @@ import pytest
 import oracle_harness as oh
 from gtsam_personal_amd import ISAM2, ISAM2GaussNewtonParams, ISAM2Params
 from gtsam_personal_amd.graph import symbol
-from isam2_examples import create_points, slamlike_steps, visual_steps
+from isam2_examples import constrained_ordering_steps, create_points, slamlike_steps, visual_steps
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not oh.have_ref(), reason="oracle/_ref (CCOLAMD of the reference) not built")]
 
@@ -200,3 +200,163 @@ def test_full_city10000_incremental_run():
     assert res["stopped"] is None, res
     assert res["updates"] == 9999 and res["same_tree"] and res["last_counts_equal"], res
     assert res["max_rel_diff"] < 1e-6 and res["widest_clique"] > 139, res
+
+
+# ---------------------------------------------------------------- ISAM2UpdateParams: factor removal, constraints, key lists
+NO_RELIN = ISAM2Params(ISAM2GaussNewtonParams(0.001), relinearizeThreshold=0.0, relinearizeSkip=0, enableRelinearization=False)
+
+
+def pair(params):
+    p = params
+    return (ISAM2(p, ccolamd=ccolamd, device=0),
+            oh.OracleISAM2(p.relinearizeThreshold, p.relinearizeSkip, p.enableRelinearization, p.optimizationParams.wildfireThreshold))
+
+
+def both(isam, orc, *args, **kw):
+    rg, ro = isam.update(*args, **kw).as_dict(), orc.update(*args, **kw)
+    assert rg == ro, (rg, ro)
+    assert isam.unusedKeys() == orc.unusedKeys()
+    assert isam.num_factors() == orc.num_factors() and isam.size() == len(orc.getLinearizationPoint().keys())
+    compare_state(isam, orc)
+    return rg
+
+
+REMOVAL_PARAMS = pytest.mark.parametrize("params", [NO_RELIN, ISAM2Params(relinearizeThreshold=0.01, relinearizeSkip=1)], ids=["norelin", "relin"])
+
+
+def slamlike_pair(params):
+    isam, orc = pair(params)
+    for g, v in slamlike_steps():
+        both(isam, orc, g, v)
+    return isam, orc
+
+
+@REMOVAL_PARAMS
+def test_remove_factors(params):
+    """TEST(ISAM2, removeFactors) tests/testGaussianISAM2.cpp:380-400 (index 12) against the oracle, which tests/test_isam2_oracle.py
+    pins to that test's expectation; then the same index again (an empty slot: a no-op) and an index beyond the list (refused)"""
+    isam, orc = slamlike_pair(params)
+    both(isam, orc, removeFactorIndices=[12])
+    assert not isam.factor_exists(12) and isam.factor_exists(11) and isam.unusedKeys() == []
+    both(isam, orc, removeFactorIndices=[12])
+    with pytest.raises(Exception):
+        isam.update(removeFactorIndices=[isam.num_factors()])
+    both(isam, orc)
+    isam.close()
+
+
+@REMOVAL_PARAMS
+def test_remove_variables(params):
+    """TEST(ISAM2, removeVariables) :403-423: indices 7 and 14 are the two measurements of landmark 100, which leaves the system with
+    them; afterwards the landmark comes back under its old key with new measurements"""
+    from gtsam_personal_amd import NonlinearFactorGraph, Values, noiseModel
+    isam, orc = slamlike_pair(params)
+    both(isam, orc, removeFactorIndices=[7, 14])
+    assert isam.unusedKeys() == [100] and 100 not in isam.getLinearizationPoint().keys() and 100 not in isam.getDelta()
+    assert isam.size() == 13
+    both(isam, orc)
+    br = noiseModel.Diagonal.Sigmas([np.pi / 100.0, 0.1])
+    g, v = NonlinearFactorGraph(), Values()
+    g.add_BearingRangeFactor2D(10, 100, np.pi / 4.0 + np.pi / 16.0, 4.5, br)
+    g.add_BearingRangeFactor2D(5, 100, np.pi / 4.0, 5.0, br)
+    v.insert_point2(100, [5.0 / np.sqrt(2.0), 5.0 / np.sqrt(2.0)])
+    both(isam, orc, g, v)
+    assert isam.size() == 14 and isam.unusedKeys() == []
+    isam.close()
+
+
+@REMOVAL_PARAMS
+def test_swap_factors(params):
+    """TEST(ISAM2, swapFactors) :426-476: the 2nd-to-last factor is replaced by one with another range in the same update"""
+    from gtsam_personal_amd import NonlinearFactorGraph, Values, noiseModel
+    isam, orc = slamlike_pair(params)
+    swap_idx = isam.num_factors() - 2
+    swap = NonlinearFactorGraph()
+    swap.add_BearingRangeFactor2D(10, 100, np.pi / 4.0 + np.pi / 16.0, 5.0, noiseModel.Diagonal.Sigmas([np.pi / 100.0, 0.1]))
+    both(isam, orc, swap, Values(), removeFactorIndices=[swap_idx])
+    assert isam.num_factors() == swap_idx + 3 and not isam.factor_exists(swap_idx)
+    isam.close()
+
+
+def test_constrained_ordering():
+    """TEST(ISAM2, constrained_ordering) :479-571: constrainedKeys {3: 1, 4: 2}; x4 ends up in the root clique"""
+    isam, orc = pair(NO_RELIN)
+    for g, v, c in constrained_ordering_steps():
+        both(isam, orc, g, v, constrainedKeys=c)
+        if c is not None:
+            assert any(4 in keys[:nfk] for keys, nfk, _, par in isam.cliques() if par < 0)
+    isam.close()
+
+
+def test_no_relin_and_extra_reelim_keys_and_full_solve():
+    isam, orc = pair(ISAM2Params(relinearizeThreshold=0.0, relinearizeSkip=1))
+    steps = slamlike_steps()
+    for g, v in steps[:-1]:
+        both(isam, orc, g, v)
+    g, v = steps[-1]
+    both(isam, orc, g, v, noRelinKeys=[0, 1, 2])
+    r = both(isam, orc, extraReelimKeys=[0, 100])
+    assert r["variablesReeliminated"] > 0
+    both(isam, orc, forceFullSolve=True, force_relinearize=True)
+    with pytest.raises(Exception):
+        isam.update(extraReelimKeys=[12345])
+    both(isam, orc)
+    isam.close()
+
+
+def test_fixed_lag_style_run_with_removals():
+    """the first 260 poses of city10000, one pose per update; from pose 150 on every update also removes the factors that reach back
+    more than 150 poses from the newest one and pins the oldest remaining pose with a prior at its current estimate (so the system
+    stays determined): the keys of removed factors are re-eliminated, poses that lose every factor leave the system.  Counts, unused
+    keys and the whole state against the oracle"""
+    import os
+    from gtsam_personal_amd import NonlinearFactorGraph, Values, noiseModel
+    from gtsam_personal_amd.datasets import readG2o
+    graph, _ = readG2o(os.path.join(os.path.dirname(__file__), "golden", "city10000_head.g2o"))
+    edges = []
+    for ftype, kind, gi, keys, meas, noise, models in graph.buckets():
+        for i, gidx in enumerate(gi.tolist()):
+            edges.append((gidx, int(keys[i][0]), int(keys[i][1]), meas[i], models[i]))
+    edges.sort()
+    isam, orc = pair(ISAM2Params())
+
+    def compose(a, d):
+        c, s = np.cos(a[2]), np.sin(a[2])
+        return np.array([a[0] + c * d[0] - s * d[1], a[1] + s * d[0] + c * d[1], a[2] + d[2]])
+
+    live = {}  # factor index -> oldest pose it touches
+    nxt, step, removed_vars = 0, 1, 0
+    while nxt < len(edges) and step <= 260:
+        g, v = NonlinearFactorGraph(), Values()
+        first = isam.num_factors()
+        if step == 1:
+            v.insert_pose2(0, 0.0, 0.0, 0.0)
+            g.add_PriorFactorPose2(0, [0.0, 0.0, 0.0], noiseModel.Unit.Create(3))
+            live[first] = 0
+        while nxt < len(edges):
+            _, k1, k2, m, model = edges[nxt]
+            if k1 > step or k2 > step:
+                break
+            live[first + g.size()] = min(k1, k2)
+            g.add_BetweenFactorPose2(k1, k2, m, model)
+            if k2 == step and k1 == step - 1:
+                prev = np.zeros(3) if step == 1 else orc.calculateEstimate().at(step - 1)
+                v.insert(step, 0, compose(prev, m))
+            nxt += 1
+        oldest = step - 150
+        old = sorted(i for i, k in live.items() if k < oldest and i < first)
+        for i in old:
+            del live[i]
+        if old:
+            live[first + g.size()] = oldest
+            g.add_PriorFactorPose2(oldest, orc.calculateEstimate().at(oldest), noiseModel.Diagonal.Sigmas([0.05, 0.05, 0.02]))
+        rg, ro = isam.update(g, v, removeFactorIndices=old).as_dict(), orc.update(g, v, removeFactorIndices=old)
+        assert rg == ro, (step, rg, ro)
+        assert isam.unusedKeys() == orc.unusedKeys(), step
+        removed_vars += len(isam.unusedKeys())
+        if step % 20 == 0:
+            compare_state(isam, orc)
+        step += 1
+    assert removed_vars > 50 and isam.size() == len(orc.getLinearizationPoint().keys())
+    compare_state(isam, orc)
+    isam.close()

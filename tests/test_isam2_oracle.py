@@ -11,15 +11,25 @@ import pytest
 import oracle_harness as oh
 from gtsam_personal_amd import NonlinearFactorGraph, Ordering, Values
 from gtsam_personal_amd.graph import VAR_DIM, symbol
-from isam2_examples import create_points, slamlike_steps, visual_steps
+from gtsam_personal_amd import noiseModel
+from isam2_examples import constrained_ordering_steps, create_points, slamlike_steps, visual_steps
 
 pytestmark = pytest.mark.skipif(not oh.have_ref(), reason="oracle/_ref (CCOLAMD of the reference) not built")
 
 
-def merge(steps):
+def merge(steps, removed=()):
+    """the full graph / initial values of a sequence; `removed`: indices (positions in the full factor list) left out"""
     graph, init = NonlinearFactorGraph(), Values()
-    for g, v in steps:
-        graph.push_back(g)
+    at = 0
+    for g, v, *_ in steps:
+        rec = [None] * g.size()
+        for ftype, _, gi, keys, meas, _, models in g.buckets():
+            for i, gidx in enumerate(gi.tolist()):
+                rec[gidx] = (ftype, keys[i], meas[i], models[i])
+        for ftype, keys, meas, model in rec:
+            if at not in removed:
+                graph._add(ftype, [keys], [meas], model)
+            at += 1
         for k in v.keys():
             init.insert(k, v.type(k), v.at(k))
     return graph, init
@@ -90,3 +100,86 @@ def test_visual_isam2_reaches_the_ground_truth():
     assert len(result.keys()) == 16
     for j, p in enumerate(create_points()):
         assert np.allclose(result.at(symbol("l", j)), p, rtol=0, atol=0.01), j
+
+
+NO_RELIN = dict(relinearizeThreshold=0.0, relinearizeSkip=0, enableRelinearization=False, wildfireThreshold=0.001)
+
+
+def slamlike_isam():
+    steps = slamlike_steps()
+    isam = oh.OracleISAM2(**NO_RELIN)
+    for g, v in steps:
+        isam.update(g, v)
+    return isam, steps
+
+
+def test_remove_factors():
+    """TEST(ISAM2, removeFactors) tests/testGaussianISAM2.cpp:380-400: remove the 2nd-to-last measurement of landmark 100 (index 12)"""
+    isam, steps = slamlike_isam()
+    n = isam.num_factors()
+    isam.update(removeFactorIndices=[12])
+    assert isam.unusedKeys() == [] and isam.num_factors() == n and not isam.factor_exists(12) and isam.factor_exists(11)
+    isam_check(isam, *merge(steps, removed={12}))
+
+
+def test_remove_variables():
+    """TEST(ISAM2, removeVariables) :403-423: both measurements of landmark 100 go (indices 7 and 14) and the landmark with them"""
+    isam, steps = slamlike_isam()
+    isam.update(removeFactorIndices=[7, 14])
+    assert isam.unusedKeys() == [100]
+    fullgraph, fullinit = merge(steps, removed={7, 14})
+    fullinit.erase(100)
+    isam_check(isam, fullgraph, fullinit)
+    assert 100 not in isam.getLinearizationPoint().keys() and 100 not in isam.getDelta()
+
+
+def test_swap_factors():
+    """TEST(ISAM2, swapFactors) :426-476: the 2nd-to-last factor is replaced by one with another range in the same update"""
+    isam, steps = slamlike_isam()
+    swap_idx = isam.num_factors() - 2
+    swap = NonlinearFactorGraph()
+    swap.add_BearingRangeFactor2D(10, 100, np.pi / 4.0 + np.pi / 16.0, 5.0, noiseModel.Diagonal.Sigmas([np.pi / 100.0, 0.1]))
+    isam.update(swap, removeFactorIndices=[swap_idx])
+    assert isam.unusedKeys() == [] and isam.num_factors() == swap_idx + 3 and not isam.factor_exists(swap_idx)
+    isam_check(isam, *merge(steps + [(swap, Values())], removed={swap_idx}))
+
+
+def test_constrained_ordering():
+    """TEST(ISAM2, constrained_ordering) :479-571: constrainedKeys {3: 1, 4: 2} from the fourth odometry step on; the batch solution is
+    reached, and the constrained variables end up last: x4 in the root clique (the largest group is eliminated last)"""
+    steps = constrained_ordering_steps()
+    isam = oh.OracleISAM2(**NO_RELIN)
+    for g, v, c in steps:
+        isam.update(g, v, constrainedKeys=c)
+        roots = [keys[:nfk] for keys, nfk, _, par in isam.cliques() if par < 0]
+        if c is not None:
+            assert any(4 in r for r in roots), roots
+    isam_check(isam, *merge(steps))
+
+
+def test_extra_reelim_and_no_relin_keys():
+    """extraReelimKeys re-eliminates the named variables' cliques (gatherInvolvedKeys, ISAM2-impl.h:210-215) without changing the solution;
+    noRelinKeys keeps the linearization point of the named variables (gatherRelinearizeKeys, :388-392)"""
+    steps = slamlike_steps()
+    a = oh.OracleISAM2(relinearizeThreshold=0.0, relinearizeSkip=1, wildfireThreshold=0.001)
+    b = oh.OracleISAM2(relinearizeThreshold=0.0, relinearizeSkip=1, wildfireThreshold=0.001)
+    for g, v in steps[:-1]:
+        a.update(g, v)
+        b.update(g, v)
+    g, v = steps[-1]
+    ra = a.update(g, v)
+    rb = b.update(g, v, noRelinKeys=[0, 1, 2])
+    la, lb = a.getLinearizationPoint(), b.getLinearizationPoint()
+    assert rb["variablesRelinearized"] < ra["variablesRelinearized"]
+    for k in (0, 1, 2):
+        assert not np.array_equal(la.at(k), lb.at(k))
+    c = oh.OracleISAM2(**NO_RELIN)
+    for g, v in steps:
+        c.update(g, v)
+    est = c.calculateEstimate()
+    r = c.update(extraReelimKeys=[0])
+    assert r["variablesReeliminated"] > 0
+    est2 = c.calculateEstimate()
+    for k in est.keys():
+        assert np.allclose(est.at(k), est2.at(k), rtol=0, atol=1e-9)
+    isam_check(c, *merge(steps))
