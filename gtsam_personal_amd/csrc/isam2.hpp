@@ -129,6 +129,8 @@ struct lmgpu_isam2 {
   size_t stage_cap = 0, stage_used = 0, stage_want = 0;
   std::vector<std::pair<void*, void*>> stage_extra;  // (pinned host, device)
   double* inv16 = nullptr;    // 16 x 256 doubles: the 16 x 16 inverses of the panel being factored (wide cliques)
+  double* d_marg = nullptr;   // marginalCovariance: one work vector per column of the block + the block itself
+  size_t marg_cap = 0;
   double* h_delta = nullptr;  // pinned copy of delta for CheckRelinearizationFull
   size_t h_delta_cap = 0;
   // LMGPU_ISAM2_TRACE=1: wall time per phase of update(), printed when the handle is destroyed (development aid)
@@ -575,6 +577,77 @@ __global__ __launch_bounds__(256) void isam2_wildfire_kernel(int32_t* __restrict
     __syncthreads();
     if (tid == 0) atomicSub(&wl[2], 1u);  // this item is finished (its children, if any, are counted already)
     __syncthreads();
+  }
+}
+
+
+// ISAM2::marginalCovariance(key) (gtsam/nonlinear/ISAM2.h:253-257 -> BayesTree::marginalFactor(key)->information().inverse()):
+// column c of Sigma = (R^T R)^-1 restricted to the variable is x with R^T y = e_c, R x = y.  In the Bayes tree both solves only touch the
+// PATH from the clique of the variable to its root: y is zero below it, and x is only wanted at the variable.  One wave per column, no
+// hand-offs: forward (R^T) up the path, back-substitution down again; w = one work vector per column (zeroed by the host), laid out like delta.
+// path[0] = the clique the variable is frontal in ... path[npath - 1] = its root.
+__global__ __launch_bounds__(64) void isam2_marginal_kernel(const int32_t* __restrict__ path, int npath, const lmgpu::FrontDesc* __restrict__ tree,
+                                                             const int32_t* __restrict__ tree_fx, const int32_t* __restrict__ tree_sx,
+                                                             const double* __restrict__ pool, double* W, int ntot, int xoff, int dim,
+                                                             double* __restrict__ out, int* __restrict__ status) {
+  extern __shared__ double v[];  // the clique's slice of the work vector: [nf frontal | ns separator]
+  const int lane = threadIdx.x, c = blockIdx.x;
+  double* w = W + (size_t)c * ntot;
+  auto ld_w = [&](int i) { return __hip_atomic_load(&w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  auto st_w = [&](int i, double x) { __hip_atomic_store(&w[i], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  auto wave_sync = [&]() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  };
+  if (lane == 0) st_w(xoff + c, 1.0);
+  wave_sync();
+  for (int dir = 0; dir < 2; dir++)
+    for (int q = 0; q < npath; q++) {
+      const int p = dir == 0 ? q : npath - 1 - q;
+      const lmgpu::FrontDesc F = tree[path[p]];
+      const int n = F.n, nf = F.nf, ns = n - nf - 1, ld = F.ld_rsd;
+      const bool wide = F.par_ld != 0;
+      const int32_t* fxr = wide ? (const int32_t*)(pool + F.par_off) : tree_fx + (size_t)path[p] * ISAM2_TREE_ROW;
+      const int32_t* sxr = wide ? fxr + nf : tree_sx + (size_t)path[p] * ISAM2_TREE_ROW;
+      const double* A = pool + F.rsd_off;
+      for (int i = lane; i < nf; i += 64) v[i] = ld_w(fxr[i]);
+      if (dir == 1)
+        for (int j = lane; j < ns; j += 64) v[nf + j] = ld_w(sxr[j]);
+      wave_sync();
+      if (dir == 0) {
+        // R^T y_F = b_F, then b_S -= S^T y_F
+        for (int i = 0; i < nf; i++) {
+          double a = 0.0;
+          for (int k = lane; k < i; k += 64) a += A[(size_t)k * ld + i] * v[k];
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+          if (lane == 0) v[i] = (v[i] - a) / A[(size_t)i * ld + i];
+          wave_sync();
+        }
+        for (int j = lane; j < ns; j += 64) {
+          double a = 0.0;
+          for (int k = 0; k < nf; k++) a += A[(size_t)k * ld + nf + j] * v[k];
+          st_w(sxr[j], ld_w(sxr[j]) - a);
+        }
+      } else {
+        // x_F = R^-1 (y_F - S x_S)
+        for (int i = nf - 1; i >= 0; i--) {
+          const double* row = A + (size_t)i * ld;
+          double a = 0.0;
+          for (int j = i + 1 + lane; j < n - 1; j += 64) a += row[j] * v[j];
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+          if (lane == 0) v[i] = (v[i] - a) / row[i];
+          wave_sync();
+        }
+      }
+      for (int i = lane; i < nf; i += 64) st_w(fxr[i], v[i]);
+      wave_sync();
+    }
+  if (lane < dim) {
+    const double x = ld_w(xoff + lane);
+    out[c * dim + lane] = x;
+    if (!(fabs(x) < 1.7e308)) atomicMin(status, 0);  // NaN / inf: a singular clique on the path
   }
 }
 
@@ -1574,6 +1647,52 @@ int lmgpu_isam2_get_values(lmgpu_isam2* S, int32_t which, uint64_t* keys_out, in
       std::memcpy(packed_out, &host[v.type][(size_t)v.tidx * kVarStore[v.type]], kVarStore[v.type] * sizeof(double));
       packed_out += kVarStore[v.type];
     }
+  }
+  return LMGPU_OK;
+}
+
+// ISAM2::marginalCovariance(key) (gtsam/nonlinear/ISAM2.h:253-257; tests/testGaussianISAM2.cpp:977-986): dim x dim, symmetric
+int lmgpu_isam2_marginal_covariance(lmgpu_isam2* S, uint64_t key, double* cov) {
+  if (!S || !cov) return LMGPU_INVALID;
+  if (S->device < 0) return LMGPU_HIP_ERROR;
+  auto it = S->vid_of.find(key);
+  if (it == S->vid_of.end() || S->node_of[it->second] < 0) {
+    S->err = "ISAM2::marginalCovariance: the variable is not in the Bayes tree";
+    return LMGPU_INVALID;
+  }
+  ISCHECK(hipSetDevice(S->device));
+  int rc = is_patch_tree(S);
+  if (rc) return rc;
+  const lmgpu_isam2::Var& var = S->vars[it->second];
+  const int dim = kVarDim[var.type];
+  std::vector<int32_t> path;
+  size_t max_n = 1;
+  for (int id = S->node_of[it->second]; id >= 0; id = S->clq[id].parent) {
+    path.push_back(id);
+    max_n = std::max(max_n, (size_t)S->clq[id].n);
+  }
+  const size_t need = (size_t)dim * S->ntot + 128;
+  if (need > S->marg_cap) {
+    if (S->d_marg) (void)hipFree(S->d_marg);
+    S->d_marg = nullptr;
+    S->marg_cap = is_next_cap(S->marg_cap, need);
+    ISCHECK(hipMalloc((void**)&S->d_marg, S->marg_cap * sizeof(double)));
+  }
+  double* d_out = S->d_marg + (size_t)dim * S->ntot;
+  int32_t* d_path;
+  if ((rc = is_stage(S, path, &d_path))) return rc;
+  ISCHECK(hipMemsetAsync(S->d_marg, 0, (size_t)dim * S->ntot * sizeof(double), S->stream));
+  ISCHECK(hipMemsetAsync(S->d_status, 0x7f, sizeof(int), S->stream));
+  hipLaunchKernelGGL(isam2_marginal_kernel, dim3(dim), dim3(64), max_n * sizeof(double), S->stream, (const int32_t*)d_path, (int)path.size(),
+                     (const FrontDesc*)S->d_tree, (const int32_t*)S->d_tree_fx, (const int32_t*)S->d_tree_sx, (const double*)S->pool, S->d_marg, S->ntot,
+                     var.xoff, dim, d_out, S->d_status);
+  ISCHECK(hipMemcpyAsync(cov, d_out, (size_t)dim * dim * sizeof(double), hipMemcpyDeviceToHost, S->stream));
+  ISCHECK(hipMemcpyAsync(S->h_status, S->d_status, sizeof(int), hipMemcpyDeviceToHost, S->stream));
+  ISCHECK(hipStreamSynchronize(S->stream));
+  if (*S->h_status == 0) {
+    S->failed_key = key;
+    S->err = "indeterminate linear system in marginalCovariance";
+    return LMGPU_INDETERMINATE;
   }
   return LMGPU_OK;
 }

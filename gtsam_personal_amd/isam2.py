@@ -136,6 +136,21 @@ class ISAM2:
         self._check(self.lib.lmgpu_isam2_update_with(self._h, ct.byref(up), ct.byref(res)))
         return ISAM2Result(res)
 
+    def marginalCovariance(self, key):
+        """ISAM2::marginalCovariance(key) (gtsam/nonlinear/ISAM2.h:253-257)"""
+        lin_type = None
+        n = self.lib.lmgpu_isam2_num_variables(self._h)
+        keys = np.zeros(n, dtype=np.uint64)
+        types = np.zeros(n, dtype=np.int32)
+        self._check(self.lib.lmgpu_isam2_get_values(self._h, 2, keys.ctypes.data_as(ct.POINTER(ct.c_uint64)), types.ctypes.data_as(_lib._I), None))
+        at = np.nonzero(keys == np.uint64(key))[0]
+        if at.size:
+            lin_type = int(types[at[0]])
+        d = VAR_DIM[lin_type] if lin_type is not None else 9
+        cov = np.zeros((d, d))
+        self._check(self.lib.lmgpu_isam2_marginal_covariance(self._h, int(key), cov.ctypes.data_as(_lib._D)))
+        return cov
+
     def unusedKeys(self):
         """ISAM2Result::unusedKeys of the last update: the variables that left the system with their last factor"""
         n = self.lib.lmgpu_isam2_get_unused_keys(self._h, None)

@@ -337,6 +337,10 @@ int lmgpu_isam2_num_factors(const lmgpu_isam2* s);   /* slots of the factor list
  * Variables ascending by Key (the reference's Values order); any of the outputs may be NULL. */
 int lmgpu_isam2_get_values(lmgpu_isam2* s, int32_t which, uint64_t* keys_out, int32_t* types_out, double* packed_out);
 int lmgpu_isam2_get_delta(lmgpu_isam2* s, double* packed); /* getDelta (:776-779), ascending by Key */
+/* ISAM2::marginalCovariance(key) (gtsam/nonlinear/ISAM2.h:253-257: the inverse of BayesTree::marginalFactor(key)'s information; the
+ * linearization point's covariance block of the variable, dim x dim): two triangular solves per column, on the device, along the path
+ * from the variable's clique to its root.  LMGPU_INVALID for a variable that is not in the tree. */
+int lmgpu_isam2_marginal_covariance(lmgpu_isam2* s, uint64_t key, double* cov);
 /* parity taps: the Bayes tree depth-first from the roots (children in order).  lmgpu_isam2_num_cliques takes the snapshot the
  * other two index; info5: n_keys, n_frontal_keys, nf, n, parent (index in the snapshot, -1 root); RSd column-major nf x n */
 int lmgpu_isam2_num_cliques(lmgpu_isam2* s);

@@ -498,6 +498,15 @@ class GpuISAM2 {
     return r;
   }
 
+  /// ISAM2::marginalCovariance(key) (ISAM2.h:253-257)
+  Matrix marginalCovariance(Key key) const {
+    if (!all_.exists(key)) throw std::out_of_range("GpuISAM2::marginalCovariance: unknown key");
+    const int d = (int)all_.at(key).dim();
+    Matrix cov(d, d);  // symmetric: the row-major block the library writes reads the same column-major
+    check(lmgpu_isam2_marginal_covariance(h_, key, cov.data()));
+    return cov;
+  }
+
   /// ISAM2Result::unusedKeys of the last update
   KeySet unusedKeys() const {
     std::vector<uint64_t> k((size_t)std::max(1, lmgpu_isam2_get_unused_keys(h_, nullptr)));

@@ -488,6 +488,22 @@ class OracleISAM2:
         return dict(variablesRelinearized=int(res[0]), variablesReeliminated=int(res[1]), factorsRecalculated=int(res[2]), cliques=int(res[3]),
                     batch=int(res[4]))
 
+    def marginalCovariance(self, key):
+        """ISAM2::marginalCovariance(key) (gtsam/nonlinear/ISAM2.h:253-257): the block of (sum over cliques [R S]^T [R S])^-1 -- the
+        Bayes tree read as a Gaussian factor graph (GaussianBayesTree), dense; for test-sized problems"""
+        lin = self._values(2)
+        off, o = {}, 0
+        for k in lin.keys():
+            off[k] = o
+            o += VAR_DIM[lin.type(k)]
+        H = np.zeros((o, o))
+        for keys, _, rsd, _ in self.cliques():
+            cols = np.concatenate([np.arange(off[k], off[k] + VAR_DIM[lin.type(k)]) for k in keys])
+            RS = rsd[:, :-1]
+            H[np.ix_(cols, cols)] += RS.T @ RS
+        d = VAR_DIM[lin.type(int(key))]
+        return np.linalg.inv(H)[off[int(key)]:off[int(key)] + d, off[int(key)]:off[int(key)] + d]
+
     def unusedKeys(self):
         """ISAM2Result::unusedKeys of the last update"""
         n = self.L.orc_isam2_unused_keys(self.h, None)

@@ -360,3 +360,38 @@ def test_fixed_lag_style_run_with_removals():
     assert removed_vars > 50 and isam.size() == len(orc.getLinearizationPoint().keys())
     compare_state(isam, orc)
     isam.close()
+
+
+def test_marginal_covariance():
+    """TEST(ISAM2, marginalCovariance) tests/testGaussianISAM2.cpp:977-986 on the device: every variable of the slamlike example (with
+    relinearization: the tree is at the linearization point) and of VisualISAM2Example against the oracle's tree; a removed variable and
+    an unknown key are refused"""
+    isam, orc = slamlike_pair(ISAM2Params(relinearizeThreshold=0.01, relinearizeSkip=1))
+    for k in orc.getLinearizationPoint().keys():
+        e = orc.marginalCovariance(k)
+        assert np.allclose(isam.marginalCovariance(k), e, rtol=1e-6, atol=1e-9 * np.abs(e).max()), k
+    both(isam, orc, removeFactorIndices=[7, 14])
+    with pytest.raises(Exception):
+        isam.marginalCovariance(100)
+    with pytest.raises(Exception):
+        isam.marginalCovariance(4242)
+    e = orc.marginalCovariance(5)
+    assert np.allclose(isam.marginalCovariance(5), e, rtol=1e-6, atol=1e-9 * np.abs(e).max())
+    isam.close()
+    isam, orc = run_sequence(visual_steps(), ISAM2Params(relinearizeThreshold=0.01, relinearizeSkip=1), check_every_step=False)
+    for k in orc.getLinearizationPoint().keys():
+        e = orc.marginalCovariance(k)
+        assert np.allclose(isam.marginalCovariance(k), e, rtol=1e-6, atol=1e-9 * np.abs(e).max()), k
+    isam.close()
+
+
+def test_marginal_covariance_through_wide_cliques():
+    """the dense pose graph whose cliques exceed an LDS front: the path to the root runs through cliques walked from memory"""
+    isam, orc = pair(ISAM2Params())
+    for g, v in dense_pose2_steps():
+        assert isam.update(g, v).as_dict() == orc.update(g, v)
+    assert max(rsd.shape[1] for _, _, rsd, _ in isam.cliques()) > 139
+    for k in orc.getLinearizationPoint().keys()[::7]:
+        e = orc.marginalCovariance(k)
+        assert np.allclose(isam.marginalCovariance(k), e, rtol=1e-6, atol=1e-9 * np.abs(e).max()), k
+    isam.close()

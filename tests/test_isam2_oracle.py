@@ -183,3 +183,16 @@ def test_extra_reelim_and_no_relin_keys():
     for k in est.keys():
         assert np.allclose(est.at(k), est2.at(k), rtol=0, atol=1e-9)
     isam_check(c, *merge(steps))
+
+
+def test_marginal_covariance():
+    """TEST(ISAM2, marginalCovariance) tests/testGaussianISAM2.cpp:977-986: isam.marginalCovariance(5) equals
+    Marginals(isam.getFactorsUnsafe(), isam.getLinearizationPoint()).marginalCovariance(5)"""
+    isam, steps = slamlike_isam()
+    fullgraph, _ = merge(steps)
+    lin = isam.getLinearizationPoint()
+    batch = oh.OracleProblem(fullgraph, lin, Ordering.Natural(fullgraph))
+    for key in (5, 0, 11, 100):
+        d = VAR_DIM[lin.type(key)]
+        expected = batch.marginal_covariance(key, d)
+        assert np.allclose(isam.marginalCovariance(key), expected, rtol=1e-9, atol=1e-12), key
