@@ -11,6 +11,13 @@
 #include "kernels_dense.hpp"
 #include "kernels_potrf.hpp"
 
+// development aid (tools/microbench.hip defines them): where the workgroups of a chained launch spend their time
+#ifndef CHAIN_PROF_BEGIN
+#define CHAIN_PROF_BEGIN()
+#define CHAIN_PROF_WAITED()
+#define CHAIN_PROF_END(cls)
+#endif
+
 namespace lmgpu {
 
 struct StepArgs {
@@ -202,17 +209,20 @@ __device__ __forceinline__ void step_body(const StepArgs& a, int t, const ChainL
       si = (t - nHead) & 3;
     }
     const bool ok = chain_wait_tile(c, T, S, si >> 1, sj >> 1, s_ok);
+    CHAIN_PROF_WAITED();
     if (!ok && threadIdx.x == 0) atomicExch(a.status + 1, 1 + a.front_id);  // hand-off timed out: a fault, reported apart from pivot failures
     if (t < nHead)
       syrk_quadrant32(a.A, a.ld, a.n, a.p0, a.kp, r0, si, sj, t & 3, a.S);
     else
       syrk_subtile64(a.A, a.ld, a.n, a.p0, a.kp, r0, si, sj, a.S);
     pdf_publish(&a.flags[PDF_TA0 + sj], threadIdx.x == 0);
+    CHAIN_PROF_END(t < nHead ? 0 : 1);
     return;
   }
   t -= nTA;
   if (t < nd) {
     panel_role(a.A, a.ld, a.n, a.nf, r0, a.kb_next, t, a.front_id, a.status, a.inv16, a.flags, sm, s_ok, true);
+    CHAIN_PROF_END(2);
     return;
   }
   t -= nd;
@@ -225,13 +235,16 @@ __device__ __forceinline__ void step_body(const StepArgs& a, int t, const ChainL
     }
     const int tj = ti + rem;
     const bool ok = chain_wait_tile(c, T, S, ti, tj, s_ok);
+    CHAIN_PROF_WAITED();
     if (!ok && threadIdx.x == 0) atomicExch(a.status + 1, 1 + a.front_id);  // hand-off timed out: a fault, reported apart from pivot failures
     syrk_tile(a.A, a.ld, a.n, a.p0, a.kp, r0, a.n, ti, tj, sm);
     if (c.publish) pdf_publish(&a.flags[PDF_TD0 + ti * T - ti * (ti - 1) / 2 + (tj - ti)], threadIdx.x == 0);
+    CHAIN_PROF_END(3);
     return;
   }
   t -= nTiles - nTArows;
   panel_role(a.A, a.ld, a.n, a.nf, r0, a.kb_next, nd + t, a.front_id, a.status, a.inv16, a.flags, sm, s_ok, true, c.publish);
+  CHAIN_PROF_END(4);
 }
 
 // a trailing update of a few tiles (the tail of a front) as 32 x 32 quadrants: grid (4 x strips, strips)
@@ -277,6 +290,7 @@ struct ChainArgs {
 __global__ __launch_bounds__(256, 2) void chain_kernel(ChainArgs ca) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ int s_bid, s_ok;
+  CHAIN_PROF_BEGIN();
   if (threadIdx.x == 0) s_bid = (int)atomicAdd(&ca.flags[(size_t)(ca.i0 + 1) * PDF_FLAG_WORDS], 1u);
   __syncthreads();
   const int2 task = ca.tasks[s_bid];

@@ -18,6 +18,46 @@
       *(unsigned long long*)&(flags)[512 + 64 * (b) + 2 * (slot)] = t_;                            \
     }                                                                                              \
   } while (0)
+// where the workgroups of a chained launch spend their time: per class (head quadrants, head 64-tiles, diagonal, update tiles, row-panel)
+// [count, ticks waiting for inputs, ticks working] + slot-time per 100 us bucket of the launch (100 MHz realtime counter)
+__device__ unsigned long long g_prof[16], g_hist[256], g_t0, g_begin[1 << 17], g_waited[1 << 17];
+__device__ __forceinline__ unsigned long long prof_now() {
+  unsigned long long t_;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+  return t_;
+}
+#define CHAIN_PROF_BEGIN()                                  \
+  do {                                                      \
+    if (threadIdx.x == 0) {                                 \
+      g_begin[blockIdx.x] = prof_now();                     \
+      g_waited[blockIdx.x] = 0;                             \
+      atomicMin(&g_t0, g_begin[blockIdx.x]);                \
+    }                                                       \
+  } while (0)
+#define CHAIN_PROF_WAITED()                                 \
+  do {                                                      \
+    if (threadIdx.x == 0) g_waited[blockIdx.x] = prof_now(); \
+  } while (0)
+#define CHAIN_PROF_END(cls)                                                              \
+  do {                                                                                   \
+    __syncthreads();                                                                     \
+    if (threadIdx.x == 0 && g_begin[blockIdx.x] != 0) { /* chained launches only */      \
+      const unsigned long long e_ = prof_now(), b_ = g_begin[blockIdx.x];                \
+      g_begin[blockIdx.x] = 0;                                                           \
+      const unsigned long long w_ = g_waited[blockIdx.x] ? g_waited[blockIdx.x] : b_;    \
+      atomicAdd(&g_prof[3 * (cls)], 1ull);                                               \
+      atomicAdd(&g_prof[3 * (cls) + 1], w_ - b_);                                        \
+      atomicAdd(&g_prof[3 * (cls) + 2], e_ - w_);                                        \
+      const unsigned long long t0_ = g_t0;                                               \
+      int it_ = 0;                                                                       \
+      for (unsigned long long x_ = w_ - t0_; x_ < e_ - t0_ && it_ < 300; it_++) {        \
+        const unsigned long long nb_ = (x_ / 10000 + 1) * 10000;                         \
+        const unsigned long long y_ = nb_ < e_ - t0_ ? nb_ : e_ - t0_;                   \
+        if (x_ / 10000 < 256) atomicAdd(&g_hist[x_ / 10000], y_ - x_);                   \
+        x_ = y_;                                                                         \
+      }                                                                                  \
+    }                                                                                    \
+  } while (0)
 #include "kernels_dense.hpp"
 #include "kernels_potrf.hpp"
 #include "kernels_step.hpp"
@@ -186,6 +226,13 @@ int main(int argc, char** argv) {
       hipLaunchKernelGGL(panel_dataflow_kernel, dim3(4 + (n - first * 256 - 256 + 63) / 64), dim3(256), PDF_LDS_BYTES, 0, A, ld, n, n - 1, first * 256, 256,
                          0, status, inv16, flags + (size_t)first * PDF_FLAG_WORDS);
       CK(hipDeviceSynchronize());
+      {
+        std::vector<unsigned long long> z(256, 0);
+        const unsigned long long big = ~0ull;
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z.data(), 16 * 8));
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_hist), z.data(), 256 * 8));
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_t0), &big, 8));
+      }
       CK(hipEventRecord(e0, 0));
       hipLaunchKernelGGL(chain_kernel, dim3((int)tasks.size()), dim3(256), STEP_LDS_BYTES, 0, ca);
       CK(hipEventRecord(e1, 0));
@@ -197,6 +244,34 @@ int main(int argc, char** argv) {
       CK(hipMemcpy(hf.data(), flags, hf.size() * 4, hipMemcpyDeviceToHost));
       auto st = [&](int region, int b, int slot) { return *(unsigned long long*)&hf[(size_t)region * PDF_FLAG_WORDS + 512 + 64 * b + 2 * slot]; };
       const unsigned long long t0 = st(first + 1, 0, 19);
+      {
+        unsigned long long pr[16], hi[256];
+        CK(hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_prof), 16 * 8));
+        CK(hipMemcpyFromSymbol(hi, HIP_SYMBOL(g_hist), 256 * 8));
+        const char* cn[5] = {"head quadrants", "head 64-tiles", "diagonal", "update tiles", "row-panel"};
+        double tot_work = 0;
+        for (int c = 0; c < 5; c++) {
+          printf("  class %-14s: %6llu workgroups, waiting %9.1f us, working %10.1f us (avg %6.1f us each)\n", cn[c], pr[3 * c], pr[3 * c + 1] / 100.0,
+                 pr[3 * c + 2] / 100.0, pr[3 * c] ? pr[3 * c + 2] / 100.0 / pr[3 * c] : 0.0);
+          tot_work += pr[3 * c + 2] / 100.0;
+        }
+        printf("  slot occupancy (working workgroup-time / (512 slots x launch time)): %.3f\n", tot_work / (512.0 * ms * 1e3));
+        printf("  working slots per 100 us bucket (of 512):");
+        for (int b = 0; b < 256 && b * 100.0 < ms * 1e3; b++) printf(" %d", (int)(hi[b] / 10000.0 + 0.5));
+        printf("\n");
+      }
+      {  // cadence of the whole chain: when panel s + 1 was complete (last diagonal workgroup published), and the flop done by then
+        double prev = 0, flop_acc = 0;
+        for (int sidx = 0; sidx < ca.nsteps; sidx++) {
+          const int reg = first + sidx + 1;
+          const double t = (double)(long long)(st(reg, 3, 23) - t0) / 100.0;
+          const double m = n - (first + sidx + 1) * 256;
+          flop_acc += 256.0 * m * (m + 1);
+          printf("  cadence step %2d m=%5d: panel done at %8.1f us (+%6.1f)   updates of steps <= this one: %6.1f GF = %6.1f us at 44.8 TF\n", first + sidx,
+                 (int)m, t, t - prev, flop_acc / 1e9, flop_acc / 44.8e12 * 1e6);
+          prev = t;
+        }
+      }
       for (int sidx = std::max(0, ca.nsteps - 12); sidx < ca.nsteps; sidx++) {
         const int reg = first + sidx + 1;
         auto us = [&](int b, int slot) { return (double)(long long)(st(reg, b, slot) - t0) / 100.0; };
