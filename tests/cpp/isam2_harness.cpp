@@ -1,0 +1,183 @@
+// isam2_harness — drives the incremental path of liblmgpu.so (lmgpu_isam2_*) from C++ in the call order of the reference-side
+// wrapper (include/lmgpu_gtsam_adapter.h: GpuISAM2::update = add_variables, add_factors in graph order, update_with; then
+// calculateEstimate), without GTSAM and without Python between the updates: what an update costs a C++ caller.
+// The constrained COLAMD the library asks for per update is the CALLER's (lmgpu_ccolamd_fn): here the reference's vendored CCOLAMD,
+// compiled by oracle/Makefile into oracle/_ref/libccolamd_ref.so and loaded with dlopen (test infrastructure, like the tests'
+// Python binding of the same library), with GTSAM's knobs (gtsam/inference/Ordering.cpp:94-97).
+//
+// The sequence of updates comes in a neutral text file written by the test / tool from the Python mirror's graphs:
+//   ISAM2 relinearizeThreshold relinearizeSkip enableRelinearization wildfireThreshold
+//   UPDATE nv nf nremove          then nv lines  V key type store d0 d1 ...
+//                                 then nf lines  F type k0 k1 k2 | nmeas meas... | noise_kind nnoise noise...
+//                                 then one line  R idx0 idx1 ...            (removeFactorIndices, nremove entries)
+//   ... END
+// usage: isam2_harness <sequence file> <device> <libccolamd_ref.so>
+// Output: one JSON object: updates, seconds inside the library calls, ms per update, the final estimate (key, packed value).
+#include <dlfcn.h>
+
+#include <chrono>
+#include <cinttypes>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "../../include/lmgpu.h"
+
+namespace {
+
+typedef size_t (*recommended_fn)(int, int, int);
+typedef void (*defaults_fn)(double*);
+typedef int (*ccolamd_fn)(int, int, int, int*, int*, double*, int*, int*);
+recommended_fn p_recommended = nullptr;
+defaults_fn p_defaults = nullptr;
+ccolamd_fn p_ccolamd = nullptr;
+double g_colamd_seconds = 0;
+
+double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// the body of Ordering::ColamdConstrained (gtsam/inference/Ordering.cpp:86-108) on the arrays the library hands over
+int colamd_cb(void*, int32_t n_rows, int32_t n_cols, const int32_t* col_ptr, const int32_t* row_idx, const int32_t* cmember, int32_t* perm_out) {
+  const double t0 = now();
+  const size_t Alen = p_recommended(col_ptr[n_cols], n_rows, n_cols);
+  std::vector<int> A(Alen), p(col_ptr, col_ptr + n_cols + 1), cm(cmember, cmember + n_cols);
+  for (int i = 0; i < col_ptr[n_cols]; i++) A[i] = row_idx[i];
+  double knobs[20];
+  p_defaults(knobs);
+  knobs[0] = -1;  // CCOLAMD_DENSE_ROW
+  knobs[1] = -1;  // CCOLAMD_DENSE_COL
+  int stats[20];
+  const int rv = p_ccolamd(n_rows, n_cols, (int)Alen, A.data(), p.data(), knobs, stats, cm.data());
+  if (rv == 1)
+    for (int j = 0; j < n_cols; j++) perm_out[j] = p[j];
+  g_colamd_seconds += now() - t0;
+  return rv == 1 ? 1 : 0;
+}
+
+struct Update {
+  std::vector<uint64_t> vkeys;
+  std::vector<int32_t> vtypes;
+  std::vector<double> vpacked;
+  struct F {
+    int32_t type, noise_kind;
+    uint64_t k[3];
+    std::vector<double> meas, noise;
+  };
+  std::vector<F> facs;
+  std::vector<uint64_t> remove;
+};
+
+int fail(const char* what, const char* detail) {
+  std::printf("{\"error\": \"%s: %s\"}\n", what, detail ? detail : "");
+  return 1;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  if (argc < 4) {
+    std::fprintf(stderr, "usage: isam2_harness <sequence file> <device> <libccolamd_ref.so>\n");
+    return 2;
+  }
+  void* so = dlopen(argv[3], RTLD_NOW);
+  if (!so) return fail("dlopen", dlerror());
+  p_recommended = (recommended_fn)dlsym(so, "ccolamd_recommended");
+  p_defaults = (defaults_fn)dlsym(so, "ccolamd_set_defaults");
+  p_ccolamd = (ccolamd_fn)dlsym(so, "ccolamd");
+  if (!p_recommended || !p_defaults || !p_ccolamd) return fail("dlsym", "ccolamd symbols");
+
+  std::ifstream is(argv[1]);
+  if (!is) return fail("open", argv[1]);
+  std::string w;
+  lmgpu_isam2_params prm{};
+  if (!(is >> w) || w != "ISAM2" || !(is >> prm.relinearizeThreshold >> prm.relinearizeSkip >> prm.enableRelinearization >> prm.wildfireThreshold))
+    return fail("parse", "header");
+  std::vector<Update> updates;
+  while (is >> w && w == "UPDATE") {
+    size_t nv, nf, nr;
+    if (!(is >> nv >> nf >> nr)) return fail("parse", "UPDATE");
+    Update u;
+    for (size_t i = 0; i < nv; i++) {
+      uint64_t k;
+      int32_t t;
+      int store;
+      if (!(is >> w >> k >> t >> store) || w != "V") return fail("parse", "V");
+      u.vkeys.push_back(k);
+      u.vtypes.push_back(t);
+      for (int j = 0; j < store; j++) {
+        double d;
+        is >> d;
+        u.vpacked.push_back(d);
+      }
+    }
+    for (size_t i = 0; i < nf; i++) {
+      Update::F f{};
+      size_t nm, nn;
+      if (!(is >> w >> f.type >> f.k[0] >> f.k[1] >> f.k[2] >> nm) || w != "F") return fail("parse", "F");
+      f.meas.resize(nm);
+      for (double& d : f.meas) is >> d;
+      if (!(is >> f.noise_kind >> nn)) return fail("parse", "noise");
+      f.noise.resize(nn);
+      for (double& d : f.noise) is >> d;
+      u.facs.push_back(std::move(f));
+    }
+    if (!(is >> w) || w != "R") return fail("parse", "R");
+    u.remove.resize(nr);
+    for (uint64_t& r : u.remove) is >> r;
+    updates.push_back(std::move(u));
+  }
+
+  lmgpu_config cfg{};
+  cfg.device = std::atoi(argv[2]);
+  cfg.world_size = 1;
+  lmgpu_isam2* h = nullptr;
+  if (lmgpu_isam2_create(&cfg, &prm, &colamd_cb, nullptr, &h) != LMGPU_OK) return fail("lmgpu_isam2_create", h ? lmgpu_isam2_last_error(h) : "");
+  double lib = 0, worst = 0;
+  lmgpu_isam2_result r{};
+  size_t done = 0;
+  for (const Update& u : updates) {
+    const double t0 = now();
+    int rc = lmgpu_isam2_add_variables(h, (int32_t)u.vkeys.size(), u.vkeys.data(), u.vtypes.data(), u.vpacked.data());
+    for (const Update::F& f : u.facs)
+      if (rc == LMGPU_OK)
+        rc = lmgpu_isam2_add_factors(h, f.type, 1, f.k, f.meas.data(), f.noise_kind, f.noise.empty() ? nullptr : f.noise.data());
+    if (rc == LMGPU_OK) {
+      const lmgpu_isam2_update_params up{(int32_t)u.remove.size(), u.remove.data(), 0, 0, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, 0};
+      rc = lmgpu_isam2_update_with(h, &up, &r);
+    }
+    const double dt = now() - t0;
+    lib += dt;
+    worst = dt > worst ? dt : worst;
+    if (rc != LMGPU_OK) {
+      std::printf("{\"error\": \"update %zu: rc %d: %s\"}\n", done, rc, lmgpu_isam2_last_error(h));
+      lmgpu_isam2_destroy(h);
+      return 1;
+    }
+    done++;
+  }
+  const double t1 = now();
+  const int n = lmgpu_isam2_num_variables(h);
+  std::vector<uint64_t> keys((size_t)n);
+  std::vector<int32_t> types((size_t)n);
+  if (lmgpu_isam2_get_values(h, 2, keys.data(), types.data(), nullptr) != LMGPU_OK) return fail("get_values", lmgpu_isam2_last_error(h));
+  static const int store[6] = {3, 12, 3, 15, 2, 5};  // lmgpu.h: doubles per packed value of each variable type
+  size_t tot = 0;
+  for (int32_t t : types) tot += (size_t)store[t];
+  std::vector<double> packed(tot);
+  if (lmgpu_isam2_get_values(h, 0, nullptr, nullptr, packed.data()) != LMGPU_OK) return fail("calculateEstimate", lmgpu_isam2_last_error(h));
+  const double t_est = now() - t1;
+  std::printf("{\"updates\": %zu, \"library_seconds\": %.6f, \"ms_per_update\": %.6f, \"worst_update_ms\": %.4f, \"ccolamd_callback_seconds\": %.6f, "
+              "\"calculate_estimate_ms\": %.4f, \"variables\": %d, \"cliques\": %d, \"estimate\": [",
+              done, lib, done ? 1e3 * lib / done : 0.0, 1e3 * worst, g_colamd_seconds, 1e3 * t_est, n, r.cliques);
+  const double* q = packed.data();
+  for (int i = 0; i < n; i++) {
+    std::printf("%s[%" PRIu64, i ? ", " : "", keys[(size_t)i]);
+    for (int j = 0; j < store[types[(size_t)i]]; j++) std::printf(", %.17g", q[j]);
+    std::printf("]");
+    q += store[types[(size_t)i]];
+  }
+  std::printf("]}\n");
+  lmgpu_isam2_destroy(h);
+  return 0;
+}

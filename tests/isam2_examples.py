@@ -119,3 +119,71 @@ def visual_steps(extra_update=True):
                 steps.append((NonlinearFactorGraph(), Values()))
             g, v = NonlinearFactorGraph(), Values()
     return steps
+
+
+def incremental_pose2_steps(g2o_path, n_poses, init_from):
+    """timing/timeIncremental.cpp:84-170 on a Pose2 g2o file: one pose per update with the edges that reach back from it; the new pose is
+    the previous one's estimate (init_from(step - 1) -> 3-vector, asked before the update that adds pose `step`) composed with the
+    odometry.  A generator of (graph, values): the caller applies each update before asking for the next."""
+    from gtsam_personal_amd.datasets import readG2o
+    graph, _ = readG2o(g2o_path)
+    edges = []
+    for ftype, kind, gi, keys, meas, noise, models in graph.buckets():
+        for i, g in enumerate(gi.tolist()):
+            edges.append((g, int(keys[i][0]), int(keys[i][1]), meas[i], models[i]))
+    edges.sort()
+
+    def compose(a, d):
+        c, s = np.cos(a[2]), np.sin(a[2])
+        return np.array([a[0] + c * d[0] - s * d[1], a[1] + s * d[0] + c * d[1], a[2] + d[2]])
+
+    nxt, step = 0, 1
+    while nxt < len(edges) and step <= n_poses:
+        g, v = NonlinearFactorGraph(), Values()
+        if step == 1:
+            v.insert_pose2(0, 0.0, 0.0, 0.0)
+            g.add_PriorFactorPose2(0, [0.0, 0.0, 0.0], noiseModel.Unit.Create(3))
+        while nxt < len(edges):
+            _, k1, k2, m, model = edges[nxt]
+            if k1 > step or k2 > step:
+                break
+            g.add_BetweenFactorPose2(k1, k2, m, model)
+            if k2 == step and k1 == step - 1:
+                v.insert(step, 0, compose(np.zeros(3) if step == 1 else init_from(step - 1), m))
+            nxt += 1
+        yield g, v
+        step += 1
+
+
+def write_isam2_sequence(path, params, steps):
+    """the input of tests/cpp/isam2_harness: what the reference-side wrapper extracts from each update's NonlinearFactorGraph / Values
+    (the packings of include/lmgpu.h), as text.  steps: [(graph, values[, removeFactorIndices])]"""
+    from gtsam_personal_amd.graph import FACTOR_ARITY, F_PRIOR_CAM, F_SFM, N_UNIT, VAR_STORE_DEV
+    u0v0 = {}
+    with open(path, "w") as f:
+        p = params
+        f.write(f"ISAM2 {p.relinearizeThreshold!r} {int(p.relinearizeSkip)} {int(bool(p.enableRelinearization))} {p.optimizationParams.wildfireThreshold!r}\n")
+        for st in steps:
+            g, v = st[0], st[1]
+            rm = list(st[2]) if len(st) > 2 and st[2] is not None else []
+            f.write(f"UPDATE {v.size()} {g.size()} {len(rm)}\n")
+            for k in v.keys():
+                t = v.type(k)
+                if t == 3:
+                    u0v0[k] = v.at(k)[15:17].copy()
+                f.write(f"V {int(k)} {t} {VAR_STORE_DEV[t]} " + " ".join(repr(float(x)) for x in v.at(k)[:VAR_STORE_DEV[t]]) + "\n")
+            rows = [None] * g.size()
+            for ftype, kind, gi, keys, meas, noise, models in g.buckets():
+                for i, gidx in enumerate(gi.tolist()):
+                    m = np.array(meas[i], dtype=np.float64)
+                    if ftype == F_SFM:
+                        m = m - u0v0[int(keys[i][0])]
+                    if ftype == F_PRIOR_CAM:
+                        m = m[:15]
+                    kk = [int(x) for x in keys[i][:FACTOR_ARITY[ftype]]] + [0] * (3 - FACTOR_ARITY[ftype])
+                    nz = [] if kind == N_UNIT else np.asarray(noise[i], dtype=np.float64).reshape(-1).tolist()
+                    rows[gidx] = (f"F {ftype} {kk[0]} {kk[1]} {kk[2]} {len(m)} " + " ".join(repr(float(x)) for x in m) + f" {kind} {len(nz)} " +
+                                  " ".join(repr(float(x)) for x in nz) + "\n")
+            f.writelines(rows)
+            f.write("R " + " ".join(str(int(i)) for i in rm) + "\n")
+        f.write("END\n")

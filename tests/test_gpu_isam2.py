@@ -395,3 +395,49 @@ def test_marginal_covariance_through_wide_cliques():
         e = orc.marginalCovariance(k)
         assert np.allclose(isam.marginalCovariance(k), e, rtol=1e-6, atol=1e-9 * np.abs(e).max()), k
     isam.close()
+
+
+def test_cpp_driver_runs_the_incremental_workloads(tmp_path):
+    """tests/cpp/isam2_harness: the C ABI driven from C++ in the reference-side wrapper's call order (no Python between the updates) on
+    VisualISAM2Example's sequence, on the slamlike sequence followed by the removals of the reference's removeVariables test, and on the
+    400-pose incremental pose graph; the final estimate against the oracle, which ran the same updates"""
+    import json
+    import os
+    import subprocess
+    from isam2_examples import incremental_pose2_steps, write_isam2_sequence
+    from gtsam_personal_amd import NonlinearFactorGraph, Values
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "tests", "cpp")], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    harness = os.path.join(root, "tests", "cpp", "isam2_harness")
+    ccolamd_so = os.path.join(root, "oracle", "_ref", "libccolamd_ref.so")
+
+    def run_case(name, params, steps_iter, orc):
+        steps = []
+        for st in steps_iter:
+            orc.update(st[0], st[1], removeFactorIndices=st[2] if len(st) > 2 else ())
+            steps.append(st)
+        path = str(tmp_path / f"{name}.txt")
+        write_isam2_sequence(path, params, steps)
+        out = subprocess.run([harness, path, "0", ccolamd_so], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert out.returncode == 0, out.stdout.decode()[-500:] + out.stderr.decode()[-500:]
+        res = json.loads(out.stdout)
+        assert res["updates"] == len(steps)
+        est = orc.calculateEstimate()
+        assert [int(r[0]) for r in res["estimate"]] == est.keys()
+        for r in res["estimate"]:
+            e = est.at(int(r[0]))
+            assert np.allclose(np.array(r[1:])[:len(e)], e[:len(r) - 1], rtol=1e-6, atol=1e-8), (name, r[0])
+        assert res["cliques"] == len(orc.cliques())
+        return res
+
+    def oracle_of(p):
+        return oh.OracleISAM2(p.relinearizeThreshold, p.relinearizeSkip, p.enableRelinearization, p.optimizationParams.wildfireThreshold)
+
+    p = ISAM2Params(relinearizeThreshold=0.01, relinearizeSkip=1)
+    run_case("visual", p, visual_steps(), oracle_of(p))
+    p = ISAM2Params()
+    run_case("slamlike_removal", p, [(g, v) for g, v in slamlike_steps()] + [(NonlinearFactorGraph(), Values(), [7, 14])], oracle_of(p))
+    orc = oracle_of(p)
+    g2o = os.path.join(os.path.dirname(__file__), "golden", "city10000_head.g2o")
+    res = run_case("city400", p, incremental_pose2_steps(g2o, 400, lambda k: orc.calculateEstimate().at(k)), orc)
+    assert res["variables"] == 400

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Side measurement (not the bench.py metric): wall time per ISAM2::update on the device vs. the CPU oracle, on the incremental
 workloads of tests/test_gpu_isam2.py (VisualISAM2Example; the first 400 poses of city10000 played timeIncremental-style).
-    python tools/bench_isam2.py"""
+The second half drives the same C ABI from C++ (tests/cpp/isam2_harness: the reference-side wrapper's call order, no Python between
+the updates; the sequence is recorded from the oracle's run first) -- what an update costs a C++ caller -- on the 400-pose sequence and
+on ALL poses of city10000 (tests/golden/city10000.g2o, one pose per update = timing/timeIncremental.cpp).
+    python tools/bench_isam2.py [--full]"""
 import os
 import sys
 import time
@@ -70,3 +73,39 @@ for name, steps, params in (("VisualISAM2Example (8 poses, 8 points)", visual_st
     to = (time.perf_counter() - t0) / (len(steps) - 1)
     print(f"{name}: device {1e3 * tg:.3f} ms per update (incl. the Python marshalling and the ccolamd callback), CPU oracle {1e3 * to:.3f} ms per update")
     isam.close()
+
+
+# ---- the C++ driver
+import json  # noqa: E402
+import subprocess  # noqa: E402
+import tempfile  # noqa: E402
+from isam2_examples import incremental_pose2_steps, write_isam2_sequence  # noqa: E402
+
+subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "cpp")], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+cases = [("city10000 head, 400 poses", os.path.join(ROOT, "tests", "golden", "city10000_head.g2o"), 400)]
+if "--full" in sys.argv:
+    cases.append(("city10000, all 10000 poses", os.path.join(ROOT, "tests", "golden", "city10000.g2o"), 10000))
+for name, g2o, n in cases:
+    p = ISAM2Params()
+    orc = oh.OracleISAM2(p.relinearizeThreshold, p.relinearizeSkip, p.enableRelinearization, p.optimizationParams.wildfireThreshold)
+    steps, t_orc = [], 0.0
+    for g, v in incremental_pose2_steps(g2o, n, lambda k: orc.calculateEstimate().at(k)):
+        t0 = time.perf_counter()
+        orc.update(g, v)
+        t_orc += time.perf_counter() - t0
+        steps.append((g, v))
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "seq.txt")
+        write_isam2_sequence(path, p, steps)
+        out = subprocess.run([os.path.join(ROOT, "tests", "cpp", "isam2_harness"), path, "0", os.path.join(ROOT, "oracle", "_ref", "libccolamd_ref.so")],
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    res = json.loads(out.stdout)
+    est = orc.calculateEstimate()
+    worst = 0.0
+    for r in res["estimate"]:
+        e = est.at(int(r[0]))
+        worst = max(worst, float(np.max(np.abs(np.array(r[1:]) - e) / np.maximum(1.0, np.abs(e)))))
+    print(f"{name}, C++ driver: {res['updates']} updates, {res['ms_per_update']:.4f} ms per update inside the library calls "
+          f"(of which the caller's ccolamd {1e3 * res['ccolamd_callback_seconds'] / res['updates']:.4f} ms), worst update {res['worst_update_ms']:.2f} ms, "
+          f"calculateEstimate {res['calculate_estimate_ms']:.2f} ms; CPU oracle {1e3 * t_orc / len(steps):.4f} ms per update (through ctypes); "
+          f"estimate vs oracle: max rel diff {worst:.2e}, cliques {res['cliques']}", flush=True)
