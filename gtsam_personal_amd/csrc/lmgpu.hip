@@ -2377,7 +2377,11 @@ int lmgpu_linearize(lmgpu_handle* h) {
 
 int lmgpu_solve(lmgpu_handle* h, double lambda, int32_t diagonal_damping, double min_diag, double max_diag, double* delta_packed,
                 double* lin_err0, double* lin_err1) {
-  if (!h || !h->finalized || !h->linearized) return LMGPU_INVALID;
+  if (!h) return LMGPU_INVALID;
+  if (!h->finalized || !h->linearized) {
+    h->err = "lmgpu_solve: no linearization to solve (call lmgpu_linearize after lmgpu_finalize_structure / lmgpu_set_values)";
+    return LMGPU_INVALID;
+  }
   int rc = need_device(h);
   if (rc) return rc;
   if ((rc = need_comm(h))) return rc;
