@@ -1588,7 +1588,11 @@ const char* lmgpu_last_error(const lmgpu_handle* h) { return h ? h->err.c_str() 
 int lmgpu_last_failed_slot(const lmgpu_handle* h) { return h ? h->failed_slot : -1; }
 
 int lmgpu_set_variables(lmgpu_handle* h, int32_t n_vars, const uint64_t* keys, const int32_t* types) {
-  if (!h || n_vars <= 0 || !keys || !types || h->finalized) return LMGPU_INVALID;
+  if (!h) return LMGPU_INVALID;
+  if (n_vars <= 0 || !keys || !types || h->finalized) {
+    h->err = "lmgpu_set_variables: refused (n_vars <= 0 || !keys || !types || h->finalized)";
+    return LMGPU_INVALID;
+  }
   h->plan.n_vars = n_vars;
   h->plan.keys.assign(keys, keys + n_vars);
   h->plan.types.assign(types, types + n_vars);
@@ -1607,7 +1611,11 @@ int lmgpu_add_factor_bucket(lmgpu_handle* h, int32_t type, int32_t n, const int3
 
 int lmgpu_add_factor_bucket_robust(lmgpu_handle* h, int32_t type, int32_t n, const int32_t* graph_index, const int32_t* var_slots,
                                    const double* meas, int32_t noise_kind, const double* noise, int32_t robust_kind, double robust_k) {
-  if (!h || h->finalized || type < 0 || type >= LMGPU_NUM_FACTOR_TYPES || n < 0 || h->plan.n_vars == 0) return LMGPU_INVALID;
+  if (!h) return LMGPU_INVALID;
+  if (h->finalized || type < 0 || type >= LMGPU_NUM_FACTOR_TYPES || n < 0 || h->plan.n_vars == 0) {
+    h->err = "lmgpu_add_factor_bucket_robust: refused (h->finalized || type < 0 || type >= LMGPU_NUM_FACTOR_TYPES || n < 0 || h->plan.n_vars == 0)";
+    return LMGPU_INVALID;
+  }
   if (robust_kind < LMGPU_ROBUST_NONE || robust_kind > LMGPU_ROBUST_L2_WITH_DEAD_ZONE || (robust_kind != LMGPU_ROBUST_NONE && !(robust_k > 0.0)))
     return LMGPU_INVALID;
   if (noise_kind != LMGPU_N_UNIT && noise_kind != LMGPU_N_DIAG && noise_kind != LMGPU_N_GAUSS) return LMGPU_INVALID;
@@ -1660,7 +1668,11 @@ int lmgpu_add_factor_bucket_robust(lmgpu_handle* h, int32_t type, int32_t n, con
 }
 
 int lmgpu_finalize_structure(lmgpu_handle* h) {
-  if (!h || h->finalized) return LMGPU_INVALID;
+  if (!h) return LMGPU_INVALID;
+  if (h->finalized) {
+    h->err = "lmgpu_finalize_structure: refused (h->finalized)";
+    return LMGPU_INVALID;
+  }
   std::string e = h->plan.build(kLdsLimitN);
   if (!e.empty()) {
     h->err = e;
@@ -2300,7 +2312,11 @@ int lmgpu_total_dim(const lmgpu_handle* h) { return (h && h->finalized) ? h->nto
 int lmgpu_total_store(const lmgpu_handle* h) { return (h && h->finalized) ? h->nstore : -1; }
 
 int lmgpu_set_values(lmgpu_handle* h, const double* packed) {
-  if (!h || !h->finalized || !packed) return LMGPU_INVALID;
+  if (!h) return LMGPU_INVALID;
+  if (!h->finalized || !packed) {
+    h->err = "lmgpu_set_values: refused (!h->finalized || !packed)";
+    return LMGPU_INVALID;
+  }
   int rc = need_device(h);
   if (rc) return rc;
   const Plan& P = h->plan;
@@ -2316,7 +2332,11 @@ int lmgpu_set_values(lmgpu_handle* h, const double* packed) {
 }
 
 int lmgpu_get_values(lmgpu_handle* h, double* packed) {
-  if (!h || !h->finalized || !packed || !h->have_values) return LMGPU_INVALID;
+  if (!h) return LMGPU_INVALID;
+  if (!h->finalized || !packed || !h->have_values) {
+    h->err = "lmgpu_get_values: refused (!h->finalized || !packed || !h->have_values)";
+    return LMGPU_INVALID;
+  }
   int rc = need_device(h);
   if (rc) return rc;
   const Plan& P = h->plan;
@@ -2333,7 +2353,11 @@ int lmgpu_get_values(lmgpu_handle* h, double* packed) {
 
 // device-side snapshot of the current values (e.g. the initial estimate) and its restore: device-to-device copies
 int lmgpu_save_values(lmgpu_handle* h) {
-  if (!h || !h->finalized || !h->have_values) return LMGPU_INVALID;
+  if (!h) return LMGPU_INVALID;
+  if (!h->finalized || !h->have_values) {
+    h->err = "lmgpu_save_values: refused (!h->finalized || !h->have_values)";
+    return LMGPU_INVALID;
+  }
   int rc = need_device(h);
   if (rc) return rc;
   for (int t = 0; t < kNumVarTypes; t++) {
@@ -2346,7 +2370,11 @@ int lmgpu_save_values(lmgpu_handle* h) {
 }
 
 int lmgpu_restore_values(lmgpu_handle* h) {
-  if (!h || !h->finalized || !h->saved[0]) return LMGPU_INVALID;
+  if (!h) return LMGPU_INVALID;
+  if (!h->finalized || !h->saved[0]) {
+    h->err = "lmgpu_restore_values: refused (!h->finalized || !h->saved[0])";
+    return LMGPU_INVALID;
+  }
   int rc = need_device(h);
   if (rc) return rc;
   for (int t = 0; t < kNumVarTypes; t++) {
@@ -2357,7 +2385,11 @@ int lmgpu_restore_values(lmgpu_handle* h) {
 }
 
 int lmgpu_error(lmgpu_handle* h, double* total) {
-  if (!h || !h->finalized || !total || !h->have_values) return LMGPU_INVALID;
+  if (!h) return LMGPU_INVALID;
+  if (!h->finalized || !total || !h->have_values) {
+    h->err = "lmgpu_error: refused (!h->finalized || !total || !h->have_values)";
+    return LMGPU_INVALID;
+  }
   int rc = need_device(h);
   if (rc) return rc;
   if ((rc = need_comm(h))) return rc;
@@ -2365,7 +2397,11 @@ int lmgpu_error(lmgpu_handle* h, double* total) {
 }
 
 int lmgpu_linearize(lmgpu_handle* h) {
-  if (!h || !h->finalized || !h->have_values) return LMGPU_INVALID;
+  if (!h) return LMGPU_INVALID;
+  if (!h->finalized || !h->have_values) {
+    h->err = "lmgpu_linearize: refused (!h->finalized || !h->have_values)";
+    return LMGPU_INVALID;
+  }
   int rc = need_device(h);
   if (rc) return rc;
   rc = do_linearize(h);
@@ -2406,7 +2442,11 @@ __global__ __launch_bounds__(256) void zero_rhs_kernel(const FacDesc* __restrict
 __global__ void set_one_kernel(double* p) { *p = 1.0; }
 
 int lmgpu_joint_marginal_covariance(lmgpu_handle* h, int32_t nslots, const int32_t* slots, double* cov) {
-  if (!h || !cov || !slots || nslots < 1 || !h->finalized || !h->have_values) return LMGPU_INVALID;
+  if (!h) return LMGPU_INVALID;
+  if (!cov || !slots || nslots < 1 || !h->finalized || !h->have_values) {
+    h->err = "lmgpu_joint_marginal_covariance: refused (!cov || !slots || nslots < 1 || !h->finalized || !h->have_values)";
+    return LMGPU_INVALID;
+  }
   for (int a = 0; a < nslots; a++) {
     if (slots[a] < 0 || slots[a] >= h->plan.n_vars) return LMGPU_INVALID;
     for (int b = 0; b < a; b++)
@@ -2461,7 +2501,11 @@ int lmgpu_marginal_covariance(lmgpu_handle* h, int32_t slot, double* cov) { retu
 // GaussianFactorGraph the reference's linearize() returned: tryLambda solves it again with a larger lambda after a rejected step
 // (LevenbergMarquardtOptimizer.cpp:302-305) whatever happened to the Values in between.
 int lmgpu_retract(lmgpu_handle* h, const double* delta_packed) {
-  if (!h || !h->finalized || !h->have_values) return LMGPU_INVALID;
+  if (!h) return LMGPU_INVALID;
+  if (!h->finalized || !h->have_values) {
+    h->err = "lmgpu_retract: refused (!h->finalized || !h->have_values)";
+    return LMGPU_INVALID;
+  }
   int rc = need_device(h);
   if (rc) return rc;
   if (delta_packed) HIPCHECK(hipMemcpy(h->delta, delta_packed, h->ntot * sizeof(double), hipMemcpyHostToDevice));
@@ -2473,7 +2517,11 @@ int lmgpu_retract(lmgpu_handle* h, const double* delta_packed) {
 }
 
 int lmgpu_hessian_diagonal(lmgpu_handle* h, double* diag) {
-  if (!h || !h->finalized || !h->linearized || !diag) return LMGPU_INVALID;
+  if (!h) return LMGPU_INVALID;
+  if (!h->finalized || !h->linearized || !diag) {
+    h->err = "lmgpu_hessian_diagonal: refused (!h->finalized || !h->linearized || !diag)";
+    return LMGPU_INVALID;
+  }
   int rc = need_device(h);
   if (rc) return rc;
   if ((rc = need_comm(h))) return rc;
@@ -2484,7 +2532,11 @@ int lmgpu_hessian_diagonal(lmgpu_handle* h, double* diag) {
 }
 
 int lmgpu_lm_init(lmgpu_handle* h, const lmgpu_lm_params* p, lmgpu_lm_state* out) {
-  if (!h || !p || !h->finalized || !h->have_values) return LMGPU_INVALID;
+  if (!h) return LMGPU_INVALID;
+  if (!p || !h->finalized || !h->have_values) {
+    h->err = "lmgpu_lm_init: refused (!p || !h->finalized || !h->have_values)";
+    return LMGPU_INVALID;
+  }
   int rc = need_device(h);
   if (rc) return rc;
   if ((rc = need_comm(h))) return rc;
@@ -2502,7 +2554,11 @@ int lmgpu_lm_init(lmgpu_handle* h, const lmgpu_lm_params* p, lmgpu_lm_state* out
 }
 
 int lmgpu_iterate(lmgpu_handle* h, const lmgpu_lm_params* p, lmgpu_lm_state* inout) {
-  if (!h || !p || !h->finalized || !h->have_values) return LMGPU_INVALID;
+  if (!h) return LMGPU_INVALID;
+  if (!p || !h->finalized || !h->have_values) {
+    h->err = "lmgpu_iterate: refused (!p || !h->finalized || !h->have_values)";
+    return LMGPU_INVALID;
+  }
   int rc = need_device(h);
   if (rc) return rc;
   if ((rc = need_comm(h))) return rc;
@@ -2513,7 +2569,11 @@ int lmgpu_iterate(lmgpu_handle* h, const lmgpu_lm_params* p, lmgpu_lm_state* ino
 }
 
 int lmgpu_gn_iterate(lmgpu_handle* h, lmgpu_lm_state* inout) {
-  if (!h || !h->finalized || !h->have_values) return LMGPU_INVALID;
+  if (!h) return LMGPU_INVALID;
+  if (!h->finalized || !h->have_values) {
+    h->err = "lmgpu_gn_iterate: refused (!h->finalized || !h->have_values)";
+    return LMGPU_INVALID;
+  }
   int rc = need_device(h);
   if (rc) return rc;
   if ((rc = need_comm(h))) return rc;
@@ -2523,7 +2583,11 @@ int lmgpu_gn_iterate(lmgpu_handle* h, lmgpu_lm_state* inout) {
   return rc;
 }
 int lmgpu_gn_optimize(lmgpu_handle* h, const lmgpu_lm_params* p, lmgpu_lm_state* inout) {
-  if (!h || !p || !h->finalized || !h->have_values) return LMGPU_INVALID;
+  if (!h) return LMGPU_INVALID;
+  if (!p || !h->finalized || !h->have_values) {
+    h->err = "lmgpu_gn_optimize: refused (!p || !h->finalized || !h->have_values)";
+    return LMGPU_INVALID;
+  }
   int rc = need_device(h);
   if (rc) return rc;
   if ((rc = need_comm(h))) return rc;
@@ -2544,7 +2608,11 @@ int lmgpu_gn_optimize(lmgpu_handle* h, const lmgpu_lm_params* p, lmgpu_lm_state*
   return rc;
 }
 int lmgpu_dl_iterate(lmgpu_handle* h, lmgpu_lm_state* inout) {
-  if (!h || !h->finalized || !h->have_values) return LMGPU_INVALID;
+  if (!h) return LMGPU_INVALID;
+  if (!h->finalized || !h->have_values) {
+    h->err = "lmgpu_dl_iterate: refused (!h->finalized || !h->have_values)";
+    return LMGPU_INVALID;
+  }
   int rc = need_device(h);
   if (rc) return rc;
   if (inout) h->lm = *inout;
@@ -2553,7 +2621,11 @@ int lmgpu_dl_iterate(lmgpu_handle* h, lmgpu_lm_state* inout) {
   return rc;
 }
 int lmgpu_dl_optimize(lmgpu_handle* h, const lmgpu_lm_params* p, lmgpu_lm_state* inout) {
-  if (!h || !p || !h->finalized || !h->have_values) return LMGPU_INVALID;
+  if (!h) return LMGPU_INVALID;
+  if (!p || !h->finalized || !h->have_values) {
+    h->err = "lmgpu_dl_optimize: refused (!p || !h->finalized || !h->have_values)";
+    return LMGPU_INVALID;
+  }
   int rc = need_device(h);
   if (rc) return rc;
   if (inout) h->lm = *inout;
@@ -2572,7 +2644,11 @@ int lmgpu_dl_optimize(lmgpu_handle* h, const lmgpu_lm_params* p, lmgpu_lm_state*
   return rc;
 }
 int lmgpu_optimize(lmgpu_handle* h, const lmgpu_lm_params* p, lmgpu_lm_state* inout) {
-  if (!h || !p || !h->finalized || !h->have_values) return LMGPU_INVALID;
+  if (!h) return LMGPU_INVALID;
+  if (!p || !h->finalized || !h->have_values) {
+    h->err = "lmgpu_optimize: refused (!p || !h->finalized || !h->have_values)";
+    return LMGPU_INVALID;
+  }
   int rc = need_device(h);
   if (rc) return rc;
   if ((rc = need_comm(h))) return rc;
@@ -2623,7 +2699,11 @@ int lmgpu_get_kernel_times(const lmgpu_handle* h, double* ms, double* work, int6
 }
 
 int lmgpu_get_jacobian(lmgpu_handle* h, int32_t graph_index, double* out, int32_t* rows, int32_t* cols) {
-  if (!h || !h->finalized) return LMGPU_INVALID;
+  if (!h) return LMGPU_INVALID;
+  if (!h->finalized) {
+    h->err = "lmgpu_get_jacobian: refused (!h->finalized)";
+    return LMGPU_INVALID;
+  }
   auto it = std::lower_bound(h->graph_index_sorted.begin(), h->graph_index_sorted.end(), graph_index);
   if (it == h->graph_index_sorted.end() || *it != graph_index) return LMGPU_INVALID;
   const FactorRef& f = h->plan.factors[it - h->graph_index_sorted.begin()];
@@ -2657,7 +2737,11 @@ int lmgpu_front_info(const lmgpu_handle* h, int32_t front, int32_t* info) {
 }
 
 int lmgpu_get_front(lmgpu_handle* h, int32_t front, int32_t* slots, double* RSd) {
-  if (!h || !h->finalized || front < 0 || front >= (int)h->plan.fronts.size()) return LMGPU_INVALID;
+  if (!h) return LMGPU_INVALID;
+  if (!h->finalized || front < 0 || front >= (int)h->plan.fronts.size()) {
+    h->err = "lmgpu_get_front: refused (!h->finalized || front < 0 || front >= (int)h->plan.fronts.size())";
+    return LMGPU_INVALID;
+  }
   const Front& fr = h->plan.fronts[front];
   if (slots) std::memcpy(slots, fr.vars.data(), fr.vars.size() * sizeof(int32_t));
   if (RSd) {
@@ -2682,7 +2766,11 @@ int lmgpu_comm_unique_id(char id128[128]) {
 }
 
 int lmgpu_comm_init(lmgpu_handle* h, const char id128[128]) {
-  if (!h || !id128) return LMGPU_INVALID;
+  if (!h) return LMGPU_INVALID;
+  if (!id128) {
+    h->err = "lmgpu_comm_init: refused (!id128)";
+    return LMGPU_INVALID;
+  }
   int rc = need_device(h);
   if (rc) return rc;
   ncclUniqueId id;
@@ -2790,7 +2878,11 @@ int lmgpu_local_group_destroy(lmgpu_local_group* g) {
   return LMGPU_OK;
 }
 int lmgpu_comm_init_local(lmgpu_handle* h, lmgpu_local_group* g) {
-  if (!h || !g || g->world != h->cfg.world_size) return LMGPU_INVALID;
+  if (!h) return LMGPU_INVALID;
+  if (!g || g->world != h->cfg.world_size) {
+    h->err = "lmgpu_comm_init_local: refused (!g || g->world != h->cfg.world_size)";
+    return LMGPU_INVALID;
+  }
   h->lgroup = g;
   return LMGPU_OK;
 }
