@@ -20,23 +20,6 @@ struct MedLevel {
   const MedFront* mf;  // this level's records
 };
 
-__global__ __launch_bounds__(64) void med_assemble_factors_kernel(MedLevel L, const FrontFac* __restrict__ ffac, const FacDesc* __restrict__ fd,
-                                                                   double* __restrict__ pool) {
-  const MedFront M = L.mf[blockIdx.y];
-  const FrontDesc& F = M.F;
-  if ((int)blockIdx.x >= F.fac_count) return;
-  assemble_factor_body(F, M.f_off, M.ld, ffac, fd, pool, blockIdx.x);
-}
-
-__global__ __launch_bounds__(256) void med_assemble_children_kernel(MedLevel L, const ChildRef* __restrict__ childs, const int32_t* __restrict__ cmap,
-                                                                    double* __restrict__ pool) {
-  __shared__ int32_t smap[160];
-  const MedFront M = L.mf[blockIdx.y];
-  const FrontDesc& F = M.F;
-  if ((int)blockIdx.x >= F.child_count) return;
-  assemble_child_body(F, M.f_off, M.ld, childs, cmap, pool, blockIdx.x, smap, blockIdx.z, gridDim.z);
-}
-
 // deterministic row-owner assembly (kernels_dense.hpp: assemble_row_body) for all medium fronts of a level: grid (max rows / 4, fronts)
 __global__ __launch_bounds__(256) void med_assemble_rows_kernel(MedLevel L, const int32_t* __restrict__ rowptr,
                                                                 const RowSrc* __restrict__ src, const ChildRef* __restrict__ childs,

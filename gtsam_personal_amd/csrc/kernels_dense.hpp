@@ -19,76 +19,13 @@ namespace lmgpu {
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------- assembly
-// one 64-lane block per own factor: F += [A b]^T [A b]
-__device__ __forceinline__ void assemble_factor_body(const FrontDesc& F, int64_t f_off, int ld, const FrontFac* __restrict__ ffac,
-                                                     const FacDesc* __restrict__ fd, double* __restrict__ pool, int bx) {
-  const FrontFac ff = ffac[F.fac_begin + bx];
-  const FacDesc d = fd[ff.fac];
-  const double* J = pool + d.joff;
-  double* A = pool + f_off;
-  const int n = F.n, m = d.rows, nc = d.d0 + d.d1 + d.d2 + 1;
-  const int npair = nc * (nc + 1) / 2;
-  for (int pidx = threadIdx.x; pidx < npair; pidx += 64) {
-    int p = 0, rem = pidx, rowlen = nc;
-    while (rem >= rowlen) {
-      rem -= rowlen;
-      rowlen--;
-      p++;
-    }
-    const int q = p + rem;
-    double v = 0;
-    for (int r = 0; r < m; r++) v += J[p * m + r] * J[q * m + r];
-    const int gp = fac_col(d, ff.c0, ff.c1, ff.c2, p, n), gq = fac_col(d, ff.c0, ff.c1, ff.c2, q, n);
-    const int lo = gp < gq ? gp : gq, hi = gp < gq ? gq : gp;
-    atomicAdd(&A[(size_t)lo * ld + hi], v);
-  }
-}
-
-__global__ __launch_bounds__(64) void hbm_assemble_factors_kernel(FrontDesc F, int64_t f_off, int ld, const FrontFac* __restrict__ ffac,
-                                                                   const FacDesc* __restrict__ fd, double* __restrict__ pool) {
-  assemble_factor_body(F, f_off, ld, ffac, fd, pool, blockIdx.x);
-}
-
-// `nsplit` blocks per child (block `split` takes every nsplit-th group of four rows): extend-add of its update matrix.  The
-// upper levels of a general sparse graph have a handful of children with 300-400-column update matrices each: with one block
-// per child a level's extend-add ran on one or two CUs (160-220 us).
-__device__ __forceinline__ void assemble_child_body(const FrontDesc& F, int64_t f_off, int ld, const ChildRef* __restrict__ childs,
-                                                    const int32_t* __restrict__ cmap, double* __restrict__ pool, int bx, int32_t* smap,
-                                                    int split, int nsplit) {
-  const ChildRef c = childs[F.child_begin + bx];
-  const double* U = pool + c.u_off;
-  const int32_t* map = cmap + c.map_begin;
-  double* A = pool + f_off;
-  const bool small = c.m <= 160;
-  if (small) {
-    for (int i = threadIdx.x; i < c.m; i += 256) smap[i] = map[i];
-    __syncthreads();
-  }
-  for (int i = 4 * split + (threadIdx.x >> 6); i < c.m; i += 4 * nsplit) {  // one wave per row: row i of U is contiguous
-    const int gi = small ? smap[i] : map[i];
-    const double* Ui = U + (size_t)i * c.ld;
-    for (int j = i + (threadIdx.x & 63); j < c.m; j += 64) {
-      const int gj = small ? smap[j] : map[j];
-      const int lo = gi < gj ? gi : gj, hi = gi < gj ? gj : gi;
-      atomicAdd(&A[(size_t)lo * ld + hi], Ui[j]);
-    }
-  }
-}
-
-__global__ __launch_bounds__(256) void hbm_assemble_children_kernel(FrontDesc F, int64_t f_off, int ld, const ChildRef* __restrict__ childs,
-                                                                    const int32_t* __restrict__ cmap, double* __restrict__ pool) {
-  __shared__ int32_t smap[160];
-  assemble_child_body(F, f_off, ld, childs, cmap, pool, blockIdx.x, smap, blockIdx.y, gridDim.y);
-}
-
 // ---- atomic-free, bitwise-reproducible assembly of an HBM front: one WAVE owns one row of the front
 // Row R of the upper triangle receives every contribution whose smaller front index is R: from a child's update matrix U (row i of
 // the child maps to R) the entries U[min(i,j)][max(i,j)] for every child index j with map[j] >= R, and from an own factor whose
 // local column p maps to R the products sum_r J[r][p] J[r][q] for its columns q with column(q) >= R.  The sources of a row are a
 // list built once by the host (RowSrc: children in child order, then factors in graph order); the wave walks it sequentially, its
 // lanes take the j / q of one source (distinct destinations inside one source: a child's column map is injective) -- so every entry
-// of the front is a sum in a FIXED order with no atomics: two solves give bitwise the same front.  (The FP64 atomicAdd forms above
-// remain for the LMGPU_NO_GATHER development switch only.)
+// of the front is a sum in a FIXED order with no atomics: two solves give bitwise the same front.
 struct RowSrc {
   int32_t idx;  // >= 0: child reference (index into childs[]); < 0: own factor, -(index into ffac[]) - 1
   int32_t i;    // child: row / column index inside its update matrix; factor: local column p of [A b]

@@ -35,12 +35,12 @@ struct FrontDesc {
   int32_t fx_begin;  // into fxoff[]: delta offset of each frontal scalar (nf entries)
   int32_t sx_begin;  // into sxoff[]: delta offset of each separator scalar (n-nf-1 entries)
   int64_t rsd_off;   // [R S d], row-major nf x ld_rsd
-  int64_t u_off;     // update matrix, row-major (n-nf) x ld_u, upper (-1: scattered into the parent instead)
+  int64_t u_off;     // update matrix, row-major (n-nf) x ld_u, upper (a gather leaf: its transposed [S d] instead, see par_ld)
   int32_t ld_rsd, ld_u;
   int32_t id;        // front index (failure report)
   int32_t pad;       // bit 0: replicated over ranks (all-reduce after assembly); bit 1: this rank skips own factors + damping
-  int64_t par_off;   // direct scatter: pool offset of the parent HBM front
-  int32_t par_ld;    // its leading dimension (0 = no direct scatter)
+  int64_t par_off;   // (ISAM2's device tree: pool offset of a wide clique's delta offsets)
+  int32_t par_ld;    // -1: gather leaf -- the parent assembles this front's update itself from [R S d] (kernels_schur.hpp); 0 otherwise
   int32_t par_map;   // into cmap[]: this front's update index -> parent column
 };
 
@@ -466,20 +466,6 @@ __global__ __launch_bounds__(MAXT) void lds_front_kernel(const int32_t* __restri
     for (int idx = tid; idx < m * nf; idx += nt) {
       const int c = idx / nf, r = idx - c * nf;
       St[idx] = S[r * n + nf + c];
-    }
-  } else if (F.par_ld > 0) {
-    // scatter-add straight into the parent HBM front (extend-add, a12); the column map is staged in the free Jacobian area
-    int* pm = (int*)Jb;
-    for (int i = tid; i < m; i += nt) pm[i] = cmap[F.par_map + i];
-    __syncthreads();
-    double* PA = pool + F.par_off;
-    for (int i = wave; i < m; i += nw) {
-      const int gi = pm[i];
-      for (int j = i + lane; j < m; j += 64) {
-        const int gj = pm[j];
-        const int lo = gi < gj ? gi : gj, hi = gi < gj ? gj : gi;
-        atomicAdd(&PA[(size_t)lo * F.par_ld + hi], S[(nf + i) * n + nf + j]);
-      }
     }
   } else {
     double* U = pool + F.u_off;

@@ -148,7 +148,6 @@ const int kNumBins = 12;  // 0..5: LDS fronts by size; 6..11: the same sizes for
 const int kLdsLimitN = 139;
 const int kLdsFrontExtra = LDSF_EXTRA_BYTES;
 const int NB = 64;    // potrf / trsm step
-const int kChildSplit = 8;  // workgroups per child in the extend-add of HBM fronts
 const int NBO = 256;  // outer panel: rows eliminated per trailing update of the HBM front
 const int kSyrkLds = 2 * 2 * SYRK_KC * SYRK_LDW * 8;
 
@@ -264,7 +263,6 @@ struct lmgpu_handle {
   std::vector<int32_t> row_begin;
   int32_t *d_row_begin = nullptr, *d_rowptr = nullptr;
   RowSrc* d_rowsrc = nullptr;
-  bool scatter_atomics = false;  // LMGPU_NO_GATHER=1 (development switch): the round-1 FP64-atomic forms
   int n_lds_fronts = 0;                         // all levels' LDS-class fronts are contiguous in d_lists
   double *bt_ebuf = nullptr, *bt_vec = nullptr;  // Dogleg: per-clique / per-row squared residuals; gradient / zero vector
   int bt_ebuf_len = 0;
@@ -627,20 +625,11 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
       const MedLevel ML{(const MedFront*)(h->d_med_fronts + L.med_begin)};
       const unsigned cnt = (unsigned)L.med_count;
       int ktm = h->kt.begin(LMGPU_KT_HBM_ASSEMBLE, s);
-      if (!h->scatter_atomics) {
-        if (L.med_max_fac > 0 || L.med_max_child > 0)
-          hipLaunchKernelGGL(med_assemble_rows_kernel, dim3((L.med_max_n + 3) / 4, cnt), dim3(256), 0, s, ML, (const int32_t*)h->d_rowptr, (const RowSrc*)h->d_rowsrc, (const ChildRef*)h->d_childs, (const int32_t*)h->d_cmap,
-                             (const FrontFac*)h->d_ffac, (const FacDesc*)h->d_fd, h->pool, (const int32_t*)h->d_fxoff, lambda_v, lambda_p,
-                             (const double*)h->dampw, (const double*)h->gex_active);
-      } else {
-        if (L.med_max_fac > 0)
-          hipLaunchKernelGGL(med_assemble_factors_kernel, dim3(L.med_max_fac, cnt), dim3(64), 0, s, ML, (const FrontFac*)h->d_ffac,
-                             (const FacDesc*)h->d_fd, h->pool);
-        if (L.med_max_child > 0)
-          hipLaunchKernelGGL(med_assemble_children_kernel, dim3(L.med_max_child, cnt, kChildSplit), dim3(256), 0, s, ML, (const ChildRef*)h->d_childs,
-                             (const int32_t*)h->d_cmap, h->pool);
-      }
-      if (h->scatter_atomics || !(L.med_max_fac > 0 || L.med_max_child > 0))  // (the row-owner assembly damps its own rows)
+      if (L.med_max_fac > 0 || L.med_max_child > 0)
+        hipLaunchKernelGGL(med_assemble_rows_kernel, dim3((L.med_max_n + 3) / 4, cnt), dim3(256), 0, s, ML, (const int32_t*)h->d_rowptr, (const RowSrc*)h->d_rowsrc, (const ChildRef*)h->d_childs, (const int32_t*)h->d_cmap,
+                           (const FrontFac*)h->d_ffac, (const FacDesc*)h->d_fd, h->pool, (const int32_t*)h->d_fxoff, lambda_v, lambda_p,
+                           (const double*)h->dampw, (const double*)h->gex_active);
+      else  // (the row-owner assembly damps its own rows)
         hipLaunchKernelGGL(med_damp_kernel, dim3((L.med_max_nf + 255) / 256, cnt), dim3(256), 0, s, ML, (const int32_t*)h->d_fxoff, h->pool, lambda_v,
                            lambda_p, (const double*)h->dampw, (const double*)h->gex_active);
       h->kt.end(ktm, s);
@@ -700,22 +689,9 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
                              (const RowSrc*)h->d_rowsrc, (const ChildRef*)h->d_childs, (const int32_t*)h->d_cmap, (const FrontFac*)h->d_ffac,
                              (const FacDesc*)h->d_fd, h->pool, with_factors ? 1 : 0);
       };
-      if (!h->scatter_atomics) {
-        assemble_rows(own_terms && !gwrite);
-      } else {
-        if (F.fac_count > 0 && own_terms && !gwrite)
-          hipLaunchKernelGGL(hbm_assemble_factors_kernel, dim3(F.fac_count), dim3(64), 0, sa, F, aoff, ld, (const FrontFac*)h->d_ffac,
-                             (const FacDesc*)h->d_fd, h->pool);
-        if (F.child_count > 0)
-          hipLaunchKernelGGL(hbm_assemble_children_kernel, dim3(F.child_count, kChildSplit), dim3(256), 0, sa, F, aoff, ld, (const ChildRef*)h->d_childs,
-                             (const int32_t*)h->d_cmap, h->pool);
-      }
+      assemble_rows(own_terms && !gwrite);
       auto own_additive_terms = [&]() {  // the front's own factors and the damping (added: after whatever initialises the entries)
-        if (F.fac_count > 0 && own_terms && !h->scatter_atomics)
-          assemble_rows(true);  // (a gather-write front has no update-matrix children: only its factors are added here)
-        else if (F.fac_count > 0 && own_terms)
-          hipLaunchKernelGGL(hbm_assemble_factors_kernel, dim3(F.fac_count), dim3(64), 0, sa, F, aoff, ld, (const FrontFac*)h->d_ffac,
-                             (const FacDesc*)h->d_fd, h->pool);
+        if (F.fac_count > 0 && own_terms) assemble_rows(true);  // (a gather-write front has no update-matrix children: only its factors are added here)
         if (own_terms)
           hipLaunchKernelGGL(hbm_damp_kernel, dim3((F.nf + 255) / 256), dim3(256), 0, sa, F, aoff, ld, (const int32_t*)h->d_fxoff, h->pool, lambda_v,
                              lambda_p, (const double*)h->dampw, (const double*)h->gex_active);
@@ -1503,7 +1479,6 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
   h->no_wide16 = getenv("LMGPU_NO_WIDE16") != nullptr;
   h->bsd_ticket = getenv("LMGPU_BSD_TICKET") != nullptr;
   h->no_gather_write = getenv("LMGPU_NO_GATHER_WRITE") != nullptr;
-  h->scatter_atomics = getenv("LMGPU_NO_GATHER") != nullptr;
   if (const char* e = getenv("LMGPU_CHAIN_FAR")) h->chain_far_pct = std::max(10, std::min(100, atoi(e)));
   *out = h;
   if (h->device >= 0) {
@@ -1793,16 +1768,15 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
       F.ld_u = fr.n - fr.nf;
       // an LDS front whose parent lives in HBM hands its update over without an update matrix in HBM:
       //   leaves (no children): the parent GATHERS -[S d]^T [S d] and the factor terms itself (kernels_schur.hpp), par_ld = -1
-      //   others: scattered straight into the parent with FP64 atomics (par_ld > 0, filled in when the parent is laid out)
+      //   others: write their update matrix like any child; the parent's rows collect it in a fixed order
       const bool direct = fr.parent >= 0 && P.fronts[fr.parent].cls == 1;
-      if (direct && (h->scatter_atomics || fr.children.empty())) {
-        F.u_off = -1;
+      if (direct && fr.children.empty()) {
         bool binary_only = true;  // the Schur gather reads factors of at most two variables
         for (int32_t f : fr.factors) binary_only = binary_only && P.factors[f].slots[2] < 0;
-        if (fr.children.empty() && !h->scatter_atomics && !binary_only) {  // such a leaf writes its update matrix like any other child
+        if (!binary_only) {  // such a leaf writes its update matrix like any other child
           F.u_off = off;
           off += (int64_t)F.ld_u * F.ld_u;
-        } else if (fr.children.empty() && !h->scatter_atomics) {
+        } else {
           F.par_ld = -1;
           F.u_off = off;  // gather leaves also keep [S d] transposed ((n - nf) x nf: every variable's block contiguous)
           off += (int64_t)F.ld_u * fr.nf;
@@ -1842,7 +1816,6 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
     F.fac_count = (int)ffac.size() - F.fac_begin;
     // children present on this rank: map child's separator scalars (+ rhs) to this front's columns
     F.child_begin = (int)childs.size();
-    bool has_scatter_child = false;
     for (int32_t c : fr.children) {
       if (!h->front_active[c]) continue;
       const Front& ch = P.fronts[c];
@@ -1882,13 +1855,6 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
           }
         continue;
       }
-      if (CF.u_off < 0) {  // direct scatter child: tell it where its parent is
-        has_scatter_child = true;
-        CF.par_off = h->s_off[fi] >= 0 ? h->s_off[fi] : h->f_off[fi];
-        CF.par_ld = h->f_ld[fi];
-        CF.par_map = map_begin;
-        continue;
-      }
       ChildRef cr{};
       cr.u_off = CF.u_off;
       cr.ld = CF.ld_u;
@@ -1897,7 +1863,7 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
       childs.push_back(cr);
     }
     F.child_count = (int)childs.size() - F.child_begin;
-    if (fr.cls == 1 && !h->scatter_atomics && (F.child_count > 0 || F.fac_count > 0)) {  // row -> sources, for the deterministic assembly
+    if (fr.cls == 1 && (F.child_count > 0 || F.fac_count > 0)) {  // row -> sources, for the deterministic assembly
       std::vector<std::vector<RowSrc>> rows(fr.n);
       for (int k = 0; k < F.child_count; k++) {
         const ChildRef& c = childs[F.child_begin + k];
@@ -1962,7 +1928,7 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
         starts(G.cl, G.pblk_long, [&](int i) { return gpblk[G.pblk_begin + G.pblk_short + i].pa; });
         starts(G.cv, G.vblk_count, [&](int i) { return gvblk[G.vblk_begin + i].pv; });
       }
-      if (F.child_count == 0 && !has_scatter_child) {  // no child adds to this front before its own level: the gather can be the first writer
+      if (F.child_count == 0) {  // no child adds to this front before its own level: the gather can be the first writer
         G.write_ok = true;
         G.zero_begin = (int)gzero.size();
         struct VB { int c, d; };

@@ -44,7 +44,8 @@ def test_launch_forms_agree_on_a_large_root(monkeypatch):
     params = LevenbergMarquardtParams()
 
     def run(env):
-        for k in ("LMGPU_NO_FUSE", "LMGPU_PANEL_2L", "LMGPU_NO_CHAIN", "LMGPU_CHAIN_FAR"):
+        for k in ("LMGPU_NO_FUSE", "LMGPU_PANEL_2L", "LMGPU_NO_CHAIN", "LMGPU_CHAIN_FAR", "LMGPU_NO_TAIL", "LMGPU_NO_GATHER_WRITE", "LMGPU_NO_INV16_REUSE",
+                  "LMGPU_NO_LEAFPACK"):
             monkeypatch.delenv(k, raising=False)
         for k in env:
             monkeypatch.setenv(k, "100" if k == "LMGPU_CHAIN_FAR" else "1")  # CHAIN_FAR=100: plain step order in the chained launch
@@ -60,13 +61,19 @@ def test_launch_forms_agree_on_a_large_root(monkeypatch):
 
     base = run([])
     assert base[1][-1][0] < 0.05 * base[0]
-    for env in (["LMGPU_CHAIN_FAR"], ["LMGPU_NO_CHAIN"], ["LMGPU_NO_FUSE"], ["LMGPU_PANEL_2L"], ["LMGPU_NO_FUSE", "LMGPU_PANEL_2L"]):
+    # (+ the remaining A/B switches of this front: the end of the front as separate launches, the gather adding into a cleared front
+    #  instead of writing it, the 16x16 inverses recomputed for the back-substitution, LDS-front descriptors unpacked)
+    for env in (["LMGPU_CHAIN_FAR"], ["LMGPU_NO_CHAIN"], ["LMGPU_NO_FUSE"], ["LMGPU_PANEL_2L"], ["LMGPU_NO_FUSE", "LMGPU_PANEL_2L"], ["LMGPU_NO_TAIL"],
+                ["LMGPU_NO_GATHER_WRITE"], ["LMGPU_NO_INV16_REUSE"], ["LMGPU_NO_LEAFPACK"]):
         other = run(env)
         assert other[0] == base[0]
         for a, b in zip(other[1], base[1]):
-            assert abs(a[0] - b[0]) <= 1e-9 * abs(b[0]) and a[1:] == b[1:], (env, a, b)
+            assert abs(a[0] - b[0]) <= 1e-9 * abs(b[0]) and a[2] == b[2] and abs(a[1] - b[1]) <= 1e-12 * b[1], (env, a, b)
         rel = np.linalg.norm(other[2] - base[2]) / np.linalg.norm(base[2])
-        assert rel < 1e-9, (env, rel)
+        # (the last four change the ORDER of a few sums -- the tail kernel adds the last 40 columns' update in plain fused multiply-adds, the
+        #  gather subtracts from a front that already holds the own factors instead of writing first -- and get rounding-level room)
+        loose = env[0] in ("LMGPU_NO_TAIL", "LMGPU_NO_GATHER_WRITE", "LMGPU_NO_INV16_REUSE", "LMGPU_NO_LEAFPACK")
+        assert rel < (5e-8 if loose else 1e-9), (env, rel)
 
 
 @pytest.mark.parametrize("n_cam", [16, 17, 21, 22, 28, 29, 35, 36, 42, 43, 50, 56, 57, 71, 72, 85, 86, 100])
