@@ -1,5 +1,5 @@
 """Stress of the dataflow launches: N damped solves of C4 from the same linearization; every solve must give the same delta
-(bitwise for the parts without FP64 atomics: the camera root's own prior factor is the only atomic contribution) and status OK.
+(bitwise: the assembly has no atomics, every sum has a fixed order) and status OK.
     python tools/stress_c4.py [solves] [cams] [points]"""
 import os
 import sys

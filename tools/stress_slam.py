@@ -1,6 +1,6 @@
 """Repeated-solve stress of the sparse-graph paths (graph replay, merged back-substitution, batched mid-size fronts):
     python tools/stress_slam.py {sphere|city|victoria} {colamd|metis} [solves]
-Every solve of the same linearization must return the same update (1e-9: child extend-adds of HBM fronts use FP64 atomics)."""
+Every solve of the same linearization must return the same update (bitwise since the row-owner assembly; the bound checked is 1e-9)."""
 import os
 import sys
 import time
