@@ -118,6 +118,9 @@ struct lmgpu_isam2 {
     bool force_relinearize = false, force_full_solve = false;
   };
   std::vector<uint64_t> last_unused;  // ISAM2Result::unusedKeys of the last update
+  // ISAM2Params::relinearizeThreshold as FastMap<char, Vector> (non-empty: in force) and enablePartialRelinearizationCheck
+  std::map<unsigned char, std::vector<double>> relin_thresholds;
+  bool partial_relin_check = false;
 
   // device scratch
   int *d_status = nullptr, *h_status = nullptr;
@@ -1266,17 +1269,59 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
     // (is_update_delta above brought delta to the host with its own wait; variables added by this update are not in it: delta = 0)
     const double* hdelta = S->h_delta;
     const int ntot_checked = relin_ntot;
-    const double threshold = up.force_full_solve ? 0.0 : S->prm.relinearizeThreshold;  // gatherRelinearizeKeys :367-399
+    // gatherRelinearizeKeys :367-399.  above(): double -> infinity norm >= threshold (:287, 361); FastMap<char, Vector> -> any
+    // |delta_i| > threshold_i of the vector registered for the key's Symbol character (:252-268, 365-377)
     std::set<uint64_t> noRelin(up.no_relin.begin(), up.no_relin.end());
-    for (size_t v = 0; v < S->vars.size(); v++) {
-      if (S->vars[v].dead || S->vars[v].xoff >= ntot_checked) continue;
-      double m = 0;
-      for (int d = 0; d < kVarDim[S->vars[v].type]; d++) m = std::max(m, std::fabs(hdelta[S->vars[v].xoff + d]));
-      if (m >= threshold && !noRelin.count(S->vars[v].key)) {
-        relin.insert((int32_t)v);
+    bool bad_threshold = false;
+    auto above = [&](int32_t v) {
+      const lmgpu_isam2::Var& var = S->vars[v];
+      const int dim = kVarDim[var.type];
+      if (var.xoff >= ntot_checked) return false;  // added by this update: delta = 0 (never above a positive threshold; see below for 0)
+      if (up.force_full_solve) return true;
+      if (S->relin_thresholds.empty()) {
+        double m = 0;
+        for (int d = 0; d < dim; d++) m = std::max(m, std::fabs(hdelta[var.xoff + d]));
+        return m >= S->prm.relinearizeThreshold;
+      }
+      auto it = S->relin_thresholds.find((unsigned char)(var.key >> 56));
+      if (it == S->relin_thresholds.end() || (int)it->second.size() != dim) {
+        bad_threshold = true;
+        return false;
+      }
+      for (int d = 0; d < dim; d++)
+        if (std::fabs(hdelta[var.xoff + d]) > it->second[d]) return true;
+      return false;
+    };
+    std::set<int32_t> cand;
+    if (S->partial_relin_check && !up.force_full_solve) {
+      // CheckRelinearizationPartial :246-331: from the roots down, every key of a clique's conditional (frontals and parents) is
+      // checked, the children only when one of them was above its threshold
+      std::vector<int32_t> stack(S->roots.rbegin(), S->roots.rend());
+      while (!stack.empty()) {
+        const lmgpu_isam2::Clq& c = S->clq[stack.back()];
+        stack.pop_back();
+        bool any = false;
+        for (int32_t v : c.vars)
+          if (above(v)) {
+            cand.insert(v);
+            any = true;
+          }
+        if (any)
+          for (auto ch = c.children.rbegin(); ch != c.children.rend(); ++ch) stack.push_back(*ch);
+      }
+    } else {
+      for (size_t v = 0; v < S->vars.size(); v++)
+        if (!S->vars[v].dead && above((int32_t)v)) cand.insert((int32_t)v);
+    }
+    if (bad_threshold) {
+      S->err = "ISAM2: relinearization threshold vector missing for a Symbol character or of the wrong dimension (ISAM2-impl.h:258-262)";
+      return LMGPU_INVALID;
+    }
+    for (int32_t v : cand)
+      if (!noRelin.count(S->vars[v].key)) {
+        relin.insert(v);
         markedKeys.insert(S->vars[v].key);
       }
-    }
     if (!relin.empty()) {
       // ---- 5. findFluid (:431-451): cliques whose separator holds a relinearized variable
       for (const lmgpu_isam2::Clq& c : S->clq) {
@@ -1603,6 +1648,26 @@ int lmgpu_isam2_update_with(lmgpu_isam2* S, const lmgpu_isam2_update_params* p, 
   up.force_relinearize = p->force_relinearize != 0;
   up.force_full_solve = p->forceFullSolve != 0;
   return is_update(S, up, out);
+}
+
+int lmgpu_isam2_set_relinearize_thresholds(lmgpu_isam2* S, int32_t n, const char* chrs, const int32_t* dims, const double* values) {
+  if (!S || n < 0 || (n && (!chrs || !dims || !values))) return LMGPU_INVALID;
+  S->relin_thresholds.clear();
+  for (int i = 0; i < n; i++) {
+    if (dims[i] <= 0) {
+      S->err = "lmgpu_isam2_set_relinearize_thresholds: bad dimension";
+      S->relin_thresholds.clear();
+      return LMGPU_INVALID;
+    }
+    S->relin_thresholds[(unsigned char)chrs[i]] = std::vector<double>(values, values + dims[i]);
+    values += dims[i];
+  }
+  return LMGPU_OK;
+}
+int lmgpu_isam2_set_partial_relinearization_check(lmgpu_isam2* S, int32_t enable) {
+  if (!S) return LMGPU_INVALID;
+  S->partial_relin_check = enable != 0;
+  return LMGPU_OK;
 }
 
 int lmgpu_isam2_get_unused_keys(const lmgpu_isam2* S, uint64_t* keys_out) {

@@ -21,13 +21,17 @@ class ISAM2GaussNewtonParams:
 
 
 class ISAM2Params:
-    """ISAM2Params(optimizationParams, relinearizeThreshold, relinearizeSkip, enableRelinearization) — ISAM2Params.h:211-246"""
+    """ISAM2Params(optimizationParams, relinearizeThreshold, relinearizeSkip, enableRelinearization) — ISAM2Params.h:211-246.
+    relinearizeThreshold: a double, or the FastMap<char, Vector> form as {symbol character: per-dof thresholds} (:139-141);
+    enablePartialRelinearizationCheck (:214-222)"""
 
-    def __init__(self, optimizationParams=None, relinearizeThreshold=0.1, relinearizeSkip=10, enableRelinearization=True):
+    def __init__(self, optimizationParams=None, relinearizeThreshold=0.1, relinearizeSkip=10, enableRelinearization=True,
+                 enablePartialRelinearizationCheck=False):
         self.optimizationParams = optimizationParams or ISAM2GaussNewtonParams()
         self.relinearizeThreshold = relinearizeThreshold
         self.relinearizeSkip = relinearizeSkip
         self.enableRelinearization = enableRelinearization
+        self.enablePartialRelinearizationCheck = enablePartialRelinearizationCheck
 
 
 class ISAM2Result:
@@ -65,12 +69,22 @@ class ISAM2:
 
         self._cb = _lib.CCOLAMD_FN(_cb)  # keep alive
         p = self.params
-        cp = _lib.lmgpu_isam2_params(float(p.relinearizeThreshold), int(p.relinearizeSkip), int(bool(p.enableRelinearization)),
-                                     float(p.optimizationParams.wildfireThreshold))
+        by_char = p.relinearizeThreshold if isinstance(p.relinearizeThreshold, dict) else None
+        cp = _lib.lmgpu_isam2_params(0.1 if by_char is not None else float(p.relinearizeThreshold), int(p.relinearizeSkip),
+                                     int(bool(p.enableRelinearization)), float(p.optimizationParams.wildfireThreshold))
         cfg = _lib.lmgpu_config(device, 0, 1, 0)
         self._h = ct.c_void_p()
         rc = self.lib.lmgpu_isam2_create(ct.byref(cfg), ct.byref(cp), ct.cast(self._cb, ct.c_void_p), None, ct.byref(self._h))
         self._check(rc)
+        if by_char is not None:
+            items = sorted(by_char.items())
+            chrs = bytes(ord(c) if isinstance(c, str) else int(c) for c, _ in items)
+            dims = np.asarray([len(v) for _, v in items], dtype=np.int32)
+            vals = np.asarray([x for _, v in items for x in v], dtype=np.float64)
+            self._check(self.lib.lmgpu_isam2_set_relinearize_thresholds(self._h, len(items), chrs, dims.ctypes.data_as(_lib._I),
+                                                                        vals.ctypes.data_as(_lib._D)))
+        if getattr(p, "enablePartialRelinearizationCheck", False):
+            self._check(self.lib.lmgpu_isam2_set_partial_relinearization_check(self._h, 1))
         self._u0v0 = {}  # constant principal points of Cal3Bundler cameras (do not travel, see lmgpu.h CAM_BUNDLER)
 
     def _check(self, rc):

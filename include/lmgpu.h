@@ -276,7 +276,8 @@ int lmgpu_selftest_chain_schedule(int n, int nf, int i0, int nsteps, int far_pct
  * enableRelinearization (gtsam/nonlinear/ISAM2Params.h:133-246); Cholesky factorisation; cacheLinearizedFactors semantics.
  * ISAM2UpdateParams (gtsam/nonlinear/ISAM2UpdateParams.h:30-90) through lmgpu_isam2_update_with: removeFactorIndices, constrainedKeys,
  * noRelinKeys, extraReelimKeys, force_relinearize, forceFullSolve.
- * Not bound: Dogleg, QR, marginalizeLeaves, newAffectedKeys (smart factors), per-type thresholds (not offered).
+ * relinearizeThreshold as FastMap<char, Vector> and enablePartialRelinearizationCheck: the two setters below.
+ * Not bound: Dogleg, QR, marginalizeLeaves, newAffectedKeys (smart factors), findUnusedFactorSlots (not offered).
  *
  * The fill-reducing ordering is a boundary input like in the batch path, but here it is needed per update: the caller hands over
  * ITS ccolamd (the reference side: the one Ordering::ColamdConstrained calls, gtsam/inference/Ordering.cpp:50-125) as a callback:
@@ -299,6 +300,14 @@ int lmgpu_isam2_create(const lmgpu_config* cfg, const lmgpu_isam2_params* params
 int lmgpu_isam2_destroy(lmgpu_isam2* s);
 const char* lmgpu_isam2_last_error(const lmgpu_isam2* s);
 uint64_t lmgpu_isam2_last_failed_key(const lmgpu_isam2* s); /* LMGPU_INDETERMINATE: first frontal key of the failing clique */
+/* ISAM2Params::relinearizeThreshold as FastMap<char, Vector> (gtsam/nonlinear/ISAM2Params.h:139-141, 169-181): n entries, entry i = the
+ * Symbol character chrs[i] with dims[i] per-dof thresholds, the vectors back to back in `values`.  A variable is then relinearized
+ * when any |delta_i| > threshold_i (strictly; ISAM2-impl.h:266, 375) of its character's vector; an update that meets a variable
+ * without a vector of its dimension returns LMGPU_INVALID (the reference throws, :258-262).  n = 0: the scalar threshold again. */
+int lmgpu_isam2_set_relinearize_thresholds(lmgpu_isam2* s, int32_t n, const char* chrs, const int32_t* dims, const double* values);
+/* ISAM2Params::enablePartialRelinearizationCheck (ISAM2Params.h:214-222): the check walks down from the roots and stops below a
+ * clique none of whose variables is above its threshold (CheckRelinearizationPartial, ISAM2-impl.h:246-331) */
+int lmgpu_isam2_set_partial_relinearization_check(lmgpu_isam2* s, int32_t enable);
 /* newTheta of the next update: packed values like lmgpu_set_values (store doubles per type, in the order given) */
 int lmgpu_isam2_add_variables(lmgpu_isam2* s, int32_t n, const uint64_t* keys, const int32_t* types, const double* packed_values);
 /* newFactors of the next update, appended in call order (= their order in the NonlinearFactorGraph); keys: n x arity Keys */

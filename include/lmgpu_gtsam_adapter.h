@@ -414,17 +414,19 @@ class GpuDoglegOptimizer : public NonlinearOptimizer {
 };
 
 /// ISAM2 on the device (lmgpu_isam2_*): the same update() / calculateEstimate() calls as gtsam::ISAM2 (gtsam/nonlinear/ISAM2.h:146-260)
-/// for the parameter subset the C ABI binds (Gauss-Newton optimisation params, one relinearization threshold, Cholesky).  Not a
+/// for the parameter subset the C ABI binds (Gauss-Newton optimisation params, relinearization threshold as a double or per Symbol
+/// character, partial relinearization check, Cholesky).  Not a
 /// subclass: ISAM2 is a BayesTree<ISAM2Clique> whose cliques live on the host; here the tree lives on the device and only the
 /// estimate comes back.  The constrained COLAMD of recalculate() stays on this side: the callback below is the body of
 /// Ordering::ColamdConstrained (gtsam/inference/Ordering.cpp:86-108) on the arrays the library hands over.
 class GpuISAM2 {
  public:
   explicit GpuISAM2(const ISAM2Params& params = ISAM2Params(), int device = 0) {
-    if (!std::holds_alternative<ISAM2GaussNewtonParams>(params.optimizationParams) || !std::holds_alternative<double>(params.relinearizeThreshold) ||
-        params.factorization != ISAM2Params::CHOLESKY || params.findUnusedFactorSlots || params.enablePartialRelinearizationCheck)
-      throw std::invalid_argument("GpuISAM2: parameter set not bound (Gauss-Newton, scalar threshold, Cholesky only)");
-    lmgpu_isam2_params p{std::get<double>(params.relinearizeThreshold), params.relinearizeSkip, params.enableRelinearization ? 1 : 0,
+    if (!std::holds_alternative<ISAM2GaussNewtonParams>(params.optimizationParams) || params.factorization != ISAM2Params::CHOLESKY ||
+        params.findUnusedFactorSlots || !params.cacheLinearizedFactors)
+      throw std::invalid_argument("GpuISAM2: parameter set not bound (Gauss-Newton optimisation, Cholesky, cached linear factors only)");
+    const bool byChar = std::holds_alternative<FastMap<char, Vector>>(params.relinearizeThreshold);
+    lmgpu_isam2_params p{byChar ? 0.1 : std::get<double>(params.relinearizeThreshold), params.relinearizeSkip, params.enableRelinearization ? 1 : 0,
                          std::get<ISAM2GaussNewtonParams>(params.optimizationParams).wildfireThreshold};
     lmgpu_config cfg{device, 0, 1, 0};
     if (lmgpu_isam2_create(&cfg, &p, &GpuISAM2::Ccolamd, nullptr, &h_) != LMGPU_OK) {
@@ -432,6 +434,18 @@ class GpuISAM2 {
       if (h_) lmgpu_isam2_destroy(h_);
       throw std::runtime_error(why);
     }
+    if (byChar) {  // ISAM2Params::relinearizeThreshold as FastMap<char, Vector> (ISAM2Params.h:139-141)
+      std::string chrs;
+      std::vector<int32_t> dims;
+      std::vector<double> values;
+      for (const auto& cv : std::get<FastMap<char, Vector>>(params.relinearizeThreshold)) {
+        chrs.push_back(cv.first);
+        dims.push_back((int32_t)cv.second.size());
+        values.insert(values.end(), cv.second.data(), cv.second.data() + cv.second.size());
+      }
+      check(lmgpu_isam2_set_relinearize_thresholds(h_, (int32_t)dims.size(), chrs.data(), dims.data(), values.data()));
+    }
+    if (params.enablePartialRelinearizationCheck) check(lmgpu_isam2_set_partial_relinearization_check(h_, 1));
   }
   ~GpuISAM2() { if (h_) lmgpu_isam2_destroy(h_); }
   GpuISAM2(const GpuISAM2&) = delete;

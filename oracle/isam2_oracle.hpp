@@ -14,8 +14,9 @@
 //   ISAM2UpdateParams (gtsam/nonlinear/ISAM2UpdateParams.h:30-90): removeFactorIndices (pushBackFactors ISAM2-impl.h:141-173,
 //                                       computeUnusedKeys :175-190, ISAM2::removeVariables ISAM2.cpp:385-398), constrainedKeys,
 //                                       noRelinKeys, extraReelimKeys, force_relinearize, forceFullSolve
+//   ISAM2Params: relinearizeThreshold as double or FastMap<char, Vector>, enablePartialRelinearizationCheck (ISAM2-impl.h:246-378)
 // Not restated (not reached by the configs): Dogleg optimisation, QR, marginalizeLeaves, newAffectedKeys (smart factors),
-// partial relinearization check, per-type threshold maps, findUnusedFactorSlots.
+// findUnusedFactorSlots.
 #pragma once
 
 namespace orc {
@@ -51,8 +52,9 @@ struct ISAM2 {
   // ISAM2Params (gtsam/nonlinear/ISAM2Params.h:133-246): GaussNewton(wildfireThreshold), relinearizeThreshold (double),
   // relinearizeSkip, enableRelinearization; cacheLinearizedFactors = true
   double wildfireThreshold = 0.001, relinearizeThreshold = 0.1;
+  std::map<unsigned char, std::vector<double>> relinearizeThresholds;  // the FastMap<char, Vector> alternative (non-empty: in force)
   int relinearizeSkip = 10;
-  bool enableRelinearization = true;
+  bool enableRelinearization = true, enablePartialRelinearizationCheck = false;
   ccolamd_fn ccolamd = nullptr;
 
   Values theta;
@@ -268,6 +270,36 @@ static int isam2_count_cliques(const ICliquePtr& c) {
   return n;
 }
 
+// is the variable's delta above its relinearization threshold?  double: infinity norm >= threshold (ISAM2-impl.h:287, 361);
+// FastMap<char, Vector>: any |delta_i| > threshold_i of the vector registered for the key's Symbol character (:252-268, 365-377)
+static bool isam2_above_threshold(const ISAM2& S, Key key, const std::vector<double>& d, double scalarThreshold) {
+  if (S.relinearizeThresholds.empty()) {
+    double m = 0;
+    for (double x : d) m = std::max(m, std::abs(x));
+    return m >= scalarThreshold;
+  }
+  auto it = S.relinearizeThresholds.find((unsigned char)(key >> 56));
+  if (it == S.relinearizeThresholds.end()) throw std::invalid_argument("ISAM2: no relinearization threshold for this Symbol character");
+  if (it->second.size() != d.size())
+    throw std::invalid_argument("Relinearization threshold vector dimensionality does not match actual variable dimensionality");
+  for (size_t i = 0; i < d.size(); i++)
+    if (std::abs(d[i]) > it->second[i]) return true;
+  return false;
+}
+
+// CheckRelinearizationRecursiveDouble / Map, ISAM2-impl.h:246-300: every key of the clique's conditional (frontals AND parents) is
+// checked; the children are only visited when one of them was above the threshold
+static void isam2_check_relin_partial(const ISAM2& S, const ICliquePtr& c, std::set<Key>* relinKeys) {
+  bool relinearize = false;
+  for (Key var : c->keys)
+    if (isam2_above_threshold(S, var, S.delta.at(var), S.relinearizeThreshold)) {
+      relinKeys->insert(var);
+      relinearize = true;
+    }
+  if (relinearize)
+    for (auto& child : c->children) isam2_check_relin_partial(S, child, relinKeys);
+}
+
 // ISAM2::update gtsam/nonlinear/ISAM2.cpp:419-480
 static ISAM2Result isam2_update(ISAM2& S, const ISAM2UpdateParams& up) {
   S.update_count += 1;
@@ -320,11 +352,13 @@ static ISAM2Result isam2_update(ISAM2& S, const ISAM2UpdateParams& up) {
   std::set<Key> relinKeys;
   if (relinNeeded) {
     // 4. gatherRelinearizeKeys :367-399: CheckRelinearizationFull (:353-383, max |delta_j| >= threshold) minus noRelinKeys
-    const double threshold = up.forceFullSolve ? 0.0 : S.relinearizeThreshold;
-    for (auto& kd : S.delta) {
-      double m = 0;
-      for (double x : kd.second) m = std::max(m, std::abs(x));
-      if (m >= threshold) relinKeys.insert(kd.first);
+    if (up.forceFullSolve) {  // CheckRelinearizationFull(delta, 0.0): everything
+      for (auto& kd : S.delta) relinKeys.insert(kd.first);
+    } else if (S.enablePartialRelinearizationCheck) {  // CheckRelinearizationPartial :315-331
+      for (auto& root : S.roots) isam2_check_relin_partial(S, root, &relinKeys);
+    } else {  // CheckRelinearizationFull :344-378
+      for (auto& kd : S.delta)
+        if (isam2_above_threshold(S, kd.first, kd.second, S.relinearizeThreshold)) relinKeys.insert(kd.first);
     }
     for (Key k : up.noRelinKeys) relinKeys.erase(k);
     markedKeys.insert(relinKeys.begin(), relinKeys.end());

@@ -1862,6 +1862,17 @@ void* orc_isam2_create(double relinearizeThreshold, int relinearizeSkip, int ena
   return h;
 }
 void orc_isam2_destroy(void* h) { delete (ISAM2Handle*)h; }
+// ISAM2Params::relinearizeThreshold = FastMap<char, Vector> (n entries: character, dimension, values back to back; n = 0: the double again)
+// and ISAM2Params::enablePartialRelinearizationCheck
+void orc_isam2_set_thresholds(void* h, int n, const unsigned char* chrs, const int* dims, const double* values) {
+  auto& S = ((ISAM2Handle*)h)->S;
+  S.relinearizeThresholds.clear();
+  for (int i = 0; i < n; i++) {
+    S.relinearizeThresholds[chrs[i]] = std::vector<double>(values, values + dims[i]);
+    values += dims[i];
+  }
+}
+void orc_isam2_set_partial_check(void* h, int enable) { ((ISAM2Handle*)h)->S.enablePartialRelinearizationCheck = enable != 0; }
 
 int orc_isam2_add_variable(void* h, uint64_t key, int type, const double* value) {
   auto& S = ((ISAM2Handle*)h)->S;

@@ -71,6 +71,29 @@ def constrained_ordering_steps():
     return out
 
 
+def stale_landmark_steps(n_poses=14):
+    """poses on a line with exact odometry (their deltas stay ~0); a landmark seen twice from pose 2 with conflicting measurements: its
+    delta stays large until the first relinearization check, by which time its clique lies below cliques of unmoved poses -- the case in
+    which CheckRelinearizationPartial (ISAM2-impl.h:302-331) marks less than CheckRelinearizationFull"""
+    odo = noiseModel.Diagonal.Sigmas([0.05, 0.05, 0.02])
+    br = noiseModel.Diagonal.Sigmas([0.05, 0.1])
+    steps = []
+    for i in range(n_poses):
+        g, v = NonlinearFactorGraph(), Values()
+        v.insert_pose2(i, float(i), 0.0, 0.0)
+        if i == 0:
+            g.add_PriorFactorPose2(0, [0.0, 0.0, 0.0], odo)
+        else:
+            g.add_BetweenFactorPose2(i - 1, i, [1.0, 0.0, 0.0], odo)
+        if i == 2:
+            g.add_BearingRangeFactor2D(2, 100, np.pi / 2, 5.0, br)
+            v.insert_point2(100, [2.0, 5.0])
+        if i == 3:
+            g.add_BearingRangeFactor2D(2, 100, np.pi / 2 + 0.2, 6.0, br)
+        steps.append((g, v))
+    return steps
+
+
 def create_points():
     return [np.array(p, dtype=np.float64) for p in ((10, 10, 10), (-10, 10, 10), (-10, -10, 10), (10, -10, 10), (10, 10, -10), (-10, 10, -10),
                                                      (-10, -10, -10), (10, -10, -10))]

@@ -432,6 +432,8 @@ class OracleISAM2:
         L.orc_isam2_add_variable.argtypes = [ct.c_void_p, ct.c_uint64, ct.c_int, _D]
         L.orc_isam2_add_factor.argtypes = [ct.c_void_p, ct.c_int, _U, _D, ct.c_int, _D]
         L.orc_isam2_update.argtypes = [ct.c_void_p, ct.c_int, _I]
+        L.orc_isam2_set_thresholds.argtypes = [ct.c_void_p, ct.c_int, ct.c_char_p, _I, _D]
+        L.orc_isam2_set_partial_check.argtypes = [ct.c_void_p, ct.c_int]
         L.orc_isam2_update_with.argtypes = [ct.c_void_p, ct.c_int, _U, ct.c_int, ct.c_int, _U, _I, ct.c_int, _U, ct.c_int, _U, ct.c_int, ct.c_int, _I]
         L.orc_isam2_unused_keys.argtypes = [ct.c_void_p, _U]
         L.orc_isam2_factor_exists.argtypes = [ct.c_void_p, ct.c_int]
@@ -450,6 +452,17 @@ class OracleISAM2:
             self.L.orc_isam2_destroy(self.h)
         except Exception:
             pass
+
+    def set_relinearize_thresholds(self, thresholds):
+        """ISAM2Params::relinearizeThreshold = FastMap<char, Vector>: {character: per-dof thresholds}; {} or None: the double again"""
+        items = sorted((thresholds or {}).items())
+        chrs = bytes(ord(c) if isinstance(c, str) else int(c) for c, _ in items)
+        dims = np.asarray([len(v) for _, v in items], dtype=np.int32)
+        vals = np.asarray([x for _, v in items for x in v], dtype=np.float64)
+        self.L.orc_isam2_set_thresholds(self.h, len(items), chrs, ip(dims) if len(items) else None, dp(vals) if len(items) else None)
+
+    def set_partial_relinearization_check(self, enable):
+        self.L.orc_isam2_set_partial_check(self.h, int(bool(enable)))
 
     def update(self, newFactors: NonlinearFactorGraph = None, newTheta: Values = None, removeFactorIndices=(), constrainedKeys=None,
                noRelinKeys=None, extraReelimKeys=None, force_relinearize=False, forceFullSolve=False):

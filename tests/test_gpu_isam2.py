@@ -12,7 +12,7 @@ import pytest
 import oracle_harness as oh
 from gtsam_personal_amd import ISAM2, ISAM2GaussNewtonParams, ISAM2Params
 from gtsam_personal_amd.graph import symbol
-from isam2_examples import constrained_ordering_steps, create_points, slamlike_steps, visual_steps
+from isam2_examples import constrained_ordering_steps, create_points, slamlike_steps, stale_landmark_steps, visual_steps
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not oh.have_ref(), reason="oracle/_ref (CCOLAMD of the reference) not built")]
 
@@ -441,3 +441,39 @@ def test_cpp_driver_runs_the_incremental_workloads(tmp_path):
     g2o = os.path.join(os.path.dirname(__file__), "golden", "city10000_head.g2o")
     res = run_case("city400", p, incremental_pose2_steps(g2o, 400, lambda k: orc.calculateEstimate().at(k)), orc)
     assert res["variables"] == 400
+
+
+def test_partial_relinearization_check_and_threshold_vectors():
+    """ISAM2Params::enablePartialRelinearizationCheck and relinearizeThreshold as FastMap<char, Vector> (ISAM2-impl.h:246-378): the
+    visual example update by update against the oracle with each; a vector of the wrong dimension is refused"""
+    for partial, thr in ((True, 0.05), (False, {"x": [0.03, 0.03, 0.03, 0.05, 0.05, 0.05], "l": [0.02, 0.02, 0.02]}),
+                         (True, {"x": [0.03, 0.03, 0.03, 0.05, 0.05, 0.05], "l": [0.02, 0.02, 0.02]})):
+        p = ISAM2Params(relinearizeThreshold=thr, relinearizeSkip=1, enablePartialRelinearizationCheck=partial)
+        isam = ISAM2(p, ccolamd=ccolamd, device=0)
+        orc = oh.OracleISAM2(0.1 if isinstance(thr, dict) else thr, 1, True, p.optimizationParams.wildfireThreshold)
+        if isinstance(thr, dict):
+            orc.set_relinearize_thresholds(thr)
+        orc.set_partial_relinearization_check(partial)
+        counts = []
+        for g, v in visual_steps():
+            rg, ro = isam.update(g, v).as_dict(), orc.update(g, v)
+            assert rg == ro, (partial, thr, rg, ro)
+            counts.append(rg["variablesRelinearized"])
+            compare_state(isam, orc)
+        assert 0 < min(c for c in counts if c) and max(counts) > 0
+        isam.close()
+    # the case that separates the two checks (tests/isam2_examples.py: stale_landmark_steps): the landmark is relinearized by the full
+    # check only
+    for partial in (False, True):
+        p = ISAM2Params(relinearizeThreshold=0.05, relinearizeSkip=10, enablePartialRelinearizationCheck=partial)
+        isam, orc = pair(p)
+        orc.set_partial_relinearization_check(partial)
+        counts = [both(isam, orc, g, v)["variablesRelinearized"] for g, v in stale_landmark_steps()]
+        assert counts[9] == (2 if partial else 3)
+        isam.close()
+    p = ISAM2Params(relinearizeThreshold={"x": [0.03] * 6, "l": [0.02] * 2}, relinearizeSkip=1)
+    isam = ISAM2(p, ccolamd=ccolamd, device=0)
+    with pytest.raises(Exception, match="threshold"):
+        for g, v in visual_steps():
+            isam.update(g, v)
+    isam.close()

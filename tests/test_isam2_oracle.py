@@ -12,7 +12,7 @@ import oracle_harness as oh
 from gtsam_personal_amd import NonlinearFactorGraph, Ordering, Values
 from gtsam_personal_amd.graph import VAR_DIM, symbol
 from gtsam_personal_amd import noiseModel
-from isam2_examples import constrained_ordering_steps, create_points, slamlike_steps, visual_steps
+from isam2_examples import constrained_ordering_steps, create_points, slamlike_steps, stale_landmark_steps, visual_steps
 
 pytestmark = pytest.mark.skipif(not oh.have_ref(), reason="oracle/_ref (CCOLAMD of the reference) not built")
 
@@ -196,3 +196,39 @@ def test_marginal_covariance():
         d = VAR_DIM[lin.type(key)]
         expected = batch.marginal_covariance(key, d)
         assert np.allclose(isam.marginalCovariance(key), expected, rtol=1e-9, atol=1e-12), key
+
+
+def test_partial_relinearization_check_and_threshold_vectors():
+    """TEST(ISAM2, slamlike_solution_partial_relinearization_check) tests/testGaussianISAM2.cpp:603-614 (the batch solution is reached with
+    enablePartialRelinearizationCheck); with relinearization ON the partial check marks a subset of what the full check marks
+    (CheckRelinearizationPartial stops below a clique without a variable above the threshold, ISAM2-impl.h:302-331), and per-character
+    threshold vectors (FastMap<char, Vector>, :252-268 / :365-377) with all entries equal to the scalar mark the same variables as the
+    scalar up to the > / >= difference -- here none sits exactly on the threshold"""
+    steps = slamlike_steps()
+    isam = oh.OracleISAM2(**NO_RELIN)
+    isam.set_partial_relinearization_check(True)
+    for g, v in steps:
+        isam.update(g, v)
+    isam_check(isam, *merge(steps))
+    # a landmark whose large delta lies below cliques of unmoved poses when the first check comes (update 10): the full check
+    # relinearizes it, the partial check stops at the root and leaves it alone
+    full = oh.OracleISAM2(relinearizeThreshold=0.05, relinearizeSkip=10)
+    part = oh.OracleISAM2(relinearizeThreshold=0.05, relinearizeSkip=10)
+    part.set_partial_relinearization_check(True)
+    cf = [full.update(g, v)["variablesRelinearized"] for g, v in stale_landmark_steps()]
+    cp = [part.update(g, v)["variablesRelinearized"] for g, v in stale_landmark_steps()]
+    assert cf[9] == 3 and cp[9] == 2 and cf[:9] == cp[:9] == [0] * 9
+    assert np.abs(full.getDelta()[100]).max() < 0.1 < 0.4 < np.abs(part.getDelta()[100]).max()
+    assert not np.array_equal(full.getLinearizationPoint().at(100), part.getLinearizationPoint().at(100))
+    scalar = oh.OracleISAM2(relinearizeThreshold=0.02, relinearizeSkip=1)
+    vec = oh.OracleISAM2(relinearizeThreshold=0.5, relinearizeSkip=1)
+    vec.set_relinearize_thresholds({"x": [0.02] * 6, "l": [0.02] * 3})
+    for g, v in visual_steps():
+        assert scalar.update(g, v) == vec.update(g, v)
+    # a vector of the wrong dimension is refused like the reference's invalid_argument
+    bad = oh.OracleISAM2(relinearizeThreshold=0.02, relinearizeSkip=1)
+    bad.set_relinearize_thresholds({"x": [0.02] * 6, "l": [0.02] * 2})
+    vs = visual_steps()
+    with pytest.raises(AssertionError):
+        for g, v in vs:
+            bad.update(g, v)
