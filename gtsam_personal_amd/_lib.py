@@ -119,6 +119,7 @@ SYMBOLS = {
     "lmgpu_isam2_num_variables": (ct.c_int, [_H]),
     "lmgpu_isam2_num_factors": (ct.c_int, [_H]),
     "lmgpu_isam2_get_values": (ct.c_int, [_H, ct.c_int32, ct.POINTER(ct.c_uint64), _I, _D]),
+    "lmgpu_isam2_get_value": (ct.c_int, [_H, ct.c_int32, ct.c_uint64, _I, _D]),
     "lmgpu_isam2_get_delta": (ct.c_int, [_H, _D]),
     "lmgpu_isam2_marginal_covariance": (ct.c_int, [_H, ct.c_uint64, _D]),
     "lmgpu_isam2_num_cliques": (ct.c_int, [_H]),

@@ -741,9 +741,13 @@ int is_patch_tree(lmgpu_isam2* S) {
 }
 
 // ISAM2::updateDelta (gtsam/nonlinear/ISAM2.cpp:701-719) -> DeltaImpl::UpdateGaussNewtonDelta (ISAM2-impl.cpp:47-77)
-int is_update_delta(lmgpu_isam2* S, bool force_full) {
+// In two halves so that a caller can queue its own reads of delta behind the walk and wait ONCE: is_update_delta_enqueue launches,
+// is_update_delta_finish waits and looks at the status word.
+// host_delta: also bring delta to the pinned host copy (CheckRelinearizationFull reads it; the estimate readers do not need it)
+int is_update_delta_enqueue(lmgpu_isam2* S, bool force_full, bool host_delta) {
   int rc = is_patch_tree(S);
   if (rc) return rc;
+  *S->h_status = 0x7f7f7f7f;
   if (S->ntot == 0) return LMGPU_OK;
   const double thr = force_full ? 0.0 : S->prm.wildfireThreshold;
   ISCHECK(hipMemsetAsync(S->d_changed, 0, (size_t)S->ntot, S->stream));
@@ -760,13 +764,18 @@ int is_update_delta(lmgpu_isam2* S, bool force_full) {
   }
   ISCHECK(hipMemsetAsync(S->d_replaced, 0, (size_t)S->ntot, S->stream));
   ISCHECK(hipMemcpyAsync(S->h_status, S->d_status, sizeof(int), hipMemcpyDeviceToHost, S->stream));
-  if ((size_t)S->ntot > S->h_delta_cap) {
-    if (S->h_delta) (void)hipHostFree(S->h_delta);
-    S->h_delta = nullptr;
-    S->h_delta_cap = is_next_cap(S->h_delta_cap, (size_t)S->ntot);
-    ISCHECK(hipHostMalloc((void**)&S->h_delta, S->h_delta_cap * sizeof(double), hipHostMallocDefault));
+  if (host_delta) {
+    if ((size_t)S->ntot > S->h_delta_cap) {
+      if (S->h_delta) (void)hipHostFree(S->h_delta);
+      S->h_delta = nullptr;
+      S->h_delta_cap = is_next_cap(S->h_delta_cap, (size_t)S->ntot);
+      ISCHECK(hipHostMalloc((void**)&S->h_delta, S->h_delta_cap * sizeof(double), hipHostMallocDefault));
+    }
+    ISCHECK(hipMemcpyAsync(S->h_delta, S->delta, (size_t)S->ntot * sizeof(double), hipMemcpyDeviceToHost, S->stream));  // CheckRelinearizationFull reads it
   }
-  ISCHECK(hipMemcpyAsync(S->h_delta, S->delta, (size_t)S->ntot * sizeof(double), hipMemcpyDeviceToHost, S->stream));  // CheckRelinearizationFull reads it
+  return LMGPU_OK;
+}
+int is_update_delta_finish(lmgpu_isam2* S) {
   ISCHECK(hipStreamSynchronize(S->stream));
   std::fill(S->replaced.begin(), S->replaced.end(), 0);
   S->any_replaced = false;
@@ -780,6 +789,10 @@ int is_update_delta(lmgpu_isam2* S, bool force_full) {
     return LMGPU_INDETERMINATE;
   }
   return LMGPU_OK;
+}
+int is_update_delta(lmgpu_isam2* S, bool force_full, bool host_delta = false) {
+  const int rc = is_update_delta_enqueue(S, force_full, host_delta);
+  return rc ? rc : is_update_delta_finish(S);
 }
 
 // Ordering::ColamdConstrained (gtsam/inference/Ordering.cpp:50-125, 193-210) on a VariableIndex given as (variables ascending by
@@ -1163,7 +1176,7 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
     ISCHECK(hipMemsetAsync(S->delta + ntot0, 0, (size_t)(S->ntot - ntot0) * sizeof(double), S->stream));  // delta_.insert(zeroVectors)
   }
   const bool relinNeeded = force_relinearize || (S->prm.enableRelinearization && S->prm.relinearizeSkip > 0 && S->update_count % S->prm.relinearizeSkip == 0);
-  if (relinNeeded && (rc = is_update_delta(S, up.force_full_solve))) return rc;
+  if (relinNeeded && (rc = is_update_delta(S, up.force_full_solve, true))) return rc;
   const int relin_ntot = S->ntot;  // scalars of delta the pinned copy holds
   lap(0);  // new variables + updateDelta (wildfire, one wait)
   // ---- 1. pushBackFactors (ISAM2-impl.h:145-175): indices continue the list
@@ -1759,6 +1772,43 @@ int lmgpu_isam2_marginal_covariance(lmgpu_isam2* S, uint64_t key, double* cov) {
     S->err = "indeterminate linear system in marginalCovariance";
     return LMGPU_INDETERMINATE;
   }
+  return LMGPU_OK;
+}
+
+// ISAM2::calculateEstimate(Key) (gtsam/nonlinear/ISAM2.cpp:757-760: theta_.at(key) retracted by getDelta()[key]) / the linearization
+// point of one variable: the back-substitution is brought up to date like for the whole estimate, but only this variable is retracted
+// and downloaded (the whole estimate of a 10 000-pose graph is an 8.6 ms download; timing/timeIncremental.cpp asks for ONE pose per step)
+int lmgpu_isam2_get_value(lmgpu_isam2* S, int32_t which, uint64_t key, int32_t* type_out, double* packed_out) {
+  if (!S || (which != 0 && which != 2) || !packed_out) return LMGPU_INVALID;
+  if (S->device < 0) return LMGPU_HIP_ERROR;
+  auto it = S->vid_of.find(key);
+  if (it == S->vid_of.end()) {
+    S->err = "ISAM2: the key is not in the system (ValuesKeyDoesNotExist)";
+    return LMGPU_INVALID;
+  }
+  ISCHECK(hipSetDevice(S->device));
+  int rc;
+  const bool walk = which == 0 && S->any_replaced;
+  if (walk && (rc = is_update_delta_enqueue(S, false, false))) return rc;
+  const lmgpu_isam2::Var& v = S->vars[it->second];
+  const int t = v.type;
+  const double* src = S->theta[t];
+  if (which == 0) {
+    const std::vector<int32_t> one{v.tidx};
+    if ((rc = is_with_list(S, one, [&](const int32_t* d, int cnt) {
+           hipLaunchKernelGGL(retract_kernel, dim3(1), dim3(256), 0, S->stream, t, cnt, (const double*)S->theta[t], S->est[t],
+                              (const int32_t*)S->d_type_xoff[t], (const double*)S->delta, d);
+         })))
+      return rc;
+    src = S->est[t];
+  }
+  ISCHECK(hipMemcpyAsync(packed_out, src + (size_t)v.tidx * kVarStore[t], kVarStore[t] * sizeof(double), hipMemcpyDeviceToHost, S->stream));
+  if (walk) {  // the one wait of this call, and the status of the back-substitution
+    if ((rc = is_update_delta_finish(S))) return rc;
+  } else {
+    ISCHECK(hipStreamSynchronize(S->stream));
+  }
+  if (type_out) *type_out = t;
   return LMGPU_OK;
 }
 

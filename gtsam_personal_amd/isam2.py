@@ -197,8 +197,20 @@ class ISAM2:
             o += VAR_STORE_DEV[t]
         return out
 
-    def calculateEstimate(self) -> Values:
-        return self._values(0)
+    def calculateEstimate(self, key=None):
+        """ISAM2::calculateEstimate() -> Values, or calculateEstimate(key) -> the packed value of one variable (ISAM2.cpp:748-760)"""
+        if key is None:
+            return self._values(0)
+        return self._value(0, key)
+
+    def _value(self, which, key):
+        t = ct.c_int32()
+        buf = np.zeros(17)
+        self._check(self.lib.lmgpu_isam2_get_value(self._h, which, int(key), ct.byref(t), buf.ctypes.data_as(_lib._D)))
+        out = buf[:VAR_STORE[t.value]].copy()
+        if t.value == 3:  # the constant principal point of a Cal3Bundler camera does not travel
+            out[15:17] = self._u0v0[int(key)]
+        return out
 
     def calculateBestEstimate(self) -> Values:
         return self._values(1)

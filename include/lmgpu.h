@@ -345,6 +345,9 @@ int lmgpu_isam2_num_factors(const lmgpu_isam2* s);   /* slots of the factor list
 /* which: 0 = calculateEstimate (ISAM2.cpp:748-754), 1 = calculateBestEstimate (:763-766), 2 = getLinearizationPoint.
  * Variables ascending by Key (the reference's Values order); any of the outputs may be NULL. */
 int lmgpu_isam2_get_values(lmgpu_isam2* s, int32_t which, uint64_t* keys_out, int32_t* types_out, double* packed_out);
+/* calculateEstimate(Key) (ISAM2.cpp:757-760) for which = 0, the linearization point of one variable for which = 2: only this variable
+ * is retracted and downloaded (store doubles of its type, lmgpu.h packings); LMGPU_INVALID for an unknown key */
+int lmgpu_isam2_get_value(lmgpu_isam2* s, int32_t which, uint64_t key, int32_t* type_out, double* packed_out);
 int lmgpu_isam2_get_delta(lmgpu_isam2* s, double* packed); /* getDelta (:776-779), ascending by Key */
 /* ISAM2::marginalCovariance(key) (gtsam/nonlinear/ISAM2.h:253-257: the inverse of BayesTree::marginalFactor(key)'s information; the
  * linearization point's covariance block of the variable, dim x dim): two triangular solves per column, on the device, along the path

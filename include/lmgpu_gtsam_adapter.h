@@ -529,6 +529,16 @@ class GpuISAM2 {
   }
 
   Values calculateEstimate() const { return download(0); }
+  /// ISAM2::calculateEstimate<VALUE>(Key) (ISAM2.h:231-236, ISAM2.cpp:757-760): only this variable is retracted and downloaded
+  template <class VALUE>
+  VALUE calculateEstimate(Key key) const {
+    int32_t t = -1;
+    double q[15];
+    check(lmgpu_isam2_get_value(h_, 0, key, &t, q));
+    Values one;
+    unpackOne(key, t, q, &one);
+    return one.at<VALUE>(key);
+  }
   Values calculateBestEstimate() const { return download(1); }
   Values getLinearizationPoint() const { return download(2); }
 
@@ -565,6 +575,19 @@ class GpuISAM2 {
       }
     }
   }
+  void unpackOne(Key k, int32_t t, const double* q, Values* out) const {
+    switch (t) {
+      case LMGPU_POSE2: out->insert(k, Pose2(q[0], q[1], q[2])); break;
+      case LMGPU_POSE3: out->insert(k, lmgpu_detail::unpackPose3(q)); break;
+      case LMGPU_POINT3: out->insert(k, Point3(q[0], q[1], q[2])); break;
+      case LMGPU_POINT2: out->insert(k, Point2(q[0], q[1])); break;
+      case LMGPU_CAL3_S2: out->insert(k, Cal3_S2(q[0], q[1], q[2], q[3], q[4])); break;
+      default: {
+        const Cal3Bundler& K0 = all_.at<lmgpu_detail::Camera>(k).calibration();
+        out->insert(k, lmgpu_detail::Camera(lmgpu_detail::unpackPose3(q), Cal3Bundler(q[12], q[13], q[14], K0.px(), K0.py())));
+      }
+    }
+  }
   Values download(int which) const {
     const int n = lmgpu_isam2_num_variables(h_);
     std::vector<uint64_t> keys((size_t)n);
@@ -578,17 +601,7 @@ class GpuISAM2 {
     const double* q = packed.data();
     for (int i = 0; i < n; i++) {
       const Key k = keys[(size_t)i];
-      switch (types[(size_t)i]) {
-        case LMGPU_POSE2: out.insert(k, Pose2(q[0], q[1], q[2])); break;
-        case LMGPU_POSE3: out.insert(k, lmgpu_detail::unpackPose3(q)); break;
-        case LMGPU_POINT3: out.insert(k, Point3(q[0], q[1], q[2])); break;
-        case LMGPU_POINT2: out.insert(k, Point2(q[0], q[1])); break;
-        case LMGPU_CAL3_S2: out.insert(k, Cal3_S2(q[0], q[1], q[2], q[3], q[4])); break;
-        default: {
-          const Cal3Bundler& K0 = all_.at<lmgpu_detail::Camera>(k).calibration();
-          out.insert(k, lmgpu_detail::Camera(lmgpu_detail::unpackPose3(q), Cal3Bundler(q[12], q[13], q[14], K0.px(), K0.py())));
-        }
-      }
+      unpackOne(k, types[(size_t)i], q, &out);
       q += lmgpu_adapter::varStore(types[(size_t)i]);
     }
     return out;

@@ -8,6 +8,9 @@
 // The sequence of updates comes in a neutral text file written by the test / tool from the Python mirror's graphs:
 //   ISAM2 relinearizeThreshold relinearizeSkip enableRelinearization wildfireThreshold
 //   UPDATE nv nf nremove          then nv lines  V key type store d0 d1 ...
+//                                            or  W key prevkey dx dy dtheta   (a Pose2 initialised at update time as the device's
+//                                                own estimate of prevkey composed with the odometry: lmgpu_isam2_get_value =
+//                                                calculateEstimate(prevkey), the loop of timing/timeIncremental.cpp:84-170)
 //                                 then nf lines  F type k0 k1 k2 | nmeas meas... | noise_kind nnoise noise...
 //                                 then one line  R idx0 idx1 ...            (removeFactorIndices, nremove entries)
 //   ... END
@@ -17,6 +20,7 @@
 
 #include <chrono>
 #include <cinttypes>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -59,6 +63,12 @@ struct Update {
   std::vector<uint64_t> vkeys;
   std::vector<int32_t> vtypes;
   std::vector<double> vpacked;
+  struct Rel {  // variable i of this update is prev (+) odometry, resolved when the update is issued
+    size_t at;  // offset of its three doubles in vpacked
+    uint64_t prev;
+    double d[3];
+  };
+  std::vector<Rel> rel;
   struct F {
     int32_t type, noise_kind;
     uint64_t k[3];
@@ -102,7 +112,17 @@ int main(int argc, char** argv) {
       uint64_t k;
       int32_t t;
       int store;
-      if (!(is >> w >> k >> t >> store) || w != "V") return fail("parse", "V");
+      if (!(is >> w >> k)) return fail("parse", "V");
+      if (w == "W") {
+        Update::Rel r{u.vpacked.size(), 0, {0, 0, 0}};
+        if (!(is >> r.prev >> r.d[0] >> r.d[1] >> r.d[2])) return fail("parse", "W");
+        u.vkeys.push_back(k);
+        u.vtypes.push_back(LMGPU_POSE2);
+        u.vpacked.insert(u.vpacked.end(), 3, 0.0);
+        u.rel.push_back(r);
+        continue;
+      }
+      if (w != "V" || !(is >> t >> store)) return fail("parse", "V");
       u.vkeys.push_back(k);
       u.vtypes.push_back(t);
       for (int j = 0; j < store; j++) {
@@ -136,9 +156,36 @@ int main(int argc, char** argv) {
   double lib = 0, worst = 0;
   lmgpu_isam2_result r{};
   size_t done = 0;
-  for (const Update& u : updates) {
+  double est_seconds = 0;
+  size_t est_calls = 0;
+  for (Update& u : updates) {
     const double t0 = now();
-    int rc = lmgpu_isam2_add_variables(h, (int32_t)u.vkeys.size(), u.vkeys.data(), u.vtypes.data(), u.vpacked.data());
+    int rc = LMGPU_OK;
+    for (const Update::Rel& r : u.rel) {  // Pose2::compose(prev estimate, odometry)
+      double a[15];
+      int32_t t = -1;
+      size_t own = 0, at = 0;  // the previous pose may be a variable of this very update (the first one adds poses 0 and 1)
+      for (; own < u.vkeys.size() && u.vkeys[own] != r.prev; own++) at += (u.vtypes[own] == LMGPU_POSE2) ? 3 : 0;
+      if (own < u.vkeys.size() && u.vtypes[own] == LMGPU_POSE2 && at < r.at) {
+        for (int j = 0; j < 3; j++) a[j] = u.vpacked[at + j];
+        t = LMGPU_POSE2;
+      } else {
+        const double te = now();
+        rc = lmgpu_isam2_get_value(h, 0, r.prev, &t, a);
+        est_seconds += now() - te;
+        est_calls++;
+      }
+      if (rc != LMGPU_OK || t != LMGPU_POSE2) {
+        std::printf("{\"error\": \"calculateEstimate(%" PRIu64 "): rc %d: %s\"}\n", r.prev, rc, lmgpu_isam2_last_error(h));
+        lmgpu_isam2_destroy(h);
+        return 1;
+      }
+      const double c = std::cos(a[2]), sn = std::sin(a[2]);
+      u.vpacked[r.at] = a[0] + c * r.d[0] - sn * r.d[1];
+      u.vpacked[r.at + 1] = a[1] + sn * r.d[0] + c * r.d[1];
+      u.vpacked[r.at + 2] = a[2] + r.d[2];
+    }
+    if (rc == LMGPU_OK) rc = lmgpu_isam2_add_variables(h, (int32_t)u.vkeys.size(), u.vkeys.data(), u.vtypes.data(), u.vpacked.data());
     for (const Update::F& f : u.facs)
       if (rc == LMGPU_OK)
         rc = lmgpu_isam2_add_factors(h, f.type, 1, f.k, f.meas.data(), f.noise_kind, f.noise.empty() ? nullptr : f.noise.data());
@@ -168,8 +215,9 @@ int main(int argc, char** argv) {
   if (lmgpu_isam2_get_values(h, 0, nullptr, nullptr, packed.data()) != LMGPU_OK) return fail("calculateEstimate", lmgpu_isam2_last_error(h));
   const double t_est = now() - t1;
   std::printf("{\"updates\": %zu, \"library_seconds\": %.6f, \"ms_per_update\": %.6f, \"worst_update_ms\": %.4f, \"ccolamd_callback_seconds\": %.6f, "
-              "\"calculate_estimate_ms\": %.4f, \"variables\": %d, \"cliques\": %d, \"estimate\": [",
-              done, lib, done ? 1e3 * lib / done : 0.0, 1e3 * worst, g_colamd_seconds, 1e3 * t_est, n, r.cliques);
+              "\"calculate_estimate_ms\": %.4f, \"single_estimates\": %zu, \"single_estimate_ms\": %.5f, \"variables\": %d, \"cliques\": %d, \"estimate\": [",
+              done, lib, done ? 1e3 * lib / done : 0.0, 1e3 * worst, g_colamd_seconds, 1e3 * t_est, est_calls,
+              est_calls ? 1e3 * est_seconds / est_calls : 0.0, n, r.cliques);
   const double* q = packed.data();
   for (int i = 0; i < n; i++) {
     std::printf("%s[%" PRIu64, i ? ", " : "", keys[(size_t)i]);

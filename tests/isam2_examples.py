@@ -178,10 +178,12 @@ def incremental_pose2_steps(g2o_path, n_poses, init_from):
         step += 1
 
 
-def write_isam2_sequence(path, params, steps):
+def write_isam2_sequence(path, params, steps, relative_pose2=False):
     """the input of tests/cpp/isam2_harness: what the reference-side wrapper extracts from each update's NonlinearFactorGraph / Values
-    (the packings of include/lmgpu.h), as text.  steps: [(graph, values[, removeFactorIndices])]"""
-    from gtsam_personal_amd.graph import FACTOR_ARITY, F_PRIOR_CAM, F_SFM, N_UNIT, VAR_STORE_DEV
+    (the packings of include/lmgpu.h), as text.  steps: [(graph, values[, removeFactorIndices])].  relative_pose2: a new Pose2 k that
+    comes with a BetweenFactor<Pose2>(k - 1, k) is written as "previous estimate composed with that odometry" (W line): the harness asks
+    the device for calculateEstimate(k - 1) at update time, like timing/timeIncremental.cpp"""
+    from gtsam_personal_amd.graph import FACTOR_ARITY, F_BETWEEN_POSE2, F_PRIOR_CAM, F_SFM, N_UNIT, POSE2, VAR_STORE_DEV
     u0v0 = {}
     with open(path, "w") as f:
         p = params
@@ -190,8 +192,18 @@ def write_isam2_sequence(path, params, steps):
             g, v = st[0], st[1]
             rm = list(st[2]) if len(st) > 2 and st[2] is not None else []
             f.write(f"UPDATE {v.size()} {g.size()} {len(rm)}\n")
+            odo = {}
+            if relative_pose2:
+                for ftype, _, _, keys, meas, _, _ in g.buckets():
+                    if ftype == F_BETWEEN_POSE2:
+                        for i in range(len(keys)):
+                            odo[(int(keys[i][0]), int(keys[i][1]))] = meas[i]
             for k in v.keys():
                 t = v.type(k)
+                if t == POSE2 and (int(k) - 1, int(k)) in odo:
+                    m = odo[(int(k) - 1, int(k))]
+                    f.write(f"W {int(k)} {int(k) - 1} {float(m[0])!r} {float(m[1])!r} {float(m[2])!r}\n")
+                    continue
                 if t == 3:
                     u0v0[k] = v.at(k)[15:17].copy()
                 f.write(f"V {int(k)} {t} {VAR_STORE_DEV[t]} " + " ".join(repr(float(x)) for x in v.at(k)[:VAR_STORE_DEV[t]]) + "\n")

@@ -477,3 +477,32 @@ def test_partial_relinearization_check_and_threshold_vectors():
         for g, v in visual_steps():
             isam.update(g, v)
     isam.close()
+
+
+def test_single_variable_estimate_and_device_driven_incremental_run():
+    """calculateEstimate(key) (ISAM2.cpp:757-760) against the whole estimate, after updates with and without pending back-substitution;
+    then timing/timeIncremental.cpp's loop with the DEVICE's own estimate of the previous pose initialising the next one, read one
+    variable per step, replayed through the oracle afterwards"""
+    import os
+    from isam2_examples import incremental_pose2_steps
+    isam, orc = slamlike_pair(ISAM2Params(relinearizeThreshold=0.01, relinearizeSkip=1))
+    whole = isam.calculateEstimate()
+    for k in whole.keys():
+        assert np.array_equal(isam.calculateEstimate(k), whole.at(k)), k
+    both(isam, orc, removeFactorIndices=[12])
+    assert np.allclose(isam.calculateEstimate(11), orc.calculateEstimate().at(11), rtol=1e-6, atol=1e-8)  # (brings the delta up to date itself)
+    with pytest.raises(Exception):
+        isam.calculateEstimate(4242)
+    isam.close()
+    p = ISAM2Params()
+    isam = ISAM2(p, ccolamd=ccolamd, device=0)
+    g2o = os.path.join(os.path.dirname(__file__), "golden", "city10000_head.g2o")
+    steps = []
+    for g, v in incremental_pose2_steps(g2o, 400, lambda k: isam.calculateEstimate(k)):
+        isam.update(g, v)
+        steps.append((g, v))
+    orc = oh.OracleISAM2(p.relinearizeThreshold, p.relinearizeSkip, p.enableRelinearization, p.optimizationParams.wildfireThreshold)
+    for g, v in steps:
+        ro = orc.update(g, v)
+    compare_state(isam, orc)
+    isam.close()

@@ -100,6 +100,16 @@ for name, g2o, n in cases:
         out = subprocess.run([os.path.join(ROOT, "tests", "cpp", "isam2_harness"), path, "0", os.path.join(ROOT, "oracle", "_ref", "libccolamd_ref.so")],
                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     res = json.loads(out.stdout)
+    # the same loop with the DEVICE's estimate of the previous pose initialising the next one (one calculateEstimate(key) per step):
+    # timing/timeIncremental.cpp as it is written; the trajectory then differs from the recorded one in the last digits only
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "seq_rel.txt")
+        write_isam2_sequence(path, p, steps, relative_pose2=True)
+        out2 = subprocess.run([os.path.join(ROOT, "tests", "cpp", "isam2_harness"), path, "0", os.path.join(ROOT, "oracle", "_ref", "libccolamd_ref.so")],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    res2 = json.loads(out2.stdout)
+    print(f"{name}, C++ driver, every new pose from calculateEstimate(previous pose) on the device: {res2['ms_per_update']:.4f} ms per update "
+          f"including {res2['single_estimates']} single-variable estimates at {res2['single_estimate_ms']:.4f} ms each", flush=True)
     est = orc.calculateEstimate()
     worst = 0.0
     for r in res["estimate"]:
