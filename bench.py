@@ -78,7 +78,7 @@ def cpu_baseline(n_cam, n_pt, obs, seed, full_tag=None):
 def metis_fixture_ordering(args, schur):
     """The reference computes its ordering once at optimizer construction (LevenbergMarquardtParams.h:112-117); it is a boundary
     INPUT of the hot path.  The METIS permutation of the bench workloads is carried by a committed fixture
-    (tools/make_c4_fixture.py: Ordering::Metis through the reference's own METIS sources, oracle/_ref)."""
+    (tests/tools/make_c4_fixture.py: Ordering::Metis through the reference's own METIS sources, oracle/_ref)."""
     import numpy as np
     tags = {(1000, 100000, 10, 42): "c4_seed42", (100, 10000, 10, 42): "bal100_seed42"}
     tag = tags.get((args.cams, args.points, args.obs, args.seed))

@@ -32,5 +32,5 @@ with open(os.path.join(REF, "city10000.g2o")) as f, open(os.path.join(HERE, "cit
             o.write(ln)
 
 # Derived fixtures (numbers the oracle / the reference's vendored CCOLAMD + METIS produced; each has its own generator):
-#   c4_seed42_{schur,metis}.npz, bal100_seed42_{schur,metis}.npz, *_timing.json   tools/make_c4_fixture.py
-#   slam_orderings.npz                                                             tools/make_ordering_fixtures.py
+#   c4_seed42_{schur,metis}.npz, bal100_seed42_{schur,metis}.npz, *_timing.json   tests/tools/make_c4_fixture.py
+#   slam_orderings.npz                                                             tests/tools/make_ordering_fixtures.py

@@ -1,4 +1,4 @@
-"""CPU side of the headline-workload fixtures (tools/make_c4_fixture.py): the small fixture equals what the oracle computes
+"""CPU side of the headline-workload fixtures (tests/tools/make_c4_fixture.py): the small fixture equals what the oracle computes
 live (so the committed numbers are not stale with respect to the oracle or the generator), and the product's symbolic analysis
 reproduces the fixture's structure at FULL size under the reference's METIS ordering (no GPU needed: structure-only handle)."""
 import os

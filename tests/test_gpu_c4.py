@@ -1,7 +1,7 @@
 """The headline workload at ITS size and under BOTH orderings BASELINE.json configs[3] can mean (METIS as named there, Schur as
 timing/timeSFMBAL.h:64-96 uses): synthetic BAL 1 000 cameras / 100 000 points / 1 000 002 factors, seed 42, one
 LevenbergMarquardtOptimizer::iterate() on the GPU against a committed fixture the CPU oracle produced ONCE in the build
-container (tools/make_c4_fixture.py; the oracle needs minutes and gigabytes at this size, so it does not run on the GPU box).
+container (tests/tools/make_c4_fixture.py; the oracle needs minutes and gigabytes at this size, so it does not run on the GPU box).
 The same checks at 1/10 scale (100 cameras / 10 000 points) where the fixture can also be cross-checked live.
 
 Tolerances (north_star): variable ordering / indexing bit-exact (clique count, key order of the root and of sampled point

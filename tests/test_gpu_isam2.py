@@ -188,12 +188,12 @@ def test_cliques_wider_than_an_lds_front():
 
 
 def test_full_city10000_incremental_run():
-    """timing/timeIncremental.cpp's workload: all 10 000 poses of city10000, one per update (tools/isam2_long_run.py), the same updates
+    """timing/timeIncremental.cpp's workload: all 10 000 poses of city10000, one per update (tests/tools/isam2_long_run.py), the same updates
     replayed through the oracle: identical Bayes tree (7 939 cliques after the closing batch step, the widest 298 columns -- the
     dense-front fallback), identical counts of the last update, estimate within 1e-6."""
     import importlib.util
     import os
-    spec = importlib.util.spec_from_file_location("isam2_long_run", os.path.join(os.path.dirname(__file__), "..", "tools", "isam2_long_run.py"))
+    spec = importlib.util.spec_from_file_location("isam2_long_run", os.path.join(os.path.dirname(__file__), "tools", "isam2_long_run.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     res = mod.run(10000, check=True, verbose=False)

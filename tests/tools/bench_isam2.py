@@ -4,14 +4,14 @@ workloads of tests/test_gpu_isam2.py (VisualISAM2Example; the first 400 poses of
 The second half drives the same C ABI from C++ (tests/cpp/isam2_harness: the reference-side wrapper's call order, no Python between
 the updates; the sequence is recorded from the oracle's run first) -- what an update costs a C++ caller -- on the 400-pose sequence and
 on ALL poses of city10000 (tests/golden/city10000.g2o, one pose per update = timing/timeIncremental.cpp).
-    python tools/bench_isam2.py [--full]"""
+    python tests/tools/bench_isam2.py [--full]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_harness as oh  # noqa: E402

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Side measurement (not the bench.py metric): one LM iteration on the general sparse graphs C1 / C3 at full size,
-GPU vs. the single-thread CPU oracle.   python tools/bench_slam.py"""
+GPU vs. the single-thread CPU oracle.   python tests/tools/bench_slam.py"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_harness as oh  # noqa: E402

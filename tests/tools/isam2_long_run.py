@@ -2,14 +2,14 @@
 """timing/timeIncremental.cpp-style ISAM2 on the first N poses of the FULL city10000 graph (tests/golden/city10000.g2o) on the device: one
 pose per update with the edges that reach back from it, the new pose initialised by dead reckoning from the device's own estimate
 (refreshed every 50 poses).  `--check` replays the same updates through the CPU oracle and compares the final state.
-    python tools/isam2_long_run.py [N=3000] [--check]"""
+    python tests/tools/isam2_long_run.py [N=3000] [--check]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

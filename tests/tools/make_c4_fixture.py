@@ -11,7 +11,7 @@ parity test and bench.py need as small fixtures:
                                           point cliques; for METIS additionally the permutation itself
   tests/golden/c4_seed42_timing.json      wall time of the oracle's iteration at FULL size (cpu_baseline at the same workload)
 
-Usage: python tools/make_c4_fixture.py [--cams 1000 --points 100000 --obs 10 --seed 42] [--orderings schur,metis] [--tag c4_seed42]
+Usage: python tests/tools/make_c4_fixture.py [--cams 1000 --points 100000 --obs 10 --seed 42] [--orderings schur,metis] [--tag c4_seed42]
 The same script with smaller sizes (--tag bal100_seed42 --cams 100 --points 10000) makes the 1/10-scale fixture."""
 from __future__ import annotations
 
@@ -23,7 +23,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

@@ -1,4 +1,4 @@
-"""One dataset of tools/bench_slam.py for profiling: python tools/slam_one.py {sphere|city|victoria} {colamd|metis} [solves]
+"""One dataset of tests/tools/bench_slam.py for profiling: python tests/tools/slam_one.py {sphere|city|victoria} {colamd|metis} [solves]
 Prints wall time per damped solve (linearize once, then `solves` x solve(1e-3))."""
 import os
 import sys
@@ -6,13 +6,13 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import oracle_harness as oh  # noqa: E402
 from gtsam_personal_amd import LevenbergMarquardtOptimizer, LevenbergMarquardtParams, noiseModel  # noqa: E402
 from gtsam_personal_amd.datasets import chain_initial_pose3, load2D, load3D, readG2o  # noqa: E402
 
-GOLD = os.path.join(os.path.dirname(__file__), "..", "tests", "golden")
+GOLD = os.path.join(os.path.dirname(__file__), "..", "golden")
 which, order = sys.argv[1], sys.argv[2]
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 if which == "sphere":

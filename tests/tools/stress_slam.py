@@ -1,5 +1,5 @@
 """Repeated-solve stress of the sparse-graph paths (graph replay, merged back-substitution, batched mid-size fronts):
-    python tools/stress_slam.py {sphere|city|victoria} {colamd|metis} [solves]
+    python tests/tools/stress_slam.py {sphere|city|victoria} {colamd|metis} [solves]
 Every solve of the same linearization must return the same update (bitwise since the row-owner assembly; the bound checked is 1e-9)."""
 import os
 import sys
@@ -7,13 +7,13 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import oracle_harness as oh  # noqa: E402
 from gtsam_personal_amd import LevenbergMarquardtOptimizer, LevenbergMarquardtParams, noiseModel  # noqa: E402
 from gtsam_personal_amd.datasets import chain_initial_pose3, load2D, load3D, readG2o  # noqa: E402
 
-GOLD = os.path.join(os.path.dirname(__file__), "..", "tests", "golden")
+GOLD = os.path.join(os.path.dirname(__file__), "..", "golden")
 which, order = sys.argv[1], sys.argv[2]
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 200
 if which == "sphere":

@@ -5,8 +5,8 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import oracle_harness as oh
 from gtsam_personal_amd import LevenbergMarquardtOptimizer, LevenbergMarquardtParams
 from gtsam_personal_amd.synthetic import make_bal

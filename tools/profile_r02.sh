@@ -12,7 +12,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench
 echo "kernel trace done" >> $O/progress.txt
 find $O/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
 rm -rf $O/prof
-timeout -k 10 300 python tools/bench_isam2.py > $O/bench_isam2.txt 2>> $O/bench_slam.err
+timeout -k 10 300 python tests/tools/bench_isam2.py > $O/bench_isam2.txt 2>> $O/bench_slam.err
 tools/backsolve_bench > $O/backsolve_bench_now.txt 2>&1
 # PMC passes: tools/pmc_r02.sh (one counter group per run)
 head -c 600 $O/bench_c4.json
