@@ -114,6 +114,9 @@ SYMBOLS = {
     "lmgpu_isam2_update_with": (ct.c_int, [_H, ct.c_void_p, ct.c_void_p]),
     "lmgpu_isam2_set_relinearize_thresholds": (ct.c_int, [_H, ct.c_int32, ct.c_char_p, _I, _D]),
     "lmgpu_isam2_set_partial_relinearization_check": (ct.c_int, [_H, ct.c_int32]),
+    "lmgpu_isam2_set_evaluate_nonlinear_error": (ct.c_int, [_H, ct.c_int32]),
+    "lmgpu_isam2_get_errors": (ct.c_int, [_H, _D, _D]),
+    "lmgpu_isam2_error": (ct.c_int, [_H, ct.c_int32, _D]),
     "lmgpu_isam2_get_unused_keys": (ct.c_int, [_H, ct.POINTER(ct.c_uint64)]),
     "lmgpu_isam2_factor_exists": (ct.c_int, [_H, ct.c_int32]),
     "lmgpu_isam2_num_variables": (ct.c_int, [_H]),

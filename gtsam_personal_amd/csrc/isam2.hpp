@@ -64,6 +64,7 @@ struct lmgpu_isam2 {
     int n = 0, cap = 0;
     int64_t joff = -1;  // pool offset of the bucket's Jacobians (cap x rows x cols)
     int32_t* d_vidx = nullptr;
+    int32_t* d_epos = nullptr;  // per row: 1 + its index in the factor list = its place in the error buffer; 0 (a dump slot) once removed
     double *d_meas = nullptr, *d_noise = nullptr;
   };
   std::vector<Bkt> bkts;
@@ -121,6 +122,11 @@ struct lmgpu_isam2 {
   // ISAM2Params::relinearizeThreshold as FastMap<char, Vector> (non-empty: in force) and enablePartialRelinearizationCheck
   std::map<unsigned char, std::vector<double>> relin_thresholds;
   bool partial_relin_check = false;
+  // ISAM2Params::evaluateNonlinearError (ISAM2Params.h:200-203): ISAM2Result::errorBefore / errorAfter of the last update
+  bool evaluate_error = false;
+  double error_before = 0, error_after = 0;
+  double *d_ebuf = nullptr, *d_epart = nullptr, *h_escal = nullptr;  // per-factor errors (slot 0 = dump), partial sums + the total, pinned total
+  size_t ebuf_cap = 0;
 
   // device scratch
   int *d_status = nullptr, *h_status = nullptr;
@@ -1084,6 +1090,72 @@ int is_with_list(lmgpu_isam2* S, const std::vector<int32_t>& v, Fn fn) {
   return LMGPU_OK;
 }
 
+// nonlinearFactors_.error(values) (gtsam/nonlinear/NonlinearFactorGraph.cpp:170-179) over the factors still in the graph: the error kernels
+// of the batch path on every bucket, one error per factor into its place (removed rows into the dump slot), fixed-order reduction.
+// at_estimate: the values are theta retracted by the current delta (the caller has brought delta up to date), else theta itself.
+int is_graph_error(lmgpu_isam2* S, bool at_estimate, double* out) {
+  const size_t nfac = S->facs.size();
+  *out = 0.0;
+  if (nfac == 0) return LMGPU_OK;
+  int rc;
+  if (nfac + 1 > S->ebuf_cap) {
+    const size_t cap = is_next_cap(S->ebuf_cap, nfac + 1);
+    if ((rc = is_realloc(S, &S->d_ebuf, cap, 0))) return rc;
+    S->ebuf_cap = cap;
+  }
+  if (!S->d_epart) ISCHECK(hipMalloc((void**)&S->d_epart, 264 * sizeof(double)));
+  if (!S->h_escal) ISCHECK(hipHostMalloc((void**)&S->h_escal, sizeof(double), hipHostMallocDefault));
+  hipStream_t s = S->stream;
+  ISCHECK(hipMemsetAsync(S->d_ebuf, 0, (nfac + 1) * sizeof(double), s));
+  ValuesDev vals;
+  for (int t = 0; t < kNumVarTypes; t++) {
+    vals.v[t] = S->theta[t];
+    if (at_estimate && S->type_count[t] > 0) {
+      hipLaunchKernelGGL(retract_kernel, dim3((S->type_count[t] + 255) / 256), dim3(256), 0, s, t, S->type_count[t], (const double*)S->theta[t], S->est[t],
+                         (const int32_t*)S->d_type_xoff[t], (const double*)S->delta, (const int32_t*)nullptr);
+      vals.v[t] = S->est[t];
+    }
+  }
+  for (const lmgpu_isam2::Bkt& b : S->bkts) {
+    if (b.n == 0) continue;
+    BucketDev d;
+    d.type = b.type;
+    d.n = b.n;
+    d.noise_kind = b.noise_kind;
+    d.vidx = b.d_vidx;
+    d.meas = b.d_meas;
+    d.noise = b.d_noise;
+    d.J = nullptr;
+    d.epos = b.d_epos;
+    d.robust = 0;
+    d.rk = 0.0;
+    d.sel = nullptr;
+    const int g256 = (b.n + 255) / 256, g128 = (b.n + 127) / 128;
+    double* eb = S->d_ebuf;
+    switch (b.type) {
+      case LMGPU_F_SFM: hipLaunchKernelGGL(sfm_error_kernel, dim3(g256), dim3(256), 0, s, d, vals, eb); break;
+      case LMGPU_F_BETWEEN_POSE2: hipLaunchKernelGGL((generic_factor_kernel<1, 3, 3, 3, 3, 0, 3, 0, 3, false>), dim3(g128), dim3(128), 0, s, d, vals, eb); break;
+      case LMGPU_F_BETWEEN_POSE3: hipLaunchKernelGGL((generic_factor_kernel<2, 6, 6, 6, 12, 1, 12, 1, 12, false>), dim3(g128), dim3(128), 0, s, d, vals, eb); break;
+      case LMGPU_F_PRIOR_POSE2: hipLaunchKernelGGL((generic_factor_kernel<3, 3, 3, 0, 3, 0, 3, -1, 0, false>), dim3(g128), dim3(128), 0, s, d, vals, eb); break;
+      case LMGPU_F_PRIOR_POSE3: hipLaunchKernelGGL((generic_factor_kernel<4, 6, 6, 0, 12, 1, 12, -1, 0, false>), dim3(g128), dim3(128), 0, s, d, vals, eb); break;
+      case LMGPU_F_PRIOR_POINT3: hipLaunchKernelGGL((generic_factor_kernel<5, 3, 3, 0, 3, 2, 3, -1, 0, false>), dim3(g128), dim3(128), 0, s, d, vals, eb); break;
+      case LMGPU_F_PRIOR_CAM: hipLaunchKernelGGL((generic_factor_kernel<6, 9, 9, 0, 15, 3, 15, -1, 0, false>), dim3(g128), dim3(128), 0, s, d, vals, eb); break;
+      case LMGPU_F_PROJECTION: hipLaunchKernelGGL((generic_factor_kernel<7, 2, 6, 3, 7, 1, 12, 2, 3, false>), dim3(g128), dim3(128), 0, s, d, vals, eb); break;
+      case LMGPU_F_PROJECTION_BPS: hipLaunchKernelGGL((generic_factor_kernel<8, 2, 6, 3, 19, 1, 12, 2, 3, false>), dim3(g128), dim3(128), 0, s, d, vals, eb); break;
+      case LMGPU_F_BEARING_RANGE_2D: hipLaunchKernelGGL((generic_factor_kernel<9, 2, 3, 2, 2, 0, 3, 4, 2, false>), dim3(g128), dim3(128), 0, s, d, vals, eb); break;
+      case LMGPU_F_SFM2: hipLaunchKernelGGL(sfm2_factor_kernel<false>, dim3(g128), dim3(128), 0, s, d, vals, eb); break;
+      case LMGPU_F_PRIOR_CAL3_S2: hipLaunchKernelGGL((generic_factor_kernel<11, 5, 5, 0, 5, 5, 5, -1, 0, false>), dim3(g128), dim3(128), 0, s, d, vals, eb); break;
+    }
+  }
+  const int g = std::min(256, std::max(1, ((int)nfac + 255) / 256));
+  hipLaunchKernelGGL(reduce_stage1, dim3(g), dim3(256), 0, s, (const double*)(S->d_ebuf + 1), (int)nfac, S->d_epart);
+  hipLaunchKernelGGL(reduce_stage2, dim3(1), dim3(256), 0, s, (const double*)S->d_epart, g, S->d_epart + 256);
+  ISCHECK(hipMemcpyAsync(S->h_escal, S->d_epart + 256, sizeof(double), hipMemcpyDeviceToHost, s));
+  ISCHECK(hipStreamSynchronize(s));
+  *out = *S->h_escal;
+  return LMGPU_OK;
+}
+
 // ISAM2::update (gtsam/nonlinear/ISAM2.cpp:419-480)
 int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_result* result) {
   const bool force_relinearize = up.force_relinearize;
@@ -1185,7 +1257,7 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
   std::map<int, std::vector<int32_t>> new_by_bucket;  // bucket -> new local indices
   struct NewRows {
     int first = -1;
-    std::vector<int32_t> vidx;
+    std::vector<int32_t> vidx, epos;
     std::vector<double> meas, noise;
   };
   std::map<int, NewRows> new_rows;  // bucket -> the descriptor rows of its new factors (consecutive local indices), uploaded after the loop
@@ -1226,6 +1298,7 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
     if (b.n + 1 > b.cap) {  // grow the bucket: descriptor arrays and its Jacobian region in the pool
       const size_t ncap = std::max<size_t>(64, (size_t)b.cap * 2);
       if ((rc = is_realloc(S, &b.d_vidx, ncap * b.ar, (size_t)b.n * b.ar))) return rc;
+      if ((rc = is_realloc(S, &b.d_epos, ncap, (size_t)b.n))) return rc;
       if ((rc = is_realloc(S, &b.d_meas, ncap * b.ml, (size_t)b.n * b.ml))) return rc;
       if ((rc = is_realloc(S, &b.d_noise, ncap * std::max(1, b.nl), (size_t)b.n * b.nl))) return rc;
       int64_t noff;
@@ -1241,6 +1314,7 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
     NewRows& nr = new_rows[bi];
     if (nr.first < 0) nr.first = b.n;
     for (int k = 0; k < ar; k++) nr.vidx.push_back(S->vars[f.v[k]].tidx);
+    nr.epos.push_back(1 + (int32_t)S->facs.size());
     nr.meas.insert(nr.meas.end(), nf.meas.begin(), nf.meas.begin() + b.ml);
     if (b.nl) nr.noise.insert(nr.noise.end(), nf.noise.begin(), nf.noise.begin() + b.nl);
     f.bucket = bi;
@@ -1252,6 +1326,7 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
     lmgpu_isam2::Bkt& b = S->bkts[kv.first];
     const NewRows& nr = kv.second;
     if ((rc = is_push(S, b.d_vidx + (size_t)nr.first * b.ar, nr.vidx.data(), nr.vidx.size() * sizeof(int32_t)))) return rc;
+    if ((rc = is_push(S, b.d_epos + nr.first, nr.epos.data(), nr.epos.size() * sizeof(int32_t)))) return rc;
     if ((rc = is_push(S, b.d_meas + (size_t)nr.first * b.ml, nr.meas.data(), nr.meas.size() * sizeof(double)))) return rc;
     if (b.nl && (rc = is_push(S, b.d_noise + (size_t)nr.first * b.nl, nr.noise.data(), nr.noise.size() * sizeof(double)))) return rc;
   }
@@ -1266,10 +1341,17 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
       entries.erase(std::find(entries.begin(), entries.end(), (int32_t)idx));
     }
     f.removed = true;
+    const int32_t dump = 0;  // its row stays in the bucket; its error lands in the dump slot from now on
+    if ((rc = is_push(S, S->bkts[f.bucket].d_epos + f.lidx, &dump, sizeof(dump)))) return rc;
   }
   // computeUnusedKeys (:175-190): keys whose last factor went and which no new factor mentions
   for (uint64_t k : keysWithRemoved)
     if (S->vindex[S->vid_of.at(k)].empty() && !newFactorKeys.count(k)) unusedKeys.insert(k);
+  // 2. errorBefore (ISAM2.cpp:444-446): the graph with the new factors at calculateEstimate(), which brings delta up to date first
+  if (S->evaluate_error) {
+    if (S->any_replaced && (rc = is_update_delta(S, false))) return rc;
+    if ((rc = is_graph_error(S, true, &S->error_before))) return rc;
+  }
   // gatherInvolvedKeys (:199-226) + updateKeys (:228-244)
   markedKeys.insert(keysWithRemoved.begin(), keysWithRemoved.end());
   markedKeys.insert(up.extra_reelim.begin(), up.extra_reelim.end());
@@ -1517,6 +1599,10 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
   lap(5);
   rc = is_finish_elimination(S);  // the one wait of an update without relinearization
   lap(6);
+  if (rc == LMGPU_OK && S->evaluate_error) {  // errorAfter (ISAM2.cpp:481-483), again through calculateEstimate()
+    if (S->any_replaced && (rc = is_update_delta(S, false))) return rc;
+    rc = is_graph_error(S, true, &S->error_after);
+  }
   return rc;
 }
 
@@ -1566,14 +1652,17 @@ int lmgpu_isam2_destroy(lmgpu_isam2* S) {
     }
     for (auto& b : S->bkts) {
       if (b.d_vidx) (void)hipFree(b.d_vidx);
+      if (b.d_epos) (void)hipFree(b.d_epos);
       if (b.d_meas) (void)hipFree(b.d_meas);
       if (b.d_noise) (void)hipFree(b.d_noise);
     }
     for (void* p : {(void*)S->delta, (void*)S->ones, (void*)S->d_replaced, (void*)S->d_changed, (void*)S->pool, (void*)S->d_status, (void*)S->d_tree,
-                    (void*)S->d_tree_fx, (void*)S->d_tree_sx, (void*)S->d_queue, (void*)S->d_wl, (void*)S->inv16})
+                    (void*)S->d_tree_fx, (void*)S->d_tree_sx, (void*)S->d_queue, (void*)S->d_wl, (void*)S->inv16, (void*)S->d_marg, (void*)S->d_ebuf,
+                    (void*)S->d_epart})
       if (p) (void)hipFree(p);
     if (S->h_status) (void)hipHostFree(S->h_status);
     if (S->h_delta) (void)hipHostFree(S->h_delta);
+    if (S->h_escal) (void)hipHostFree(S->h_escal);
     if (S->h_stage) (void)hipHostFree(S->h_stage);
     if (S->d_stage) (void)hipFree(S->d_stage);
     for (auto& e : S->stage_extra) {
@@ -1676,6 +1765,26 @@ int lmgpu_isam2_set_relinearize_thresholds(lmgpu_isam2* S, int32_t n, const char
     values += dims[i];
   }
   return LMGPU_OK;
+}
+int lmgpu_isam2_set_evaluate_nonlinear_error(lmgpu_isam2* S, int32_t enable) {
+  if (!S) return LMGPU_INVALID;
+  S->evaluate_error = enable != 0;
+  return LMGPU_OK;
+}
+int lmgpu_isam2_get_errors(const lmgpu_isam2* S, double* error_before, double* error_after) {
+  if (!S) return LMGPU_INVALID;
+  if (error_before) *error_before = S->error_before;
+  if (error_after) *error_after = S->error_after;
+  return LMGPU_OK;
+}
+// getFactorsUnsafe().error(calculateEstimate()) (which = 0) / .error(getLinearizationPoint()) (which = 2)
+int lmgpu_isam2_error(lmgpu_isam2* S, int32_t which, double* out) {
+  if (!S || !out || (which != 0 && which != 2)) return LMGPU_INVALID;
+  if (S->device < 0) return LMGPU_HIP_ERROR;
+  ISCHECK(hipSetDevice(S->device));
+  int rc;
+  if (which == 0 && S->any_replaced && (rc = is_update_delta(S, false))) return rc;
+  return is_graph_error(S, which == 0, out);
 }
 int lmgpu_isam2_set_partial_relinearization_check(lmgpu_isam2* S, int32_t enable) {
   if (!S) return LMGPU_INVALID;

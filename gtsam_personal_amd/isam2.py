@@ -26,16 +26,18 @@ class ISAM2Params:
     enablePartialRelinearizationCheck (:214-222)"""
 
     def __init__(self, optimizationParams=None, relinearizeThreshold=0.1, relinearizeSkip=10, enableRelinearization=True,
-                 enablePartialRelinearizationCheck=False):
+                 enablePartialRelinearizationCheck=False, evaluateNonlinearError=False):
         self.optimizationParams = optimizationParams or ISAM2GaussNewtonParams()
         self.relinearizeThreshold = relinearizeThreshold
         self.relinearizeSkip = relinearizeSkip
         self.enableRelinearization = enableRelinearization
         self.enablePartialRelinearizationCheck = enablePartialRelinearizationCheck
+        self.evaluateNonlinearError = evaluateNonlinearError  # ISAM2Params.h:200-203
 
 
 class ISAM2Result:
-    def __init__(self, r):
+    def __init__(self, r, errors=None):
+        self.errorBefore, self.errorAfter = errors if errors else (None, None)  # with ISAM2Params.evaluateNonlinearError
         self.variablesRelinearized = r.variablesRelinearized
         self.variablesReeliminated = r.variablesReeliminated
         self.factorsRecalculated = r.factorsRecalculated
@@ -85,6 +87,8 @@ class ISAM2:
                                                                         vals.ctypes.data_as(_lib._D)))
         if getattr(p, "enablePartialRelinearizationCheck", False):
             self._check(self.lib.lmgpu_isam2_set_partial_relinearization_check(self._h, 1))
+        if getattr(p, "evaluateNonlinearError", False):
+            self._check(self.lib.lmgpu_isam2_set_evaluate_nonlinear_error(self._h, 1))
         self._u0v0 = {}  # constant principal points of Cal3Bundler cameras (do not travel, see lmgpu.h CAM_BUNDLER)
 
     def _check(self, rc):
@@ -148,7 +152,18 @@ class ISAM2:
                                             cg.ctypes.data_as(_lib._I), len(nr), nr.ctypes.data_as(U64), len(ex), ex.ctypes.data_as(U64),
                                             int(force_relinearize), int(forceFullSolve))
         self._check(self.lib.lmgpu_isam2_update_with(self._h, ct.byref(up), ct.byref(res)))
-        return ISAM2Result(res)
+        errors = None
+        if getattr(self.params, "evaluateNonlinearError", False):
+            b, a = ct.c_double(), ct.c_double()
+            self._check(self.lib.lmgpu_isam2_get_errors(self._h, ct.byref(b), ct.byref(a)))
+            errors = (b.value, a.value)
+        return ISAM2Result(res, errors)
+
+    def error(self, which=0):
+        """getFactorsUnsafe().error(calculateEstimate()) (which = 0) or .error(getLinearizationPoint()) (which = 2)"""
+        e = ct.c_double()
+        self._check(self.lib.lmgpu_isam2_error(self._h, int(which), ct.byref(e)))
+        return e.value
 
     def marginalCovariance(self, key):
         """ISAM2::marginalCovariance(key) (gtsam/nonlinear/ISAM2.h:253-257)"""

@@ -305,6 +305,14 @@ uint64_t lmgpu_isam2_last_failed_key(const lmgpu_isam2* s); /* LMGPU_INDETERMINA
  * when any |delta_i| > threshold_i (strictly; ISAM2-impl.h:266, 375) of its character's vector; an update that meets a variable
  * without a vector of its dimension returns LMGPU_INVALID (the reference throws, :258-262).  n = 0: the scalar threshold again. */
 int lmgpu_isam2_set_relinearize_thresholds(lmgpu_isam2* s, int32_t n, const char* chrs, const int32_t* dims, const double* values);
+/* ISAM2Params::evaluateNonlinearError (ISAM2Params.h:200-203): every update also evaluates the nonlinear error of the whole graph at
+ * calculateEstimate() after the new factors have been added (ISAM2Result::errorBefore, ISAM2.cpp:444-446) and at its end (errorAfter,
+ * :481-483) -- each through calculateEstimate(), i.e. with the back-substitution brought up to date first, like the reference.
+ * lmgpu_isam2_get_errors returns the two of the last update; lmgpu_isam2_error is getFactorsUnsafe().error(values) on demand,
+ * which = 0 at calculateEstimate(), 2 at the linearization point (the error kernels of the batch path on every factor bucket). */
+int lmgpu_isam2_set_evaluate_nonlinear_error(lmgpu_isam2* s, int32_t enable);
+int lmgpu_isam2_get_errors(const lmgpu_isam2* s, double* error_before, double* error_after);
+int lmgpu_isam2_error(lmgpu_isam2* s, int32_t which, double* out);
 /* ISAM2Params::enablePartialRelinearizationCheck (ISAM2Params.h:214-222): the check walks down from the roots and stops below a
  * clique none of whose variables is above its threshold (CheckRelinearizationPartial, ISAM2-impl.h:246-331) */
 int lmgpu_isam2_set_partial_relinearization_check(lmgpu_isam2* s, int32_t enable);

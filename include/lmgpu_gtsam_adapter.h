@@ -446,6 +446,7 @@ class GpuISAM2 {
       check(lmgpu_isam2_set_relinearize_thresholds(h_, (int32_t)dims.size(), chrs.data(), dims.data(), values.data()));
     }
     if (params.enablePartialRelinearizationCheck) check(lmgpu_isam2_set_partial_relinearization_check(h_, 1));
+    if (params.evaluateNonlinearError) check(lmgpu_isam2_set_evaluate_nonlinear_error(h_, 1));
   }
   ~GpuISAM2() { if (h_) lmgpu_isam2_destroy(h_); }
   GpuISAM2(const GpuISAM2&) = delete;
@@ -519,6 +520,19 @@ class GpuISAM2 {
     Matrix cov(d, d);  // symmetric: the row-major block the library writes reads the same column-major
     check(lmgpu_isam2_marginal_covariance(h_, key, cov.data()));
     return cov;
+  }
+
+  /// ISAM2Result::errorBefore / errorAfter of the last update (with ISAM2Params::evaluateNonlinearError)
+  std::pair<double, double> errors() const {
+    double before = 0, after = 0;
+    check(lmgpu_isam2_get_errors(h_, &before, &after));
+    return {before, after};
+  }
+  /// getFactorsUnsafe().error(calculateEstimate())
+  double error() const {
+    double e = 0;
+    check(lmgpu_isam2_error(h_, 0, &e));
+    return e;
   }
 
   /// ISAM2Result::unusedKeys of the last update

@@ -55,6 +55,8 @@ struct ISAM2 {
   std::map<unsigned char, std::vector<double>> relinearizeThresholds;  // the FastMap<char, Vector> alternative (non-empty: in force)
   int relinearizeSkip = 10;
   bool enableRelinearization = true, enablePartialRelinearizationCheck = false;
+  bool evaluateNonlinearError = false;  // ISAM2Params.h:200-203: ISAM2Result::errorBefore / errorAfter
+  double errorBefore = 0, errorAfter = 0;
   ccolamd_fn ccolamd = nullptr;
 
   Values theta;
@@ -300,6 +302,9 @@ static void isam2_check_relin_partial(const ISAM2& S, const ICliquePtr& c, std::
     for (auto& child : c->children) isam2_check_relin_partial(S, child, relinKeys);
 }
 
+static Values isam2_calculate_estimate(ISAM2& S, bool best);
+static double isam2_graph_error(const ISAM2& S, const Values& values);
+
 // ISAM2::update gtsam/nonlinear/ISAM2.cpp:419-480
 static ISAM2Result isam2_update(ISAM2& S, const ISAM2UpdateParams& up) {
   S.update_count += 1;
@@ -341,6 +346,8 @@ static ISAM2Result isam2_update(ISAM2& S, const ISAM2UpdateParams& up) {
     for (int k = 0; k < kFactorArity[f.type]; k++) newFactorKeys.insert(f.keys[k]);
   for (Key key : keysWithRemovedFactors)
     if (S.variableIndex.at(key).empty() && !newFactorKeys.count(key)) unusedKeys.insert(key);
+  // 2. errorBefore (ISAM2.cpp:444-446): the graph WITH the new factors at calculateEstimate(), which brings delta up to date first
+  if (S.evaluateNonlinearError) S.errorBefore = isam2_graph_error(S, isam2_calculate_estimate(S, false));
   // 3. gatherInvolvedKeys :199-226: keys of the new factors, of the removed factors, extraReelimKeys; updateKeys :228-244:
   //    observedKeys = the marked keys that stay in the system
   std::set<Key> markedKeys = newFactorKeys;
@@ -485,10 +492,19 @@ static ISAM2Result isam2_update(ISAM2& S, const ISAM2UpdateParams& up) {
     S.theta.erase(key);
   }
   S.lastUnusedKeys.assign(unusedKeys.begin(), unusedKeys.end());
+  if (S.evaluateNonlinearError) S.errorAfter = isam2_graph_error(S, isam2_calculate_estimate(S, false));  // ISAM2.cpp:481-483
   result.cliques = 0;
   for (auto& r : S.roots) result.cliques += isam2_count_cliques(r);
   S.last = result;
   return result;
+}
+
+// nonlinearFactors_.error(values) over the factors still in the graph (NonlinearFactorGraph.cpp:170-179: empty slots are skipped)
+static double isam2_graph_error(const ISAM2& S, const Values& values) {
+  double total = 0;
+  for (size_t i = 0; i < S.nonlinearFactors.size(); i++)
+    if (!S.removedFactor[i]) total += factor_error(S.nonlinearFactors[i], values);
+  return total;
 }
 
 // ISAM2::calculateEstimate :748-754 (getDelta :776-779)

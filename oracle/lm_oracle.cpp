@@ -1872,6 +1872,17 @@ void orc_isam2_set_thresholds(void* h, int n, const unsigned char* chrs, const i
     values += dims[i];
   }
 }
+// ISAM2Params::evaluateNonlinearError; ISAM2Result::errorBefore / errorAfter of the last update
+void orc_isam2_set_evaluate_error(void* h, int enable) { ((ISAM2Handle*)h)->S.evaluateNonlinearError = enable != 0; }
+void orc_isam2_errors(void* h, double* before, double* after) {
+  *before = ((ISAM2Handle*)h)->S.errorBefore;
+  *after = ((ISAM2Handle*)h)->S.errorAfter;
+}
+// getFactorsUnsafe().error(values): which = 0 calculateEstimate(), 2 the linearization point
+double orc_isam2_error(void* h, int which) {
+  auto& S = ((ISAM2Handle*)h)->S;
+  return isam2_graph_error(S, which == 2 ? S.theta : isam2_calculate_estimate(S, false));
+}
 void orc_isam2_set_partial_check(void* h, int enable) { ((ISAM2Handle*)h)->S.enablePartialRelinearizationCheck = enable != 0; }
 
 int orc_isam2_add_variable(void* h, uint64_t key, int type, const double* value) {

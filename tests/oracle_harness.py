@@ -434,6 +434,10 @@ class OracleISAM2:
         L.orc_isam2_update.argtypes = [ct.c_void_p, ct.c_int, _I]
         L.orc_isam2_set_thresholds.argtypes = [ct.c_void_p, ct.c_int, ct.c_char_p, _I, _D]
         L.orc_isam2_set_partial_check.argtypes = [ct.c_void_p, ct.c_int]
+        L.orc_isam2_set_evaluate_error.argtypes = [ct.c_void_p, ct.c_int]
+        L.orc_isam2_errors.argtypes = [ct.c_void_p, _D, _D]
+        L.orc_isam2_error.argtypes = [ct.c_void_p, ct.c_int]
+        L.orc_isam2_error.restype = ct.c_double
         L.orc_isam2_update_with.argtypes = [ct.c_void_p, ct.c_int, _U, ct.c_int, ct.c_int, _U, _I, ct.c_int, _U, ct.c_int, _U, ct.c_int, ct.c_int, _I]
         L.orc_isam2_unused_keys.argtypes = [ct.c_void_p, _U]
         L.orc_isam2_factor_exists.argtypes = [ct.c_void_p, ct.c_int]
@@ -463,6 +467,19 @@ class OracleISAM2:
 
     def set_partial_relinearization_check(self, enable):
         self.L.orc_isam2_set_partial_check(self.h, int(bool(enable)))
+
+    def set_evaluate_nonlinear_error(self, enable):
+        self.L.orc_isam2_set_evaluate_error(self.h, int(bool(enable)))
+
+    def errors(self):
+        """(ISAM2Result::errorBefore, errorAfter) of the last update"""
+        b, a = np.zeros(1), np.zeros(1)
+        self.L.orc_isam2_errors(self.h, dp(b), dp(a))
+        return float(b[0]), float(a[0])
+
+    def error(self, which=0):
+        """getFactorsUnsafe().error(calculateEstimate()) (which = 0) / at the linearization point (which = 2)"""
+        return float(self.L.orc_isam2_error(self.h, int(which)))
 
     def update(self, newFactors: NonlinearFactorGraph = None, newTheta: Values = None, removeFactorIndices=(), constrainedKeys=None,
                noRelinKeys=None, extraReelimKeys=None, force_relinearize=False, forceFullSolve=False):

@@ -506,3 +506,28 @@ def test_single_variable_estimate_and_device_driven_incremental_run():
         ro = orc.update(g, v)
     compare_state(isam, orc)
     isam.close()
+
+
+def test_evaluate_nonlinear_error():
+    """ISAM2Params::evaluateNonlinearError on the device (errorBefore / errorAfter of every update, lmgpu_isam2_error on demand) against
+    the oracle on the visual example (projection factors, priors) and on the slamlike sequence followed by a removal (the removed
+    factor's error must no longer count), a removal of the empty slot and a bare update"""
+    for steps, tail in ((visual_steps(), []), (slamlike_steps(), [dict(removeFactorIndices=[12]), dict(removeFactorIndices=[12]), dict()])):
+        p = ISAM2Params(relinearizeThreshold=0.01, relinearizeSkip=1, evaluateNonlinearError=True)
+        isam, orc = pair(p)
+        orc.set_evaluate_nonlinear_error(True)
+        for g, v in steps:
+            r = isam.update(g, v)
+            assert r.as_dict() == orc.update(g, v)
+            eb, ea = orc.errors()
+            assert abs(r.errorBefore - eb) <= 1e-6 * max(1e-9, abs(eb)) + 1e-12, (r.errorBefore, eb)
+            assert abs(r.errorAfter - ea) <= 1e-6 * max(1e-9, abs(ea)) + 1e-12, (r.errorAfter, ea)
+        for kw in tail:
+            r = isam.update(**kw)
+            assert r.as_dict() == orc.update(**kw)
+            eb, ea = orc.errors()
+            assert abs(r.errorBefore - eb) <= 1e-6 * abs(eb) + 1e-12 and abs(r.errorAfter - ea) <= 1e-6 * abs(ea) + 1e-12
+        for which in (0, 2):
+            assert abs(isam.error(which) - orc.error(which)) <= 1e-6 * abs(orc.error(which)) + 1e-12
+        compare_state(isam, orc)
+        isam.close()

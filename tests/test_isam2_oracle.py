@@ -232,3 +232,26 @@ def test_partial_relinearization_check_and_threshold_vectors():
     with pytest.raises(AssertionError):
         for g, v in vs:
             bad.update(g, v)
+
+
+def test_evaluate_nonlinear_error():
+    """ISAM2Params::evaluateNonlinearError: errorAfter of every update = the nonlinear error of the full graph at calculateEstimate()
+    (evaluated independently through the batch oracle), errorBefore = the same graph at the estimate before the update's elimination;
+    after a removal the removed factor no longer counts (ISAM2.cpp:444-446, 481-483)"""
+    steps = slamlike_steps()
+    isam = oh.OracleISAM2(relinearizeThreshold=0.01, relinearizeSkip=1)
+    isam.set_evaluate_nonlinear_error(True)
+    for n, (g, v) in enumerate(steps):
+        isam.update(g, v)
+        before, after = isam.errors()
+        fullgraph, _ = merge(steps[:n + 1])
+        est = isam.calculateEstimate()
+        batch = oh.OracleProblem(fullgraph, est, Ordering.Natural(fullgraph))
+        assert abs(after - batch.error()) <= 1e-12 * max(1.0, batch.error()), n
+        assert abs(isam.error(0) - after) <= 1e-15 * max(1.0, after) and before >= after - 1e-9
+    isam.update(removeFactorIndices=[12])
+    fullgraph, _ = merge(steps, removed={12})
+    batch = oh.OracleProblem(fullgraph, isam.calculateEstimate(), Ordering.Natural(fullgraph))
+    assert abs(isam.errors()[1] - batch.error()) <= 1e-12 * max(1.0, batch.error())
+    lin = oh.OracleProblem(fullgraph, isam.getLinearizationPoint(), Ordering.Natural(fullgraph))
+    assert abs(isam.error(2) - lin.error()) <= 1e-12 * max(1.0, lin.error())
