@@ -137,6 +137,16 @@ struct lmgpu_isam2 {
   char *h_stage = nullptr, *d_stage = nullptr;
   size_t stage_cap = 0, stage_used = 0, stage_want = 0;
   std::vector<std::pair<void*, void*>> stage_extra;  // (pinned host, device)
+  // Deferred uploads: what is_stage / is_push put into the pinned arena since the last flush travels to the device arena in ONE copy,
+  // and the pushes (payload in the arena -> a persistent device array) are carried out by ONE scatter kernel (is_flush) -- an update
+  // issued 28 copy commands of a few hundred bytes each before (rocprofv3: half of its GPU time, and ~4 us of host time apiece).
+  size_t stage_flushed = 0;
+  struct PushRec {
+    void* dst;
+    const void* src;  // in the device arena
+    uint32_t words, pad;
+  };
+  std::vector<PushRec> pushes;
   double* inv16 = nullptr;    // 16 x 256 doubles: the 16 x 16 inverses of the panel being factored (wide cliques)
   double* d_marg = nullptr;   // marginalCovariance: one work vector per column of the block + the block itself
   size_t marg_cap = 0;
@@ -162,6 +172,14 @@ struct lmgpu_isam2 {
   std::vector<int32_t> snap;
 };
 
+// the pending pushes of an update: record i = words 4-byte words from the device staging arena to their place in a persistent array
+__global__ __launch_bounds__(256) void isam2_scatter_kernel(const lmgpu_isam2::PushRec* __restrict__ recs) {
+  const lmgpu_isam2::PushRec r = recs[blockIdx.x];
+  uint32_t* dst = (uint32_t*)r.dst;
+  const uint32_t* src = (const uint32_t*)r.src;
+  for (uint32_t w = threadIdx.x; w < r.words; w += 256) dst[w] = src[w];
+}
+
 namespace {
 
 #define ISCHECK(expr)                                                 \
@@ -173,9 +191,12 @@ namespace {
     }                                                                 \
   } while (0)
 
+int is_flush(lmgpu_isam2* S);
 // reallocate a device array to exactly `newcap` elements, keeping its `used` leading elements
 template <typename T>
 int is_realloc(lmgpu_isam2* S, T** p, size_t newcap, size_t used) {
+  const int rcf = is_flush(S);  // a pending push may point into the array that goes away
+  if (rcf) return rcf;
   T* q = nullptr;
   ISCHECK(hipMalloc((void**)&q, std::max<size_t>(1, newcap) * sizeof(T)));
   if (*p && used) ISCHECK(hipMemcpyAsync(q, *p, used * sizeof(T), hipMemcpyDeviceToDevice, S->stream));
@@ -188,6 +209,8 @@ inline size_t is_next_cap(size_t cap, size_t need) { return std::max<size_t>(nee
 
 // start of an update: the stream is idle (every entry point ends with a wait), so the arenas can be reused / regrown
 int is_stage_begin(lmgpu_isam2* S) {
+  const int rcf = is_flush(S);
+  if (rcf) return rcf;
   ISCHECK(hipStreamSynchronize(S->stream));
   for (auto& e : S->stage_extra) {
     (void)hipHostFree(e.first);
@@ -207,6 +230,7 @@ int is_stage_begin(lmgpu_isam2* S) {
     S->stage_cap = want;
   }
   S->stage_used = 0;
+  S->stage_flushed = 0;
   S->stage_want = 0;
   return LMGPU_OK;
 }
@@ -228,27 +252,58 @@ int is_stage_raw(lmgpu_isam2* S, size_t bytes, char** hp, char** dp) {
   if (dp) *dp = (char*)d;
   return LMGPU_OK;
 }
-// a table the update's kernels read: host vector -> device arena, asynchronously
+// a table the update's kernels read: host vector -> device arena (with the next flush; a request beyond the arena is copied at once)
 template <typename T>
 int is_stage(lmgpu_isam2* S, const std::vector<T>& src, T** d) {
   char *hp, *dp;
+  const size_t before = S->stage_extra.size();
   const int rc = is_stage_raw(S, src.size() * sizeof(T), &hp, &dp);
   if (rc) return rc;
   if (!src.empty()) {
     std::memcpy(hp, src.data(), src.size() * sizeof(T));
-    ISCHECK(hipMemcpyAsync(dp, hp, src.size() * sizeof(T), hipMemcpyHostToDevice, S->stream));
+    if (S->stage_extra.size() != before) ISCHECK(hipMemcpyAsync(dp, hp, src.size() * sizeof(T), hipMemcpyHostToDevice, S->stream));
   }
   *d = (T*)dp;
   return LMGPU_OK;
 }
-// host data into a persistent device array, asynchronously (the source is copied into the pinned arena first)
+// host data into a persistent device array (the source is copied into the pinned arena; the scatter kernel of the next flush moves it)
 int is_push(lmgpu_isam2* S, void* dst, const void* src, size_t bytes) {
   if (!bytes) return LMGPU_OK;
-  char* hp;
-  const int rc = is_stage_raw(S, bytes, &hp, nullptr);
+  char *hp, *dp;
+  const size_t before = S->stage_extra.size();
+  const int rc = is_stage_raw(S, bytes, &hp, &dp);
   if (rc) return rc;
   std::memcpy(hp, src, bytes);
-  ISCHECK(hipMemcpyAsync(dst, hp, bytes, hipMemcpyHostToDevice, S->stream));
+  if (S->stage_extra.size() != before || (bytes & 3) != 0) {  // beyond the arena (or not whole words): its own copy, now
+    ISCHECK(hipMemcpyAsync(dst, hp, bytes, hipMemcpyHostToDevice, S->stream));
+    return LMGPU_OK;
+  }
+  S->pushes.push_back(lmgpu_isam2::PushRec{dst, dp, (uint32_t)(bytes >> 2), 0u});
+  return LMGPU_OK;
+}
+// everything staged or pushed so far reaches the device: one copy of the arena's new part, one scatter kernel for the pushes.
+// Called before anything that consumes staged tables or pushed arrays is launched (and before an array a push points into moves).
+int is_flush(lmgpu_isam2* S) {
+  const lmgpu_isam2::PushRec* d_recs = nullptr;
+  const size_t npush = S->pushes.size();
+  bool recs_in_arena = true;
+  if (npush) {
+    char *hp, *dp;
+    const size_t before = S->stage_extra.size();
+    const int rc = is_stage_raw(S, npush * sizeof(lmgpu_isam2::PushRec), &hp, &dp);
+    if (rc) return rc;
+    std::memcpy(hp, S->pushes.data(), npush * sizeof(lmgpu_isam2::PushRec));
+    recs_in_arena = S->stage_extra.size() == before;
+    if (!recs_in_arena) ISCHECK(hipMemcpyAsync(dp, hp, npush * sizeof(lmgpu_isam2::PushRec), hipMemcpyHostToDevice, S->stream));
+    d_recs = (const lmgpu_isam2::PushRec*)dp;
+    S->pushes.clear();
+  }
+  if (S->stage_used > S->stage_flushed) {
+    ISCHECK(hipMemcpyAsync(S->d_stage + S->stage_flushed, S->h_stage + S->stage_flushed, S->stage_used - S->stage_flushed, hipMemcpyHostToDevice,
+                           S->stream));
+    S->stage_flushed = S->stage_used;
+  }
+  if (npush) hipLaunchKernelGGL(isam2_scatter_kernel, dim3((unsigned)npush), dim3(256), 0, S->stream, d_recs);
   return LMGPU_OK;
 }
 
@@ -740,6 +795,7 @@ int is_patch_tree(lmgpu_isam2* S) {
   if ((rc = is_stage(S, ids, &d_ids)) || (rc = is_stage(S, td, &d_td)) || (rc = is_stage(S, fx, &d_fx)) || (rc = is_stage(S, sx, &d_sx)) ||
       (rc = is_stage(S, kids, &d_kids)) || (rc = is_stage(S, kids_begin, &d_kb)) || (rc = is_stage(S, xrow_begin, &d_xb)))
     return rc;
+  if ((rc = is_flush(S))) return rc;
   hipLaunchKernelGGL(isam2_tree_patch_kernel, dim3((unsigned)ids.size()), dim3(256), 0, S->stream, (const int32_t*)d_ids, (const FrontDesc*)d_td,
                      (const int32_t*)d_fx, (const int32_t*)d_sx, (const int32_t*)d_kids, (const int32_t*)d_kb, (const int32_t*)d_xb, S->d_tree,
                      S->d_tree_fx, S->d_tree_sx, S->pool);
@@ -764,6 +820,7 @@ int is_update_delta_enqueue(lmgpu_isam2* S, bool force_full, bool host_delta) {
     const unsigned int ctl[4] = {r, 0u, r, 0u};
     if ((rc = is_push(S, S->d_queue, S->roots.data(), r * sizeof(int32_t)))) return rc;
     if ((rc = is_push(S, S->d_wl, ctl, sizeof(ctl)))) return rc;
+    if ((rc = is_flush(S))) return rc;
     hipLaunchKernelGGL(isam2_wildfire_kernel, dim3(ISAM2_WL_GROUPS), dim3(256), (S->tree_lds + LDSB_TAIL) * sizeof(double), S->stream, S->d_queue, S->d_wl,
                        (const FrontDesc*)S->d_tree, (const int32_t*)S->d_tree_fx, (const int32_t*)S->d_tree_sx, (const double*)S->pool, S->delta,
                        (const unsigned char*)S->d_replaced, S->d_changed, thr, S->d_status);
@@ -1010,6 +1067,7 @@ int is_eliminate(lmgpu_isam2* S, const std::vector<IsGF>& gfs, const std::vector
   if ((rc = is_stage(S, fds, &d_fds)) || (rc = is_stage(S, ffac, &d_ffac)) || (rc = is_stage(S, fd, &d_fd)) || (rc = is_stage(S, childs, &d_childs)) ||
       (rc = is_stage(S, cmap, &d_cmap)) || (rc = is_stage(S, fxoff, &d_fxoff)) || (rc = is_stage(S, list, &d_list)))
     return rc;
+  if ((rc = is_flush(S))) return rc;  // the tables above, and whatever the update pushed before (new values, factor rows)
   ISCHECK(hipMemsetAsync(S->d_status, 0x7f, sizeof(int), S->stream));
   for (int l = 0; l <= max_level; l++) {
     for (int32_t fi : wide[l]) {  // (the level's LDS fronts and these only depend on the levels below)
@@ -1066,6 +1124,8 @@ int is_eliminate(lmgpu_isam2* S, const std::vector<IsGF>& gfs, const std::vector
 
 // the wait that ends an update: EliminateCholesky failed -> IndeterminantLinearSystemException(first frontal key), HessianFactor.cpp:475-482
 int is_finish_elimination(lmgpu_isam2* S) {
+  const int rcf = is_flush(S);  // nothing staged or pushed outlives the entry point
+  if (rcf) return rcf;
   ISCHECK(hipStreamSynchronize(S->stream));
   ISCHECK(hipGetLastError());
   if (!S->elim_pending) return LMGPU_OK;
@@ -1084,8 +1144,9 @@ template <typename Fn>
 int is_with_list(lmgpu_isam2* S, const std::vector<int32_t>& v, Fn fn) {
   if (v.empty()) return LMGPU_OK;
   int32_t* d = nullptr;
-  const int rc = is_stage(S, v, &d);
+  int rc = is_stage(S, v, &d);
   if (rc) return rc;
+  if ((rc = is_flush(S))) return rc;
   fn((const int32_t*)d, (int)v.size());
   return LMGPU_OK;
 }
@@ -1106,6 +1167,7 @@ int is_graph_error(lmgpu_isam2* S, bool at_estimate, double* out) {
   if (!S->d_epart) ISCHECK(hipMalloc((void**)&S->d_epart, 264 * sizeof(double)));
   if (!S->h_escal) ISCHECK(hipHostMalloc((void**)&S->h_escal, sizeof(double), hipHostMallocDefault));
   hipStream_t s = S->stream;
+  if ((rc = is_flush(S))) return rc;
   ISCHECK(hipMemsetAsync(S->d_ebuf, 0, (nfac + 1) * sizeof(double), s));
   ValuesDev vals;
   for (int t = 0; t < kNumVarTypes; t++) {
@@ -1807,6 +1869,7 @@ int lmgpu_isam2_get_values(lmgpu_isam2* S, int32_t which, uint64_t* keys_out, in
   if (S->device < 0) return LMGPU_HIP_ERROR;
   ISCHECK(hipSetDevice(S->device));
   int rc;
+  if ((rc = is_flush(S))) return rc;
   if (which == 1) {  // calculateBestEstimate: full back-substitution (ISAM2.cpp:763-766)
     if ((rc = is_update_delta(S, true))) return rc;
   } else if (which == 0 && S->any_replaced) {  // getDelta (:776-779)
@@ -1868,6 +1931,7 @@ int lmgpu_isam2_marginal_covariance(lmgpu_isam2* S, uint64_t key, double* cov) {
   double* d_out = S->d_marg + (size_t)dim * S->ntot;
   int32_t* d_path;
   if ((rc = is_stage(S, path, &d_path))) return rc;
+  if ((rc = is_flush(S))) return rc;
   ISCHECK(hipMemsetAsync(S->d_marg, 0, (size_t)dim * S->ntot * sizeof(double), S->stream));
   ISCHECK(hipMemsetAsync(S->d_status, 0x7f, sizeof(int), S->stream));
   hipLaunchKernelGGL(isam2_marginal_kernel, dim3(dim), dim3(64), max_n * sizeof(double), S->stream, (const int32_t*)d_path, (int)path.size(),
