@@ -8,4 +8,4 @@ LevenbergMarquardtOptimizer does, and fails loudly if liblmgpu.so has not been b
 from .graph import (CAL3_S2, CAM_BUNDLER, POINT2, POINT3, POSE2, POSE3, C, L, NonlinearFactorGraph, Ordering, P, Values, X, noiseModel, symbol)  # noqa: F401
 from .optimizer import (DoglegOptimizer, DoglegParams, GaussNewtonOptimizer, GaussNewtonParams, LevenbergMarquardtOptimizer,  # noqa: F401
                         LevenbergMarquardtParams, JointMarginal, Marginals)
-from .isam2 import ISAM2, ISAM2GaussNewtonParams, ISAM2Params, ISAM2Result  # noqa: F401
+from .isam2 import ISAM2, ISAM2DoglegParams, ISAM2GaussNewtonParams, ISAM2Params, ISAM2Result  # noqa: F401

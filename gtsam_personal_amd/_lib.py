@@ -114,6 +114,8 @@ SYMBOLS = {
     "lmgpu_isam2_update_with": (ct.c_int, [_H, ct.c_void_p, ct.c_void_p]),
     "lmgpu_isam2_set_relinearize_thresholds": (ct.c_int, [_H, ct.c_int32, ct.c_char_p, _I, _D]),
     "lmgpu_isam2_set_partial_relinearization_check": (ct.c_int, [_H, ct.c_int32]),
+    "lmgpu_isam2_set_dogleg": (ct.c_int, [_H, ct.c_double, ct.c_double, ct.c_int32]),
+    "lmgpu_isam2_get_dogleg_delta": (ct.c_double, [_H]),
     "lmgpu_isam2_set_evaluate_nonlinear_error": (ct.c_int, [_H, ct.c_int32]),
     "lmgpu_isam2_get_errors": (ct.c_int, [_H, _D, _D]),
     "lmgpu_isam2_error": (ct.c_int, [_H, ct.c_int32, _D]),

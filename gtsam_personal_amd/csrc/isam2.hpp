@@ -21,7 +21,8 @@
 // ISAM2UpdateParams (gtsam/nonlinear/ISAM2UpdateParams.h:30-90) honoured: removeFactorIndices (a removed factor leaves an empty slot, a
 // variable that lost its last factor leaves the system: pushBackFactors / computeUnusedKeys / removeVariables), constrainedKeys,
 // noRelinKeys, extraReelimKeys, force_relinearize, forceFullSolve.
-// Limits (fail loudly): Gauss-Newton params, Cholesky, no marginalizeLeaves, no newAffectedKeys (smart factors).
+// ISAM2Params: Gauss-Newton or Dogleg optimisation params, relinearization thresholds (double or per Symbol character), partial check,
+// evaluateNonlinearError.  Limits (fail loudly): Cholesky, no marginalizeLeaves, no newAffectedKeys (smart factors).
 #pragma once
 
 #include <chrono>
@@ -122,6 +123,13 @@ struct lmgpu_isam2 {
   // ISAM2Params::relinearizeThreshold as FastMap<char, Vector> (non-empty: in force) and enablePartialRelinearizationCheck
   std::map<unsigned char, std::vector<double>> relin_thresholds;
   bool partial_relin_check = false;
+  // ISAM2Params::optimizationParams = ISAM2DoglegParams (ISAM2Params.h:68-110): Powell's dog leg in updateDelta (ISAM2.cpp:739-779)
+  bool dogleg = false;
+  double dogleg_delta = 1.0, dogleg_wildfire = 1e-5;  // doglegDelta_ (the trust-region radius), ISAM2DoglegParams::wildfireThreshold
+  int dogleg_mode = 0;                                // 0 SEARCH_EACH_ITERATION, 1 SEARCH_REDUCE_ONLY, 2 ONE_STEP_PER_ITERATION
+  double *delta_newton = nullptr, *rgprod = nullptr, *grad = nullptr, *dx_u = nullptr;  // laid out like delta
+  double *d_cerr = nullptr, *d_dlscal = nullptr, *h_dlscal = nullptr;  // per-clique tree errors; eight scalars on the device / pinned
+  size_t cerr_cap = 0;
   // ISAM2Params::evaluateNonlinearError (ISAM2Params.h:200-203): ISAM2Result::errorBefore / errorAfter of the last update
   bool evaluate_error = false;
   double error_before = 0, error_after = 0;
@@ -715,6 +723,104 @@ __global__ __launch_bounds__(64) void isam2_marginal_kernel(const int32_t* __res
   }
 }
 
+// ---- the Bayes tree as a Gaussian factor graph of unit-noise factors [R S | d], one per clique (GaussianBayesTree): the three products
+//      Powell's dog leg needs (ISAM2.cpp:739-779), on the device copy of the tree.  One wave per clique, four per workgroup.
+//      Columns j >= i only in the R part (what lies below the diagonal of a wide clique's rows is not part of R).
+__device__ __forceinline__ void isam2_clique_rows(const lmgpu::FrontDesc& F, int id, const int32_t* tree_fx, const int32_t* tree_sx, const double* pool,
+                                                  const int32_t** fxr, const int32_t** sxr) {
+  const bool wide = F.par_ld != 0;
+  *fxr = wide ? (const int32_t*)(pool + F.par_off) : tree_fx + (size_t)id * ISAM2_TREE_ROW;
+  *sxr = wide ? *fxr + F.nf : tree_sx + (size_t)id * ISAM2_TREE_ROW;
+}
+// g -= [R S]^T d  (ISAM2::gradientAtZero, ISAM2.cpp:825-833: the sum of the cliques' gradient contributions, ISAM2Clique.cpp:35-46)
+__global__ __launch_bounds__(256) void isam2_tree_gradient_kernel(const int32_t* __restrict__ list, int nlist, const lmgpu::FrontDesc* __restrict__ tree,
+                                                                  const int32_t* __restrict__ tree_fx, const int32_t* __restrict__ tree_sx,
+                                                                  const double* __restrict__ pool, double* __restrict__ g) {
+  const int li = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (li >= nlist) return;
+  const int id = list[li];
+  const lmgpu::FrontDesc F = tree[id];
+  const int n = F.n, nf = F.nf, ld = F.ld_rsd;
+  const int32_t *fxr, *sxr;
+  isam2_clique_rows(F, id, tree_fx, tree_sx, pool, &fxr, &sxr);
+  const double* A = pool + F.rsd_off;
+  for (int j = lane; j < n - 1; j += 64) {
+    double s = 0.0;
+    const int imax = j < nf ? j : nf - 1;
+    for (int i = 0; i <= imax; i++) s += A[(size_t)i * ld + j] * A[(size_t)i * ld + n - 1];
+    atomicAdd(&g[j < nf ? fxr[j] : sxr[j - nf]], -s);
+  }
+}
+// RgProd_F = R g_F + S g_S  (UpdateRgProd, ISAM2-impl.cpp:82-141; recomputed for every clique: below a clique without a replaced key
+// neither its rows nor the gradient on its keys have changed, so the reference's walk would have left the same numbers)
+__global__ __launch_bounds__(256) void isam2_tree_rg_kernel(const int32_t* __restrict__ list, int nlist, const lmgpu::FrontDesc* __restrict__ tree,
+                                                            const int32_t* __restrict__ tree_fx, const int32_t* __restrict__ tree_sx,
+                                                            const double* __restrict__ pool, const double* __restrict__ g, double* __restrict__ rg) {
+  const int li = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (li >= nlist) return;
+  const int id = list[li];
+  const lmgpu::FrontDesc F = tree[id];
+  const int n = F.n, nf = F.nf, ld = F.ld_rsd;
+  const int32_t *fxr, *sxr;
+  isam2_clique_rows(F, id, tree_fx, tree_sx, pool, &fxr, &sxr);
+  const double* A = pool + F.rsd_off;
+  for (int i = 0; i < nf; i++) {
+    double s = 0.0;
+    for (int j = i + lane; j < n - 1; j += 64) s += A[(size_t)i * ld + j] * g[j < nf ? fxr[j] : sxr[j - nf]];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) rg[fxr[i]] = s;
+  }
+}
+// out[li] = || [R S] x - d ||^2 of clique li (ISAM2::error(x) = GaussianFactorGraph(*this).error(x), ISAM2.cpp:820-823); x == nullptr: x = 0
+__global__ __launch_bounds__(256) void isam2_tree_error_kernel(const int32_t* __restrict__ list, int nlist, const lmgpu::FrontDesc* __restrict__ tree,
+                                                               const int32_t* __restrict__ tree_fx, const int32_t* __restrict__ tree_sx,
+                                                               const double* __restrict__ pool, const double* __restrict__ x, double* __restrict__ out) {
+  const int li = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (li >= nlist) return;
+  const int id = list[li];
+  const lmgpu::FrontDesc F = tree[id];
+  const int n = F.n, nf = F.nf, ld = F.ld_rsd;
+  const int32_t *fxr, *sxr;
+  isam2_clique_rows(F, id, tree_fx, tree_sx, pool, &fxr, &sxr);
+  const double* A = pool + F.rsd_off;
+  double tot = 0.0;
+  for (int i = 0; i < nf; i++) {
+    double s = 0.0;
+    if (x)
+      for (int j = i + lane; j < n - 1; j += 64) s += A[(size_t)i * ld + j] * x[j < nf ? fxr[j] : sxr[j - nf]];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const double e = s - A[(size_t)i * ld + n - 1];
+    tot += e * e;
+  }
+  if (lane == 0) out[li] = tot;
+}
+// out[slot] = sum_i a[i] b[i], one workgroup, fixed order
+__global__ __launch_bounds__(1024) void isam2_dot_kernel(const double* __restrict__ a, const double* __restrict__ b, int n, double* __restrict__ out) {
+  __shared__ double red[1024];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) s += a[i] * b[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = red[0];
+}
+// dx_u = -(g.g / Rg.Rg) g  (ComputeGradientSearch, ISAM2-impl.cpp:144-157); scal[0] = g.g, scal[1] = Rg.Rg
+__global__ __launch_bounds__(256) void isam2_gradient_search_kernel(const double* __restrict__ g, const double* __restrict__ scal, int n, double* __restrict__ dx_u) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dx_u[i] = -(scal[0] / scal[1]) * g[i];
+}
+// dx_d = a dx_u + b dx_n  (ComputeDoglegPoint / ComputeBlend, DoglegOptimizerImpl.cpp:26-91)
+__global__ __launch_bounds__(256) void isam2_blend_kernel(const double* __restrict__ dx_u, const double* __restrict__ dx_n, double a, double b, int n,
+                                                          double* __restrict__ dx_d) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dx_d[i] = a * dx_u[i] + b * dx_n[i];
+}
+
 namespace {
 
 // bring the device copy of the tree up to date: only the cliques the updates since the last call created or re-parented
@@ -806,12 +912,15 @@ int is_patch_tree(lmgpu_isam2* S) {
 // In two halves so that a caller can queue its own reads of delta behind the walk and wait ONCE: is_update_delta_enqueue launches,
 // is_update_delta_finish waits and looks at the status word.
 // host_delta: also bring delta to the pinned host copy (CheckRelinearizationFull reads it; the estimate readers do not need it)
-int is_update_delta_enqueue(lmgpu_isam2* S, bool force_full, bool host_delta) {
+int is_update_delta_dogleg(lmgpu_isam2* S, bool force_full, bool host_delta);
+int is_update_delta_enqueue(lmgpu_isam2* S, bool force_full, bool host_delta, double* target = nullptr) {
+  if (S->dogleg && !target) return is_update_delta_dogleg(S, force_full, host_delta);  // (waits itself; _finish then finds an idle stream)
   int rc = is_patch_tree(S);
   if (rc) return rc;
   *S->h_status = 0x7f7f7f7f;
   if (S->ntot == 0) return LMGPU_OK;
-  const double thr = force_full ? 0.0 : S->prm.wildfireThreshold;
+  const double thr = force_full ? 0.0 : (S->dogleg ? S->dogleg_wildfire : S->prm.wildfireThreshold);
+  double* const wf_delta = target ? target : S->delta;
   ISCHECK(hipMemsetAsync(S->d_changed, 0, (size_t)S->ntot, S->stream));
   ISCHECK(hipMemsetAsync(S->d_status, 0x7f, sizeof(int), S->stream));
   if (!S->roots.empty()) {
@@ -822,12 +931,12 @@ int is_update_delta_enqueue(lmgpu_isam2* S, bool force_full, bool host_delta) {
     if ((rc = is_push(S, S->d_wl, ctl, sizeof(ctl)))) return rc;
     if ((rc = is_flush(S))) return rc;
     hipLaunchKernelGGL(isam2_wildfire_kernel, dim3(ISAM2_WL_GROUPS), dim3(256), (S->tree_lds + LDSB_TAIL) * sizeof(double), S->stream, S->d_queue, S->d_wl,
-                       (const FrontDesc*)S->d_tree, (const int32_t*)S->d_tree_fx, (const int32_t*)S->d_tree_sx, (const double*)S->pool, S->delta,
+                       (const FrontDesc*)S->d_tree, (const int32_t*)S->d_tree_fx, (const int32_t*)S->d_tree_sx, (const double*)S->pool, wf_delta,
                        (const unsigned char*)S->d_replaced, S->d_changed, thr, S->d_status);
   }
   ISCHECK(hipMemsetAsync(S->d_replaced, 0, (size_t)S->ntot, S->stream));
   ISCHECK(hipMemcpyAsync(S->h_status, S->d_status, sizeof(int), hipMemcpyDeviceToHost, S->stream));
-  if (host_delta) {
+  if (host_delta && !target) {
     if ((size_t)S->ntot > S->h_delta_cap) {
       if (S->h_delta) (void)hipHostFree(S->h_delta);
       S->h_delta = nullptr;
@@ -1218,6 +1327,137 @@ int is_graph_error(lmgpu_isam2* S, bool at_estimate, double* out) {
   return LMGPU_OK;
 }
 
+// ISAM2::updateDelta with ISAM2DoglegParams (gtsam/nonlinear/ISAM2.cpp:739-779): the Newton point by the wildfire walk (into deltaNewton_),
+// the steepest-descent point from the tree's gradient (gradientAtZero :825-833, UpdateRgProd / ComputeGradientSearch ISAM2-impl.cpp:82-157),
+// then DoglegOptimizerImpl::Iterate (DoglegOptimizerImpl.h:139-254) with Rd = the tree, f = the nonlinear graph, x0 = theta.  The vectors
+// stay on the device; per trial point the host sees three scalars (the graph error at theta (+) dx_d, the tree's error at dx_d) and
+// decides about the radius like the reference.  delta_ = dx_d, doglegDelta_ = the new radius.
+int is_update_delta_dogleg(lmgpu_isam2* S, bool force_full, bool host_delta) {
+  int rc = is_update_delta_enqueue(S, force_full, false, S->delta_newton);  // patches the tree, walks, clears the replaced flags
+  if (rc) return rc;
+  if ((rc = is_update_delta_finish(S))) return rc;
+  if (S->ntot == 0) return LMGPU_OK;
+  hipStream_t s = S->stream;
+  const int n = S->ntot;
+  auto to_host = [&]() -> int {  // the pinned copy of delta for CheckRelinearizationFull, and the wait that ends the call
+    if (host_delta) {
+      if ((size_t)S->ntot > S->h_delta_cap) {
+        if (S->h_delta) (void)hipHostFree(S->h_delta);
+        S->h_delta = nullptr;
+        S->h_delta_cap = is_next_cap(S->h_delta_cap, (size_t)S->ntot);
+        ISCHECK(hipHostMalloc((void**)&S->h_delta, S->h_delta_cap * sizeof(double), hipHostMallocDefault));
+      }
+      ISCHECK(hipMemcpyAsync(S->h_delta, S->delta, (size_t)S->ntot * sizeof(double), hipMemcpyDeviceToHost, s));
+    }
+    ISCHECK(hipStreamSynchronize(s));
+    return LMGPU_OK;
+  };
+  std::vector<int32_t> alive;
+  for (int id = 0; id < (int)S->clq.size(); id++)
+    if (S->clq[id].alive) alive.push_back(id);
+  const int nc = (int)alive.size();
+  if (nc == 0) return to_host();  // no tree yet (the first update): delta stays zero
+  int32_t* d_alive = nullptr;
+  if ((rc = is_stage(S, alive, &d_alive))) return rc;
+  if ((size_t)nc > S->cerr_cap) {
+    const size_t cap = is_next_cap(S->cerr_cap, (size_t)nc);
+    if ((rc = is_realloc(S, &S->d_cerr, cap, 0))) return rc;
+    S->cerr_cap = cap;
+  }
+  if (!S->d_dlscal) ISCHECK(hipMalloc((void**)&S->d_dlscal, 264 * sizeof(double)));
+  if (!S->h_dlscal) ISCHECK(hipHostMalloc((void**)&S->h_dlscal, 8 * sizeof(double), hipHostMallocDefault));
+  if ((rc = is_flush(S))) return rc;
+  const FrontDesc* T = (const FrontDesc*)S->d_tree;
+  const int32_t *FX = (const int32_t*)S->d_tree_fx, *SX = (const int32_t*)S->d_tree_sx;
+  const dim3 gq((nc + 3) / 4), gv((n + 255) / 256);
+  auto tree_error = [&](const double* x, double* dst) {  // dst = sum over the cliques of ||[R S] x - d||^2
+    hipLaunchKernelGGL(isam2_tree_error_kernel, gq, dim3(256), 0, s, (const int32_t*)d_alive, nc, T, FX, SX, (const double*)S->pool, x, S->d_cerr);
+    const int g = std::min(256, std::max(1, (nc + 255) / 256));
+    hipLaunchKernelGGL(reduce_stage1, dim3(g), dim3(256), 0, s, (const double*)S->d_cerr, nc, S->d_dlscal + 8);
+    hipLaunchKernelGGL(reduce_stage2, dim3(1), dim3(256), 0, s, (const double*)(S->d_dlscal + 8), g, dst);
+  };
+  ISCHECK(hipMemsetAsync(S->grad, 0, (size_t)n * sizeof(double), s));
+  hipLaunchKernelGGL(isam2_tree_gradient_kernel, gq, dim3(256), 0, s, (const int32_t*)d_alive, nc, T, FX, SX, (const double*)S->pool, S->grad);
+  hipLaunchKernelGGL(isam2_tree_rg_kernel, gq, dim3(256), 0, s, (const int32_t*)d_alive, nc, T, FX, SX, (const double*)S->pool, (const double*)S->grad, S->rgprod);
+  double* sc = S->d_dlscal;  // [0] g.g  [1] Rg.Rg  [2] u.u  [3] n.n  [4] u.n  [5] M(0) x 2  [6] M(dx_d) x 2
+  hipLaunchKernelGGL(isam2_dot_kernel, dim3(1), dim3(1024), 0, s, (const double*)S->grad, (const double*)S->grad, n, sc + 0);
+  hipLaunchKernelGGL(isam2_dot_kernel, dim3(1), dim3(1024), 0, s, (const double*)S->rgprod, (const double*)S->rgprod, n, sc + 1);
+  hipLaunchKernelGGL(isam2_gradient_search_kernel, gv, dim3(256), 0, s, (const double*)S->grad, (const double*)sc, n, S->dx_u);
+  hipLaunchKernelGGL(isam2_dot_kernel, dim3(1), dim3(1024), 0, s, (const double*)S->dx_u, (const double*)S->dx_u, n, sc + 2);
+  hipLaunchKernelGGL(isam2_dot_kernel, dim3(1), dim3(1024), 0, s, (const double*)S->delta_newton, (const double*)S->delta_newton, n, sc + 3);
+  hipLaunchKernelGGL(isam2_dot_kernel, dim3(1), dim3(1024), 0, s, (const double*)S->dx_u, (const double*)S->delta_newton, n, sc + 4);
+  tree_error(nullptr, sc + 5);
+  ISCHECK(hipMemcpyAsync(S->h_dlscal, sc, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
+  double f_error = 0.0;
+  if ((rc = is_graph_error(S, false, &f_error))) return rc;  // nonlinearFactors_.error(theta_); waits
+  const double uu = S->h_dlscal[2], nn = S->h_dlscal[3], un = S->h_dlscal[4], M_error = 0.5 * S->h_dlscal[5];
+  double delta = S->dogleg_delta;
+  enum { NONE, INCREASED_DELTA, DECREASED_DELTA } lastAction = NONE;
+  const int mode = S->dogleg_mode;
+  bool stay = true, zero_step = false;
+  while (stay) {
+    // ComputeDoglegPoint (DoglegOptimizerImpl.cpp:26-64): dx_d = a dx_u + b dx_n
+    double a = 0.0, b = 1.0;
+    const double deltaSq = delta * delta;
+    if (deltaSq < uu) {
+      a = std::sqrt(deltaSq / uu);
+      b = 0.0;
+    } else if (deltaSq < nn) {  // ComputeBlend :67-91
+      const double qa = uu - 2. * un + nn, qb = 2. * (un - uu), qc = uu - deltaSq;
+      const double sq = std::sqrt(qb * qb - 4 * qa * qc);
+      const double tau1 = (-qb + sq) / (2. * qa), tau2 = (-qb - sq) / (2. * qa);
+      const double eps = std::numeric_limits<double>::epsilon();
+      const double tau = (-eps <= tau1 && tau1 <= 1.0 + eps) ? tau1 : tau2;
+      a = 1. - tau;
+      b = tau;
+    }
+    hipLaunchKernelGGL(isam2_blend_kernel, gv, dim3(256), 0, s, (const double*)S->dx_u, (const double*)S->delta_newton, a, b, n, S->delta);
+    tree_error((const double*)S->delta, sc + 6);
+    ISCHECK(hipMemcpyAsync(S->h_dlscal + 6, sc + 6, sizeof(double), hipMemcpyDeviceToHost, s));
+    double new_f = 0.0;
+    if ((rc = is_graph_error(S, true, &new_f))) return rc;  // f.error(x0.retract(dx_d)); waits
+    const double new_M = 0.5 * S->h_dlscal[6];
+    const double rho = (std::fabs(f_error - new_f) < 1e-15 || std::fabs(M_error - new_M) < 1e-15) ? 0.5 : (f_error - new_f) / (M_error - new_M);
+    if (rho >= 0.75) {
+      const double dnorm = std::sqrt(std::max(0.0, a * a * uu + 2. * a * b * un + b * b * nn));
+      const double newDelta = std::max(delta, 3.0 * dnorm);
+      if (mode == 2 || mode == 1) {
+        stay = false;
+      } else if (std::fabs(newDelta - delta) < 1e-15 || lastAction == DECREASED_DELTA) {
+        stay = false;
+      } else {
+        stay = true;
+        lastAction = INCREASED_DELTA;
+      }
+      delta = newDelta;
+    } else if (rho >= 0.25) {
+      stay = false;
+    } else if (rho >= 0.0) {
+      const bool hitMinimumDelta = !(delta > 1e-5);
+      const double newDelta = hitMinimumDelta ? delta : 0.5 * delta;
+      if (mode == 2 || lastAction == INCREASED_DELTA || hitMinimumDelta) {
+        stay = false;
+      } else {
+        stay = true;
+        lastAction = DECREASED_DELTA;
+      }
+      delta = newDelta;
+    } else {
+      if (delta > 1e-5) {
+        delta *= 0.5;
+        stay = true;
+        lastAction = DECREASED_DELTA;
+      } else {
+        zero_step = true;  // "don't allow error to increase"
+        stay = false;
+      }
+    }
+  }
+  if (zero_step) ISCHECK(hipMemsetAsync(S->delta, 0, (size_t)n * sizeof(double), s));
+  S->dogleg_delta = delta;
+  return to_host();
+}
+
 // ISAM2::update (gtsam/nonlinear/ISAM2.cpp:419-480)
 int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_result* result) {
   const bool force_relinearize = up.force_relinearize;
@@ -1276,6 +1516,11 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
     if (S->ntot + addtot > S->ntot_cap) {
       const size_t ncap = is_next_cap((size_t)S->ntot_cap, (size_t)(S->ntot + addtot));
       if ((rc = is_realloc(S, &S->delta, ncap, (size_t)S->ntot))) return rc;
+      if (S->dogleg) {
+        if ((rc = is_realloc(S, &S->delta_newton, ncap, (size_t)S->ntot)) || (rc = is_realloc(S, &S->rgprod, ncap, (size_t)S->ntot)) ||
+            (rc = is_realloc(S, &S->grad, ncap, 0)) || (rc = is_realloc(S, &S->dx_u, ncap, 0)))
+          return rc;
+      }
       if ((rc = is_realloc(S, &S->ones, ncap, 0))) return rc;
       if ((rc = is_realloc(S, &S->d_replaced, ncap, (size_t)S->ntot))) return rc;
       if ((rc = is_realloc(S, &S->d_changed, ncap, 0))) return rc;
@@ -1308,6 +1553,10 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
       if ((rc = is_push(S, S->d_type_xoff[t] + first_tidx[t], xoffs[t].data(), xoffs[t].size() * sizeof(int32_t)))) return rc;
     }
     ISCHECK(hipMemsetAsync(S->delta + ntot0, 0, (size_t)(S->ntot - ntot0) * sizeof(double), S->stream));  // delta_.insert(zeroVectors)
+    if (S->dogleg) {  // deltaNewton_ / RgProd_.insert(zeroVectors) (ISAM2.cpp:373-374)
+      ISCHECK(hipMemsetAsync(S->delta_newton + ntot0, 0, (size_t)(S->ntot - ntot0) * sizeof(double), S->stream));
+      ISCHECK(hipMemsetAsync(S->rgprod + ntot0, 0, (size_t)(S->ntot - ntot0) * sizeof(double), S->stream));
+    }
   }
   const bool relinNeeded = force_relinearize || (S->prm.enableRelinearization && S->prm.relinearizeSkip > 0 && S->update_count % S->prm.relinearizeSkip == 0);
   if (relinNeeded && (rc = is_update_delta(S, up.force_full_solve, true))) return rc;
@@ -1651,6 +1900,12 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
   for (uint64_t k : unusedKeys) {
     const int32_t v = S->vid_of.at(k);
     S->vars[v].dead = true;
+    if (S->dogleg) {  // the vectors of the dog leg are summed over all scalars: a retired variable must not count
+      const size_t o = (size_t)S->vars[v].xoff, nb = (size_t)kVarDim[S->vars[v].type] * sizeof(double);
+      ISCHECK(hipMemsetAsync(S->delta + o, 0, nb, S->stream));
+      ISCHECK(hipMemsetAsync(S->delta_newton + o, 0, nb, S->stream));
+      ISCHECK(hipMemsetAsync(S->rgprod + o, 0, nb, S->stream));
+    }
     S->replaced[v] = 0;
     S->node_of[v] = -1;
     S->vid_of.erase(k);
@@ -1720,11 +1975,12 @@ int lmgpu_isam2_destroy(lmgpu_isam2* S) {
     }
     for (void* p : {(void*)S->delta, (void*)S->ones, (void*)S->d_replaced, (void*)S->d_changed, (void*)S->pool, (void*)S->d_status, (void*)S->d_tree,
                     (void*)S->d_tree_fx, (void*)S->d_tree_sx, (void*)S->d_queue, (void*)S->d_wl, (void*)S->inv16, (void*)S->d_marg, (void*)S->d_ebuf,
-                    (void*)S->d_epart})
+                    (void*)S->d_epart, (void*)S->delta_newton, (void*)S->rgprod, (void*)S->grad, (void*)S->dx_u, (void*)S->d_cerr, (void*)S->d_dlscal})
       if (p) (void)hipFree(p);
     if (S->h_status) (void)hipHostFree(S->h_status);
     if (S->h_delta) (void)hipHostFree(S->h_delta);
     if (S->h_escal) (void)hipHostFree(S->h_escal);
+    if (S->h_dlscal) (void)hipHostFree(S->h_dlscal);
     if (S->h_stage) (void)hipHostFree(S->h_stage);
     if (S->d_stage) (void)hipFree(S->d_stage);
     for (auto& e : S->stage_extra) {
@@ -1828,6 +2084,19 @@ int lmgpu_isam2_set_relinearize_thresholds(lmgpu_isam2* S, int32_t n, const char
   }
   return LMGPU_OK;
 }
+int lmgpu_isam2_set_dogleg(lmgpu_isam2* S, double initialDelta, double wildfireThreshold, int32_t adaptationMode) {
+  if (!S) return LMGPU_INVALID;
+  if (S->ntot > 0 || !S->new_vars.empty() || adaptationMode < 0 || adaptationMode > 2 || !(initialDelta > 0.0)) {
+    S->err = "lmgpu_isam2_set_dogleg: before the first variable, with a positive radius and an adaptation mode 0..2";
+    return LMGPU_INVALID;
+  }
+  S->dogleg = true;
+  S->dogleg_delta = initialDelta;
+  S->dogleg_wildfire = wildfireThreshold;
+  S->dogleg_mode = adaptationMode;
+  return LMGPU_OK;
+}
+double lmgpu_isam2_get_dogleg_delta(const lmgpu_isam2* S) { return S ? S->dogleg_delta : 0.0; }
 int lmgpu_isam2_set_evaluate_nonlinear_error(lmgpu_isam2* S, int32_t enable) {
   if (!S) return LMGPU_INVALID;
   S->evaluate_error = enable != 0;

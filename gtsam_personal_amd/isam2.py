@@ -20,6 +20,17 @@ class ISAM2GaussNewtonParams:
         self.wildfireThreshold = wildfireThreshold
 
 
+class ISAM2DoglegParams:
+    """ISAM2DoglegParams(initialDelta, wildfireThreshold, adaptationMode) (ISAM2Params.h:68-110); adaptationMode as
+    DoglegOptimizerImpl::TrustRegionAdaptationMode: 0 SEARCH_EACH_ITERATION, 1 SEARCH_REDUCE_ONLY, 2 ONE_STEP_PER_ITERATION"""
+    SEARCH_EACH_ITERATION, SEARCH_REDUCE_ONLY, ONE_STEP_PER_ITERATION = 0, 1, 2
+
+    def __init__(self, initialDelta=1.0, wildfireThreshold=1e-5, adaptationMode=0):
+        self.initialDelta = initialDelta
+        self.wildfireThreshold = wildfireThreshold
+        self.adaptationMode = adaptationMode
+
+
 class ISAM2Params:
     """ISAM2Params(optimizationParams, relinearizeThreshold, relinearizeSkip, enableRelinearization) — ISAM2Params.h:211-246.
     relinearizeThreshold: a double, or the FastMap<char, Vector> form as {symbol character: per-dof thresholds} (:139-141);
@@ -89,6 +100,9 @@ class ISAM2:
             self._check(self.lib.lmgpu_isam2_set_partial_relinearization_check(self._h, 1))
         if getattr(p, "evaluateNonlinearError", False):
             self._check(self.lib.lmgpu_isam2_set_evaluate_nonlinear_error(self._h, 1))
+        if isinstance(p.optimizationParams, ISAM2DoglegParams):
+            o = p.optimizationParams
+            self._check(self.lib.lmgpu_isam2_set_dogleg(self._h, float(o.initialDelta), float(o.wildfireThreshold), int(o.adaptationMode)))
         self._u0v0 = {}  # constant principal points of Cal3Bundler cameras (do not travel, see lmgpu.h CAM_BUNDLER)
 
     def _check(self, rc):
@@ -179,6 +193,10 @@ class ISAM2:
         cov = np.zeros((d, d))
         self._check(self.lib.lmgpu_isam2_marginal_covariance(self._h, int(key), cov.ctypes.data_as(_lib._D)))
         return cov
+
+    def doglegDelta(self):
+        """the current trust-region radius (ISAM2::doglegDelta_) with ISAM2DoglegParams"""
+        return float(self.lib.lmgpu_isam2_get_dogleg_delta(self._h))
 
     def unusedKeys(self):
         """ISAM2Result::unusedKeys of the last update: the variables that left the system with their last factor"""

@@ -277,7 +277,8 @@ int lmgpu_selftest_chain_schedule(int n, int nf, int i0, int nsteps, int far_pct
  * ISAM2UpdateParams (gtsam/nonlinear/ISAM2UpdateParams.h:30-90) through lmgpu_isam2_update_with: removeFactorIndices, constrainedKeys,
  * noRelinKeys, extraReelimKeys, force_relinearize, forceFullSolve.
  * relinearizeThreshold as FastMap<char, Vector> and enablePartialRelinearizationCheck: the two setters below.
- * Not bound: Dogleg, QR, marginalizeLeaves, newAffectedKeys (smart factors), findUnusedFactorSlots (not offered).
+ * ISAM2DoglegParams: lmgpu_isam2_set_dogleg.
+ * Not bound: QR, marginalizeLeaves, newAffectedKeys (smart factors), findUnusedFactorSlots (not offered).
  *
  * The fill-reducing ordering is a boundary input like in the batch path, but here it is needed per update: the caller hands over
  * ITS ccolamd (the reference side: the one Ordering::ColamdConstrained calls, gtsam/inference/Ordering.cpp:50-125) as a callback:
@@ -305,6 +306,12 @@ uint64_t lmgpu_isam2_last_failed_key(const lmgpu_isam2* s); /* LMGPU_INDETERMINA
  * when any |delta_i| > threshold_i (strictly; ISAM2-impl.h:266, 375) of its character's vector; an update that meets a variable
  * without a vector of its dimension returns LMGPU_INVALID (the reference throws, :258-262).  n = 0: the scalar threshold again. */
 int lmgpu_isam2_set_relinearize_thresholds(lmgpu_isam2* s, int32_t n, const char* chrs, const int32_t* dims, const double* values);
+/* ISAM2Params::optimizationParams = ISAM2DoglegParams(initialDelta, wildfireThreshold, adaptationMode) (ISAM2Params.h:68-110) instead of
+ * ISAM2GaussNewtonParams: updateDelta becomes one iteration of Powell's dog leg (ISAM2.cpp:739-779; adaptationMode as
+ * DoglegOptimizerImpl::TrustRegionAdaptationMode: 0 SEARCH_EACH_ITERATION (the default), 1 SEARCH_REDUCE_ONLY, 2 ONE_STEP_PER_ITERATION).
+ * To be called before the first variable is added.  lmgpu_isam2_get_dogleg_delta: the current trust-region radius (doglegDelta_). */
+int lmgpu_isam2_set_dogleg(lmgpu_isam2* s, double initialDelta, double wildfireThreshold, int32_t adaptationMode);
+double lmgpu_isam2_get_dogleg_delta(const lmgpu_isam2* s);
 /* ISAM2Params::evaluateNonlinearError (ISAM2Params.h:200-203): every update also evaluates the nonlinear error of the whole graph at
  * calculateEstimate() after the new factors have been added (ISAM2Result::errorBefore, ISAM2.cpp:444-446) and at its end (errorAfter,
  * :481-483) -- each through calculateEstimate(), i.e. with the back-substitution brought up to date first, like the reference.

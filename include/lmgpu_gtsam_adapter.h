@@ -414,7 +414,7 @@ class GpuDoglegOptimizer : public NonlinearOptimizer {
 };
 
 /// ISAM2 on the device (lmgpu_isam2_*): the same update() / calculateEstimate() calls as gtsam::ISAM2 (gtsam/nonlinear/ISAM2.h:146-260)
-/// for the parameter subset the C ABI binds (Gauss-Newton optimisation params, relinearization threshold as a double or per Symbol
+/// for the parameter subset the C ABI binds (Gauss-Newton or Dogleg optimisation params, relinearization threshold as a double or per Symbol
 /// character, partial relinearization check, Cholesky).  Not a
 /// subclass: ISAM2 is a BayesTree<ISAM2Clique> whose cliques live on the host; here the tree lives on the device and only the
 /// estimate comes back.  The constrained COLAMD of recalculate() stays on this side: the callback below is the body of
@@ -422,18 +422,19 @@ class GpuDoglegOptimizer : public NonlinearOptimizer {
 class GpuISAM2 {
  public:
   explicit GpuISAM2(const ISAM2Params& params = ISAM2Params(), int device = 0) {
-    if (!std::holds_alternative<ISAM2GaussNewtonParams>(params.optimizationParams) || params.factorization != ISAM2Params::CHOLESKY ||
-        params.findUnusedFactorSlots || !params.cacheLinearizedFactors)
-      throw std::invalid_argument("GpuISAM2: parameter set not bound (Gauss-Newton optimisation, Cholesky, cached linear factors only)");
+    if (params.factorization != ISAM2Params::CHOLESKY || params.findUnusedFactorSlots || !params.cacheLinearizedFactors)
+      throw std::invalid_argument("GpuISAM2: parameter set not bound (Cholesky, cached linear factors, no reuse of factor slots)");
     const bool byChar = std::holds_alternative<FastMap<char, Vector>>(params.relinearizeThreshold);
+    const ISAM2DoglegParams* dl = std::get_if<ISAM2DoglegParams>(&params.optimizationParams);
     lmgpu_isam2_params p{byChar ? 0.1 : std::get<double>(params.relinearizeThreshold), params.relinearizeSkip, params.enableRelinearization ? 1 : 0,
-                         std::get<ISAM2GaussNewtonParams>(params.optimizationParams).wildfireThreshold};
+                         dl ? dl->wildfireThreshold : std::get<ISAM2GaussNewtonParams>(params.optimizationParams).wildfireThreshold};
     lmgpu_config cfg{device, 0, 1, 0};
     if (lmgpu_isam2_create(&cfg, &p, &GpuISAM2::Ccolamd, nullptr, &h_) != LMGPU_OK) {
       const std::string why = h_ ? lmgpu_isam2_last_error(h_) : "lmgpu_isam2_create failed";
       if (h_) lmgpu_isam2_destroy(h_);
       throw std::runtime_error(why);
     }
+    if (dl) check(lmgpu_isam2_set_dogleg(h_, dl->initialDelta, dl->wildfireThreshold, (int32_t)dl->adaptationMode));  // ISAM2Params.h:68-110
     if (byChar) {  // ISAM2Params::relinearizeThreshold as FastMap<char, Vector> (ISAM2Params.h:139-141)
       std::string chrs;
       std::vector<int32_t> dims;

@@ -15,7 +15,8 @@
 //                                       computeUnusedKeys :175-190, ISAM2::removeVariables ISAM2.cpp:385-398), constrainedKeys,
 //                                       noRelinKeys, extraReelimKeys, force_relinearize, forceFullSolve
 //   ISAM2Params: relinearizeThreshold as double or FastMap<char, Vector>, enablePartialRelinearizationCheck (ISAM2-impl.h:246-378)
-// Not restated (not reached by the configs): Dogleg optimisation, QR, marginalizeLeaves, newAffectedKeys (smart factors),
+//   ISAM2DoglegParams: ISAM2::updateDelta's Dogleg branch (ISAM2.cpp:739-779), DoglegOptimizerImpl::Iterate (DoglegOptimizerImpl.h:139-254)
+// Not restated (not reached by the configs): QR, marginalizeLeaves, newAffectedKeys (smart factors),
 // findUnusedFactorSlots.
 #pragma once
 
@@ -55,6 +56,12 @@ struct ISAM2 {
   std::map<unsigned char, std::vector<double>> relinearizeThresholds;  // the FastMap<char, Vector> alternative (non-empty: in force)
   int relinearizeSkip = 10;
   bool enableRelinearization = true, enablePartialRelinearizationCheck = false;
+  // ISAM2DoglegParams (ISAM2Params.h:68-110) instead of ISAM2GaussNewtonParams: initialDelta -> doglegDelta (ISAM2.cpp:41-46),
+  // wildfireThreshold, adaptationMode (DoglegOptimizerImpl.h:54-58: 0 SEARCH_EACH_ITERATION, 1 SEARCH_REDUCE_ONLY, 2 ONE_STEP_PER_ITERATION)
+  bool dogleg = false;
+  double doglegDelta = 1.0, doglegWildfireThreshold = 1e-5;
+  int doglegAdaptationMode = 0;
+  VectorValues deltaNewton, RgProd;
   bool evaluateNonlinearError = false;  // ISAM2Params.h:200-203: ISAM2Result::errorBefore / errorAfter
   double errorBefore = 0, errorAfter = 0;
   ccolamd_fn ccolamd = nullptr;
@@ -173,8 +180,7 @@ static std::vector<double> isam2_solve_clique(const IClique& c, const VectorValu
 
 // DeltaImpl::UpdateGaussNewtonDelta gtsam/nonlinear/ISAM2-impl.cpp:47-77 with optimizeWildfireNonRecursive
 // (ISAM2Clique.cpp:236-268; optimizeWildfireNode :211-234, isDirty :56-77, valuesChanged :151-158)
-static void isam2_update_delta(ISAM2& S, bool forceFullSolve) {
-  const double threshold = forceFullSolve ? 0.0 : S.wildfireThreshold;
+static void isam2_wildfire(ISAM2& S, double threshold, VectorValues& delta) {
   std::vector<ICliquePtr> stack;
   for (auto& root : S.roots) {
     std::set<Key> changed;  // one per root (optimizeWildfireNonRecursive's local)
@@ -194,19 +200,19 @@ static void isam2_update_delta(ISAM2& S, bool forceFullSolve) {
             }
       }
       if (!dirty) continue;
-      const std::vector<double> sol = isam2_solve_clique(*c, S.delta);
+      const std::vector<double> sol = isam2_solve_clique(*c, delta);
       bool valuesChanged = true;
       if (threshold > 0.0 && !S.deltaReplacedMask.count(c->keys.front())) {
         double maxdiff = 0;
         int o = 0;
         for (int k = 0; k < c->nFrontal; k++)
-          for (int d = 0; d < c->dims[k]; d++, o++) maxdiff = std::max(maxdiff, std::abs(S.delta.at(c->keys[k])[d] - sol[o]));
+          for (int d = 0; d < c->dims[k]; d++, o++) maxdiff = std::max(maxdiff, std::abs(delta.at(c->keys[k])[d] - sol[o]));
         valuesChanged = maxdiff >= threshold;
       }
       if (valuesChanged) {  // otherwise restoreFromOriginals: the old values stay
         int o = 0;
         for (int k = 0; k < c->nFrontal; k++) {
-          auto& v = S.delta[c->keys[k]];
+          auto& v = delta[c->keys[k]];
           v.assign(sol.begin() + o, sol.begin() + o + c->dims[k]);
           o += c->dims[k];
           changed.insert(c->keys[k]);
@@ -215,7 +221,146 @@ static void isam2_update_delta(ISAM2& S, bool forceFullSolve) {
       for (auto& child : c->children) stack.push_back(child);
     }
   }
+}
+
+static double isam2_graph_error(const ISAM2& S, const Values& values);
+static void isam2_for_each_clique(const ICliquePtr& c, const std::function<void(const IClique&)>& fn) {
+  fn(*c);
+  for (auto& ch : c->children) isam2_for_each_clique(ch, fn);
+}
+// ISAM2::error(x) = GaussianFactorGraph(*this).error(x) (ISAM2.cpp:820-823): 1/2 sum over the cliques of ||[R S] x - d||^2
+static double isam2_tree_error(const ISAM2& S, const VectorValues& x) {
+  double tot = 0;
+  for (auto& root : S.roots)
+    isam2_for_each_clique(root, [&](const IClique& c) {
+      const int nf = c.RSd.r, n = c.RSd.c;
+      for (int i = 0; i < nf; i++) {
+        double e = -c.RSd(i, n - 1);
+        int col = 0;
+        for (size_t k = 0; k < c.keys.size(); k++) {
+          const auto& xk = x.at(c.keys[k]);
+          for (int d = 0; d < c.dims[k]; d++, col++) e += c.RSd(i, col) * xk[d];
+        }
+        tot += e * e;
+      }
+    });
+  return 0.5 * tot;
+}
+// UpdateRgProd (ISAM2-impl.cpp:82-141): below a clique none of whose keys was replaced nothing has changed, so the walk stops there
+static void isam2_update_rgprod(const ISAM2& S, const ICliquePtr& c, const VectorValues& grad, VectorValues* RgProd) {
+  bool anyReplaced = false;
+  for (Key j : c->keys)
+    if (S.deltaReplacedMask.count(j)) {
+      anyReplaced = true;
+      break;
+    }
+  if (!anyReplaced) return;
+  const int nf = c->RSd.r;
+  std::vector<double> prod(nf, 0.0);
+  int col = 0;
+  for (size_t k = 0; k < c->keys.size(); k++) {
+    const auto& gk = grad.at(c->keys[k]);
+    for (int d = 0; d < c->dims[k]; d++, col++)
+      for (int i = 0; i < nf; i++) prod[i] += c->RSd(i, col) * gk[d];
+  }
+  int o = 0;
+  for (int k = 0; k < c->nFrontal; k++) {
+    (*RgProd)[c->keys[k]].assign(prod.begin() + o, prod.begin() + o + c->dims[k]);
+    o += c->dims[k];
+  }
+  for (auto& child : c->children) isam2_update_rgprod(S, child, grad, RgProd);
+}
+static double vv_norm2(const VectorValues& a) {
+  double s = 0;
+  for (auto& kv : a)
+    for (double x : kv.second) s += x * x;
+  return s;
+}
+
+// ISAM2::updateDelta gtsam/nonlinear/ISAM2.cpp:722-784
+static void isam2_update_delta(ISAM2& S, bool forceFullSolve) {
+  if (!S.dogleg) {
+    isam2_wildfire(S, forceFullSolve ? 0.0 : S.wildfireThreshold, S.delta);
+    S.deltaReplacedMask.clear();
+    return;
+  }
+  // Powell's dog leg: Newton point by wildfire, steepest-descent point from the tree's gradient, one trust-region iteration
+  isam2_wildfire(S, forceFullSolve ? 0.0 : S.doglegWildfireThreshold, S.deltaNewton);
+  VectorValues grad;  // ISAM2::gradientAtZero :825-833: sum of the cliques' -[R S]^T d (ISAM2Clique.cpp:35-46, 328-343)
+  for (auto& root : S.roots)
+    isam2_for_each_clique(root, [&](const IClique& c) {
+      const int nf = c.RSd.r, n = c.RSd.c;
+      int col = 0;
+      for (size_t k = 0; k < c.keys.size(); k++) {
+        auto& gk = grad[c.keys[k]];
+        gk.resize(c.dims[k], 0.0);
+        for (int d = 0; d < c.dims[k]; d++, col++)
+          for (int i = 0; i < nf; i++) gk[d] -= c.RSd(i, col) * c.RSd(i, n - 1);
+      }
+    });
+  for (auto& root : S.roots) isam2_update_rgprod(S, root, grad, &S.RgProd);
+  const double step = -vv_norm2(grad) / vv_norm2(S.RgProd);  // ComputeGradientSearch ISAM2-impl.cpp:144-157
+  VectorValues dx_u = grad;
+  for (auto& kv : dx_u)
+    for (auto& x : kv.second) x *= step;
   S.deltaReplacedMask.clear();
+  // DoglegOptimizerImpl::Iterate (DoglegOptimizerImpl.h:139-254) with Rd = this tree, f = the nonlinear graph, x0 = theta
+  VectorValues dx_n;  // (over the variables of the tree, like dx_u: VectorValues arithmetic needs equal structure)
+  for (auto& kv : dx_u) dx_n[kv.first] = S.deltaNewton.at(kv.first);
+  const double f_error = isam2_graph_error(S, S.theta);
+  VectorValues zero = dx_u;
+  for (auto& kv : zero)
+    for (auto& x : kv.second) x = 0.0;
+  const double M_error = isam2_tree_error(S, zero);
+  double delta = S.doglegDelta;
+  const int mode = S.doglegAdaptationMode;
+  enum { NONE, INCREASED_DELTA, DECREASED_DELTA } lastAction = NONE;
+  VectorValues dx_d;
+  bool stay = true;
+  while (stay) {
+    dx_d = dogleg_point(delta, dx_u, dx_n);
+    Values x_d = S.theta;
+    for (auto& kv : dx_d) x_d[kv.first] = retract(S.theta.at(kv.first), kv.second.data());
+    const double new_f = isam2_graph_error(S, x_d);
+    const double new_M = isam2_tree_error(S, dx_d);
+    const double rho = (std::abs(f_error - new_f) < 1e-15 || std::abs(M_error - new_M) < 1e-15) ? 0.5 : (f_error - new_f) / (M_error - new_M);
+    if (rho >= 0.75) {
+      const double newDelta = std::max(delta, 3.0 * std::sqrt(vv_norm2(dx_d)));
+      if (mode == 2 || mode == 1) {
+        stay = false;
+      } else if (std::abs(newDelta - delta) < 1e-15 || lastAction == DECREASED_DELTA) {
+        stay = false;
+      } else {
+        stay = true;
+        lastAction = INCREASED_DELTA;
+      }
+      delta = newDelta;
+    } else if (rho >= 0.25) {
+      stay = false;
+    } else if (rho >= 0.0) {
+      const bool hitMinimumDelta = !(delta > 1e-5);
+      const double newDelta = hitMinimumDelta ? delta : 0.5 * delta;
+      if (mode == 2 || lastAction == INCREASED_DELTA || hitMinimumDelta) {
+        stay = false;
+      } else {
+        stay = true;
+        lastAction = DECREASED_DELTA;
+      }
+      delta = newDelta;
+    } else {  // the error went up (or rho is NaN, which the reference's assert only sees in debug builds)
+      if (delta > 1e-5) {
+        delta *= 0.5;
+        stay = true;
+        lastAction = DECREASED_DELTA;
+      } else {
+        for (auto& kv : dx_d)
+          for (auto& x : kv.second) x = 0.0;
+        stay = false;
+      }
+    }
+  }
+  S.doglegDelta = delta;
+  for (auto& kv : dx_d) S.delta[kv.first] = kv.second;  // delta_ = doglegResult.dx_d
 }
 
 // the elimination of a junction tree into ISAM2 cliques: EliminatableClusterTree::eliminate with ISAM2Clique::setEliminationResult
@@ -318,6 +463,8 @@ static ISAM2Result isam2_update(ISAM2& S, const ISAM2UpdateParams& up) {
     if (S.theta.count(kv.first)) throw std::invalid_argument("ISAM2: variable already exists");
     S.theta[kv.first] = kv.second;
     S.delta[kv.first] = std::vector<double>(kVarDim[kv.second.type], 0.0);
+    S.deltaNewton[kv.first] = S.delta[kv.first];
+    S.RgProd[kv.first] = S.delta[kv.first];
   }
   const bool relinNeeded = up.force_relinearize || (S.enableRelinearization && S.relinearizeSkip > 0 && S.update_count % S.relinearizeSkip == 0);
   if (relinNeeded) isam2_update_delta(S, up.forceFullSolve);
@@ -487,6 +634,8 @@ static ISAM2Result isam2_update(ISAM2& S, const ISAM2UpdateParams& up) {
   for (Key key : unusedKeys) {
     S.variableIndex.erase(key);
     S.delta.erase(key);
+    S.deltaNewton.erase(key);
+    S.RgProd.erase(key);
     S.deltaReplacedMask.erase(key);
     S.nodes.erase(key);
     S.theta.erase(key);

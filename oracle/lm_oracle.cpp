@@ -18,6 +18,7 @@
 #include <atomic>
 #include <cassert>
 #include <cmath>
+#include <functional>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -1883,6 +1884,15 @@ double orc_isam2_error(void* h, int which) {
   auto& S = ((ISAM2Handle*)h)->S;
   return isam2_graph_error(S, which == 2 ? S.theta : isam2_calculate_estimate(S, false));
 }
+// ISAM2Params::optimizationParams = ISAM2DoglegParams(initialDelta, wildfireThreshold, adaptationMode) (before the first update)
+void orc_isam2_set_dogleg(void* h, double initialDelta, double wildfireThreshold, int adaptationMode) {
+  auto& S = ((ISAM2Handle*)h)->S;
+  S.dogleg = true;
+  S.doglegDelta = initialDelta;
+  S.doglegWildfireThreshold = wildfireThreshold;
+  S.doglegAdaptationMode = adaptationMode;
+}
+double orc_isam2_dogleg_delta(void* h) { return ((ISAM2Handle*)h)->S.doglegDelta; }
 void orc_isam2_set_partial_check(void* h, int enable) { ((ISAM2Handle*)h)->S.enablePartialRelinearizationCheck = enable != 0; }
 
 int orc_isam2_add_variable(void* h, uint64_t key, int type, const double* value) {

@@ -434,6 +434,9 @@ class OracleISAM2:
         L.orc_isam2_update.argtypes = [ct.c_void_p, ct.c_int, _I]
         L.orc_isam2_set_thresholds.argtypes = [ct.c_void_p, ct.c_int, ct.c_char_p, _I, _D]
         L.orc_isam2_set_partial_check.argtypes = [ct.c_void_p, ct.c_int]
+        L.orc_isam2_set_dogleg.argtypes = [ct.c_void_p, ct.c_double, ct.c_double, ct.c_int]
+        L.orc_isam2_dogleg_delta.argtypes = [ct.c_void_p]
+        L.orc_isam2_dogleg_delta.restype = ct.c_double
         L.orc_isam2_set_evaluate_error.argtypes = [ct.c_void_p, ct.c_int]
         L.orc_isam2_errors.argtypes = [ct.c_void_p, _D, _D]
         L.orc_isam2_error.argtypes = [ct.c_void_p, ct.c_int]
@@ -467,6 +470,15 @@ class OracleISAM2:
 
     def set_partial_relinearization_check(self, enable):
         self.L.orc_isam2_set_partial_check(self.h, int(bool(enable)))
+
+    def set_dogleg(self, initialDelta=1.0, wildfireThreshold=1e-5, adaptationMode=0):
+        """ISAM2Params::optimizationParams = ISAM2DoglegParams(...) (ISAM2Params.h:68-110); adaptationMode: 0 SEARCH_EACH_ITERATION,
+        1 SEARCH_REDUCE_ONLY, 2 ONE_STEP_PER_ITERATION (DoglegOptimizerImpl.h:54-58).  Before the first update."""
+        self.L.orc_isam2_set_dogleg(self.h, float(initialDelta), float(wildfireThreshold), int(adaptationMode))
+
+    def doglegDelta(self):
+        """the current trust-region radius (ISAM2::doglegDelta_)"""
+        return float(self.L.orc_isam2_dogleg_delta(self.h))
 
     def set_evaluate_nonlinear_error(self, enable):
         self.L.orc_isam2_set_evaluate_error(self.h, int(bool(enable)))

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import oracle_harness as oh
-from gtsam_personal_amd import ISAM2, ISAM2GaussNewtonParams, ISAM2Params
+from gtsam_personal_amd import ISAM2, ISAM2DoglegParams, ISAM2GaussNewtonParams, ISAM2Params
 from gtsam_personal_amd.graph import symbol
 from isam2_examples import constrained_ordering_steps, create_points, slamlike_steps, stale_landmark_steps, visual_steps
 
@@ -530,4 +530,24 @@ def test_evaluate_nonlinear_error():
         for which in (0, 2):
             assert abs(isam.error(which) - orc.error(which)) <= 1e-6 * abs(orc.error(which)) + 1e-12
         compare_state(isam, orc)
+        isam.close()
+
+
+@pytest.mark.parametrize("mode,radius", [(0, 1.0), (2, 0.05), (1, 0.5)])
+def test_dogleg(mode, radius):
+    """ISAM2DoglegParams on the device (Powell's dog leg in updateDelta, ISAM2.cpp:739-779) against the oracle, whose restatement
+    tests/test_isam2_oracle.py pins to TEST(ISAM2, slamlike_solution_dogleg): update by update the same tree, delta (= the dog-leg step),
+    estimate and trust-region radius -- the slamlike sequence without and the visual example with relinearization; the three adaptation
+    modes, a radius that cuts the first steps included"""
+    for steps, kw in ((slamlike_steps(), dict(relinearizeThreshold=0.0, relinearizeSkip=0, enableRelinearization=False)),
+                      (visual_steps(), dict(relinearizeThreshold=0.01, relinearizeSkip=1))):
+        p = ISAM2Params(ISAM2DoglegParams(radius, 1e-5, mode), **kw)
+        isam = ISAM2(p, ccolamd=ccolamd, device=0)
+        orc = oh.OracleISAM2(p.relinearizeThreshold, p.relinearizeSkip, p.enableRelinearization, 1e-5)
+        orc.set_dogleg(radius, 1e-5, mode)
+        for g, v in steps:
+            rg, ro = isam.update(g, v).as_dict(), orc.update(g, v)
+            assert rg == ro, (rg, ro)
+            compare_state(isam, orc)  # (calculateEstimate -> updateDelta -> one dog-leg iteration on both sides)
+            assert abs(isam.doglegDelta() - orc.doglegDelta()) <= 1e-6 * orc.doglegDelta()
         isam.close()

@@ -255,3 +255,39 @@ def test_evaluate_nonlinear_error():
     assert abs(isam.errors()[1] - batch.error()) <= 1e-12 * max(1.0, batch.error())
     lin = oh.OracleProblem(fullgraph, isam.getLinearizationPoint(), Ordering.Natural(fullgraph))
     assert abs(isam.error(2) - lin.error()) <= 1e-12 * max(1.0, lin.error())
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_slamlike_solution_dogleg(mode):
+    """TEST(ISAM2, slamlike_solution_dogleg) tests/testGaussianISAM2.cpp:310-319: ISAM2Params(ISAM2DoglegParams(1.0), 0.0, 0, false)
+    (adaptation mode SEARCH_EACH_ITERATION, the default) reaches the batch solution (isam_check).  The other two adaptation modes only
+    shrink / take one trust-region step per update: they must lower the error of the graph at the linearization point"""
+    steps = slamlike_steps()
+    isam = oh.OracleISAM2(**NO_RELIN)
+    isam.set_dogleg(1.0, 1e-5, mode)
+    for g, v in steps:
+        isam.update(g, v)
+    if mode == 0:
+        isam_check(isam, *merge(steps))
+        assert isam.doglegDelta() >= 1.0
+    else:
+        assert isam.error(0) < isam.error(2)
+
+
+def test_dogleg_trust_region_limits_the_step():
+    """a small initial trust region: the first estimates are NOT the Newton point (the dog leg cuts the step), the radius adapts, and the
+    sequence still ends near the batch solution of the visual example"""
+    dl = oh.OracleISAM2(relinearizeThreshold=0.01, relinearizeSkip=1)
+    dl.set_dogleg(0.05, 1e-5, 2)  # ONE_STEP_PER_ITERATION: one trust-region step per updateDelta (SEARCH_EACH_ITERATION grows the radius
+    #                               inside the call until the Newton point fits, which here reproduces Gauss-Newton)
+    gn = oh.OracleISAM2(relinearizeThreshold=0.01, relinearizeSkip=1)
+    radii, differs = [], False
+    for g, v in visual_steps():
+        dl.update(g, v)
+        gn.update(g, v)
+        radii.append(dl.doglegDelta())
+        a, b = dl.calculateEstimate(), gn.calculateEstimate()
+        differs = differs or any(not np.allclose(a.at(k), b.at(k), atol=1e-6) for k in b.keys())
+    assert differs and radii[0] == 0.05 and radii[-1] > 5.0 and sorted(radii) == radii
+    for j, p in enumerate(create_points()):
+        assert np.allclose(dl.calculateEstimate().at(symbol("l", j)), p, rtol=0, atol=0.05), j
