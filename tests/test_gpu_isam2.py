@@ -550,4 +550,8 @@ def test_dogleg(mode, radius):
             assert rg == ro, (rg, ro)
             compare_state(isam, orc)  # (calculateEstimate -> updateDelta -> one dog-leg iteration on both sides)
             assert abs(isam.doglegDelta() - orc.doglegDelta()) <= 1e-6 * orc.doglegDelta()
+        if steps[0][1].exists(0):  # the slamlike sequence: landmark 100 loses its factors and leaves (its scalars must stop counting in
+            both(isam, orc, removeFactorIndices=[7, 14])  # the norms of the dog leg), then a bare update
+            both(isam, orc)
+            assert abs(isam.doglegDelta() - orc.doglegDelta()) <= 1e-6 * orc.doglegDelta()
         isam.close()
