@@ -555,3 +555,20 @@ def test_dogleg(mode, radius):
             both(isam, orc)
             assert abs(isam.doglegDelta() - orc.doglegDelta()) <= 1e-6 * orc.doglegDelta()
         isam.close()
+
+
+def test_dogleg_through_wide_cliques():
+    """the dog leg's tree products (gradient, R g, error) on cliques walked from memory (more than 139 columns), update by update against
+    the oracle on the dense pose graph"""
+    p = ISAM2Params(ISAM2DoglegParams(1.0, 1e-5, 0))
+    isam = ISAM2(p, ccolamd=ccolamd, device=0)
+    orc = oh.OracleISAM2(p.relinearizeThreshold, p.relinearizeSkip, p.enableRelinearization, 1e-5)
+    orc.set_dogleg(1.0, 1e-5, 0)
+    for i, (g, v) in enumerate(dense_pose2_steps()):
+        assert isam.update(g, v).as_dict() == orc.update(g, v)
+        if i % 10 == 9:
+            compare_state(isam, orc)
+            assert abs(isam.doglegDelta() - orc.doglegDelta()) <= 1e-6 * orc.doglegDelta()
+    assert max(rsd.shape[1] for _, _, rsd, _ in isam.cliques()) > 139
+    compare_state(isam, orc)
+    isam.close()
