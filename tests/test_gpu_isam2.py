@@ -572,3 +572,25 @@ def test_dogleg_through_wide_cliques():
     assert max(rsd.shape[1] for _, _, rsd, _ in isam.cliques()) > 139
     compare_state(isam, orc)
     isam.close()
+
+
+def test_dogleg_incremental_pose_graph():
+    """the 400-pose incremental pose graph (loop closures, default relinearization) with ISAM2DoglegParams: counts per update, the state and
+    the radius every 50 updates and at the end, against the oracle"""
+    import os
+    from isam2_examples import incremental_pose2_steps
+    p = ISAM2Params(ISAM2DoglegParams(1.0, 1e-5, 0))
+    isam = ISAM2(p, ccolamd=ccolamd, device=0)
+    orc = oh.OracleISAM2(p.relinearizeThreshold, p.relinearizeSkip, p.enableRelinearization, 1e-5)
+    orc.set_dogleg(1.0, 1e-5, 0)
+    g2o = os.path.join(os.path.dirname(__file__), "golden", "city10000_head.g2o")
+    last = {"k": None}
+    for i, (g, v) in enumerate(incremental_pose2_steps(g2o, 400, lambda k: last["k"])):
+        rg, ro = isam.update(g, v).as_dict(), orc.update(g, v)
+        assert rg == ro, (i, rg, ro)
+        last["k"] = orc.calculateEstimate().at(i + 1) if i % 7 == 0 else (v.at(i + 1) if v.exists(i + 1) else last["k"])
+        if i % 50 == 49:
+            compare_state(isam, orc)
+            assert abs(isam.doglegDelta() - orc.doglegDelta()) <= 1e-6 * orc.doglegDelta()
+    compare_state(isam, orc)
+    isam.close()
