@@ -18,6 +18,7 @@
 // Output: one JSON object: updates, seconds inside the library calls, ms per update, the final estimate (key, packed value).
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cinttypes>
 #include <cmath>
@@ -154,6 +155,7 @@ int main(int argc, char** argv) {
   lmgpu_isam2* h = nullptr;
   if (lmgpu_isam2_create(&cfg, &prm, &colamd_cb, nullptr, &h) != LMGPU_OK) return fail("lmgpu_isam2_create", h ? lmgpu_isam2_last_error(h) : "");
   double lib = 0, worst = 0;
+  std::vector<double> per_update;
   lmgpu_isam2_result r{};
   size_t done = 0;
   double est_seconds = 0;
@@ -195,6 +197,7 @@ int main(int argc, char** argv) {
     }
     const double dt = now() - t0;
     lib += dt;
+    per_update.push_back(dt);
     worst = dt > worst ? dt : worst;
     if (rc != LMGPU_OK) {
       std::printf("{\"error\": \"update %zu: rc %d: %s\"}\n", done, rc, lmgpu_isam2_last_error(h));
@@ -214,9 +217,11 @@ int main(int argc, char** argv) {
   std::vector<double> packed(tot);
   if (lmgpu_isam2_get_values(h, 0, nullptr, nullptr, packed.data()) != LMGPU_OK) return fail("calculateEstimate", lmgpu_isam2_last_error(h));
   const double t_est = now() - t1;
-  std::printf("{\"updates\": %zu, \"library_seconds\": %.6f, \"ms_per_update\": %.6f, \"worst_update_ms\": %.4f, \"ccolamd_callback_seconds\": %.6f, "
+  std::sort(per_update.begin(), per_update.end());
+  auto pct = [&](double q) { return per_update.empty() ? 0.0 : 1e3 * per_update[std::min(per_update.size() - 1, (size_t)(q * per_update.size()))]; };
+  std::printf("{\"updates\": %zu, \"library_seconds\": %.6f, \"ms_per_update\": %.6f, \"p50_ms\": %.4f, \"p95_ms\": %.4f, \"p99_ms\": %.4f, \"worst_update_ms\": %.4f, \"ccolamd_callback_seconds\": %.6f, "
               "\"calculate_estimate_ms\": %.4f, \"single_estimates\": %zu, \"single_estimate_ms\": %.5f, \"variables\": %d, \"cliques\": %d, \"estimate\": [",
-              done, lib, done ? 1e3 * lib / done : 0.0, 1e3 * worst, g_colamd_seconds, 1e3 * t_est, est_calls,
+              done, lib, done ? 1e3 * lib / done : 0.0, pct(0.50), pct(0.95), pct(0.99), 1e3 * worst, g_colamd_seconds, 1e3 * t_est, est_calls,
               est_calls ? 1e3 * est_seconds / est_calls : 0.0, n, r.cliques);
   const double* q = packed.data();
   for (int i = 0; i < n; i++) {

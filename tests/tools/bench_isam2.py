@@ -116,6 +116,7 @@ for name, g2o, n in cases:
         e = est.at(int(r[0]))
         worst = max(worst, float(np.max(np.abs(np.array(r[1:]) - e) / np.maximum(1.0, np.abs(e)))))
     print(f"{name}, C++ driver: {res['updates']} updates, {res['ms_per_update']:.4f} ms per update inside the library calls "
-          f"(of which the caller's ccolamd {1e3 * res['ccolamd_callback_seconds'] / res['updates']:.4f} ms), worst update {res['worst_update_ms']:.2f} ms, "
+          f"(of which the caller's ccolamd {1e3 * res['ccolamd_callback_seconds'] / res['updates']:.4f} ms; median {res['p50_ms']:.3f}, p95 {res['p95_ms']:.3f}, "
+          f"p99 {res['p99_ms']:.3f}), worst update {res['worst_update_ms']:.2f} ms, "
           f"calculateEstimate {res['calculate_estimate_ms']:.2f} ms; CPU oracle {1e3 * t_orc / len(steps):.4f} ms per update (through ctypes); "
           f"estimate vs oracle: max rel diff {worst:.2e}, cliques {res['cliques']}", flush=True)
