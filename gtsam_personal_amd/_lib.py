@@ -96,6 +96,7 @@ SYMBOLS = {
     "lmgpu_set_kernel_timing": (ct.c_int, [_H, ct.c_int32]),
     "lmgpu_get_kernel_times": (ct.c_int, [_H, _D, _D, ct.POINTER(ct.c_int64)]),
     "lmgpu_get_jacobian": (ct.c_int, [_H, ct.c_int32, _D, _I, _I]),
+    "lmgpu_get_jacobians": (ct.c_int, [_H, _I, _I, _I, _I, ct.POINTER(ct.c_int64), _D]),
     "lmgpu_num_fronts": (ct.c_int, [_H]),
     "lmgpu_front_info": (ct.c_int, [_H, ct.c_int32, _I]),
     "lmgpu_get_front": (ct.c_int, [_H, ct.c_int32, _I, _D]),

@@ -200,6 +200,7 @@ struct lmgpu_handle {
   Plan plan;
   std::vector<Bucket> buckets;
   bool finalized = false, have_values = false, linearized = false, solved = false;
+  bool have_jacobians = false;  // the pool holds the [A b] of the last linearization (they outlive `linearized`: an accepted step moves the values, not the Jacobians)
   std::vector<int32_t> graph_index_sorted;  // parallel to plan.factors
 
   // ---- ownership (multi-GPU).  Everything is "active" and "counted" when world_size == 1.
@@ -491,6 +492,7 @@ int do_linearize(lmgpu_handle* h) {
   launch_factors<true>(h, h->cur);
   HIPCHECK(hipGetLastError());
   h->linearized = true;
+  h->have_jacobians = true;
   return LMGPU_OK;
 }
 
@@ -2679,9 +2681,57 @@ int lmgpu_get_jacobian(lmgpu_handle* h, int32_t graph_index, double* out, int32_
   if (out) {
     int rc = need_device(h);
     if (rc) return rc;
-    if (!h->linearized || b.loc_of[f.idx] < 0) return LMGPU_INVALID;  // not linearized, or the factor lives on another rank
+    if (!h->have_jacobians || b.loc_of[f.idx] < 0) return LMGPU_INVALID;  // never linearized, or the factor lives on another rank
     HIPCHECK(hipMemcpy(out, h->pool + b.joff + (int64_t)b.loc_of[f.idx] * b.rows * b.cols, (size_t)b.rows * b.cols * sizeof(double),
                        hipMemcpyDeviceToHost));
+  }
+  return LMGPU_OK;
+}
+
+int lmgpu_get_jacobians(lmgpu_handle* h, int32_t* n_out, int32_t* graph_index, int32_t* rows, int32_t* cols, int64_t* offsets, double* out) {
+  if (!h) return LMGPU_INVALID;
+  if (!h->finalized) {
+    h->err = "lmgpu_get_jacobians: refused (!h->finalized)";
+    return LMGPU_INVALID;
+  }
+  const int NFAC = (int)h->plan.factors.size();
+  if (n_out) *n_out = NFAC;
+  int64_t off = 0;
+  for (int i = 0; i < NFAC; i++) {  // plan.factors is ascending by graph index
+    const FactorRef& f = h->plan.factors[i];
+    const Bucket& b = h->buckets[f.bucket];
+    if (graph_index) graph_index[i] = f.graph_index;
+    if (rows) rows[i] = b.rows;
+    if (cols) cols[i] = b.cols;
+    if (offsets) offsets[i] = off;
+    off += (int64_t)b.rows * b.cols;
+  }
+  if (offsets) offsets[NFAC] = off;
+  if (!out) return LMGPU_OK;
+  int rc = need_device(h);
+  if (rc) return rc;
+  if (!h->have_jacobians) {
+    h->err = "lmgpu_get_jacobians: refused (no linearization on the device)";
+    return LMGPU_INVALID;
+  }
+  // one copy per bucket, then the host puts every factor at its place in graph order
+  std::vector<std::vector<double>> jb(h->buckets.size());
+  for (size_t k = 0; k < h->buckets.size(); k++) {
+    const Bucket& b = h->buckets[k];
+    jb[k].resize((size_t)b.n_loc * b.rows * b.cols);
+    if (b.n_loc) HIPCHECK(hipMemcpy(jb[k].data(), h->pool + b.joff, jb[k].size() * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  off = 0;
+  for (int i = 0; i < NFAC; i++) {
+    const FactorRef& f = h->plan.factors[i];
+    const Bucket& b = h->buckets[f.bucket];
+    const size_t sz = (size_t)b.rows * b.cols;
+    if (b.loc_of[f.idx] < 0) {
+      h->err = "lmgpu_get_jacobians: a factor lives on another rank";
+      return LMGPU_INVALID;
+    }
+    std::memcpy(out + off, jb[f.bucket].data() + (size_t)b.loc_of[f.idx] * sz, sz * sizeof(double));
+    off += (int64_t)sz;
   }
   return LMGPU_OK;
 }

@@ -199,12 +199,25 @@ class LevenbergMarquardtOptimizer:
         return self.state.totalNumberInnerIterations
 
     def iterate(self):
+        """one outer iteration; returns the linearized graph like the reference (NonlinearOptimizer.h:136,
+        LevenbergMarquardtOptimizer.cpp:281,307): the whitened Jacobians of the linearization this iteration solved, fetched from
+        the device when first read"""
         cp = self.params._c()
         self._check(self.lib.lmgpu_iterate(self._h, ct.byref(cp), ct.byref(self.state)))
+        return self._returned_linear_graph()
+
+    def _returned_linear_graph(self):
+        self._lin_generation = getattr(self, "_lin_generation", 0) + 1
+        return GaussianFactorGraph(self, self._lin_generation)
+
+    def linear_graph(self):
+        """the linearization currently on the device as a GaussianFactorGraph (one copy per factor bucket)"""
+        return GaussianFactorGraph(self, getattr(self, "_lin_generation", 0))
 
     def optimize(self) -> Values:
         cp = self.params._c()
         self._check(self.lib.lmgpu_optimize(self._h, ct.byref(cp), ct.byref(self.state)))
+        self._lin_generation = getattr(self, "_lin_generation", 0) + 1
         return self.values()
 
     def timings(self):
@@ -256,7 +269,9 @@ class LevenbergMarquardtOptimizer:
         return e.value
 
     def linearize(self):
+        """LevenbergMarquardtOptimizer::linearize() (LevenbergMarquardtOptimizer.h:113): returns the linear graph (fetched on first read)"""
         self._check(self.lib.lmgpu_linearize(self._h))
+        return self._returned_linear_graph()
 
     def solve(self, lam, diagonal_damping=False, min_diag=1e-6, max_diag=1e32):
         """returns (delta by key dict, packed delta in slot order, linear error at 0, linear error at delta)"""
@@ -304,6 +319,97 @@ class LevenbergMarquardtOptimizer:
         return keys, (rsd.reshape(fi["n"], fi["nf"]).T.copy() if numeric else None)
 
 
+class JacobianFactor:
+    """the part of gtsam/linear/JacobianFactor.h the returned linear graph is read through: keys(), getA(i) / jacobian(), getb(),
+    error(x) = 0.5 ||A x - b||^2 (JacobianFactor.cpp:509-514); unit noise model (already whitened)"""
+
+    def __init__(self, keys, dims, Ab):
+        self._keys, self._dims, self._Ab = list(keys), list(dims), Ab
+        self._off = np.concatenate([[0], np.cumsum(dims)]).astype(int)
+
+    def keys(self):
+        return list(self._keys)
+
+    def getA(self, i):
+        return self._Ab[:, self._off[i]:self._off[i + 1]].copy()
+
+    def getb(self):
+        return self._Ab[:, -1].copy()
+
+    def jacobian(self):
+        return self._Ab[:, :-1].copy(), self.getb()
+
+    def augmentedJacobian(self):
+        return self._Ab.copy()
+
+    def error(self, x):
+        r = -self._Ab[:, -1]
+        for i, k in enumerate(self._keys):
+            r = r + self._Ab[:, self._off[i]:self._off[i + 1]] @ np.asarray(x[k], dtype=float)
+        return 0.5 * float(r @ r)
+
+
+class GaussianFactorGraph:
+    """What iterate() / linearize() return: the linearization on the device as a list of JacobianFactors, index-preserving like
+    NonlinearFactorGraph::linearize (NonlinearFactorGraph.cpp:239-278; a slot without a factor is None).  The numbers are fetched at the
+    first read (lmgpu_get_jacobians: one copy per factor bucket); a graph that is first read after the optimizer has linearized again
+    refuses — its linearization is no longer on the device."""
+
+    def __init__(self, opt, generation):
+        self._opt, self._generation, self._factors = opt, generation, None
+
+    def _fetch(self):
+        if self._factors is not None:
+            return
+        o = self._opt
+        if getattr(o, "_lin_generation", 0) != self._generation:
+            raise _lib.LmgpuError("this linear graph was not read before the optimizer linearized again")
+        n = ct.c_int32()
+        o._check(o.lib.lmgpu_get_jacobians(o._h, ct.byref(n), None, None, None, None, None))
+        gi, rows, cols = (np.zeros(n.value, dtype=np.int32) for _ in range(3))
+        off = np.zeros(n.value + 1, dtype=np.int64)
+        o._check(o.lib.lmgpu_get_jacobians(o._h, ct.byref(n), _ip(gi), _ip(rows), _ip(cols), off.ctypes.data_as(ct.POINTER(ct.c_int64)), None))
+        out = np.empty(int(off[-1]))
+        o._check(o.lib.lmgpu_get_jacobians(o._h, ct.byref(n), None, None, None, None, _dp(out)))
+        fac = [None] * o.graph.size()
+        fkeys = o.graph.factor_keys_in_graph_order()
+        for i in range(n.value):
+            Ab = out[off[i]:off[i + 1]].reshape(cols[i], rows[i]).T  # column-major -> (rows, cols)
+            keys = fkeys[int(gi[i])]
+            dims = [VAR_DIM[o._types[o._slot[int(k)]]] for k in keys]
+            fac[int(gi[i])] = JacobianFactor(keys, dims, Ab)
+        self._factors = fac
+
+    def size(self):
+        self._fetch()
+        return len(self._factors)
+
+    __len__ = size
+
+    def at(self, i):
+        self._fetch()
+        return self._factors[i]
+
+    __getitem__ = at
+
+    def error(self, x):
+        """GaussianFactorGraph::error (GaussianFactorGraph.cpp:71-78); x: {key: vector}"""
+        self._fetch()
+        return sum(f.error(x) for f in self._factors if f is not None)
+
+    def gradientAtZero(self):
+        """GaussianFactorGraph::gradientAtZero (GaussianFactorGraph.cpp:357-367): {key: -sum A_k^T b}"""
+        self._fetch()
+        g = {}
+        for f in self._factors:
+            if f is None:
+                continue
+            b = f.getb()
+            for i, k in enumerate(f.keys()):
+                g[k] = g.get(k, 0.0) - f.getA(i).T @ b
+        return g
+
+
 class GaussNewtonParams(LevenbergMarquardtParams):
     """NonlinearOptimizerParams defaults (gtsam/nonlinear/NonlinearOptimizerParams.h: maxIterations 100, relativeErrorTol 1e-5,
     absoluteErrorTol 1e-5, errorTol 0); the LM-only fields of the shared C struct are ignored by the Gauss-Newton entry points."""
@@ -321,10 +427,12 @@ class GaussNewtonOptimizer(LevenbergMarquardtOptimizer):
 
     def iterate(self):
         self._check(self.lib.lmgpu_gn_iterate(self._h, ct.byref(self.state)))
+        return self._returned_linear_graph()  # GaussNewtonOptimizer.cpp:49,65
 
     def optimize(self) -> Values:
         cp = self.params._c()
         self._check(self.lib.lmgpu_gn_optimize(self._h, ct.byref(cp), ct.byref(self.state)))
+        self._lin_generation = getattr(self, "_lin_generation", 0) + 1
         return self.values()
 
 
@@ -349,10 +457,12 @@ class DoglegOptimizer(LevenbergMarquardtOptimizer):
 
     def iterate(self):
         self._check(self.lib.lmgpu_dl_iterate(self._h, ct.byref(self.state)))
+        return self._returned_linear_graph()  # DoglegOptimizer.cpp:87,122
 
     def optimize(self) -> Values:
         cp = self.params._c()
         self._check(self.lib.lmgpu_dl_optimize(self._h, ct.byref(cp), ct.byref(self.state)))
+        self._lin_generation = getattr(self, "_lin_generation", 0) + 1
         return self.values()
 
 

@@ -235,6 +235,12 @@ int lmgpu_get_kernel_times(const lmgpu_handle* h, double* ms /*[LMGPU_KT_NUM]*/,
 /* whitened Jacobian of graph factor `graph_index`, column-major rows x (sum dims + 1) like the reference's
  * VerticalBlockMatrix ([A1 A2 b]); out may be NULL to query the shape. */
 int lmgpu_get_jacobian(lmgpu_handle* h, int32_t graph_index, double* out, int32_t* rows, int32_t* cols);
+/* The whole linearization in one call: what LevenbergMarquardtOptimizer::iterate() RETURNS (the GaussianFactorGraph of
+ * gtsam/nonlinear/NonlinearOptimizer.h:136, LevenbergMarquardtOptimizer.cpp:281,307; read by tests/testNonlinearOptimizer.cpp:282).
+ * Every factor's whitened [A1 .. Ak b] back to back in ascending graph-index order (index-preserving like
+ * NonlinearFactorGraph::linearize), column-major rows[i] x cols[i] at out + offsets[i]; offsets has *n_out + 1 entries.
+ * Any output may be NULL (out == NULL: shapes only, no device needed).  One device copy per factor bucket. */
+int lmgpu_get_jacobians(lmgpu_handle* h, int32_t* n_out, int32_t* graph_index, int32_t* rows, int32_t* cols, int64_t* offsets, double* out);
 int lmgpu_num_fronts(const lmgpu_handle* h);
 /* info8: n_keys, n_frontal_keys, nf (rows of [R S d]), n (cols), parent front (-1 root), class (0 = LDS front, 1 = HBM front),
  *        owner rank (-1 = replicated on every rank), level (0 = leaf) */

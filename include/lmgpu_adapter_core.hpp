@@ -177,6 +177,26 @@ class Problem {
     return out;
   }
 
+  /// the whole linearization (what iterate() returns in the reference): one copy per factor bucket instead of one per factor
+  struct LinearGraph {
+    std::vector<int32_t> graphIndex, rows, cols;  // ascending graph index
+    std::vector<int64_t> offsets;                 // n + 1
+    std::vector<double> data;                     // [A1 .. Ak b] column-major, back to back
+  };
+  LinearGraph jacobians() const {
+    LinearGraph g;
+    int32_t n = 0;
+    check(lmgpu_get_jacobians(h_, &n, nullptr, nullptr, nullptr, nullptr, nullptr));
+    g.graphIndex.resize((size_t)n);
+    g.rows.resize((size_t)n);
+    g.cols.resize((size_t)n);
+    g.offsets.resize((size_t)n + 1);
+    check(lmgpu_get_jacobians(h_, &n, g.graphIndex.data(), g.rows.data(), g.cols.data(), g.offsets.data(), nullptr));
+    g.data.resize((size_t)g.offsets.back());
+    check(lmgpu_get_jacobians(h_, &n, nullptr, nullptr, nullptr, nullptr, g.data.data()));
+    return g;
+  }
+
   // ---- the hot path, whole
   lmgpu_lm_state lmInit(const lmgpu_lm_params& p) {
     lmgpu_lm_state st{};

@@ -8,8 +8,9 @@
 //
 // This file only EXTRACTS numbers from GTSAM objects; slot assignment, bucketing, packing, the call order of the C ABI and
 // the status -> exception mapping are in lmgpu_adapter_core.hpp, which has no GTSAM include and is compiled and tested in the
-// repository (tests/cpp/adapter_harness.cpp).  This file itself cannot be compiled there (GTSAM needs CMake-generated headers,
-// DESIGN.md section 3); it is written against the reference headers cited next to each accessor.
+// repository (tests/cpp/adapter_harness.cpp).  This file is type-checked against the reference's headers by
+// tests/test_adapter_header_compiles.py (g++ -fsyntax-only; the two CMake-generated headers GTSAM's sources include are written into
+// the test's temporary directory); it cannot be LINKED there (libgtsam is not buildable in the repository's container).
 //
 // Two modes (constructor argument):
 //   WholeIterate (default)  iterate() = lmgpu_iterate: the whole tryLambda loop on device-resident data; values come back
@@ -19,17 +20,31 @@
 //                           JacobianFactors, which tryLambda needs for linear.error), solve() -> lmgpu_solve at state lambda.
 #pragma once
 
+#include <gtsam/base/GenericValue.h>
+#include <gtsam/geometry/BearingRange.h>
 #include <gtsam/geometry/Cal3Bundler.h>
 #include <gtsam/geometry/Cal3_S2.h>
 #include <gtsam/geometry/PinholeCamera.h>
+#include <gtsam/geometry/Point2.h>
+#include <gtsam/geometry/Point3.h>
+#include <gtsam/geometry/Pose2.h>
+#include <gtsam/geometry/Pose3.h>
+#include <gtsam/geometry/Rot2.h>
+#include <gtsam/geometry/Rot3.h>
+#include <gtsam/inference/Ordering.h>
+#include <gtsam/linear/GaussianFactorGraph.h>
 #include <gtsam/linear/JacobianFactor.h>
+#include <gtsam/linear/NoiseModel.h>
+#include <gtsam/linear/VectorValues.h>
 #include <gtsam/linear/linearExceptions.h>
 #include <gtsam/nonlinear/DoglegOptimizer.h>
 #include <gtsam/nonlinear/GaussNewtonOptimizer.h>
 #include <gtsam/nonlinear/ISAM2.h>
 #include <gtsam/3rdparty/CCOLAMD/Include/ccolamd.h>
 #include <gtsam/nonlinear/LevenbergMarquardtOptimizer.h>
+#include <gtsam/nonlinear/NonlinearFactorGraph.h>
 #include <gtsam/nonlinear/PriorFactor.h>
+#include <gtsam/nonlinear/Values.h>
 #include <gtsam/nonlinear/internal/LevenbergMarquardtState.h>
 #include <gtsam/nonlinear/internal/NonlinearOptimizerState.h>
 #include <gtsam/sam/BearingRangeFactor.h>
@@ -37,8 +52,13 @@
 #include <gtsam/slam/GeneralSFMFactor.h>
 #include <gtsam/slam/ProjectionFactor.h>
 
+#include <algorithm>
 #include <memory>
+#include <optional>
 #include <stdexcept>
+#include <string>
+#include <utility>
+#include <variant>
 #include <vector>
 
 #include "lmgpu_adapter_core.hpp"
@@ -271,13 +291,16 @@ class Device {
   /// the device-resident linearization as the GaussianFactorGraph NonlinearFactorGraph::linearize returns: one JacobianFactor
   /// per factor, already whitened (unit noise model), index-preserving
   GaussianFactorGraph::shared_ptr downloadLinearGraph(const NonlinearFactorGraph& graph) const {
+    const lmgpu_adapter::Problem::LinearGraph lg = p_.jacobians();  // one device copy per factor bucket
     auto out = std::make_shared<GaussianFactorGraph>();
     out->reserve(graph.size());
+    size_t next = 0;
     for (size_t i = 0; i < graph.size(); i++) {
       if (!graph[i]) { out->push_back(GaussianFactor::shared_ptr()); continue; }
-      int32_t rows = 0, cols = 0;
-      const std::vector<double> Ab = p_.jacobian((int32_t)i, &rows, &cols);
-      Eigen::Map<const Matrix> M(Ab.data(), rows, cols);  // column-major
+      if (next >= lg.graphIndex.size() || (size_t)lg.graphIndex[next] != i) throw std::logic_error("lmgpu adapter: linear graph does not match the nonlinear graph");
+      const int rows = lg.rows[next], cols = lg.cols[next];
+      Eigen::Map<const Matrix> M(lg.data.data() + lg.offsets[next], rows, cols);  // column-major
+      next++;
       std::vector<std::pair<Key, Matrix>> terms;
       int c0 = 0;
       for (Key k : graph[i]->keys()) {
@@ -326,8 +349,24 @@ class GpuLevenbergMarquardtOptimizer : public LevenbergMarquardtOptimizer {
     }
     state_.reset(new internal::LevenbergMarquardtState(dev_.download(cur->values), st.error, st.lambda, st.currentFactor,
                                                        (unsigned)st.iterations, (unsigned)st.totalNumberInnerIterations));
-    // in-tree callers ignore the returned linear graph; lastLinearGraph() downloads it on request
-    return std::make_shared<GaussianFactorGraph>();
+    // the hook's contract (NonlinearOptimizer.h:136, LevenbergMarquardtOptimizer.cpp:281,307; read at tests/testNonlinearOptimizer.cpp:282):
+    // the linearization this iteration solved -- lmgpu_iterate leaves it on the device (it linearizes once per outer iteration, before
+    // the lambda loop, and the accepted step does not touch the Jacobians).  optimize() below discards the graph like defaultOptimize
+    // does (NonlinearOptimizer.cpp:92) and therefore does not fetch it.
+    return discardLinear_ ? GaussianFactorGraph::shared_ptr() : dev_.downloadLinearGraph(graph_);
+  }
+
+  /// NonlinearOptimizer::optimize() (NonlinearOptimizer.h:98): defaultOptimize() calls iterate() and drops what it returns; skip the download
+  const Values& optimize() override {
+    discardLinear_ = true;
+    try {
+      defaultOptimize();
+    } catch (...) {
+      discardLinear_ = false;
+      throw;
+    }
+    discardLinear_ = false;
+    return values();
   }
 
   /// LevenbergMarquardtOptimizer::linearize() (LevenbergMarquardtOptimizer.h:113): graph_.linearize(state_->values) on the device
@@ -351,6 +390,7 @@ class GpuLevenbergMarquardtOptimizer : public LevenbergMarquardtOptimizer {
   mutable lmgpu_detail::Device dev_;
   lmgpu_lm_params cp_;
   Mode mode_;
+  bool discardLinear_ = false;
 };
 
 /// drop-in for GaussNewtonOptimizer (gtsam/nonlinear/GaussNewtonOptimizer.cpp:44-66): iterate() = lmgpu_gn_iterate
@@ -368,7 +408,19 @@ class GpuGaussNewtonOptimizer : public GaussNewtonOptimizer {
       throw IndeterminantLinearSystemException(e.key);
     }
     state_.reset(new internal::NonlinearOptimizerState(dev_.download(state_->values), st.error, (unsigned)st.iterations));
-    return std::make_shared<GaussianFactorGraph>();
+    return discardLinear_ ? GaussianFactorGraph::shared_ptr() : dev_.downloadLinearGraph(graph_);  // GaussNewtonOptimizer.cpp:49,65
+  }
+
+  const Values& optimize() override {  // see GpuLevenbergMarquardtOptimizer::optimize
+    discardLinear_ = true;
+    try {
+      defaultOptimize();
+    } catch (...) {
+      discardLinear_ = false;
+      throw;
+    }
+    discardLinear_ = false;
+    return values();
   }
 
   VectorValues solve(const GaussianFactorGraph& /*linear*/, const NonlinearOptimizerParams& /*params*/) const override {
@@ -377,6 +429,7 @@ class GpuGaussNewtonOptimizer : public GaussNewtonOptimizer {
 
  private:
   mutable lmgpu_detail::Device dev_;
+  bool discardLinear_ = false;
 };
 
 /// DoglegOptimizer's state type (internal::DoglegState) is private to DoglegOptimizer.cpp:54-62, so a subclass cannot replace
@@ -404,13 +457,26 @@ class GpuDoglegOptimizer : public NonlinearOptimizer {
       throw IndeterminantLinearSystemException(e.key);
     }
     state_.reset(new State(dev_->download(state_->values), st.error, st.lambda, (unsigned)st.iterations));
-    return std::make_shared<GaussianFactorGraph>();
+    return discardLinear_ ? GaussianFactorGraph::shared_ptr() : dev_->downloadLinearGraph(graph_);  // DoglegOptimizer.cpp:87,122
+  }
+
+  const Values& optimize() override {  // see GpuLevenbergMarquardtOptimizer::optimize
+    discardLinear_ = true;
+    try {
+      defaultOptimize();
+    } catch (...) {
+      discardLinear_ = false;
+      throw;
+    }
+    discardLinear_ = false;
+    return values();
   }
 
  protected:
   const NonlinearOptimizerParams& _params() const override { return params_; }
   DoglegParams params_;
   std::unique_ptr<lmgpu_detail::Device> dev_;
+  bool discardLinear_ = false;
 };
 
 /// ISAM2 on the device (lmgpu_isam2_*): the same update() / calculateEstimate() calls as gtsam::ISAM2 (gtsam/nonlinear/ISAM2.h:146-260)

@@ -15,6 +15,7 @@
 // Output: one JSON object on stdout.  Exit code 0 ok, 1 lmgpu error (message in the JSON), 2 usage.
 #include <cinttypes>
 #include <cstdarg>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -196,6 +197,17 @@ int main(int argc, char** argv) {
     } else {
       std::fprintf(stderr, "unknown mode %s\n", mode.c_str());
       return 2;
+    }
+    {  // what iterate() returns through the adapter (Problem::jacobians, one copy per bucket) against the per-factor tap
+      const Problem::LinearGraph lg = p.jacobians();
+      bool same = lg.graphIndex.size() == in.factors.size();
+      for (size_t i = 0; same && i < lg.graphIndex.size(); i++) {
+        int32_t rows = 0, cols = 0;
+        const std::vector<double> one = p.jacobian(lg.graphIndex[i], &rows, &cols);
+        same = rows == lg.rows[i] && cols == lg.cols[i] && lg.offsets[i + 1] - lg.offsets[i] == (int64_t)one.size() &&
+               std::equal(one.begin(), one.end(), lg.data.begin() + lg.offsets[i]);
+      }
+      outf(", \"linear_graph_factors\": %zu, \"linear_graph_matches_taps\": %s", lg.graphIndex.size(), same ? "true" : "false");
     }
     outf(", \"error\": %.17g, \"lambda\": %.17g, \"iterations\": %d, \"inner\": %d, ", st.error, st.lambda, st.iterations,
                 st.totalNumberInnerIterations);

@@ -132,6 +132,8 @@ def test_sfm_example_bal_through_the_adapter_reaches_the_reference_error(tmp_pat
     so = orc.lm_state()
     assert abs(so["error"] - REFERENCE_SFMEXAMPLE_BAL_FINAL_ERROR) <= 1e-6 * REFERENCE_SFMEXAMPLE_BAL_FINAL_ERROR
     assert whole["iterations"] == so["iterations"] and whole["inner"] == so["inner"]
+    # the linear graph iterate() hands back through the adapter (one copy per bucket) is the per-factor taps, for every factor
+    assert whole["linear_graph_matches_taps"] and whole["linear_graph_factors"] == graph.size()
     assert abs(whole["error"] - so["error"]) <= 1e-6 * so["error"]
     # Piecewise mode (the reference's own tryLambda around linearize() / solve()): same decisions, same result
     rc, piece = run_harness(prob, 0, "piecewise")

@@ -690,3 +690,44 @@ def test_pinhole_projection_known_answers_on_gpu():
     opt.linearize()
     for i in range(4):
         assert np.allclose(-opt.jacobian(i)[:, -1], expect[i], atol=1e-9)
+
+
+def test_iterate_returns_the_linearized_graph():
+    """NonlinearOptimizer::iterate() returns the linear graph (NonlinearOptimizer.h:136; tests/testNonlinearOptimizer.cpp:282 reads
+    it): the whitened Jacobians at the values the iteration STARTED from, index-preserving, for LM, Gauss-Newton and Dogleg; the
+    bulk tap equals the per-factor tap"""
+    from gtsam_personal_amd import DoglegOptimizer, GaussNewtonOptimizer
+    graph, initial, _, ordering = make_bal(n_cam=6, n_pt=50, obs_per_point=4, seed=4)
+    for cls in (LevenbergMarquardtOptimizer, GaussNewtonOptimizer, DoglegOptimizer):
+        opt = cls(graph, initial, ordering, device=0)
+        orc = oh.OracleProblem(graph, initial, ordering)
+        orc.linearize()  # at the initial values
+        linear = opt.iterate()
+        assert linear.size() == graph.size()
+        fk = graph.factor_keys_in_graph_order()
+        zero = {k: np.zeros(len(opt.delta_by_key(np.zeros(opt._ntot))[k])) for k in ordering}
+        e0 = 0.0
+        for g in range(graph.size()):
+            f, Jo = linear.at(g), orc.jacobian(g)
+            assert tuple(f.keys()) == tuple(fk[g])
+            assert np.allclose(f.augmentedJacobian(), Jo, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(Jo).max())), (cls.__name__, g)
+            e0 += 0.5 * float(Jo[:, -1] @ Jo[:, -1])
+        assert abs(linear.error(zero) - e0) <= 1e-9 * max(1.0, e0)
+        # a graph that is first read after the next linearization refuses instead of returning the wrong numbers
+        stale = opt.iterate()
+        opt.iterate()
+        with pytest.raises(_lib.LmgpuError):
+            stale.size()
+        opt.close()
+
+
+def test_gradient_of_the_returned_linear_graph_is_zero_at_the_optimum():
+    """tests/testNonlinearOptimizer.cpp:270-283: after optimize(), optimizer.linearize()->gradientAtZero() is zero"""
+    graph, initial, _, ordering = make_bal(n_cam=6, n_pt=50, obs_per_point=4, seed=4)
+    params = LevenbergMarquardtParams()
+    params.relativeErrorTol, params.absoluteErrorTol = 1e-14, 1e-14
+    opt = LevenbergMarquardtOptimizer(graph, initial, ordering, params, device=0)
+    opt.optimize()
+    g = opt.linearize().gradientAtZero()
+    scale = max(np.abs(opt.hessian_diagonal()[k]).max() for k in g)
+    assert max(np.abs(v).max() for v in g.values()) < 1e-6 * scale
