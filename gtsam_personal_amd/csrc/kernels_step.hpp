@@ -171,6 +171,11 @@ static_assert(STEP_LDS_BYTES >= PDF_LDS_BYTES, "panel roles reuse the update's L
 struct ChainLink {
   const unsigned int* prev;  // flag region of the finished panel (= of the step before), nullptr for the first step of a chain
   bool publish;              // a later step of the same launch consumes this step's tiles and panel
+  // merged update tile: the task applies the panels of the step before AND of this step in one pass of depth 512 (half the
+  // read-modify-write of C per flop, half the prologues and epilogues: 44 -> 52-56 TFLOP/s stand-alone, tools/syrk4_bench.hip);
+  // the tile it continues is then the one of TWO steps back (prev2: its flag region, nullptr if that step is not in this launch)
+  bool merged = false;
+  const unsigned int* prev2 = nullptr;
 };
 
 // one 64-strip count per 128-column block q of a trailing matrix with S strips
@@ -178,8 +183,11 @@ __device__ __forceinline__ unsigned int chain_pr_need(int S, int q) { return (un
 // wait for the inputs of the update of 128-tile (ti, tj) (or a part of it) of a step with T tile rows and S strips
 __device__ __forceinline__ bool chain_wait_tile(const ChainLink& c, int T, int S, int ti, int tj, int* s_ok) {
   if (!c.prev) return true;
-  const int Tp = T + 2, pi = ti + 2, pj = tj + 2;  // the step before: trailing origin 256 rows / columns earlier
-  const unsigned int* td = c.prev + PDF_TD0 + pi * Tp - pi * (pi - 1) / 2 + (pj - pi);
+  // the tile this one continues: of the step before (trailing origin 256 rows / columns earlier), or of two steps back for a merged task
+  const int back = c.merged ? 4 : 2;
+  const unsigned int* tdr = c.merged ? c.prev2 : c.prev;
+  const int Tp = T + back, pi = ti + back, pj = tj + back;
+  const unsigned int* td = tdr ? tdr + PDF_TD0 + pi * Tp - pi * (pi - 1) / 2 + (pj - pi) : nullptr;
   return pdf_wait3(c.prev + PDF_PR0 + ti, chain_pr_need(S, ti), ti == tj ? nullptr : c.prev + PDF_PR0 + tj, chain_pr_need(S, tj), td, 1u, s_ok,
                    threadIdx.x);
 }
@@ -237,7 +245,10 @@ __device__ __forceinline__ void step_body(const StepArgs& a, int t, const ChainL
     const bool ok = chain_wait_tile(c, T, S, ti, tj, s_ok);
     CHAIN_PROF_WAITED();
     if (!ok && threadIdx.x == 0) atomicExch(a.status + 1, 1 + a.front_id);  // hand-off timed out: a fault, reported apart from pivot failures
-    syrk_tile(a.A, a.ld, a.n, a.p0, a.kp, r0, a.n, ti, tj, sm);
+    if (c.merged)
+      syrk_tile(a.A, a.ld, a.n, a.p0 - 256, a.kp + 256, r0, a.n, ti, tj, sm);  // panels i - 1 and i are consecutive rows: one operand slab of depth 512
+    else
+      syrk_tile(a.A, a.ld, a.n, a.p0, a.kp, r0, a.n, ti, tj, sm);
     if (c.publish) pdf_publish(&a.flags[PDF_TD0 + ti * T - ti * (ti - 1) / 2 + (tj - ti)], threadIdx.x == 0);
     CHAIN_PROF_END(3);
     return;
@@ -274,6 +285,7 @@ __global__ __launch_bounds__(256, 2) void step_kernel(StepArgs a) {
 // with the matrix cores idle.  The schedule instead gives every step about the same number of update tiles: tiles of the
 // early steps that lie far from the diagonal are deferred (earliest deadline first: a tile row must be complete when it
 // becomes the next panel) and fill the late steps; the chain then runs under the update work from the first panel to the last.
+#define CHAIN_TASK_MERGED (1 << 30)  // in tasks[k].x: update tile of step s that also applies the panel of step s - 1 (which then has no task for this tile)
 struct ChainArgs {
   double* A;
   int ld, n, nf;
@@ -294,11 +306,13 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(ChainArgs ca) {
   if (threadIdx.x == 0) s_bid = (int)atomicAdd(&ca.flags[(size_t)(ca.i0 + 1) * PDF_FLAG_WORDS], 1u);
   __syncthreads();
   const int2 task = ca.tasks[s_bid];
-  const int s = task.x, i = ca.i0 + s;
+  const bool merged = (task.x & CHAIN_TASK_MERGED) != 0;
+  const int s = task.x & ~CHAIN_TASK_MERGED, i = ca.i0 + s;
   const int kbn = min(ca.nf, (i + 2) * 256) - (i + 1) * 256;
   StepArgs a{ca.A, ca.ld, ca.n, ca.nf, 256 * i, 256, kbn, ca.front_id, ca.status, ca.inv16 + (size_t)(i + 1) * 4096,
              ca.flags + (size_t)(i + 1) * PDF_FLAG_WORDS, ca.S};
-  const ChainLink c{s > 0 ? ca.flags + (size_t)i * PDF_FLAG_WORDS : nullptr, s + 1 < ca.nsteps};
+  const ChainLink c{s > 0 ? ca.flags + (size_t)i * PDF_FLAG_WORDS : nullptr, s + 1 < ca.nsteps, merged,
+                    (merged && s > 1) ? ca.flags + (size_t)(i - 1) * PDF_FLAG_WORDS : nullptr};
   step_body(a, task.y, c, sm, &s_ok);
 }
 
@@ -326,7 +340,21 @@ namespace lmgpu {
 // dispatched.  Order of dependencies: a unit (s', R) is listed after (s' - 1, R) and in a block s >= s', i.e. after the
 // row-panel workgroups of step s' - 1; head tiles of step s + 1 come after every unit of the rows they read (mandatory below).
 // far_pct = 100: no far rows, plain step order.
-inline std::vector<int2> chain_schedule(int n, int nf, int i0, int nsteps, int far_pct = 100) {
+//
+// merge = true (round 3, the default): update tiles go as PAIRS of steps in one pass of depth 512 (CHAIN_TASK_MERGED).  Stand-alone the
+// tile is bound by what it does per pass, not by the matrix instruction (tools/syrk4_bench.hip: 61-69 TFLOP/s with neither operand
+// fetch nor the read-modify-write of C, 43-44 with both at K = 256, 52-56 at K = 512).  A tile row R lives through the steps
+// 0 .. L = last(R); its units are paired from the END -- (L-1, L), (L-3, L-2), ... and a single unit of step 0 if L + 1 is odd -- so
+// that the last pair is exactly what block L must deliver (rows 2 L + 2, 2 L + 3 are the head rows of step L + 1).  Block s:
+//   A  pairs (s-2, s-1) of every other aligned near row (postponed from block s-1) and the pairs a deferred FAR row owes:
+//      nothing here depends on panel s, so this section runs while the row-panel workgroups of step s-1 finish panel s
+//   head tiles + diagonal workgroups of step s
+//   C  rows whose last step is s: everything they still owe (their final pair)
+//   B  pairs (s-1, s) of the other aligned near rows (row R is aligned in block s when s-1 = L-1 mod 2)
+//   row-panel workgroups of step s
+// Two tasks of one tile are always at least a block apart in the list (a pair takes ~130 us: a dependent task right behind it
+// would hold its slot spinning that long).  A far row idles until it has to deliver one pair per block to finish in block L.
+inline std::vector<int2> chain_schedule(int n, int nf, int i0, int nsteps, int far_pct = 100, bool merge = false) {
   struct StepGeo { int T, S, nTA, nd, nTB, ntrsm; };
   std::vector<StepGeo> g(nsteps);
   for (int s = 0; s < nsteps; s++) {
@@ -344,12 +372,57 @@ inline std::vector<int2> chain_schedule(int n, int nf, int i0, int nsteps, int f
   std::vector<int> next_step(T0 + 2, 0);  // per tile row: the next step whose unit is to be listed
   std::vector<int2> tasks;
   auto last_of = [&](int R) { return std::min(nsteps - 1, (R - 2) / 2); };
-  auto emit_unit = [&](int R) {  // the tiles of step next_step[R] in tile row R
-    const int sp = next_step[R]++, ti = R - 2 * sp, T = g[sp].T;
+  auto emit_tiles = [&](int R, int sp, bool mg) {  // the tiles of tile row R as tasks of step sp (mg: applying the panel of step sp - 1 as well)
+    const int ti = R - 2 * sp, T = g[sp].T;
     int off = g[sp].nTA + g[sp].nd;
     for (int r = 2; r < ti; r++) off += T - r;
-    for (int tj = ti; tj < T; tj++) tasks.push_back(int2{sp, off + (tj - ti)});
+    for (int tj = ti; tj < T; tj++) tasks.push_back(int2{sp | (mg ? CHAIN_TASK_MERGED : 0), off + (tj - ti)});
   };
+  if (merge) {
+    // the next group of row R: a single unit when an odd number of units remains (only ever the first), else a pair
+    auto group_len = [&](int R) { return ((last_of(R) + 1 - next_step[R]) & 1) ? 1 : 2; };
+    auto emit_group = [&](int R) {
+      const int len = group_len(R), a = next_step[R];
+      emit_tiles(R, a + len - 1, len == 2);
+      next_step[R] += len;
+    };
+    // the group's panels are all <= `panel_max`
+    auto available = [&](int R, int panel_max) { return next_step[R] <= last_of(R) && next_step[R] + group_len(R) - 1 <= panel_max; };
+    auto groups_left = [&](int R) { return (last_of(R) + 1 - next_step[R] + 1) / 2; };
+    std::vector<char> postponed(T0 + 2, 0);
+    for (int s = 0; s < nsteps; s++) {
+      // A: no dependence on panel s
+      for (int R = 2 * s + 4; R < T0; R++) {
+        if (R < far_row || last_of(R) - s < 1) {
+          if (postponed[R] && available(R, s - 1)) emit_group(R);
+          postponed[R] = 0;
+        } else if (available(R, s - 1) && groups_left(R) >= last_of(R) - s + 1) {
+          emit_group(R);  // a far row on its final run: one group per block
+        }
+      }
+      for (int t = 0; t < g[s].nTA + g[s].nd; t++) tasks.push_back(int2{s, t});
+      // C: rows that end here
+      for (int R = 2 * s + 2; R < T0; R++)
+        if (last_of(R) == s)
+          while (next_step[R] <= s) emit_group(R);
+      // B: near rows whose next group closes at step s (every other one goes to section A of the next block)
+      int alt = 0;
+      for (int R = 2 * s + 4; R < T0; R++) {
+        if (R >= far_row && last_of(R) - s >= 1) continue;
+        if (last_of(R) <= s) continue;
+        if (available(R, s) && next_step[R] + group_len(R) - 1 == s) {
+          if ((alt++ & 1) && s + 1 < nsteps && last_of(R) > s + 1)
+            postponed[R] = 1;
+          else
+            emit_group(R);
+        }
+      }
+      const int first_trsm = g[s].nTA + g[s].nd + g[s].nTB;
+      for (int t = 0; t < g[s].ntrsm; t++) tasks.push_back(int2{s, first_trsm + t});
+    }
+    return tasks;
+  }
+  auto emit_unit = [&](int R) { emit_tiles(R, next_step[R]++, false); };  // the tiles of step next_step[R] in tile row R
   auto pending = [&](int R, int s) { return next_step[R] <= std::min(s, last_of(R)); };  // a unit of row R that block s may list
   auto far_need = [&](int R, int s) { return last_of(R) + 1 - 2 * (last_of(R) - s); };   // units a far row must have after block s
   for (int s = 0; s < nsteps; s++) {

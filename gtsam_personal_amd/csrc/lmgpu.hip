@@ -218,6 +218,7 @@ struct lmgpu_handle {
   bool no_fuse = false;                        // LMGPU_NO_FUSE=1: trailing update and next panel as separate launches (A/B)
   struct ChainPlan { int i0 = -1, nsteps = 0, ntasks = 0; int2* d_tasks = nullptr; double flop = 0; };
   std::map<int, std::vector<ChainPlan>> chain_plans;  // per HBM front: ticket order of its chained launch(es) (built at first use)
+  bool chain_merge = true;                     // LMGPU_NO_MERGE: update tiles one step per pass instead of pairs of steps (chain_schedule)
   int chain_far_pct = 50;                      // LMGPU_CHAIN_FAR: tile rows beyond this percentage of the front are scheduled late (chain_schedule)
   double* d_lambda = nullptr;   // damping parameter of the solve being queued (device memory: see do_solve_enqueue)
   bool merge_backsub = false;   // LDS fronts of consecutive levels in one dataflow launch (deep trees; LMGPU_MERGE_BACKSUB=0/1)
@@ -835,7 +836,7 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
                 const int is = at + q, ms = F.n - (is + 1) * NBO;
                 cp.flop += 2.0 * NBO * ((double)ms * (ms + 1) / 2.0) + panel_flop(is + 1);
               }
-              const std::vector<int2> tasks = chain_schedule(F.n, F.nf, cp.i0, cp.nsteps, h->chain_far_pct);
+              const std::vector<int2> tasks = chain_schedule(F.n, F.nf, cp.i0, cp.nsteps, h->chain_far_pct, h->chain_merge);
               cp.ntasks = (int)tasks.size();
               HIPCHECK(hipMalloc((void**)&cp.d_tasks, tasks.size() * sizeof(int2)));
               HIPCHECK(hipMemcpyAsync(cp.d_tasks, tasks.data(), tasks.size() * sizeof(int2), hipMemcpyHostToDevice, s));
@@ -1481,6 +1482,7 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
   h->no_wide16 = getenv("LMGPU_NO_WIDE16") != nullptr;
   h->bsd_ticket = getenv("LMGPU_BSD_TICKET") != nullptr;
   h->no_gather_write = getenv("LMGPU_NO_GATHER_WRITE") != nullptr;
+  if (getenv("LMGPU_NO_MERGE")) h->chain_merge = false;
   if (const char* e = getenv("LMGPU_CHAIN_FAR")) h->chain_far_pct = std::max(10, std::min(100, atoi(e)));
   *out = h;
   if (h->device >= 0) {
@@ -2812,10 +2814,13 @@ int lmgpu_local_group_create(int32_t world_size, lmgpu_local_group** out) {
 // step exactly once, and every dependency step_body waits for at an earlier ticket.  0 = valid, else the 1-based ticket at fault.
 int lmgpu_selftest_chain_schedule(int n, int nf, int i0, int nsteps, int far_pct) {
   if (nsteps < 1 || n <= nf || nf < (i0 + nsteps + 1) * 256 - 255) return -1;
-  const std::vector<int2> tasks = chain_schedule(n, nf, i0, nsteps, far_pct);
+  const bool merge = far_pct >= 1000;  // far_pct + 1000: the schedule with merged pairs of steps
+  if (merge) far_pct -= 1000;
+  const std::vector<int2> tasks = chain_schedule(n, nf, i0, nsteps, far_pct, merge);
   struct Geo { int T, S, nHead, nTA, nd, nTB, ntrsm, grid; };
   std::vector<Geo> g(nsteps);
   std::vector<std::vector<int>> pos(nsteps);
+  std::vector<std::vector<char>> pair_tail(nsteps);  // the update tile's task of this step also applied the step before
   long total = 0;
   for (int s = 0; s < nsteps; s++) {
     const int i = i0 + s, m = n - (i + 1) * 256, kbn = std::min(nf, (i + 2) * 256) - (i + 1) * 256;
@@ -2831,19 +2836,42 @@ int lmgpu_selftest_chain_schedule(int n, int nf, int i0, int nsteps, int far_pct
     G.grid = step_grid(m, kbn);
     if (G.grid != G.nTA + G.nd + G.nTB + G.ntrsm) return -1;
     pos[s].assign(G.grid, -1);
+    pair_tail[s].assign(G.grid, 0);
     total += G.grid;
-  }
-  if ((long)tasks.size() != total) return -2;
-  for (size_t k = 0; k < tasks.size(); k++) {
-    const int s = tasks[k].x, t = tasks[k].y;
-    if (s < 0 || s >= nsteps || t < 0 || t >= g[s].grid || pos[s][t] >= 0) return (int)k + 1;
-    pos[s][t] = (int)k;
   }
   auto tb_index = [&](int s, int ti, int tj) {  // logical workgroup of update tile (ti, tj), ti >= 2
     int off = g[s].nTA + g[s].nd;
     for (int r = 2; r < ti; r++) off += g[s].T - r;
     return off + (tj - ti);
   };
+  auto tb_tile = [&](int s, int t, int* ti, int* tj) {
+    int rem = t - g[s].nTA - g[s].nd;
+    *ti = 2;
+    while (rem >= g[s].T - *ti) {
+      rem -= g[s].T - *ti;
+      (*ti)++;
+    }
+    *tj = *ti + rem;
+  };
+  long covered = 0;
+  for (size_t k = 0; k < tasks.size(); k++) {
+    const bool mg = (tasks[k].x & CHAIN_TASK_MERGED) != 0;
+    const int s = tasks[k].x & ~CHAIN_TASK_MERGED, t = tasks[k].y;
+    if (s < 0 || s >= nsteps || t < 0 || t >= g[s].grid || pos[s][t] >= 0) return (int)k + 1;
+    pos[s][t] = (int)k;
+    covered++;
+    if (mg) {  // only update tiles pair up, and the pair's first half is the same tile one step earlier
+      if (!merge || s < 1 || t < g[s].nTA + g[s].nd || t >= g[s].nTA + g[s].nd + g[s].nTB) return (int)k + 1;
+      int ti, tj;
+      tb_tile(s, t, &ti, &tj);
+      const int tp = tb_index(s - 1, ti + 2, tj + 2);
+      if (pos[s - 1][tp] >= 0) return (int)k + 1;
+      pos[s - 1][tp] = (int)k;
+      pair_tail[s][t] = 1;
+      covered++;
+    }
+  }
+  if (covered != total) return -2;
   for (int s = 0; s < nsteps; s++) {
     const Geo& G = g[s];
     int last_prev_trsm = -1, last_ta = -1, last_diag = -1;
@@ -2869,19 +2897,15 @@ int lmgpu_selftest_chain_schedule(int n, int nf, int i0, int nsteps, int far_pct
       } else if (t < G.nTA + G.nd) {
         if (me < last_ta) return me + 1;  // diagonal workgroups read the head tiles
       } else if (t < G.nTA + G.nd + G.nTB) {
-        int rem = t - G.nTA - G.nd;
-        ti = 2;
-        while (rem >= G.T - ti) {
-          rem -= G.T - ti;
-          ti++;
-        }
-        tj = ti + rem;
+        tb_tile(s, t, &ti, &tj);
       } else {
         if (me < last_ta || me < last_diag) return me + 1;  // row-panel workgroups read head tiles and diagonal tiles
       }
       if (ti >= 0 && s > 0) {
+        // the finished panel of this step -- for the first half of a pair this is implied by the second half's wait (panels finish in order)
         if (me < last_prev_trsm) return me + 1;
-        if (me < pos[s - 1][tb_index(s - 1, ti + 2, tj + 2)]) return me + 1;
+        const int before = pos[s - 1][tb_index(s - 1, ti + 2, tj + 2)];
+        if (pair_tail[s][t] ? before != me : me <= before) return me + 1;  // the tile this one continues (or is paired with)
       }
     }
   }

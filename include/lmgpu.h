@@ -267,7 +267,8 @@ int lmgpu_marginal_covariance(lmgpu_handle* h, int32_t slot, double* cov /* dim 
 int lmgpu_joint_marginal_covariance(lmgpu_handle* h, int32_t nslots, const int32_t* slots, double* cov /* D x D */);
 
 /* Host-only self-test (no GPU work): the ticket order the library gives the chained factorisation launch of a dense front
- * with n columns (nf frontal) for the steps i0 .. i0 + nsteps - 1 (tile rows beyond far_pct percent scheduled late) is a permutation of all logical workgroups in which every
+ * with n columns (nf frontal) for the steps i0 .. i0 + nsteps - 1 (tile rows beyond far_pct percent scheduled late; far_pct + 1000: the
+ * default schedule, whose update tiles apply two steps per pass) is a permutation of all logical workgroups in which every
  * in-launch dependency points to an earlier ticket.  0 = valid.  No reference counterpart (the reference factors a front with
  * one Eigen LLT call, gtsam/base/cholesky.cpp:108-159); it exists so that the CPU test-suite can check the scheduler. */
 int lmgpu_selftest_chain_schedule(int n, int nf, int i0, int nsteps, int far_pct);

@@ -45,7 +45,7 @@ def test_launch_forms_agree_on_a_large_root(monkeypatch):
 
     def run(env):
         for k in ("LMGPU_NO_FUSE", "LMGPU_PANEL_2L", "LMGPU_NO_CHAIN", "LMGPU_CHAIN_FAR", "LMGPU_NO_TAIL", "LMGPU_NO_GATHER_WRITE", "LMGPU_NO_INV16_REUSE",
-                  "LMGPU_NO_LEAFPACK"):
+                  "LMGPU_NO_LEAFPACK", "LMGPU_NO_MERGE"):
             monkeypatch.delenv(k, raising=False)
         for k in env:
             monkeypatch.setenv(k, "100" if k == "LMGPU_CHAIN_FAR" else "1")  # CHAIN_FAR=100: plain step order in the chained launch
@@ -63,7 +63,7 @@ def test_launch_forms_agree_on_a_large_root(monkeypatch):
     assert base[1][-1][0] < 0.05 * base[0]
     # (+ the remaining A/B switches of this front: the end of the front as separate launches, the gather adding into a cleared front
     #  instead of writing it, the 16x16 inverses recomputed for the back-substitution, LDS-front descriptors unpacked)
-    for env in (["LMGPU_CHAIN_FAR"], ["LMGPU_NO_CHAIN"], ["LMGPU_NO_FUSE"], ["LMGPU_PANEL_2L"], ["LMGPU_NO_FUSE", "LMGPU_PANEL_2L"], ["LMGPU_NO_TAIL"],
+    for env in (["LMGPU_CHAIN_FAR"], ["LMGPU_NO_MERGE"], ["LMGPU_NO_MERGE", "LMGPU_CHAIN_FAR"], ["LMGPU_NO_CHAIN"], ["LMGPU_NO_FUSE"], ["LMGPU_PANEL_2L"], ["LMGPU_NO_FUSE", "LMGPU_PANEL_2L"], ["LMGPU_NO_TAIL"],
                 ["LMGPU_NO_GATHER_WRITE"], ["LMGPU_NO_INV16_REUSE"], ["LMGPU_NO_LEAFPACK"]):
         other = run(env)
         assert other[0] == base[0]
@@ -72,7 +72,9 @@ def test_launch_forms_agree_on_a_large_root(monkeypatch):
         rel = np.linalg.norm(other[2] - base[2]) / np.linalg.norm(base[2])
         # (the last four change the ORDER of a few sums -- the tail kernel adds the last 40 columns' update in plain fused multiply-adds, the
         #  gather subtracts from a front that already holds the own factors instead of writing first -- and get rounding-level room)
-        loose = env[0] in ("LMGPU_NO_TAIL", "LMGPU_NO_GATHER_WRITE", "LMGPU_NO_INV16_REUSE", "LMGPU_NO_LEAFPACK")
+        #  the chained launch applies the update two panels per pass (one sum of depth 512 instead of two of depth 256), which every form
+        #  that updates panel by panel rounds differently.  Only another ticket order of the same passes is held to 1e-9.
+        loose = env != ["LMGPU_CHAIN_FAR"]
         assert rel < (5e-8 if loose else 1e-9), (env, rel)
 
 
