@@ -111,8 +111,11 @@ __device__ __forceinline__ void glds_row(const double* g, double* lds_row) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_row, 16, 0, 0);
 }
 
+// Sadd != nullptr (multi-rank, rows of the next panel): the tile also receives its so far separate assembled contributions,
+// C += Sadd - P^T P (same layout as A)
+template <bool HAS_S = false>
 __device__ __forceinline__ void syrk_tile(double* __restrict__ A, int ld, int n, int p0, int kp, int r0, int r1, int ti, int tj,
-                                          double* sm /* [2 stages][2 operands][SYRK_KC][SYRK_LDW] */) {
+                                          double* sm /* [2 stages][2 operands][SYRK_KC][SYRK_LDW] */, const double* __restrict__ Sadd = nullptr) {
   if (tj < ti) return;
   const int it0 = r0 + ti * 128, jt0 = r0 + tj * 128;  // tile origins
   if (it0 >= r1 || jt0 >= n) return;
@@ -182,6 +185,14 @@ __device__ __forceinline__ void syrk_tile(double* __restrict__ A, int ld, int n,
       for (int b = 0; b < 4; b++)
 #pragma unroll
         for (int r = 0; r < 4; r++) c[b][r] = A[(size_t)(i0 + a * 16 + kk + 4 * r) * ld + j0 + b * 16 + cc];
+      if constexpr (HAS_S) {
+        if (Sadd) {
+#pragma unroll
+          for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) c[b][r] += Sadd[(size_t)(i0 + a * 16 + kk + 4 * r) * ld + j0 + b * 16 + cc];
+        }
+      }
 #pragma unroll
       for (int b = 0; b < 4; b++)
 #pragma unroll
@@ -197,6 +208,9 @@ __device__ __forceinline__ void syrk_tile(double* __restrict__ A, int ld, int n,
         for (int r = 0; r < 4; r++) {  // clamped (always mapped) address; the value is only used where valid
           const int row = min(i0 + a * 16 + kk + 4 * r, r1 - 1), col = min(j0 + b * 16 + cc, n - 1);
           c[b][r] = A[(size_t)row * ld + col];
+          if constexpr (HAS_S) {
+            if (Sadd) c[b][r] += Sadd[(size_t)row * ld + col];
+          }
         }
 #pragma unroll
       for (int b = 0; b < 4; b++)

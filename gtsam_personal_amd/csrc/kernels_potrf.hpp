@@ -511,8 +511,8 @@ __global__ __launch_bounds__(256) void front_tail_kernel(double* __restrict__ A,
 #define PDF_LDS_BYTES (PDF_LDS_DOUBLES * 8)
 
 // publications a finished column strip sj of the next panel's rows has received (kernels_step.hpp): strips 0..3 are cut into
-// 32x32 quadrant workgroups (sj + 1 sub-tiles x 4), the others into four 64x64 sub-tiles
-__host__ __device__ inline unsigned int pdf_ta_need(int sj) { return sj < 4 ? 4u * (unsigned int)(sj + 1) : 4u; }
+// 32x32 quadrant workgroups (sj + 1 sub-tiles x 4), the others belong to the two 128x128 tiles (tile rows 0 and 1) of their tile column
+__host__ __device__ inline unsigned int pdf_ta_need(int sj) { return sj < 4 ? 4u * (unsigned int)(sj + 1) : 2u; }
 
 // all threads call; thread 0 waits until flags[w] >= need for the (up to two) words given, then one acquire covers the workgroup
 __device__ __forceinline__ bool pdf_wait(unsigned int* flags, int w0, unsigned int need0, int w1, unsigned int need1, int* s_ok, int tid) {
@@ -573,6 +573,18 @@ __device__ __forceinline__ void pdf_publish(unsigned int* flag, bool signaller) 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// the same for a workgroup that completes two flags at once (flag1 may be nullptr)
+__device__ __forceinline__ void pdf_publish2(unsigned int* flag0, unsigned int* flag1, bool signaller) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (signaller) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(flag0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (flag1) __hip_atomic_fetch_add(flag1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

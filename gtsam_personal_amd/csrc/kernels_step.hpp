@@ -156,7 +156,11 @@ __device__ __forceinline__ void syrk_quadrant32(double* __restrict__ A, int ld, 
 
 // workgroups of a step launch that factors a next panel: shared by the kernel and its launchers
 __host__ __device__ inline int step_head_units(int S) { return S >= 4 ? 10 : S * (S + 1) / 2; }  // 64x64 sub-tiles of strips 0..3
-__host__ __device__ inline int step_ta_workgroups(int S) { return 4 * step_head_units(S) + (S > 4 ? 4 * (S - 4) : 0); }
+// + beyond strip 3 the two 128x128 tiles (tile rows 0, 1) of every tile column from 2 on.  (Through round 2 these rows went as four 64x64
+// sub-tile workgroups per strip, operands straight from the L2: in-kernel stamps showed them taking 20 % of all slot-time of the chained
+// launch -- 9 112 workgroups of the C4 root at 64 GFLOP/s each, waiting as long as they worked -- for 5 % of its flop; only strips 0..3
+// gate the diagonal workgroups, the row-panel workgroups need theirs a whole diagonal chain later.)
+__host__ __device__ inline int step_ta_workgroups(int S) { return 4 * step_head_units(S) + (S > 4 ? 2 * ((S + 1) / 2 - 2) : 0); }
 __host__ inline int step_grid(int m, int kbn) {
   const int T = (m + 127) / 128, S = (m + 63) / 64;
   return T * (T + 1) / 2 - (T >= 2 ? 2 * T - 1 : T) + step_ta_workgroups(S) + kbn / 64 + (m - kbn + 63) / 64;
@@ -205,26 +209,27 @@ __device__ __forceinline__ void step_body(const StepArgs& a, int t, const ChainL
   const int nTArows = next ? (T >= 2 ? 2 * T - 1 : T) : 0;  // 128x128 tiles they replace
   const int nd = next ? (a.kb_next >> 6) : 0;
   const int nTiles = T * (T + 1) / 2;
-  if (t < nTA) {
-    int si, sj;
-    if (t < nHead) {
-      const int u = t >> 2;
-      sj = (u >= 6) ? 3 : ((u >= 3) ? 2 : (u >= 1 ? 1 : 0));
-      si = u - sj * (sj + 1) / 2;
-      __builtin_amdgcn_s_setprio(2);
-    } else {
-      sj = 4 + ((t - nHead) >> 2);
-      si = (t - nHead) & 3;
-    }
+  if (t < nHead) {
+    const int u = t >> 2;
+    const int sj = (u >= 6) ? 3 : ((u >= 3) ? 2 : (u >= 1 ? 1 : 0));
+    const int si = u - sj * (sj + 1) / 2;
+    __builtin_amdgcn_s_setprio(2);
     const bool ok = chain_wait_tile(c, T, S, si >> 1, sj >> 1, s_ok);
     CHAIN_PROF_WAITED();
     if (!ok && threadIdx.x == 0) atomicExch(a.status + 1, 1 + a.front_id);  // hand-off timed out: a fault, reported apart from pivot failures
-    if (t < nHead)
-      syrk_quadrant32(a.A, a.ld, a.n, a.p0, a.kp, r0, si, sj, t & 3, a.S);
-    else
-      syrk_subtile64(a.A, a.ld, a.n, a.p0, a.kp, r0, si, sj, a.S);
+    syrk_quadrant32(a.A, a.ld, a.n, a.p0, a.kp, r0, si, sj, t & 3, a.S);
     pdf_publish(&a.flags[PDF_TA0 + sj], threadIdx.x == 0);
-    CHAIN_PROF_END(t < nHead ? 0 : 1);
+    CHAIN_PROF_END(0);
+    return;
+  }
+  if (t < nTA) {  // the rest of the next panel's rows: tile rows 0 and 1, tile columns 2 ..
+    const int u = t - nHead, ti = u & 1, tj = 2 + (u >> 1);
+    const bool ok = chain_wait_tile(c, T, S, ti, tj, s_ok);
+    CHAIN_PROF_WAITED();
+    if (!ok && threadIdx.x == 0) atomicExch(a.status + 1, 1 + a.front_id);
+    syrk_tile<true>(a.A, a.ld, a.n, a.p0, a.kp, r0, a.n, ti, tj, sm, a.S);
+    pdf_publish2(&a.flags[PDF_TA0 + 2 * tj], 2 * tj + 1 < S ? &a.flags[PDF_TA0 + 2 * tj + 1] : nullptr, threadIdx.x == 0);
+    CHAIN_PROF_END(1);
     return;
   }
   t -= nTA;
@@ -346,15 +351,18 @@ namespace lmgpu {
 // fetch nor the read-modify-write of C, 43-44 with both at K = 256, 52-56 at K = 512).  A tile row R lives through the steps
 // 0 .. L = last(R); its units are paired from the END -- (L-1, L), (L-3, L-2), ... and a single unit of step 0 if L + 1 is odd -- so
 // that the last pair is exactly what block L must deliver (rows 2 L + 2, 2 L + 3 are the head rows of step L + 1).  Block s:
-//   A  pairs (s-2, s-1) of every other aligned near row (postponed from block s-1) and the pairs a deferred FAR row owes:
-//      nothing here depends on panel s, so this section runs while the row-panel workgroups of step s-1 finish panel s
 //   head tiles + diagonal workgroups of step s
-//   C  rows whose last step is s: everything they still owe (their final pair)
-//   B  pairs (s-1, s) of the other aligned near rows (row R is aligned in block s when s-1 = L-1 mod 2)
-//   row-panel workgroups of step s
-// Two tasks of one tile are always at least a block apart in the list (a pair takes ~130 us: a dependent task right behind it
-// would hold its slot spinning that long).  A far row idles until it has to deliver one pair per block to finish in block L.
-inline std::vector<int2> chain_schedule(int n, int nf, int i0, int nsteps, int far_pct = 100, bool merge = false) {
+//   X1 = the first split_pct percent of the block's update tasks, starting with the rows whose last step is s (their final pair: the
+//        next step's head tiles read them)
+//   row-panel workgroups of step s -- behind enough update work that the diagonal chain (~100-160 us) is mostly done when they are
+//        drawn: drawn right behind the diagonal workgroups they hold ~130 slots spinning on it (in-kernel stamps: 11 % of all slot-time)
+//   X2 = the rest of the update tasks: what runs while the row-panel workgroups finish panel s + 1, so that the head tiles of step
+//        s + 1 find it complete
+// The update tasks of a block: the pairs (s-1, s) of the aligned near rows (row R is aligned in block s when s = L mod 2), every other
+// one postponed to the next block, and the pairs a deferred FAR row owes.  Two tasks of one tile are always about a block apart in the
+// list (a pair takes ~120 us: a dependent task right behind it would hold its slot spinning that long).  A far row idles until it has
+// to deliver one pair per block to finish in block L.
+inline std::vector<int2> chain_schedule(int n, int nf, int i0, int nsteps, int far_pct = 100, bool merge = false, int split_pct = 60) {
   struct StepGeo { int T, S, nTA, nd, nTB, ntrsm; };
   std::vector<StepGeo> g(nsteps);
   for (int s = 0; s < nsteps; s++) {
@@ -390,35 +398,40 @@ inline std::vector<int2> chain_schedule(int n, int nf, int i0, int nsteps, int f
     auto available = [&](int R, int panel_max) { return next_step[R] <= last_of(R) && next_step[R] + group_len(R) - 1 <= panel_max; };
     auto groups_left = [&](int R) { return (last_of(R) + 1 - next_step[R] + 1) / 2; };
     std::vector<char> postponed(T0 + 2, 0);
+    std::vector<int2> head, upd;
     for (int s = 0; s < nsteps; s++) {
-      // A: no dependence on panel s
-      for (int R = 2 * s + 4; R < T0; R++) {
-        if (R < far_row || last_of(R) - s < 1) {
-          if (postponed[R] && available(R, s - 1)) emit_group(R);
-          postponed[R] = 0;
-        } else if (available(R, s - 1) && groups_left(R) >= last_of(R) - s + 1) {
-          emit_group(R);  // a far row on its final run: one group per block
-        }
-      }
-      for (int t = 0; t < g[s].nTA + g[s].nd; t++) tasks.push_back(int2{s, t});
-      // C: rows that end here
+      // the block's update tasks into `upd`: C first (the next step's head tiles read those rows), then A and B interleaved row by row
+      std::swap(head, tasks);  // (emit_* append to `tasks`)
+      tasks.clear();
       for (int R = 2 * s + 2; R < T0; R++)
         if (last_of(R) == s)
           while (next_step[R] <= s) emit_group(R);
-      // B: near rows whose next group closes at step s (every other one goes to section A of the next block)
       int alt = 0;
       for (int R = 2 * s + 4; R < T0; R++) {
-        if (R >= far_row && last_of(R) - s >= 1) continue;
         if (last_of(R) <= s) continue;
-        if (available(R, s) && next_step[R] + group_len(R) - 1 == s) {
-          if ((alt++ & 1) && s + 1 < nsteps && last_of(R) > s + 1)
-            postponed[R] = 1;
+        if (R >= far_row && last_of(R) - s >= 1) {
+          if (available(R, s - 1) && groups_left(R) >= last_of(R) - s + 1) emit_group(R);  // a far row on its final run: one group per block
+          continue;
+        }
+        if (postponed[R]) {
+          if (available(R, s - 1)) emit_group(R);
+          postponed[R] = 0;
+        } else if (available(R, s) && next_step[R] + group_len(R) - 1 == s) {
+          if ((alt++ & 1) && last_of(R) > s + 1)
+            postponed[R] = 1;  // every other aligned near row delivers this group in the next block: two blocks' worth of rows to draw from
           else
             emit_group(R);
         }
       }
+      std::swap(upd, tasks);
+      std::swap(head, tasks);
+      for (int t = 0; t < g[s].nTA + g[s].nd; t++) tasks.push_back(int2{s, t});
+      const size_t cut = upd.size() * (size_t)split_pct / 100;
+      tasks.insert(tasks.end(), upd.begin(), upd.begin() + cut);
       const int first_trsm = g[s].nTA + g[s].nd + g[s].nTB;
       for (int t = 0; t < g[s].ntrsm; t++) tasks.push_back(int2{s, first_trsm + t});
+      tasks.insert(tasks.end(), upd.begin() + cut, upd.end());
+      upd.clear();
     }
     return tasks;
   }

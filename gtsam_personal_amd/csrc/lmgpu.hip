@@ -218,6 +218,7 @@ struct lmgpu_handle {
   bool no_fuse = false;                        // LMGPU_NO_FUSE=1: trailing update and next panel as separate launches (A/B)
   struct ChainPlan { int i0 = -1, nsteps = 0, ntasks = 0; int2* d_tasks = nullptr; double flop = 0; };
   std::map<int, std::vector<ChainPlan>> chain_plans;  // per HBM front: ticket order of its chained launch(es) (built at first use)
+  int chain_split_pct = 60;                    // LMGPU_CHAIN_SPLIT (development): share of a block's update tasks listed in front of its row-panel workgroups
   bool chain_merge = true;                     // LMGPU_NO_MERGE: update tiles one step per pass instead of pairs of steps (chain_schedule)
   int chain_far_pct = 50;                      // LMGPU_CHAIN_FAR: tile rows beyond this percentage of the front are scheduled late (chain_schedule)
   double* d_lambda = nullptr;   // damping parameter of the solve being queued (device memory: see do_solve_enqueue)
@@ -836,7 +837,7 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
                 const int is = at + q, ms = F.n - (is + 1) * NBO;
                 cp.flop += 2.0 * NBO * ((double)ms * (ms + 1) / 2.0) + panel_flop(is + 1);
               }
-              const std::vector<int2> tasks = chain_schedule(F.n, F.nf, cp.i0, cp.nsteps, h->chain_far_pct, h->chain_merge);
+              const std::vector<int2> tasks = chain_schedule(F.n, F.nf, cp.i0, cp.nsteps, h->chain_far_pct, h->chain_merge, h->chain_split_pct);
               cp.ntasks = (int)tasks.size();
               HIPCHECK(hipMalloc((void**)&cp.d_tasks, tasks.size() * sizeof(int2)));
               HIPCHECK(hipMemcpyAsync(cp.d_tasks, tasks.data(), tasks.size() * sizeof(int2), hipMemcpyHostToDevice, s));
@@ -1483,6 +1484,7 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
   h->bsd_ticket = getenv("LMGPU_BSD_TICKET") != nullptr;
   h->no_gather_write = getenv("LMGPU_NO_GATHER_WRITE") != nullptr;
   if (getenv("LMGPU_NO_MERGE")) h->chain_merge = false;
+  if (const char* e = getenv("LMGPU_CHAIN_SPLIT")) h->chain_split_pct = std::max(0, std::min(100, atoi(e)));
   if (const char* e = getenv("LMGPU_CHAIN_FAR")) h->chain_far_pct = std::max(10, std::min(100, atoi(e)));
   *out = h;
   if (h->device >= 0) {
@@ -2814,9 +2816,14 @@ int lmgpu_local_group_create(int32_t world_size, lmgpu_local_group** out) {
 // step exactly once, and every dependency step_body waits for at an earlier ticket.  0 = valid, else the 1-based ticket at fault.
 int lmgpu_selftest_chain_schedule(int n, int nf, int i0, int nsteps, int far_pct) {
   if (nsteps < 1 || n <= nf || nf < (i0 + nsteps + 1) * 256 - 255) return -1;
-  const bool merge = far_pct >= 1000;  // far_pct + 1000: the schedule with merged pairs of steps
-  if (merge) far_pct -= 1000;
-  const std::vector<int2> tasks = chain_schedule(n, nf, i0, nsteps, far_pct, merge);
+  int split_pct = 60;
+  if (far_pct >= 100000) {  // + 100000 x (split_pct + 1): another share of the update tasks in front of the row-panel workgroups
+    split_pct = far_pct / 100000 - 1;
+    far_pct %= 100000;
+  }
+  const bool merge2 = far_pct >= 1000;
+  if (merge2) far_pct -= 1000;
+  const std::vector<int2> tasks = chain_schedule(n, nf, i0, nsteps, far_pct, merge2, split_pct);
   struct Geo { int T, S, nHead, nTA, nd, nTB, ntrsm, grid; };
   std::vector<Geo> g(nsteps);
   std::vector<std::vector<int>> pos(nsteps);
@@ -2861,7 +2868,7 @@ int lmgpu_selftest_chain_schedule(int n, int nf, int i0, int nsteps, int far_pct
     pos[s][t] = (int)k;
     covered++;
     if (mg) {  // only update tiles pair up, and the pair's first half is the same tile one step earlier
-      if (!merge || s < 1 || t < g[s].nTA + g[s].nd || t >= g[s].nTA + g[s].nd + g[s].nTB) return (int)k + 1;
+      if (!merge2 || s < 1 || t < g[s].nTA + g[s].nd || t >= g[s].nTA + g[s].nd + g[s].nTB) return (int)k + 1;
       int ti, tj;
       tb_tile(s, t, &ti, &tj);
       const int tp = tb_index(s - 1, ti + 2, tj + 2);
@@ -2888,12 +2895,12 @@ int lmgpu_selftest_chain_schedule(int n, int nf, int i0, int nsteps, int far_pct
           const int u = t >> 2;
           sj = (u >= 6) ? 3 : ((u >= 3) ? 2 : (u >= 1 ? 1 : 0));
           si = u - sj * (sj + 1) / 2;
+          ti = si >> 1;
+          tj = sj >> 1;
         } else {
-          sj = 4 + ((t - G.nHead) >> 2);
-          si = (t - G.nHead) & 3;
+          ti = (t - G.nHead) & 1;
+          tj = 2 + ((t - G.nHead) >> 1);
         }
-        ti = si >> 1;
-        tj = sj >> 1;
       } else if (t < G.nTA + G.nd) {
         if (me < last_ta) return me + 1;  // diagonal workgroups read the head tiles
       } else if (t < G.nTA + G.nd + G.nTB) {

@@ -104,12 +104,13 @@ def test_fronts_match_oracle_pose2_grid_all_orderings():
         _structure_matches(graph, initial, ordering)
 
 
-@pytest.mark.parametrize("far_pct", [100, 70, 55, 30, 10, 1100, 1070, 1050, 1030, 1010])
+@pytest.mark.parametrize("far_pct", [100, 70, 55, 30, 10, 1100, 1070, 1050, 1030, 1010, 101050, 10101050, 3101030, 8101100])
 def test_chained_launch_ticket_order_is_a_topological_order(far_pct):
     """The chained factorisation launch of a dense front (kernels_step.hpp) hands its logical workgroups out by ticket; a
     workgroup spins for workgroups it depends on, so every dependency must hold an earlier ticket or the launch could hang.
     The library checks its own schedule on the host (no GPU): every workgroup of every step exactly once, dependencies
-    earlier.  far_pct + 1000 = the schedule that applies the update in pairs of steps (one pass of depth 512 per pair).  Front shapes: the C4 root (9001 x 9001), the 600-camera root, separator-heavy and small fronts."""
+    earlier.  far_pct + 1000 = the schedule that applies the update in pairs of steps (one pass of depth 512 per pair);
+    + 100000 (p + 1): with p percent (instead of 60) of a block's update tasks in front of its row-panel workgroups.  Front shapes: the C4 root (9001 x 9001), the 600-camera root, separator-heavy and small fronts."""
     lib = _lib.load()
     checked = 0
     for n, nf in [(9001, 9000), (5401, 5400), (2000, 1500), (1081, 1080), (30000, 29000), (10000, 4000), (777, 770), (4097, 4096)]:

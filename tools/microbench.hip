@@ -119,8 +119,9 @@ int main(int argc, char** argv) {
     }
     printf("%-44s best %9.1f us   avg %9.1f us\n", name, best * 1e3, tot / reps * 1e3);
   };
+  const bool chain_only = argc > 3;  // microbench <n> <far_pct> <merge 0|1>: only the chained launch
   // 1. one outer panel as a dataflow launch: duration and the phase stamps of the four diagonal workgroups
-  {
+  if (!chain_only) {
     unsigned int* flags;
     double* inv16;
     CK(hipMalloc((void**)&flags, PDF_FLAG_WORDS * 4));
@@ -159,7 +160,7 @@ int main(int argc, char** argv) {
     }
   }
   // 2. the fused step launch (update with panel at p0 + factorisation of the next panel) with the same stamps
-  {
+  if (!chain_only) {
     unsigned int* flags;
     double* inv16;
     CK(hipMalloc((void**)&flags, PDF_FLAG_WORDS * 4));
@@ -215,7 +216,7 @@ int main(int argc, char** argv) {
     for (int first : {0, 17}) {
       int nsteps = 0;
       while (first + nsteps + 1 < np && rows_of(first + nsteps) == 256 && rows_of(first + nsteps + 1) % 64 == 0 && n - (first + nsteps + 1) * 256 > 0) nsteps++;
-      const std::vector<int2> tasks = chain_schedule(n, n - 1, first, nsteps, argc > 2 ? atoi(argv[2]) : 50);
+      const std::vector<int2> tasks = chain_schedule(n, n - 1, first, nsteps, argc > 2 ? atoi(argv[2]) : 50, argc > 3 ? atoi(argv[3]) != 0 : true);
       int2* d_tasks;
       CK(hipMalloc((void**)&d_tasks, tasks.size() * sizeof(int2)));
       CK(hipMemcpy(d_tasks, tasks.data(), tasks.size() * sizeof(int2), hipMemcpyHostToDevice));
@@ -281,6 +282,7 @@ int main(int argc, char** argv) {
       }
     }
   }
+  if (chain_only) return 0;
   // 3. strip updates (K = 64, <= 192 rows) and big updates (K = 256) at several trailing sizes
   for (int r0 : {64, 4160, 8256}) {
     char nm[128];
