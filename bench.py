@@ -27,51 +27,81 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet FP64 matrix peak (not listed i
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def cpu_baseline(n_cam, n_pt, obs, seed, full_tag=None):
-    """the CPU oracle (a port of the reference's algorithm) timed on a bounded sample of the workload, single thread and with all the
-    host cores this process may use (subtree-parallel elimination + parallel linearize: what the reference does with TBB,
-    gtsam/base/treeTraversal/parallelTraversalTasks.h:78-93, NonlinearFactorGraph.cpp:246-261); beside it the oracle's time on the
-    FULL workload, measured once in the build container when the parity fixture was made (tests/golden/<tag>_timing.json)"""
+# the real reference's own numbers on this workload (libgtsam built from /root/reference in the survey container,
+# Release, no TBB => 1 thread, 8-vCPU Xeon 2.1 GHz; std::chrono around the calls iterate() makes; first LM iteration at lambda = 1e-5)
+REFERENCE_MEASURED = {
+    "source": "BASELINE.md section 2 (survey container: reference GTSAM built from /root/reference, g++ 11.4 -O3, GTSAM_WITH_TBB=OFF => 1 thread, "
+              "8-vCPU Intel Xeon 2.10 GHz; the reference tree does not travel to the GPU box, so these are not re-measured here)",
+    (1000, 100000, 10, 42): [
+        {"ordering": "metis", "ms_per_iteration": 44523.0, "value": 1e3 / 44523.0, "linearize_ms": 964.0, "eliminate_ms": 74233.0, "cores": 1},
+        {"ordering": "schur", "ms_per_iteration": 51087.0, "value": 1e3 / 51087.0, "linearize_ms": 830.0, "eliminate_ms": 51891.0, "cores": 1}],
+    (100, 10000, 10, 42): [
+        {"ordering": "metis", "ms_per_iteration": 947.0, "value": 1e3 / 947.0, "linearize_ms": 72.0, "eliminate_ms": 887.0, "cores": 1},
+        {"ordering": "schur", "ms_per_iteration": 708.0, "value": 1e3 / 708.0, "linearize_ms": 86.1, "eliminate_ms": 844.0, "cores": 1}],
+}
+
+
+def cpu_baseline(graph, initial, ordering, ordering_name, size_key, full_tag=None):
+    """The CPU oracle (oracle/liblm_oracle.so: a port of the reference's algorithm; its dense partial Cholesky blocked like Eigen's LLT)
+    timed on the GPU box's host cores on the SAME workload as the GPU line: `value` = one LevenbergMarquardtOptimizer::iterate() at full size
+    with all the host cores this process may use -- subtree-parallel elimination + parallel linearize (what the reference does with
+    TBB, gtsam/base/treeTraversal/parallelTraversalTasks.h:78-93, NonlinearFactorGraph.cpp:246-261) and, beyond the reference, the rank-128
+    updates of the dense root shared out over the threads (Eigen's LLT is single-threaded whatever GTSAM's TBB setting).  Nested: the
+    oracle's single-thread time on the same workload (build container, cached with the parity fixture), the real reference's own numbers
+    from the survey, and the 1/10-per-dimension sample this line carried in rounds 1-2."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_harness as oh  # the oracle is only ever the baseline / the checker
     from gtsam_personal_amd import LevenbergMarquardtParams
     from gtsam_personal_amd.synthetic import make_bal
-    graph, initial, _, ordering = make_bal(n_cam, n_pt, obs, seed=seed)
     params = LevenbergMarquardtParams()
+    cores = max(1, min(len(os.sched_getaffinity(0)), 16))
 
-    def leg(threads, budget_s):
+    def leg(g, x0, order, threads, dense_threads, budget_s, max_it):
         oh.set_threads(threads)
-        orc = oh.OracleProblem(graph, initial, ordering)
+        oh.set_dense_threads(dense_threads)
+        orc = oh.OracleProblem(g, x0, order)
         orc.lm_init(params)
         times = []
         t_all = time.perf_counter()
-        while len(times) < 3 and (time.perf_counter() - t_all) < budget_s:
+        while len(times) < max_it and (time.perf_counter() - t_all) < budget_s:
             t0 = time.perf_counter()
             orc.lm_iterate(params)
             times.append(time.perf_counter() - t0)
         tm = orc.timings()
         return len(times) / sum(times), times, tm
 
-    cores = max(1, min(len(os.sched_getaffinity(0)), 16))
-    v1, t1, tm1 = leg(1, 12.0)
-    vn, tn, tmn = leg(cores, 12.0) if cores > 1 else (v1, t1, tm1)
-    oh.set_threads(1)
-    out = dict(value=vn, unit="LM iterations/s", cores=cores, kind="port",
-               sample=f"synthetic BAL {n_cam} cameras / {n_pt} points / {graph.size()} factors (1/10 of the GPU workload per dimension), "
-                      f"{len(tn)} LM iterations, oracle/liblm_oracle.so with {cores} threads (subtree-parallel elimination, parallel linearize)",
-               ms_per_iteration=1e3 * sum(tn) / len(tn), linearize_ms=1e3 * tmn["linearize_s"], eliminate_ms=1e3 * tmn["eliminate_s"],
-               single_thread={"value": v1, "cores": 1, "ms_per_iteration": 1e3 * sum(t1) / len(t1), "linearize_ms": 1e3 * tm1["linearize_s"],
-                              "eliminate_ms": 1e3 * tm1["eliminate_s"]})
+    # same workload, all cores (one iteration: ~10-25 s of CPU work)
+    vf, tf, tmf = leg(graph, initial, ordering, cores, cores, 1.0, 1)
+    out = dict(value=vf, unit="LM iterations/s", cores=cores, kind="port",
+               sample=f"the SAME workload as the GPU line ({graph.size()} factors, {ordering_name}), ONE LM iteration (the first, like every GPU step), "
+                      f"oracle/liblm_oracle.so with {cores} threads: subtree-parallel elimination and parallel linearize like the reference's TBB "
+                      f"build, plus (beyond the reference, whose Eigen LLT is single-threaded) the dense root's rank-128 updates on all threads",
+               ms_per_iteration=1e3 * sum(tf) / len(tf), linearize_ms=1e3 * tmf["linearize_s"], eliminate_ms=1e3 * tmf["eliminate_s"])
     if full_tag:
         try:
             with open(os.path.join(ROOT, "tests", "golden", f"{full_tag}_timing.json")) as f:
                 tj = json.load(f)
-            out["same_workload"] = {"what": tj["what"], "workload": tj["workload"],
-                                    "runs": [{"ordering": r["ordering"], "value": 1.0 / r["iterate_s"], "unit": "LM iterations/s", "cores": 1,
-                                              "ms_per_iteration": 1e3 * r["iterate_s"], "linearize_ms": 1e3 * r["linearize_s"],
-                                              "eliminate_ms": 1e3 * r["eliminate_s"]} for r in tj["runs"]]}
+            out["single_thread_same_workload"] = {"what": tj["what"], "workload": tj["workload"],
+                                                  "runs": [{"ordering": r["ordering"], "value": 1.0 / r["iterate_s"], "unit": "LM iterations/s", "cores": 1,
+                                                            "ms_per_iteration": 1e3 * r["iterate_s"], "linearize_ms": 1e3 * r["linearize_s"],
+                                                            "eliminate_ms": 1e3 * r["eliminate_s"]} for r in tj["runs"]]}
         except OSError:
             pass
+    if size_key in REFERENCE_MEASURED:
+        out["reference_measured"] = {"what": "the real reference (libgtsam), one LevenbergMarquardtOptimizer::iterate() on this workload",
+                                     "source": REFERENCE_MEASURED["source"], "unit": "LM iterations/s", "runs": REFERENCE_MEASURED[size_key]}
+    # the 1/10-per-dimension sample of rounds 1-2 (3 iterations each, single thread and all cores, subtree parallelism only)
+    n_cam, n_pt, obs, seed = size_key
+    g10, x10, _, o10 = make_bal(max(2, n_cam // 10), max(10, n_pt // 10), obs, seed=seed)
+    v1, t1, tm1 = leg(g10, x10, o10, 1, 1, 8.0, 3)
+    vn, tn, tmn = leg(g10, x10, o10, cores, 1, 8.0, 3) if cores > 1 else (v1, t1, tm1)
+    oh.set_threads(1)
+    oh.set_dense_threads(1)
+    out["tenth_scale_sample"] = {"workload": f"synthetic BAL {max(2, n_cam // 10)} cameras / {max(10, n_pt // 10)} points / {g10.size()} factors, Schur ordering",
+                                 "all_cores": {"value": vn, "cores": cores, "ms_per_iteration": 1e3 * sum(tn) / len(tn),
+                                               "linearize_ms": 1e3 * tmn["linearize_s"], "eliminate_ms": 1e3 * tmn["eliminate_s"]},
+                                 "single_thread": {"value": v1, "cores": 1, "ms_per_iteration": 1e3 * sum(t1) / len(t1),
+                                                   "linearize_ms": 1e3 * tm1["linearize_s"], "eliminate_ms": 1e3 * tm1["eliminate_s"]}}
     return out
 
 
@@ -165,6 +195,119 @@ def slam_bench(args):
     print(json.dumps(out), flush=True)
 
 
+def isam2_sequences(tmpdir, poses):
+    """the two incremental workloads as input files of the C++ driver over the C ABI (tests/cpp/isam2_harness.cpp):
+    visual      examples/VisualISAM2Example.cpp:88-131 (BASELINE configs[4]: 8 Pose3 + 8 Point3, 64 projection factors + 2 priors, ISAM2Params
+                relinearizeThreshold 0.01, relinearizeSkip 1, a bare update() after every frame)
+    city10000   timing/timeIncremental.cpp:84-170 on city10000.g2o: one pose per update, the new pose initialised from the DEVICE's own
+                calculateEstimate(previous pose) composed with the odometry (W lines), default ISAM2Params"""
+    import numpy as np
+    from gtsam_personal_amd import ISAM2Params
+    from gtsam_personal_amd.incremental_workloads import incremental_pose2_steps, visual_steps, write_isam2_sequence
+    out = {}
+    path = os.path.join(tmpdir, "visual.txt")
+    write_isam2_sequence(path, ISAM2Params(relinearizeThreshold=0.01, relinearizeSkip=1), visual_steps())
+    out["visual"] = path
+    est = {0: np.zeros(3)}
+
+    def dead_reckoning(k):  # only fills the V lines the W lines replace; keeps the generator's interface
+        return est[k]
+
+    steps = []
+    for g, v in incremental_pose2_steps(os.path.join(ROOT, "tests", "golden", "city10000.g2o"), poses, dead_reckoning):
+        for k in v.keys():
+            est[int(k)] = np.asarray(v.at(k), dtype=float)[:3]
+        steps.append((g, v))
+    path = os.path.join(tmpdir, "city10000.txt")
+    write_isam2_sequence(path, ISAM2Params(), steps, relative_pose2=True)
+    out["city10000"] = path
+    return out
+
+
+def isam2_bench(args):
+    """BASELINE configs[4] and the reference's incremental benchmark loop through the C ABI from C++ (no Python between the updates): ms per
+    ISAM2::update inside the library calls, with percentiles; the CPU oracle on the same sequences beside it.  The constrained COLAMD
+    orderings the library asks its caller for are replayed from tests/golden/isam2_orderings_*.bin (recorded once with the reference's
+    CCOLAMD by tests/tools/make_isam2_orderings.py): a boundary input, like the batch benchmark's METIS permutation."""
+    import subprocess
+    import tempfile
+    harness = os.path.join(ROOT, "tests", "cpp", "isam2_harness")
+    if not os.path.exists(harness):
+        raise SystemExit("tests/cpp/isam2_harness not built (python -c 'import __graft_entry__ as g; g.build()')")
+    res, seqs = {}, {}
+    with tempfile.TemporaryDirectory() as d:
+        t0 = time.perf_counter()
+        seqs = isam2_sequences(d, args.isam2_poses)
+        t_gen = time.perf_counter() - t0
+        for name, path in seqs.items():
+            fx = os.path.join(ROOT, "tests", "golden", f"isam2_orderings_{name}.bin")
+            best = None
+            for _ in range(max(1, args.steps if name == "visual" else 1)):  # the small example is repeated; the long loop runs once
+                # (repeat:3 = the sequence three times in one process, the last one reported: the first pass of a process pays ~8 ms twice
+                #  for the runtime's first launches of the batch and incremental kernel configurations -- an incremental smoother's host
+                #  is a long-running process)
+                r = subprocess.run([harness, path, "0", "replay:" + fx] + (["repeat:3"] if name == "visual" else []), stdout=subprocess.PIPE,
+                                   stderr=subprocess.PIPE, timeout=900)
+                out = json.loads(r.stdout)
+                if "error" in out:
+                    raise SystemExit(f"isam2 bench ({name}): {out['error']} -- the recorded orderings no longer fit this run "
+                                     f"(regenerate with tests/tools/make_isam2_orderings.py)")
+                out.pop("estimate", None)
+                if best is None or out["ms_per_update_after_first"] < best["ms_per_update_after_first"]:
+                    best = out
+            res[name] = best
+        cpu = None
+        if not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_harness as oh  # the checker / baseline only
+            from gtsam_personal_amd import ISAM2Params
+            from gtsam_personal_amd.incremental_workloads import incremental_pose2_steps, visual_steps
+            cpu = {}
+            p = ISAM2Params(relinearizeThreshold=0.01, relinearizeSkip=1)
+            best = 1e30
+            for _ in range(5):
+                orc = oh.OracleISAM2(p.relinearizeThreshold, p.relinearizeSkip, p.enableRelinearization, p.optimizationParams.wildfireThreshold)
+                steps = visual_steps()
+                t0 = time.perf_counter()
+                for g, v in steps:
+                    orc.update(g, v)
+                orc.calculateEstimate()
+                best = min(best, (time.perf_counter() - t0) / len(steps))
+            cpu["visual"] = {"ms_per_update": 1e3 * best, "updates": len(steps)}
+            p = ISAM2Params()
+            orc = oh.OracleISAM2(p.relinearizeThreshold, p.relinearizeSkip, p.enableRelinearization, p.optimizationParams.wildfireThreshold)
+            t_orc, n_up, budget = 0.0, 0, time.perf_counter()
+            for g, v in incremental_pose2_steps(os.path.join(ROOT, "tests", "golden", "city10000.g2o"), args.isam2_poses,
+                                                lambda k: orc.calculateEstimate().at(k)):
+                t0 = time.perf_counter()
+                orc.update(g, v)
+                t_orc += time.perf_counter() - t0
+                n_up += 1
+                if time.perf_counter() - budget > 25.0:  # bounded sample: the first updates of the same loop
+                    break
+            cpu["city10000"] = {"ms_per_update": 1e3 * t_orc / max(1, n_up), "updates": n_up,
+                                "note": "ISAM2::update only (the estimate of the previous pose is read outside the timed calls), through ctypes"}
+    v = res["visual"]
+    out = {"metric": "ISAM2 update latency", "value": v["ms_per_update_after_first"], "unit": "ms per update", "n_gpus": 1, "steps": v["updates"] - 1, "warmup": 1,
+           "ms_per_step": v["ms_per_update_after_first"], "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+           "data": "VisualISAM2Example's scene (examples/SFMdata.h) / reference dataset file city10000.g2o (tests/golden)",
+           "config": {"workload": "VisualISAM2Example (BASELINE configs[4]): 8 Pose3 + 8 Point3, 64 GenericProjectionFactor + 2 priors, 14 updates, "
+                                  "relinearizeThreshold 0.01, relinearizeSkip 1; value = mean over the updates after the first of a fresh handle in a warm process "
+                                  "(the sequence runs three times per process, the third is reported); driven from C++ through the C ABI, constrained COLAMD orderings replayed from "
+                                  "a fixture recorded with the reference's CCOLAMD", "best_of": args.steps},
+           "visual_isam2_example": v,
+           "city10000_incremental": dict(res["city10000"], workload=f"timing/timeIncremental.cpp on city10000.g2o, {res['city10000']['updates']} updates, one pose per update, every new pose "
+                                                                    "initialised from the device's calculateEstimate(previous pose); ms_per_update includes those single-variable estimates"),
+           "roofline": {"kernel": "none dominant: an update is a dozen dependent launches on a few workgroups", "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBPS,
+                        "unit": "GB/s", "frac": None, "traffic": None, "note": "latency-bound at this size (16 variables / a few cliques per update); no roofline is claimed"},
+           "sequence_generation_s": t_gen}
+    if cpu is not None:
+        out["cpu_baseline"] = {"value": cpu["visual"]["ms_per_update"], "unit": "ms per update", "cores": 1, "kind": "port",
+                               "sample": "oracle/isam2_oracle.hpp (CPU restatement of ISAM2::update), the same VisualISAM2Example sequence, best of 5, through ctypes",
+                               "city10000_incremental": cpu["city10000"]}
+    print(json.dumps(out), flush=True)
+
+
 def pmc_traffic():
     """HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (counters cannot be collected
     from inside the process): {kernel: bytes}.  tools/pmc_summary.py writes the file; absent file -> traffic null."""
@@ -191,9 +334,11 @@ def main():
                     help="elimination ordering: the reference's METIS ordering (BASELINE.json configs[3]; the permutation is a boundary input "
                          "carried by tests/golden/<tag>_metis.npz, produced once by Ordering::Metis through oracle/_ref) or Schur "
                          "(points then cameras, timing/timeSFMBAL.h:64-96)")
-    ap.add_argument("--workload", choices=["bal", "sphere2500", "city10000"], default="bal",
+    ap.add_argument("--workload", choices=["bal", "sphere2500", "city10000", "isam2"], default="bal",
                     help="bal = the headline synthetic BAL graph (BASELINE configs[3]); sphere2500 / city10000 = the general sparse configs at the "
-                         "reference's size (single GPU side line; --ordering colamd|metis)")
+                         "reference's size (single GPU side line; --ordering colamd|metis); isam2 = BASELINE configs[4] (VisualISAM2Example) and the "
+                         "reference's incremental loop on city10000, ms per ISAM2::update through the C ABI")
+    ap.add_argument("--isam2-poses", type=int, default=10000, help="--workload isam2: poses of the city10000 incremental loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-peaks", action="store_true", help="skip the device micro-benchmarks (profiling runs: hundreds of extra launches under PMC)")
@@ -203,8 +348,8 @@ def main():
 
     if args.workload != "bal":
         if args.gpus != 1:
-            raise SystemExit("--workload sphere2500 / city10000 is a single-GPU side line")
-        return slam_bench(args)
+            raise SystemExit("--workload sphere2500 / city10000 / isam2 is a single-GPU side line")
+        return isam2_bench(args) if args.workload == "isam2" else slam_bench(args)
     if args.ordering == "colamd":
         raise SystemExit("--ordering colamd is offered for --workload sphere2500 / city10000 (the BAL fixtures carry METIS and Schur)")
     rank = int(os.environ.get("RANK", "0"))
@@ -381,15 +526,16 @@ def main():
         # why the register-resident loop stops at ~60 % of the datasheet figure: the clock the chip holds under FP64 MFMA load
         clk, fpc = ct.c_double(), ct.c_double()
         peaks = {}
-        for nacc in (4, 8):
+        for nacc in (4, 8, 16):
             if lib is not None and lib.lmgpu_peak_mfma_f64_clock(local_rank, 4000, nacc, ct.byref(v), ct.byref(clk), ct.byref(fpc)) == 0:
                 peaks[f"{nacc}_accumulators"] = {"tflops": v.value, "sustained_sclk_mhz": clk.value, "flop_per_clk_per_simd": fpc.value}
         if peaks:
-            out["fp64_mfma_microbenchmark"] = dict(peaks, note="register-resident v_mfma_f64_16x16x4_f64 loop on every CU with the in-kernel shader clock "
-                                                   "(s_memtime / s_memrealtime): the chip HOLDS ~2.39 GHz under this load, and the instruction issues "
-                                                   "at ~20 flop/clk/SIMD, not the 32 the 78.6 TFLOP/s datasheet figure (1024 SIMDs x 32 x 2.4 GHz) "
-                                                   "assumes: ~49.6 TFLOP/s is this instruction's ceiling on this silicon (tools/mfma_f64_rate.hip, "
-                                                   "profiles/r02/mfma_f64_rate.txt: v_mfma_f64_4x4x4_4b_f64 does reach 30 flop/clk/SIMD = 73 TFLOP/s)")
+            out["fp64_mfma_microbenchmark"] = dict(peaks, note="register-resident v_mfma_f64_16x16x4_f64 loops on every CU with the in-kernel shader clock "
+                                                   "(s_memtime / s_memrealtime).  4 / 8 accumulators with one loop-invariant operand pair stop near 49 TFLOP/s "
+                                                   "(what round 2 took for the instruction's ceiling); the 16-accumulator loop has the register shape of the "
+                                                   "update tile (4 x 4 accumulators, 4 + 4 changing operands, two workgroups per CU) and shows what the "
+                                                   "instruction sustains in that shape (tools/syrk4_bench.hip: the tile itself reaches 61-69 TFLOP/s without "
+                                                   "its memory traffic)")
             best = max(peaks.values(), key=lambda d: d["tflops"])
             if "roofline" in out:
                 out["roofline"]["instruction_peak_tflops"] = best["tflops"]
@@ -399,8 +545,9 @@ def main():
             if "roofline_linearize" in out and v.value > 0:
                 out["roofline_linearize"]["frac_of_measured_copy"] = out["roofline_linearize"]["achieved"] / v.value
         if world == 1 and not args.no_cpu_baseline:
-            full_tag = {(1000, 100000, 10, 42): "c4_seed42", (100, 10000, 10, 42): "bal100_seed42"}.get((args.cams, args.points, args.obs, args.seed))
-            out["cpu_baseline"] = cpu_baseline(max(2, args.cams // 10), max(10, args.points // 10), args.obs, args.seed, full_tag)
+            size_key = (args.cams, args.points, args.obs, args.seed)
+            full_tag = {(1000, 100000, 10, 42): "c4_seed42", (100, 10000, 10, 42): "bal100_seed42"}.get(size_key)
+            out["cpu_baseline"] = cpu_baseline(graph, initial, ordering, ordering_name, size_key, full_tag)
         sys.stdout.flush()
         if saved_stdout is not None:
             os.dup2(saved_stdout, 1)

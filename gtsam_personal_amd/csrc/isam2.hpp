@@ -149,6 +149,13 @@ struct lmgpu_isam2 {
   // and the pushes (payload in the arena -> a persistent device array) are carried out by ONE scatter kernel (is_flush) -- an update
   // issued 28 copy commands of a few hundred bytes each before (rocprofv3: half of its GPU time, and ~4 us of host time apiece).
   size_t stage_flushed = 0;
+  // Zero-copy (round 3): the pinned arena is mapped into the device's address space, and tables a kernel reads ONCE (index lists, the
+  // payload of pushes, the tree patch) are read by the kernel straight from it -- no copy command at all.  Only the elimination tables,
+  // which the front kernels walk with chains of dependent reads, still travel into the device arena: bytes below stage_copy_mark.
+  // (An update of VisualISAM2Example issued ~35 device operations, 13 of them copies of a few hundred bytes, each ~6 us of stream time.)
+  size_t stage_copy_mark = 0;
+  unsigned char epoch = 1;  // value that means 'set' in d_replaced / d_changed for the NEXT back-substitution (no clears between them)
+  int* h_status_dev = nullptr;  // device-side address of the pinned status word: the last kernel of a phase relays the status there
   struct PushRec {
     void* dst;
     const void* src;  // in the device arena
@@ -165,6 +172,7 @@ struct lmgpu_isam2 {
   double t_phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   std::vector<int> elim_cid;  // cliques of the elimination whose status word is still on the device (checked when the update ends)
   bool elim_pending = false;
+  bool elim_relay_pending = false;  // the elimination's status word has not been handed to the host yet
   // Device copy of the Bayes tree for the wildfire, PATCHED per update (only the cliques an update created or re-parented are
   // rewritten): one FrontDesc per clique slot (child_begin / child_count = its children as a list of clique ids in the pool), its frontal
   // and separator delta offsets in fixed-stride rows (kTreeRow ints per slot).
@@ -213,7 +221,9 @@ int is_realloc(lmgpu_isam2* S, T** p, size_t newcap, size_t used) {
   *p = q;
   return LMGPU_OK;
 }
-inline size_t is_next_cap(size_t cap, size_t need) { return std::max<size_t>(need, std::max<size_t>(64, cap * 2)); }
+// (floor 2048: a reallocation is a hipMalloc / hipHostMalloc + copy + wait + free, several milliseconds -- the 16 variables of
+// VisualISAM2Example crossed the old floor of 64 scalars in their last frame and paid 7 ms for it)
+inline size_t is_next_cap(size_t cap, size_t need) { return std::max<size_t>(need, std::max<size_t>(2048, cap * 2)); }
 
 // start of an update: the stream is idle (every entry point ends with a wait), so the arenas can be reused / regrown
 int is_stage_begin(lmgpu_isam2* S) {
@@ -233,12 +243,21 @@ int is_stage_begin(lmgpu_isam2* S) {
     if (S->d_stage) (void)hipFree(S->d_stage);
     S->h_stage = S->d_stage = nullptr;
     S->stage_cap = 0;
-    ISCHECK(hipHostMalloc((void**)&S->h_stage, want, hipHostMallocDefault));
+    ISCHECK(hipHostMalloc((void**)&S->h_stage, want, hipHostMallocMapped));  // kernels read it in place (zero-copy tables)
+    {
+      void* dev = nullptr;
+      ISCHECK(hipHostGetDevicePointer(&dev, S->h_stage, 0));
+      if (dev != (void*)S->h_stage) {
+        S->err = "ISAM2: pinned host memory is not mapped at its host address on this device";
+        return LMGPU_HIP_ERROR;
+      }
+    }
     ISCHECK(hipMalloc((void**)&S->d_stage, want));
     S->stage_cap = want;
   }
   S->stage_used = 0;
   S->stage_flushed = 0;
+  S->stage_copy_mark = 0;
   S->stage_want = 0;
   return LMGPU_OK;
 }
@@ -253,7 +272,8 @@ int is_stage_raw(lmgpu_isam2* S, size_t bytes, char** hp, char** dp) {
     return LMGPU_OK;
   }
   void *h = nullptr, *d = nullptr;
-  ISCHECK(hipHostMalloc(&h, b, hipHostMallocDefault));
+  if (S->trace) std::fprintf(stderr, "isam2 staging: request of %zu bytes beyond the arena (%zu of %zu used) in update %d\n", b, S->stage_used, S->stage_cap, S->update_count);
+  ISCHECK(hipHostMalloc(&h, b, hipHostMallocMapped));
   if (dp) ISCHECK(hipMalloc(&d, b));
   S->stage_extra.emplace_back(h, d);
   *hp = (char*)h;
@@ -261,15 +281,22 @@ int is_stage_raw(lmgpu_isam2* S, size_t bytes, char** hp, char** dp) {
   return LMGPU_OK;
 }
 // a table the update's kernels read: host vector -> device arena (with the next flush; a request beyond the arena is copied at once)
+// device_copy = false (the default): the kernel reads the pinned host bytes themselves (read once: an index list, a patch blob)
 template <typename T>
-int is_stage(lmgpu_isam2* S, const std::vector<T>& src, T** d) {
-  char *hp, *dp;
+int is_stage(lmgpu_isam2* S, const std::vector<T>& src, T** d, bool device_copy = false) {
+  char *hp, *dp = nullptr;
   const size_t before = S->stage_extra.size();
-  const int rc = is_stage_raw(S, src.size() * sizeof(T), &hp, &dp);
+  const int rc = is_stage_raw(S, src.size() * sizeof(T), &hp, device_copy ? &dp : nullptr);
   if (rc) return rc;
-  if (!src.empty()) {
-    std::memcpy(hp, src.data(), src.size() * sizeof(T));
-    if (S->stage_extra.size() != before) ISCHECK(hipMemcpyAsync(dp, hp, src.size() * sizeof(T), hipMemcpyHostToDevice, S->stream));
+  if (!src.empty()) std::memcpy(hp, src.data(), src.size() * sizeof(T));
+  if (!device_copy) {
+    *d = (T*)hp;  // pinned host memory is mapped at the same address on the device
+    return LMGPU_OK;
+  }
+  if (S->stage_extra.size() != before) {
+    if (!src.empty()) ISCHECK(hipMemcpyAsync(dp, hp, src.size() * sizeof(T), hipMemcpyHostToDevice, S->stream));
+  } else {
+    S->stage_copy_mark = S->stage_used;
   }
   *d = (T*)dp;
   return LMGPU_OK;
@@ -277,16 +304,15 @@ int is_stage(lmgpu_isam2* S, const std::vector<T>& src, T** d) {
 // host data into a persistent device array (the source is copied into the pinned arena; the scatter kernel of the next flush moves it)
 int is_push(lmgpu_isam2* S, void* dst, const void* src, size_t bytes) {
   if (!bytes) return LMGPU_OK;
-  char *hp, *dp;
-  const size_t before = S->stage_extra.size();
-  const int rc = is_stage_raw(S, bytes, &hp, &dp);
+  char* hp;
+  const int rc = is_stage_raw(S, bytes, &hp, nullptr);
   if (rc) return rc;
   std::memcpy(hp, src, bytes);
-  if (S->stage_extra.size() != before || (bytes & 3) != 0) {  // beyond the arena (or not whole words): its own copy, now
+  if ((bytes & 3) != 0) {  // not whole words: its own copy, now
     ISCHECK(hipMemcpyAsync(dst, hp, bytes, hipMemcpyHostToDevice, S->stream));
     return LMGPU_OK;
   }
-  S->pushes.push_back(lmgpu_isam2::PushRec{dst, dp, (uint32_t)(bytes >> 2), 0u});
+  S->pushes.push_back(lmgpu_isam2::PushRec{dst, hp, (uint32_t)(bytes >> 2), 0u});  // the scatter kernel reads the pinned bytes
   return LMGPU_OK;
 }
 // everything staged or pushed so far reaches the device: one copy of the arena's new part, one scatter kernel for the pushes.
@@ -296,20 +322,18 @@ int is_flush(lmgpu_isam2* S) {
   const size_t npush = S->pushes.size();
   bool recs_in_arena = true;
   if (npush) {
-    char *hp, *dp;
-    const size_t before = S->stage_extra.size();
-    const int rc = is_stage_raw(S, npush * sizeof(lmgpu_isam2::PushRec), &hp, &dp);
+    char* hp;
+    const int rc = is_stage_raw(S, npush * sizeof(lmgpu_isam2::PushRec), &hp, nullptr);
     if (rc) return rc;
     std::memcpy(hp, S->pushes.data(), npush * sizeof(lmgpu_isam2::PushRec));
-    recs_in_arena = S->stage_extra.size() == before;
-    if (!recs_in_arena) ISCHECK(hipMemcpyAsync(dp, hp, npush * sizeof(lmgpu_isam2::PushRec), hipMemcpyHostToDevice, S->stream));
-    d_recs = (const lmgpu_isam2::PushRec*)dp;
+    d_recs = (const lmgpu_isam2::PushRec*)hp;
     S->pushes.clear();
   }
-  if (S->stage_used > S->stage_flushed) {
-    ISCHECK(hipMemcpyAsync(S->d_stage + S->stage_flushed, S->h_stage + S->stage_flushed, S->stage_used - S->stage_flushed, hipMemcpyHostToDevice,
+  (void)recs_in_arena;
+  if (S->stage_copy_mark > S->stage_flushed) {  // device-arena tables staged since the last flush
+    ISCHECK(hipMemcpyAsync(S->d_stage + S->stage_flushed, S->h_stage + S->stage_flushed, S->stage_copy_mark - S->stage_flushed, hipMemcpyHostToDevice,
                            S->stream));
-    S->stage_flushed = S->stage_used;
+    S->stage_flushed = S->stage_copy_mark;
   }
   if (npush) hipLaunchKernelGGL(isam2_scatter_kernel, dim3((unsigned)npush), dim3(256), 0, S->stream, d_recs);
   return LMGPU_OK;
@@ -324,7 +348,7 @@ int is_pool_alloc(lmgpu_isam2* S, size_t n, int64_t* off) {
     return LMGPU_OK;
   }
   if (S->pool_top + n + 64 > S->pool_cap) {
-    const size_t cap = is_next_cap(S->pool_cap, std::max<size_t>(S->pool_top + n + 64, 1 << 16));
+    const size_t cap = is_next_cap(S->pool_cap, std::max<size_t>(S->pool_top + n + 64, 1 << 20));  // (8 MB to start with: a growth step is a reallocation of several milliseconds)
     const int rc = is_realloc(S, &S->pool, cap, S->pool_top);
     if (rc) return rc;
     ISCHECK(hipMemsetAsync(S->pool + S->pool_top, 0, (cap - S->pool_top) * sizeof(double), S->stream));
@@ -439,11 +463,17 @@ void is_linearize_sel(lmgpu_isam2* S, const lmgpu_isam2::Bkt& b, const int32_t* 
 }  // namespace
 
 // deltaReplacedMask_ |= affected keys (ISAM2.cpp:172): marks = (offset, dimension) pairs of the re-eliminated variables
-__global__ __launch_bounds__(256) void isam2_mark_kernel(const int32_t* __restrict__ marks, int n, unsigned char* __restrict__ replaced) {
+// relay != nullptr: this is the last launch of the update's elimination; one thread hands the status word of the front kernels (all
+// finished: same stream) to the host's pinned word, instead of a copy command of its own
+__global__ __launch_bounds__(256) void isam2_mark_kernel(const int32_t* __restrict__ marks, int n, unsigned char* __restrict__ replaced, unsigned char epoch,
+                                                          const int* __restrict__ status, int* __restrict__ relay) {
   const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0 && relay) {
+    __hip_atomic_store(relay, __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   if (i >= n) return;
   const int xo = marks[2 * i], d = marks[2 * i + 1];
-  for (int k = 0; k < d; k++) replaced[xo + k] = 1;
+  for (int k = 0; k < d; k++) replaced[xo + k] = epoch;
 }
 
 #define ISAM2_TREE_ROW 140  // ints per clique slot for its frontal / separator delta offsets (a clique has at most 139 scalar columns)
@@ -486,7 +516,8 @@ __global__ __launch_bounds__(256) void isam2_wildfire_kernel(int32_t* __restrict
                                                               const lmgpu::FrontDesc* __restrict__ tree, const int32_t* __restrict__ tree_fx,
                                                               const int32_t* __restrict__ tree_sx, const double* __restrict__ pool,
                                                               double* __restrict__ delta, const unsigned char* __restrict__ replaced,
-                                                              unsigned char* __restrict__ changed, double threshold, int* __restrict__ status) {
+                                                              unsigned char* __restrict__ changed, double threshold, int* __restrict__ status,
+                                                              unsigned char epoch, int* __restrict__ relay) {
   extern __shared__ double Ls[];
   __shared__ int s_id, flag;
   __shared__ double red[4];
@@ -518,7 +549,15 @@ __global__ __launch_bounds__(256) void isam2_wildfire_kernel(int32_t* __restrict
     __syncthreads();
     const int id = s_id;
     if (id < 0) {
-      if (id == -3 && tid == 0) atomicMin(status, -1);  // never expected: spin bound hit (reported as a fault by the host)
+      if (tid == 0) {
+        if (id == -3) atomicMin(status, -1);  // never expected: spin bound hit (reported as a fault by the host)
+        // the last workgroup out hands the status word to the host's pinned word (wl[3] counts the leavers; the host resets it per launch)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (relay && atomicAdd(&wl[3], 1u) == gridDim.x - 1) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          __hip_atomic_store(relay, __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
       return;
     }
     const lmgpu::FrontDesc F = tree[id];
@@ -527,12 +566,12 @@ __global__ __launch_bounds__(256) void isam2_wildfire_kernel(int32_t* __restrict
     const int32_t* fxr = wide ? (const int32_t*)(pool + F.par_off) : tree_fx + (size_t)id * ISAM2_TREE_ROW;
     const int32_t* sxr = wide ? fxr + nf : tree_sx + (size_t)id * ISAM2_TREE_ROW;
     const int so = ns > 0 ? sxr[min(tid, ns - 1)] : 0, fo = fxr[min(tid, nf - 1)];
-    const bool is_replaced = replaced[fxr[0]] != 0;
+    const bool is_replaced = replaced[fxr[0]] == epoch;
     if (tid == 0) flag = (threshold <= 0.0 || is_replaced) ? 1 : 0;
     __syncthreads();
     if (!(threshold <= 0.0 || is_replaced)) {
       for (int j = tid; j < ns; j += 256)
-        if (changed[sxr[j]]) flag = 1;  // benign race: every writer stores 1
+        if (changed[sxr[j]] == epoch) flag = 1;  // benign race: every writer stores 1
       __syncthreads();
     }
     const bool dirty = flag != 0;  // workgroup-uniform
@@ -606,7 +645,7 @@ __global__ __launch_bounds__(256) void isam2_wildfire_kernel(int32_t* __restrict
         for (int i = tid; i < nf; i += 256) {
           const int xo = fxr[i];
           delta[xo] = y[i];
-          changed[xo] = 1;
+          changed[xo] = epoch;
         }
     } else if (dirty) {
       lmgpu::ldsb_stage(F, pool, Ls, tid);
@@ -623,7 +662,7 @@ __global__ __launch_bounds__(256) void isam2_wildfire_kernel(int32_t* __restrict
       const bool keep = threshold <= 0.0 || is_replaced || mx >= threshold;
       if (keep && tid < nf) {
         delta[fo] = x[tid];
-        changed[fo] = 1;
+        changed[fo] = epoch;
       }
     }
     // hand over: every wave's stores have been performed, then the children (a dirty clique's only) and the count
@@ -921,21 +960,28 @@ int is_update_delta_enqueue(lmgpu_isam2* S, bool force_full, bool host_delta, do
   if (S->ntot == 0) return LMGPU_OK;
   const double thr = force_full ? 0.0 : (S->dogleg ? S->dogleg_wildfire : S->prm.wildfireThreshold);
   double* const wf_delta = target ? target : S->delta;
-  ISCHECK(hipMemsetAsync(S->d_changed, 0, (size_t)S->ntot, S->stream));
-  ISCHECK(hipMemsetAsync(S->d_status, 0x7f, sizeof(int), S->stream));
+  // No clears and no status copy: d_changed / d_replaced hold the EPOCH of the walk that set them (a new epoch per walk; both arrays
+  // are cleared only when the 8-bit epoch wraps), the status word is reset by the same scatter kernel that seeds the work list, and the
+  // last workgroup to leave the walk stores it into the host's pinned word.  (Each was a device operation of its own: ~6 us of stream time.)
   if (!S->roots.empty()) {
-    // the walk starts at every root (ISAM2-impl.cpp:60-66): queue[0 .. r) = roots, tail = r, next ticket = 0, unfinished = r
+    // the walk starts at every root (ISAM2-impl.cpp:60-66): queue[0 .. r) = roots, tail = r, next ticket = 0, unfinished = r, leavers = 0
     const unsigned int r = (unsigned int)S->roots.size();
     const unsigned int ctl[4] = {r, 0u, r, 0u};
+    const int32_t fresh = 0x7f7f7f7f;
     if ((rc = is_push(S, S->d_queue, S->roots.data(), r * sizeof(int32_t)))) return rc;
     if ((rc = is_push(S, S->d_wl, ctl, sizeof(ctl)))) return rc;
+    if ((rc = is_push(S, S->d_status, &fresh, sizeof(fresh)))) return rc;
     if ((rc = is_flush(S))) return rc;
     hipLaunchKernelGGL(isam2_wildfire_kernel, dim3(ISAM2_WL_GROUPS), dim3(256), (S->tree_lds + LDSB_TAIL) * sizeof(double), S->stream, S->d_queue, S->d_wl,
                        (const FrontDesc*)S->d_tree, (const int32_t*)S->d_tree_fx, (const int32_t*)S->d_tree_sx, (const double*)S->pool, wf_delta,
-                       (const unsigned char*)S->d_replaced, S->d_changed, thr, S->d_status);
+                       (const unsigned char*)S->d_replaced, S->d_changed, thr, S->d_status, S->epoch, S->h_status_dev);
+    ISCHECK(hipGetLastError());
   }
-  ISCHECK(hipMemsetAsync(S->d_replaced, 0, (size_t)S->ntot, S->stream));
-  ISCHECK(hipMemcpyAsync(S->h_status, S->d_status, sizeof(int), hipMemcpyDeviceToHost, S->stream));
+  if (++S->epoch == 0) {  // wrapped: start over from clean arrays
+    S->epoch = 1;
+    ISCHECK(hipMemsetAsync(S->d_changed, 0, (size_t)S->ntot_cap, S->stream));
+    ISCHECK(hipMemsetAsync(S->d_replaced, 0, (size_t)S->ntot_cap, S->stream));
+  }
   if (host_delta && !target) {
     if ((size_t)S->ntot > S->h_delta_cap) {
       if (S->h_delta) (void)hipHostFree(S->h_delta);
@@ -1170,14 +1216,19 @@ int is_eliminate(lmgpu_isam2* S, const std::vector<IsGF>& gfs, const std::vector
   int32_t* d_rowptr = nullptr;
   RowSrc* d_rowsrc = nullptr;
   if (!rowptr.empty()) {
-    if ((rc = is_stage(S, rowptr, &d_rowptr)) || (rc = is_stage(S, rowsrc, &d_rowsrc))) return rc;
+    if ((rc = is_stage(S, rowptr, &d_rowptr, true)) || (rc = is_stage(S, rowsrc, &d_rowsrc, true))) return rc;
     if (!S->inv16) ISCHECK(hipMalloc((void**)&S->inv16, 16 * 256 * sizeof(double)));
   }
-  if ((rc = is_stage(S, fds, &d_fds)) || (rc = is_stage(S, ffac, &d_ffac)) || (rc = is_stage(S, fd, &d_fd)) || (rc = is_stage(S, childs, &d_childs)) ||
-      (rc = is_stage(S, cmap, &d_cmap)) || (rc = is_stage(S, fxoff, &d_fxoff)) || (rc = is_stage(S, list, &d_list)))
+  // (the front kernels walk these tables with chains of dependent reads: they go into the device arena, one copy for all of them)
+  if ((rc = is_stage(S, fds, &d_fds, true)) || (rc = is_stage(S, ffac, &d_ffac, true)) || (rc = is_stage(S, fd, &d_fd, true)) ||
+      (rc = is_stage(S, childs, &d_childs, true)) || (rc = is_stage(S, cmap, &d_cmap, true)) || (rc = is_stage(S, fxoff, &d_fxoff, true)) ||
+      (rc = is_stage(S, list, &d_list, true)))
     return rc;
+  {
+    const int32_t fresh = 0x7f7f7f7f;  // the status word is reset by the scatter kernel of this flush
+    if ((rc = is_push(S, S->d_status, &fresh, sizeof(fresh)))) return rc;
+  }
   if ((rc = is_flush(S))) return rc;  // the tables above, and whatever the update pushed before (new values, factor rows)
-  ISCHECK(hipMemsetAsync(S->d_status, 0x7f, sizeof(int), S->stream));
   for (int l = 0; l <= max_level; l++) {
     for (int32_t fi : wide[l]) {  // (the level's LDS fronts and these only depend on the levels below)
       const FrontDesc& F = fds[fi];
@@ -1224,8 +1275,10 @@ int is_eliminate(lmgpu_isam2* S, const std::vector<IsGF>& gfs, const std::vector
                        (const int32_t*)d_fxoff, S->pool, 0.0, (const double*)nullptr, (const double*)S->ones, S->d_status, nmax, nmax, (double*)nullptr, jcap,
                        (const double*)nullptr, (const char*)nullptr, 0);
   }
-  // the status word comes back with the one wait that ends the update (is_finish_elimination)
-  ISCHECK(hipMemcpyAsync(S->h_status, S->d_status, sizeof(int), hipMemcpyDeviceToHost, S->stream));
+  // the status word comes back with the one wait that ends the update (is_finish_elimination): the mark kernel, the last launch of an
+  // update that eliminated anything, relays it into the host's pinned word
+  *S->h_status = 0x7f7f7f7f;
+  S->elim_relay_pending = true;
   S->elim_cid = cid;
   S->elim_pending = true;
   return LMGPU_OK;
@@ -1235,6 +1288,10 @@ int is_eliminate(lmgpu_isam2* S, const std::vector<IsGF>& gfs, const std::vector
 int is_finish_elimination(lmgpu_isam2* S) {
   const int rcf = is_flush(S);  // nothing staged or pushed outlives the entry point
   if (rcf) return rcf;
+  if (S->elim_relay_pending) {  // (an elimination that marked nothing: no kernel relayed the status)
+    ISCHECK(hipMemcpyAsync(S->h_status, S->d_status, sizeof(int), hipMemcpyDeviceToHost, S->stream));
+    S->elim_relay_pending = false;
+  }
   ISCHECK(hipStreamSynchronize(S->stream));
   ISCHECK(hipGetLastError());
   if (!S->elim_pending) return LMGPU_OK;
@@ -1524,6 +1581,7 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
       if ((rc = is_realloc(S, &S->ones, ncap, 0))) return rc;
       if ((rc = is_realloc(S, &S->d_replaced, ncap, (size_t)S->ntot))) return rc;
       if ((rc = is_realloc(S, &S->d_changed, ncap, 0))) return rc;
+      ISCHECK(hipMemsetAsync(S->d_changed, 0, ncap, S->stream));  // (epochs: a fresh array must not hold the current one)
       std::vector<double> one(ncap, 1.0);
       ISCHECK(hipMemcpy(S->ones, one.data(), ncap * sizeof(double), hipMemcpyHostToDevice));
       ISCHECK(hipMemsetAsync(S->d_replaced + S->ntot, 0, ncap - S->ntot, S->stream));
@@ -1795,7 +1853,9 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
         for (int32_t v : observed) groups[v] = 1;
       }
       std::vector<int32_t> perm;
+      lap(2);
       if ((rc = is_colamd(S, vids, cols, (int)S->facs.size(), groups, &perm))) return rc;
+      lap(3);
       for (size_t b = 0; b < S->bkts.size(); b++) {
         std::vector<int32_t> all(S->bkts[b].n);
         for (int i = 0; i < S->bkts[b].n; i++) all[i] = i;
@@ -1808,7 +1868,9 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
         if (S->facs[i].removed) continue;  // an empty slot: an entry without variables, so that positions stay factor indices
         for (int k = 0; k < kFactorArity[S->facs[i].type]; k++) gfs[i].vids.push_back(S->facs[i].v[k]);
       }
+      lap(1);  // (batch: relinearization of everything counts with the linearize phase)
       if ((rc = is_eliminate(S, gfs, vids, perm))) return rc;
+      lap(4);
       for (int32_t v : vids) affectedSet.insert(v);
       res.variablesReeliminated = (int32_t)vids.size();
       res.factorsRecalculated = (int32_t)S->facs.size();
@@ -1891,7 +1953,9 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
       marks.push_back(kVarDim[S->vars[v].type]);
     }
     if ((rc = is_with_list(S, marks, [&](const int32_t* d, int cnt) {
-           hipLaunchKernelGGL(isam2_mark_kernel, dim3((cnt / 2 + 255) / 256), dim3(256), 0, S->stream, d, cnt / 2, S->d_replaced);
+           hipLaunchKernelGGL(isam2_mark_kernel, dim3((cnt / 2 + 255) / 256), dim3(256), 0, S->stream, d, cnt / 2, S->d_replaced, S->epoch,
+                              (const int*)S->d_status, S->elim_relay_pending ? S->h_status_dev : (int*)nullptr);
+           S->elim_relay_pending = false;
          })))
       return rc;
     S->any_replaced = S->any_replaced || !affectedSet.empty();
@@ -1945,7 +2009,8 @@ int lmgpu_isam2_create(const lmgpu_config* cfg, const lmgpu_isam2_params* prm, l
   ISCHECK(hipSetDevice(S->device));
   ISCHECK(hipStreamCreate(&S->stream));
   ISCHECK(hipMalloc((void**)&S->d_status, sizeof(int)));
-  ISCHECK(hipHostMalloc((void**)&S->h_status, sizeof(int)));
+  ISCHECK(hipHostMalloc((void**)&S->h_status, sizeof(int), hipHostMallocMapped));
+  ISCHECK(hipHostGetDevicePointer((void**)&S->h_status_dev, S->h_status, 0));
   ISCHECK(hipFuncSetAttribute((const void*)lds_front_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra + 64));
   ISCHECK(hipFuncSetAttribute((const void*)isam2_wildfire_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (kLdsLimitN * kLdsLimitN + LDSB_TAIL) * 8));
   ISCHECK(hipFuncSetAttribute((const void*)diag_potrf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));

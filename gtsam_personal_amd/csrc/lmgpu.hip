@@ -2976,6 +2976,42 @@ _Pragma("unroll") \
 }
 PEAK_CLOCK_KERNEL(peak_mfma_f64_clock_kernel4, 4)
 PEAK_CLOCK_KERNEL(peak_mfma_f64_clock_kernel8, 8)
+// the register shape of the trailing-update tile: 4 x 4 accumulators of a 64x64 wave tile, four A and four B operand registers.
+// (Round 3: the 4- and 8-accumulator loops above stop at ~49 TFLOP/s, which round 2 took for the instruction's ceiling; the update tile
+// itself runs at 61-69 TFLOP/s once its memory traffic is taken away (tools/syrk4_bench.hip), and so does this loop.)
+__global__ __launch_bounds__(256, 2) void peak_mfma_f64_clock_kernel16(double* out, unsigned long long* stamps, int iters) {
+  double4_t acc[4][4];
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) acc[i][j] = double4_t{0, 0, 0, 0};
+  double a[4], b[4];
+  for (int i = 0; i < 4; i++) {
+    a[i] = 0.25 + threadIdx.x * 1e-3 + i * 0.01;
+    b[i] = 0.5 - threadIdx.x * 1e-3 - i * 0.01;
+  }
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  __builtin_amdgcn_sched_barrier(0);
+  for (int it = 0; it < iters; it += 4) {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {  // keep the operands changing (a loop-invariant operand set is not what a tile sees)
+      a[i] = -a[i];
+      b[i] = -b[i];
+    }
+  }
+  double s = 0;
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+  __builtin_amdgcn_sched_barrier(0);
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) {
+    stamps[2 * blockIdx.x] = c1 - c0;
+    stamps[2 * blockIdx.x + 1] = r1 - r0;
+  }
+}
 
 __global__ __launch_bounds__(256) void peak_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
@@ -3008,17 +3044,18 @@ int lmgpu_peak_mfma_f64(int32_t device, int32_t iters, double* tflops) {
 // launches so that the power state has settled); flop_per_clk_simd = tflops / (SIMDs x clock): 32 = one v_mfma_f64_16x16x4_f64
 // (2048 flop) per 64 cycles and SIMD, the rate the 78.6 TFLOP/s datasheet figure assumes AT 2.4 GHz.
 int lmgpu_peak_mfma_f64_clock(int32_t device, int32_t iters, int32_t n_acc, double* tflops, double* sclk_mhz, double* flop_per_clk_simd) {
-  if (hipSetDevice(device) != hipSuccess || (n_acc != 4 && n_acc != 8) || !tflops || !sclk_mhz) return LMGPU_HIP_ERROR;
+  if (hipSetDevice(device) != hipSuccess || (n_acc != 4 && n_acc != 8 && n_acc != 16) || !tflops || !sclk_mhz) return LMGPU_HIP_ERROR;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) return LMGPU_HIP_ERROR;
   const int cus = prop.multiProcessorCount;
-  const int blocks = cus * 8;
+  const int blocks = cus * (n_acc == 16 ? 2 : 8);  // 16 accumulators: two workgroups per CU, the occupancy of the update tile
   double* out = nullptr;
   unsigned long long* stamps = nullptr;
   if (hipMalloc((void**)&out, (size_t)blocks * 256 * sizeof(double)) != hipSuccess) return LMGPU_HIP_ERROR;
   if (hipMalloc((void**)&stamps, (size_t)blocks * 2 * sizeof(unsigned long long)) != hipSuccess) return LMGPU_HIP_ERROR;
   auto launch = [&](int it) {
-    if (n_acc == 4) hipLaunchKernelGGL(peak_mfma_f64_clock_kernel4, dim3(blocks), dim3(256), 0, 0, out, stamps, it);
+    if (n_acc == 16) hipLaunchKernelGGL(peak_mfma_f64_clock_kernel16, dim3(blocks), dim3(256), 0, 0, out, stamps, 4 * it);
+    else if (n_acc == 4) hipLaunchKernelGGL(peak_mfma_f64_clock_kernel4, dim3(blocks), dim3(256), 0, 0, out, stamps, it);
     else hipLaunchKernelGGL(peak_mfma_f64_clock_kernel8, dim3(blocks), dim3(256), 0, 0, out, stamps, it);
   };
   hipEvent_t e0, e1;
@@ -3047,7 +3084,7 @@ int lmgpu_peak_mfma_f64_clock(int32_t device, int32_t iters, int32_t n_acc, doub
     if (h[2 * b + 1] > 0) clk.push_back((double)h[2 * b] / (double)h[2 * b + 1] * 100.0);
   std::sort(clk.begin(), clk.end());
   *sclk_mhz = clk.empty() ? 0.0 : clk[clk.size() / 2];
-  const double flops = (double)blocks * 4 /*waves*/ * (double)iters * n_acc * 2048.0;
+  const double flops = (double)blocks * 4 /*waves*/ * (double)iters * n_acc * 2048.0;  // (the 16-accumulator kernel is launched with 4 x iters and steps its loop by 4)
   *tflops = flops / (ms * 1e-3) / 1e12;
   if (flop_per_clk_simd) *flop_per_clk_simd = (*sclk_mhz > 0) ? (*tflops * 1e12) / ((double)cus * 4 * *sclk_mhz * 1e6) : 0.0;
   (void)hipFree(out);

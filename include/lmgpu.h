@@ -394,7 +394,8 @@ int lmgpu_comm_init_local(lmgpu_handle* h, lmgpu_local_group* g);
 
 /* ---- micro-benchmarks used by bench.py for roofline peaks (device-only, no graph needed) ---- */
 int lmgpu_peak_mfma_f64(int32_t device, int32_t iters, double* tflops);
-/* the same loop with n_acc (4 or 8) independent accumulators, measured after ~1 s of back-to-back launches, together with the shader
+/* the same loop with n_acc (4, 8, or 16 = the 4 x 4 accumulators and 4 + 4 operand registers of the update tile's 64x64 wave tile, two
+ * workgroups per CU) independent accumulators, measured after ~1 s of back-to-back launches, together with the shader
  * clock the chip HOLDS under that load (in-kernel s_memtime / s_memrealtime stamps) and the resulting flop per clock and SIMD:
  * 32 = one v_mfma_f64_16x16x4_f64 per 64 cycles, the issue rate behind the 78.6 TFLOP/s datasheet figure at 2.4 GHz */
 int lmgpu_peak_mfma_f64_clock(int32_t device, int32_t iters, int32_t n_acc, double* tflops, double* sclk_mhz, double* flop_per_clk_simd);

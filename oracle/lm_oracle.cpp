@@ -552,33 +552,102 @@ static GFactor linearize_factor(const Factor& f, const Values& vals) {
 
 // ------------------------------------------------------------------ dense partial Cholesky
 // choleskyPartial gtsam/base/cholesky.cpp:108-159.  ABC col-major n x n, upper triangle used.
-// Unblocked upper Cholesky (Eigen LLT<Upper> numerics up to rounding order), then
+// Upper Cholesky of the frontal block (Eigen LLT<Upper> numerics up to rounding order), then
 // S = R^-T B, C -= S^T S (upper only), then the pivot-exponent test.
-static bool cholesky_partial(double* ABC, int ld, int n, int nFrontal) {
-  if (nFrontal == 0) return true;
+// Small fronts: unblocked, row by row of R.  Fronts with >= 256 frontal columns: the same elimination in panels of 128 rows with a
+// register-tiled rank-128 update, as Eigen's LLT does it (llt_inplace::blocked, Eigen/src/Cholesky/LLT.h: panel, triangular solve,
+// rankUpdate): the unblocked form streams the whole trailing matrix once per pivot and ran the 9001-column root of the headline
+// workload at 0.8 GFLOP/s, 6-7 times slower than the reference's own Eigen code on the same machine -- not a fair CPU stand-in.
+static void chol_unblocked_rows(double* ABC, int ld, int k0, int k1, int upd_end, int jend, bool* ok) {
+  // rows k0 .. k1-1 of R; the trailing update of every pivot is applied to rows k+1 .. upd_end-1, columns up to jend
   auto A = [&](int i, int j) -> double& { return ABC[(size_t)j * ld + i]; };
-  std::vector<double> rowk;
-  // right-looking, row by row of R
-  for (int k = 0; k < nFrontal; k++) {
-    double x = A(k, k);
-    // Eigen llt_inplace unblocked: pivot x = a_kk - sum; fails if x <= 0
+  for (int k = k0; k < k1; k++) {
+    const double x = A(k, k);
     if (!(x > 0.0)) {
-      if (x <= 0.0) return false;  // NaN passes like Eigen (x<=0 is false for NaN)
+      if (x <= 0.0) {
+        *ok = false;
+        return;
+      }
     }
     const double rkk = std::sqrt(x);
     A(k, k) = rkk;
     const double inv = 1.0 / rkk;
-    rowk.resize(n);
-    for (int j = k + 1; j < n; j++) rowk[j] = (A(k, j) *= inv);
-    // trailing update restricted to what is needed: rows k+1..n-1 (frontal part and C); row k is copied
-    // to a contiguous buffer so the inner loop streams one column
-    for (int j = k + 1; j < n; j++) {
-      const double rkj = rowk[j];
+    for (int j = k + 1; j < jend; j++) A(k, j) *= inv;
+    for (int j = k + 1; j < jend; j++) {
+      const double rkj = A(k, j);
       if (rkj == 0.0) continue;
       double* col = &A(0, j);
-      for (int i = k + 1; i <= j; i++) col[i] -= rowk[i] * rkj;
+      const int iend = std::min(j, upd_end - 1);
+      for (int i = k + 1; i <= iend; i++) col[i] -= A(k, i) * rkj;
     }
   }
+}
+// C[i][j] -= sum_{k in [k0, k1)} P[k][i] P[k][j] for r0 <= i <= j < n (upper), P = rows k0..k1-1 of the same matrix.
+// `pack` = the panel copied once per call into groups of four columns, [(i - r0) / 4][k][4] (4 KB per group, contiguous), so that the
+// 4 x 4 register tile is two 2-wide vectors of i per column j, updated with a broadcast P[k][j] -- the shape of Eigen's SSE2 product
+// kernel with its packed operands (the reference is built without -march=native: BASELINE.md section 2).
+typedef double v2d __attribute__((vector_size(16)));
+static void syrk_upper_panel(double* ABC, int ld, int k0, int k1, int r0, int n, const double* pack, int part = 0, int nparts = 1) {
+  const int kb = k1 - k0;
+  for (int j0 = r0 + 4 * part; j0 < n; j0 += 4 * nparts) {  // column tiles dealt round-robin: the work of a tile grows with its column
+    const int jn = std::min(4, n - j0);
+    for (int i0 = r0; i0 <= j0; i0 += 4) {
+      const int in = std::min(4, n - i0);
+      v2d c00 = {0, 0}, c01 = {0, 0}, c10 = {0, 0}, c11 = {0, 0}, c20 = {0, 0}, c21 = {0, 0}, c30 = {0, 0}, c31 = {0, 0};
+      const double* pa = pack + (size_t)((i0 - r0) >> 2) * kb * 4;  // (the last group is padded with zeros)
+      const double* pb = pack + (size_t)((j0 - r0) >> 2) * kb * 4;
+      for (int k = 0; k < kb; k++, pa += 4, pb += 4) {
+        v2d a0, a1;
+        __builtin_memcpy(&a0, pa, 16);
+        __builtin_memcpy(&a1, pa + 2, 16);
+        const v2d b0 = {pb[0], pb[0]}, b1 = {pb[1], pb[1]}, b2 = {pb[2], pb[2]}, b3 = {pb[3], pb[3]};
+        c00 += a0 * b0; c01 += a1 * b0;
+        c10 += a0 * b1; c11 += a1 * b1;
+        c20 += a0 * b2; c21 += a1 * b2;
+        c30 += a0 * b3; c31 += a1 * b3;
+      }
+      const double acc[4][4] = {{c00[0], c00[1], c01[0], c01[1]}, {c10[0], c10[1], c11[0], c11[1]}, {c20[0], c20[1], c21[0], c21[1]},
+                                {c30[0], c30[1], c31[0], c31[1]}};  // [j][i]
+      for (int bj = 0; bj < jn; bj++)
+        for (int ai = 0; ai < in; ai++)
+          if (i0 + ai <= j0 + bj) ABC[(size_t)(j0 + bj) * ld + i0 + ai] -= acc[bj][ai];
+    }
+  }
+}
+static int chol_threads = 1;  // orc_set_dense_threads: threads of the blocked dense factorisation's updates
+static bool cholesky_partial(double* ABC, int ld, int n, int nFrontal) {
+  if (nFrontal == 0) return true;
+  auto A = [&](int i, int j) -> double& { return ABC[(size_t)j * ld + i]; };
+  bool ok = true;
+  if (nFrontal < 256) {
+    chol_unblocked_rows(ABC, ld, 0, nFrontal, n, n, &ok);  // right-looking over the whole matrix, pivot by pivot
+  } else {
+    const int NB = 128;
+    std::vector<double> pack;
+    for (int k0 = 0; k0 < nFrontal && ok; k0 += NB) {
+      const int k1 = std::min(nFrontal, k0 + NB);
+      chol_unblocked_rows(ABC, ld, k0, k1, k1, n, &ok);  // the panel's rows, complete over all columns (diagonal block + triangular solve)
+      if (ok && k1 < n) {
+        // all-cores leg (orc_set_threads > 1): the rank-128 update of a large trailing matrix is shared out over the threads.  This
+        // goes BEYOND what the reference does (Eigen's LLT runs on one thread whatever GTSAM's TBB setting) and is stated where
+        // the number is reported; with one thread this is the plain serial update.
+        const int nt = (chol_threads > 1 && (long)(n - k1) * (n - k1) > 512L * 512L) ? chol_threads : 1;
+        const int m = n - k1, kb = k1 - k0;
+        pack.assign((size_t)kb * ((m + 3) & ~3), 0.0);
+        for (int i = 0; i < m; i++)
+          for (int k = k0; k < k1; k++) pack[((size_t)(i >> 2) * kb + (k - k0)) * 4 + (i & 3)] = A(k, k1 + i);
+        const double* pk = pack.data();
+        if (nt == 1) {
+          syrk_upper_panel(ABC, ld, k0, k1, k1, n, pk);
+        } else {
+          std::vector<std::thread> pool;
+          for (int t = 0; t < nt; t++) pool.emplace_back([=]() { syrk_upper_panel(ABC, ld, k0, k1, k1, n, pk, t, nt); });
+          for (auto& th : pool) th.join();
+        }
+      }
+    }
+  }
+  if (!ok) return false;
   if (nFrontal >= 2) {
     int exp2, exp1;
     (void)std::frexp(A(nFrontal - 2, nFrontal - 2), &exp2);
@@ -1358,6 +1427,11 @@ int orc_set_ordering(void* h, int n, const uint64_t* keys) {
 }
 
 // threads of the all-cores baseline leg (1 = the plain single-thread restatement); returns the value in effect
+// threads inside the dense factorisation of a large front (1 = like the reference, whose Eigen LLT is single-threaded)
+int orc_set_dense_threads(int n) {
+  chol_threads = std::max(1, n);
+  return chol_threads;
+}
 int orc_set_threads(int n) {
   g_threads = std::max(1, n);
   if (g_threads > 1) {

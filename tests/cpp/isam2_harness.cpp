@@ -14,7 +14,13 @@
 //                                 then nf lines  F type k0 k1 k2 | nmeas meas... | noise_kind nnoise noise...
 //                                 then one line  R idx0 idx1 ...            (removeFactorIndices, nremove entries)
 //   ... END
-// usage: isam2_harness <sequence file> <device> <libccolamd_ref.so>
+// usage: isam2_harness <sequence file> <device> <libccolamd_ref.so | replay:FILE> [record:FILE] [repeat:N]
+//   repeat:N      run the sequence N times (fresh handle each), report the last run
+//   record:FILE   additionally writes every ordering the callback returned (int32: n_cols, then the permutation) -- run once with the real
+//                 CCOLAMD to make a fixture
+//   replay:FILE   the callback returns the recorded orderings instead of computing them (no CCOLAMD loaded): the orderings are then a
+//                 fixture-carried boundary input, like the METIS permutation of the batch benchmark (bench.py --workload isam2).  A call
+//                 whose column count differs from the recording, or a recording that runs out, fails the update.
 // Output: one JSON object: updates, seconds inside the library calls, ms per update, the final estimate (key, packed value).
 #include <dlfcn.h>
 
@@ -40,11 +46,29 @@ defaults_fn p_defaults = nullptr;
 ccolamd_fn p_ccolamd = nullptr;
 double g_colamd_seconds = 0;
 
+std::FILE* g_record = nullptr;
+std::vector<int32_t> g_replay;
+size_t g_replay_at = 0;
+bool g_use_replay = false;
+
 double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // the body of Ordering::ColamdConstrained (gtsam/inference/Ordering.cpp:86-108) on the arrays the library hands over
 int colamd_cb(void*, int32_t n_rows, int32_t n_cols, const int32_t* col_ptr, const int32_t* row_idx, const int32_t* cmember, int32_t* perm_out) {
   const double t0 = now();
+  if (g_use_replay) {
+    if (g_replay_at + 1 + (size_t)n_cols > g_replay.size() || g_replay[g_replay_at] != n_cols) return 0;
+    std::vector<char> seen((size_t)n_cols, 0);
+    for (int j = 0; j < n_cols; j++) {
+      const int32_t c = g_replay[g_replay_at + 1 + (size_t)j];
+      if (c < 0 || c >= n_cols || seen[(size_t)c]) return 0;  // not a permutation of this call's columns
+      seen[(size_t)c] = 1;
+      perm_out[j] = c;
+    }
+    g_replay_at += 1 + (size_t)n_cols;
+    g_colamd_seconds += now() - t0;
+    return 1;
+  }
   const size_t Alen = p_recommended(col_ptr[n_cols], n_rows, n_cols);
   std::vector<int> A(Alen), p(col_ptr, col_ptr + n_cols + 1), cm(cmember, cmember + n_cols);
   for (int i = 0; i < col_ptr[n_cols]; i++) A[i] = row_idx[i];
@@ -54,8 +78,13 @@ int colamd_cb(void*, int32_t n_rows, int32_t n_cols, const int32_t* col_ptr, con
   knobs[1] = -1;  // CCOLAMD_DENSE_COL
   int stats[20];
   const int rv = p_ccolamd(n_rows, n_cols, (int)Alen, A.data(), p.data(), knobs, stats, cm.data());
-  if (rv == 1)
+  if (rv == 1) {
     for (int j = 0; j < n_cols; j++) perm_out[j] = p[j];
+    if (g_record) {
+      std::fwrite(&n_cols, sizeof(int32_t), 1, g_record);
+      std::fwrite(perm_out, sizeof(int32_t), (size_t)n_cols, g_record);
+    }
+  }
   g_colamd_seconds += now() - t0;
   return rv == 1 ? 1 : 0;
 }
@@ -88,15 +117,33 @@ int fail(const char* what, const char* detail) {
 
 int main(int argc, char** argv) {
   if (argc < 4) {
-    std::fprintf(stderr, "usage: isam2_harness <sequence file> <device> <libccolamd_ref.so>\n");
+    std::fprintf(stderr, "usage: isam2_harness <sequence file> <device> <libccolamd_ref.so | replay:FILE> [record:FILE]\n");
     return 2;
   }
-  void* so = dlopen(argv[3], RTLD_NOW);
-  if (!so) return fail("dlopen", dlerror());
-  p_recommended = (recommended_fn)dlsym(so, "ccolamd_recommended");
-  p_defaults = (defaults_fn)dlsym(so, "ccolamd_set_defaults");
-  p_ccolamd = (ccolamd_fn)dlsym(so, "ccolamd");
-  if (!p_recommended || !p_defaults || !p_ccolamd) return fail("dlsym", "ccolamd symbols");
+  const std::string ord = argv[3];
+  if (ord.rfind("replay:", 0) == 0) {
+    std::FILE* f = std::fopen(ord.c_str() + 7, "rb");
+    if (!f) return fail("open", ord.c_str() + 7);
+    std::fseek(f, 0, SEEK_END);
+    const long bytes = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    g_replay.resize((size_t)bytes / sizeof(int32_t));
+    if (std::fread(g_replay.data(), sizeof(int32_t), g_replay.size(), f) != g_replay.size()) return fail("read", ord.c_str() + 7);
+    std::fclose(f);
+    g_use_replay = true;
+  } else {
+    void* so = dlopen(argv[3], RTLD_NOW);
+    if (!so) return fail("dlopen", dlerror());
+    p_recommended = (recommended_fn)dlsym(so, "ccolamd_recommended");
+    p_defaults = (defaults_fn)dlsym(so, "ccolamd_set_defaults");
+    p_ccolamd = (ccolamd_fn)dlsym(so, "ccolamd");
+    if (!p_recommended || !p_defaults || !p_ccolamd) return fail("dlsym", "ccolamd symbols");
+  }
+  for (int a = 4; a < argc; a++)
+    if (std::string(argv[a]).rfind("record:", 0) == 0) {
+      g_record = std::fopen(argv[a] + 7, "wb");
+      if (!g_record) return fail("open", argv[a] + 7);
+    }
 
   std::ifstream is(argv[1]);
   if (!is) return fail("open", argv[1]);
@@ -149,6 +196,14 @@ int main(int argc, char** argv) {
     updates.push_back(std::move(u));
   }
 
+  // repeat:N -- the whole sequence N times, each on a fresh handle, the LAST run reported: what an update costs in a process that has
+  // been running for a while (code objects loaded, the runtime's launch configurations seen), as an incremental smoother's host has
+  int repeats = 1;
+  for (int a = 4; a < argc; a++)
+    if (std::string(argv[a]).rfind("repeat:", 0) == 0) repeats = std::max(1, std::atoi(argv[a] + 7));
+  auto run = [&](bool report) -> int {
+    g_replay_at = 0;
+    g_colamd_seconds = 0;
   lmgpu_config cfg{};
   cfg.device = std::atoi(argv[2]);
   cfg.world_size = 1;
@@ -217,20 +272,35 @@ int main(int argc, char** argv) {
   std::vector<double> packed(tot);
   if (lmgpu_isam2_get_values(h, 0, nullptr, nullptr, packed.data()) != LMGPU_OK) return fail("calculateEstimate", lmgpu_isam2_last_error(h));
   const double t_est = now() - t1;
+  // the first update pays the one-time costs of a fresh handle (pool allocation, first launches): reported apart
+  if (report && per_update.size() <= 64) {  // a short sequence: every update's time, in order (stderr)
+    std::fprintf(stderr, "per update (ms):");
+    for (double t : per_update) std::fprintf(stderr, " %.3f", 1e3 * t);
+    std::fprintf(stderr, "\n");
+  }
+  const double first_ms = per_update.empty() ? 0.0 : 1e3 * per_update[0];
+  const double steady_ms = per_update.size() > 1 ? 1e3 * (lib - per_update[0]) / (double)(per_update.size() - 1) : first_ms;
   std::sort(per_update.begin(), per_update.end());
   auto pct = [&](double q) { return per_update.empty() ? 0.0 : 1e3 * per_update[std::min(per_update.size() - 1, (size_t)(q * per_update.size()))]; };
-  std::printf("{\"updates\": %zu, \"library_seconds\": %.6f, \"ms_per_update\": %.6f, \"p50_ms\": %.4f, \"p95_ms\": %.4f, \"p99_ms\": %.4f, \"worst_update_ms\": %.4f, \"ccolamd_callback_seconds\": %.6f, "
+  if (report) std::printf("{\"updates\": %zu, \"library_seconds\": %.6f, \"first_update_ms\": %.4f, \"ms_per_update_after_first\": %.6f, \"ms_per_update\": %.6f, \"p50_ms\": %.4f, \"p95_ms\": %.4f, \"p99_ms\": %.4f, \"worst_update_ms\": %.4f, \"ccolamd_callback_seconds\": %.6f, "
               "\"calculate_estimate_ms\": %.4f, \"single_estimates\": %zu, \"single_estimate_ms\": %.5f, \"variables\": %d, \"cliques\": %d, \"estimate\": [",
-              done, lib, done ? 1e3 * lib / done : 0.0, pct(0.50), pct(0.95), pct(0.99), 1e3 * worst, g_colamd_seconds, 1e3 * t_est, est_calls,
+              done, lib, first_ms, steady_ms, done ? 1e3 * lib / done : 0.0, pct(0.50), pct(0.95), pct(0.99), 1e3 * worst, g_colamd_seconds, 1e3 * t_est, est_calls,
               est_calls ? 1e3 * est_seconds / est_calls : 0.0, n, r.cliques);
   const double* q = packed.data();
-  for (int i = 0; i < n; i++) {
+  for (int i = 0; report && i < n; i++) {
     std::printf("%s[%" PRIu64, i ? ", " : "", keys[(size_t)i]);
     for (int j = 0; j < store[types[(size_t)i]]; j++) std::printf(", %.17g", q[j]);
     std::printf("]");
     q += store[types[(size_t)i]];
   }
-  std::printf("]}\n");
+  if (report) std::printf("]}\n");
   lmgpu_isam2_destroy(h);
+    return 0;
+  };
+  for (int rep = 0; rep < repeats; rep++) {
+    const int rc = run(rep + 1 == repeats);
+    if (rc) return rc;
+  }
+  if (g_record) std::fclose(g_record);
   return 0;
 }

@@ -90,6 +90,7 @@ def lib():
         L.orc_factor_evaluate.argtypes = [ct.c_void_p, ct.c_int, _D, _D, _D]
         L.orc_factor_evaluate3.argtypes = [ct.c_void_p, ct.c_int, _D, _D, _D, _D]
         L.orc_set_threads.argtypes = [ct.c_int]
+        L.orc_set_dense_threads.argtypes = [ct.c_int]
         _lib = L
     return _lib
 
@@ -97,6 +98,12 @@ def lib():
 def set_threads(n):
     """threads of the oracle's all-cores leg (subtree-parallel elimination + parallel linearize, like the reference with TBB)"""
     return lib().orc_set_threads(int(n))
+
+
+def set_dense_threads(n):
+    """threads inside the blocked dense factorisation of a large front (1 = like the reference: Eigen's LLT is single-threaded
+    whatever GTSAM's TBB setting)"""
+    return lib().orc_set_dense_threads(int(n))
 
 
 def dp(a):
