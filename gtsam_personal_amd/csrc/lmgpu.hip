@@ -1428,39 +1428,71 @@ bool check_convergence(double relTol, double absTol, double errTol, double curre
 
 // Deal the subtrees below the replicated top fronts to the ranks.  A front is replicated iff it is an HBM front
 // whose ancestors are all replicated (for BAL: the camera root); with no such front every rank does everything.
+// Which fronts are REPLICATED (eliminated by every rank from the all-reduced sum of the ranks' partial assemblies) and which rank
+// OWNS each of the others.  A subtree goes to one rank as a whole -- its fronts of either class: with a nested-dissection ordering
+// (Ordering::Metis, gtsam/inference/Ordering.cpp:211-256) of a graph whose camera blocks are sparse these are the camera
+// subtrees below the top separators, dense HBM fronts included -- unless it is too heavy for one rank (more than 1 / world_size
+// of the whole elimination: nf n^2 per front as the measure); then its root front is replicated and its children are looked at
+// in turn.  The synthetic C4 graph (every camera pair co-visible) has ONE dense root that is all of the work above the point
+// leaves: it is replicated and the leaves are dealt out, as in rounds 1-2.
 void assign_owners(lmgpu_handle* h) {
   const Plan& P = h->plan;
   const int NF = (int)P.fronts.size(), W = std::max(1, h->cfg.world_size), R = h->cfg.rank;
   h->front_owner.assign(NF, -1);
   h->front_active.assign(NF, 1);
   if (W == 1) return;
+  // cost of the subtree below (and including) every front (post-order: children come first)
+  std::vector<double> wsub(NF, 0.0);
+  double total = 0;
+  for (int fi = 0; fi < NF; fi++) {
+    const Front& fr = P.fronts[fi];
+    wsub[fi] += (double)fr.nf * fr.n * fr.n + 40.0 * (double)fr.factors.size() + 100.0;
+    if (fr.parent >= 0) wsub[fr.parent] += wsub[fi]; else total += wsub[fi];
+  }
   std::vector<char> rep(NF, 0);
   bool any = false;
-  for (int fi = NF - 1; fi >= 0; fi--) {
+  for (int fi = NF - 1; fi >= 0; fi--) {  // parents before children
     const Front& fr = P.fronts[fi];
-    rep[fi] = (fr.cls == 1) && (fr.parent < 0 || rep[fr.parent]);
+    rep[fi] = (fr.cls == 1) && (fr.parent < 0 || rep[fr.parent]) && wsub[fi] * W > total;
     any = any || rep[fi];
   }
   if (!any) return;  // nothing to shard: replicate the whole (small) tree
-  // weights: factors below each subtree root (post-order: children come first)
-  std::vector<double> wsub(NF, 0.0);
-  for (int fi = 0; fi < NF; fi++) {
-    wsub[fi] += (double)P.fronts[fi].factors.size() + 1.0;
-    if (P.fronts[fi].parent >= 0) wsub[P.fronts[fi].parent] += wsub[fi];
+  // the subtrees to deal out: roots = fronts that are not replicated under a replicated parent (or tree roots)
+  std::vector<int> tops;
+  double top_total = 0, top_max = 0;
+  for (int fi = NF - 1; fi >= 0; fi--) {
+    const Front& fr = P.fronts[fi];
+    if (!rep[fi] && (fr.parent < 0 || rep[fr.parent])) {
+      tops.push_back(fi);
+      top_total += wsub[fi];
+      top_max = std::max(top_max, wsub[fi]);
+    }
   }
-  double total = 0;
-  for (int fi = 0; fi < NF; fi++)
-    if (!rep[fi] && (P.fronts[fi].parent < 0 || rep[P.fronts[fi].parent])) total += wsub[fi];
-  double cum = 0;
-  for (int fi = NF - 1; fi >= 0; fi--) {  // parents before children
+  std::vector<int> top_owner(NF, -1);
+  if (top_max * 4.0 * W > top_total) {
+    // a few heavy subtrees: largest first to the rank with the least work so far (ties: the lower rank; stable order of equal weights)
+    std::vector<int> order(tops);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return wsub[a] > wsub[b]; });
+    std::vector<double> load(W, 0.0);
+    for (int fi : order) {
+      int best = 0;
+      for (int r = 1; r < W; r++)
+        if (load[r] < load[best]) best = r;
+      top_owner[fi] = best;
+      load[best] += wsub[fi];
+    }
+  } else {
+    // many light subtrees (BAL's point leaves): contiguous chunks of about equal cost, in front order
+    double cum = 0;
+    for (int fi : tops) {
+      top_owner[fi] = std::min(W - 1, (int)(cum / top_total * W));
+      cum += wsub[fi];
+    }
+  }
+  for (int fi = NF - 1; fi >= 0; fi--) {
     const Front& fr = P.fronts[fi];
     if (rep[fi]) continue;
-    if (fr.parent < 0 || rep[fr.parent]) {
-      h->front_owner[fi] = std::min(W - 1, (int)(cum / total * W));
-      cum += wsub[fi];
-    } else {
-      h->front_owner[fi] = h->front_owner[fr.parent];
-    }
+    h->front_owner[fi] = (fr.parent < 0 || rep[fr.parent]) ? top_owner[fi] : h->front_owner[fr.parent];
   }
   for (int fi = 0; fi < NF; fi++) h->front_active[fi] = rep[fi] || h->front_owner[fi] == R;
 }
@@ -1824,6 +1856,8 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
     F.child_begin = (int)childs.size();
     for (int32_t c : fr.children) {
       if (!h->front_active[c]) continue;
+      // a replicated child of a replicated front is identical on every rank: its update matrix enters the parent's sum over the ranks once
+      if ((F.pad & 1) && (h->h_fronts[c].pad & 1) && R != 0) continue;
       const Front& ch = P.fronts[c];
       FrontDesc& CF = h->h_fronts[c];
       const int map_begin = (int)cmap.size();

@@ -47,8 +47,12 @@ def project_bundler(R, t, f, k1, k2, p):
     return np.stack([f * g * u, f * g * v], axis=1), q[:, 2]
 
 
-def make_bal(n_cam=20, n_pt=1000, obs_per_point=10, seed=42, pixel_sigma=0.5, with_priors=True):
-    """returns (graph, initial, truth, ordering_schur)"""
+def make_bal(n_cam=20, n_pt=1000, obs_per_point=10, seed=42, pixel_sigma=0.5, with_priors=True, window=None):
+    """returns (graph, initial, truth, ordering_schur).
+    window = None: every point is seen by `obs_per_point` cameras drawn from ALL cameras (SURVEY's C4: every camera pair ends up
+    co-visible, the camera block of the Hessian is dense).  window = w: the cameras of a point are drawn from w consecutive cameras of
+    the ring around a random one -- the banded co-visibility of a real sequence (BAL's datasets: a camera shares points with its
+    neighbours along the trajectory), whose nested-dissection ordering has small top separators over independent camera subtrees."""
     rng = np.random.default_rng(seed)
     ang = 2 * np.pi * np.arange(n_cam) / n_cam
     eyes = np.stack([30 * np.cos(ang), 30 * np.sin(ang), rng.uniform(-3, 3, n_cam)], axis=1)
@@ -61,13 +65,23 @@ def make_bal(n_cam=20, n_pt=1000, obs_per_point=10, seed=42, pixel_sigma=0.5, wi
     k2 = 1e-4 * rng.uniform(-1, 1, n_cam)
     pts = rng.uniform(-8, 8, (n_pt, 3))
     k = min(obs_per_point, n_cam)
-    cam_idx = rng.integers(0, n_cam, (n_pt, k))
+    if window is None:
+        cam_idx = rng.integers(0, n_cam, (n_pt, k))
+        redraw = lambda m: rng.integers(0, n_cam, (m, k))  # noqa: E731
+    else:
+        w = int(min(max(window, k), n_cam))
+        centre = rng.integers(0, n_cam, n_pt)
+
+        def draw(c):
+            return (c[:, None] - w // 2 + rng.integers(0, w, (len(c), k))) % n_cam
+
+        cam_idx = draw(centre)
     for _ in range(64):  # redraw rows that contain a repeated camera
         srt = np.sort(cam_idx, axis=1)
         bad = (srt[:, 1:] == srt[:, :-1]).any(axis=1)
         if not bad.any():
             break
-        cam_idx[bad] = rng.integers(0, n_cam, (int(bad.sum()), k))
+        cam_idx[bad] = redraw(int(bad.sum())) if window is None else draw(centre[bad])
     cam_idx = np.sort(cam_idx, axis=1)
     ci = cam_idx.reshape(-1)
     pj = np.repeat(np.arange(n_pt), k)
