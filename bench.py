@@ -87,7 +87,7 @@ def cpu_baseline(graph, initial, ordering, ordering_name, size_key, full_tag=Non
                                                             "eliminate_ms": 1e3 * r["eliminate_s"]} for r in tj["runs"]]}
         except OSError:
             pass
-    if size_key in REFERENCE_MEASURED:
+    if size_key in REFERENCE_MEASURED and "co-visibility window" not in (full_tag or "") and not (full_tag or "").startswith("c4band"):
         out["reference_measured"] = {"what": "the real reference (libgtsam), one LevenbergMarquardtOptimizer::iterate() on this workload",
                                      "source": REFERENCE_MEASURED["source"], "unit": "LM iterations/s", "runs": REFERENCE_MEASURED[size_key]}
     # the 1/10-per-dimension sample of rounds 1-2 (3 iterations each, single thread and all cores, subtree parallelism only)
@@ -110,8 +110,8 @@ def metis_fixture_ordering(args, schur):
     INPUT of the hot path.  The METIS permutation of the bench workloads is carried by a committed fixture
     (tests/tools/make_c4_fixture.py: Ordering::Metis through the reference's own METIS sources, oracle/_ref)."""
     import numpy as np
-    tags = {(1000, 100000, 10, 42): "c4_seed42", (100, 10000, 10, 42): "bal100_seed42"}
-    tag = tags.get((args.cams, args.points, args.obs, args.seed))
+    tags = {(1000, 100000, 10, 42, None): "c4_seed42", (100, 10000, 10, 42, None): "bal100_seed42", (1000, 100000, 10, 42, 40): "c4band_seed42"}
+    tag = tags.get((args.cams, args.points, args.obs, args.seed, args.window))
     if tag is None:
         raise SystemExit("--ordering metis: no METIS fixture for this size (tests/golden/*_metis.npz); use --ordering schur")
     fx = np.load(os.path.join(ROOT, "tests", "golden", f"{tag}_metis.npz"))
@@ -308,6 +308,38 @@ def isam2_bench(args):
     print(json.dumps(out), flush=True)
 
 
+def scaling_model(graph, initial, ordering, worlds=(2, 4, 8)):
+    """What the ownership rule (csrc/lmgpu.hip: assign_owners) gives this graph at 2 / 4 / 8 ranks, from structure-only handles (no device):
+    replicated fronts, per-rank owned work, bytes all-reduced, and a time model -- a dense front = 150 us of dependent launches (measured:
+    the 122 dense fronts of the --window 40 workload take 20 ms on one GPU, each its own gather / panel / update launch sequence) + its
+    flop at the single-GPU rate of the chained factorisation (2 nf n^2 / 3 at 44 TFLOP/s); point leaves at the measured 16 ns each (leaf
+    fronts + their share of the back-substitution); the all-reduce of a replicated front as a ring over xGMI at 100 GB/s algorithm
+    bandwidth, of which the first 512 rows are exposed (the rest travels beside the factorisation).  A model, not a measurement: no
+    multi-GPU node is available to the build."""
+    from gtsam_personal_amd import LevenbergMarquardtOptimizer
+
+    def t_front(f):
+        return (f["nf"] * f["n"] * f["n"] / 3.0) * 2.0 / 44e12 + 150e-6 if f["cls"] == 1 else 16e-9
+
+    out = {}
+    for W in worlds:
+        probe = LevenbergMarquardtOptimizer(graph, initial, ordering, device=-1, rank=0, world_size=W)
+        info = [probe.front_info(i) for i in range(probe.num_fronts())]
+        probe.close()
+        rep = [f for f in info if f["owner"] < 0]
+        t_rep = sum(t_front(f) for f in rep)
+        t_own = [sum(t_front(f) for f in info if f["owner"] == r) for r in range(W)]
+        t_one = sum(t_front(f) for f in info)
+        ar_bytes = sum(f["n"] * f["n"] * 4 for f in rep)  # upper triangle, FP64
+        t_ar_exposed = sum(min(f["n"], 512) * f["n"] * 8 for f in rep) * 2.0 * (W - 1) / W / 100e9  # the first chunks; the rest hides behind the factorisation
+        out[str(W)] = {"replicated_fronts": len(rep), "replicated_dense_columns": sum(f["nf"] for f in rep),
+                       "owned_dense_fronts_per_rank": [sum(1 for f in info if f["owner"] == r and f["cls"] == 1) for r in range(W)],
+                       "model_ms_single": 1e3 * t_one, "model_ms_replicated": 1e3 * t_rep, "model_ms_owned_max": 1e3 * max(t_own),
+                       "allreduce_mbytes": ar_bytes / 1e6, "model_ms_allreduce_exposed": 1e3 * t_ar_exposed,
+                       "model_speedup": t_one / (t_rep + max(t_own) + t_ar_exposed)}
+    return out
+
+
 def pmc_traffic():
     """HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (counters cannot be collected
     from inside the process): {kernel: bytes}.  tools/pmc_summary.py writes the file; absent file -> traffic null."""
@@ -339,6 +371,10 @@ def main():
                          "reference's size (single GPU side line; --ordering colamd|metis); isam2 = BASELINE configs[4] (VisualISAM2Example) and the "
                          "reference's incremental loop on city10000, ms per ISAM2::update through the C ABI")
     ap.add_argument("--isam2-poses", type=int, default=10000, help="--workload isam2: poses of the city10000 incremental loop")
+    ap.add_argument("--window", type=int, default=None,
+                    help="banded co-visibility: every point is seen from cameras within this window of the ring (synthetic.make_bal window=); "
+                         "--window 40 at the default size has a METIS fixture.  The camera block of the Hessian is then sparse and the camera "
+                         "subtrees below the top separators shard over the ranks, dense fronts included")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-peaks", action="store_true", help="skip the device micro-benchmarks (profiling runs: hundreds of extra launches under PMC)")
@@ -388,7 +424,7 @@ def main():
         del x
         torch.cuda.empty_cache()
     t_setup = time.perf_counter()
-    graph, initial, _, ordering = make_bal(args.cams, args.points, args.obs, seed=args.seed)
+    graph, initial, _, ordering = make_bal(args.cams, args.points, args.obs, seed=args.seed, window=args.window)
     ordering_name = "Schur ordering (points then cameras)"
     if args.ordering == "metis":
         ordering = metis_fixture_ordering(args, ordering)
@@ -466,13 +502,14 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"synthetic BAL {args.cams} cameras / {args.points} points / {n_factors} factors (GeneralSFMFactor<Cal3Bundler> + 2 priors), "
-                                   f"seed {args.seed}, {ordering_name}, LM legacy defaults",
+                                   f"seed {args.seed}, {ordering_name}, LM legacy defaults" + (f", co-visibility window {args.window}" if args.window else ""),
                        "ordering": args.ordering,
                        "cameras": args.cams, "points": args.points, "factors": n_factors, "fronts": opt.num_fronts(),
-                       "parallelism": "single GPU" if world == 1 else f"point subtrees sharded over {world} ranks, camera root replicated after ncclAllReduce",
-                       # what this design can reach with more ranks: only the leaves and the Schur gather (~1.5 ms of the 8.7 ms step) shard; the
-                       # 9001^2 camera root (~6.2 ms) is factored on every rank behind a 324 MB all-reduce
-                       **({} if world == 1 else {"scaling_ceiling": "<= ~1.2x over one GPU by construction (replicated root, DESIGN.md section 7)"})},
+                       "parallelism": "single GPU" if world == 1 else f"elimination subtrees (dense fronts included) owned by one of {world} ranks each; fronts too heavy "
+                                                                      "for one rank replicated after ncclAllReduce of their partial assemblies",
+                       # what the ownership rule gives this graph with more ranks (structure-only model; the dense C4 root is all of the work above the
+                       # leaves and stays replicated: <= ~1.2x; with --window the camera subtrees shard)
+                       **({} if (world == 1 and args.window is None) else {"scaling_model": scaling_model(graph, initial, ordering)})},
             "ms_per_linearize": phases["linearize_ms"] / steps,
             "ms_per_eliminate": phases["eliminate_ms"] / max(1, inner),
             "ms_per_backsub": phases["backsub_ms"] / max(1, inner),
@@ -546,7 +583,8 @@ def main():
                 out["roofline_linearize"]["frac_of_measured_copy"] = out["roofline_linearize"]["achieved"] / v.value
         if world == 1 and not args.no_cpu_baseline:
             size_key = (args.cams, args.points, args.obs, args.seed)
-            full_tag = {(1000, 100000, 10, 42): "c4_seed42", (100, 10000, 10, 42): "bal100_seed42"}.get(size_key)
+            full_tag = {(1000, 100000, 10, 42): "c4_seed42", (100, 10000, 10, 42): "bal100_seed42"}.get(size_key) if args.window is None else \
+                {(1000, 100000, 10, 42, 40): "c4band_seed42"}.get(size_key + (args.window,))
             out["cpu_baseline"] = cpu_baseline(graph, initial, ordering, ordering_name, size_key, full_tag)
         sys.stdout.flush()
         if saved_stdout is not None:

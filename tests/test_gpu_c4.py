@@ -18,6 +18,10 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 CASES = {"bal100_seed42": (100, 10000, 10, 42), "c4_seed42": (1000, 100000, 10, 42)}
+# the same size with banded co-visibility (every point seen from 40 neighbouring cameras of the ring): the workload whose camera subtrees
+# shard over the ranks (bench.py --window 40); METIS only
+WINDOW = {"c4band_seed42": 40}
+CASES["c4band_seed42"] = (1000, 100000, 10, 42)
 
 
 def fixture_ordering(fx, schur):
@@ -33,12 +37,12 @@ def rel(a, b):
     return float(np.linalg.norm(a - b) / np.linalg.norm(b))
 
 
-@pytest.mark.parametrize("ordering_name", ["schur", "metis"])
-@pytest.mark.parametrize("tag", ["bal100_seed42", "c4_seed42"])
+@pytest.mark.parametrize("tag,ordering_name", [("bal100_seed42", "schur"), ("bal100_seed42", "metis"), ("c4_seed42", "schur"), ("c4_seed42", "metis"),
+                                               ("c4band_seed42", "metis")])
 def test_headline_workload_matches_oracle_fixture(tag, ordering_name):
     fx = np.load(os.path.join(GOLD, f"{tag}_{ordering_name}.npz"))
     n_cam, n_pt, obs, seed = CASES[tag]
-    graph, initial, _, schur = make_bal(n_cam, n_pt, obs, seed=seed)
+    graph, initial, _, schur = make_bal(n_cam, n_pt, obs, seed=seed, window=WINDOW.get(tag))
     ordering = fixture_ordering(fx, schur)
     params = LevenbergMarquardtParams()
     opt = LevenbergMarquardtOptimizer(graph, initial, ordering, params, device=0)

@@ -133,8 +133,9 @@ def main():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--orderings", default="schur,metis")
     ap.add_argument("--tag", default="c4_seed42")
+    ap.add_argument("--window", type=int, default=None, help="banded co-visibility (synthetic.make_bal window=): the multi-GPU camera-subtree workload")
     args = ap.parse_args()
-    graph, initial, _, schur = make_bal(args.cams, args.points, args.obs, seed=args.seed)
+    graph, initial, _, schur = make_bal(args.cams, args.points, args.obs, seed=args.seed, window=args.window)
     gold = os.path.join(ROOT, "tests", "golden")
     timings = []
     for name in args.orderings.split(","):
@@ -150,7 +151,8 @@ def main():
         timings.append(run(graph, initial, ordering, name, os.path.join(gold, f"{args.tag}_{name}.npz"), rng))
     import platform
     with open(os.path.join(gold, f"{args.tag}_timing.json"), "w") as f:
-        json.dump(dict(workload=f"synthetic BAL {args.cams} cameras / {args.points} points / {graph.size()} factors, seed {args.seed}",
+        json.dump(dict(workload=f"synthetic BAL {args.cams} cameras / {args.points} points / {graph.size()} factors, seed {args.seed}" +
+                                (f", co-visibility window {args.window}" if args.window else ""),
                        what="oracle/liblm_oracle.so (CPU restatement of the reference's algorithm), ONE LevenbergMarquardtOptimizer::iterate(), "
                             "1 thread, build container (8 vCPU Xeon 2.1 GHz)", host=platform.processor() or platform.machine(),
                        runs=timings), f, indent=1)
