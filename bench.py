@@ -375,6 +375,8 @@ def main():
                     help="banded co-visibility: every point is seen from cameras within this window of the ring (synthetic.make_bal window=); "
                          "--window 40 at the default size has a METIS fixture.  The camera block of the Hessian is then sparse and the camera "
                          "subtrees below the top separators shard over the ranks, dense fronts included")
+    ap.add_argument("--dev-library", action="store_true",
+                    help="development: run on liblmgpu_test.so, the build that reads the LMGPU_* A/B switches from the environment (tools/variants/ab.sh)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-peaks", action="store_true", help="skip the device micro-benchmarks (profiling runs: hundreds of extra launches under PMC)")
@@ -382,6 +384,9 @@ def main():
                     help="1-GPU rehearsal of the multi-rank data path: one-rank RCCL communicator, chunked all-reduce of the root")
     args = ap.parse_args()
 
+    if args.dev_library:
+        from gtsam_personal_amd import _lib as _l
+        _l.use_test_library(True)
     if args.workload != "bal":
         if args.gpus != 1:
             raise SystemExit("--workload sphere2500 / city10000 / isam2 is a single-GPU side line")

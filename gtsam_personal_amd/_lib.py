@@ -150,11 +150,22 @@ _lib_test = None
 TEST_LIB_PATH = os.path.join(_HERE, "liblmgpu_test.so")
 
 
+_prefer_test_library = False
+
+
+def use_test_library(on: bool):
+    """tests only: make load() hand out liblmgpu_test.so -- the build that reads the LMGPU_* development switches from the environment
+    (A/B forms of the same arithmetic, tests/test_gpu_lookahead.py) and exports the in-process communicator.  The product library reads
+    none of them."""
+    global _prefer_test_library
+    _prefer_test_library = bool(on)
+
+
 def load(test_hooks=False):
     """Load liblmgpu.so once; raises if it has not been built (no fallback).  test_hooks=True: liblmgpu_test.so, the same library
-    built with the in-process communicator the sharded-loop test needs (never used by the product path)."""
+    built with the in-process communicator the sharded-loop test needs and the development switches (never used by the product path)."""
     global _lib, _lib_test
-    if test_hooks:
+    if test_hooks or _prefer_test_library:
         if _lib_test is None:
             if not os.path.exists(TEST_LIB_PATH):
                 raise ImportError(f"{TEST_LIB_PATH} not built: run `make -C gtsam_personal_amd/csrc`")

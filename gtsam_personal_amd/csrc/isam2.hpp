@@ -130,6 +130,8 @@ struct lmgpu_isam2 {
   double *delta_newton = nullptr, *rgprod = nullptr, *grad = nullptr, *dx_u = nullptr;  // laid out like delta
   double *d_cerr = nullptr, *d_dlscal = nullptr, *h_dlscal = nullptr;  // per-clique tree errors; eight scalars on the device / pinned
   size_t cerr_cap = 0;
+  double* d_gpart = nullptr;  // the gradient's terms, a slot per (clique, column): summed per scalar in a fixed order
+  size_t gpart_cap = 0;
   // ISAM2Params::evaluateNonlinearError (ISAM2Params.h:200-203): ISAM2Result::errorBefore / errorAfter of the last update
   bool evaluate_error = false;
   double error_before = 0, error_after = 0;
@@ -236,8 +238,8 @@ int is_stage_begin(lmgpu_isam2* S) {
   }
   S->stage_extra.clear();
   size_t floor_bytes = size_t(1) << 20;
-  if (const char* e = getenv("LMGPU_ISAM2_STAGE_BYTES")) floor_bytes = (size_t)std::max(64L, atol(e));  // tests: a tiny arena, every request overflows
-  const size_t want = getenv("LMGPU_ISAM2_STAGE_BYTES") ? floor_bytes : std::max<size_t>(floor_bytes, 2 * S->stage_want);
+  if (const char* e = dev_switch("LMGPU_ISAM2_STAGE_BYTES")) floor_bytes = (size_t)std::max(64L, atol(e));  // tests: a tiny arena, every request overflows
+  const size_t want = dev_switch("LMGPU_ISAM2_STAGE_BYTES") ? floor_bytes : std::max<size_t>(floor_bytes, 2 * S->stage_want);
   if (want > S->stage_cap) {
     if (S->h_stage) (void)hipHostFree(S->h_stage);
     if (S->d_stage) (void)hipFree(S->d_stage);
@@ -774,21 +776,31 @@ __device__ __forceinline__ void isam2_clique_rows(const lmgpu::FrontDesc& F, int
 // g -= [R S]^T d  (ISAM2::gradientAtZero, ISAM2.cpp:825-833: the sum of the cliques' gradient contributions, ISAM2Clique.cpp:35-46)
 __global__ __launch_bounds__(256) void isam2_tree_gradient_kernel(const int32_t* __restrict__ list, int nlist, const lmgpu::FrontDesc* __restrict__ tree,
                                                                   const int32_t* __restrict__ tree_fx, const int32_t* __restrict__ tree_sx,
-                                                                  const double* __restrict__ pool, double* __restrict__ g) {
+                                                                  const double* __restrict__ pool, const int32_t* __restrict__ part_off,
+                                                                  double* __restrict__ part) {
+  // every clique writes the terms of its columns into slots of their own; isam2_gradient_gather_kernel adds, per scalar, the slots the
+  // host listed for it in a fixed order (FP64 atomics before round 3: the dog leg's trust-region decisions could differ in the last bit)
   const int li = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (li >= nlist) return;
   const int id = list[li];
   const lmgpu::FrontDesc F = tree[id];
   const int n = F.n, nf = F.nf, ld = F.ld_rsd;
-  const int32_t *fxr, *sxr;
-  isam2_clique_rows(F, id, tree_fx, tree_sx, pool, &fxr, &sxr);
   const double* A = pool + F.rsd_off;
+  double* out = part + part_off[li];
   for (int j = lane; j < n - 1; j += 64) {
     double s = 0.0;
     const int imax = j < nf ? j : nf - 1;
     for (int i = 0; i <= imax; i++) s += A[(size_t)i * ld + j] * A[(size_t)i * ld + n - 1];
-    atomicAdd(&g[j < nf ? fxr[j] : sxr[j - nf]], -s);
+    out[j] = -s;
   }
+}
+__global__ __launch_bounds__(256) void isam2_gradient_gather_kernel(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx, const double* __restrict__ part,
+                                                                     int n, double* __restrict__ g) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= n) return;
+  double s = 0;
+  for (int e = ptr[x]; e < ptr[x + 1]; e++) s += part[idx[e]];
+  g[x] = s;
 }
 // RgProd_F = R g_F + S g_S  (UpdateRgProd, ISAM2-impl.cpp:82-141; recomputed for every clique: below a clique without a replaced key
 // neither its rows nor the gradient on its keys have changed, so the reference's walk would have left the same numbers)
@@ -1433,8 +1445,42 @@ int is_update_delta_dogleg(lmgpu_isam2* S, bool force_full, bool host_delta) {
     hipLaunchKernelGGL(reduce_stage1, dim3(g), dim3(256), 0, s, (const double*)S->d_cerr, nc, S->d_dlscal + 8);
     hipLaunchKernelGGL(reduce_stage2, dim3(1), dim3(256), 0, s, (const double*)(S->d_dlscal + 8), g, dst);
   };
-  ISCHECK(hipMemsetAsync(S->grad, 0, (size_t)n * sizeof(double), s));
-  hipLaunchKernelGGL(isam2_tree_gradient_kernel, gq, dim3(256), 0, s, (const int32_t*)d_alive, nc, T, FX, SX, (const double*)S->pool, S->grad);
+  {
+    // the gradient as a fixed-order sum: slot table of this tree (clique by clique in `alive` order), per scalar the slots that are its
+    std::vector<int32_t> part_off((size_t)nc), ptr((size_t)n + 1, 0), idx;
+    int32_t off = 0;
+    for (int li = 0; li < nc; li++) {
+      part_off[(size_t)li] = off;
+      off += S->clq[alive[(size_t)li]].n - 1;
+    }
+    for (int li = 0; li < nc; li++)  // count
+      for (int32_t v : S->clq[alive[(size_t)li]].vars) {
+        const int xo = S->vars[v].xoff, d = kVarDim[S->vars[v].type];
+        for (int q = 0; q < d; q++) ptr[(size_t)(xo + q) + 1]++;
+      }
+    for (int x = 0; x < n; x++) ptr[(size_t)x + 1] += ptr[(size_t)x];
+    idx.resize((size_t)ptr[(size_t)n]);
+    std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
+    for (int li = 0; li < nc; li++) {
+      int col = 0;
+      for (int32_t v : S->clq[alive[(size_t)li]].vars) {
+        const int xo = S->vars[v].xoff, d = kVarDim[S->vars[v].type];
+        for (int q = 0; q < d; q++) idx[(size_t)fill[(size_t)(xo + q)]++] = part_off[(size_t)li] + col + q;
+        col += d;
+      }
+    }
+    if ((size_t)off > S->gpart_cap) {
+      const size_t cap = is_next_cap(S->gpart_cap, (size_t)off);
+      if ((rc = is_realloc(S, &S->d_gpart, cap, 0))) return rc;
+      S->gpart_cap = cap;
+    }
+    int32_t *d_poff = nullptr, *d_ptr = nullptr, *d_idx = nullptr;
+    if ((rc = is_stage(S, part_off, &d_poff)) || (rc = is_stage(S, ptr, &d_ptr)) || (rc = is_stage(S, idx, &d_idx))) return rc;
+    if ((rc = is_flush(S))) return rc;
+    hipLaunchKernelGGL(isam2_tree_gradient_kernel, gq, dim3(256), 0, s, (const int32_t*)d_alive, nc, T, FX, SX, (const double*)S->pool, (const int32_t*)d_poff,
+                       S->d_gpart);
+    hipLaunchKernelGGL(isam2_gradient_gather_kernel, gv, dim3(256), 0, s, (const int32_t*)d_ptr, (const int32_t*)d_idx, (const double*)S->d_gpart, n, S->grad);
+  }
   hipLaunchKernelGGL(isam2_tree_rg_kernel, gq, dim3(256), 0, s, (const int32_t*)d_alive, nc, T, FX, SX, (const double*)S->pool, (const double*)S->grad, S->rgprod);
   double* sc = S->d_dlscal;  // [0] g.g  [1] Rg.Rg  [2] u.u  [3] n.n  [4] u.n  [5] M(0) x 2  [6] M(dx_d) x 2
   hipLaunchKernelGGL(isam2_dot_kernel, dim3(1), dim3(1024), 0, s, (const double*)S->grad, (const double*)S->grad, n, sc + 0);
@@ -2038,7 +2084,7 @@ int lmgpu_isam2_destroy(lmgpu_isam2* S) {
       if (b.d_meas) (void)hipFree(b.d_meas);
       if (b.d_noise) (void)hipFree(b.d_noise);
     }
-    for (void* p : {(void*)S->delta, (void*)S->ones, (void*)S->d_replaced, (void*)S->d_changed, (void*)S->pool, (void*)S->d_status, (void*)S->d_tree,
+    for (void* p : {(void*)S->delta, (void*)S->ones, (void*)S->d_replaced, (void*)S->d_changed, (void*)S->pool, (void*)S->d_status, (void*)S->d_gpart, (void*)S->d_tree,
                     (void*)S->d_tree_fx, (void*)S->d_tree_sx, (void*)S->d_queue, (void*)S->d_wl, (void*)S->inv16, (void*)S->d_marg, (void*)S->d_ebuf,
                     (void*)S->d_epart, (void*)S->delta_newton, (void*)S->rgprod, (void*)S->grad, (void*)S->dx_u, (void*)S->d_cerr, (void*)S->d_dlscal})
       if (p) (void)hipFree(p);

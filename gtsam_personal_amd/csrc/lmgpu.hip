@@ -36,6 +36,19 @@
 #include "kernels_schur.hpp"
 #include "plan.hpp"
 
+// Development switches (A/B forms of the same arithmetic, cross-checked by tests/test_gpu_lookahead.py): read from the environment by the
+// TEST library only (liblmgpu_test.so, -DLMGPU_TEST_HOOKS).  The product library has two: LMGPU_GRAPH (graph replay on / off) and
+// LMGPU_ISAM2_TRACE (phase times of the incremental path on stderr).
+static const char* dev_switch(const char* name) {
+#ifdef LMGPU_TEST_HOOKS
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+
+
 using namespace lmgpu;
 
 #define HIPCHECK(expr)                                                                         \
@@ -269,6 +282,12 @@ struct lmgpu_handle {
   int n_lds_fronts = 0;                         // all levels' LDS-class fronts are contiguous in d_lists
   double *bt_ebuf = nullptr, *bt_vec = nullptr;  // Dogleg: per-clique / per-row squared residuals; gradient / zero vector
   int bt_ebuf_len = 0;
+  // the gradient as a fixed-order sum: a slot per (clique, column) [per 64-row chunk for HBM fronts], gathered per scalar (built on first use)
+  double* bt_part = nullptr;
+  int64_t* d_bt_part_off = nullptr;  // per entry of d_lists (LDS-class fronts)
+  std::vector<int64_t> bt_hbm_part_off;  // per front id (HBM fronts)
+  int32_t *d_bt_ptr = nullptr, *d_bt_idx = nullptr;
+  bool bt_gather_built = false;
   double* inv16_med = nullptr;
   std::vector<char> is_med;
   int64_t* d_f_off = nullptr;
@@ -984,7 +1003,7 @@ int do_backsub(lmgpu_handle* h) {
       // inverse of the diagonal blocks (all in parallel), then ONE dataflow launch: workgroup b waits for x_j (j > b) flags
       HIPCHECK(hipMemsetAsync(h->bs_flags, 0, (nblk + 1) * sizeof(unsigned int), s));  // flags + ticket
       HIPCHECK(hipMemsetAsync(h->bs_x, 0xff, (size_t)nblk * NB * sizeof(double), s));  // sentinel: "not published yet"
-      if (h->inv16_owner == fi && !getenv("LMGPU_NO_INV16_REUSE"))
+      if (h->inv16_owner == fi && !dev_switch("LMGPU_NO_INV16_REUSE"))
         hipLaunchKernelGGL(hbm_invert_diag64_from16_kernel, dim3(nblk), dim3(64), 0, s, (const double*)(h->pool + off), ld, F.nf,
                            (const double*)h->inv16, h->bs_inv);
       else
@@ -1298,19 +1317,75 @@ int bt_forward(lmgpu_handle* h, const double* x, double alpha, double* out) {
   return LMGPU_OK;
 }
 
-// g = - sum over the cliques of [R S]^T d   (into h->bt_vec)
+// the slots of the gradient's terms and, per scalar, the list of slots that belong to it (front order: LDS-class fronts in the order of
+// d_lists, then the HBM fronts level by level, chunk by chunk): built once per structure, on the first Dogleg iteration
+int bt_build_gather(lmgpu_handle* h) {
+  if (h->bt_gather_built) return LMGPU_OK;
+  const Plan& P = h->plan;
+  std::vector<int32_t> lists((size_t)h->n_lds_fronts);
+  HIPCHECK(hipMemcpy(lists.data(), h->d_lists, lists.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+  std::vector<int64_t> lds_off(lists.size());
+  std::vector<std::vector<int32_t>> slots((size_t)h->ntot);
+  int64_t off = 0;
+  auto scalar_of = [&](const Front& fr, int j) {  // column j of the front -> index in delta
+    size_t k = 0;
+    while (k + 1 < fr.vars.size() && fr.col_off[k + 1] <= j) k++;
+    return P.xoff[fr.vars[k]] + (j - fr.col_off[k]);
+  };
+  for (size_t li = 0; li < lists.size(); li++) {
+    const Front& fr = P.fronts[lists[li]];
+    lds_off[li] = off;
+    for (int j = 0; j < fr.n - 1; j++) slots[(size_t)scalar_of(fr, j)].push_back((int32_t)(off + j));
+    off += fr.n - 1;
+  }
+  h->bt_hbm_part_off.assign(P.fronts.size(), -1);
+  for (const LevelWork& L : h->levels)
+    for (int fi : L.hbm) {
+      const Front& fr = P.fronts[fi];
+      h->bt_hbm_part_off[fi] = off;
+      const int nchunk = (fr.nf + 63) / 64;
+      for (int c = 0; c < nchunk; c++)
+        for (int j = 64 * c; j < fr.n - 1; j++) slots[(size_t)scalar_of(fr, j)].push_back((int32_t)(off + (int64_t)c * (fr.n - 1) + j));
+      off += (int64_t)nchunk * (fr.n - 1);
+    }
+  if (off >= (int64_t)1 << 31) {
+    h->err = "Dogleg: the gradient's slot table exceeds 2^31 entries";
+    return LMGPU_INVALID;
+  }
+  std::vector<int32_t> ptr((size_t)h->ntot + 1, 0), idx;
+  for (int x = 0; x < h->ntot; x++) {
+    ptr[(size_t)x] = (int32_t)idx.size();
+    idx.insert(idx.end(), slots[(size_t)x].begin(), slots[(size_t)x].end());
+  }
+  ptr[(size_t)h->ntot] = (int32_t)idx.size();
+  HIPCHECK(hipMalloc((void**)&h->bt_part, std::max<int64_t>(1, off) * sizeof(double)));
+  HIPCHECK(hipMalloc((void**)&h->d_bt_part_off, std::max<size_t>(1, lds_off.size()) * sizeof(int64_t)));
+  HIPCHECK(hipMalloc((void**)&h->d_bt_ptr, ptr.size() * sizeof(int32_t)));
+  HIPCHECK(hipMalloc((void**)&h->d_bt_idx, std::max<size_t>(1, idx.size()) * sizeof(int32_t)));
+  if (!lds_off.empty()) HIPCHECK(hipMemcpy(h->d_bt_part_off, lds_off.data(), lds_off.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+  HIPCHECK(hipMemcpy(h->d_bt_ptr, ptr.data(), ptr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (!idx.empty()) HIPCHECK(hipMemcpy(h->d_bt_idx, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  h->bt_gather_built = true;
+  return LMGPU_OK;
+}
+
+// g = - sum over the cliques of [R S]^T d   (into h->bt_vec), every entry a sum in a fixed order
 int bt_gradient(lmgpu_handle* h) {
   hipStream_t s = h->stream;
-  HIPCHECK(hipMemsetAsync(h->bt_vec, 0, h->ntot * sizeof(double), s));
+  const int rcb = bt_build_gather(h);
+  if (rcb) return rcb;
   if (h->n_lds_fronts > 0)
     hipLaunchKernelGGL(bt_lds_transpose_kernel, dim3((h->n_lds_fronts + 3) / 4), dim3(256), 0, s, (const int32_t*)h->d_lists, h->n_lds_fronts,
-                       (const FrontDesc*)h->d_fronts, (const int32_t*)h->d_fxoff, (const int32_t*)h->d_sxoff, (const double*)h->pool, h->bt_vec);
+                       (const FrontDesc*)h->d_fronts, (const int32_t*)h->d_fxoff, (const int32_t*)h->d_sxoff, (const double*)h->pool,
+                       (const int64_t*)h->d_bt_part_off, h->bt_part);
   for (const LevelWork& L : h->levels)
     for (int fi : L.hbm) {
       const FrontDesc& F = h->h_fronts[fi];
       hipLaunchKernelGGL(bt_hbm_transpose_kernel, dim3((F.n - 1 + 255) / 256, (F.nf + 63) / 64), dim3(256), 0, s, F, h->f_off[fi], h->f_ld[fi],
-                         (const int32_t*)h->d_fxoff, (const int32_t*)h->d_sxoff, (const double*)h->pool, h->bt_vec);
+                         (const double*)h->pool, h->bt_part + h->bt_hbm_part_off[fi]);
     }
+  hipLaunchKernelGGL(bt_gather_kernel, dim3((h->ntot + 255) / 256), dim3(256), 0, s, (const int32_t*)h->d_bt_ptr, (const int32_t*)h->d_bt_idx,
+                     (const double*)h->bt_part, h->ntot, h->bt_vec);
   HIPCHECK(hipGetLastError());
   return LMGPU_OK;
 }
@@ -1508,16 +1583,16 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
   h->cfg = *cfg;
   if (h->cfg.world_size < 1) h->cfg.world_size = 1;
   h->device = cfg->device;
-  h->two_launch_panel = getenv("LMGPU_PANEL_2L") != nullptr;
-  h->no_fuse = getenv("LMGPU_NO_FUSE") != nullptr;
-  h->no_chain = getenv("LMGPU_NO_CHAIN") != nullptr;
-  h->no_tail = getenv("LMGPU_NO_TAIL") != nullptr;
-  h->no_wide16 = getenv("LMGPU_NO_WIDE16") != nullptr;
-  h->bsd_ticket = getenv("LMGPU_BSD_TICKET") != nullptr;
-  h->no_gather_write = getenv("LMGPU_NO_GATHER_WRITE") != nullptr;
-  if (getenv("LMGPU_NO_MERGE")) h->chain_merge = false;
-  if (const char* e = getenv("LMGPU_CHAIN_SPLIT")) h->chain_split_pct = std::max(0, std::min(100, atoi(e)));
-  if (const char* e = getenv("LMGPU_CHAIN_FAR")) h->chain_far_pct = std::max(10, std::min(100, atoi(e)));
+  h->two_launch_panel = dev_switch("LMGPU_PANEL_2L") != nullptr;
+  h->no_fuse = dev_switch("LMGPU_NO_FUSE") != nullptr;
+  h->no_chain = dev_switch("LMGPU_NO_CHAIN") != nullptr;
+  h->no_tail = dev_switch("LMGPU_NO_TAIL") != nullptr;
+  h->no_wide16 = dev_switch("LMGPU_NO_WIDE16") != nullptr;
+  h->bsd_ticket = dev_switch("LMGPU_BSD_TICKET") != nullptr;
+  h->no_gather_write = dev_switch("LMGPU_NO_GATHER_WRITE") != nullptr;
+  if (dev_switch("LMGPU_NO_MERGE")) h->chain_merge = false;
+  if (const char* e = dev_switch("LMGPU_CHAIN_SPLIT")) h->chain_split_pct = std::max(0, std::min(100, atoi(e)));
+  if (const char* e = dev_switch("LMGPU_CHAIN_FAR")) h->chain_far_pct = std::max(10, std::min(100, atoi(e)));
   *out = h;
   if (h->device >= 0) {
     HIPCHECK(hipSetDevice(h->device));
@@ -1571,7 +1646,7 @@ int lmgpu_destroy(lmgpu_handle* h) {
     for (int t = 0; t < kNumVarTypes; t++) fr(h->type_xoff[t]);
     for (int t = 0; t < kNumVarTypes; t++) fr(h->saved[t]);
     fr(h->gex); fr(h->delta); fr(h->dampw); fr(h->hdiag); fr(h->ebuf0); fr(h->ebuf1); fr(h->partial); fr(h->dscal); fr(h->ywork); fr(h->d_status);
-    fr(h->d_fd); fr(h->d_fronts); fr(h->d_ffac); fr(h->d_childs); fr(h->d_cmap); fr(h->d_fxoff); fr(h->d_sxoff); fr(h->d_lists); fr(h->d_hbm_small); fr(h->d_med_list); fr(h->d_med_fronts); fr(h->inv16_med); fr(h->bt_ebuf); fr(h->bt_vec); fr(h->d_f_ld); fr(h->d_f_off);
+    fr(h->d_fd); fr(h->d_fronts); fr(h->d_ffac); fr(h->d_childs); fr(h->d_cmap); fr(h->d_fxoff); fr(h->d_sxoff); fr(h->d_lists); fr(h->d_hbm_small); fr(h->d_med_list); fr(h->d_med_fronts); fr(h->inv16_med); fr(h->bt_ebuf); fr(h->bt_vec); fr(h->bt_part); fr(h->d_bt_part_off); fr(h->d_bt_ptr); fr(h->d_bt_idx); fr(h->d_f_ld); fr(h->d_f_off);
     fr(h->d_scalar_var); fr(h->d_scalar_col); fr(h->d_vi_ptr); fr(h->d_vi_fac); fr(h->d_vi_pos);
     for (Bucket& b : h->buckets) {
       fr(b.d_vidx); fr(b.d_meas); fr(b.d_noise); fr(b.d_epos);
@@ -2070,7 +2145,7 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
   // deep trees are launch-bound: replay the solve as a graph (LMGPU_GRAPH=0 / 1 overrides the depth rule)
   h->use_graph = (int)h->levels.size() >= 12;
   h->merge_backsub = (int)h->levels.size() >= 12;
-  if (const char* e = getenv("LMGPU_MERGE_BACKSUB")) h->merge_backsub = atoi(e) != 0;
+  if (const char* e = dev_switch("LMGPU_MERGE_BACKSUB")) h->merge_backsub = atoi(e) != 0;
   if (const char* e = getenv("LMGPU_GRAPH")) h->use_graph = atoi(e) != 0;
   // ---- device upload
   HIPCHECK(hipSetDevice(h->device));
@@ -2078,7 +2153,7 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
   // once: entries the kernels read but never write (lower triangles inside diagonal tiles, padding columns) must be finite
   HIPCHECK(hipMemset(h->pool, 0, h->pool_doubles * sizeof(double)));
   int rc;
-  if (!getenv("LMGPU_NO_LEAFPACK")) {  // packed records of the LDS fronts, launch by launch
+  if (!dev_switch("LMGPU_NO_LEAFPACK")) {  // packed records of the LDS fronts, launch by launch
     std::vector<char> packs;
     for (LevelWork& L : h->levels)
       for (int b = 0; b < kNumBins; b++) {
@@ -2190,7 +2265,7 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
         const Front& fr = P.fronts[fi];
         const FrontDesc& F = h->h_fronts[fi];
         const lmgpu_handle::GatherRange& G = h->gather[fi];
-        if (fr.nf > NBO || (F.pad & 1) || G.leaf_count > 0 || G.pblk_short + G.pblk_long + G.vblk_count > 0 || getenv("LMGPU_NO_MED")) continue;
+        if (fr.nf > NBO || (F.pad & 1) || G.leaf_count > 0 || G.pblk_short + G.pblk_long + G.vblk_count > 0 || dev_switch("LMGPU_NO_MED")) continue;
         med.push_back(fi);
         h->is_med[fi] = 1;
         L.med_max_fac = std::max(L.med_max_fac, F.fac_count);

@@ -18,3 +18,12 @@ def _built():
     """build the oracle (test infrastructure) and the product library once per session"""
     import __graft_entry__ as g
     g.build(quiet=True)
+
+
+@pytest.fixture
+def dev_switches():
+    """the LMGPU_* development switches (A/B launch forms) are read by liblmgpu_test.so only: tests that set them run on that build"""
+    from gtsam_personal_amd import _lib
+    _lib.use_test_library(True)
+    yield
+    _lib.use_test_library(False)

@@ -129,3 +129,25 @@ def test_inputs_the_reference_rejects():
     extra.insert_pose2(77, 0.0, 0.0, 0.0)
     with pytest.raises(Exception):  # a variable no factor touches: the elimination tree has no place for it
         LevenbergMarquardtOptimizer(graph, extra, [0, 1, 2, 3, 77], LevenbergMarquardtParams(), device=0).optimize()
+
+
+def test_dogleg_is_bitwise_reproducible():
+    """the Bayes tree's gradient (the steepest-descent half of the dog leg) is a fixed-order sum since round 3 (FP64 atomics before): two runs
+    of DoglegOptimizer take bitwise the same steps -- batch path and the incremental one (ISAM2DoglegParams)"""
+    from gtsam_personal_amd import DoglegOptimizer, DoglegParams
+    from gtsam_personal_amd.synthetic import make_bal
+    graph, initial, _, ordering = make_bal(n_cam=24, n_pt=400, obs_per_point=5, seed=17)
+    runs = []
+    for _ in range(2):
+        p = DoglegParams()
+        p.deltaInitial = 0.5  # small enough that the first steps are cut by the trust region (the gradient matters)
+        opt = DoglegOptimizer(graph, initial, ordering, p, device=0)
+        trace = []
+        for _ in range(4):
+            opt.iterate()
+            trace.append((opt.error(), opt.getDelta()))
+        vals = opt.values()
+        runs.append((trace, np.concatenate([vals.at(k) for k in ordering])))
+        opt.close()
+    assert runs[0][0] == runs[1][0]
+    assert np.array_equal(runs[0][1], runs[1][1])

@@ -67,7 +67,7 @@ def test_visual_isam2_example_step_by_step():
     isam.close()
 
 
-def test_updates_with_a_staging_arena_that_always_overflows(monkeypatch):
+def test_updates_with_a_staging_arena_that_always_overflows(monkeypatch, dev_switches):
     """every table and index list of an update goes through the pinned staging arena (csrc/isam2.hpp); with a 64-byte arena each
     request takes the overflow path (a chunk of its own, freed at the next update) -- same results"""
     monkeypatch.setenv("LMGPU_ISAM2_STAGE_BYTES", "64")

@@ -35,7 +35,7 @@ def test_outer_panels_match_oracle(n_cam):
         assert abs(e1 - o1) <= 1e-6 * max(1.0, abs(o1))
 
 
-def test_launch_forms_agree_on_a_large_root(monkeypatch):
+def test_launch_forms_agree_on_a_large_root(monkeypatch, dev_switches):
     """Beyond the oracle's reach (600 cameras -> 5401 x 5401 root, 22 outer panels, 15 000 leaf fronts): the default path
     (dataflow panels fused into the trailing-update launches) against the same arithmetic issued as separate launches
     (LMGPU_NO_FUSE) and with the two-launch panel form (LMGPU_PANEL_2L) -- three different synchronisation structures, one
@@ -104,7 +104,7 @@ def test_root_sizes_across_block_boundaries(n_cam):
     assert np.allclose(R, rsd, rtol=1e-6, atol=1e-7 * max(1.0, np.abs(rsd).max()))
 
 
-def test_graph_replay_and_merged_backsubstitution_agree_with_eager_launches(monkeypatch):
+def test_graph_replay_and_merged_backsubstitution_agree_with_eager_launches(monkeypatch, dev_switches):
     """Deep clique trees replay their solve as a hipGraph and back-substitute consecutive levels of small fronts in one dataflow
     launch; both only change HOW the same kernels / the same per-front arithmetic are issued.  victoria_park (first 1500 poses,
     natural ordering: a tree of hundreds of levels): repeated solves with different lambda in every mode give the same update."""
@@ -134,7 +134,7 @@ def test_graph_replay_and_merged_backsubstitution_agree_with_eager_launches(monk
             assert abs(e1 - e10) <= 1e-12 * max(1.0, abs(e10)), mode
 
 
-def test_deep_tree_launch_forms_agree(monkeypatch):
+def test_deep_tree_launch_forms_agree(monkeypatch, dev_switches):
     """Round-2 forms of the deep-tree kernels against each other on sphere2500 (20 levels, mid-size fronts of up to 546 columns): the
     block back-substitution with and without tickets (LMGPU_BSD_TICKET: the path of levels with more 64-row blocks than CUs), LDS fronts
     with four and with sixteen waves (LMGPU_NO_WIDE16), mid-size fronts batched per level or one by one (LMGPU_NO_MED: the trailing

@@ -1,7 +1,7 @@
 set -e
 run() { # name, env...
   name=$1; shift
-  env "$@" timeout -k 10 200 python bench.py > gpurun_out/ab_$name.json 2> gpurun_out/ab_$name.err
+  env "$@" timeout -k 10 200 python bench.py --dev-library --no-cpu-baseline > gpurun_out/ab_$name.json 2> gpurun_out/ab_$name.err
   python - "$name" <<'PY'
 import json, sys
 d = json.load(open(f"gpurun_out/ab_{sys.argv[1]}.json"))
