@@ -263,6 +263,11 @@ int is_stage_begin(lmgpu_isam2* S) {
   S->stage_want = 0;
   return LMGPU_OK;
 }
+// Read-only entry points stage tables too, but only an update starts a new arena: between updates (marginals or single estimates of
+// thousands of variables) the arena would fill up and every request would take the overflow path (a pinned allocation each).  They call
+// this first: every entry point ends with a wait, so the stream is idle and a half-full arena can start over.
+int is_stage_recycle(lmgpu_isam2* S) { return (S->stage_used > S->stage_cap / 2 || !S->stage_extra.empty()) ? is_stage_begin(S) : LMGPU_OK; }
+
 // pinned bytes for `bytes` of payload (+ where the device arena mirrors them, if asked for)
 int is_stage_raw(lmgpu_isam2* S, size_t bytes, char** hp, char** dp) {
   const size_t b = (std::max<size_t>(bytes, 1) + 63) & ~size_t(63);
@@ -1578,6 +1583,41 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
       return LMGPU_INVALID;
     }
   }
+  {
+    // the pending input is checked as a whole BEFORE anything changes; a refused update drops it, so that the handle stays as it was and the
+    // next update starts clean (a refusal in the middle used to leave variables committed, factors half entered and the queues still full)
+    auto refuse = [&](const char* why) {
+      S->new_vars.clear();
+      S->new_facs.clear();
+      S->err = why;
+      return LMGPU_INVALID;
+    };
+    std::map<uint64_t, int32_t> pending_type;
+    for (const lmgpu_isam2::NewVar& nv : S->new_vars) {
+      if (S->vid_of.count(nv.key) || !pending_type.emplace(nv.key, nv.type).second) return refuse("ISAM2: variable already exists");
+      if (!S->relin_thresholds.empty()) {  // the reference throws when a variable's Symbol character has no vector of its dimension (ISAM2-impl.h:258-262)
+        auto it = S->relin_thresholds.find((unsigned char)(nv.key >> 56));
+        if (it == S->relin_thresholds.end() || (int)it->second.size() != kVarDim[nv.type])
+          return refuse("ISAM2: the relinearization threshold (FastMap<char, Vector>) has no vector of the right dimension for a new variable's Symbol character");
+      }
+    }
+    for (const lmgpu_isam2::NewFac& nf : S->new_facs)
+      for (int k = 0; k < kFactorArity[nf.type]; k++) {
+        int32_t t = -1;
+        auto it = S->vid_of.find(nf.k[k]);
+        if (it != S->vid_of.end()) {
+          t = S->vars[it->second].type;
+        } else {
+          auto pt = pending_type.find(nf.k[k]);
+          if (pt == pending_type.end()) return refuse("ISAM2: a new factor references a variable that has no value");
+          t = pt->second;
+        }
+        if (t != factor_var_type(nf.type, k)) return refuse("factor/variable type mismatch");
+      }
+    if (up.has_constrained)
+      for (auto& kg : up.constrained)
+        if (!S->vid_of.count(kg.first) && !pending_type.count(kg.first)) return refuse("ISAM2: constrainedKeys names a variable that is not in the system");
+  }
   S->update_count += 1;
   lmgpu_isam2_result res{};
   int rc;
@@ -1881,8 +1921,8 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
       S->roots.clear();
       std::fill(S->node_of.begin(), S->node_of.end(), -1);
       std::vector<int32_t> vids;
-      for (auto& kv : S->vid_of)
-        if (!unusedKeys.count(kv.first)) vids.push_back(kv.second);
+      for (auto& kv : S->vid_of)  // the keys of variableIndex_ (ISAM2.cpp:186-190): a variable that has a value but no factor yet stays out of the tree
+        if (!unusedKeys.count(kv.first) && !S->vindex[kv.second].empty()) vids.push_back(kv.second);
       std::vector<std::vector<int32_t>> cols;
       for (int32_t v : vids) cols.push_back(S->vindex[v]);
       std::map<int32_t, int> groups;
@@ -2225,6 +2265,7 @@ int lmgpu_isam2_error(lmgpu_isam2* S, int32_t which, double* out) {
   if (S->device < 0) return LMGPU_HIP_ERROR;
   ISCHECK(hipSetDevice(S->device));
   int rc;
+  if ((rc = is_stage_recycle(S))) return rc;
   if (which == 0 && S->any_replaced && (rc = is_update_delta(S, false))) return rc;
   return is_graph_error(S, which == 0, out);
 }
@@ -2249,6 +2290,7 @@ int lmgpu_isam2_get_values(lmgpu_isam2* S, int32_t which, uint64_t* keys_out, in
   if (S->device < 0) return LMGPU_HIP_ERROR;
   ISCHECK(hipSetDevice(S->device));
   int rc;
+  if ((rc = is_stage_recycle(S))) return rc;
   if ((rc = is_flush(S))) return rc;
   if (which == 1) {  // calculateBestEstimate: full back-substitution (ISAM2.cpp:763-766)
     if ((rc = is_update_delta(S, true))) return rc;
@@ -2291,6 +2333,10 @@ int lmgpu_isam2_marginal_covariance(lmgpu_isam2* S, uint64_t key, double* cov) {
     return LMGPU_INVALID;
   }
   ISCHECK(hipSetDevice(S->device));
+  {
+    const int rcr = is_stage_recycle(S);
+    if (rcr) return rcr;
+  }
   int rc = is_patch_tree(S);
   if (rc) return rc;
   const lmgpu_isam2::Var& var = S->vars[it->second];
@@ -2314,9 +2360,14 @@ int lmgpu_isam2_marginal_covariance(lmgpu_isam2* S, uint64_t key, double* cov) {
   if ((rc = is_flush(S))) return rc;
   ISCHECK(hipMemsetAsync(S->d_marg, 0, (size_t)dim * S->ntot * sizeof(double), S->stream));
   ISCHECK(hipMemsetAsync(S->d_status, 0x7f, sizeof(int), S->stream));
+  if (max_n * sizeof(double) > 64 * 1024) {  // (a clique of more than 8 192 scalar columns: beyond the kernel's LDS row; refused, not mis-launched)
+    S->err = "ISAM2::marginalCovariance: a clique on the variable's path is wider than this kernel handles";
+    return LMGPU_INVALID;
+  }
   hipLaunchKernelGGL(isam2_marginal_kernel, dim3(dim), dim3(64), max_n * sizeof(double), S->stream, (const int32_t*)d_path, (int)path.size(),
                      (const FrontDesc*)S->d_tree, (const int32_t*)S->d_tree_fx, (const int32_t*)S->d_tree_sx, (const double*)S->pool, S->d_marg, S->ntot,
                      var.xoff, dim, d_out, S->d_status);
+  ISCHECK(hipGetLastError());  // a rejected launch would leave the status word untouched and a stale block in d_out
   ISCHECK(hipMemcpyAsync(cov, d_out, (size_t)dim * dim * sizeof(double), hipMemcpyDeviceToHost, S->stream));
   ISCHECK(hipMemcpyAsync(S->h_status, S->d_status, sizeof(int), hipMemcpyDeviceToHost, S->stream));
   ISCHECK(hipStreamSynchronize(S->stream));
@@ -2341,6 +2392,7 @@ int lmgpu_isam2_get_value(lmgpu_isam2* S, int32_t which, uint64_t key, int32_t* 
   }
   ISCHECK(hipSetDevice(S->device));
   int rc;
+  if ((rc = is_stage_recycle(S))) return rc;
   const bool walk = which == 0 && S->any_replaced;
   if (walk && (rc = is_update_delta_enqueue(S, false, false))) return rc;
   const lmgpu_isam2::Var& v = S->vars[it->second];
@@ -2370,6 +2422,7 @@ int lmgpu_isam2_get_delta(lmgpu_isam2* S, double* packed) {
   if (S->device < 0) return LMGPU_HIP_ERROR;
   ISCHECK(hipSetDevice(S->device));
   int rc;
+  if ((rc = is_stage_recycle(S))) return rc;
   if (S->any_replaced && (rc = is_update_delta(S, false))) return rc;
   std::vector<double> h((size_t)S->ntot);
   if (S->ntot) ISCHECK(hipMemcpy(h.data(), S->delta, h.size() * sizeof(double), hipMemcpyDeviceToHost));

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import oracle_harness as oh
-from gtsam_personal_amd import ISAM2, ISAM2DoglegParams, ISAM2GaussNewtonParams, ISAM2Params
+from gtsam_personal_amd import ISAM2, ISAM2DoglegParams, ISAM2GaussNewtonParams, ISAM2Params, NonlinearFactorGraph, Values, noiseModel
 from gtsam_personal_amd.graph import symbol
 from isam2_examples import constrained_ordering_steps, create_points, slamlike_steps, stale_landmark_steps, visual_steps
 
@@ -593,4 +593,53 @@ def test_dogleg_incremental_pose_graph():
             compare_state(isam, orc)
             assert abs(isam.doglegDelta() - orc.doglegDelta()) <= 1e-6 * orc.doglegDelta()
     compare_state(isam, orc)
+    isam.close()
+
+
+def test_batch_step_with_a_variable_that_has_no_factor_yet():
+    """recalculateBatch orders the keys of variableIndex_ only (gtsam/nonlinear/ISAM2.cpp:186-190): a variable that came with a value but no
+    factor stays out of the tree until a factor reaches it.  Here the first update (always a batch step) carries such a pose; the
+    second one ties it in.  Update by update against the oracle."""
+    odo = noiseModel.Diagonal.Sigmas([0.1, 0.1, 0.05])
+    steps = []
+    g, v = NonlinearFactorGraph(), Values()
+    g.add_PriorFactorPose2(0, [0.0, 0.0, 0.0], odo)
+    g.add_BetweenFactorPose2(0, 1, [1.0, 0.0, 0.0], odo)
+    v.insert_pose2(0, 0.01, 0.01, 0.01)
+    v.insert_pose2(1, 1.1, -0.1, 0.01)
+    v.insert_pose2(2, 2.1, 0.1, 0.0)  # no factor yet
+    steps.append((g, v))
+    g, v = NonlinearFactorGraph(), Values()
+    g.add_BetweenFactorPose2(1, 2, [1.0, 0.0, 0.0], odo)
+    steps.append((g, v))
+    g, v = NonlinearFactorGraph(), Values()
+    g.add_BetweenFactorPose2(2, 3, [1.0, 0.0, 0.0], odo)
+    v.insert_pose2(3, 3.0, 0.0, 0.0)
+    steps.append((g, v))
+    isam, _ = run_sequence(steps, ISAM2Params(ISAM2GaussNewtonParams(0.001), 0.01, 1, True))
+    isam.close()
+
+
+def test_refused_update_leaves_the_handle_usable():
+    """an update whose input is refused (a factor on a variable without a value) changes nothing and drops the pending input: the next,
+    correct update runs as if the refused one had never been issued"""
+    from gtsam_personal_amd import _lib
+    odo = noiseModel.Diagonal.Sigmas([0.1, 0.1, 0.05])
+    isam = ISAM2(ISAM2Params(), ccolamd=ccolamd, device=0)
+    g, v = NonlinearFactorGraph(), Values()
+    g.add_PriorFactorPose2(0, [0.0, 0.0, 0.0], odo)
+    v.insert_pose2(0, 0.0, 0.0, 0.0)
+    isam.update(g, v)
+    bad, bv = NonlinearFactorGraph(), Values()
+    bad.add_BetweenFactorPose2(0, 7, [1.0, 0.0, 0.0], odo)  # pose 7 has no value
+    bv.insert_pose2(1, 1.0, 0.0, 0.0)
+    with pytest.raises(_lib.LmgpuError):
+        isam.update(bad, bv)
+    assert len(isam.calculateEstimate().keys()) == 1  # pose 1 of the refused update was not committed
+    g, v = NonlinearFactorGraph(), Values()
+    g.add_BetweenFactorPose2(0, 1, [1.0, 0.0, 0.0], odo)
+    v.insert_pose2(1, 1.0, 0.0, 0.0)
+    isam.update(g, v)
+    est = isam.calculateEstimate()
+    assert sorted(est.keys()) == [0, 1] and np.allclose(est.at(1), [1.0, 0.0, 0.0], atol=1e-6)
     isam.close()
