@@ -342,15 +342,26 @@ def scaling_model(graph, initial, ordering, worlds=(2, 4, 8)):
 
 def pmc_traffic():
     """HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (counters cannot be collected
-    from inside the process): {kernel: bytes}.  tools/pmc_summary.py writes the file; absent file -> traffic null."""
-    path = os.path.join(ROOT, "profiles", "r02", "pmc_summary.json")
-    try:
-        with open(path) as f:
-            d = json.load(f)
-    except OSError:
-        return {}
-    return {k: v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"] for k, v in d.items()
-            if "hbm_read_bytes_corrected" in v and "hbm_write_bytes" in v}
+    from inside the process): {kernel: bytes}.  tools/pmc_round.sh + tools/pmc_summary.py write the file, together with a sha256 of the
+    kernel sources it was collected from: a summary of OTHER kernels than the ones that run now is not reported (traffic null, with the
+    reason beside it)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    for rnd in ("r03", "r02"):
+        path = os.path.join(ROOT, "profiles", rnd, "pmc_summary.json")
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except OSError:
+            continue
+        from pmc_summary import kernel_source_hash
+        sha = d.pop("_kernel_source_sha256", None)
+        if sha != kernel_source_hash():
+            return {"_stale": f"profiles/{rnd}/pmc_summary.json was collected from other kernel sources than the ones in the tree (re-run tools/pmc_round.sh)"}
+        out = {k: v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"] for k, v in d.items()
+               if isinstance(v, dict) and "hbm_read_bytes_corrected" in v and "hbm_write_bytes" in v}
+        out["_source"] = f"profiles/{rnd}/pmc_summary.json"
+        return out
+    return {}
 
 
 def main():
@@ -542,7 +553,7 @@ def main():
                                                       "+ factorisation of panel i+1 in the same launch)"),
                                    "bound": "mfma", "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                    "frac": tf / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc.get(kname),
-                                   "traffic_unit": "HBM bytes per launch (FETCH_SIZE x 2 gfx950 correction + WRITE_SIZE; profiles/r02/pmc_summary.json)",
+                                   "traffic_unit": "HBM bytes per launch (FETCH_SIZE x 2 gfx950 correction + WRITE_SIZE; " + pmc.get("_source", pmc.get("_stale", "no PMC summary committed")) + ")",
                                    "launches": syrk["launches"], "avg_launch_us": 1e3 * syrk["ms"] / syrk["launches"],
                                    "flop_per_launch": syrk["work"] / syrk["launches"]}
             if lin["launches"] > 0 and lin["ms"] > 0:

@@ -1,7 +1,9 @@
 #!/bin/bash
-# PMC passes of the default bench command, one counter group per run (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass)
+# PMC passes of the default bench command, one counter group per run (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass).
+# usage: tools/pmc_round.sh r03
+R=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r02
+O=gpurun_out/$R
 mkdir -p $O
 for grp in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY"; do
   tag=$(echo $grp | tr ' ' '_' | cut -c1-24)

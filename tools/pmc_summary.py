@@ -10,10 +10,25 @@ summary gives the mean per launch and the launch count of every kernel.
 """
 import csv
 import glob
+import hashlib
 import json
+import os
 import re
 import sys
 from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_source_hash():
+    """sha256 over the kernel sources: bench.py reports the counters of a summary only while the kernels are the ones that were profiled"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "gtsam_personal_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hpp", ".hip", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()
 
 
 def short(name):
@@ -51,6 +66,7 @@ def main():
             e["mfma_busy_over_sq_busy"] = e["SQ_VALU_MFMA_BUSY_CYCLES_mean"] / e["SQ_BUSY_CYCLES_mean"]
         e["avg_us_under_pmc"] = dur[k][1] / max(1, dur[k][0])
         out[k] = e
+    out["_kernel_source_sha256"] = kernel_source_hash()
     json.dump(out, sys.stdout, indent=1)
     print()
 
