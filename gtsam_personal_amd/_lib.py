@@ -111,6 +111,7 @@ SYMBOLS = {
     "lmgpu_isam2_last_failed_key": (ct.c_uint64, [_H]),
     "lmgpu_isam2_add_variables": (ct.c_int, [_H, ct.c_int32, ct.POINTER(ct.c_uint64), _I, _D]),
     "lmgpu_isam2_add_factors": (ct.c_int, [_H, ct.c_int32, ct.c_int32, ct.POINTER(ct.c_uint64), _D, ct.c_int32, _D]),
+    "lmgpu_isam2_add_factors_robust": (ct.c_int, [_H, ct.c_int32, ct.c_int32, ct.POINTER(ct.c_uint64), _D, ct.c_int32, _D, ct.c_int32, ct.c_double]),
     "lmgpu_isam2_update": (ct.c_int, [_H, ct.c_int32, ct.c_void_p]),
     "lmgpu_isam2_update_with": (ct.c_int, [_H, ct.c_void_p, ct.c_void_p]),
     "lmgpu_isam2_set_relinearize_thresholds": (ct.c_int, [_H, ct.c_int32, ct.c_char_p, _I, _D]),

@@ -62,6 +62,8 @@ struct lmgpu_isam2 {
   std::vector<Fac> facs;
   struct Bkt {
     int type = 0, noise_kind = 0, rows = 0, cols = 0, ml = 0, nl = 0, ar = 0;
+    int robust = 0;  // noiseModel::Robust around the Gaussian model of every factor of the bucket (lmgpu_robust_kind), tuning constant
+    double rk = 0.0;
     int n = 0, cap = 0;
     int64_t joff = -1;  // pool offset of the bucket's Jacobians (cap x rows x cols)
     int32_t* d_vidx = nullptr;
@@ -108,6 +110,8 @@ struct lmgpu_isam2 {
     int32_t type, noise_kind;
     uint64_t k[3];
     std::vector<double> meas, noise;
+    int32_t robust = 0;  // lmgpu_robust_kind around the Gaussian model (0 = none) and its tuning constant
+    double rk = 0.0;
   };
   std::vector<NewFac> new_facs;
   int update_count = 0;
@@ -443,8 +447,8 @@ void is_linearize_sel(lmgpu_isam2* S, const lmgpu_isam2::Bkt& b, const int32_t* 
   d.noise = b.d_noise;
   d.J = S->pool + b.joff;
   d.epos = nullptr;
-  d.robust = 0;
-  d.rk = 0.0;
+  d.robust = b.robust;
+  d.rk = b.rk;
   d.sel = d_sel;
   ValuesDev vals;
   for (int t = 0; t < kNumVarTypes; t++) vals.v[t] = S->theta[t];
@@ -1372,8 +1376,8 @@ int is_graph_error(lmgpu_isam2* S, bool at_estimate, double* out) {
     d.noise = b.d_noise;
     d.J = nullptr;
     d.epos = b.d_epos;
-    d.robust = 0;
-    d.rk = 0.0;
+    d.robust = b.robust;
+    d.rk = b.rk;
     d.sel = nullptr;
     const int g256 = (b.n + 255) / 256, g128 = (b.n + 127) / 128;
     double* eb = S->d_ebuf;
@@ -1735,11 +1739,13 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
     }
     int bi = -1;
     for (size_t b = 0; b < S->bkts.size(); b++)
-      if (S->bkts[b].type == nf.type && S->bkts[b].noise_kind == nf.noise_kind) bi = (int)b;
+      if (S->bkts[b].type == nf.type && S->bkts[b].noise_kind == nf.noise_kind && S->bkts[b].robust == nf.robust && S->bkts[b].rk == nf.rk) bi = (int)b;
     if (bi < 0) {
       lmgpu_isam2::Bkt b;
       b.type = nf.type;
       b.noise_kind = nf.noise_kind;
+      b.robust = nf.robust;
+      b.rk = nf.rk;
       b.rows = kFactorRows[nf.type];
       b.ar = ar;
       b.ml = kFactorMeas[nf.type];
@@ -2181,6 +2187,19 @@ int lmgpu_isam2_add_factors(lmgpu_isam2* S, int32_t factor_type, int32_t n, cons
     f.meas.assign(meas + (size_t)i * ml, meas + (size_t)(i + 1) * ml);
     if (nl) f.noise.assign(noise + (size_t)i * nl, noise + (size_t)(i + 1) * nl);
     S->new_facs.push_back(std::move(f));
+  }
+  return LMGPU_OK;
+}
+
+int lmgpu_isam2_add_factors_robust(lmgpu_isam2* S, int32_t factor_type, int32_t n, const uint64_t* keys, const double* meas, int32_t noise_kind,
+                                   const double* noise, int32_t robust_kind, double robust_k) {
+  if (!S || robust_kind < LMGPU_ROBUST_NONE || robust_kind > LMGPU_ROBUST_L2_WITH_DEAD_ZONE) return LMGPU_INVALID;
+  const size_t first = S->new_facs.size();
+  const int rc = lmgpu_isam2_add_factors(S, factor_type, n, keys, meas, noise_kind, noise);
+  if (rc) return rc;
+  for (size_t i = first; i < S->new_facs.size(); i++) {
+    S->new_facs[i].robust = robust_kind;
+    S->new_facs[i].rk = robust_k;
   }
   return LMGPU_OK;
 }

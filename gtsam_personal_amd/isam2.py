@@ -143,10 +143,8 @@ class ISAM2:
             rec = [None] * newFactors.size()
             for ftype, kind, gi, keys, meas, noise, models in newFactors.buckets():
                 for i, g in enumerate(gi.tolist()):
-                    if models[i].robust_kind:
-                        raise NotImplementedError("robust noise models are not bound in the incremental path")
-                    rec[g] = (ftype, kind, keys[i], meas[i], None if kind == N_UNIT else noise[i])
-            for ftype, kind, keys, meas, noise in rec:  # one call per factor keeps the graph order across buckets
+                    rec[g] = (ftype, kind, keys[i], meas[i], None if kind == N_UNIT else noise[i], models[i].robust_kind, models[i].robust_k)
+            for ftype, kind, keys, meas, noise, rkind, rk in rec:  # one call per factor keeps the graph order across buckets
                 m = np.array(meas, dtype=np.float64)
                 if ftype == F_SFM:
                     m = m - self._u0v0[int(keys[0])]
@@ -154,8 +152,8 @@ class ISAM2:
                     m = m[:15]
                 kk = np.ascontiguousarray(keys[:FACTOR_ARITY[ftype]], dtype=np.uint64)
                 nz = None if noise is None else np.ascontiguousarray(noise, dtype=np.float64)
-                self._check(self.lib.lmgpu_isam2_add_factors(self._h, ftype, 1, kk.ctypes.data_as(U64), np.ascontiguousarray(m).ctypes.data_as(_lib._D),
-                                                             kind, None if nz is None else nz.ctypes.data_as(_lib._D)))
+                self._check(self.lib.lmgpu_isam2_add_factors_robust(self._h, ftype, 1, kk.ctypes.data_as(U64), np.ascontiguousarray(m).ctypes.data_as(_lib._D),
+                                                                    kind, None if nz is None else nz.ctypes.data_as(_lib._D), int(rkind), float(rk)))
         res = _lib.lmgpu_isam2_result()
         rm = np.asarray(list(removeFactorIndices), dtype=np.uint64)
         ck = np.asarray(sorted(constrainedKeys) if constrainedKeys else [], dtype=np.uint64)

@@ -285,6 +285,7 @@ int lmgpu_selftest_chain_schedule(int n, int nf, int i0, int nsteps, int far_pct
  * noRelinKeys, extraReelimKeys, force_relinearize, forceFullSolve.
  * relinearizeThreshold as FastMap<char, Vector> and enablePartialRelinearizationCheck: the two setters below.
  * ISAM2DoglegParams: lmgpu_isam2_set_dogleg.
+ * Robust noise models: lmgpu_isam2_add_factors_robust.
  * Not bound: QR, marginalizeLeaves, newAffectedKeys (smart factors), findUnusedFactorSlots (not offered).
  *
  * The fill-reducing ordering is a boundary input like in the batch path, but here it is needed per update: the caller hands over
@@ -335,6 +336,11 @@ int lmgpu_isam2_add_variables(lmgpu_isam2* s, int32_t n, const uint64_t* keys, c
 /* newFactors of the next update, appended in call order (= their order in the NonlinearFactorGraph); keys: n x arity Keys */
 int lmgpu_isam2_add_factors(lmgpu_isam2* s, int32_t factor_type, int32_t n, const uint64_t* keys, const double* meas, int32_t noise_kind,
                             const double* noise);
+/* the same with noiseModel::Robust(mEstimator(robust_k), model) around the Gaussian model of every one of the n factors (lmgpu_robust_kind;
+ * gtsam/linear/NoiseModel.h:663-760): relinearization reweights [A b] by sqrt(weight(||b||)) (Robust::WhitenSystem, Block scheme) and
+ * evaluateNonlinearError uses the m-estimator's loss, exactly as in the batch path (lmgpu_add_factor_bucket_robust) */
+int lmgpu_isam2_add_factors_robust(lmgpu_isam2* s, int32_t factor_type, int32_t n, const uint64_t* keys, const double* meas, int32_t noise_kind,
+                                   const double* noise, int32_t robust_kind, double robust_k);
 int lmgpu_isam2_update(lmgpu_isam2* s, int32_t force_relinearize, lmgpu_isam2_result* out);
 /* ISAM2::update(newFactors, newTheta, const ISAM2UpdateParams&) (gtsam/nonlinear/ISAM2.h:176-186, ISAM2UpdateParams.h:30-90).
  * removeFactorIndices: positions in the factor list (getFactorsUnsafe(); the factors of update k start at lmgpu_isam2_num_factors()

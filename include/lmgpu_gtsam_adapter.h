@@ -559,9 +559,8 @@ class GpuISAM2 {
       std::vector<double> meas;
       if (!nm || !lmgpu_detail::extractFactor(newFactors[i], all_, &type, &meas)) throw std::invalid_argument("GpuISAM2: factor type not bound");
       const lmgpu_detail::Noise nz = lmgpu_detail::extractNoise(nm->noiseModel());
-      if (nz.robust != LMGPU_ROBUST_NONE) throw std::invalid_argument("GpuISAM2: robust noise models are not bound in the incremental path");
       std::vector<uint64_t> fk(nm->keys().begin(), nm->keys().end());
-      check(lmgpu_isam2_add_factors(h_, type, 1, fk.data(), meas.data(), nz.kind, nz.data.empty() ? nullptr : nz.data.data()));
+      check(lmgpu_isam2_add_factors_robust(h_, type, 1, fk.data(), meas.data(), nz.kind, nz.data.empty() ? nullptr : nz.data.data(), nz.robust, nz.robustK));
     }
     std::vector<uint64_t> rm(up.removeFactorIndices.begin(), up.removeFactorIndices.end()), ck, nr, ex;
     std::vector<int32_t> cg;

@@ -1998,6 +1998,15 @@ int orc_isam2_add_factor(void* h, int type, const uint64_t* keys, const double* 
   S.newFactors.push_back(f);
   return 0;
 }
+// the same with noiseModel::Robust(mEstimator(k), model) around the factor's Gaussian model (gtsam/linear/NoiseModel.h:663-760)
+int orc_isam2_add_factor_robust(void* h, int type, const uint64_t* keys, const double* meas, int noise_kind, const double* noise, int robust, double rk) {
+  const int rc = orc_isam2_add_factor(h, type, keys, meas, noise_kind, noise);
+  if (rc) return rc;
+  auto& S = ((ISAM2Handle*)h)->S;
+  S.newFactors.back().robust = robust;
+  S.newFactors.back().rk = rk;
+  return 0;
+}
 
 // result5: variablesRelinearized, variablesReeliminated, factorsRecalculated, cliques, batch.  1 = indeterminate system
 static int isam2_update_guarded(void* h, const orc::ISAM2UpdateParams& up, int* result5) {

@@ -438,6 +438,7 @@ class OracleISAM2:
         L.orc_isam2_destroy.argtypes = [ct.c_void_p]
         L.orc_isam2_add_variable.argtypes = [ct.c_void_p, ct.c_uint64, ct.c_int, _D]
         L.orc_isam2_add_factor.argtypes = [ct.c_void_p, ct.c_int, _U, _D, ct.c_int, _D]
+        L.orc_isam2_add_factor_robust.argtypes = [ct.c_void_p, ct.c_int, _U, _D, ct.c_int, _D, ct.c_int, ct.c_double]
         L.orc_isam2_update.argtypes = [ct.c_void_p, ct.c_int, _I]
         L.orc_isam2_set_thresholds.argtypes = [ct.c_void_p, ct.c_int, ct.c_char_p, _I, _D]
         L.orc_isam2_set_partial_check.argtypes = [ct.c_void_p, ct.c_int]
@@ -514,7 +515,6 @@ class OracleISAM2:
                 for i, g in enumerate(gi.tolist()):
                     rec[g] = (ftype, keys[i], meas[i], models[i])
             for ftype, keys, meas, model in rec:
-                assert not getattr(model, "robust_kind", 0)
                 kk = np.zeros(3, dtype=np.uint64)
                 kk[:FACTOR_ARITY[ftype]] = keys
                 m = np.ascontiguousarray(meas, dtype=np.float64)
@@ -524,7 +524,10 @@ class OracleISAM2:
                     nd = dp(np.array([float(model.data)]))
                 else:
                     nd = dp(np.ascontiguousarray(model.data, dtype=np.float64).reshape(-1))
-                assert self.L.orc_isam2_add_factor(self.h, ftype, up(kk), dp(m), model.kind, nd) == 0
+                if getattr(model, "robust_kind", 0):
+                    assert self.L.orc_isam2_add_factor_robust(self.h, ftype, up(kk), dp(m), model.kind, nd, int(model.robust_kind), float(model.robust_k)) == 0
+                else:
+                    assert self.L.orc_isam2_add_factor(self.h, ftype, up(kk), dp(m), model.kind, nd) == 0
         res = np.zeros(5, dtype=np.int32)
         rm = np.asarray(list(removeFactorIndices), dtype=np.uint64)
         ck = np.asarray(sorted(constrainedKeys) if constrainedKeys else [], dtype=np.uint64)

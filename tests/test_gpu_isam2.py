@@ -643,3 +643,32 @@ def test_refused_update_leaves_the_handle_usable():
     est = isam.calculateEstimate()
     assert sorted(est.keys()) == [0, 1] and np.allclose(est.at(1), [1.0, 0.0, 0.0], atol=1e-6)
     isam.close()
+
+
+def test_robust_noise_in_the_incremental_path():
+    """noiseModel::Robust around the factors' Gaussian models (Huber on the odometry, Cauchy on the bearing-range measurements of the
+    slamlike sequence, one landmark measurement a gross outlier): relinearization reweights the cached [A b] like the batch path, update
+    by update against the oracle.  The reference holds no incremental test with robust noise (parity pinned by the oracle's batch
+    equivalence, tests/test_isam2_oracle.py, and by the m-estimator known answers of testNoiseModel.cpp in test_oracle_golden.py)."""
+    mEstimator = noiseModel.mEstimator
+    odo = noiseModel.Robust.Create(mEstimator.Huber.Create(1.0), noiseModel.Diagonal.Sigmas([0.1, 0.1, np.pi / 100.0]))
+    br = noiseModel.Robust.Create(mEstimator.Cauchy.Create(0.5), noiseModel.Diagonal.Sigmas([np.pi / 100.0, 0.1]))
+    steps = []
+    g, v = NonlinearFactorGraph(), Values()
+    g.add_PriorFactorPose2(0, [0.0, 0.0, 0.0], noiseModel.Diagonal.Sigmas([0.1, 0.1, 0.05]))
+    v.insert_pose2(0, 0.01, 0.01, 0.01)
+    steps.append((g, v))
+    for i in range(8):
+        g, v = NonlinearFactorGraph(), Values()
+        g.add_BetweenFactorPose2(i, i + 1, [1.0, 0.0, 0.0], odo)
+        v.insert_pose2(i + 1, float(i + 1) + 0.1, -0.1, 0.01)
+        if i == 2:
+            g.add_BearingRangeFactor2D(i, 100, np.pi / 4.0, 5.0, br)
+            v.insert_point2(100, [2.0 + 5.0 / np.sqrt(2.0), 5.0 / np.sqrt(2.0)])
+        if i == 4:
+            g.add_BearingRangeFactor2D(i, 100, np.pi / 2.0 + 0.9, 9.0, br)  # an outlier: the Cauchy weight takes it out
+        if i == 6:
+            g.add_BearingRangeFactor2D(i, 100, 3.0 * np.pi / 4.0 + 0.35, 4.3, br)
+        steps.append((g, v))
+    isam, orc = run_sequence(steps, ISAM2Params(ISAM2GaussNewtonParams(0.001), 0.01, 1, True))
+    isam.close()
