@@ -573,4 +573,173 @@ __global__ __launch_bounds__(256) void hbm_backsolve_dataflow_kernel(FrontDesc F
   }
 }
 
+// ---- round 3: the same dataflow back-substitution with what sat on its hop-to-hop chain taken off it.
+// (1) Workgroup b builds inv(R_bb) itself while it waits for its turn (from the 16 x 16 inverses the factorisation left behind, as
+//     hbm_invert_diag64_from16_kernel does for all blocks in a launch of its own: 40 us in front of the chain before) and, with it,
+//     M_b = inv(R_bb) R_{b,b+1}.  (2) The hop then is  x_b = u_b - M_b x_{b+1}  with  u_b = inv(R_bb) (y_b - sum_{j > b+1} R_bj x_j)
+//     finished BEFORE x_{b+1} arrives: one 64 x 64 matrix-vector product behind the poll instead of the fold, an LDS round trip, a
+//     barrier and the product with the inverse.  (3) y = d is read from the front's right-hand-side column when the front has no
+//     separator (a root): no launch to copy it.  Measured on the C4 root (141 hops): see DESIGN.md section 6, round 3.
+__global__ __launch_bounds__(256) void hbm_backsolve_dataflow2_kernel(FrontDesc F, int64_t f_off, int ld, const int32_t* __restrict__ fxoff,
+                                                                       const double* __restrict__ pool, const double* __restrict__ inv16,
+                                                                       const double* __restrict__ y /* nullptr: the rhs column itself */,
+                                                                       double* __restrict__ xbuf, unsigned int* __restrict__ flags,
+                                                                       double* __restrict__ delta, int* __restrict__ status) {
+  typedef double d4_t __attribute__((ext_vector_type(4)));
+  constexpr int NB = 64;
+  __shared__ double Rl[64][65];   // R_bb, then R_{b,b+1}
+  __shared__ double Xl[64][65];   // inv(R_bb)
+  __shared__ double Ml[64][65];   // M_b
+  __shared__ double Il[4][16][17];
+  __shared__ double acc[NB], xs[NB], ub[NB];
+  __shared__ int ok, s_ticket;
+  const int nblk = gridDim.x;
+  if (threadIdx.x == 0) s_ticket = (int)atomicAdd(&flags[nblk], 1u);
+  __syncthreads();
+  const int b = nblk - 1 - s_ticket;
+  const int r0 = b * NB, nb = min(NB, F.nf - r0);
+  const int tid = threadIdx.x, row = tid >> 2, quarter = tid & 3, lane = tid & 63, wave = tid >> 6;
+  const int kk = lane >> 4, cc = lane & 15;
+  const double* A = pool + f_off;
+  const int n = F.n;
+  if (tid < NB) acc[tid] = (tid < nb) ? (y ? y[r0 + tid] : A[(size_t)(r0 + tid) * ld + n - 1]) : 0.0;
+  if (tid == 0) ok = 1;
+  // ---- inv(R_bb): identity-padded partial last block
+  for (int idx = tid; idx < 64 * 64; idx += 256) {
+    const int p = idx >> 6, q = idx & 63;
+    double v = (p == q) ? 1.0 : 0.0;
+    if (p < nb && q < nb && q >= p) v = A[(size_t)(r0 + p) * ld + r0 + q];
+    Rl[p][q] = v;
+    Xl[p][q] = 0.0;
+  }
+  const double* I16 = inv16 + (size_t)(b >> 2) * 4096 + (size_t)(4 * (b & 3)) * 256;
+  for (int idx = tid; idx < 4 * 256; idx += 256) Il[idx >> 8][(idx >> 4) & 15][idx & 15] = I16[idx];
+  __syncthreads();
+  if (wave == 0) {  // block back-substitution on the matrix cores: X_hh = I_h;  X_gh = -I_g (sum_{k = g+1..h} R_gk X_kh)
+#pragma unroll
+    for (int h = 0; h < 4; h++) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) Xl[16 * h + kk + 4 * r][16 * h + cc] = Il[h][kk + 4 * r][cc];
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int g = h - 1; g >= 0; g--) {
+        d4_t m = d4_t{0, 0, 0, 0};
+#pragma unroll
+        for (int k = g + 1; k <= h; k++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) m = __builtin_amdgcn_mfma_f64_16x16x4f64(Rl[16 * g + cc][16 * k + 4 * r + kk], Xl[16 * k + 4 * r + kk][16 * h + cc], m, 0, 0, 0);
+        d4_t x = d4_t{0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < 4; r++) x = __builtin_amdgcn_mfma_f64_16x16x4f64(-Il[g][cc][4 * r + kk], m[r], x, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) Xl[16 * g + kk + 4 * r][16 * h + cc] = x[r];
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    }
+  }
+  __syncthreads();
+  // ---- M_b = inv(R_bb) R_{b,b+1} (b < nblk - 1): the tile into Rl, one 16-row slice of the product per wave
+  if (b + 1 < nblk) {
+    const int c0n = (b + 1) * NB, ncoln = min(NB, F.nf - c0n);
+    for (int idx = tid; idx < 64 * 64; idx += 256) {
+      const int p = idx >> 6, q = idx & 63;
+      Rl[p][q] = (p < nb && q < ncoln) ? A[(size_t)(r0 + p) * ld + c0n + q] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 4; h++) {  // rows 16 wave .., columns 16 h ..
+      d4_t m = d4_t{0, 0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < 16; k++) m = __builtin_amdgcn_mfma_f64_16x16x4f64(Xl[16 * wave + cc][4 * k + kk], Rl[4 * k + kk][16 * h + cc], m, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; r++) Ml[16 * wave + kk + 4 * r][16 * h + cc] = m[r];
+    }
+  }
+  __syncthreads();
+  double ibv[16], mv[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    ibv[k] = Xl[row][quarter * 16 + k];
+    mv[k] = Ml[row][quarter * 16 + k];
+  }
+  const double* arow = A + (size_t)(r0 + row) * ld;
+  auto load_rv = [&](int j, double(&r)[16]) {
+    const int c0 = j * NB, ncol = min(NB, F.nf - c0);
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int c = quarter * 16 + k;
+      r[k] = (j > b + 1 && row < nb && c < ncol) ? arow[c0 + c] : 0.0;
+    }
+  };
+  auto poll = [&](int j) {  // wave 0: the 64 values of x_j (the data is the flag: sentinel-preset buffer) into xs
+    const int c0 = j * NB, ncol = min(NB, F.nf - c0);
+    if (tid < NB) {
+      double v = 0.0;
+      if (tid < ncol) {
+        long spins = 0;
+        for (;;) {
+          v = __hip_atomic_load(&xbuf[c0 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (__double_as_longlong(v) != -1LL) break;
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > 2000000L) {
+            ok = 0;
+            v = 0.0;
+            break;
+          }
+        }
+      }
+      xs[tid] = v;
+    }
+  };
+  double rv[16], rv_next[16];
+  load_rv(nblk - 1, rv);
+  for (int j = nblk - 1; j > b + 1; j--) {  // the folds that are not on the chain: every block but the neighbour
+    poll(j);
+    load_rv(j - 1, rv_next);
+    __syncthreads();
+    if (!ok) break;
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) s += rv[k] * xs[quarter * 16 + k];
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    if (quarter == 0) acc[row] -= s;
+#pragma unroll
+    for (int k = 0; k < 16; k++) rv[k] = rv_next[k];
+    __syncthreads();
+  }
+  // u_b = inv(R_bb) acc, before the neighbour's x is there
+  {
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) s += ibv[k] * acc[quarter * 16 + k];
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    if (quarter == 0) ub[row] = s;
+  }
+  double xr;
+  if (b + 1 < nblk && ok) {
+    poll(b + 1);
+    __syncthreads();
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) s += mv[k] * xs[quarter * 16 + k];
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    xr = ub[row] - s;
+  } else {
+    __syncthreads();
+    xr = ub[row];
+  }
+  if (!ok && tid == 0) atomicExch(status + 1, 1 + F.id);  // never expected: spin bound hit (a fault, reported apart from pivot failures)
+  if (quarter == 0 && row < nb) {
+    const double pub = (xr != xr) ? __longlong_as_double(0x7ff8000000000000LL) : xr;  // never the sentinel
+    __hip_atomic_store(&xbuf[r0 + row], pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    delta[fxoff[F.fx_begin + r0 + row]] = xr;
+    if (xr != xr) atomicMin(status, F.id);
+  }
+}
+
 }  // namespace lmgpu

@@ -997,20 +997,28 @@ int do_backsub(lmgpu_handle* h) {
       const int64_t off = h->f_off[fi];
       const int ld = h->f_ld[fi];
       const int kt = h->kt.begin(LMGPU_KT_BACKSUB_HBM, s);
-      hipLaunchKernelGGL(hbm_rhs_init_kernel, dim3(F.nf), dim3(64), 0, s, F, off, ld, (const int32_t*)h->d_sxoff, (const double*)h->pool,
-                         (const double*)h->delta, h->ywork);
       const int nblk = (F.nf + NB - 1) / NB;
-      // inverse of the diagonal blocks (all in parallel), then ONE dataflow launch: workgroup b waits for x_j (j > b) flags
+      const bool has_sep = F.n - F.nf - 1 > 0;
+      if (has_sep)  // y = d - S x_S (a root reads d in place)
+        hipLaunchKernelGGL(hbm_rhs_init_kernel, dim3(F.nf), dim3(64), 0, s, F, off, ld, (const int32_t*)h->d_sxoff, (const double*)h->pool,
+                           (const double*)h->delta, h->ywork);
+      // ONE dataflow launch: workgroup b waits for x_j (j > b); the inverses of the diagonal blocks are built inside it when the 16 x 16
+      // inverses of this front's factorisation are still there (else by a launch of their own in front of it)
       HIPCHECK(hipMemsetAsync(h->bs_flags, 0, (nblk + 1) * sizeof(unsigned int), s));  // flags + ticket
       HIPCHECK(hipMemsetAsync(h->bs_x, 0xff, (size_t)nblk * NB * sizeof(double), s));  // sentinel: "not published yet"
-      if (h->inv16_owner == fi && !dev_switch("LMGPU_NO_INV16_REUSE"))
-        hipLaunchKernelGGL(hbm_invert_diag64_from16_kernel, dim3(nblk), dim3(64), 0, s, (const double*)(h->pool + off), ld, F.nf,
-                           (const double*)h->inv16, h->bs_inv);
-      else
+      if (h->inv16_owner == fi && !dev_switch("LMGPU_NO_INV16_REUSE")) {
+        hipLaunchKernelGGL(hbm_backsolve_dataflow2_kernel, dim3(nblk), dim3(256), 0, s, F, off, ld, (const int32_t*)h->d_fxoff, (const double*)h->pool,
+                           (const double*)h->inv16, has_sep ? (const double*)h->ywork : (const double*)nullptr, h->bs_x, h->bs_flags, h->delta,
+                           h->d_status);
+      } else {
+        if (!has_sep)
+          hipLaunchKernelGGL(hbm_rhs_init_kernel, dim3(F.nf), dim3(64), 0, s, F, off, ld, (const int32_t*)h->d_sxoff, (const double*)h->pool,
+                             (const double*)h->delta, h->ywork);
         hipLaunchKernelGGL((hbm_invert_diag_kernel<NB>), dim3(nblk), dim3(NB), 0, s, (const double*)(h->pool + off), ld, F.nf, h->bs_inv);
-      hipLaunchKernelGGL((hbm_backsolve_dataflow_kernel<NB>), dim3(nblk), dim3(256), 0, s, F, off, ld, (const int32_t*)h->d_fxoff,
-                         (const double*)h->pool, (const double*)h->bs_inv, (const double*)h->ywork, h->bs_x, h->bs_flags, h->delta,
-                         h->d_status);
+        hipLaunchKernelGGL((hbm_backsolve_dataflow_kernel<NB>), dim3(nblk), dim3(256), 0, s, F, off, ld, (const int32_t*)h->d_fxoff,
+                           (const double*)h->pool, (const double*)h->bs_inv, (const double*)h->ywork, h->bs_x, h->bs_flags, h->delta,
+                           h->d_status);
+      }
       h->kt.end(kt, s);
     }
     if (merge) {  // accumulated; flushed before the next HBM front or at the end
