@@ -16,8 +16,10 @@
 //                                       noRelinKeys, extraReelimKeys, force_relinearize, forceFullSolve
 //   ISAM2Params: relinearizeThreshold as double or FastMap<char, Vector>, enablePartialRelinearizationCheck (ISAM2-impl.h:246-378)
 //   ISAM2DoglegParams: ISAM2::updateDelta's Dogleg branch (ISAM2.cpp:739-779), DoglegOptimizerImpl::Iterate (DoglegOptimizerImpl.h:139-254)
-// Not restated (not reached by the configs): QR, marginalizeLeaves, newAffectedKeys (smart factors),
-// findUnusedFactorSlots.
+//   ISAM2::marginalizeLeaves           gtsam/nonlinear/ISAM2.cpp:487-720 (BayesTree::removeSubtree gtsam/inference/BayesTree-inst.h:512-547;
+//                                       LinearContainerFactor without a linearization point, gtsam/nonlinear/LinearContainerFactor.cpp:77-109;
+//                                       fixedVariables_ ISAM2-impl.h:385-388; ISAM2Params::findUnusedFactorSlots, FactorGraph-inst.h:109-137)
+// Not restated (not reached by the configs): QR, newAffectedKeys (smart factors).
 #pragma once
 
 namespace orc {
@@ -71,6 +73,11 @@ struct ISAM2 {
   VectorValues delta;
   std::set<Key> deltaReplacedMask;
   std::vector<Factor> nonlinearFactors;
+  // a slot may hold a LinearContainerFactor (what marginalizeLeaves adds: a constant Gaussian factor on any number of keys, no linearization
+  // point): isContainer[i], its factor is linearFactors[i] for good (never relinearized, error 0: LinearContainerFactor.cpp:77-79, 104-108)
+  std::vector<char> isContainer;
+  std::set<Key> fixedVariables;       // keys of marginal factors: never relinearized (ISAM2.cpp:693, ISAM2-impl.h:385-388)
+  bool findUnusedFactorSlots = false;  // ISAM2Params.h:225
   std::vector<char> removedFactor;  // a removed factor leaves its slot behind (NonlinearFactorGraph::remove resets the pointer): indices stay
   std::vector<GFactor> linearFactors;
   std::vector<ICliquePtr> roots;
@@ -115,6 +122,13 @@ static std::vector<Key> colamd_constrained(const ISAM2& S, const VariableIndex& 
   std::vector<Key> result(nVars);
   for (size_t j = 0; j < nVars; ++j) result[j] = keys[perm[j]];
   return result;
+}
+
+// keys of the factor in slot i (a typed factor's first `arity` keys; a container's own list)
+static std::vector<Key> isam2_factor_keys(const ISAM2& S, size_t i) {
+  if (i < S.isContainer.size() && S.isContainer[i]) return S.linearFactors[i].keys;
+  const Factor& f = S.nonlinearFactors[i];
+  return std::vector<Key>(f.keys, f.keys + kFactorArity[f.type]);
 }
 
 // BayesTree::removeClique gtsam/inference/BayesTree-inst.h:440-460
@@ -468,23 +482,43 @@ static ISAM2Result isam2_update(ISAM2& S, const ISAM2UpdateParams& up) {
   }
   const bool relinNeeded = up.force_relinearize || (S.enableRelinearization && S.relinearizeSkip > 0 && S.update_count % S.relinearizeSkip == 0);
   if (relinNeeded) isam2_update_delta(S, up.forceFullSolve);
-  // 1. pushBackFactors (ISAM2-impl.h:141-173): indices continue the list (findUnusedFactorSlots = false); then the removals
-  const size_t firstNew = S.nonlinearFactors.size();
-  for (auto& f : newFactors) {
-    S.nonlinearFactors.push_back(f);
-    S.removedFactor.push_back(0);
+  // 1. pushBackFactors (ISAM2-impl.h:141-173): FactorGraph::add_factors (FactorGraph-inst.h:109-137) -- the indices continue the list, or
+  //    (findUnusedFactorSlots) the new factors fill the empty slots from the front; then the removals
+  std::vector<size_t> newFactorsIndices;
+  {
+    size_t i = 0;
+    for (auto& f : newFactors) {
+      if (S.findUnusedFactorSlots) {
+        while (i < S.nonlinearFactors.size() && !S.removedFactor[i]) ++i;
+      } else {
+        i = S.nonlinearFactors.size();
+      }
+      if (i >= S.nonlinearFactors.size()) {
+        S.nonlinearFactors.push_back(f);
+        S.removedFactor.push_back(0);
+        S.isContainer.push_back(0);
+        S.linearFactors.push_back(GFactor());
+        i = S.nonlinearFactors.size() - 1;
+      } else {
+        S.nonlinearFactors[i] = f;
+        S.removedFactor[i] = 0;
+        S.isContainer[i] = 0;
+      }
+      newFactorsIndices.push_back(i);
+    }
   }
+  const std::set<size_t> newIndexSet(newFactorsIndices.begin(), newFactorsIndices.end());
   std::set<Key> keysWithRemovedFactors;
   for (size_t index : up.removeFactorIndices) {
-    if (index >= firstNew) throw std::invalid_argument("ISAM2: removeFactorIndices out of range");
+    if (index >= S.nonlinearFactors.size() || newIndexSet.count(index)) throw std::invalid_argument("ISAM2: removeFactorIndices out of range");
     if (S.removedFactor[index]) continue;  // an empty slot: nothing to take out of the variable index
-    const Factor& f = S.nonlinearFactors[index];
-    for (int k = 0; k < kFactorArity[f.type]; k++) {
-      keysWithRemovedFactors.insert(f.keys[k]);
-      auto& entries = S.variableIndex.at(f.keys[k]);  // VariableIndex::remove (VariableIndex-inl.h:52-80): the key keeps its (emptier) list
+    for (Key key : isam2_factor_keys(S, index)) {
+      keysWithRemovedFactors.insert(key);
+      auto& entries = S.variableIndex.at(key);  // VariableIndex::remove (VariableIndex-inl.h:52-80): the key keeps its (emptier) list
       entries.erase(std::find(entries.begin(), entries.end(), index));
     }
     S.removedFactor[index] = 1;
+    S.isContainer[index] = 0;
     S.linearFactors[index] = GFactor();
   }
   // computeUnusedKeys :175-190: keys whose last factor went and which no new factor mentions
@@ -514,6 +548,7 @@ static ISAM2Result isam2_update(ISAM2& S, const ISAM2UpdateParams& up) {
       for (auto& kd : S.delta)
         if (isam2_above_threshold(S, kd.first, kd.second, S.relinearizeThreshold)) relinKeys.insert(kd.first);
     }
+    for (Key k : S.fixedVariables) relinKeys.erase(k);  // "keys whose linearization points are fixed" (ISAM2-impl.h:385-388)
     for (Key k : up.noRelinKeys) relinKeys.erase(k);
     markedKeys.insert(relinKeys.begin(), relinKeys.end());
     if (!relinKeys.empty()) {
@@ -524,9 +559,11 @@ static ISAM2Result isam2_update(ISAM2& S, const ISAM2UpdateParams& up) {
     result.variablesRelinearized = (int)markedKeys.size();
   }
   // 7. linearizeNewFactors (:454-468) + augmentVariableIndex
-  for (size_t i = firstNew; i < S.nonlinearFactors.size(); i++) {
-    S.linearFactors.push_back(linearize_factor(S.nonlinearFactors[i], S.theta));
-    for (int k = 0; k < kFactorArity[S.nonlinearFactors[i].type]; k++) S.variableIndex[S.nonlinearFactors[i].keys[k]].push_back(i);
+  for (size_t i : newFactorsIndices) {
+    S.linearFactors[i] = linearize_factor(S.nonlinearFactors[i], S.theta);
+    for (int k = 0; k < kFactorArity[S.nonlinearFactors[i].type]; k++) {  // VariableIndex::augment appends (VariableIndex-inl.h:27-49)
+      S.variableIndex[S.nonlinearFactors[i].keys[k]].push_back(i);
+    }
   }
   // 8. recalculate (ISAM2.cpp:117-175)
   if (!markedKeys.empty() || !observedKeys.empty()) {
@@ -559,7 +596,7 @@ static ISAM2Result isam2_update(ISAM2& S, const ISAM2UpdateParams& up) {
       std::vector<IFactor> graph(S.linearFactors.size());  // an empty slot stays an entry without keys (the indices are the row ids)
       for (size_t i = 0; i < S.nonlinearFactors.size(); i++) {
         if (S.removedFactor[i]) continue;
-        S.linearFactors[i] = linearize_factor(S.nonlinearFactors[i], S.theta);
+        if (!S.isContainer[i]) S.linearFactors[i] = linearize_factor(S.nonlinearFactors[i], S.theta);  // (a container linearizes to itself)
         graph[i].g = &S.linearFactors[i];
         graph[i].keys = S.linearFactors[i].keys;
       }
@@ -581,15 +618,15 @@ static ISAM2Result isam2_update(ISAM2& S, const ISAM2UpdateParams& up) {
       for (size_t idx : candidates) {
         bool inside = true, useCachedLinear = true;
         const Factor& nf = S.nonlinearFactors[idx];
-        for (int k = 0; k < kFactorArity[nf.type]; k++) {
-          if (!inSet.count(nf.keys[k])) {
+        for (Key key : isam2_factor_keys(S, idx)) {
+          if (!inSet.count(key)) {
             inside = false;
             break;
           }
-          if (relinKeys.count(nf.keys[k])) useCachedLinear = false;
+          if (relinKeys.count(key)) useCachedLinear = false;
         }
         if (!inside) continue;
-        if (!useCachedLinear) S.linearFactors[idx] = linearize_factor(nf, S.theta);
+        if (!useCachedLinear && !S.isContainer[idx]) S.linearFactors[idx] = linearize_factor(nf, S.theta);
         IFactor f;
         f.g = &S.linearFactors[idx];
         f.keys = S.linearFactors[idx].keys;
@@ -639,6 +676,7 @@ static ISAM2Result isam2_update(ISAM2& S, const ISAM2UpdateParams& up) {
     S.deltaReplacedMask.erase(key);
     S.nodes.erase(key);
     S.theta.erase(key);
+    S.fixedVariables.erase(key);
   }
   S.lastUnusedKeys.assign(unusedKeys.begin(), unusedKeys.end());
   if (S.evaluateNonlinearError) S.errorAfter = isam2_graph_error(S, isam2_calculate_estimate(S, false));  // ISAM2.cpp:481-483
@@ -652,7 +690,7 @@ static ISAM2Result isam2_update(ISAM2& S, const ISAM2UpdateParams& up) {
 static double isam2_graph_error(const ISAM2& S, const Values& values) {
   double total = 0;
   for (size_t i = 0; i < S.nonlinearFactors.size(); i++)
-    if (!S.removedFactor[i]) total += factor_error(S.nonlinearFactors[i], values);
+    if (!S.removedFactor[i] && !S.isContainer[i]) total += factor_error(S.nonlinearFactors[i], values);  // (a container without a linearization point: 0)
   return total;
 }
 
@@ -663,6 +701,182 @@ static Values isam2_calculate_estimate(ISAM2& S, bool best) {
   Values out;
   for (auto& kv : S.theta) out[kv.first] = retract(kv.second, S.delta.at(kv.first).data());
   return out;
+}
+
+// BayesTree::removeSubtree gtsam/inference/BayesTree-inst.h:512-547: the clique leaves its parent (or the roots); it and everything below it
+// leave the nodes index; returned breadth-first like the reference's list
+static std::vector<ICliquePtr> isam2_remove_subtree(ISAM2& S, const ICliquePtr& subtree) {
+  std::vector<ICliquePtr> cliques{subtree};
+  ICliquePtr parent = subtree->parent.lock();
+  if (parent) parent->children.erase(std::find(parent->children.begin(), parent->children.end(), subtree));
+  else S.roots.erase(std::find(S.roots.begin(), S.roots.end(), subtree));
+  for (size_t i = 0; i < cliques.size(); i++) {
+    ICliquePtr c = cliques[i];
+    for (auto& child : c->children) cliques.push_back(child);
+    for (int k = 0; k < c->nFrontal; k++) S.nodes.erase(c->keys[k]);
+    c->parent.reset();
+    c->children.clear();
+  }
+  return cliques;
+}
+
+// ISAM2::marginalizeLeaves gtsam/nonlinear/ISAM2.cpp:487-720.  marginalFactorsIndices / deletedFactorsIndices may be null.
+static void isam2_marginalize_leaves(ISAM2& S, const std::vector<Key>& leafKeysList, std::vector<size_t>* marginalFactorsIndices,
+                                     std::vector<size_t>* deletedFactorsIndices) {
+  const std::set<Key> leafKeys(leafKeysList.begin(), leafKeysList.end());
+  std::map<Key, std::vector<GFactor>> marginalFactors;  // front key of a clique -> marginals passed up to it
+  std::set<Key> leafKeysRemoved;
+  std::set<size_t> factorIndicesToRemove;
+  std::map<Key, int> keyDim;
+  for (auto& kv : S.theta) keyDim[kv.first] = kVarDim[kv.second.type];
+  auto trackingRemoveSubtree = [&](const ICliquePtr& subtreeRoot) {
+    const std::vector<ICliquePtr> removed = isam2_remove_subtree(S, subtreeRoot);
+    for (const ICliquePtr& rc : removed) {
+      marginalFactors.erase(rc->keys[0]);
+      for (int k = 0; k < rc->nFrontal; k++) {
+        const Key frontal = rc->keys[k];
+        leafKeysRemoved.insert(frontal);
+        const auto& involved = S.variableIndex.at(frontal);
+        factorIndicesToRemove.insert(involved.begin(), involved.end());
+        if (!leafKeys.count(frontal))
+          throw std::runtime_error("Requesting to marginalize variables that are not leaves, the ISAM2 object is now in an inconsistent state so should no longer be used.");
+      }
+    }
+    return removed;
+  };
+  for (Key j : leafKeys) {
+    if (leafKeysRemoved.count(j)) continue;
+    ICliquePtr clique = S.nodes.at(j);
+    while (ICliquePtr parent = clique->parent.lock()) {  // up to the root of the marginalized subtree
+      if (leafKeys.count(parent->keys[0])) clique = parent;
+      else break;
+    }
+    bool marginalizeEntireClique = true;
+    for (int k = 0; k < clique->nFrontal; k++)
+      if (!leafKeys.count(clique->keys[k])) {
+        marginalizeEntireClique = false;
+        break;
+      }
+    if (marginalizeEntireClique) {
+      // the whole clique and its subtree go; its cached factor is the marginal on its separator and belongs to its parent from now on
+      if (ICliquePtr parent = clique->parent.lock()) marginalFactors[parent->keys[0]].push_back(clique->cached);
+      trackingRemoveSubtree(clique);
+    } else {
+      // re-eliminate the marginalized frontals of this clique with the marginals of its removed children and the factors they pull in
+      std::vector<GFactor> graph;
+      std::vector<ICliquePtr> subtreesToRemove;
+      for (const ICliquePtr& child : clique->children)
+        for (size_t k = child->nFrontal; k < child->keys.size(); k++)
+          if (leafKeys.count(child->keys[k])) {
+            subtreesToRemove.push_back(child);
+            graph.push_back(child->cached);
+            break;
+          }
+      std::vector<ICliquePtr> childrenRemoved;
+      for (const ICliquePtr& st : subtreesToRemove) {
+        const std::vector<ICliquePtr> removed = trackingRemoveSubtree(st);
+        childrenRemoved.insert(childrenRemoved.end(), removed.begin(), removed.end());
+      }
+      std::set<size_t> factorsFromMarginalizedInClique;
+      for (int k = 0; k < clique->nFrontal; k++)
+        if (leafKeys.count(clique->keys[k])) {
+          const auto& involved = S.variableIndex.at(clique->keys[k]);
+          factorsFromMarginalizedInClique.insert(involved.begin(), involved.end());
+        }
+      for (const ICliquePtr& rc : childrenRemoved)
+        for (int k = 0; k < rc->nFrontal; k++)
+          for (size_t f : S.variableIndex.at(rc->keys[k])) factorsFromMarginalizedInClique.erase(f);
+      for (size_t index : factorsFromMarginalizedInClique)  // nonlinearFactors_[index]->linearize(theta_): a container gives itself
+        graph.push_back(S.isContainer[index] ? S.linearFactors[index] : linearize_factor(S.nonlinearFactors[index], S.theta));
+      std::vector<Key> cliqueFrontalsToEliminate;
+      {
+        std::set<Key> cf(clique->keys.begin(), clique->keys.begin() + clique->nFrontal);
+        for (Key k : cf)
+          if (leafKeys.count(k)) cliqueFrontalsToEliminate.push_back(k);  // set_intersection: ascending by key
+      }
+      std::vector<const GFactor*> gathered;
+      for (auto& g : graph) gathered.push_back(&g);
+      Clique tmp;
+      GFactor marginal;
+      eliminate_clique(gathered, cliqueFrontalsToEliminate, keyDim, tmp, marginal);
+      marginalFactors[clique->keys[0]].push_back(marginal);  // (keyed by the front key the clique has BEFORE the split)
+      // split the clique: its leading leaf keys go, the conditional on the rest stays as it is
+      size_t nToRemove = 0;
+      while (nToRemove < clique->keys.size() && leafKeys.count(clique->keys[nToRemove])) ++nToRemove;
+      int dimToRemove = 0;
+      for (size_t k = 0; k < nToRemove; k++) dimToRemove += clique->dims[k];
+      {
+        const int nfOld = clique->RSd.r, nOld = clique->RSd.c;
+        Mat R2(nfOld - dimToRemove, nOld - dimToRemove);
+        for (int i = dimToRemove; i < nfOld; i++)
+          for (int jj = dimToRemove; jj < nOld; jj++) R2(i - dimToRemove, jj - dimToRemove) = clique->RSd(i, jj);
+        clique->RSd = R2;
+      }
+      for (Key k : cliqueFrontalsToEliminate) S.nodes.erase(k);  // (removeVariables below does it in the reference)
+      clique->keys.erase(clique->keys.begin(), clique->keys.begin() + nToRemove);
+      clique->dims.erase(clique->dims.begin(), clique->dims.begin() + nToRemove);
+      clique->nFrontal -= (int)nToRemove;
+      for (Key frontal : cliqueFrontalsToEliminate) {
+        const auto& involved = S.variableIndex.at(frontal);
+        factorIndicesToRemove.insert(involved.begin(), involved.end());
+      }
+      leafKeysRemoved.insert(cliqueFrontalsToEliminate.begin(), cliqueFrontalsToEliminate.end());
+    }
+  }
+  // the factors the marginals summarise leave the graph (and the variable index)
+  for (size_t index : factorIndicesToRemove) {
+    for (Key key : isam2_factor_keys(S, index)) {
+      auto& entries = S.variableIndex.at(key);
+      entries.erase(std::find(entries.begin(), entries.end(), index));
+    }
+    S.removedFactor[index] = 1;
+    S.isContainer[index] = 0;
+    S.linearFactors[index] = GFactor();
+  }
+  // the marginal factors enter it as LinearContainerFactors (no linearization point); their keys are fixed from now on
+  std::vector<GFactor> factorsToAdd;
+  for (auto& kf : marginalFactors)
+    for (auto& f : kf.second) {  // (a marginal on no keys still takes a slot, as the reference's non-null check lets it)
+      factorsToAdd.push_back(f);
+      for (Key k : f.keys) S.fixedVariables.insert(k);
+    }
+  std::vector<size_t> newFactorIndices;
+  {
+    size_t i = 0;
+    for (auto& f : factorsToAdd) {
+      if (S.findUnusedFactorSlots) {
+        while (i < S.nonlinearFactors.size() && !S.removedFactor[i]) ++i;
+      } else {
+        i = S.nonlinearFactors.size();
+      }
+      if (i >= S.nonlinearFactors.size()) {
+        S.nonlinearFactors.push_back(Factor());
+        S.removedFactor.push_back(0);
+        S.isContainer.push_back(1);
+        S.linearFactors.push_back(f);
+        i = S.nonlinearFactors.size() - 1;
+      } else {
+        S.removedFactor[i] = 0;
+        S.isContainer[i] = 1;
+        S.linearFactors[i] = f;
+      }
+      newFactorIndices.push_back(i);
+      for (Key k : f.keys) S.variableIndex[k].push_back(i);
+    }
+  }
+  // removeVariables(leafKeys) ISAM2.cpp:385-398
+  for (Key key : leafKeys) {
+    S.variableIndex.erase(key);
+    S.delta.erase(key);
+    S.deltaNewton.erase(key);
+    S.RgProd.erase(key);
+    S.deltaReplacedMask.erase(key);
+    S.nodes.erase(key);
+    S.theta.erase(key);
+    S.fixedVariables.erase(key);
+  }
+  if (deletedFactorsIndices) deletedFactorsIndices->assign(factorIndicesToRemove.begin(), factorIndicesToRemove.end());
+  if (marginalFactorsIndices) *marginalFactorsIndices = newFactorIndices;
 }
 
 static void isam2_collect(const ICliquePtr& c, std::vector<ICliquePtr>* out) {

@@ -2059,6 +2059,88 @@ int orc_isam2_factor_exists(void* h, int i) {
   return i >= 0 && i < (int)S.nonlinearFactors.size() && !S.removedFactor[i];
 }
 
+// ISAM2Params::findUnusedFactorSlots (ISAM2Params.h:225)
+void orc_isam2_set_find_unused_slots(void* h, int enable) { ((ISAM2Handle*)h)->S.findUnusedFactorSlots = enable != 0; }
+
+// ISAM2::marginalizeLeaves(leafKeys, &marginalFactorsIndices, &deletedFactorsIndices) (ISAM2.h:198-222).  The index outputs may be null
+// (their counts are returned in counts2: marginal, deleted).  1 = a key is not a leaf (the reference's debug-build exception; the object
+// is unusable afterwards, as there), 2 = another error
+int orc_isam2_marginalize_leaves(void* h, int n, const uint64_t* keys, uint64_t* marginal_idx, uint64_t* deleted_idx, int* counts2) {
+  auto& S = ((ISAM2Handle*)h)->S;
+  try {
+    std::vector<size_t> mi, di;
+    isam2_marginalize_leaves(S, std::vector<Key>(keys, keys + n), &mi, &di);
+    if (marginal_idx) std::copy(mi.begin(), mi.end(), marginal_idx);
+    if (deleted_idx) std::copy(di.begin(), di.end(), deleted_idx);
+    if (counts2) {
+      counts2[0] = (int)mi.size();
+      counts2[1] = (int)di.size();
+    }
+  } catch (const std::runtime_error& e) {
+    std::fprintf(stderr, "orc_isam2_marginalize_leaves: %s\n", e.what());
+    return 1;
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "orc_isam2_marginalize_leaves: %s\n", e.what());
+    return 2;
+  }
+  return 0;
+}
+// slot i as a marginal (LinearContainerFactor) factor: returns its number of keys, -1 when the slot holds none; keys / dims / the
+// augmented information matrix ((sum dims + 1)^2, column-major, both triangles filled) may be null
+int orc_isam2_marginal_factor(void* h, int i, uint64_t* keys, int* dims, double* info_colmajor) {
+  auto& S = ((ISAM2Handle*)h)->S;
+  if (i < 0 || i >= (int)S.nonlinearFactors.size() || S.removedFactor[i] || !S.isContainer[i]) return -1;
+  const GFactor& g = S.linearFactors[i];
+  if (keys) std::copy(g.keys.begin(), g.keys.end(), keys);
+  if (dims) std::copy(g.dims.begin(), g.dims.end(), dims);
+  if (info_colmajor) {
+    const int N = g.info.r;
+    for (int c = 0; c < N; c++)
+      for (int r = 0; r < N; r++) info_colmajor[(size_t)c * N + r] = r <= c ? g.info(r, c) : g.info(c, r);
+  }
+  return (int)g.keys.size();
+}
+// ISAM2::getFixedVariables() (ISAM2.h:259), ascending; returns their number
+int orc_isam2_fixed_variables(void* h, uint64_t* keys_out) {
+  auto& S = ((ISAM2Handle*)h)->S;
+  if (keys_out) std::copy(S.fixedVariables.begin(), S.fixedVariables.end(), keys_out);
+  return (int)S.fixedVariables.size();
+}
+
+// getFactorsUnsafe().linearize(getLinearizationPoint())->augmentedHessian() with the variables ascending by key: (D+1)^2 doubles,
+// symmetric (the reference's own marginalizeLeaves checks compare this, tests/testGaussianISAM2.cpp:617-660); returns D
+int orc_isam2_graph_hessian(void* h, double* out) {
+  auto& S = ((ISAM2Handle*)h)->S;
+  std::map<Key, int> off;
+  int D = 0;
+  for (auto& kv : S.theta) {
+    off[kv.first] = D;
+    D += kVarDim[kv.second.type];
+  }
+  if (!out) return D;
+  const int N = D + 1;
+  std::fill(out, out + (size_t)N * N, 0.0);
+  for (size_t i = 0; i < S.nonlinearFactors.size(); i++) {
+    if (S.removedFactor[i]) continue;
+    const GFactor g = S.isContainer[i] ? S.linearFactors[i] : linearize_factor(S.nonlinearFactors[i], S.theta);
+    std::vector<int> col;
+    for (size_t k = 0; k < g.keys.size(); k++)
+      for (int d = 0; d < g.dims[k]; d++) col.push_back(off.at(g.keys[k]) + d);
+    col.push_back(D);
+    const int n = (int)col.size();
+    for (int a = 0; a < n; a++)
+      for (int b = a; b < n; b++) {
+        double v = 0;
+        if (g.hessian) v = g.info(a, b);
+        else
+          for (int r = 0; r < g.Ab.r; r++) v += g.Ab(r, a) * g.Ab(r, b);
+        out[(size_t)col[b] * N + col[a]] += v;
+        if (col[a] != col[b]) out[(size_t)col[a] * N + col[b]] += v;
+      }
+  }
+  return D;
+}
+
 int orc_isam2_num_variables(void* h) { return (int)((ISAM2Handle*)h)->S.theta.size(); }
 int orc_isam2_num_factors(void* h) { return (int)((ISAM2Handle*)h)->S.nonlinearFactors.size(); }
 

@@ -459,6 +459,11 @@ class OracleISAM2:
         L.orc_isam2_snapshot.argtypes = [ct.c_void_p]
         L.orc_isam2_clique_info.argtypes = [ct.c_void_p, ct.c_int, _I]
         L.orc_isam2_clique_get.argtypes = [ct.c_void_p, ct.c_int, _U, _D]
+        L.orc_isam2_set_find_unused_slots.argtypes = [ct.c_void_p, ct.c_int]
+        L.orc_isam2_marginalize_leaves.argtypes = [ct.c_void_p, ct.c_int, _U, _U, _U, _I]
+        L.orc_isam2_marginal_factor.argtypes = [ct.c_void_p, ct.c_int, _U, _I, _D]
+        L.orc_isam2_fixed_variables.argtypes = [ct.c_void_p, _U]
+        L.orc_isam2_graph_hessian.argtypes = [ct.c_void_p, _D]
         self.h = ct.c_void_p(L.orc_isam2_create(relinearizeThreshold, relinearizeSkip, int(enableRelinearization), wildfireThreshold,
                                                 CCOLAMD_CALLBACK))
 
@@ -555,6 +560,59 @@ class OracleISAM2:
             H[np.ix_(cols, cols)] += RS.T @ RS
         d = VAR_DIM[lin.type(int(key))]
         return np.linalg.inv(H)[off[int(key)]:off[int(key)] + d, off[int(key)]:off[int(key)] + d]
+
+    def set_find_unused_factor_slots(self, enable):
+        """ISAM2Params::findUnusedFactorSlots"""
+        self.L.orc_isam2_set_find_unused_slots(self.h, int(bool(enable)))
+
+    def marginalizeLeaves(self, leafKeys):
+        """ISAM2::marginalizeLeaves(leafKeys, &marginalFactorsIndices, &deletedFactorsIndices) (gtsam/nonlinear/ISAM2.h:198-222);
+        returns (marginalFactorsIndices, deletedFactorsIndices).  RuntimeError when a key is not a leaf."""
+        keys = np.asarray([int(k) for k in leafKeys], dtype=np.uint64)
+        cap = self.num_factors() + 4 * len(keys) + 16
+        mi, di, cnt = np.zeros(cap, dtype=np.uint64), np.zeros(cap, dtype=np.uint64), np.zeros(2, dtype=np.int32)
+        rc = self.L.orc_isam2_marginalize_leaves(self.h, len(keys), up(keys), up(mi), up(di), ip(cnt))
+        if rc:
+            raise RuntimeError("marginalizeLeaves: rc %d" % rc)
+        return [int(i) for i in mi[:cnt[0]]], [int(i) for i in di[:cnt[1]]]
+
+    def marginal_factor(self, i):
+        """slot i as the LinearContainerFactor marginalizeLeaves left there: (keys, dims, augmented information matrix) or None"""
+        n = self.L.orc_isam2_marginal_factor(self.h, int(i), None, None, None)
+        if n < 0:
+            return None
+        keys, dims = np.zeros(max(n, 1), dtype=np.uint64), np.zeros(max(n, 1), dtype=np.int32)
+        self.L.orc_isam2_marginal_factor(self.h, int(i), up(keys), ip(dims), None)
+        N = int(dims[:n].sum()) + 1
+        info = np.zeros(N * N)
+        self.L.orc_isam2_marginal_factor(self.h, int(i), None, None, dp(info))
+        return [int(k) for k in keys[:n]], [int(d) for d in dims[:n]], info.reshape(N, N).T.copy()
+
+    def getFixedVariables(self):
+        n = self.L.orc_isam2_fixed_variables(self.h, None)
+        keys = np.zeros(max(n, 1), dtype=np.uint64)
+        self.L.orc_isam2_fixed_variables(self.h, up(keys))
+        return [int(k) for k in keys[:n]]
+
+    def graph_augmented_hessian(self):
+        """getFactorsUnsafe().linearize(getLinearizationPoint())->augmentedHessian(), variables ascending by key"""
+        D = self.L.orc_isam2_graph_hessian(self.h, None)
+        out = np.zeros((D + 1) * (D + 1))
+        self.L.orc_isam2_graph_hessian(self.h, dp(out))
+        return out.reshape(D + 1, D + 1)
+
+    def tree_augmented_hessian(self):
+        """GaussianFactorGraph(isam).augmentedHessian(): sum over cliques of [R S d]^T [R S d], variables ascending by key"""
+        lin = self._values(2)
+        off, o = {}, 0
+        for k in lin.keys():
+            off[k] = o
+            o += VAR_DIM[lin.type(k)]
+        H = np.zeros((o + 1, o + 1))
+        for keys, _, rsd, _ in self.cliques():
+            cols = np.concatenate([np.arange(off[k], off[k] + VAR_DIM[lin.type(k)]) for k in keys] + [np.array([o])]).astype(int)
+            H[np.ix_(cols, cols)] += rsd.T @ rsd
+        return H
 
     def unusedKeys(self):
         """ISAM2Result::unusedKeys of the last update"""
