@@ -123,6 +123,11 @@ SYMBOLS = {
     "lmgpu_isam2_error": (ct.c_int, [_H, ct.c_int32, _D]),
     "lmgpu_isam2_get_unused_keys": (ct.c_int, [_H, ct.POINTER(ct.c_uint64)]),
     "lmgpu_isam2_factor_exists": (ct.c_int, [_H, ct.c_int32]),
+    "lmgpu_isam2_set_find_unused_factor_slots": (ct.c_int, [_H, ct.c_int32]),
+    "lmgpu_isam2_marginalize_leaves": (ct.c_int, [_H, ct.c_int32, ct.POINTER(ct.c_uint64), _I, _I]),
+    "lmgpu_isam2_get_marginalize_result": (ct.c_int, [_H, ct.POINTER(ct.c_uint64), ct.POINTER(ct.c_uint64)]),
+    "lmgpu_isam2_get_fixed_variables": (ct.c_int, [_H, ct.POINTER(ct.c_uint64)]),
+    "lmgpu_isam2_get_marginal_factor": (ct.c_int, [_H, ct.c_int32, ct.POINTER(ct.c_uint64), _I, _D]),
     "lmgpu_isam2_num_variables": (ct.c_int, [_H]),
     "lmgpu_isam2_num_factors": (ct.c_int, [_H]),
     "lmgpu_isam2_get_values": (ct.c_int, [_H, ct.c_int32, ct.POINTER(ct.c_uint64), _I, _D]),

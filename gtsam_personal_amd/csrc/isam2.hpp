@@ -22,7 +22,8 @@
 // variable that lost its last factor leaves the system: pushBackFactors / computeUnusedKeys / removeVariables), constrainedKeys,
 // noRelinKeys, extraReelimKeys, force_relinearize, forceFullSolve.
 // ISAM2Params: Gauss-Newton or Dogleg optimisation params, relinearization thresholds (double or per Symbol character), partial check,
-// evaluateNonlinearError.  Limits (fail loudly): Cholesky, no marginalizeLeaves, no newAffectedKeys (smart factors).
+// evaluateNonlinearError, findUnusedFactorSlots.  ISAM2::marginalizeLeaves: is_marginalize_leaves below.
+// Limits (fail loudly): Cholesky, no newAffectedKeys (smart factors).
 #pragma once
 
 #include <chrono>
@@ -57,9 +58,26 @@ struct lmgpu_isam2 {
 
   struct Fac {
     int32_t type, bucket, lidx, v[3];
-    bool removed;  // an empty slot of nonlinearFactors_ (NonlinearFactorGraph::remove): the index is not reused
+    bool removed;       // an empty slot of nonlinearFactors_ (NonlinearFactorGraph::remove): reused only with findUnusedFactorSlots
+    int32_t marg = -1;  // >= 0: the slot holds a LinearContainerFactor left by marginalizeLeaves (type = -1): margs[marg]
   };
   std::vector<Fac> facs;
+  // A marginal factor (ISAM2.cpp:684-697: LinearContainerFactor around a HessianFactor, no linearization point): its augmented information
+  // matrix is the update matrix a clique or a one-front elimination left in the pool (upper, row-major, m = scalars + 1, stride ld); it
+  // enters later eliminations through a column map exactly like a cached boundary factor, is never relinearized and has error 0
+  // (LinearContainerFactor.cpp:77-79, 104-108).
+  struct Marg {
+    std::vector<int32_t> vids;  // in the order of the matrix's blocks
+    int64_t u_off = -1;
+    int32_t ld = 0, m = 0;
+    int64_t blk_off = -1;  // the pool block that holds it (given back when the factor goes)
+    size_t blk_n = 0;
+  };
+  std::vector<Marg> margs;
+  std::vector<int32_t> free_margs;
+  std::set<uint64_t> fixed;        // fixedVariables_ (ISAM2.h:103): keys of marginal factors, never relinearized (ISAM2-impl.h:385-388)
+  bool find_unused_slots = false;  // ISAM2Params::findUnusedFactorSlots
+  std::vector<uint64_t> last_marginal_idx, last_deleted_idx;  // marginalizeLeaves' two optional outputs, of the last call
   struct Bkt {
     int type = 0, noise_kind = 0, rows = 0, cols = 0, ml = 0, nl = 0, ar = 0;
     int robust = 0;  // noiseModel::Robust around the Gaussian model of every factor of the bucket (lmgpu_robust_kind), tuning constant
@@ -373,6 +391,28 @@ void is_pool_free(lmgpu_isam2* S, int64_t off, size_t n) {
   if (off >= 0) S->freelist[std::max<size_t>(n, 1)].push_back(off);
 }
 
+// the variables of the factor in slot i (a typed factor's first `arity` variables; a marginal factor's own list)
+std::vector<int32_t> is_fac_vids(const lmgpu_isam2* S, const lmgpu_isam2::Fac& f) {
+  if (f.marg >= 0) return S->margs[f.marg].vids;
+  return std::vector<int32_t>(f.v, f.v + kFactorArity[f.type]);
+}
+void is_free_marg(lmgpu_isam2* S, int32_t mi) {
+  lmgpu_isam2::Marg& m = S->margs[mi];
+  is_pool_free(S, m.blk_off, m.blk_n);
+  m = lmgpu_isam2::Marg();
+  S->free_margs.push_back(mi);
+}
+int32_t is_new_marg(lmgpu_isam2* S, const lmgpu_isam2::Marg& m) {
+  if (!S->free_margs.empty()) {
+    const int32_t mi = S->free_margs.back();
+    S->free_margs.pop_back();
+    S->margs[mi] = m;
+    return mi;
+  }
+  S->margs.push_back(m);
+  return (int32_t)S->margs.size() - 1;
+}
+
 int is_new_clique(lmgpu_isam2* S) {
   int id;
   if (!S->free_clq.empty()) {
@@ -387,13 +427,22 @@ int is_new_clique(lmgpu_isam2* S) {
   S->n_alive++;
   return id;
 }
-void is_release_clique(lmgpu_isam2* S, int id) {
+// keep_u: the clique's update matrix (its cached factor) lives on as a marginal factor -- `*keep` takes over the block that holds it
+void is_release_clique(lmgpu_isam2* S, int id, lmgpu_isam2::Marg* keep = nullptr) {
   lmgpu_isam2::Clq& c = S->clq[id];
+  if (keep) {
+    keep->vids.assign(c.vars.begin() + c.nfv, c.vars.end());
+    keep->u_off = c.u_off;
+    keep->m = c.n - c.nf;
+    keep->ld = c.ld > 0 ? c.ld : c.n - c.nf;
+    keep->blk_off = c.ld > 0 ? c.f_off : c.u_off;
+    keep->blk_n = c.ld > 0 ? (size_t)c.n * c.ld : (size_t)(c.n - c.nf) * (c.n - c.nf);
+  }
   if (c.ld > 0) {
-    is_pool_free(S, c.f_off, (size_t)c.n * c.ld);
+    if (!keep) is_pool_free(S, c.f_off, (size_t)c.n * c.ld);
   } else {
     is_pool_free(S, c.rsd_off, (size_t)c.nf * c.n);
-    is_pool_free(S, c.u_off, (size_t)(c.n - c.nf) * (c.n - c.nf));
+    if (!keep) is_pool_free(S, c.u_off, (size_t)(c.n - c.nf) * (c.n - c.nf));
   }
   if (c.xrow_off >= 0) is_pool_free(S, c.xrow_off, (size_t)c.n / 2 + 1);
   c.xrow_off = -1;
@@ -1057,13 +1106,18 @@ int is_colamd(lmgpu_isam2* S, const std::vector<int32_t>& vids, const std::vecto
 
 // one entry of the linear graph handed to the partial elimination
 struct IsGF {
-  int kind;  // 0: linear factor of nonlinear factor `id`; 1: cached boundary factor of orphan clique `id`; 2: the orphan subtree itself
+  int kind;  // 0: linear factor of nonlinear factor `id`; 1: cached boundary factor of orphan clique `id`; 2: the orphan subtree itself;
+             // 3: the marginal factor in slot `id` of the factor list
   int32_t id;
   std::vector<int32_t> vids;
 };
 
+int is_eliminate_fronts(lmgpu_isam2* S, const std::vector<IsGF>& gfs, const std::vector<int32_t>& vid_of_slot, const SymbolicFronts& sf, bool attach,
+                        std::vector<int>* cid_out);
 // eliminate `gfs` over the variables `vids` (ascending by key) in the order `perm`: new cliques on the device, attached to the tree
-int is_eliminate(lmgpu_isam2* S, const std::vector<IsGF>& gfs, const std::vector<int32_t>& vids, const std::vector<int32_t>& perm) {
+// var_cols (optional, batch): per variable of `vids` its factor list as the variable index keeps it (the elimination tree follows that order)
+int is_eliminate(lmgpu_isam2* S, const std::vector<IsGF>& gfs, const std::vector<int32_t>& vids, const std::vector<int32_t>& perm,
+                 const std::vector<std::vector<int32_t>>* var_cols = nullptr) {
   const int n = (int)vids.size();
   if (n == 0) return LMGPU_OK;
   // slot = position in the elimination order; keyrank = rank by key (vids is ascending by key)
@@ -1078,11 +1132,24 @@ int is_eliminate(lmgpu_isam2* S, const std::vector<IsGF>& gfs, const std::vector
   for (size_t i = 0; i < gfs.size(); i++)
     for (int32_t v : gfs[i].vids) fvars[i].push_back(slot_of_vid.at(v));
   SymbolicFronts sf;
-  const std::string e = symbolic_multifrontal(n, keyrank, fvars, &sf);
+  std::vector<std::vector<int32_t>> slot_cols;
+  if (var_cols) {
+    slot_cols.resize(n);
+    for (int j = 0; j < n; j++) slot_cols[j] = (*var_cols)[perm[j]];
+  }
+  const std::string e = symbolic_multifrontal(n, keyrank, fvars, &sf, var_cols ? &slot_cols : nullptr);
   if (!e.empty()) {
     S->err = e;
     return LMGPU_INVALID;
   }
+  return is_eliminate_fronts(S, gfs, vid_of_slot, sf, true, nullptr);
+}
+
+// the numeric half: the fronts of `sf` (over slots; vid_of_slot names their variables) as new cliques on the device.
+// attach = false: the cliques stay outside the tree (marginalizeLeaves eliminates ONE front to get a marginal and throws the conditional
+// away, ISAM2.cpp:624-637); their ids come back in *cid_out and the caller releases them.
+int is_eliminate_fronts(lmgpu_isam2* S, const std::vector<IsGF>& gfs, const std::vector<int32_t>& vid_of_slot, const SymbolicFronts& sf, bool attach,
+                        std::vector<int>* cid_out) {
   const int NF = (int)sf.fronts.size();
   std::vector<int> cid(NF);
   std::vector<FrontDesc> fds(NF);
@@ -1097,7 +1164,7 @@ int is_eliminate(lmgpu_isam2* S, const std::vector<IsGF>& gfs, const std::vector
     const SymbolicFronts::F& fr = sf.fronts[fi];
     const int id = is_new_clique(S);
     cid[fi] = id;
-    S->touched.push_back(id);  // its descriptor reaches the device copy of the tree with the next patch
+    if (attach) S->touched.push_back(id);  // its descriptor reaches the device copy of the tree with the next patch
     lmgpu_isam2::Clq& c = S->clq[id];
     for (int32_t s : fr.frontals) c.vars.push_back(vid_of_slot[s]);
     c.nfv = (int)fr.frontals.size();
@@ -1120,7 +1187,8 @@ int is_eliminate(lmgpu_isam2* S, const std::vector<IsGF>& gfs, const std::vector
       if ((rc = is_pool_alloc(S, (size_t)c.nf * c.n, &c.rsd_off))) return rc;
       if ((rc = is_pool_alloc(S, (size_t)(c.n - c.nf) * (c.n - c.nf), &c.u_off))) return rc;
     }
-    for (int k = 0; k < c.nfv; k++) S->node_of[c.vars[k]] = id;
+    if (attach)
+      for (int k = 0; k < c.nfv; k++) S->node_of[c.vars[k]] = id;
     FrontDesc& F = fds[fi];
     F = FrontDesc{};
     F.n = c.n;
@@ -1166,6 +1234,17 @@ int is_eliminate(lmgpu_isam2* S, const std::vector<IsGF>& gfs, const std::vector
         ffac.push_back(ff);
       } else if (gf.kind == 1) {
         add_child(S->clq[gf.id]);
+      } else if (gf.kind == 3) {  // a marginal factor: its information matrix through a column map, like a cached boundary factor
+        const lmgpu_isam2::Marg& mg = S->margs[S->facs[gf.id].marg];
+        ChildRef cr{};
+        cr.u_off = mg.u_off;
+        cr.ld = mg.ld;
+        cr.m = mg.m;
+        cr.map_begin = (int)cmap.size();
+        for (int32_t v : mg.vids)
+          for (int d = 0; d < kVarDim[S->vars[v].type]; d++) cmap.push_back(colof.at(v) + d);
+        cmap.push_back(c.n - 1);
+        childs.push_back(cr);
       }
     }
     F.fac_count = (int)ffac.size() - F.fac_begin;
@@ -1185,7 +1264,9 @@ int is_eliminate(lmgpu_isam2* S, const std::vector<IsGF>& gfs, const std::vector
       for (int d = 0; d < kVarDim[S->vars[c.vars[k]].type]; d++) fxoff.push_back(S->vars[c.vars[k]].xoff + d);
     max_level = std::max(max_level, (int)fr.level);
   }
-  for (int32_t r : sf.roots) S->roots.push_back(cid[r]);
+  if (attach)
+    for (int32_t r : sf.roots) S->roots.push_back(cid[r]);
+  if (cid_out) *cid_out = cid;
   // ---- device: one lds_front_kernel launch per level of the new cliques
   FrontDesc* d_fds = nullptr;
   FrontFac* d_ffac = nullptr;
@@ -1570,6 +1651,19 @@ int is_update_delta_dogleg(lmgpu_isam2* S, bool force_full, bool host_delta) {
   return to_host();
 }
 
+// NonlinearFactorGraph::remove(i) + linearFactors_.remove(i): the slot empties (the caller has taken it out of the variable index)
+int is_empty_slot(lmgpu_isam2* S, int32_t idx) {
+  lmgpu_isam2::Fac& f = S->facs[idx];
+  f.removed = true;
+  if (f.marg >= 0) {
+    is_free_marg(S, f.marg);
+    f.marg = -1;
+    return LMGPU_OK;
+  }
+  const int32_t dump = 0;  // a typed factor's row stays in its bucket; its error lands in the dump slot from now on
+  return is_push(S, S->bkts[f.bucket].d_epos + f.lidx, &dump, sizeof(dump));
+}
+
 // ISAM2::update (gtsam/nonlinear/ISAM2.cpp:419-480)
 int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_result* result) {
   const bool force_relinearize = up.force_relinearize;
@@ -1710,8 +1804,10 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
   if (relinNeeded && (rc = is_update_delta(S, up.force_full_solve, true))) return rc;
   const int relin_ntot = S->ntot;  // scalars of delta the pinned copy holds
   lap(0);  // new variables + updateDelta (wildfire, one wait)
-  // ---- 1. pushBackFactors (ISAM2-impl.h:145-175): indices continue the list
-  const int firstNew = (int)S->facs.size();
+  // ---- 1. pushBackFactors (ISAM2-impl.h:145-175): FactorGraph::add_factors (FactorGraph-inst.h:109-137) -- the indices continue the list,
+  //         or (findUnusedFactorSlots) the new factors fill the empty slots from the front
+  std::vector<int32_t> new_idx;
+  size_t slot_scan = 0;
   std::set<uint64_t> markedKeys;
   std::map<int, std::vector<int32_t>> new_by_bucket;  // bucket -> new local indices
   struct NewRows {
@@ -1722,7 +1818,12 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
   std::map<int, NewRows> new_rows;  // bucket -> the descriptor rows of its new factors (consecutive local indices), uploaded after the loop
   for (const lmgpu_isam2::NewFac& nf : new_facs) {
     const int ar = kFactorArity[nf.type];
-    lmgpu_isam2::Fac f{nf.type, -1, -1, {-1, -1, -1}, false};
+    lmgpu_isam2::Fac f{nf.type, -1, -1, {-1, -1, -1}, false, -1};
+    size_t slot = S->facs.size();
+    if (S->find_unused_slots) {
+      while (slot_scan < S->facs.size() && !S->facs[slot_scan].removed) ++slot_scan;
+      slot = slot_scan;
+    }
     for (int k = 0; k < ar; k++) {
       auto it = S->vid_of.find(nf.k[k]);
       if (it == S->vid_of.end()) {
@@ -1775,13 +1876,17 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
     NewRows& nr = new_rows[bi];
     if (nr.first < 0) nr.first = b.n;
     for (int k = 0; k < ar; k++) nr.vidx.push_back(S->vars[f.v[k]].tidx);
-    nr.epos.push_back(1 + (int32_t)S->facs.size());
+    nr.epos.push_back(1 + (int32_t)slot);
     nr.meas.insert(nr.meas.end(), nf.meas.begin(), nf.meas.begin() + b.ml);
     if (b.nl) nr.noise.insert(nr.noise.end(), nf.noise.begin(), nf.noise.begin() + b.nl);
     f.bucket = bi;
     f.lidx = b.n++;
     new_by_bucket[bi].push_back(f.lidx);
-    S->facs.push_back(f);
+    if (slot == S->facs.size())
+      S->facs.push_back(f);
+    else
+      S->facs[slot] = f;
+    new_idx.push_back((int32_t)slot);
   }
   for (auto& kv : new_rows) {  // (a bucket that grew in the loop moved its old rows only; the new ones arrive here)
     lmgpu_isam2::Bkt& b = S->bkts[kv.first];
@@ -1796,14 +1901,12 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
   for (uint64_t idx : up.remove) {
     lmgpu_isam2::Fac& f = S->facs[idx];
     if (f.removed) continue;
-    for (int k = 0; k < kFactorArity[f.type]; k++) {
-      keysWithRemoved.insert(S->vars[f.v[k]].key);
-      std::vector<int32_t>& entries = S->vindex[f.v[k]];
+    for (int32_t v : is_fac_vids(S, f)) {
+      keysWithRemoved.insert(S->vars[v].key);
+      std::vector<int32_t>& entries = S->vindex[v];
       entries.erase(std::find(entries.begin(), entries.end(), (int32_t)idx));
     }
-    f.removed = true;
-    const int32_t dump = 0;  // its row stays in the bucket; its error lands in the dump slot from now on
-    if ((rc = is_push(S, S->bkts[f.bucket].d_epos + f.lidx, &dump, sizeof(dump)))) return rc;
+    if ((rc = is_empty_slot(S, (int32_t)idx))) return rc;
   }
   // computeUnusedKeys (:175-190): keys whose last factor went and which no new factor mentions
   for (uint64_t k : keysWithRemoved)
@@ -1873,8 +1976,8 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
       S->err = "ISAM2: relinearization threshold vector missing for a Symbol character or of the wrong dimension (ISAM2-impl.h:258-262)";
       return LMGPU_INVALID;
     }
-    for (int32_t v : cand)
-      if (!noRelin.count(S->vars[v].key)) {
+    for (int32_t v : cand)  // minus the keys whose linearization point is fixed (marginal factors) and the caller's noRelinKeys (ISAM2-impl.h:385-392)
+      if (!noRelin.count(S->vars[v].key) && !S->fixed.count(S->vars[v].key)) {
         relin.insert(v);
         markedKeys.insert(S->vars[v].key);
       }
@@ -1902,7 +2005,7 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
   // ---- 7. linearizeNewFactors (:454-468) + augmentVariableIndex
   for (auto& kv : new_by_bucket)
     if ((rc = is_with_list(S, kv.second, [&](const int32_t* d, int cnt) { is_linearize_sel(S, S->bkts[kv.first], d, cnt); }))) return rc;
-  for (int i = firstNew; i < (int)S->facs.size(); i++)
+  for (int32_t i : new_idx)
     for (int k = 0; k < kFactorArity[S->facs[i].type]; k++) S->vindex[S->facs[i].v[k]].push_back(i);
   lap(1);  // new factors, relinearization check, retract, linearize
   // ---- 8. recalculate (ISAM2.cpp:117-175)
@@ -1958,10 +2061,11 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
         gfs[i].kind = 0;
         gfs[i].id = (int32_t)i;
         if (S->facs[i].removed) continue;  // an empty slot: an entry without variables, so that positions stay factor indices
-        for (int k = 0; k < kFactorArity[S->facs[i].type]; k++) gfs[i].vids.push_back(S->facs[i].v[k]);
+        if (S->facs[i].marg >= 0) gfs[i].kind = 3;
+        gfs[i].vids = is_fac_vids(S, S->facs[i]);
       }
       lap(1);  // (batch: relinearization of everything counts with the linearize phase)
-      if ((rc = is_eliminate(S, gfs, vids, perm))) return rc;
+      if ((rc = is_eliminate(S, gfs, vids, perm, &cols))) return rc;  // (variableIndex_ as it stands: GaussianEliminationTree(*linearized, affectedFactorsVarIndex, order))
       lap(4);
       for (int32_t v : vids) affectedSet.insert(v);
       res.variablesReeliminated = (int32_t)vids.size();
@@ -1979,19 +2083,19 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
       for (int32_t idx : candidates) {
         const lmgpu_isam2::Fac& f = S->facs[idx];
         bool inside = true, useCached = true;
-        for (int k = 0; k < kFactorArity[f.type]; k++) {
-          if (!inSet.count(f.v[k])) {
+        IsGF g;
+        g.vids = is_fac_vids(S, f);
+        for (int32_t v : g.vids) {
+          if (!inSet.count(v)) {
             inside = false;
             break;
           }
-          if (relin.count(f.v[k])) useCached = false;
+          if (relin.count(v)) useCached = false;
         }
         if (!inside) continue;
-        if (!useCached) relin_by_bucket[f.bucket].push_back(f.lidx);
-        IsGF g;
-        g.kind = 0;
+        if (!useCached && f.marg < 0) relin_by_bucket[f.bucket].push_back(f.lidx);  // (a marginal factor linearizes to itself)
+        g.kind = f.marg >= 0 ? 3 : 0;
         g.id = idx;
-        for (int k = 0; k < kFactorArity[f.type]; k++) g.vids.push_back(f.v[k]);
         gfs.push_back(std::move(g));
       }
       for (auto& kv : relin_by_bucket)
@@ -2065,6 +2169,7 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
     S->replaced[v] = 0;
     S->node_of[v] = -1;
     S->vid_of.erase(k);
+    S->fixed.erase(k);
   }
   S->last_unused.assign(unusedKeys.begin(), unusedKeys.end());
   res.cliques = S->n_alive;  // (every alive clique hangs in the tree again by now; counting them by a walk was O(cliques) per update)
@@ -2077,6 +2182,301 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
     rc = is_graph_error(S, true, &S->error_after);
   }
   return rc;
+}
+
+// ISAM2::marginalizeLeaves (gtsam/nonlinear/ISAM2.cpp:487-720).  The host walks the tree and the variable index exactly as the reference
+// does; the numbers stay on the device:
+//   * a clique that goes entirely hands its cached factor (its update matrix, already in the pool) to its parent as a marginal factor --
+//     the block changes owner, nothing is copied (:556-571);
+//   * a clique that loses its leading frontals gets ONE front eliminated over them -- the cached factors of the removed children, the
+//     linear factors the leaving variables pull in (the linearization cache: it is at theta, :600-622) and marginal factors of earlier
+//     calls -- by the same front kernels an update uses; the conditional is thrown away, the update matrix is the marginal (:624-637);
+//     its [R S d] loses the leading rows and columns (the reference re-points its block matrix, :639-653; here the remaining block is
+//     copied into storage of its own shape, so that every kernel keeps seeing dense cliques);
+//   * the factors the marginals summarise leave the graph, the marginals enter it as LinearContainerFactors (slots as add_factors gives
+//     them, findUnusedFactorSlots honoured), their keys become fixedVariables_, the leaves leave theta / delta (:669-712).
+// What the reference only checks in debug builds (a key that is not a leaf leaves the object "in an inconsistent state", :516-523) is
+// checked here BEFORE anything changes, and refused.
+int is_marginalize_leaves(lmgpu_isam2* S, const std::vector<uint64_t>& leafList) {
+  S->last_marginal_idx.clear();
+  S->last_deleted_idx.clear();
+  if (!S->new_vars.empty() || !S->new_facs.empty()) {
+    S->err = "ISAM2::marginalizeLeaves: variables or factors are waiting for an update";
+    return LMGPU_INVALID;
+  }
+  const std::set<uint64_t> leafKeys(leafList.begin(), leafList.end());
+  std::set<int32_t> leafV;
+  for (uint64_t k : leafKeys) {
+    auto it = S->vid_of.find(k);
+    if (it == S->vid_of.end() || S->node_of[it->second] < 0) {
+      S->failed_key = k;
+      S->err = "ISAM2::marginalizeLeaves: a key is not a variable of the Bayes tree";
+      return LMGPU_INVALID;
+    }
+    leafV.insert(it->second);
+  }
+  if (leafV.empty()) return LMGPU_OK;
+  // ---- the plan: the reference's loop (:530-667) without touching anything
+  struct Act {
+    bool whole;
+    int clique;
+    std::vector<int> subtrees;  // partial: the children that hang on a leaving variable
+  };
+  std::vector<Act> plan;
+  std::set<int32_t> goneV;
+  auto not_leaf = [&](int32_t v) {
+    S->failed_key = S->vars[v].key;
+    S->err = "ISAM2::marginalizeLeaves: requesting to marginalize variables that are not leaves (a variable that stays is eliminated before this one)";
+    return LMGPU_INVALID;
+  };
+  auto plan_subtree = [&](int root) -> int {  // every frontal below must leave too
+    std::vector<int> q{root};
+    for (size_t i = 0; i < q.size(); i++) {
+      const lmgpu_isam2::Clq& c = S->clq[q[i]];
+      for (int k = 0; k < c.nfv; k++) {
+        if (!leafV.count(c.vars[k])) return not_leaf(c.vars[k]);
+        goneV.insert(c.vars[k]);
+      }
+      q.insert(q.end(), c.children.begin(), c.children.end());
+    }
+    return LMGPU_OK;
+  };
+  int rc;
+  for (uint64_t key : leafKeys) {
+    const int32_t v = S->vid_of.at(key);
+    if (goneV.count(v)) continue;
+    int id = S->node_of[v];
+    while (S->clq[id].parent >= 0) {  // up to the root of the marginalized subtree: only the first variable of the parent needs a look
+      const int32_t pf = S->clq[S->clq[id].parent].vars[0];
+      if (leafV.count(pf) && !goneV.count(pf))
+        id = S->clq[id].parent;
+      else
+        break;
+    }
+    const lmgpu_isam2::Clq& c = S->clq[id];
+    int nleaf = 0;
+    for (int k = 0; k < c.nfv; k++) nleaf += leafV.count(c.vars[k]) && !goneV.count(c.vars[k]);
+    Act a{nleaf == c.nfv, id, {}};
+    if (a.whole) {
+      if ((rc = plan_subtree(id))) return rc;
+    } else {
+      for (int k = 0; k < c.nfv; k++)  // the leaving frontals lead the clique (:639-642 counts them from the front)
+        if ((k < nleaf) != (leafV.count(c.vars[k]) > 0)) return not_leaf(c.vars[k < nleaf ? k : nleaf]);
+      for (int ch : c.children) {
+        bool hangs = false;
+        for (size_t k = S->clq[ch].nfv; k < S->clq[ch].vars.size() && !hangs; k++) hangs = leafV.count(S->clq[ch].vars[k]) > 0;
+        if (!hangs) continue;
+        a.subtrees.push_back(ch);
+        if ((rc = plan_subtree(ch))) return rc;
+      }
+      for (int k = 0; k < nleaf; k++) goneV.insert(c.vars[k]);
+    }
+    plan.push_back(std::move(a));
+  }
+  S->failed_key = 0;
+  // ---- carry it out
+  if ((rc = is_stage_begin(S))) return rc;
+  S->elim_pending = false;
+  std::map<uint64_t, std::vector<lmgpu_isam2::Marg>> marginalFactors;  // front key of a clique -> the marginals passed up to it
+  std::set<int32_t> factorIndicesToRemove;
+  std::vector<int> deferred;  // removed cliques whose update matrices a launch of this call still reads
+  auto drop_marginals = [&](uint64_t frontKey) {
+    auto it = marginalFactors.find(frontKey);
+    if (it == marginalFactors.end()) return;
+    for (lmgpu_isam2::Marg& m : it->second) is_pool_free(S, m.blk_off, m.blk_n);
+    marginalFactors.erase(it);
+  };
+  // BayesTree::removeSubtree (BayesTree-inst.h:512-547) + the bookkeeping of trackingRemoveSubtree (:506-527); returns the cliques, root first
+  auto remove_subtree = [&](int root) {
+    lmgpu_isam2::Clq& r = S->clq[root];
+    if (r.parent >= 0) {
+      auto& pc = S->clq[r.parent].children;
+      pc.erase(std::find(pc.begin(), pc.end(), root));
+      S->touched.push_back(r.parent);
+    } else {
+      S->roots.erase(std::find(S->roots.begin(), S->roots.end(), root));
+    }
+    r.parent = -1;
+    std::vector<int> q{root};
+    for (size_t i = 0; i < q.size(); i++) {
+      const lmgpu_isam2::Clq& c = S->clq[q[i]];
+      q.insert(q.end(), c.children.begin(), c.children.end());
+      drop_marginals(S->vars[c.vars[0]].key);
+      for (int k = 0; k < c.nfv; k++) {
+        S->node_of[c.vars[k]] = -1;
+        factorIndicesToRemove.insert(S->vindex[c.vars[k]].begin(), S->vindex[c.vars[k]].end());
+      }
+    }
+    return q;
+  };
+  for (const Act& a : plan) {
+    if (a.whole) {
+      const int parent = S->clq[a.clique].parent;
+      const uint64_t parentFront = parent >= 0 ? S->vars[S->clq[parent].vars[0]].key : 0;
+      const std::vector<int> gone = remove_subtree(a.clique);
+      for (int id : gone) {
+        if (id == a.clique && parent >= 0) {  // its cached factor belongs to the parent from now on; a root's is dropped (:559-568)
+          lmgpu_isam2::Marg m;
+          is_release_clique(S, id, &m);
+          marginalFactors[parentFront].push_back(std::move(m));
+        } else {
+          is_release_clique(S, id);
+        }
+      }
+      continue;
+    }
+    // ---- part of a clique: one front over its leaving frontals
+    const int id = a.clique;
+    std::vector<IsGF> gfs;
+    for (int ch : a.subtrees) {  // the child marginals (:583-592)
+      IsGF g;
+      g.kind = 1;
+      g.id = ch;
+      g.vids.assign(S->clq[ch].vars.begin() + S->clq[ch].nfv, S->clq[ch].vars.end());
+      gfs.push_back(std::move(g));
+    }
+    std::set<int32_t> pulled;  // factors the leaving frontals pull in, minus those of the subtrees removed at this step (:600-622)
+    std::vector<int32_t> leaving;
+    for (int k = 0; k < S->clq[id].nfv && leafV.count(S->clq[id].vars[k]); k++) {
+      leaving.push_back(S->clq[id].vars[k]);
+      pulled.insert(S->vindex[S->clq[id].vars[k]].begin(), S->vindex[S->clq[id].vars[k]].end());
+    }
+    for (int ch : a.subtrees)
+      for (int gid : remove_subtree(ch)) {
+        for (int k = 0; k < S->clq[gid].nfv; k++)
+          for (int32_t f : S->vindex[S->clq[gid].vars[k]]) pulled.erase(f);
+        deferred.push_back(gid);
+      }
+    for (int32_t f : pulled) {
+      IsGF g;
+      g.kind = S->facs[f].marg >= 0 ? 3 : 0;
+      g.id = f;
+      g.vids = is_fac_vids(S, S->facs[f]);
+      gfs.push_back(std::move(g));
+    }
+    // the front: the leaving frontals ascending by key (Ordering(cliqueFrontalsToEliminate), :627-633), then everything else they touch
+    auto by_key = [&](int32_t x, int32_t y) { return S->vars[x].key < S->vars[y].key; };
+    std::sort(leaving.begin(), leaving.end(), by_key);
+    std::set<int32_t> others;
+    for (const IsGF& g : gfs)
+      for (int32_t v : g.vids)
+        if (!std::count(leaving.begin(), leaving.end(), v)) others.insert(v);
+    std::vector<int32_t> sep(others.begin(), others.end());
+    std::sort(sep.begin(), sep.end(), by_key);
+    std::vector<int32_t> vid_of_slot = leaving;
+    vid_of_slot.insert(vid_of_slot.end(), sep.begin(), sep.end());
+    SymbolicFronts sf;
+    sf.fronts.resize(1);
+    for (size_t i = 0; i < leaving.size(); i++) sf.fronts[0].frontals.push_back((int32_t)i);
+    for (size_t i = 0; i < sep.size(); i++) sf.fronts[0].sep.push_back((int32_t)(leaving.size() + i));
+    for (size_t i = 0; i < gfs.size(); i++) sf.fronts[0].factors.push_back((int32_t)i);
+    sf.roots.push_back(0);
+    const uint64_t frontKey = S->vars[S->clq[id].vars[0]].key;  // (the marginal is filed under the front key the clique has BEFORE the split, :637)
+    std::vector<int> tmp;
+    if ((rc = is_eliminate_fronts(S, gfs, vid_of_slot, sf, false, &tmp))) return rc;
+    if ((rc = is_finish_elimination(S))) return rc;
+    {
+      lmgpu_isam2::Marg m;
+      is_release_clique(S, tmp[0], &m);
+      marginalFactors[frontKey].push_back(std::move(m));
+    }
+    // ---- split the clique (:639-653): the leading `leaving` variables go, the conditional on the rest stays as it is
+    lmgpu_isam2::Clq& c = S->clq[id];
+    int dimToRemove = 0;
+    for (int32_t v : leaving) dimToRemove += kVarDim[S->vars[v].type];
+    const int n0 = c.n, nf0 = c.nf, n1 = n0 - dimToRemove, nf1 = nf0 - dimToRemove, m1 = n1 - nf1;
+    const int ld0 = c.ld > 0 ? c.ld : n0;
+    const int64_t src = c.rsd_off + (int64_t)dimToRemove * ld0 + dimToRemove;
+    if (n1 > kLdsLimitN) {  // stays a dense-front clique: one n1 x ld1 block
+      const int ld1 = (n1 + 15) & ~15;
+      int64_t f1;
+      if ((rc = is_pool_alloc(S, (size_t)n1 * ld1, &f1))) return rc;
+      ISCHECK(hipMemsetAsync(S->pool + f1, 0, (size_t)n1 * ld1 * sizeof(double), S->stream));
+      ISCHECK(hipMemcpy2DAsync(S->pool + f1, (size_t)ld1 * sizeof(double), S->pool + src, (size_t)ld0 * sizeof(double), (size_t)n1 * sizeof(double), (size_t)n1,
+                               hipMemcpyDeviceToDevice, S->stream));
+      is_pool_free(S, c.f_off, (size_t)n0 * c.ld);
+      c.f_off = f1;
+      c.ld = ld1;
+      c.rsd_off = f1;
+      c.u_off = f1 + (int64_t)nf1 * ld1 + nf1;
+    } else {
+      int64_t r1;
+      if ((rc = is_pool_alloc(S, (size_t)nf1 * n1, &r1))) return rc;
+      ISCHECK(hipMemcpy2DAsync(S->pool + r1, (size_t)n1 * sizeof(double), S->pool + src, (size_t)ld0 * sizeof(double), (size_t)n1 * sizeof(double), (size_t)nf1,
+                               hipMemcpyDeviceToDevice, S->stream));
+      if (c.ld > 0) {  // it now fits an LDS front: [R S d] and the update matrix in dense blocks of their own
+        int64_t u1;
+        if ((rc = is_pool_alloc(S, (size_t)m1 * m1, &u1))) return rc;
+        ISCHECK(hipMemcpy2DAsync(S->pool + u1, (size_t)m1 * sizeof(double), S->pool + c.u_off, (size_t)c.ld * sizeof(double), (size_t)m1 * sizeof(double), (size_t)m1,
+                                 hipMemcpyDeviceToDevice, S->stream));
+        is_pool_free(S, c.f_off, (size_t)n0 * c.ld);
+        c.f_off = -1;
+        c.ld = 0;
+        c.u_off = u1;
+      } else {
+        is_pool_free(S, c.rsd_off, (size_t)nf0 * n0);
+      }
+      c.rsd_off = r1;
+    }
+    if (c.xrow_off >= 0) is_pool_free(S, c.xrow_off, (size_t)n0 / 2 + 1);
+    c.xrow_off = -1;
+    for (int32_t v : leaving) {
+      S->node_of[v] = -1;
+      factorIndicesToRemove.insert(S->vindex[v].begin(), S->vindex[v].end());
+    }
+    c.vars.erase(c.vars.begin(), c.vars.begin() + leaving.size());
+    c.nfv -= (int)leaving.size();
+    c.nf = nf1;
+    c.n = n1;
+    S->touched.push_back(id);
+  }
+  for (int id : deferred) is_release_clique(S, id);
+  // ---- the factors the marginals summarise leave the graph and the variable index (:672-682)
+  for (int32_t idx : factorIndicesToRemove) {
+    for (int32_t v : is_fac_vids(S, S->facs[idx])) {
+      std::vector<int32_t>& entries = S->vindex[v];
+      entries.erase(std::find(entries.begin(), entries.end(), idx));
+    }
+    if ((rc = is_empty_slot(S, idx))) return rc;
+  }
+  // ---- the marginals enter it (:684-709), in the order of the map (ascending front key), slots as FactorGraph::add_factors gives them
+  size_t slot_scan = 0;
+  for (auto& kf : marginalFactors)
+    for (lmgpu_isam2::Marg& m : kf.second) {
+      size_t slot = S->facs.size();
+      if (S->find_unused_slots) {
+        while (slot_scan < S->facs.size() && !S->facs[slot_scan].removed) ++slot_scan;
+        slot = slot_scan;
+      }
+      lmgpu_isam2::Fac f{-1, -1, -1, {-1, -1, -1}, false, -1};
+      for (int32_t v : m.vids) {
+        S->fixed.insert(S->vars[v].key);
+        S->vindex[v].push_back((int32_t)slot);
+      }
+      f.marg = is_new_marg(S, m);
+      if (slot == S->facs.size())
+        S->facs.push_back(f);
+      else
+        S->facs[slot] = f;
+      S->last_marginal_idx.push_back((uint64_t)slot);
+    }
+  // ---- removeVariables(leafKeys) (:385-398, 712)
+  for (int32_t v : leafV) {
+    S->vars[v].dead = true;
+    S->vindex[v].clear();
+    if (S->dogleg) {
+      const size_t o = (size_t)S->vars[v].xoff, nb = (size_t)kVarDim[S->vars[v].type] * sizeof(double);
+      ISCHECK(hipMemsetAsync(S->delta + o, 0, nb, S->stream));
+      ISCHECK(hipMemsetAsync(S->delta_newton + o, 0, nb, S->stream));
+      ISCHECK(hipMemsetAsync(S->rgprod + o, 0, nb, S->stream));
+    }
+    S->replaced[v] = 0;
+    S->node_of[v] = -1;
+    S->fixed.erase(S->vars[v].key);
+    S->vid_of.erase(S->vars[v].key);
+  }
+  S->last_deleted_idx.assign(factorIndicesToRemove.begin(), factorIndicesToRemove.end());
+  return is_finish_elimination(S);
 }
 
 }  // namespace
@@ -2300,6 +2700,49 @@ int lmgpu_isam2_get_unused_keys(const lmgpu_isam2* S, uint64_t* keys_out) {
   return (int)S->last_unused.size();
 }
 int lmgpu_isam2_factor_exists(const lmgpu_isam2* S, int32_t i) { return S && i >= 0 && i < (int)S->facs.size() && !S->facs[i].removed; }
+
+int lmgpu_isam2_set_find_unused_factor_slots(lmgpu_isam2* S, int32_t enable) {
+  if (!S) return LMGPU_INVALID;
+  S->find_unused_slots = enable != 0;
+  return LMGPU_OK;
+}
+int lmgpu_isam2_marginalize_leaves(lmgpu_isam2* S, int32_t n, const uint64_t* leaf_keys, int32_t* n_marginal_out, int32_t* n_deleted_out) {
+  if (!S || n < 0 || (n && !leaf_keys)) return LMGPU_INVALID;
+  if (S->device < 0) return LMGPU_HIP_ERROR;
+  ISCHECK(hipSetDevice(S->device));
+  const int rc = is_marginalize_leaves(S, std::vector<uint64_t>(leaf_keys, leaf_keys + n));
+  if (n_marginal_out) *n_marginal_out = (int32_t)S->last_marginal_idx.size();
+  if (n_deleted_out) *n_deleted_out = (int32_t)S->last_deleted_idx.size();
+  return rc;
+}
+int lmgpu_isam2_get_marginalize_result(const lmgpu_isam2* S, uint64_t* marginal_idx_out, uint64_t* deleted_idx_out) {
+  if (!S) return LMGPU_INVALID;
+  if (marginal_idx_out) std::copy(S->last_marginal_idx.begin(), S->last_marginal_idx.end(), marginal_idx_out);
+  if (deleted_idx_out) std::copy(S->last_deleted_idx.begin(), S->last_deleted_idx.end(), deleted_idx_out);
+  return LMGPU_OK;
+}
+int lmgpu_isam2_get_fixed_variables(const lmgpu_isam2* S, uint64_t* keys_out) {
+  if (!S) return -1;
+  if (keys_out) std::copy(S->fixed.begin(), S->fixed.end(), keys_out);
+  return (int)S->fixed.size();
+}
+int lmgpu_isam2_get_marginal_factor(lmgpu_isam2* S, int32_t i, uint64_t* keys_out, int32_t* dims_out, double* info_colmajor) {
+  if (!S || i < 0 || i >= (int)S->facs.size() || S->facs[i].removed || S->facs[i].marg < 0) return -1;
+  const lmgpu_isam2::Marg& m = S->margs[S->facs[i].marg];
+  for (size_t k = 0; k < m.vids.size(); k++) {
+    if (keys_out) keys_out[k] = S->vars[m.vids[k]].key;
+    if (dims_out) dims_out[k] = kVarDim[S->vars[m.vids[k]].type];
+  }
+  if (info_colmajor) {
+    if (S->device < 0) return -1;
+    if (hipSetDevice(S->device) != hipSuccess) return -1;
+    std::vector<double> rm((size_t)m.m * m.ld);
+    if (hipMemcpy(rm.data(), S->pool + m.u_off, ((size_t)(m.m - 1) * m.ld + m.m) * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    for (int r = 0; r < m.m; r++)
+      for (int c = r; c < m.m; c++) info_colmajor[(size_t)c * m.m + r] = info_colmajor[(size_t)r * m.m + c] = rm[(size_t)r * m.ld + c];
+  }
+  return (int)m.vids.size();
+}
 
 int lmgpu_isam2_num_variables(const lmgpu_isam2* S) { return S ? (int)S->vid_of.size() : -1; }
 int lmgpu_isam2_num_factors(const lmgpu_isam2* S) { return S ? (int)S->facs.size() : -1; }

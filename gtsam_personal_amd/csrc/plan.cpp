@@ -16,15 +16,22 @@ namespace lmgpu {
 // unary / binary factors of a nonlinear graph; the incremental path (csrc/isam2.hpp) feeds it the affected factors, the
 // cached boundary factors and the orphan subtrees' separators (gtsam/nonlinear/ISAM2.cpp:250-362).
 std::string symbolic_multifrontal(int32_t n, const std::vector<int32_t>& keyrank, const std::vector<std::vector<int32_t>>& fvars,
-                                  SymbolicFronts* out) {
+                                  SymbolicFronts* out, const std::vector<std::vector<int32_t>>* var_factors) {
   const int32_t none = -1;
   const int32_t m = (int32_t)fvars.size();
   std::vector<std::vector<int32_t>> vi(n);
   for (int32_t i = 0; i < m; i++)
     for (int32_t v : fvars[i]) {
       if (v < 0 || v >= n) return "factor references unknown variable";
-      vi[v].push_back(i);
+      if (!var_factors) vi[v].push_back(i);
     }
+  if (var_factors) {  // the caller's VariableIndex: the elimination tree hooks children in the order a variable's factors are listed
+    if ((int32_t)var_factors->size() != n) return "variable index of the wrong size";
+    vi = *var_factors;
+    for (int32_t s = 0; s < n; s++)
+      for (int32_t i : vi[s])
+        if (i < 0 || i >= m || std::find(fvars[i].begin(), fvars[i].end(), s) == fvars[i].end()) return "variable index does not match the factors";
+  }
   for (int32_t s = 0; s < n; s++)
     if (vi[s].empty()) return "EliminationTree: given ordering contains variables that are not involved in the factor graph";
 

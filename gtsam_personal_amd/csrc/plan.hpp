@@ -56,8 +56,10 @@ struct SymbolicFronts {
   std::vector<F> fronts;
   std::vector<int32_t> roots, etree_parent;
 };
+// var_factors (optional): per slot its factor indices in the order of the caller's VariableIndex (ISAM2 keeps one incrementally: with
+// findUnusedFactorSlots its lists are not ascending, and EliminationTree-inst.h:94-134 walks them as they are); default: ascending
 std::string symbolic_multifrontal(int32_t n, const std::vector<int32_t>& keyrank, const std::vector<std::vector<int32_t>>& fvars,
-                                  SymbolicFronts* out);
+                                  SymbolicFronts* out, const std::vector<std::vector<int32_t>>* var_factors = nullptr);
 
 struct Plan {
   // inputs

@@ -37,13 +37,14 @@ class ISAM2Params:
     enablePartialRelinearizationCheck (:214-222)"""
 
     def __init__(self, optimizationParams=None, relinearizeThreshold=0.1, relinearizeSkip=10, enableRelinearization=True,
-                 enablePartialRelinearizationCheck=False, evaluateNonlinearError=False):
+                 enablePartialRelinearizationCheck=False, evaluateNonlinearError=False, findUnusedFactorSlots=False):
         self.optimizationParams = optimizationParams or ISAM2GaussNewtonParams()
         self.relinearizeThreshold = relinearizeThreshold
         self.relinearizeSkip = relinearizeSkip
         self.enableRelinearization = enableRelinearization
         self.enablePartialRelinearizationCheck = enablePartialRelinearizationCheck
         self.evaluateNonlinearError = evaluateNonlinearError  # ISAM2Params.h:200-203
+        self.findUnusedFactorSlots = findUnusedFactorSlots  # ISAM2Params.h:225
 
 
 class ISAM2Result:
@@ -100,6 +101,8 @@ class ISAM2:
             self._check(self.lib.lmgpu_isam2_set_partial_relinearization_check(self._h, 1))
         if getattr(p, "evaluateNonlinearError", False):
             self._check(self.lib.lmgpu_isam2_set_evaluate_nonlinear_error(self._h, 1))
+        if getattr(p, "findUnusedFactorSlots", False):
+            self._check(self.lib.lmgpu_isam2_set_find_unused_factor_slots(self._h, 1))
         if isinstance(p.optimizationParams, ISAM2DoglegParams):
             o = p.optimizationParams
             self._check(self.lib.lmgpu_isam2_set_dogleg(self._h, float(o.initialDelta), float(o.wildfireThreshold), int(o.adaptationMode)))
@@ -202,6 +205,38 @@ class ISAM2:
         keys = np.zeros(max(n, 1), dtype=np.uint64)
         self.lib.lmgpu_isam2_get_unused_keys(self._h, keys.ctypes.data_as(ct.POINTER(ct.c_uint64)))
         return [int(k) for k in keys[:n]]
+
+    def marginalizeLeaves(self, leafKeys):
+        """ISAM2::marginalizeLeaves(leafKeys, &marginalFactorsIndices, &deletedFactorsIndices) (gtsam/nonlinear/ISAM2.h:198-222); returns
+        (marginalFactorsIndices, deletedFactorsIndices).  A key that is not a leaf is refused before anything changes (LmgpuError)."""
+        keys = np.asarray([int(k) for k in leafKeys], dtype=np.uint64)
+        U = ct.POINTER(ct.c_uint64)
+        nm, nd = ct.c_int32(0), ct.c_int32(0)
+        self._check(self.lib.lmgpu_isam2_marginalize_leaves(self._h, len(keys), keys.ctypes.data_as(U), ct.byref(nm), ct.byref(nd)))
+        mi, di = np.zeros(max(nm.value, 1), dtype=np.uint64), np.zeros(max(nd.value, 1), dtype=np.uint64)
+        self._check(self.lib.lmgpu_isam2_get_marginalize_result(self._h, mi.ctypes.data_as(U), di.ctypes.data_as(U)))
+        return [int(i) for i in mi[:nm.value]], [int(i) for i in di[:nd.value]]
+
+    def getFixedVariables(self):
+        """ISAM2::getFixedVariables() (ISAM2.h:259): the keys of the marginal factors, ascending"""
+        n = self.lib.lmgpu_isam2_get_fixed_variables(self._h, None)
+        keys = np.zeros(max(n, 1), dtype=np.uint64)
+        self.lib.lmgpu_isam2_get_fixed_variables(self._h, keys.ctypes.data_as(ct.POINTER(ct.c_uint64)))
+        return [int(k) for k in keys[:n]]
+
+    def marginal_factor(self, i):
+        """parity tap: slot i of getFactorsUnsafe() as the LinearContainerFactor marginalizeLeaves left there -> (keys, dims, augmented
+        information matrix), None when the slot holds none"""
+        n = self.lib.lmgpu_isam2_get_marginal_factor(self._h, int(i), None, None, None)
+        if n < 0:
+            return None
+        keys, dims = np.zeros(max(n, 1), dtype=np.uint64), np.zeros(max(n, 1), dtype=np.int32)
+        self.lib.lmgpu_isam2_get_marginal_factor(self._h, int(i), keys.ctypes.data_as(ct.POINTER(ct.c_uint64)), dims.ctypes.data_as(_lib._I), None)
+        N = int(dims[:n].sum()) + 1
+        info = np.zeros(N * N)
+        if self.lib.lmgpu_isam2_get_marginal_factor(self._h, int(i), None, None, info.ctypes.data_as(_lib._D)) < 0:
+            raise _lib.LmgpuError("reading a marginal factor failed")
+        return [int(k) for k in keys[:n]], [int(d) for d in dims[:n]], info.reshape(N, N).T.copy()
 
     def factor_exists(self, i):
         """getFactorsUnsafe().exists(i)"""

@@ -286,7 +286,8 @@ int lmgpu_selftest_chain_schedule(int n, int nf, int i0, int nsteps, int far_pct
  * relinearizeThreshold as FastMap<char, Vector> and enablePartialRelinearizationCheck: the two setters below.
  * ISAM2DoglegParams: lmgpu_isam2_set_dogleg.
  * Robust noise models: lmgpu_isam2_add_factors_robust.
- * Not bound: QR, marginalizeLeaves, newAffectedKeys (smart factors), findUnusedFactorSlots (not offered).
+ * ISAM2::marginalizeLeaves: lmgpu_isam2_marginalize_leaves; ISAM2Params::findUnusedFactorSlots: lmgpu_isam2_set_find_unused_factor_slots.
+ * Not bound: QR, newAffectedKeys (smart factors).
  *
  * The fill-reducing ordering is a boundary input like in the batch path, but here it is needed per update: the caller hands over
  * ITS ccolamd (the reference side: the one Ordering::ColamdConstrained calls, gtsam/inference/Ordering.cpp:50-125) as a callback:
@@ -368,6 +369,23 @@ int lmgpu_isam2_update_with(lmgpu_isam2* s, const lmgpu_isam2_update_params* par
 int lmgpu_isam2_get_unused_keys(const lmgpu_isam2* s, uint64_t* keys_out);
 /* 1 when slot i of the factor list holds a factor (getFactorsUnsafe().exists(i)) */
 int lmgpu_isam2_factor_exists(const lmgpu_isam2* s, int32_t i);
+/* ISAM2Params::findUnusedFactorSlots (gtsam/nonlinear/ISAM2Params.h:225): new factors -- of an update and of marginalizeLeaves -- fill the
+ * empty slots of the factor list from the front before they extend it (FactorGraph::add_factors, gtsam/inference/FactorGraph-inst.h:109-137). */
+int lmgpu_isam2_set_find_unused_factor_slots(lmgpu_isam2* s, int32_t enable);
+/* ISAM2::marginalizeLeaves(leafKeys, &marginalFactorsIndices, &deletedFactorsIndices) (gtsam/nonlinear/ISAM2.h:198-222, ISAM2.cpp:487-720):
+ * the variables must be leaves of the Bayes tree (the caller orders them first with constrainedKeys, as with the reference: see
+ * IncrementalFixedLagSmoother).  The marginal on what they were connected to stays in the factor list as LinearContainerFactors (constant
+ * Hessian factors in device memory: they enter later eliminations, are never relinearized and add nothing to the nonlinear error), their
+ * keys become fixedVariables_ (lmgpu_isam2_get_fixed_variables, ascending; returns their number), the summarised factors' slots empty.
+ * n_marginal_out / n_deleted_out: sizes of the two index lists, read with lmgpu_isam2_get_marginalize_result (either may be NULL).
+ * A key that is not a leaf is refused BEFORE anything changes (LMGPU_INVALID, lmgpu_isam2_last_failed_key names the variable that is in
+ * the way) -- the reference checks this in debug builds only and leaves the object unusable.
+ * lmgpu_isam2_get_marginal_factor: parity tap -- slot i as a marginal factor: its keys, their dimensions and the augmented information
+ * matrix ((sum dims + 1)^2, column-major, symmetric); returns the number of keys, -1 when slot i holds no marginal factor. */
+int lmgpu_isam2_marginalize_leaves(lmgpu_isam2* s, int32_t n, const uint64_t* leaf_keys, int32_t* n_marginal_out, int32_t* n_deleted_out);
+int lmgpu_isam2_get_marginalize_result(const lmgpu_isam2* s, uint64_t* marginal_idx_out, uint64_t* deleted_idx_out);
+int lmgpu_isam2_get_fixed_variables(const lmgpu_isam2* s, uint64_t* keys_out);
+int lmgpu_isam2_get_marginal_factor(lmgpu_isam2* s, int32_t i, uint64_t* keys_out, int32_t* dims_out, double* info_colmajor);
 int lmgpu_isam2_num_variables(const lmgpu_isam2* s); /* live variables = theta_.size() */
 int lmgpu_isam2_num_factors(const lmgpu_isam2* s);   /* slots of the factor list, removed ones included */
 /* which: 0 = calculateEstimate (ISAM2.cpp:748-754), 1 = calculateBestEstimate (:763-766), 2 = getLinearizationPoint.
