@@ -131,7 +131,8 @@ class ISAM2:
                constrainedKeys=None, noRelinKeys=None, extraReelimKeys=None, force_relinearize=False, forceFullSolve=False) -> ISAM2Result:
         """ISAM2::update(newFactors, newTheta, removeFactorIndices, constrainedKeys, noRelinKeys, extraReelimKeys, force_relinearize)
         (gtsam/nonlinear/ISAM2.h:146-186, ISAM2UpdateParams.h:30-90).  removeFactorIndices: positions in getFactorsUnsafe();
-        constrainedKeys: {key: group} (None = not given); the new factors of this update get the indices size() .. of the list"""
+        constrainedKeys: {key: group} (None = not given); the new factors of this update get the indices size() .. of the list (with
+        ISAM2Params.findUnusedFactorSlots: its empty slots first)"""
         U64 = ct.POINTER(ct.c_uint64)
         if newTheta is not None and newTheta.size():
             keys = np.array(newTheta.keys(), dtype=np.uint64)

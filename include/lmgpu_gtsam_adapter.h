@@ -488,8 +488,8 @@ class GpuDoglegOptimizer : public NonlinearOptimizer {
 class GpuISAM2 {
  public:
   explicit GpuISAM2(const ISAM2Params& params = ISAM2Params(), int device = 0) {
-    if (params.factorization != ISAM2Params::CHOLESKY || params.findUnusedFactorSlots || !params.cacheLinearizedFactors)
-      throw std::invalid_argument("GpuISAM2: parameter set not bound (Cholesky, cached linear factors, no reuse of factor slots)");
+    if (params.factorization != ISAM2Params::CHOLESKY || !params.cacheLinearizedFactors)
+      throw std::invalid_argument("GpuISAM2: parameter set not bound (Cholesky, cached linear factors)");
     const bool byChar = std::holds_alternative<FastMap<char, Vector>>(params.relinearizeThreshold);
     const ISAM2DoglegParams* dl = std::get_if<ISAM2DoglegParams>(&params.optimizationParams);
     lmgpu_isam2_params p{byChar ? 0.1 : std::get<double>(params.relinearizeThreshold), params.relinearizeSkip, params.enableRelinearization ? 1 : 0,
@@ -514,6 +514,7 @@ class GpuISAM2 {
     }
     if (params.enablePartialRelinearizationCheck) check(lmgpu_isam2_set_partial_relinearization_check(h_, 1));
     if (params.evaluateNonlinearError) check(lmgpu_isam2_set_evaluate_nonlinear_error(h_, 1));
+    if (params.findUnusedFactorSlots) check(lmgpu_isam2_set_find_unused_factor_slots(h_, 1));
   }
   ~GpuISAM2() { if (h_) lmgpu_isam2_destroy(h_); }
   GpuISAM2(const GpuISAM2&) = delete;
@@ -535,7 +536,7 @@ class GpuISAM2 {
   }
 
   /// ISAM2::update(newFactors, newTheta, const ISAM2UpdateParams&) (ISAM2.h:176-186, ISAM2.cpp:419-480).  The new factors take the
-  /// indices size() .. of the factor list like ISAM2Result::newFactorsIndices (findUnusedFactorSlots is not bound).
+  /// indices ISAM2Result::newFactorsIndices would name: size() .. of the factor list, or its empty slots first with findUnusedFactorSlots.
   lmgpu_isam2_result update(const NonlinearFactorGraph& newFactors, const Values& newTheta, const ISAM2UpdateParams& up) {
     if (up.newAffectedKeys) throw std::invalid_argument("GpuISAM2: newAffectedKeys (smart factors) is not bound");
     std::vector<uint64_t> keys;
@@ -577,6 +578,27 @@ class GpuISAM2 {
     lmgpu_isam2_result r{};
     check(lmgpu_isam2_update_with(h_, &p, &r));
     return r;
+  }
+
+  /// ISAM2::marginalizeLeaves(leafKeys, marginalFactorsIndices, deletedFactorsIndices) (ISAM2.h:198-222, ISAM2.cpp:487-720).  The leaf
+  /// keys must have been ordered first (constrainedKeys of the update before, as IncrementalFixedLagSmoother does).  A key that is not a
+  /// leaf throws std::runtime_error BEFORE anything changes (the reference checks it in debug builds only).
+  void marginalizeLeaves(const FastList<Key>& leafKeys, FactorIndices* marginalFactorsIndices = nullptr, FactorIndices* deletedFactorsIndices = nullptr) {
+    const std::vector<uint64_t> keys(leafKeys.begin(), leafKeys.end());
+    int32_t nm = 0, nd = 0;
+    check(lmgpu_isam2_marginalize_leaves(h_, (int32_t)keys.size(), keys.data(), &nm, &nd));
+    std::vector<uint64_t> mi((size_t)std::max(1, nm)), di((size_t)std::max(1, nd));
+    check(lmgpu_isam2_get_marginalize_result(h_, mi.data(), di.data()));
+    if (marginalFactorsIndices) marginalFactorsIndices->assign(mi.begin(), mi.begin() + nm);
+    if (deletedFactorsIndices) deletedFactorsIndices->assign(di.begin(), di.begin() + nd);
+    for (Key k : leafKeys)
+      if (all_.exists(k)) all_.erase(k);
+  }
+  /// ISAM2::getFixedVariables() (ISAM2.h:259)
+  KeySet getFixedVariables() const {
+    std::vector<uint64_t> k((size_t)std::max(1, lmgpu_isam2_get_fixed_variables(h_, nullptr)));
+    const int n = lmgpu_isam2_get_fixed_variables(h_, k.data());
+    return KeySet(k.begin(), k.begin() + n);
   }
 
   /// ISAM2::marginalCovariance(key) (ISAM2.h:253-257)
