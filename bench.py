@@ -135,6 +135,10 @@ def slam_workload(name):
     elif name == "city10000":
         graph, initial = readG2o(os.path.join(gold, "city10000.g2o"))
         graph.add_PriorFactorPose2(0, initial.at(0), noiseModel.Diagonal.Variances([1e-6, 1e-6, 1e-8]))
+    elif name == "victoria_park":  # examples/Data/victoria_park.txt: 6 969 Pose2, 151 Point2 landmarks, 6 968 odometry + 3 640 bearing-range factors
+        from gtsam_personal_amd.datasets import load2D
+        graph, initial = load2D(os.path.join(gold, "victoria_park.txt"))
+        graph.add_PriorFactorPose2(0, initial.at(0), noiseModel.Diagonal.Variances([1e-6, 1e-6, 1e-8]))
     else:
         raise SystemExit(name)
     return graph, initial
@@ -377,7 +381,7 @@ def main():
                     help="elimination ordering: the reference's METIS ordering (BASELINE.json configs[3]; the permutation is a boundary input "
                          "carried by tests/golden/<tag>_metis.npz, produced once by Ordering::Metis through oracle/_ref) or Schur "
                          "(points then cameras, timing/timeSFMBAL.h:64-96)")
-    ap.add_argument("--workload", choices=["bal", "sphere2500", "city10000", "isam2"], default="bal",
+    ap.add_argument("--workload", choices=["bal", "sphere2500", "city10000", "victoria_park", "isam2"], default="bal",
                     help="bal = the headline synthetic BAL graph (BASELINE configs[3]); sphere2500 / city10000 = the general sparse configs at the "
                          "reference's size (single GPU side line; --ordering colamd|metis); isam2 = BASELINE configs[4] (VisualISAM2Example) and the "
                          "reference's incremental loop on city10000, ms per ISAM2::update through the C ABI")
@@ -400,7 +404,7 @@ def main():
         _l.use_test_library(True)
     if args.workload != "bal":
         if args.gpus != 1:
-            raise SystemExit("--workload sphere2500 / city10000 / isam2 is a single-GPU side line")
+            raise SystemExit("--workload sphere2500 / city10000 / victoria_park / isam2 is a single-GPU side line")
         return isam2_bench(args) if args.workload == "isam2" else slam_bench(args)
     if args.ordering == "colamd":
         raise SystemExit("--ordering colamd is offered for --workload sphere2500 / city10000 (the BAL fixtures carry METIS and Schur)")

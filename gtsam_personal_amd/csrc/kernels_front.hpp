@@ -99,7 +99,7 @@ static_assert(sizeof(LFac) == 32, "leaf records embed LFac entries");
 #ifdef LDSF_STAMPS_LEAVES
 #define LDSF_SAMPLED (gridDim.x > 1000 && blockIdx.x == gridDim.x / 2)
 #else
-#define LDSF_SAMPLED (gridDim.x <= 8 && blockIdx.x == 0)
+#define LDSF_SAMPLED (DATAFLOW ? ((work - flow.seg_begin) * 4 > 3 * (flow.seg_end - flow.seg_begin)) : (gridDim.x <= 8 && blockIdx.x == 0))
 #endif
 __device__ unsigned long long ldsf_dbg[16];
 #define LDSF_STAMP(i)                                                  \
@@ -113,14 +113,22 @@ __device__ unsigned long long ldsf_dbg[16];
 #else
 #define LDSF_STAMP(i) do { } while (0)
 #endif
-template <bool GATHER, int MAXT = 256>
-__global__ __launch_bounds__(MAXT) void lds_front_kernel(const int32_t* __restrict__ list, const FrontDesc* __restrict__ fronts,
-                                                         const FrontFac* __restrict__ ffac, const FacDesc* __restrict__ fd,
-                                                         const ChildRef* __restrict__ childs, const int32_t* __restrict__ cmap,
-                                                         const int32_t* __restrict__ fxoff, double* __restrict__ pool, double lambda_v, const double* __restrict__ lambda_p,
-                                                         const double* __restrict__ dampw, int* __restrict__ status, int nmax, int srows,
-                                                         double* __restrict__ gcorner, int jcap, const double* __restrict__ gex,
-                                                         const char* __restrict__ pack, int pack_stride) {
+// DATAFLOW (lds_front_merged_kernel below): the fronts of several consecutive tree levels in one launch; a front waits for those of its
+// children that belong to the same launch (their flags in `done`) between its own factors and the extend-add, and raises its own flag
+// when [R S d] and its update matrix are in memory.
+struct FrontFlow {
+  const int32_t* pos_of;  // per front: position in the level lists
+  unsigned int* done;     // per front: 1 once its outputs are visible
+  int seg_begin, seg_end; // positions of this launch's fronts
+};
+template <bool GATHER, int MAXT, bool DATAFLOW>
+__device__ __forceinline__ void lds_front_body(const int work, const int32_t* __restrict__ list, const FrontDesc* __restrict__ fronts,
+                                               const FrontFac* __restrict__ ffac, const FacDesc* __restrict__ fd,
+                                               const ChildRef* __restrict__ childs, const int32_t* __restrict__ cmap,
+                                               const int32_t* __restrict__ fxoff, double* __restrict__ pool, double lambda_v, const double* __restrict__ lambda_p,
+                                               const double* __restrict__ dampw, int* __restrict__ status, int nmax, int srows,
+                                               double* __restrict__ gcorner, int jcap, const double* __restrict__ gex,
+                                               const char* __restrict__ pack, int pack_stride, const FrontFlow flow) {
   extern __shared__ double S[];
 #ifdef LDSF_STAMPS
   unsigned long long ldsf_last = wall_clock64();
@@ -130,8 +138,8 @@ __global__ __launch_bounds__(MAXT) void lds_front_kernel(const int32_t* __restri
   double* Jb = corner_g + 8;
   LFac* LF = (LFac*)(Jb + jcap);  // jcap <= LDSF_JCAP doubles of staged Jacobians: the launch's largest front (fewer for small ones => more fronts per CU)
   int* meta = (int*)(LF + LDSF_MAXB);
-  const char* pk = pack ? pack + (size_t)blockIdx.x * pack_stride : nullptr;
-  const FrontDesc F = pk ? *(const FrontDesc*)pk : fronts[list[blockIdx.x]];
+  const char* pk = pack ? pack + (size_t)work * pack_stride : nullptr;
+  const FrontDesc F = pk ? *(const FrontDesc*)pk : fronts[list[work]];
   const int pk_n = pk ? ((const int*)(pk + LEAFPACK_HDR))[0] : 0;  // > 0: factor descriptors, staging offsets and damping offsets come from the record
   const int pk_tot = pk_n ? ((const int*)(pk + LEAFPACK_HDR))[1] : 0, pk_contig = pk_n ? ((const int*)(pk + LEAFPACK_HDR))[2] : 0;
   const int n = F.n, nf = F.nf, tid = threadIdx.x, nt = blockDim.x;
@@ -143,6 +151,29 @@ __global__ __launch_bounds__(MAXT) void lds_front_kernel(const int32_t* __restri
     if (gex) gex_pre = gex[xo];
   }
   const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+  // Everything the later phases read from memory that does not depend on the children is requested NOW, under the own-factor phase (and, in
+  // a merged launch, under the wait for the children): the damping weights (fxoff -> dampw: two dependent reads), lambda, and the
+  // descriptors and column maps of the first two children (childs -> cmap: two more).  Behind the wait each of them was a memory round
+  // trip of its own on the critical path of a tree level (~9 us per level of victoria_park's chain of small fronts before).
+  const double lambda = lambda_p ? *lambda_p : lambda_v;
+  const bool damp_regs = !pk_xo && nf <= nt;
+  if (damp_regs && tid < nf) {
+    const int xo = fxoff[F.fx_begin + tid];
+    damp_pre = dampw[xo];
+    if (gex) gex_pre = gex[xo];
+  }
+  ChildRef pc0{}, pc1{};
+  int pm0 = 0, pm1 = 0;
+  if constexpr (!GATHER) {
+    if (F.child_count > 0) {
+      pc0 = childs[F.child_begin];
+      pm0 = cmap[pc0.map_begin + min(tid, pc0.m - 1)];
+    }
+    if (F.child_count > 1) {
+      pc1 = childs[F.child_begin + 1];
+      pm1 = cmap[pc1.map_begin + min(tid, pc1.m - 1)];
+    }
+  }
   // gather mode (par_ld < 0): the parent assembles this leaf's update itself from [R S d] (kernels_schur.hpp); only the
   // frontal rows and the (rhs, rhs) corner of the trailing block are needed here
   constexpr bool gather = GATHER;
@@ -263,6 +294,30 @@ __global__ __launch_bounds__(MAXT) void lds_front_kernel(const int32_t* __restri
   }
   __syncthreads();
   LDSF_STAMP(0);  // descriptors, clear, own factors
+  if constexpr (DATAFLOW) {
+    // children of the same launch: their update matrices must be in memory (they hold lower tickets, so they are running or done)
+    __shared__ int s_flow_ok;
+    if (tid == 0) s_flow_ok = 1;
+    __syncthreads();
+    for (int k = tid; k < F.child_count; k += nt) {
+      const int cf = childs[F.child_begin + k].pad - 1;
+      if (cf < 0) continue;
+      const int pp = flow.pos_of[cf];
+      if (pp < flow.seg_begin || pp >= flow.seg_end) continue;
+      long spins = 0;
+      while (__hip_atomic_load(&flow.done[cf], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > 4000000L) {
+          s_flow_ok = 0;
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (!s_flow_ok && tid == 0) atomicExch(status + 1, 1 + F.id);  // never expected: spin bound hit (reported apart from pivot failures)
+    LDSF_STAMP(5);  // waiting for the children of the same launch
+  }
   // ---- children: extend-add of their update matrices (row i of U contiguous: lanes along j).  The child's column map is staged
   //      in LDS once and four (sixteen-wave form: eight) rows per wave are fetched before the first is added -- row by row, every row was a memory round
   //      trip of its own (25-35 of them per child of ~100 columns: most of the 27-60 us an upper-level front took).  The loads are
@@ -271,10 +326,14 @@ __global__ __launch_bounds__(MAXT) void lds_front_kernel(const int32_t* __restri
     constexpr int EAB = (MAXT > 256) ? 8 : 4;  // rows per wave in flight (eight cost the four-wave form occupancy on leaf levels)
     int* cm = (int*)Jb;  // jcap >= 96 doubles: room for 139 ints (a child's update matrix is at most as wide as this front)
     for (int k = 0; k < F.child_count; k++) {
-      const ChildRef c = childs[F.child_begin + k];
+      const ChildRef c = k == 0 ? pc0 : (k == 1 ? pc1 : childs[F.child_begin + k]);
       const double* U = pool + c.u_off;
       const int32_t* map = cmap + c.map_begin;
-      for (int i = tid; i < c.m; i += nt) cm[i] = map[i];
+      if (k < 2 && c.m <= nt) {  // fetched at the top of the kernel
+        if (tid < c.m) cm[tid] = k == 0 ? pm0 : pm1;
+      } else {
+        for (int i = tid; i < c.m; i += nt) cm[i] = map[i];
+      }
       __syncthreads();
       int gjs[3];
 #pragma unroll
@@ -308,8 +367,7 @@ __global__ __launch_bounds__(MAXT) void lds_front_kernel(const int32_t* __restri
   LDSF_STAMP(1);  // extend-add of the children
   // ---- damping on the frontal diagonal
   // lambda_p != nullptr: the value lives in device memory so that a captured launch sequence can be replayed with a new one
-  const double lambda = lambda_p ? *lambda_p : lambda_v;
-  if (pk_xo) {  // nf <= LEAFPACK_MAXNF <= nt: the weights were fetched with the record
+  if (pk_xo || damp_regs) {  // the weights were fetched at the top (pk_xo: nf <= LEAFPACK_MAXNF <= nt, offsets from the record)
     if (tid < nf) {
       S[tid * n + tid] += lambda * damp_pre;
       if (gex) S[tid * n + n - 1] += gex_pre;
@@ -476,6 +534,47 @@ __global__ __launch_bounds__(MAXT) void lds_front_kernel(const int32_t* __restri
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   LDSF_STAMP(4);  // [R S d] and the update matrix written
 #endif
+  if constexpr (DATAFLOW) {  // publish: every wave's stores have been performed, then one release + flag
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(&flow.done[F.id], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    LDSF_STAMP(6);  // publish
+  }
+}
+
+template <bool GATHER, int MAXT = 256>
+__global__ __launch_bounds__(MAXT) void lds_front_kernel(const int32_t* __restrict__ list, const FrontDesc* __restrict__ fronts,
+                                                         const FrontFac* __restrict__ ffac, const FacDesc* __restrict__ fd,
+                                                         const ChildRef* __restrict__ childs, const int32_t* __restrict__ cmap,
+                                                         const int32_t* __restrict__ fxoff, double* __restrict__ pool, double lambda_v, const double* __restrict__ lambda_p,
+                                                         const double* __restrict__ dampw, int* __restrict__ status, int nmax, int srows,
+                                                         double* __restrict__ gcorner, int jcap, const double* __restrict__ gex,
+                                                         const char* __restrict__ pack, int pack_stride) {
+  lds_front_body<GATHER, MAXT, false>((int)blockIdx.x, list, fronts, ffac, fd, childs, cmap, fxoff, pool, lambda_v, lambda_p, dampw, status, nmax, srows, gcorner, jcap,
+                                      gex, pack, pack_stride, FrontFlow{});
+}
+
+// The LDS fronts of SEVERAL consecutive tree levels in one launch, bottom-up (deep clique trees: an upper level is a handful of fronts, a
+// launch of ~15-25 us of which most is latency -- descriptor chains, Jacobian staging -- that does not depend on the children at all).
+// list[seg_begin, seg_end) holds the levels bottom-up; ticket t takes list[seg_begin + t], so children hold lower tickets than their
+// parents: whatever a workgroup waits for has been started before it (no residency assumption).  FrontDesc::id must be the front's index.
+template <int MAXT>
+__global__ __launch_bounds__(MAXT) void lds_front_merged_kernel(const int32_t* __restrict__ list, int seg_begin, int seg_end, const FrontDesc* __restrict__ fronts,
+                                                                const FrontFac* __restrict__ ffac, const FacDesc* __restrict__ fd,
+                                                                const ChildRef* __restrict__ childs, const int32_t* __restrict__ cmap,
+                                                                const int32_t* __restrict__ fxoff, double* __restrict__ pool, double lambda_v,
+                                                                const double* __restrict__ lambda_p, const double* __restrict__ dampw, int* __restrict__ status,
+                                                                int nmax, int jcap, const double* __restrict__ gex, const int32_t* __restrict__ pos_of,
+                                                                unsigned int* __restrict__ done, unsigned int* __restrict__ ticket) {
+  __shared__ int s_ticket;
+  if (threadIdx.x == 0) s_ticket = (int)atomicAdd(ticket, 1u);
+  __syncthreads();
+  lds_front_body<false, MAXT, true>(seg_begin + s_ticket, list, fronts, ffac, fd, childs, cmap, fxoff, pool, lambda_v, lambda_p, dampw, status, nmax, nmax,
+                                    (double*)nullptr, jcap, gex, (const char*)nullptr, 0, FrontFlow{pos_of, done, seg_begin, seg_end});
 }
 
 // back-substitution for LDS-class fronts with at most LDSB_SMALL_NF frontal scalars (leaves and the levels just above them: the host
@@ -617,12 +716,33 @@ __device__ __forceinline__ void ldsb_stage(const FrontDesc& F, const double* __r
 // after the front's ancestors are visible.  so = this thread's separator offset (sxoff[sx_begin + min(tid, ns - 1)]); Ls staged by
 // ldsb_stage (a barrier follows here).  Leaves x_F in LDS (the pointer returned, nf entries; a barrier precedes the return) and
 // whether this thread saw a NaN in it.
-__device__ __forceinline__ double* ldsb_solve_core(const FrontDesc& F, double* Ls, int so, const double* __restrict__ delta, bool* bad_out) {
+// POLL (merged launches): delta was filled with the all-ones pattern before the back-substitution started and is written with agent-scope
+// stores; a separator value that is still the pattern has not been published by its front yet -- the load of x_S IS the wait (no flag, no
+// fence: the hand-off is one store and one load).  *timed_out: the bounded spin gave up (never expected).
+template <bool POLL = false>
+__device__ __forceinline__ double* ldsb_solve_core(const FrontDesc& F, double* Ls, int so, const double* __restrict__ delta, bool* bad_out,
+                                                   bool* timed_out = nullptr) {
   const int n = F.n, nf = F.nf, ns = n - nf - 1, nl = n | 1;
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   double* xsl = Ls + (size_t)nf * nl;  // [144]
   double* y = xsl + 144;               // [144]
-  const double xv = delta[so];
+  double xv;
+  if constexpr (POLL) {
+    unsigned long long bits = 0ull;
+    if (ns > 0) {
+      long spins = 0;
+      while ((bits = __hip_atomic_load((const unsigned long long*)(delta + so), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == ~0ull) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > 4000000L) {
+          *timed_out = true;
+          break;
+        }
+      }
+    }
+    xv = __longlong_as_double((long long)bits);
+  } else {
+    xv = delta[so];
+  }
   if (tid < ns) xsl[tid] = xv;
   __syncthreads();  // Ls and x_S in LDS
   for (int i0 = w; i0 < nf; i0 += 32) {  // rows i0, i0 + 4, ..., i0 + 28
@@ -710,11 +830,11 @@ __global__ __launch_bounds__(256) void lds_backsub_wide_kernel(const int32_t* __
 
 // The LDS fronts of SEVERAL consecutive tree levels in one launch (deep clique trees: a level's launch does ~10-25 us of work
 // and costs about as much again in launch latency).  list[seg_begin, seg_end) holds the levels bottom-up; ticket t takes
-// list[seg_end - 1 - t], so parents hold lower tickets than their children.  A front whose parent lies in the same segment
-// waits for the parent's flag (pos_of[parent] inside the segment; a parent outside was finished by an earlier launch);
-// the parent raised it after its delta was stored, and it had waited for its own parent, so every ancestor is visible.
-// Same per-front work as lds_backsub_wide_kernel, the staging of [R S d] under the wait.  Hand-off and progress as in
-// kernels_potrf.hpp (release / acquire at agent scope, tickets drawn at workgroup start, bounded spin).
+// list[seg_end - 1 - t], so parents hold lower tickets than their children.  Hand-off through delta itself (round 3; a flag per front
+// with release / acquire fences before): the host fills delta with the all-ones pattern before the back-substitution, a front stores its
+// x_F with agent-scope stores, and a front that needs a value polls the value (ldsb_solve_core<true>): one store and one load per tree
+// level instead of store, write-back, flag, poll, invalidate, load.  Same per-front work as lds_backsub_wide_kernel, the staging of
+// [R S d] under the wait; tickets drawn at workgroup start (whatever a workgroup waits for has started before it), bounded spin.
 __global__ __launch_bounds__(256) void lds_backsub_merged_kernel(const int32_t* __restrict__ list, int seg_begin, int seg_end,
                                                                   const FrontDesc* __restrict__ fronts, const int32_t* __restrict__ fxoff,
                                                                   const int32_t* __restrict__ sxoff, const double* __restrict__ pool,
@@ -730,38 +850,18 @@ __global__ __launch_bounds__(256) void lds_backsub_merged_kernel(const int32_t* 
   const FrontDesc F = fronts[fi];
   const int ns = F.n - F.nf - 1;
   const int so = sxoff[F.sx_begin + max(min(tid, ns - 1), 0)], fo = fxoff[F.fx_begin + min(tid, F.nf - 1)];
-  // [R S d] does not depend on the parent: stage it before waiting
+  // [R S d] does not depend on the ancestors: it is staged before the first look at x_S
   ldsb_stage(F, pool, Ls, tid);
-  if (tid == 0) {
-    int ok = 1;
-    const int par = parent_of[fi];
-    if (par >= 0) {
-      const int pp = pos_of[par];
-      if (pp >= seg_begin && pp < seg_end) {
-        long spins = 0;
-        while (__hip_atomic_load(&done[par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-          __builtin_amdgcn_s_sleep(1);
-          if (++spins > 2000000L) {
-            ok = 0;
-            break;
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      }
-    }
-    s_ok = ok;
-  }
-  __syncthreads();
-  if (!s_ok && tid == 0) atomicExch(status + 1, 1 + F.id);  // never expected: spin bound hit (a fault, reported apart from pivot failures)
-  ldsb_solve(F, Ls, ns > 0 ? so : fo, fo, delta, status);
-  // publish: every wave's stores of delta have been performed, then one release + flag
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(&done[fi], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  bool bad, timed_out = false;
+  const double* y = ldsb_solve_core<true>(F, Ls, ns > 0 ? so : fo, delta, &bad, &timed_out);
+  if (tid < F.nf)  // published value by value: whoever needs it polls the value itself
+    __hip_atomic_store((unsigned long long*)(delta + fo), (unsigned long long)__double_as_longlong(y[tid]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (bad && lane == 0) atomicMin(status, F.id);  // NaN -> IndeterminantLinearSystemException (linearAlgorithms-inst.h:99)
+  if (timed_out) atomicExch(status + 1, 1 + F.id);  // never expected: spin bound hit (a fault, reported apart from pivot failures)
+  (void)s_ok;
+  (void)parent_of;
+  (void)pos_of;
+  (void)done;
   (void)lane;
 }
 

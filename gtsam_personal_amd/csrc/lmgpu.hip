@@ -236,6 +236,14 @@ struct lmgpu_handle {
   int chain_far_pct = 50;                      // LMGPU_CHAIN_FAR: tile rows beyond this percentage of the front are scheduled late (chain_schedule)
   double* d_lambda = nullptr;   // damping parameter of the solve being queued (device memory: see do_solve_enqueue)
   bool merge_backsub = false;   // LDS fronts of consecutive levels in one dataflow launch (deep trees; LMGPU_MERGE_BACKSUB=0/1)
+  // the same on the way up: runs of consecutive levels without dense fronts in between whose LDS fronts go as ONE launch
+  // (lds_front_merged_kernel); elim_seg_of[level] = index into elim_segs when the level starts a segment, -2 when it lies inside one
+  struct ElimSeg {
+    int lvl_lo, lvl_hi, nmax, jcap, threads;
+  };
+  std::vector<ElimSeg> elim_segs;
+  std::vector<int> elim_seg_of;
+  bool merge_elim = false;
   int32_t *d_bs_parent = nullptr, *d_bs_pos = nullptr;  // per front: parent front if it is an LDS front (else -1); position in d_lists (-1: HBM)
   char* d_leafpack = nullptr;                           // packed descriptors of the LDS fronts (kernels_front.hpp, LEAFPACK_*)
   unsigned int* d_bs_done = nullptr;                    // per front flag + one ticket counter per level
@@ -608,8 +616,32 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
   // (Running a level's LDS fronts on a second stream beside its dense fronts -- they only depend on the levels below -- was measured
   //  with the replayed graph: 4.9 vs 2.5 ms per LM iteration on sphere2500; every cross-stream edge of the graph costs more than the
   //  45 us of LDS-front latency it hides.  Not kept.)
-  for (const LevelWork& L : h->levels) {
-    for (int b = 0; b < kNumBins; b++) {
+  const bool merge_el = h->merge_elim && !h->elim_segs.empty();
+  if (merge_el)  // flags of the merged launches + one ticket counter per level (shared with the back-substitution, which clears them again)
+    HIPCHECK(hipMemsetAsync(h->d_bs_done, 0, (size_t)(h->h_fronts.size() + h->levels.size() + 1) * sizeof(unsigned int), s));
+  for (size_t li = 0; li < h->levels.size(); li++) {
+    const LevelWork& L = h->levels[li];
+    const int seg = merge_el ? h->elim_seg_of[li] : -1;
+    if (seg >= 0) {
+      const lmgpu_handle::ElimSeg& E = h->elim_segs[seg];
+      const int b0 = h->levels[E.lvl_lo].list_begin, e0 = h->levels[E.lvl_hi].list_begin + h->levels[E.lvl_hi].list_count;
+      const size_t lds = kLdsFrontExtra - (size_t)(LDSF_JCAP - E.jcap) * 8 + 64 + (size_t)E.nmax * E.nmax * sizeof(double);
+      const int kt = h->kt.begin(LMGPU_KT_LDS_FRONT, s);
+      unsigned int* done = h->d_bs_done;
+      unsigned int* ticket = h->d_bs_done + h->h_fronts.size() + E.lvl_hi;
+      if (E.threads == 1024)
+        hipLaunchKernelGGL(lds_front_merged_kernel<1024>, dim3(e0 - b0), dim3(1024), lds, s, (const int32_t*)h->d_lists, b0, e0, (const FrontDesc*)h->d_fronts,
+                           (const FrontFac*)h->d_ffac, (const FacDesc*)h->d_fd, (const ChildRef*)h->d_childs, (const int32_t*)h->d_cmap,
+                           (const int32_t*)h->d_fxoff, h->pool, lambda_v, lambda_p, (const double*)h->dampw, h->d_status, E.nmax, E.jcap,
+                           (const double*)h->gex_active, (const int32_t*)h->d_bs_pos, done, ticket);
+      else
+        hipLaunchKernelGGL(lds_front_merged_kernel<256>, dim3(e0 - b0), dim3(E.threads), lds, s, (const int32_t*)h->d_lists, b0, e0, (const FrontDesc*)h->d_fronts,
+                           (const FrontFac*)h->d_ffac, (const FacDesc*)h->d_fd, (const ChildRef*)h->d_childs, (const int32_t*)h->d_cmap,
+                           (const int32_t*)h->d_fxoff, h->pool, lambda_v, lambda_p, (const double*)h->dampw, h->d_status, E.nmax, E.jcap,
+                           (const double*)h->gex_active, (const int32_t*)h->d_bs_pos, done, ticket);
+      h->kt.end(kt, s);
+    }
+    for (int b = 0; b < kNumBins && seg == -1; b++) {
       const int cnt = L.bin_begin[b + 1] - L.bin_begin[b];
       if (cnt == 0) continue;
       const int nmax = kBinN[b % 6], srows = L.bin_srows[b];
@@ -944,7 +976,10 @@ int do_backsub(lmgpu_handle* h) {
   // deep trees: the LDS fronts of consecutive levels without HBM fronts in between go as ONE dataflow launch
   const bool merge = h->merge_backsub && h->cfg.world_size == 1 && !(h->cfg.flags & LMGPU_FLAG_SPLIT_ROOT);
   const int NFR = (int)h->h_fronts.size();
-  if (merge) HIPCHECK(hipMemsetAsync(h->d_bs_done, 0, (size_t)(NFR + h->levels.size() + 1) * sizeof(unsigned int), s));
+  if (merge) {
+    HIPCHECK(hipMemsetAsync(h->d_bs_done, 0, (size_t)(NFR + h->levels.size() + 1) * sizeof(unsigned int), s));  // (the ticket counters)
+    HIPCHECK(hipMemsetAsync(h->delta, 0xff, h->ntot * sizeof(double), s));  // "not published yet": merged launches hand x over through delta itself
+  }
   if (h->bsd_x_count > 0) {
     HIPCHECK(hipMemsetAsync(h->d_bsd_x, 0xff, h->bsd_x_count * sizeof(double), s));  // "not published yet"
     HIPCHECK(hipMemsetAsync(h->d_bsd_ticket, 0, h->levels.size() * sizeof(unsigned int), s));
@@ -1625,6 +1660,8 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
     HIPCHECK(hipFuncSetAttribute((const void*)lds_front_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra + 64));
     HIPCHECK(hipFuncSetAttribute((const void*)lds_front_kernel<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra + 64));
     HIPCHECK(hipFuncSetAttribute((const void*)lds_front_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra + 64));
+    HIPCHECK(hipFuncSetAttribute((const void*)lds_front_merged_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra + 64));
+    HIPCHECK(hipFuncSetAttribute((const void*)lds_front_merged_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra + 64));
     HIPCHECK(hipFuncSetAttribute((const void*)syrk_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSyrkLds));
     HIPCHECK(hipFuncSetAttribute((const void*)lds_backsub_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (kLdsLimitN * kLdsLimitN + LDSB_TAIL) * 8));
     HIPCHECK(hipFuncSetAttribute((const void*)lds_backsub_merged_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (kLdsLimitN * kLdsLimitN + LDSB_TAIL) * 8));
@@ -1983,6 +2020,7 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
       cr.ld = CF.ld_u;
       cr.m = ch.n - ch.nf;
       cr.map_begin = map_begin;
+      cr.pad = c + 1;  // the child front (merged launches wait for children of their own launch)
       childs.push_back(cr);
     }
     F.child_count = (int)childs.size() - F.child_begin;
@@ -2145,6 +2183,52 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
     L.bin_begin[kNumBins] = c;
     L.list_count = c;
   }
+  // ---- merged elimination launches: runs of consecutive levels, each a handful of LDS fronts, with no dense front between them (only
+  //      the top level of a run may hold dense fronts: they are launched after it and nothing in the run depends on them)
+  {
+    h->elim_segs.clear();
+    h->elim_seg_of.assign(P.n_levels, -1);
+    const int kMergeCap = 160;  // fronts per level: a merged launch sizes its LDS for its largest front, wider levels keep their per-bin launches
+    auto level_class = [&](int l, int* nmax, int* jcap, int* threads) {
+      const LevelWork& L = h->levels[l];
+      if (L.list_count == 0 || L.list_count > kMergeCap || L.bin_begin[kNumBins] != L.bin_begin[6]) return false;  // (no gather leaves)
+      int top = -1, jc = 96, cnt_top = 0;
+      for (int b = 0; b < 6; b++)
+        if (L.bin_begin[b + 1] > L.bin_begin[b]) {
+          top = b;
+          cnt_top = L.bin_begin[b + 1] - L.bin_begin[b];
+          jc = std::max(jc, L.bin_jcap[b]);
+        }
+      *nmax = kBinN[top];
+      *jcap = jc;
+      const bool wide16 = top >= 3 && cnt_top <= 64 && !h->no_wide16;
+      *threads = wide16 ? 1024 : (top == 0 ? 64 : (top == 1 ? 128 : 256));
+      return true;
+    };
+    int l = 0;
+    while (l < P.n_levels) {
+      int nmax, jcap, threads;
+      if (!level_class(l, &nmax, &jcap, &threads)) {
+        l++;
+        continue;
+      }
+      lmgpu_handle::ElimSeg E{l, l, nmax, jcap, threads};
+      while (E.lvl_hi + 1 < P.n_levels && h->levels[E.lvl_hi].hbm.empty()) {
+        int n2, j2, t2;
+        if (!level_class(E.lvl_hi + 1, &n2, &j2, &t2) || (t2 == 1024) != (E.threads == 1024)) break;
+        E.lvl_hi++;
+        E.nmax = std::max(E.nmax, n2);
+        E.jcap = std::max(E.jcap, j2);
+        E.threads = std::max(E.threads, t2);
+      }
+      if (E.lvl_hi > E.lvl_lo) {
+        h->elim_seg_of[E.lvl_lo] = (int)h->elim_segs.size();
+        for (int q = E.lvl_lo + 1; q <= E.lvl_hi; q++) h->elim_seg_of[q] = -2;
+        h->elim_segs.push_back(E);
+      }
+      l = E.lvl_hi + 1;
+    }
+  }
   h->finalized = true;
   if (h->device < 0) return LMGPU_OK;  // structure-only handle: symbolic analysis available, no compute
 
@@ -2154,6 +2238,8 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
   h->use_graph = (int)h->levels.size() >= 12;
   h->merge_backsub = (int)h->levels.size() >= 12;
   if (const char* e = dev_switch("LMGPU_MERGE_BACKSUB")) h->merge_backsub = atoi(e) != 0;
+  h->merge_elim = (int)h->levels.size() >= 12 && h->cfg.world_size == 1;
+  if (const char* e = dev_switch("LMGPU_MERGE_ELIM")) h->merge_elim = atoi(e) != 0 && h->cfg.world_size == 1;
   if (const char* e = getenv("LMGPU_GRAPH")) h->use_graph = atoi(e) != 0;
   // ---- device upload
   HIPCHECK(hipSetDevice(h->device));

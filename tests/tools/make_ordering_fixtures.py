@@ -15,7 +15,7 @@ import oracle_harness as oh  # noqa: E402
 from bench import slam_workload  # noqa: E402
 
 out = {}
-for name in ("sphere2500", "city10000"):
+for name in ("sphere2500", "city10000", "victoria_park"):
     graph, initial = slam_workload(name)
     keys = np.array(sorted(graph.keys()), dtype=np.uint64)
     for oname, fn in (("colamd", oh.colamd), ("metis", oh.metis)):

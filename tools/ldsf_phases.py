@@ -20,7 +20,7 @@ _lib.LIB_PATH = DBG
 import bench
 from gtsam_personal_amd import LevenbergMarquardtOptimizer, LevenbergMarquardtParams
 
-wl = sys.argv[1] if len(sys.argv) > 1 else "city10000"
+wl = sys.argv[1] if len(sys.argv) > 1 else "city10000"  # or sphere2500, victoria_park
 on = sys.argv[2] if len(sys.argv) > 2 else "colamd"
 graph, initial = bench.slam_workload(wl)
 fx = np.load(os.path.join(ROOT, "tests", "golden", "slam_orderings.npz"))
@@ -39,8 +39,9 @@ for it in range(3):
     dbg(out, 1)
     opt.iterate()
     dbg(out, 0)
-names = ["descriptors + clear + own factors", "extend-add of the children", "damping", "partial Cholesky", "emit [R S d] + update matrix"]
+names = ["descriptors + clear + own factors", "extend-add of the children", "damping", "partial Cholesky", "emit [R S d] + update matrix",
+         "(merged launches) wait for the children", "(merged launches) publish"]
 n = out[15]
-print(f"{wl}/{on}: {n} launches of <= 8 fronts in one LM iteration (inner iterations: {opt.timings()['inner_iterations']})")
+print(f"{wl}/{on}: {n} sampled workgroups (launches of <= 8 fronts; the top quarter of merged launches) in one LM iteration (inner iterations: {opt.timings()['inner_iterations']})")
 for i, nm in enumerate(names):
     print(f"  {nm:36s} {out[i] * 0.01:9.1f} us total   {out[i] * 0.01 / max(n, 1):6.2f} us per launch")
