@@ -323,7 +323,7 @@ __device__ __forceinline__ void lds_front_body(const int work, const int32_t* __
   //      trip of its own (25-35 of them per child of ~100 columns: most of the 27-60 us an upper-level front took).  The loads are
   //      unconditional on clamped addresses (the lower triangle and the padding of U are finite: the pool is cleared once).
   if constexpr (!GATHER) {  // (gather leaves have no children; keeping the block out of that instantiation keeps its 41 VGPRs)
-    constexpr int EAB = (MAXT > 256) ? 8 : 4;  // rows per wave in flight (eight cost the four-wave form occupancy on leaf levels)
+    constexpr int EAB = (MAXT > 256 || DATAFLOW) ? 8 : 4;  // rows per wave in flight (eight cost the four-wave form occupancy on leaf levels; a merged launch holds upper levels only)
     int* cm = (int*)Jb;  // jcap >= 96 doubles: room for 139 ints (a child's update matrix is at most as wide as this front)
     for (int k = 0; k < F.child_count; k++) {
       const ChildRef c = k == 0 ? pc0 : (k == 1 ? pc1 : childs[F.child_begin + k]);
@@ -772,7 +772,7 @@ __device__ __forceinline__ double* ldsb_solve_core(const FrontDesc& F, double* L
       const int il = r0 + min(lane, nb - 1);
       const double rd = (lane < nb) ? 1.0 / Ls[il * nl + il] : 1.0;
       double yi = (lane < nb) ? y[il] * rd : 0.0;
-      for (int k0 = 63; k0 >= 0; k0 -= 8) {
+      for (int k0 = (nb - 1) | 7; k0 >= 0; k0 -= 8) {  // (columns k >= nb carry zero coefficients: a 3-row front takes one group of eight, not eight)
         double cf[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
