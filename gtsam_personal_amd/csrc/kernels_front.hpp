@@ -113,13 +113,10 @@ __device__ unsigned long long ldsf_dbg[16];
 #else
 #define LDSF_STAMP(i) do { } while (0)
 #endif
-// DATAFLOW (lds_front_merged_kernel below): the fronts of several consecutive tree levels in one launch; a front waits for those of its
-// children that belong to the same launch (their flags in `done`) between its own factors and the extend-add, and raises its own flag
-// when [R S d] and its update matrix are in memory.
+// DATAFLOW (lds_front_merged_kernel below): the fronts of several consecutive tree levels in one launch; a front's extend-add polls the
+// values of its children's update matrices (see there).
 struct FrontFlow {
-  const int32_t* pos_of;  // per front: position in the level lists
-  unsigned int* done;     // per front: 1 once its outputs are visible
-  int seg_begin, seg_end; // positions of this launch's fronts
+  int seg_begin, seg_end;  // positions of this launch's fronts in the level lists
 };
 template <bool GATHER, int MAXT, bool DATAFLOW>
 __device__ __forceinline__ void lds_front_body(const int work, const int32_t* __restrict__ list, const FrontDesc* __restrict__ fronts,
@@ -294,30 +291,7 @@ __device__ __forceinline__ void lds_front_body(const int work, const int32_t* __
   }
   __syncthreads();
   LDSF_STAMP(0);  // descriptors, clear, own factors
-  if constexpr (DATAFLOW) {
-    // children of the same launch: their update matrices must be in memory (they hold lower tickets, so they are running or done)
-    __shared__ int s_flow_ok;
-    if (tid == 0) s_flow_ok = 1;
-    __syncthreads();
-    for (int k = tid; k < F.child_count; k += nt) {
-      const int cf = childs[F.child_begin + k].pad - 1;
-      if (cf < 0) continue;
-      const int pp = flow.pos_of[cf];
-      if (pp < flow.seg_begin || pp >= flow.seg_end) continue;
-      long spins = 0;
-      while (__hip_atomic_load(&flow.done[cf], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > 4000000L) {
-          s_flow_ok = 0;
-          break;
-        }
-      }
-    }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    if (!s_flow_ok && tid == 0) atomicExch(status + 1, 1 + F.id);  // never expected: spin bound hit (reported apart from pivot failures)
-    LDSF_STAMP(5);  // waiting for the children of the same launch
-  }
+  bool flow_timeout = false;
   // ---- children: extend-add of their update matrices (row i of U contiguous: lanes along j).  The child's column map is staged
   //      in LDS once and four (sixteen-wave form: eight) rows per wave are fetched before the first is added -- row by row, every row was a memory round
   //      trip of its own (25-35 of them per child of ~100 columns: most of the 27-60 us an upper-level front took).  The loads are
@@ -340,10 +314,38 @@ __device__ __forceinline__ void lds_front_body(const int work, const int32_t* __
       for (int q = 0; q < 3; q++) gjs[q] = cm[min(lane + 64 * q, c.m - 1)];
       for (int i0 = wave; i0 < c.m; i0 += EAB * nw) {
         double u[EAB][3];
+        if constexpr (DATAFLOW) {
+          // a child of the same launch publishes its update matrix VALUE BY VALUE (agent-scope stores over the all-ones pattern the host
+          // filled its upper triangle with): the load of an entry is the wait for it -- no flag, no write-back, no invalidate on the path
+          // from one tree level to the next.  (A child finished by an earlier launch simply has its values there.)
+          long spins = 0;
+          bool again;
+          do {
+            again = false;
 #pragma unroll
-        for (int r = 0; r < EAB; r++)
+            for (int r = 0; r < EAB; r++)
 #pragma unroll
-          for (int q = 0; q < 3; q++) u[r][q] = U[(size_t)min(i0 + r * nw, c.m - 1) * c.ld + min(lane + 64 * q, c.m - 1)];
+              for (int q = 0; q < 3; q++) {
+                const int i = i0 + r * nw, j = lane + 64 * q;
+                const unsigned long long bits = __hip_atomic_load((const unsigned long long*)(U + (size_t)min(i, c.m - 1) * c.ld + min(j, c.m - 1)),
+                                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                u[r][q] = __longlong_as_double((long long)bits);
+                if (bits == ~0ull && i < c.m && j >= i && j < c.m) again = true;
+              }
+            if (again) {
+              __builtin_amdgcn_s_sleep(1);
+              if (++spins > 2000000L) {
+                flow_timeout = true;
+                again = false;
+              }
+            }
+          } while (again);
+        } else {
+#pragma unroll
+          for (int r = 0; r < EAB; r++)
+#pragma unroll
+            for (int q = 0; q < 3; q++) u[r][q] = U[(size_t)min(i0 + r * nw, c.m - 1) * c.ld + min(lane + 64 * q, c.m - 1)];
+        }
 #pragma unroll
         for (int r = 0; r < EAB; r++) {
           const int i = i0 + r * nw;
@@ -364,6 +366,7 @@ __device__ __forceinline__ void lds_front_body(const int work, const int32_t* __
       __syncthreads();
     }
   }
+  if (DATAFLOW && flow_timeout) atomicExch(status + 1, 1 + F.id);  // never expected: spin bound hit (reported apart from pivot failures)
   LDSF_STAMP(1);  // extend-add of the children
   // ---- damping on the frontal diagonal
   // lambda_p != nullptr: the value lives in device memory so that a captured launch sequence can be replayed with a new one
@@ -528,22 +531,30 @@ __device__ __forceinline__ void lds_front_body(const int work, const int32_t* __
   } else {
     double* U = pool + F.u_off;
     for (int i = wave; i < m; i += nw)
-      for (int j = i + lane; j < m; j += 64) U[(size_t)i * F.ld_u + j] = S[(nf + i) * n + nf + j];
+      for (int j = i + lane; j < m; j += 64) {
+        if constexpr (DATAFLOW)
+          __hip_atomic_store((unsigned long long*)(U + (size_t)i * F.ld_u + j), (unsigned long long)__double_as_longlong(S[(nf + i) * n + nf + j]),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else
+          U[(size_t)i * F.ld_u + j] = S[(nf + i) * n + nf + j];
+      }
   }
 #ifdef LDSF_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   LDSF_STAMP(4);  // [R S d] and the update matrix written
 #endif
-  if constexpr (DATAFLOW) {  // publish: every wave's stores have been performed, then one release + flag
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(&flow.done[F.id], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    LDSF_STAMP(6);  // publish
-  }
+}
+
+// "not published yet" over the upper triangles of the update matrices of the fronts of the merged launches: grid = entries of `list`
+struct FillUpper {
+  int64_t u_off;
+  int32_t m, ld;
+};
+__global__ __launch_bounds__(256) void fill_upper_kernel(const FillUpper* __restrict__ list, double* __restrict__ pool) {
+  const FillUpper f = list[blockIdx.x];
+  unsigned long long* U = (unsigned long long*)(pool + f.u_off);
+  for (int i = threadIdx.x >> 6; i < f.m; i += 4)
+    for (int j = i + (threadIdx.x & 63); j < f.m; j += 64) U[(size_t)i * f.ld + j] = ~0ull;
 }
 
 template <bool GATHER, int MAXT = 256>
@@ -561,20 +572,20 @@ __global__ __launch_bounds__(MAXT) void lds_front_kernel(const int32_t* __restri
 // The LDS fronts of SEVERAL consecutive tree levels in one launch, bottom-up (deep clique trees: an upper level is a handful of fronts, a
 // launch of ~15-25 us of which most is latency -- descriptor chains, Jacobian staging -- that does not depend on the children at all).
 // list[seg_begin, seg_end) holds the levels bottom-up; ticket t takes list[seg_begin + t], so children hold lower tickets than their
-// parents: whatever a workgroup waits for has been started before it (no residency assumption).  FrontDesc::id must be the front's index.
+// parents: whatever a workgroup waits for has been started before it (no residency assumption).  The host fills the upper triangles of the
+// update matrices of the launch's fronts with the all-ones pattern first (fill_upper_kernel).
 template <int MAXT>
 __global__ __launch_bounds__(MAXT) void lds_front_merged_kernel(const int32_t* __restrict__ list, int seg_begin, int seg_end, const FrontDesc* __restrict__ fronts,
                                                                 const FrontFac* __restrict__ ffac, const FacDesc* __restrict__ fd,
                                                                 const ChildRef* __restrict__ childs, const int32_t* __restrict__ cmap,
                                                                 const int32_t* __restrict__ fxoff, double* __restrict__ pool, double lambda_v,
                                                                 const double* __restrict__ lambda_p, const double* __restrict__ dampw, int* __restrict__ status,
-                                                                int nmax, int jcap, const double* __restrict__ gex, const int32_t* __restrict__ pos_of,
-                                                                unsigned int* __restrict__ done, unsigned int* __restrict__ ticket) {
+                                                                int nmax, int jcap, const double* __restrict__ gex, unsigned int* __restrict__ ticket) {
   __shared__ int s_ticket;
   if (threadIdx.x == 0) s_ticket = (int)atomicAdd(ticket, 1u);
   __syncthreads();
   lds_front_body<false, MAXT, true>(seg_begin + s_ticket, list, fronts, ffac, fd, childs, cmap, fxoff, pool, lambda_v, lambda_p, dampw, status, nmax, nmax,
-                                    (double*)nullptr, jcap, gex, (const char*)nullptr, 0, FrontFlow{pos_of, done, seg_begin, seg_end});
+                                    (double*)nullptr, jcap, gex, (const char*)nullptr, 0, FrontFlow{seg_begin, seg_end});
 }
 
 // back-substitution for LDS-class fronts with at most LDSB_SMALL_NF frontal scalars (leaves and the levels just above them: the host

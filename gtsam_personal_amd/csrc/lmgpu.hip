@@ -244,6 +244,8 @@ struct lmgpu_handle {
   std::vector<ElimSeg> elim_segs;
   std::vector<int> elim_seg_of;
   bool merge_elim = false;
+  FillUpper* d_fill_upper = nullptr;  // the update matrices of the merged launches' fronts (fill_upper_kernel)
+  int n_fill_upper = 0;
   int32_t *d_bs_parent = nullptr, *d_bs_pos = nullptr;  // per front: parent front if it is an LDS front (else -1); position in d_lists (-1: HBM)
   char* d_leafpack = nullptr;                           // packed descriptors of the LDS fronts (kernels_front.hpp, LEAFPACK_*)
   unsigned int* d_bs_done = nullptr;                    // per front flag + one ticket counter per level
@@ -617,8 +619,10 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
   //  with the replayed graph: 4.9 vs 2.5 ms per LM iteration on sphere2500; every cross-stream edge of the graph costs more than the
   //  45 us of LDS-front latency it hides.  Not kept.)
   const bool merge_el = h->merge_elim && !h->elim_segs.empty();
-  if (merge_el)  // flags of the merged launches + one ticket counter per level (shared with the back-substitution, which clears them again)
+  if (merge_el) {  // one ticket counter per level (shared with the back-substitution, which clears them again); "not published yet" over the update matrices
     HIPCHECK(hipMemsetAsync(h->d_bs_done, 0, (size_t)(h->h_fronts.size() + h->levels.size() + 1) * sizeof(unsigned int), s));
+    hipLaunchKernelGGL(fill_upper_kernel, dim3(h->n_fill_upper), dim3(256), 0, s, (const FillUpper*)h->d_fill_upper, h->pool);
+  }
   for (size_t li = 0; li < h->levels.size(); li++) {
     const LevelWork& L = h->levels[li];
     const int seg = merge_el ? h->elim_seg_of[li] : -1;
@@ -627,18 +631,17 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
       const int b0 = h->levels[E.lvl_lo].list_begin, e0 = h->levels[E.lvl_hi].list_begin + h->levels[E.lvl_hi].list_count;
       const size_t lds = kLdsFrontExtra - (size_t)(LDSF_JCAP - E.jcap) * 8 + 64 + (size_t)E.nmax * E.nmax * sizeof(double);
       const int kt = h->kt.begin(LMGPU_KT_LDS_FRONT, s);
-      unsigned int* done = h->d_bs_done;
       unsigned int* ticket = h->d_bs_done + h->h_fronts.size() + E.lvl_hi;
       if (E.threads == 1024)
         hipLaunchKernelGGL(lds_front_merged_kernel<1024>, dim3(e0 - b0), dim3(1024), lds, s, (const int32_t*)h->d_lists, b0, e0, (const FrontDesc*)h->d_fronts,
                            (const FrontFac*)h->d_ffac, (const FacDesc*)h->d_fd, (const ChildRef*)h->d_childs, (const int32_t*)h->d_cmap,
                            (const int32_t*)h->d_fxoff, h->pool, lambda_v, lambda_p, (const double*)h->dampw, h->d_status, E.nmax, E.jcap,
-                           (const double*)h->gex_active, (const int32_t*)h->d_bs_pos, done, ticket);
+                           (const double*)h->gex_active, ticket);
       else
         hipLaunchKernelGGL(lds_front_merged_kernel<256>, dim3(e0 - b0), dim3(E.threads), lds, s, (const int32_t*)h->d_lists, b0, e0, (const FrontDesc*)h->d_fronts,
                            (const FrontFac*)h->d_ffac, (const FacDesc*)h->d_fd, (const ChildRef*)h->d_childs, (const int32_t*)h->d_cmap,
                            (const int32_t*)h->d_fxoff, h->pool, lambda_v, lambda_p, (const double*)h->dampw, h->d_status, E.nmax, E.jcap,
-                           (const double*)h->gex_active, (const int32_t*)h->d_bs_pos, done, ticket);
+                           (const double*)h->gex_active, ticket);
       h->kt.end(kt, s);
     }
     for (int b = 0; b < kNumBins && seg == -1; b++) {
@@ -1701,7 +1704,7 @@ int lmgpu_destroy(lmgpu_handle* h) {
     for (int i = 0; i < 8; i++)
       if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     for (hipEvent_t e : h->kt.pool) (void)hipEventDestroy(e);
-    fr(h->bs_inv); fr(h->bs_x); fr(h->bs_flags); fr(h->inv16); fr(h->d_pflags); fr(h->d_bs_parent); fr(h->d_bs_pos); fr(h->d_bs_done); fr(h->d_bsd_table); fr(h->d_zero_ranges); fr(h->d_bsd_x); fr(h->d_bsd_ticket); fr(h->d_leafpack); fr(h->d_gzero);
+    fr(h->bs_inv); fr(h->bs_x); fr(h->bs_flags); fr(h->inv16); fr(h->d_pflags); fr(h->d_bs_parent); fr(h->d_bs_pos); fr(h->d_bs_done); fr(h->d_fill_upper); fr(h->d_bsd_table); fr(h->d_zero_ranges); fr(h->d_bsd_x); fr(h->d_bsd_ticket); fr(h->d_leafpack); fr(h->d_gzero);
     for (auto& kv : h->chain_plans)
       for (auto& cp : kv.second) fr(cp.d_tasks);
     fr(h->d_gpblk); fr(h->d_gpent); fr(h->d_gvblk); fr(h->d_gvent); fr(h->d_gcorner); fr(h->d_row_begin); fr(h->d_rowptr); fr(h->d_rowsrc);
@@ -2240,6 +2243,7 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
   if (const char* e = dev_switch("LMGPU_MERGE_BACKSUB")) h->merge_backsub = atoi(e) != 0;
   h->merge_elim = (int)h->levels.size() >= 12 && h->cfg.world_size == 1;
   if (const char* e = dev_switch("LMGPU_MERGE_ELIM")) h->merge_elim = atoi(e) != 0 && h->cfg.world_size == 1;
+  if (h->elim_segs.empty()) h->merge_elim = false;
   if (const char* e = getenv("LMGPU_GRAPH")) h->use_graph = atoi(e) != 0;
   // ---- device upload
   HIPCHECK(hipSetDevice(h->device));
@@ -2323,6 +2327,16 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
     HIPCHECK(hipMalloc((void**)&h->d_bs_done, (size_t)(NF + h->levels.size() + 1) * sizeof(unsigned int)));
   }
   h->n_lds_fronts = (int)lists.size();
+  if (h->merge_elim) {
+    std::vector<FillUpper> fu;
+    for (const lmgpu_handle::ElimSeg& E : h->elim_segs)
+      for (int q = h->levels[E.lvl_lo].list_begin; q < h->levels[E.lvl_hi].list_begin + h->levels[E.lvl_hi].list_count; q++) {
+        const FrontDesc& F = h->h_fronts[lists[q]];
+        fu.push_back(FillUpper{F.u_off, F.n - F.nf, F.ld_u});
+      }
+    h->n_fill_upper = (int)fu.size();
+    if ((rc = upload(h, &h->d_fill_upper, fu))) return rc;
+  }
   {
     std::vector<int32_t> small;
     for (LevelWork& L : h->levels) {
