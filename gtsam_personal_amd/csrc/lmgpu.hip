@@ -32,6 +32,7 @@
 #include "kernels_potrf.hpp"
 #include "kernels_step.hpp"
 #include "kernels_batched.hpp"
+#include "kernels_level.hpp"
 #include "kernels_bayes.hpp"
 #include "kernels_schur.hpp"
 #include "plan.hpp"
@@ -102,6 +103,8 @@ struct LevelWork {
   int bsd_begin = 0, bsd_count = 0;      // their 64-row blocks in d_bsd_table (hbm_backsolve_blocks_kernel: one workgroup per block)
   // "medium" HBM fronts (one outer panel, no gather leaves, not replicated): eliminated with batched launches (kernels_batched.hpp)
   int med_begin = 0, med_count = 0, med_max_fac = 0, med_max_child = 0, med_max_nf = 0, med_max_cols = 0, med_max_n = 0;
+  // LDS fronts + medium fronts of the level as ONE launch (level_fused_kernel): its slice of d_level_tasks, the LDS size class of the launch
+  int fuse_task_begin = 0, fuse_task_count = 0, fuse_nmax = 0, fuse_jcap = 0, fuse_threads = 0;
 };
 
 struct KTimer {
@@ -246,6 +249,10 @@ struct lmgpu_handle {
   bool merge_elim = false;
   FillUpper* d_fill_upper = nullptr;  // the update matrices of the merged launches' fronts (fill_upper_kernel)
   int n_fill_upper = 0;
+  bool fuse_levels = false;            // levels with LDS fronts and medium fronts: one launch for both (LMGPU_FUSE_LEVELS=0/1)
+  LevelTask* d_level_tasks = nullptr;
+  LevelSync* d_level_sync = nullptr;   // one record per medium front (all levels)
+  int n_level_sync = 0;
   int32_t *d_bs_parent = nullptr, *d_bs_pos = nullptr;  // per front: parent front if it is an LDS front (else -1); position in d_lists (-1: HBM)
   char* d_leafpack = nullptr;                           // packed descriptors of the LDS fronts (kernels_front.hpp, LEAFPACK_*)
   unsigned int* d_bs_done = nullptr;                    // per front flag + one ticket counter per level
@@ -253,6 +260,7 @@ struct lmgpu_handle {
   int eager_solves = 0;
   hipGraphExec_t solve_graph[2] = {nullptr, nullptr};  // [1]: with the extra gradient vector of the marginal solves
   bool no_wide16 = false;                      // LMGPU_NO_WIDE16=1: LDS fronts always with four waves (A/B)
+  int wide16_max = 256;                        // launches of at most this many wide LDS fronts take sixteen waves per front (LMGPU_WIDE16_MAX)
   bool bsd_ticket = false;                     // LMGPU_BSD_TICKET=1: the block back-substitution always draws tickets (tests: the path of levels with more blocks than CUs)
   bool no_tail = false;                        // LMGPU_NO_TAIL=1: the end of a front as separate update / panel launches (A/B)
   bool no_chain = false;                       // LMGPU_NO_CHAIN=1: one launch per fused step instead of one per run of steps (A/B)
@@ -619,10 +627,11 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
   //  with the replayed graph: 4.9 vs 2.5 ms per LM iteration on sphere2500; every cross-stream edge of the graph costs more than the
   //  45 us of LDS-front latency it hides.  Not kept.)
   const bool merge_el = h->merge_elim && !h->elim_segs.empty();
-  if (merge_el) {  // one ticket counter per level (shared with the back-substitution, which clears them again); "not published yet" over the update matrices
+  if (merge_el || h->fuse_levels)  // one ticket counter per level (shared with the back-substitution, which clears them again)
     HIPCHECK(hipMemsetAsync(h->d_bs_done, 0, (size_t)(h->h_fronts.size() + h->levels.size() + 1) * sizeof(unsigned int), s));
+  if (merge_el)  // "not published yet" over the update matrices of the merged launches' fronts
     hipLaunchKernelGGL(fill_upper_kernel, dim3(h->n_fill_upper), dim3(256), 0, s, (const FillUpper*)h->d_fill_upper, h->pool);
-  }
+  if (h->fuse_levels) HIPCHECK(hipMemsetAsync(h->d_level_sync, 0, (size_t)h->n_level_sync * sizeof(LevelSync), s));
   for (size_t li = 0; li < h->levels.size(); li++) {
     const LevelWork& L = h->levels[li];
     const int seg = merge_el ? h->elim_seg_of[li] : -1;
@@ -644,7 +653,28 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
                            (const double*)h->gex_active, ticket);
       h->kt.end(kt, s);
     }
-    for (int b = 0; b < kNumBins && seg == -1; b++) {
+    const bool fused = h->fuse_levels && L.fuse_task_count > 0;
+    if (fused) {  // the level's LDS fronts and medium fronts in one grid
+      const MedLevel ML{(const MedFront*)(h->d_med_fronts + L.med_begin)};
+      const size_t lds = std::max<size_t>(kLdsFrontExtra - (size_t)(LDSF_JCAP - L.fuse_jcap) * 8 + 64 + (size_t)L.fuse_nmax * L.fuse_nmax * sizeof(double),
+                                          (size_t)DIAG_LDS_BYTES);
+      unsigned int* ticket = h->d_bs_done + h->h_fronts.size() + li;
+      const int kt = h->kt.begin(LMGPU_KT_PANEL, s);
+      if (L.fuse_threads == 1024)
+        hipLaunchKernelGGL(level_fused_kernel<1024>, dim3(L.fuse_task_count), dim3(1024), lds, s, (const LevelTask*)(h->d_level_tasks + L.fuse_task_begin), ticket,
+                           (const int32_t*)h->d_lists, (const FrontDesc*)h->d_fronts, (const FrontFac*)h->d_ffac, (const FacDesc*)h->d_fd,
+                           (const ChildRef*)h->d_childs, (const int32_t*)h->d_cmap, (const int32_t*)h->d_fxoff, h->pool, lambda_v, lambda_p,
+                           (const double*)h->dampw, h->d_status, L.fuse_nmax, L.fuse_jcap, (const double*)h->gex_active, ML, (const int32_t*)h->d_rowptr,
+                           (const RowSrc*)h->d_rowsrc, h->inv16_med, h->d_level_sync + L.med_begin);
+      else
+        hipLaunchKernelGGL(level_fused_kernel<256>, dim3(L.fuse_task_count), dim3(256), lds, s, (const LevelTask*)(h->d_level_tasks + L.fuse_task_begin), ticket,
+                           (const int32_t*)h->d_lists, (const FrontDesc*)h->d_fronts, (const FrontFac*)h->d_ffac, (const FacDesc*)h->d_fd,
+                           (const ChildRef*)h->d_childs, (const int32_t*)h->d_cmap, (const int32_t*)h->d_fxoff, h->pool, lambda_v, lambda_p,
+                           (const double*)h->dampw, h->d_status, L.fuse_nmax, L.fuse_jcap, (const double*)h->gex_active, ML, (const int32_t*)h->d_rowptr,
+                           (const RowSrc*)h->d_rowsrc, h->inv16_med, h->d_level_sync + L.med_begin);
+      h->kt.end(kt, s);
+    }
+    for (int b = 0; b < kNumBins && seg == -1 && !fused; b++) {
       const int cnt = L.bin_begin[b + 1] - L.bin_begin[b];
       if (cnt == 0) continue;
       const int nmax = kBinN[b % 6], srows = L.bin_srows[b];
@@ -655,7 +685,7 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
       const int kt = h->kt.begin(LMGPU_KT_LDS_FRONT, s);
       // a handful of wide fronts (the upper levels of a general sparse tree, where a launch lasts as long as its slowest front and the
       // device is idle): sixteen waves per front -- the rank-4 trailing updates, the extend-add and the emission all scale with them
-      const bool wide16 = b >= 3 && b < 6 && cnt <= 64 && !h->no_wide16;
+      const bool wide16 = b >= 3 && b < 6 && cnt <= h->wide16_max && !h->no_wide16;
       if (wide16)
         hipLaunchKernelGGL((lds_front_kernel<false, 1024>), dim3(cnt), dim3(1024), lds, s,
                            (const int32_t*)(h->d_lists + L.list_begin + L.bin_begin[b]), (const FrontDesc*)h->d_fronts,
@@ -679,7 +709,7 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
                            L.pack_stride[b]);
       h->kt.end(kt, s);
     }
-    if (L.med_count > 0) {  // medium fronts of this level: six launches for all of them
+    if (L.med_count > 0 && !fused) {  // medium fronts of this level: six launches for all of them
       const MedLevel ML{(const MedFront*)(h->d_med_fronts + L.med_begin)};
       const unsigned cnt = (unsigned)L.med_count;
       int ktm = h->kt.begin(LMGPU_KT_HBM_ASSEMBLE, s);
@@ -970,6 +1000,26 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
   }
   HIPCHECK(hipGetLastError());
   return LMGPU_OK;
+}
+
+// the LDS fronts of level l as one launch sized for the level's largest front (merged and fused launches): false when the level has none, too
+// many of them (a launch sized for the largest front would cost the small ones their occupancy), or gather leaves
+static bool level_lds_class(const lmgpu_handle* h, int l, int* nmax, int* jcap, int* threads) {
+  const int kMergeCap = 160;
+  const LevelWork& L = h->levels[l];
+  if (L.list_count == 0 || L.list_count > kMergeCap || L.bin_begin[kNumBins] != L.bin_begin[6]) return false;
+  int top = -1, jc = 96, cnt_top = 0;
+  for (int b = 0; b < 6; b++)
+    if (L.bin_begin[b + 1] > L.bin_begin[b]) {
+      top = b;
+      cnt_top = L.bin_begin[b + 1] - L.bin_begin[b];
+      jc = std::max(jc, L.bin_jcap[b]);
+    }
+  *nmax = kBinN[top];
+  *jcap = jc;
+  const bool wide16 = top >= 3 && cnt_top <= h->wide16_max && !h->no_wide16;
+  *threads = wide16 ? 1024 : (top == 0 ? 64 : (top == 1 ? 128 : 256));
+  return true;
 }
 
 // ---- back-substitution, top-down (a14)
@@ -1634,6 +1684,7 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
   h->no_chain = dev_switch("LMGPU_NO_CHAIN") != nullptr;
   h->no_tail = dev_switch("LMGPU_NO_TAIL") != nullptr;
   h->no_wide16 = dev_switch("LMGPU_NO_WIDE16") != nullptr;
+  if (const char* e = dev_switch("LMGPU_WIDE16_MAX")) h->wide16_max = atoi(e);
   h->bsd_ticket = dev_switch("LMGPU_BSD_TICKET") != nullptr;
   h->no_gather_write = dev_switch("LMGPU_NO_GATHER_WRITE") != nullptr;
   if (dev_switch("LMGPU_NO_MERGE")) h->chain_merge = false;
@@ -1665,6 +1716,8 @@ int lmgpu_create(const lmgpu_config* cfg, lmgpu_handle** out) {
     HIPCHECK(hipFuncSetAttribute((const void*)lds_front_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra + 64));
     HIPCHECK(hipFuncSetAttribute((const void*)lds_front_merged_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra + 64));
     HIPCHECK(hipFuncSetAttribute((const void*)lds_front_merged_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra + 64));
+    HIPCHECK(hipFuncSetAttribute((const void*)level_fused_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra + 64));
+    HIPCHECK(hipFuncSetAttribute((const void*)level_fused_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra + 64));
     HIPCHECK(hipFuncSetAttribute((const void*)syrk_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSyrkLds));
     HIPCHECK(hipFuncSetAttribute((const void*)lds_backsub_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (kLdsLimitN * kLdsLimitN + LDSB_TAIL) * 8));
     HIPCHECK(hipFuncSetAttribute((const void*)lds_backsub_merged_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (kLdsLimitN * kLdsLimitN + LDSB_TAIL) * 8));
@@ -1704,7 +1757,7 @@ int lmgpu_destroy(lmgpu_handle* h) {
     for (int i = 0; i < 8; i++)
       if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     for (hipEvent_t e : h->kt.pool) (void)hipEventDestroy(e);
-    fr(h->bs_inv); fr(h->bs_x); fr(h->bs_flags); fr(h->inv16); fr(h->d_pflags); fr(h->d_bs_parent); fr(h->d_bs_pos); fr(h->d_bs_done); fr(h->d_fill_upper); fr(h->d_bsd_table); fr(h->d_zero_ranges); fr(h->d_bsd_x); fr(h->d_bsd_ticket); fr(h->d_leafpack); fr(h->d_gzero);
+    fr(h->bs_inv); fr(h->bs_x); fr(h->bs_flags); fr(h->inv16); fr(h->d_pflags); fr(h->d_bs_parent); fr(h->d_bs_pos); fr(h->d_bs_done); fr(h->d_fill_upper); fr(h->d_level_tasks); fr(h->d_level_sync); fr(h->d_bsd_table); fr(h->d_zero_ranges); fr(h->d_bsd_x); fr(h->d_bsd_ticket); fr(h->d_leafpack); fr(h->d_gzero);
     for (auto& kv : h->chain_plans)
       for (auto& cp : kv.second) fr(cp.d_tasks);
     fr(h->d_gpblk); fr(h->d_gpent); fr(h->d_gvblk); fr(h->d_gvent); fr(h->d_gcorner); fr(h->d_row_begin); fr(h->d_rowptr); fr(h->d_rowsrc);
@@ -2191,23 +2244,7 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
   {
     h->elim_segs.clear();
     h->elim_seg_of.assign(P.n_levels, -1);
-    const int kMergeCap = 160;  // fronts per level: a merged launch sizes its LDS for its largest front, wider levels keep their per-bin launches
-    auto level_class = [&](int l, int* nmax, int* jcap, int* threads) {
-      const LevelWork& L = h->levels[l];
-      if (L.list_count == 0 || L.list_count > kMergeCap || L.bin_begin[kNumBins] != L.bin_begin[6]) return false;  // (no gather leaves)
-      int top = -1, jc = 96, cnt_top = 0;
-      for (int b = 0; b < 6; b++)
-        if (L.bin_begin[b + 1] > L.bin_begin[b]) {
-          top = b;
-          cnt_top = L.bin_begin[b + 1] - L.bin_begin[b];
-          jc = std::max(jc, L.bin_jcap[b]);
-        }
-      *nmax = kBinN[top];
-      *jcap = jc;
-      const bool wide16 = top >= 3 && cnt_top <= 64 && !h->no_wide16;
-      *threads = wide16 ? 1024 : (top == 0 ? 64 : (top == 1 ? 128 : 256));
-      return true;
-    };
+    auto level_class = [&](int l, int* nmax, int* jcap, int* threads) { return level_lds_class(h, l, nmax, jcap, threads); };
     int l = 0;
     while (l < P.n_levels) {
       int nmax, jcap, threads;
@@ -2397,6 +2434,48 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
       for (int fi : L.hbm)
         if (h->is_med[fi]) mfs.push_back(MedFront{h->h_fronts[fi], h->f_off[fi], h->f_ld[fi], h->row_begin[fi]});
     if ((rc = upload(h, &h->d_med_fronts, mfs))) return rc;
+    // ---- fused level launches: task lists [LDS fronts | assembly rows | diagonal blocks | panel strips | update quadrants] per level
+    h->fuse_levels = (int)h->levels.size() >= 12 && h->cfg.world_size == 1;
+    if (const char* e = dev_switch("LMGPU_FUSE_LEVELS")) h->fuse_levels = atoi(e) != 0 && h->cfg.world_size == 1;
+    std::vector<LevelTask> tasks;
+    int li = 0;
+    for (LevelWork& L : h->levels) {
+      const int l = li++;
+      L.fuse_task_count = 0;
+      int nmax, jcap, threads;
+      if (!h->fuse_levels || L.med_count == 0 || !(L.med_max_fac > 0 || L.med_max_child > 0)) continue;
+      if (h->merge_elim && h->elim_seg_of[l] != -1) continue;  // its LDS fronts belong to a merged launch
+      if (!level_lds_class(h, l, &nmax, &jcap, &threads)) continue;
+      L.fuse_task_begin = (int)tasks.size();
+      L.fuse_nmax = nmax;
+      L.fuse_jcap = jcap;
+      L.fuse_threads = threads == 1024 ? 1024 : 256;
+      for (int q = 0; q < L.list_count; q++) tasks.push_back(LevelTask{0, L.list_begin + q, 0, 0});
+      for (int m = 0; m < L.med_count; m++) {
+        const FrontDesc& F = mfs[L.med_begin + m].F;
+        for (int r = 0; r < F.n; r += 4) tasks.push_back(LevelTask{1, m, r, 0});
+      }
+      for (int m = 0; m < L.med_count; m++) tasks.push_back(LevelTask{2, m, 0, 0});
+      for (int m = 0; m < L.med_count; m++) {
+        const FrontDesc& F = mfs[L.med_begin + m].F;
+        for (int st = 0; st * 64 < F.n - F.nf; st++) tasks.push_back(LevelTask{3, m, st, 0});
+      }
+      for (int m = 0; m < L.med_count; m++) {
+        const FrontDesc& F = mfs[L.med_begin + m].F;
+        const int S = (F.n - F.nf + 63) / 64;
+        for (int sj = 0; sj < S; sj++)
+          for (int si = 0; si <= sj; si++)
+            for (int qd = 0; qd < 4; qd++) tasks.push_back(LevelTask{4, m, si | (sj << 8), qd});
+      }
+      L.fuse_task_count = (int)tasks.size() - L.fuse_task_begin;
+    }
+    if (!tasks.empty()) {
+      if ((rc = upload(h, &h->d_level_tasks, tasks))) return rc;
+      h->n_level_sync = (int)mfs.size();
+      HIPCHECK(hipMalloc((void**)&h->d_level_sync, std::max<size_t>(1, mfs.size()) * sizeof(LevelSync)));
+    } else {
+      h->fuse_levels = false;
+    }
   }
   if ((rc = upload(h, &h->d_rowptr, rowptr))) return rc;
   if ((rc = upload(h, &h->d_rowsrc, rowsrc))) return rc;
