@@ -186,6 +186,7 @@ struct lmgpu_isam2 {
     uint32_t words, pad;
   };
   std::vector<PushRec> pushes;
+  unsigned int* d_eticket = nullptr;  // ticket counter of the merged elimination launch
   double* inv16 = nullptr;    // 16 x 256 doubles: the 16 x 16 inverses of the panel being factored (wide cliques)
   double* d_marg = nullptr;   // marginalCovariance: one work vector per column of the block + the block itself
   size_t marg_cap = 0;
@@ -1330,8 +1331,48 @@ int is_eliminate_fronts(lmgpu_isam2* S, const std::vector<IsGF>& gfs, const std:
     const int32_t fresh = 0x7f7f7f7f;  // the status word is reset by the scatter kernel of this flush
     if ((rc = is_push(S, S->d_status, &fresh, sizeof(fresh)))) return rc;
   }
+  // Several levels of LDS cliques and no wide one: ONE dataflow launch for all of them (lds_front_merged_kernel: tickets bottom-up, update
+  // matrices handed from child to parent by value) instead of a launch per level -- an update of VisualISAM2Example is two levels, one of
+  // the city10000 loop two to five, each a dependent launch of a few workgroups.
+  bool any_wide = false;
+  for (int l = 0; l <= max_level; l++) any_wide = any_wide || !wide[l].empty();
+  const bool merged = !any_wide && max_level >= 1 && list.size() <= 4096 && !dev_switch("LMGPU_ISAM2_NO_MERGE");
+  FillUpper* d_fu = nullptr;
+  int m_nmax = 1, m_jc = 96;
+  if (merged) {
+    std::vector<FillUpper> fu;
+    for (int32_t fi : list) {
+      fu.push_back(FillUpper{fds[fi].u_off, fds[fi].n - fds[fi].nf, fds[fi].ld_u});
+      m_nmax = std::max(m_nmax, fds[fi].n);
+      int tot = 0;
+      for (int k = 0; k < fds[fi].fac_count; k++) {
+        const FacDesc& d = fd[ffac[fds[fi].fac_begin + k].fac];
+        tot += d.rows * (d.d0 + d.d1 + d.d2 + 1);
+      }
+      m_jc = std::max(m_jc, std::min(tot, LDSF_JCAP));
+    }
+    if ((rc = is_stage(S, fu, &d_fu))) return rc;
+    if (!S->d_eticket) ISCHECK(hipMalloc((void**)&S->d_eticket, sizeof(unsigned int)));
+    const unsigned int zero = 0u;
+    if ((rc = is_push(S, S->d_eticket, &zero, sizeof(zero)))) return rc;
+  }
   if ((rc = is_flush(S))) return rc;  // the tables above, and whatever the update pushed before (new values, factor rows)
-  for (int l = 0; l <= max_level; l++) {
+  if (merged) {
+    const int jcap = (m_jc + 7) & ~7;
+    const size_t lds = kLdsFrontExtra - (size_t)(LDSF_JCAP - jcap) * 8 + 64 + (size_t)m_nmax * m_nmax * sizeof(double);
+    hipLaunchKernelGGL(fill_upper_kernel, dim3((unsigned)list.size()), dim3(256), 0, S->stream, (const FillUpper*)d_fu, S->pool);
+    if (m_nmax > 72)
+      hipLaunchKernelGGL(lds_front_merged_kernel<1024>, dim3((unsigned)list.size()), dim3(1024), lds, S->stream, (const int32_t*)d_list, 0, (int)list.size(),
+                         (const FrontDesc*)d_fds, (const FrontFac*)d_ffac, (const FacDesc*)d_fd, (const ChildRef*)d_childs, (const int32_t*)d_cmap,
+                         (const int32_t*)d_fxoff, S->pool, 0.0, (const double*)nullptr, (const double*)S->ones, S->d_status, m_nmax, jcap,
+                         (const double*)nullptr, S->d_eticket);
+    else
+      hipLaunchKernelGGL(lds_front_merged_kernel<256>, dim3((unsigned)list.size()), dim3(m_nmax <= 24 ? 64 : (m_nmax <= 48 ? 128 : 256)), lds, S->stream,
+                         (const int32_t*)d_list, 0, (int)list.size(), (const FrontDesc*)d_fds, (const FrontFac*)d_ffac, (const FacDesc*)d_fd,
+                         (const ChildRef*)d_childs, (const int32_t*)d_cmap, (const int32_t*)d_fxoff, S->pool, 0.0, (const double*)nullptr,
+                         (const double*)S->ones, S->d_status, m_nmax, jcap, (const double*)nullptr, S->d_eticket);
+  }
+  for (int l = 0; l <= max_level && !merged; l++) {
     for (int32_t fi : wide[l]) {  // (the level's LDS fronts and these only depend on the levels below)
       const FrontDesc& F = fds[fi];
       const lmgpu_isam2::Clq& c = S->clq[cid[fi]];
@@ -1372,10 +1413,16 @@ int is_eliminate_fronts(lmgpu_isam2* S, const std::vector<IsGF>& gfs, const std:
     const int jcap = (jc + 7) & ~7;
     const int threads = nmax <= 24 ? 64 : (nmax <= 48 ? 128 : 256);
     const size_t lds = kLdsFrontExtra - (size_t)(LDSF_JCAP - jcap) * 8 + 64 + (size_t)nmax * nmax * sizeof(double);
-    hipLaunchKernelGGL(lds_front_kernel<false>, dim3(lv[l].second), dim3(threads), lds, S->stream, (const int32_t*)(d_list + lv[l].first),
-                       (const FrontDesc*)d_fds, (const FrontFac*)d_ffac, (const FacDesc*)d_fd, (const ChildRef*)d_childs, (const int32_t*)d_cmap,
-                       (const int32_t*)d_fxoff, S->pool, 0.0, (const double*)nullptr, (const double*)S->ones, S->d_status, nmax, nmax, (double*)nullptr, jcap,
-                       (const double*)nullptr, (const char*)nullptr, 0);
+    if (nmax > 72 && lv[l].second <= 256)  // a handful of wide cliques: sixteen waves each (the batch path's rule)
+      hipLaunchKernelGGL((lds_front_kernel<false, 1024>), dim3(lv[l].second), dim3(1024), lds, S->stream, (const int32_t*)(d_list + lv[l].first),
+                         (const FrontDesc*)d_fds, (const FrontFac*)d_ffac, (const FacDesc*)d_fd, (const ChildRef*)d_childs, (const int32_t*)d_cmap,
+                         (const int32_t*)d_fxoff, S->pool, 0.0, (const double*)nullptr, (const double*)S->ones, S->d_status, nmax, nmax, (double*)nullptr, jcap,
+                         (const double*)nullptr, (const char*)nullptr, 0);
+    else
+      hipLaunchKernelGGL(lds_front_kernel<false>, dim3(lv[l].second), dim3(threads), lds, S->stream, (const int32_t*)(d_list + lv[l].first),
+                         (const FrontDesc*)d_fds, (const FrontFac*)d_ffac, (const FacDesc*)d_fd, (const ChildRef*)d_childs, (const int32_t*)d_cmap,
+                         (const int32_t*)d_fxoff, S->pool, 0.0, (const double*)nullptr, (const double*)S->ones, S->d_status, nmax, nmax, (double*)nullptr, jcap,
+                         (const double*)nullptr, (const char*)nullptr, 0);
   }
   // the status word comes back with the one wait that ends the update (is_finish_elimination): the mark kernel, the last launch of an
   // update that eliminated anything, relays it into the host's pinned word
@@ -2504,6 +2551,9 @@ int lmgpu_isam2_create(const lmgpu_config* cfg, const lmgpu_isam2_params* prm, l
   ISCHECK(hipHostMalloc((void**)&S->h_status, sizeof(int), hipHostMallocMapped));
   ISCHECK(hipHostGetDevicePointer((void**)&S->h_status_dev, S->h_status, 0));
   ISCHECK(hipFuncSetAttribute((const void*)lds_front_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra + 64));
+  ISCHECK(hipFuncSetAttribute((const void*)lds_front_kernel<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra + 64));
+  ISCHECK(hipFuncSetAttribute((const void*)lds_front_merged_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra + 64));
+  ISCHECK(hipFuncSetAttribute((const void*)lds_front_merged_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra + 64));
   ISCHECK(hipFuncSetAttribute((const void*)isam2_wildfire_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (kLdsLimitN * kLdsLimitN + LDSB_TAIL) * 8));
   ISCHECK(hipFuncSetAttribute((const void*)diag_potrf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
   ISCHECK(hipFuncSetAttribute((const void*)syrk_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSyrkLds));
@@ -2531,7 +2581,7 @@ int lmgpu_isam2_destroy(lmgpu_isam2* S) {
       if (b.d_noise) (void)hipFree(b.d_noise);
     }
     for (void* p : {(void*)S->delta, (void*)S->ones, (void*)S->d_replaced, (void*)S->d_changed, (void*)S->pool, (void*)S->d_status, (void*)S->d_gpart, (void*)S->d_tree,
-                    (void*)S->d_tree_fx, (void*)S->d_tree_sx, (void*)S->d_queue, (void*)S->d_wl, (void*)S->inv16, (void*)S->d_marg, (void*)S->d_ebuf,
+                    (void*)S->d_tree_fx, (void*)S->d_tree_sx, (void*)S->d_queue, (void*)S->d_wl, (void*)S->inv16, (void*)S->d_eticket, (void*)S->d_marg, (void*)S->d_ebuf,
                     (void*)S->d_epart, (void*)S->delta_newton, (void*)S->rgprod, (void*)S->grad, (void*)S->dx_u, (void*)S->d_cerr, (void*)S->d_dlscal})
       if (p) (void)hipFree(p);
     if (S->h_status) (void)hipHostFree(S->h_status);
