@@ -456,8 +456,38 @@ __device__ __forceinline__ void lds_front_body(const int work, const int32_t* __
           if (q < kb) S[(k0 + q) * n + j] = x[q];
       }
       __syncthreads();
-      const int t0 = k0 + kb, m = n - t0;
+      // Two levels (round 3): inside a PANEL of sixteen pivots the rank-4 update only reaches the panel's own remaining rows (at most
+      // twelve: one row of tiles); the rows below the panel receive the whole panel as ONE rank-16 update (four MFMAs on a tile that is
+      // read and written once) after its last group.  Group by group over the whole trailing matrix, every tile went LDS -> registers
+      // -> LDS four times per sixteen pivots: the Cholesky of a 70-row clique was 50 of the 70 us its front took.
+      const int t0 = k0 + kb;
+      const int p0 = k0 & ~15, pend = min(p0 + 16, nf);
+      if (t0 < pend) {  // rows t0 .. pend - 1 of the panel, all columns from t0
+        const int T = (n - t0 + 15) >> 4;
+        for (int tj = wave; tj < T; tj += nw) {
+          const int row0 = t0, col0 = t0 + 16 * tj;
+          const bool kv = kk < kb;
+          const double a = (kv && row0 + cc < pend) ? -S[(k0 + kk) * n + row0 + cc] : 0.0;
+          const double b = (kv && col0 + cc < n) ? S[(k0 + kk) * n + col0 + cc] : 0.0;
+          d4_t c;
+#pragma unroll
+          for (int rr = 0; rr < 4; rr++) {
+            const int row = row0 + kk + 4 * rr, col = col0 + cc;
+            c[rr] = (row < pend && col < n) ? S[row * n + col] : 0.0;
+          }
+          c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+#pragma unroll
+          for (int rr = 0; rr < 4; rr++) {
+            const int row = row0 + kk + 4 * rr, col = col0 + cc;
+            if (row < pend && col < n && col >= row) S[row * n + col] = c[rr];
+          }
+        }
+        continue;
+      }
+      // the panel p0 .. pend - 1 is finished: everything below it
+      const int m = n - pend;
       if (m <= 0) continue;
+      const int K = pend - p0;
       const int T = (m + 15) >> 4, ntile = T * (T + 1) / 2;
       for (int t = wave; t < ntile; t += nw) {
         int ti = 0, rem = t;
@@ -465,18 +495,21 @@ __device__ __forceinline__ void lds_front_body(const int work, const int32_t* __
           rem -= T - ti;
           ti++;
         }
-        const int row0 = t0 + 16 * ti, col0 = t0 + 16 * (ti + rem);
-        // A[i = cc][k = kk] = -R[k0 + kk][row0 + cc],  B[k = kk][j = cc] = R[k0 + kk][col0 + cc]
-        const bool kv = kk < kb;
-        const double a = (kv && row0 + cc < n) ? -S[(k0 + kk) * n + row0 + cc] : 0.0;
-        const double b = (kv && col0 + cc < n) ? S[(k0 + kk) * n + col0 + cc] : 0.0;
+        const int row0 = pend + 16 * ti, col0 = pend + 16 * (ti + rem);
         d4_t c;
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) {
           const int row = row0 + kk + 4 * rr, col = col0 + cc;
           c[rr] = (row < n && col < n) ? S[row * n + col] : 0.0;
         }
-        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+#pragma unroll
+        for (int sx = 0; sx < 4; sx++) {
+          // A[i = cc][k = kk] = -R[p0 + 4 sx + kk][row0 + cc],  B[k = kk][j = cc] = R[p0 + 4 sx + kk][col0 + cc]
+          const bool kv = 4 * sx + kk < K;
+          const double a = (kv && row0 + cc < n) ? -S[(p0 + 4 * sx + kk) * n + row0 + cc] : 0.0;
+          const double b = (kv && col0 + cc < n) ? S[(p0 + 4 * sx + kk) * n + col0 + cc] : 0.0;
+          c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+        }
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) {
           const int row = row0 + kk + 4 * rr, col = col0 + cc;
