@@ -228,6 +228,34 @@ def isam2_sequences(tmpdir, poses):
     return out
 
 
+def fixed_lag_sequence(tmpdir, fixture=None):
+    """a fixed-lag smoother's calls on city10000 (order the pose about to leave first, update, ISAM2::marginalizeLeaves: what
+    gtsam_unstable/nonlinear/IncrementalFixedLagSmoother.cpp does around its ISAM2; one pose per update, findUnusedFactorSlots) as an input
+    file of the C++ driver.  The extraReelimKeys a smoother reads off its copy of the Bayes tree come from a fixture
+    (tests/tools/make_fixed_lag_fixture.py), like the orderings."""
+    import numpy as np
+    from gtsam_personal_amd import ISAM2Params
+    from gtsam_personal_amd.incremental_workloads import fixed_lag_pose2_steps, write_isam2_sequence
+    fx = json.load(open(fixture or os.path.join(ROOT, "tests", "golden", "isam2_fixed_lag_city10000.json")))
+    poses, lag = fx["poses"], fx["lag"]
+    est = {0: np.zeros(3)}
+    steps = []
+    for step, (g, v, leaving) in enumerate(fixed_lag_pose2_steps(os.path.join(ROOT, "tests", "golden", "city10000.g2o"), poses, lag, lambda k: est[k]), start=1):
+        for k in v.keys():  # (only fills the V lines the W lines replace)
+            est[int(k)] = np.asarray(v.at(k), dtype=float)[:3]
+        constrained = None
+        if leaving:
+            constrained = {k: 1 for k in range(max(0, step - lag), step + 1)}
+            for k in leaving:
+                constrained[int(k)] = 0
+        steps.append((g, v, None, dict(constrained=constrained, extra_reelim=fx["extra_reelim"][step - 1], marginalize=leaving)))
+    p = ISAM2Params()
+    p.findUnusedFactorSlots = True
+    path = os.path.join(tmpdir, "fixed_lag.txt")
+    write_isam2_sequence(path, p, steps, relative_pose2=True)
+    return path
+
+
 def isam2_bench(args):
     """BASELINE configs[4] and the reference's incremental benchmark loop through the C ABI from C++ (no Python between the updates): ms per
     ISAM2::update inside the library calls, with percentiles; the CPU oracle on the same sequences beside it.  The constrained COLAMD
@@ -242,6 +270,8 @@ def isam2_bench(args):
     with tempfile.TemporaryDirectory() as d:
         t0 = time.perf_counter()
         seqs = isam2_sequences(d, args.isam2_poses)
+        if os.path.exists(os.path.join(ROOT, "tests", "golden", "isam2_fixed_lag_city10000.json")):
+            seqs["fixed_lag"] = fixed_lag_sequence(d)
         t_gen = time.perf_counter() - t0
         for name, path in seqs.items():
             fx = os.path.join(ROOT, "tests", "golden", f"isam2_orderings_{name}.bin")
@@ -291,6 +321,28 @@ def isam2_bench(args):
                     break
             cpu["city10000"] = {"ms_per_update": 1e3 * t_orc / max(1, n_up), "updates": n_up,
                                 "note": "ISAM2::update only (the estimate of the previous pose is read outside the timed calls), through ctypes"}
+            if "fixed_lag" in res:
+                from gtsam_personal_amd.incremental_workloads import fixed_lag_pose2_steps
+                fx = json.load(open(os.path.join(ROOT, "tests", "golden", "isam2_fixed_lag_city10000.json")))
+                orc = oh.OracleISAM2(p.relinearizeThreshold, p.relinearizeSkip, p.enableRelinearization, p.optimizationParams.wildfireThreshold)
+                orc.set_find_unused_factor_slots(True)
+                t_orc, n_up, budget = 0.0, 0, time.perf_counter()
+                for step, (g, v, leaving) in enumerate(fixed_lag_pose2_steps(os.path.join(ROOT, "tests", "golden", "city10000.g2o"), fx["poses"], fx["lag"],
+                                                                             lambda k: orc.calculateEstimate().at(k)), start=1):
+                    constrained = None
+                    if leaving:
+                        constrained = {k: 1 for k in range(max(0, step - fx["lag"]), step + 1)}
+                        constrained[leaving[0]] = 0
+                    t0 = time.perf_counter()
+                    orc.update(g, v, constrainedKeys=constrained, extraReelimKeys=fx["extra_reelim"][step - 1])
+                    if leaving:
+                        orc.marginalizeLeaves(leaving)
+                    t_orc += time.perf_counter() - t0
+                    n_up += 1
+                    if time.perf_counter() - budget > 15.0:
+                        break
+                cpu["fixed_lag"] = {"ms_per_update": 1e3 * t_orc / max(1, n_up), "updates": n_up,
+                                    "note": "ISAM2::update + marginalizeLeaves (the estimate of the previous pose is read outside the timed calls), through ctypes"}
     v = res["visual"]
     out = {"metric": "ISAM2 update latency", "value": v["ms_per_update_after_first"], "unit": "ms per update", "n_gpus": 1, "steps": v["updates"] - 1, "warmup": 1,
            "ms_per_step": v["ms_per_update_after_first"], "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
@@ -302,13 +354,16 @@ def isam2_bench(args):
            "visual_isam2_example": v,
            "city10000_incremental": dict(res["city10000"], workload=f"timing/timeIncremental.cpp on city10000.g2o, {res['city10000']['updates']} updates, one pose per update, every new pose "
                                                                     "initialised from the device's calculateEstimate(previous pose); ms_per_update includes those single-variable estimates"),
+           "fixed_lag_city10000": (dict(res["fixed_lag"], workload="a fixed-lag smoother's calls on city10000.g2o (lag 50 poses, one pose per update: update with the leaving pose ordered "
+                                                                  "first, then ISAM2::marginalizeLeaves; loop closures inside the window; findUnusedFactorSlots); ms_per_update = update + "
+                                                                  "marginalizeLeaves + the single-variable estimate that initialises the next pose") if "fixed_lag" in res else None),
            "roofline": {"kernel": "none dominant: an update is a dozen dependent launches on a few workgroups", "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBPS,
                         "unit": "GB/s", "frac": None, "traffic": None, "note": "latency-bound at this size (16 variables / a few cliques per update); no roofline is claimed"},
            "sequence_generation_s": t_gen}
     if cpu is not None:
         out["cpu_baseline"] = {"value": cpu["visual"]["ms_per_update"], "unit": "ms per update", "cores": 1, "kind": "port",
                                "sample": "oracle/isam2_oracle.hpp (CPU restatement of ISAM2::update), the same VisualISAM2Example sequence, best of 5, through ctypes",
-                               "city10000_incremental": cpu["city10000"]}
+                               "city10000_incremental": cpu["city10000"], "fixed_lag_city10000": cpu.get("fixed_lag")}
     print(json.dumps(out), flush=True)
 
 

@@ -94,9 +94,59 @@ def incremental_pose2_steps(g2o_path, n_poses, init_from):
         step += 1
 
 
+def fixed_lag_pose2_steps(g2o_path, n_poses, lag, init_from):
+    """A fixed-lag smoother's use of ISAM2 (gtsam_unstable/nonlinear/IncrementalFixedLagSmoother.cpp: order the keys that are about to
+    leave first, update, ISAM2::marginalizeLeaves) on a Pose2 g2o file, one pose per update: after the update that adds pose s, pose
+    s - lag is marginalized out.  Edges that reach back beyond the window are dropped (their older end has left the system).
+    Yields (graph, values, leaving_keys); init_from as in incremental_pose2_steps."""
+    for step, (g, v) in enumerate(incremental_pose2_steps(g2o_path, n_poses, init_from), start=1):
+        gw = NonlinearFactorGraph()
+        for ftype, kind, gi, keys, meas, noise, models in g.buckets():
+            order = np.argsort(gi)
+            for i in order.tolist():
+                if len(keys[i]) > 1 and ftype == 1 and min(int(keys[i][0]), int(keys[i][1])) < step - lag:
+                    continue
+                if ftype == 1:
+                    gw.add_BetweenFactorPose2(int(keys[i][0]), int(keys[i][1]), meas[i], models[i])
+                else:
+                    gw.add_PriorFactorPose2(int(keys[i][0]), meas[i], models[i])
+        yield gw, v, ([step - lag] if step - lag >= 0 else [])
+
+
+def fixed_lag_update_params(cliques, existing_keys, new_keys, leaving):
+    """what IncrementalFixedLagSmoother hands to ISAM2::update for keys that are about to be marginalized (the reference's own test helper
+    does the same: tests/testGaussianISAM2.cpp:662-726): constrainedKeys = leaving keys in group 0, everything else in group 1;
+    extraReelimKeys = the leaving keys and the frontals of every clique below them that has them in its separator.
+    cliques: [(keys, n_frontal_keys, RSd, parent)] depth-first (the tree taps).  Returns (constrainedKeys, extraReelimKeys)."""
+    if not leaving:
+        return None, []
+    constrained = {int(k): 1 for k in existing_keys}
+    for k in new_keys:
+        constrained[int(k)] = 1
+    for k in leaving:
+        constrained[int(k)] = 0
+    children = {i: [] for i in range(len(cliques))}
+    for i, (_, _, _, par) in enumerate(cliques):
+        if par >= 0:
+            children[par].append(i)
+    marked = []
+    for key in sorted(leaving):
+        marked.append(int(key))
+        home = next(i for i, (keys, nf, _, _) in enumerate(cliques) if key in keys[:nf])
+        stack = list(children[home])
+        while stack:
+            i = stack.pop()
+            keys, nf, _, _ = cliques[i]
+            if key in keys[nf:]:
+                marked.extend(int(k) for k in keys[:nf])
+                stack.extend(children[i])
+    return constrained, marked
+
+
 def write_isam2_sequence(path, params, steps, relative_pose2=False):
     """the input of tests/cpp/isam2_harness: what the reference-side wrapper extracts from each update's NonlinearFactorGraph / Values
-    (the packings of include/lmgpu.h), as text.  steps: [(graph, values[, removeFactorIndices])].  relative_pose2: a new Pose2 k that
+    (the packings of include/lmgpu.h), as text.  steps: [(graph, values[, removeFactorIndices[, {"constrained": {key: group},
+    "extra_reelim": [keys], "marginalize": [keys]}]])].  relative_pose2: a new Pose2 k that
     comes with a BetweenFactor<Pose2>(k - 1, k) is written as "previous estimate composed with that odometry" (W line): the harness asks
     the device for calculateEstimate(k - 1) at update time, like timing/timeIncremental.cpp"""
     from .graph import FACTOR_ARITY, F_BETWEEN_POSE2, F_PRIOR_CAM, F_SFM, N_UNIT, POSE2, VAR_STORE_DEV
@@ -104,6 +154,8 @@ def write_isam2_sequence(path, params, steps, relative_pose2=False):
     with open(path, "w") as f:
         p = params
         f.write(f"ISAM2 {p.relinearizeThreshold!r} {int(p.relinearizeSkip)} {int(bool(p.enableRelinearization))} {p.optimizationParams.wildfireThreshold!r}\n")
+        if getattr(p, "findUnusedFactorSlots", False):
+            f.write("OPT find_unused_slots 1\n")
         for st in steps:
             g, v = st[0], st[1]
             rm = list(st[2]) if len(st) > 2 and st[2] is not None else []
@@ -137,4 +189,12 @@ def write_isam2_sequence(path, params, steps, relative_pose2=False):
                                   " ".join(repr(float(x)) for x in nz) + "\n")
             f.writelines(rows)
             f.write("R " + " ".join(str(int(i)) for i in rm) + "\n")
+            extra = st[3] if len(st) > 3 and st[3] else {}
+            if extra.get("constrained") is not None:  # ISAM2UpdateParams::constrainedKeys: key group pairs
+                ck = sorted(extra["constrained"].items())
+                f.write(f"C {len(ck)} " + " ".join(f"{int(k)} {int(g_)}" for k, g_ in ck) + "\n")
+            if extra.get("extra_reelim"):  # ISAM2UpdateParams::extraReelimKeys
+                f.write(f"X {len(extra['extra_reelim'])} " + " ".join(str(int(k)) for k in extra["extra_reelim"]) + "\n")
+            if extra.get("marginalize"):  # ISAM2::marginalizeLeaves after the update
+                f.write(f"M {len(extra['marginalize'])} " + " ".join(str(int(k)) for k in extra["marginalize"]) + "\n")
         f.write("END\n")

@@ -7,12 +7,17 @@
 //
 // The sequence of updates comes in a neutral text file written by the test / tool from the Python mirror's graphs:
 //   ISAM2 relinearizeThreshold relinearizeSkip enableRelinearization wildfireThreshold
+//   [OPT find_unused_slots 1]
 //   UPDATE nv nf nremove          then nv lines  V key type store d0 d1 ...
 //                                            or  W key prevkey dx dy dtheta   (a Pose2 initialised at update time as the device's
 //                                                own estimate of prevkey composed with the odometry: lmgpu_isam2_get_value =
 //                                                calculateEstimate(prevkey), the loop of timing/timeIncremental.cpp:84-170)
 //                                 then nf lines  F type k0 k1 k2 | nmeas meas... | noise_kind nnoise noise...
 //                                 then one line  R idx0 idx1 ...            (removeFactorIndices, nremove entries)
+//                                 optionally     C n key group ...          (ISAM2UpdateParams::constrainedKeys)
+//                                                X n key ...                (ISAM2UpdateParams::extraReelimKeys)
+//                                                M n key ...                (ISAM2::marginalizeLeaves after the update: the fixed-lag
+//                                                                            smoother's use, IncrementalFixedLagSmoother.cpp)
 //   ... END
 // usage: isam2_harness <sequence file> <device> <libccolamd_ref.so | replay:FILE> [record:FILE] [repeat:N]
 //   repeat:N      run the sequence N times (fresh handle each), report the last run
@@ -106,6 +111,10 @@ struct Update {
   };
   std::vector<F> facs;
   std::vector<uint64_t> remove;
+  // ISAM2UpdateParams::constrainedKeys / extraReelimKeys of this update and the keys ISAM2::marginalizeLeaves takes out after it
+  bool has_constrained = false;
+  std::vector<uint64_t> ckeys, extra, marginalize;
+  std::vector<int32_t> cgroups;
 };
 
 int fail(const char* what, const char* detail) {
@@ -152,7 +161,16 @@ int main(int argc, char** argv) {
   if (!(is >> w) || w != "ISAM2" || !(is >> prm.relinearizeThreshold >> prm.relinearizeSkip >> prm.enableRelinearization >> prm.wildfireThreshold))
     return fail("parse", "header");
   std::vector<Update> updates;
-  while (is >> w && w == "UPDATE") {
+  int find_unused_slots = 0;
+  is >> w;
+  while (w == "OPT") {  // OPT find_unused_slots 1  (ISAM2Params::findUnusedFactorSlots)
+    std::string name;
+    int val = 0;
+    is >> name >> val;
+    if (name == "find_unused_slots") find_unused_slots = val;
+    is >> w;
+  }
+  while (w == "UPDATE") {
     size_t nv, nf, nr;
     if (!(is >> nv >> nf >> nr)) return fail("parse", "UPDATE");
     Update u;
@@ -193,6 +211,30 @@ int main(int argc, char** argv) {
     if (!(is >> w) || w != "R") return fail("parse", "R");
     u.remove.resize(nr);
     for (uint64_t& r : u.remove) is >> r;
+    for (;;) {  // optional lines, then the next UPDATE / END
+      if (!(is >> w)) {
+        w.clear();
+        break;
+      }
+      size_t cnt;
+      if (w == "C") {
+        is >> cnt;
+        u.has_constrained = true;
+        u.ckeys.resize(cnt);
+        u.cgroups.resize(cnt);
+        for (size_t i = 0; i < cnt; i++) is >> u.ckeys[i] >> u.cgroups[i];
+      } else if (w == "X") {
+        is >> cnt;
+        u.extra.resize(cnt);
+        for (uint64_t& k : u.extra) is >> k;
+      } else if (w == "M") {
+        is >> cnt;
+        u.marginalize.resize(cnt);
+        for (uint64_t& k : u.marginalize) is >> k;
+      } else {
+        break;
+      }
+    }
     updates.push_back(std::move(u));
   }
 
@@ -209,12 +251,13 @@ int main(int argc, char** argv) {
   cfg.world_size = 1;
   lmgpu_isam2* h = nullptr;
   if (lmgpu_isam2_create(&cfg, &prm, &colamd_cb, nullptr, &h) != LMGPU_OK) return fail("lmgpu_isam2_create", h ? lmgpu_isam2_last_error(h) : "");
+  if (find_unused_slots && lmgpu_isam2_set_find_unused_factor_slots(h, 1) != LMGPU_OK) return fail("set_find_unused_factor_slots", lmgpu_isam2_last_error(h));
   double lib = 0, worst = 0;
   std::vector<double> per_update;
   lmgpu_isam2_result r{};
   size_t done = 0;
   double est_seconds = 0;
-  size_t est_calls = 0;
+  size_t est_calls = 0, marginalized = 0;
   for (Update& u : updates) {
     const double t0 = now();
     int rc = LMGPU_OK;
@@ -247,8 +290,13 @@ int main(int argc, char** argv) {
       if (rc == LMGPU_OK)
         rc = lmgpu_isam2_add_factors(h, f.type, 1, f.k, f.meas.data(), f.noise_kind, f.noise.empty() ? nullptr : f.noise.data());
     if (rc == LMGPU_OK) {
-      const lmgpu_isam2_update_params up{(int32_t)u.remove.size(), u.remove.data(), 0, 0, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, 0};
+      const lmgpu_isam2_update_params up{(int32_t)u.remove.size(), u.remove.data(), u.has_constrained ? 1 : 0, (int32_t)u.ckeys.size(), u.ckeys.data(),
+                                         u.cgroups.data(), 0, nullptr, (int32_t)u.extra.size(), u.extra.data(), 0, 0};
       rc = lmgpu_isam2_update_with(h, &up, &r);
+    }
+    if (rc == LMGPU_OK && !u.marginalize.empty()) {
+      rc = lmgpu_isam2_marginalize_leaves(h, (int32_t)u.marginalize.size(), u.marginalize.data(), nullptr, nullptr);
+      marginalized += u.marginalize.size();
     }
     const double dt = now() - t0;
     lib += dt;
@@ -283,9 +331,9 @@ int main(int argc, char** argv) {
   std::sort(per_update.begin(), per_update.end());
   auto pct = [&](double q) { return per_update.empty() ? 0.0 : 1e3 * per_update[std::min(per_update.size() - 1, (size_t)(q * per_update.size()))]; };
   if (report) std::printf("{\"updates\": %zu, \"library_seconds\": %.6f, \"first_update_ms\": %.4f, \"ms_per_update_after_first\": %.6f, \"ms_per_update\": %.6f, \"p50_ms\": %.4f, \"p95_ms\": %.4f, \"p99_ms\": %.4f, \"worst_update_ms\": %.4f, \"ccolamd_callback_seconds\": %.6f, "
-              "\"calculate_estimate_ms\": %.4f, \"single_estimates\": %zu, \"single_estimate_ms\": %.5f, \"variables\": %d, \"cliques\": %d, \"estimate\": [",
+              "\"calculate_estimate_ms\": %.4f, \"single_estimates\": %zu, \"single_estimate_ms\": %.5f, \"variables\": %d, \"cliques\": %d, \"marginalized\": %zu, \"factor_slots\": %d, \"estimate\": [",
               done, lib, first_ms, steady_ms, done ? 1e3 * lib / done : 0.0, pct(0.50), pct(0.95), pct(0.99), 1e3 * worst, g_colamd_seconds, 1e3 * t_est, est_calls,
-              est_calls ? 1e3 * est_seconds / est_calls : 0.0, n, r.cliques);
+              est_calls ? 1e3 * est_seconds / est_calls : 0.0, n, r.cliques, marginalized, lmgpu_isam2_num_factors(h));
   const double* q = packed.data();
   for (int i = 0; report && i < n; i++) {
     std::printf("%s[%" PRIu64, i ? ", " : "", keys[(size_t)i]);

@@ -228,3 +228,50 @@ def test_fixed_lag_run_with_dogleg():
     assert isam.size() == lag
     assert isam.num_factors() < 40  # slots are reused: the list does not grow with the run
     isam.close()
+
+
+def test_fixed_lag_smoother_over_city10000_against_the_oracle(tmp_path):
+    """300 poses of city10000 through a fixed-lag smoother's calls (lag 25: order the leaving pose first, update, marginalizeLeaves; loop
+    closures inside the window stay) on the device and on the oracle, compared step by step; then the same sequence through the C ABI
+    from C++ (tests/cpp/isam2_harness: C / X / M lines) must land on the same estimate."""
+    import json
+    import os
+    import subprocess
+    from gtsam_personal_amd.incremental_workloads import fixed_lag_pose2_steps, fixed_lag_update_params, write_isam2_sequence
+    g2o = os.path.join(os.path.dirname(__file__), "golden", "city10000.g2o")
+    p = ISAM2Params()
+    isam, orc = pair(p, find_unused=True)
+    est = {}
+    steps = []
+    for g, v, leaving in fixed_lag_pose2_steps(g2o, 300, 25, lambda k: est[k]):
+        constrained, marked = fixed_lag_update_params(orc.cliques(), list(orc.getDelta().keys()), list(v.keys()), leaving)
+        kw = dict(constrainedKeys=constrained, extraReelimKeys=marked)
+        rg, ro = isam.update(g, v, **kw).as_dict(), orc.update(g, v, **kw)
+        assert rg == ro, (rg, ro)
+        if leaving:
+            assert isam.marginalizeLeaves(leaving) == orc.marginalizeLeaves(leaving)
+        e = isam.calculateEstimate()
+        est = {int(k): np.asarray(e.at(k), dtype=float)[:3] for k in e.keys()}
+        steps.append((g, v, None, dict(constrained=constrained, extra_reelim=marked, marginalize=leaving)))
+        if len(steps) % 25 == 0:
+            compare_state(isam, orc)
+    compare_state(isam, orc)
+    compare_factor_list(isam, orc)
+    assert isam.size() == 25 and isam.num_factors() < 120
+    final = isam.calculateEstimate()
+    isam.close()
+    # ---- the same calls from C++
+    harness = os.path.join(os.path.dirname(__file__), "cpp", "isam2_harness")
+    ref = os.path.join(os.path.dirname(os.path.dirname(__file__)), "oracle", "_ref", "libccolamd_ref.so")
+    if not (os.path.exists(harness) and os.path.exists(ref)):
+        pytest.skip("tests/cpp/isam2_harness or oracle/_ref not built")
+    seq = str(tmp_path / "fixed_lag.txt")
+    write_isam2_sequence(seq, p, steps)
+    out = subprocess.run([harness, seq, "0", ref], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    res = json.loads(out.stdout)
+    assert res["updates"] == len(steps) and res["variables"] == 25 and res["marginalized"] == sum(len(st[3]["marginalize"]) for st in steps)
+    got = {int(rec[0]): np.array(rec[1:]) for rec in res["estimate"]}
+    assert sorted(got) == sorted(int(k) for k in final.keys())
+    for k in final.keys():
+        assert np.allclose(got[int(k)], final.at(k)[:3], rtol=1e-9, atol=1e-9), k
