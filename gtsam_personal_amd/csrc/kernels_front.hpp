@@ -391,7 +391,149 @@ __device__ __forceinline__ void lds_front_body(const int work, const int32_t* __
   // LDS bandwidth alone, 100-200 us per front, which is what a narrow tree level costs.  Same arithmetic up to the order of
   // the four subtractions.
   const bool blocked = !gather && nf >= 8 && nw >= 4;
-  if (blocked) {
+  // (smaller fronts: the four-pivot groups below -- every thread factors the 4 x 4 block itself; and only the launch forms of upper levels carry
+  //  the eight-pivot code: its registers would cost the per-level launches of leaf levels their occupancy)
+  constexpr bool kEightOk = (MAXT > 256) || DATAFLOW;
+  const bool eight = kEightOk && nf >= 32;
+  if constexpr (kEightOk)
+  if (blocked && eight) {
+    typedef double d4_t __attribute__((ext_vector_type(4)));
+    const int kk = lane >> 4, cc = lane & 15;
+    double* inv8 = corner_g;  // (eight doubles behind the front that only gather leaves use)
+    // Pivots EIGHT at a time (round 3; four before): wave 0 factors the 8 x 8 diagonal block in registers -- a chain of eight dependent
+    // sqrt / divide pairs, ~0.15 us each, which is what a group cannot go below -- and leaves it (in place) and the eight reciprocals in
+    // LDS; every thread then solves its columns of the eight-row panel against it.  Per group: three barriers, as with four pivots -- a
+    // clique of 72 frontal scalars (VisualISAM2Example's root) paid for eighteen groups at 2-3 us each.  Element by element the operations
+    // and their order are the ones of the row-by-row form.
+    // Two levels: inside a PANEL of sixteen pivots the first group's rank-8 update only reaches the panel's own remaining eight rows (one
+    // row of tiles); the rows below the panel receive the whole panel as ONE rank-16 update (four MFMAs on a tile that is read and written
+    // once) after its second group.
+    for (int k0 = 0; k0 < nf; k0 += 8) {
+      const int kb = min(8, nf - k0);
+      __syncthreads();  // previous trailing update complete
+      if (wave == 0) {
+        double d[8][8];
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+#pragma unroll
+          for (int c = q; c < 8; c++) d[q][c] = (c < kb) ? S[(k0 + q) * n + k0 + c] : ((q == c) ? 1.0 : 0.0);
+        double inv[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          inv[q] = 1.0;
+          if (q < kb) {
+            double piv = d[q][q];
+            if (!(piv > 0.0)) {
+              if (piv <= 0.0) failed = true;  // Eigen LLT: pivot <= 0 -> NumericalIssue (NaN passes, like Eigen)
+              piv = (piv == piv && piv != 0.0) ? fabs(piv) : 1.0;
+            }
+            const double r = sqrt(piv);
+            inv[q] = 1.0 / r;
+            d[q][q] = r;
+#pragma unroll
+            for (int c = q + 1; c < 8; c++) d[q][c] *= inv[q];
+#pragma unroll
+            for (int i = q + 1; i < 8; i++)
+#pragma unroll
+              for (int c = i; c < 8; c++) d[i][c] -= d[q][i] * d[q][c];
+          }
+        }
+        // lane (q, c) = (lane >> 3, lane & 7) puts its entry back; lanes 0 .. 7 the reciprocals
+        {
+          const int q = lane >> 3, c = lane & 7;
+          double v = 0.0, iv = 0.0;
+#pragma unroll
+          for (int qq = 0; qq < 8; qq++)
+#pragma unroll
+            for (int c2 = 0; c2 < 8; c2++)
+              if (qq == q && c2 == c && c2 >= qq) v = d[qq][c2];
+#pragma unroll
+          for (int qq = 0; qq < 8; qq++)
+            if (qq == lane) iv = inv[qq];
+          if (q <= c && c < kb) S[(k0 + q) * n + k0 + c] = v;
+          if (lane < 8) inv8[lane] = iv;
+        }
+      }
+      __syncthreads();  // the factored block and the reciprocals are in LDS
+      for (int j = k0 + kb + tid; j < n; j += nt) {
+        double x[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) x[q] = (q < kb) ? S[(k0 + q) * n + j] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+          if (q < kb) {
+            x[q] *= inv8[q];
+#pragma unroll
+            for (int i = q + 1; i < 8; i++)
+              if (i < kb) x[i] -= S[(k0 + q) * n + k0 + i] * x[q];
+          }
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+          if (q < kb) S[(k0 + q) * n + j] = x[q];
+      }
+      __syncthreads();
+      const int t0 = k0 + kb;
+      const int p0 = k0 & ~15, pend = min(p0 + 16, nf);
+      if (t0 < pend) {  // rows t0 .. pend - 1 of the panel, all columns from t0: rank-kb
+        const int T = (n - t0 + 15) >> 4;
+        for (int tj = wave; tj < T; tj += nw) {
+          const int row0 = t0, col0 = t0 + 16 * tj;
+          d4_t c;
+#pragma unroll
+          for (int rr = 0; rr < 4; rr++) {
+            const int row = row0 + kk + 4 * rr, col = col0 + cc;
+            c[rr] = (row < pend && col < n) ? S[row * n + col] : 0.0;
+          }
+#pragma unroll
+          for (int sx = 0; sx < 2; sx++) {
+            const bool kv = 4 * sx + kk < kb;
+            const double a = (kv && row0 + cc < pend) ? -S[(k0 + 4 * sx + kk) * n + row0 + cc] : 0.0;
+            const double b = (kv && col0 + cc < n) ? S[(k0 + 4 * sx + kk) * n + col0 + cc] : 0.0;
+            c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+          }
+#pragma unroll
+          for (int rr = 0; rr < 4; rr++) {
+            const int row = row0 + kk + 4 * rr, col = col0 + cc;
+            if (row < pend && col < n && col >= row) S[row * n + col] = c[rr];
+          }
+        }
+        continue;
+      }
+      // the panel p0 .. pend - 1 is finished: everything below it
+      const int m = n - pend;
+      if (m <= 0) continue;
+      const int K = pend - p0;
+      const int T = (m + 15) >> 4, ntile = T * (T + 1) / 2;
+      for (int t = wave; t < ntile; t += nw) {
+        int ti = 0, rem = t;
+        while (rem >= T - ti) {
+          rem -= T - ti;
+          ti++;
+        }
+        const int row0 = pend + 16 * ti, col0 = pend + 16 * (ti + rem);
+        d4_t c;
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+          const int row = row0 + kk + 4 * rr, col = col0 + cc;
+          c[rr] = (row < n && col < n) ? S[row * n + col] : 0.0;
+        }
+#pragma unroll
+        for (int sx = 0; sx < 4; sx++) {
+          // A[i = cc][k = kk] = -R[p0 + 4 sx + kk][row0 + cc],  B[k = kk][j = cc] = R[p0 + 4 sx + kk][col0 + cc]
+          const bool kv = 4 * sx + kk < K;
+          const double a = (kv && row0 + cc < n) ? -S[(p0 + 4 * sx + kk) * n + row0 + cc] : 0.0;
+          const double b = (kv && col0 + cc < n) ? S[(p0 + 4 * sx + kk) * n + col0 + cc] : 0.0;
+          c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+          const int row = row0 + kk + 4 * rr, col = col0 + cc;
+          if (row < n && col < n && col >= row) S[row * n + col] = c[rr];
+        }
+      }
+    }
+  }
+  if (blocked && !eight) {
     typedef double d4_t __attribute__((ext_vector_type(4)));
     const int kk = lane >> 4, cc = lane & 15;
     for (int k0 = 0; k0 < nf; k0 += 4) {
