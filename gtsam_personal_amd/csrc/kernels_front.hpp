@@ -118,7 +118,7 @@ __device__ unsigned long long ldsf_dbg[16];
 struct FrontFlow {
   int seg_begin, seg_end;  // positions of this launch's fronts in the level lists
 };
-template <bool GATHER, int MAXT, bool DATAFLOW>
+template <bool GATHER, int MAXT, bool DATAFLOW, bool EIGHT = (MAXT > 256) || DATAFLOW>
 __device__ __forceinline__ void lds_front_body(const int work, const int32_t* __restrict__ list, const FrontDesc* __restrict__ fronts,
                                                const FrontFac* __restrict__ ffac, const FacDesc* __restrict__ fd,
                                                const ChildRef* __restrict__ childs, const int32_t* __restrict__ cmap,
@@ -393,7 +393,7 @@ __device__ __forceinline__ void lds_front_body(const int work, const int32_t* __
   const bool blocked = !gather && nf >= 8 && nw >= 4;
   // (smaller fronts: the four-pivot groups below -- every thread factors the 4 x 4 block itself; and only the launch forms of upper levels carry
   //  the eight-pivot code: its registers would cost the per-level launches of leaf levels their occupancy)
-  constexpr bool kEightOk = (MAXT > 256) || DATAFLOW;
+  constexpr bool kEightOk = EIGHT;
   const bool eight = kEightOk && nf >= 32;
   if constexpr (kEightOk)
   if (blocked && eight) {

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(MAXT) void level_fused_kernel(const LevelTask* __re
   __syncthreads();
   const LevelTask t = tasks[s_ticket];
   if (t.kind == 0) {
-    lds_front_body<false, MAXT, false>(t.front, list, fronts, ffac, fd, childs, cmap, fxoff, pool, lambda_v, lambda_p, dampw, status, nmax, nmax, (double*)nullptr, jcap,
+    lds_front_body<false, MAXT, false, true>(t.front, list, fronts, ffac, fd, childs, cmap, fxoff, pool, lambda_v, lambda_p, dampw, status, nmax, nmax, (double*)nullptr, jcap,
                                        gex, (const char*)nullptr, 0, FrontFlow{});
     return;
   }

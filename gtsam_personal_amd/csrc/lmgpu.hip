@@ -2449,7 +2449,10 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
       L.fuse_task_begin = (int)tasks.size();
       L.fuse_nmax = nmax;
       L.fuse_jcap = jcap;
-      L.fuse_threads = threads == 1024 ? 1024 : 256;
+      // four waves per workgroup for every role: with sixteen (what a launch of wide LDS fronts alone takes) the kernel is held to 128 VGPRs and the
+      // register Cholesky of the dense fronts' diagonal blocks spills (sphere2500: 1.93 vs 1.87 ms)
+      L.fuse_threads = 256;
+      if (const char* e = dev_switch("LMGPU_FUSE_THREADS")) L.fuse_threads = atoi(e) == 1024 && threads == 1024 ? 1024 : 256;
       for (int q = 0; q < L.list_count; q++) tasks.push_back(LevelTask{0, L.list_begin + q, 0, 0});
       for (int m = 0; m < L.med_count; m++) {
         const FrontDesc& F = mfs[L.med_begin + m].F;
