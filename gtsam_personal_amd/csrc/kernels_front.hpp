@@ -113,6 +113,159 @@ __device__ unsigned long long ldsf_dbg[16];
 #else
 #define LDSF_STAMP(i) do { } while (0)
 #endif
+// A front of at most sixteen columns as ONE wave with the whole front in registers (the 16 x 16 accumulator layout of
+// v_mfma_f64_16x16x4_f64: entry (kk + 4 r, cc) in component r of lane 16 kk + cc): own factors as J^T J on the matrix core, the children's
+// update matrices fetched by the lanes that own their destinations, the pivots by lane shuffles -- no LDS, no barrier.  The general
+// body spends ~7.5 us per tree level on a chain of such fronts (victoria_park's upper 112 levels, a fixed-lag window, the cliques of an
+// incremental pose-graph update): four waves in lock step through a dozen barriers for a 10 x 10 matrix.  Merged launches only
+// (POLL: the children's entries are awaited by value, see lds_front_body).  The symmetric matrix is kept in full.
+template <bool POLL>
+__device__ __forceinline__ void lds_front_tiny(const FrontDesc& F, const FrontFac* __restrict__ ffac, const FacDesc* __restrict__ fd,
+                                               const ChildRef* __restrict__ childs, const int32_t* __restrict__ cmap, const int32_t* __restrict__ fxoff,
+                                               double* __restrict__ pool, double lambda, const double* __restrict__ dampw, int* __restrict__ status,
+                                               const double* __restrict__ gex) {
+  typedef double d4_t __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63, kk = lane >> 4, cc = lane & 15;
+  const int n = F.n, nf = F.nf;
+  d4_t S = d4_t{0, 0, 0, 0};
+  // ---- own factors: S += [A b]^T [A b], four rows of a factor per matrix instruction
+  for (int k = 0; k < F.fac_count; k++) {
+    const FrontFac ff = ffac[F.fac_begin + k];
+    const FacDesc d = fd[ff.fac];
+    const int m = d.rows, nc = d.d0 + d.d1 + d.d2 + 1;
+    int q = -1;  // the factor's local column that lands on front column cc
+    if (cc >= ff.c0 && cc < ff.c0 + d.d0)
+      q = cc - ff.c0;
+    else if (d.d1 > 0 && cc >= ff.c1 && cc < ff.c1 + d.d1)
+      q = d.d0 + cc - ff.c1;
+    else if (d.d2 > 0 && cc >= ff.c2 && cc < ff.c2 + d.d2)
+      q = d.d0 + d.d1 + cc - ff.c2;
+    else if (cc == n - 1)
+      q = nc - 1;
+    const double* J = pool + d.joff;
+    for (int r0 = 0; r0 < m; r0 += 4) {
+      const int r = r0 + kk;
+      const double v = (q >= 0 && r < m) ? J[q * m + r] : 0.0;
+      S = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, S, 0, 0, 0);
+    }
+  }
+  // damping and the extra gradient term, by the lanes that own the entries
+  {
+    const int xo = fxoff[F.fx_begin + min(cc, nf - 1)];
+    const double dw = lambda * dampw[xo];
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++)
+      if (kk + 4 * rr == cc && cc < nf) S[rr] += dw;
+    if (gex && cc == n - 1) {
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) {
+        const int I = kk + 4 * rr;
+        if (I < nf) {
+          const double gv = gex[fxoff[F.fx_begin + I]];
+          S[rr] += gv;
+        }
+      }
+    }
+    if (gex && cc < nf) {  // (and its mirror: the matrix is kept in full)
+      const double gv = gex[xo];
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++)
+        if (kk + 4 * rr == n - 1) S[rr] += gv;
+    }
+  }
+  // ---- children: the lane that owns (I, J) fetches the child's entry that lands there
+  bool timeout = false;
+  for (int k = 0; k < F.child_count; k++) {
+    const ChildRef c = childs[F.child_begin + k];
+    const double* U = pool + c.u_off;
+    const int mt = cmap[c.map_begin + min(lane, c.m - 1)];  // lane t: where the child's index t lands
+    int iJ = -1, iI[4] = {-1, -1, -1, -1};
+    for (int t = 0; t < c.m; t++) {
+      const int dst = __builtin_amdgcn_readlane(mt, t);
+      if (dst == cc) iJ = t;
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++)
+        if (dst == kk + 4 * rr) iI[rr] = t;
+    }
+    double u[4] = {0.0, 0.0, 0.0, 0.0};
+    long spins = 0;
+    bool again;
+    do {
+      again = false;
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) {
+        const bool valid = iJ >= 0 && iI[rr] >= 0;
+        const int a = valid ? min(iI[rr], iJ) : 0, b = valid ? max(iI[rr], iJ) : 0;
+        if (POLL) {
+          const unsigned long long bits = __hip_atomic_load((const unsigned long long*)(U + (size_t)a * c.ld + b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          u[rr] = __longlong_as_double((long long)bits);
+          if (valid && bits == ~0ull) again = true;
+        } else {
+          u[rr] = U[(size_t)a * c.ld + b];
+        }
+        if (!valid) u[rr] = 0.0;
+      }
+      if (again) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > 2000000L) {
+          timeout = true;
+          again = false;
+        }
+      }
+    } while (again);
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) S[rr] += u[rr];
+  }
+  if (timeout) atomicExch(status + 1, 1 + F.id);  // never expected: spin bound hit (reported apart from pivot failures)
+  // ---- partial Cholesky: row k lives in component k >> 2 of lanes 16 (k & 3) .. + 15
+  bool failed = false;
+  double dlast = 1.0, dprev = 1.0;  // the last two pivots' R_kk (pivot-exponent test)
+  for (int k = 0; k < nf; k++) {
+    const int pk = k >> 2, lk = (k & 3) << 4;
+    const double rowk = pk == 0 ? S[0] : (pk == 1 ? S[1] : (pk == 2 ? S[2] : S[3]));
+    double piv = __shfl(rowk, lk + k);
+    if (!(piv > 0.0)) {
+      if (piv <= 0.0) failed = true;  // Eigen LLT: pivot <= 0 -> NumericalIssue (NaN passes, like Eigen)
+      piv = (piv == piv && piv != 0.0) ? fabs(piv) : 1.0;
+    }
+    const double r = sqrt(piv), inv = 1.0 / r;
+    dprev = dlast;
+    dlast = r;
+    const double Rkj = __shfl(rowk, lk + cc) * inv;  // R[k][cc]
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+      const int I = kk + 4 * rr;
+      const double RkI = __shfl(rowk, lk + I) * inv;  // R[k][I]
+      if (I > k && cc > k) S[rr] -= RkI * Rkj;
+      if (I == k) S[rr] = cc > k ? Rkj : (cc == k ? r : 0.0);
+    }
+  }
+  if (lane == 0) {
+    // pivot-exponent test, gtsam/base/cholesky.cpp:146-158
+    if (nf >= 2) {
+      if (!(frexp_exp(dprev) - frexp_exp(dlast) < 12)) failed = true;
+    } else if (nf == 1) {
+      if (!(frexp_exp(dlast) > -12)) failed = true;
+    }
+  }
+  if (failed) atomicMin(status, F.id);
+  // ---- emit [R S d] (strictly-lower zeroed) and the update matrix (upper)
+  double* RSd = pool + F.rsd_off;
+  double* Uo = pool + F.u_off;
+#pragma unroll
+  for (int rr = 0; rr < 4; rr++) {
+    const int I = kk + 4 * rr;
+    if (I < nf && cc < n) RSd[(size_t)I * F.ld_rsd + cc] = cc >= I ? S[rr] : 0.0;
+    if (I >= nf && I < n && cc >= I && cc < n) {
+      if (POLL)
+        __hip_atomic_store((unsigned long long*)(Uo + (size_t)(I - nf) * F.ld_u + (cc - nf)), (unsigned long long)__double_as_longlong(S[rr]), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      else
+        Uo[(size_t)(I - nf) * F.ld_u + (cc - nf)] = S[rr];
+    }
+  }
+}
+
 // DATAFLOW (lds_front_merged_kernel below): the fronts of several consecutive tree levels in one launch; a front's extend-add polls the
 // values of its children's update matrices (see there).
 struct FrontFlow {
@@ -140,6 +293,12 @@ __device__ __forceinline__ void lds_front_body(const int work, const int32_t* __
   const int pk_n = pk ? ((const int*)(pk + LEAFPACK_HDR))[0] : 0;  // > 0: factor descriptors, staging offsets and damping offsets come from the record
   const int pk_tot = pk_n ? ((const int*)(pk + LEAFPACK_HDR))[1] : 0, pk_contig = pk_n ? ((const int*)(pk + LEAFPACK_HDR))[2] : 0;
   const int n = F.n, nf = F.nf, tid = threadIdx.x, nt = blockDim.x;
+  if constexpr (DATAFLOW && !GATHER) {
+    if (n <= 16) {  // one wave, the front in registers (the other waves leave before any barrier of this body)
+      if (tid < 64) lds_front_tiny<true>(F, ffac, fd, childs, cmap, fxoff, pool, lambda_p ? *lambda_p : lambda_v, dampw, status, gex);
+      return;
+    }
+  }
   const bool pk_xo = pk_n && ((const int*)(pk + LEAFPACK_HDR))[3] != 0;  // the record also carries the frontal delta offsets (nf <= 8)
   double damp_pre = 0.0, gex_pre = 0.0;
   if (pk_xo && tid < nf) {

@@ -130,7 +130,9 @@ def test_graph_replay_and_merged_backsubstitution_agree_with_eager_launches(monk
     assert np.linalg.norm(base[0][0] - base[1][0]) > 1e-6 * np.linalg.norm(base[0][0])  # the lambdas do make a difference
     assert np.array_equal(base[0][0], base[2][0]) and np.array_equal(base[1][0], base[4][0])
     for mode, out in results.items():
-        tol = 1e-12 if mode[2] == 1 else 1e-9  # per-level launches give small fronts one wave: the pivots of a front are then taken one by one
+        # per-level launches take a small front's pivots one by one in LDS; a merged launch keeps a front of <= 16 columns in the registers of one wave
+        # and sums its factors on the matrix core (other rounding; hundreds of levels deep, natural ordering: 1e-8)
+        tol = 1e-12 if mode[2] == 1 else 5e-8
         for (d, e1), (d0, e10) in zip(out, base):
             assert np.linalg.norm(d - d0) <= tol * np.linalg.norm(d0), mode
             assert abs(e1 - e10) <= tol * max(1.0, abs(e10)), mode
