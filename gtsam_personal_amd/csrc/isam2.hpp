@@ -205,7 +205,8 @@ struct lmgpu_isam2 {
   FrontDesc* d_tree = nullptr;
   int32_t *d_tree_fx = nullptr, *d_tree_sx = nullptr;
   size_t tree_slots = 0;         // capacity of the three arrays, in clique slots
-  int32_t* d_queue = nullptr;    // work list of the wildfire kernel (clique ids; -1 = not published; consumers reset what they take)
+  long long* d_queue = nullptr;  // work list of the wildfire kernel (clique id | parent clique id << 32; -1 = not published; consumers reset what they take)
+  unsigned char* d_tree_done = nullptr;  // per clique slot: the epoch of the walk that finished it (a child starts under its parent's solve and waits for this)
   size_t queue_cap = 0;
   unsigned int* d_wl = nullptr;  // [0] tail, [1] next ticket, [2] items published and not finished
   size_t tree_lds = 0;           // largest nf x (n | 1) of a clique: doubles of LDS the wildfire kernel stages
@@ -573,24 +574,27 @@ __global__ __launch_bounds__(256) void isam2_tree_patch_kernel(const int32_t* __
 // Progress: tickets and queue slots are both handed out in increasing order, an entry is published by a clique that is being processed
 // (counted in wl[2]), and a waiting workgroup leaves when its entry is empty AND wl[2] == 0.  Every spin is bounded.
 // wl: [0] tail (next free queue slot), [1] next ticket, [2] published and unfinished items; the host presets them and the roots.
-__global__ __launch_bounds__(256) void isam2_wildfire_kernel(int32_t* __restrict__ queue, unsigned int* __restrict__ wl,
+__global__ __launch_bounds__(256) void isam2_wildfire_kernel(long long* __restrict__ queue, unsigned int* __restrict__ wl,
                                                               const lmgpu::FrontDesc* __restrict__ tree, const int32_t* __restrict__ tree_fx,
                                                               const int32_t* __restrict__ tree_sx, const double* __restrict__ pool,
                                                               double* __restrict__ delta, const unsigned char* __restrict__ replaced,
                                                               unsigned char* __restrict__ changed, double threshold, int* __restrict__ status,
-                                                              unsigned char epoch, int* __restrict__ relay) {
+                                                              unsigned char epoch, int* __restrict__ relay, unsigned char* __restrict__ done) {
   extern __shared__ double Ls[];
-  __shared__ int s_id, flag;
+  __shared__ int s_id, s_par, flag;
   __shared__ double red[4];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   for (;;) {
     if (tid == 0) {
       const unsigned int my = atomicAdd(&wl[1], 1u);
-      int id;
+      int id, par = -1;
       long spins = 0;
       for (;;) {
-        id = __hip_atomic_load(&queue[my], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (id >= 0) break;
+        const long long ent = __hip_atomic_load(&queue[my], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        id = (int)(ent & 0xffffffffLL);
+        par = (int)(ent >> 32);
+        if (ent != -1LL) break;
+        id = -1;
         if (__hip_atomic_load(&wl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
           id = -2;  // nothing is being processed and nothing is queued: the walk is over
           break;
@@ -601,11 +605,9 @@ __global__ __launch_bounds__(256) void isam2_wildfire_kernel(int32_t* __restrict
           break;
         }
       }
-      if (id >= 0) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the parent's delta / changed flags
-        __hip_atomic_store(&queue[my], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the slot is clean for the next launch
-      }
+      if (id >= 0) __hip_atomic_store(&queue[my], -1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the slot is clean for the next launch
       s_id = id;
+      s_par = par;
     }
     __syncthreads();
     const int id = s_id;
@@ -628,14 +630,49 @@ __global__ __launch_bounds__(256) void isam2_wildfire_kernel(int32_t* __restrict
     const int32_t* sxr = wide ? fxr + nf : tree_sx + (size_t)id * ISAM2_TREE_ROW;
     const int so = ns > 0 ? sxr[min(tid, ns - 1)] : 0, fo = fxr[min(tid, nf - 1)];
     const bool is_replaced = replaced[fxr[0]] == epoch;
-    if (tid == 0) flag = (threshold <= 0.0 || is_replaced) ? 1 : 0;
+    // A clique is queued by its parent as soon as the parent knows it is dirty, BEFORE the parent solves: the child's descriptor chain
+    // (queue -> clique -> offsets -> flags) and the staging of its [R S d] run under the parent's solve; what depends on the parent -- the
+    // changed flags of the separator, x_S -- waits for the parent's done flag (the epoch of this walk).  The hand-off between two levels was
+    // ten dependent round trips (7.8 us per level of a chain of small cliques); now the parent's publish and the child's x_S.
+    const int par = s_par;
+    if (!wide) lmgpu::ldsb_stage(F, pool, Ls, tid);
+    if (tid == 0) {
+      int ok = 1;
+      if (par >= 0) {
+        long spins = 0;
+        while (__hip_atomic_load(&done[par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > 4000000L) {
+            ok = 0;
+            break;
+          }
+        }
+      }
+      if (!ok) atomicMin(status, -1);  // never expected: spin bound hit (reported as a fault by the host)
+      flag = (threshold <= 0.0 || is_replaced) ? 1 : 0;
+    }
     __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the parent's delta / changed flags
+    const double xs_pre = delta[ns > 0 ? so : fo];  // (in flight together with the changed flags below: one round trip, not two)
     if (!(threshold <= 0.0 || is_replaced)) {
       for (int j = tid; j < ns; j += 256)
         if (changed[sxr[j]] == epoch) flag = 1;  // benign race: every writer stores 1
       __syncthreads();
     }
     const bool dirty = flag != 0;  // workgroup-uniform
+    // the children (a dirty clique's only) are queued now, with this clique as the parent they wait for
+    const int nk = dirty ? F.child_count : 0;
+    if (nk > 0) {
+      if (tid == 0) {
+        atomicAdd(&wl[2], (unsigned int)nk);
+        s_id = (int)atomicAdd(&wl[0], (unsigned int)nk);
+      }
+      __syncthreads();
+      const int32_t* kids = (const int32_t*)(pool + F.child_begin);
+      for (int k = tid; k < nk; k += 256)
+        __hip_atomic_store(&queue[(unsigned int)s_id + k], (long long)(unsigned int)kids[k] | (long long)(unsigned int)id << 32, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (dirty && wide) {
       // A clique too wide for the LDS staging (rare: loop closures of large graphs): x_S and y in LDS, R / S streamed from memory by this
       // one workgroup -- y = d - S x_S one wave per row, then 64 unknowns at a time (the diagonal block staged in LDS, the readlane
@@ -709,9 +746,8 @@ __global__ __launch_bounds__(256) void isam2_wildfire_kernel(int32_t* __restrict
           changed[xo] = epoch;
         }
     } else if (dirty) {
-      lmgpu::ldsb_stage(F, pool, Ls, tid);
       bool bad;
-      const double* x = lmgpu::ldsb_solve_core(F, Ls, ns > 0 ? so : fo, delta, &bad);
+      const double* x = lmgpu::ldsb_solve_core(F, Ls, ns > 0 ? so : fo, delta, &bad, nullptr, &xs_pre);
       double md = 0.0;
       if (tid < nf) md = fabs(delta[fo] - x[tid]);
 #pragma unroll
@@ -726,27 +762,14 @@ __global__ __launch_bounds__(256) void isam2_wildfire_kernel(int32_t* __restrict
         changed[fo] = epoch;
       }
     }
-    // hand over: every wave's stores have been performed, then the children (a dirty clique's only) and the count
+    // done: every wave's stores have been performed, then one release + the flag the children wait for
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int nk = dirty ? F.child_count : 0;
-    unsigned int base = 0;
     if (tid == 0) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (nk > 0) {
-        atomicAdd(&wl[2], (unsigned int)nk);
-        base = atomicAdd(&wl[0], (unsigned int)nk);
-      }
-      s_id = (int)base;
+      __hip_atomic_store(&done[id], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();
-    if (nk > 0) {
-      const int32_t* kids = (const int32_t*)(pool + F.child_begin);
-      for (int k = tid; k < nk; k += 256) __hip_atomic_store(&queue[(unsigned int)s_id + k], kids[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
     if (tid == 0) atomicSub(&wl[2], 1u);  // this item is finished (its children, if any, are counted already)
     __syncthreads();
   }
@@ -942,12 +965,14 @@ int is_patch_tree(lmgpu_isam2* S) {
     if ((rc = is_realloc(S, &S->d_tree, cap, S->tree_slots))) return rc;
     if ((rc = is_realloc(S, &S->d_tree_fx, cap * ISAM2_TREE_ROW, S->tree_slots * ISAM2_TREE_ROW))) return rc;
     if ((rc = is_realloc(S, &S->d_tree_sx, cap * ISAM2_TREE_ROW, S->tree_slots * ISAM2_TREE_ROW))) return rc;
+    if ((rc = is_realloc(S, &S->d_tree_done, cap, 0))) return rc;
+    ISCHECK(hipMemsetAsync(S->d_tree_done, 0, cap, S->stream));  // (epochs: a fresh array must not hold the current one)
     S->tree_slots = cap;
   }
   if (NC + ISAM2_WL_GROUPS + 1 > S->queue_cap) {  // every clique once + the tickets of the workgroups that find nothing
     const size_t cap = is_next_cap(S->queue_cap, NC + ISAM2_WL_GROUPS + 1);
     if ((rc = is_realloc(S, &S->d_queue, cap, 0))) return rc;
-    ISCHECK(hipMemsetAsync(S->d_queue, 0xff, cap * sizeof(int32_t), S->stream));  // all slots "not published"; consumers keep it that way
+    ISCHECK(hipMemsetAsync(S->d_queue, 0xff, cap * sizeof(long long), S->stream));  // all slots "not published"; consumers keep it that way
     S->queue_cap = cap;
   }
   if (!S->d_wl) ISCHECK(hipMalloc((void**)&S->d_wl, 4 * sizeof(unsigned int)));
@@ -1039,19 +1064,22 @@ int is_update_delta_enqueue(lmgpu_isam2* S, bool force_full, bool host_delta, do
     const unsigned int r = (unsigned int)S->roots.size();
     const unsigned int ctl[4] = {r, 0u, r, 0u};
     const int32_t fresh = 0x7f7f7f7f;
-    if ((rc = is_push(S, S->d_queue, S->roots.data(), r * sizeof(int32_t)))) return rc;
+    std::vector<long long> seeds(r);
+    for (unsigned int q = 0; q < r; q++) seeds[q] = (long long)(unsigned int)S->roots[q] | (long long)0xffffffffu << 32;  // (no parent)
+    if ((rc = is_push(S, S->d_queue, seeds.data(), r * sizeof(long long)))) return rc;
     if ((rc = is_push(S, S->d_wl, ctl, sizeof(ctl)))) return rc;
     if ((rc = is_push(S, S->d_status, &fresh, sizeof(fresh)))) return rc;
     if ((rc = is_flush(S))) return rc;
     hipLaunchKernelGGL(isam2_wildfire_kernel, dim3(ISAM2_WL_GROUPS), dim3(256), (S->tree_lds + LDSB_TAIL) * sizeof(double), S->stream, S->d_queue, S->d_wl,
                        (const FrontDesc*)S->d_tree, (const int32_t*)S->d_tree_fx, (const int32_t*)S->d_tree_sx, (const double*)S->pool, wf_delta,
-                       (const unsigned char*)S->d_replaced, S->d_changed, thr, S->d_status, S->epoch, S->h_status_dev);
+                       (const unsigned char*)S->d_replaced, S->d_changed, thr, S->d_status, S->epoch, S->h_status_dev, S->d_tree_done);
     ISCHECK(hipGetLastError());
   }
   if (++S->epoch == 0) {  // wrapped: start over from clean arrays
     S->epoch = 1;
     ISCHECK(hipMemsetAsync(S->d_changed, 0, (size_t)S->ntot_cap, S->stream));
     ISCHECK(hipMemsetAsync(S->d_replaced, 0, (size_t)S->ntot_cap, S->stream));
+    if (S->d_tree_done) ISCHECK(hipMemsetAsync(S->d_tree_done, 0, S->tree_slots, S->stream));
   }
   if (host_delta && !target) {
     if ((size_t)S->ntot > S->h_delta_cap) {
@@ -2581,7 +2609,7 @@ int lmgpu_isam2_destroy(lmgpu_isam2* S) {
       if (b.d_noise) (void)hipFree(b.d_noise);
     }
     for (void* p : {(void*)S->delta, (void*)S->ones, (void*)S->d_replaced, (void*)S->d_changed, (void*)S->pool, (void*)S->d_status, (void*)S->d_gpart, (void*)S->d_tree,
-                    (void*)S->d_tree_fx, (void*)S->d_tree_sx, (void*)S->d_queue, (void*)S->d_wl, (void*)S->inv16, (void*)S->d_eticket, (void*)S->d_marg, (void*)S->d_ebuf,
+                    (void*)S->d_tree_fx, (void*)S->d_tree_sx, (void*)S->d_tree_done, (void*)S->d_queue, (void*)S->d_wl, (void*)S->inv16, (void*)S->d_eticket, (void*)S->d_marg, (void*)S->d_ebuf,
                     (void*)S->d_epart, (void*)S->delta_newton, (void*)S->rgprod, (void*)S->grad, (void*)S->dx_u, (void*)S->d_cerr, (void*)S->d_dlscal})
       if (p) (void)hipFree(p);
     if (S->h_status) (void)hipHostFree(S->h_status);

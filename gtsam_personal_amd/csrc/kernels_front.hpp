@@ -1066,7 +1066,7 @@ __device__ __forceinline__ void ldsb_stage(const FrontDesc& F, const double* __r
 // fence: the hand-off is one store and one load).  *timed_out: the bounded spin gave up (never expected).
 template <bool POLL = false>
 __device__ __forceinline__ double* ldsb_solve_core(const FrontDesc& F, double* Ls, int so, const double* __restrict__ delta, bool* bad_out,
-                                                   bool* timed_out = nullptr) {
+                                                   bool* timed_out = nullptr, const double* xv_pre = nullptr /* this thread's x_S value, already fetched */) {
   const int n = F.n, nf = F.nf, ns = n - nf - 1, nl = n | 1;
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   double* xsl = Ls + (size_t)nf * nl;  // [144]
@@ -1086,7 +1086,7 @@ __device__ __forceinline__ double* ldsb_solve_core(const FrontDesc& F, double* L
     }
     xv = __longlong_as_double((long long)bits);
   } else {
-    xv = delta[so];
+    xv = xv_pre ? *xv_pre : delta[so];
   }
   if (tid < ns) xsl[tid] = xv;
   __syncthreads();  // Ls and x_S in LDS
