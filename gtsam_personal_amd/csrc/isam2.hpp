@@ -219,6 +219,15 @@ __global__ __launch_bounds__(256) void isam2_scatter_kernel(const lmgpu_isam2::P
   const lmgpu_isam2::PushRec r = recs[blockIdx.x];
   uint32_t* dst = (uint32_t*)r.dst;
   const uint32_t* src = (const uint32_t*)r.src;
+  if (r.pad == 1) {  // a fill with the all-ones pattern ("not published yet": the update matrices of a merged elimination launch)
+    for (uint32_t w = threadIdx.x; w < r.words; w += 256) dst[w] = 0xffffffffu;
+    return;
+  }
+  if (r.pad == 2) {  // `words` BYTES set to the value carried in src (deltaReplacedMask_ |= affected keys: the walk's epoch)
+    const unsigned char v = (unsigned char)(uintptr_t)r.src;
+    for (uint32_t w = threadIdx.x; w < r.words; w += 256) ((unsigned char*)r.dst)[w] = v;
+    return;
+  }
   for (uint32_t w = threadIdx.x; w < r.words; w += 256) dst[w] = src[w];
 }
 
@@ -350,6 +359,21 @@ int is_push(lmgpu_isam2* S, void* dst, const void* src, size_t bytes) {
 // Called before anything that consumes staged tables or pushed arrays is launched (and before an array a push points into moves).
 int is_flush(lmgpu_isam2* S) {
   const lmgpu_isam2::PushRec* d_recs = nullptr;
+  if (S->stage_copy_mark > S->stage_flushed) {
+    // device-arena tables staged since the last flush: carried by the scatter kernel too (records of 16 KB: it reads the pinned arena in
+    // place) -- a copy command of its own was one more dependent device operation per update
+    const size_t bytes = (S->stage_copy_mark - S->stage_flushed + 3) & ~size_t(3);
+    if (bytes <= (size_t(1) << 20)) {
+      for (size_t o = 0; o < bytes; o += 16384) {
+        const size_t nb = std::min<size_t>(16384, bytes - o);
+        S->pushes.push_back(lmgpu_isam2::PushRec{S->d_stage + S->stage_flushed + o, S->h_stage + S->stage_flushed + o, (uint32_t)(nb >> 2), 0u});
+      }
+    } else {  // (a batch step's tables: the copy engine)
+      ISCHECK(hipMemcpyAsync(S->d_stage + S->stage_flushed, S->h_stage + S->stage_flushed, S->stage_copy_mark - S->stage_flushed, hipMemcpyHostToDevice,
+                             S->stream));
+    }
+    S->stage_flushed = S->stage_copy_mark;
+  }
   const size_t npush = S->pushes.size();
   bool recs_in_arena = true;
   if (npush) {
@@ -361,11 +385,6 @@ int is_flush(lmgpu_isam2* S) {
     S->pushes.clear();
   }
   (void)recs_in_arena;
-  if (S->stage_copy_mark > S->stage_flushed) {  // device-arena tables staged since the last flush
-    ISCHECK(hipMemcpyAsync(S->d_stage + S->stage_flushed, S->h_stage + S->stage_flushed, S->stage_copy_mark - S->stage_flushed, hipMemcpyHostToDevice,
-                           S->stream));
-    S->stage_flushed = S->stage_copy_mark;
-  }
   if (npush) hipLaunchKernelGGL(isam2_scatter_kernel, dim3((unsigned)npush), dim3(256), 0, S->stream, d_recs);
   return LMGPU_OK;
 }
@@ -978,8 +997,9 @@ int is_patch_tree(lmgpu_isam2* S) {
   if (!S->d_wl) ISCHECK(hipMalloc((void**)&S->d_wl, 4 * sizeof(unsigned int)));
   std::sort(S->touched.begin(), S->touched.end());
   S->touched.erase(std::unique(S->touched.begin(), S->touched.end()), S->touched.end());
-  std::vector<int32_t> ids, fx, sx, kids, kids_begin, xrow_begin;
-  std::vector<FrontDesc> td;
+  // the descriptors of the touched cliques travel as pushes of the next flush (the scatter kernel that also seeds the walk): the descriptor,
+  // the delta offsets of its frontal and separator scalars (fixed-stride rows; a wide clique: an array of its own in the pool), its children
+  std::vector<int32_t> row;
   for (int32_t id : S->touched) {
     lmgpu_isam2::Clq& c = S->clq[id];
     if (!c.alive) continue;
@@ -989,6 +1009,11 @@ int is_patch_tree(lmgpu_isam2* S) {
     }
     c.kids_n = (int)c.children.size();
     if (c.kids_n > 0 && c.kids_off < 0 && (rc = is_pool_alloc(S, (size_t)(c.kids_n + 1) / 2, &c.kids_off))) return rc;
+    if (c.ld > 0 && c.xrow_off < 0 && (rc = is_pool_alloc(S, (size_t)c.n / 2 + 1, &c.xrow_off))) return rc;
+  }
+  for (int32_t id : S->touched) {  // (second pass: the pool may have moved while the first one allocated)
+    lmgpu_isam2::Clq& c = S->clq[id];
+    if (!c.alive) continue;
     if (c.kids_off > (int64_t)INT32_MAX) {
       S->err = "ISAM2: pool offset beyond the range of a tree descriptor";
       return LMGPU_INVALID;
@@ -1005,41 +1030,27 @@ int is_patch_tree(lmgpu_isam2* S) {
       S->tree_lds = std::max(S->tree_lds, (size_t)c.n + 64 * 65 + 64);
     else
       S->tree_lds = std::max(S->tree_lds, (size_t)c.nf * (size_t)(c.n | 1));
-    const size_t row = ids.size() * ISAM2_TREE_ROW;
-    fx.resize(row + ISAM2_TREE_ROW, 0);
-    sx.resize(row + ISAM2_TREE_ROW, 0);
     if (c.ld == 0) {
-      int o = 0;
+      row.clear();
       for (int k = 0; k < c.nfv; k++)
-        for (int d = 0; d < kVarDim[S->vars[c.vars[k]].type]; d++) fx[row + o++] = S->vars[c.vars[k]].xoff + d;
-      o = 0;
+        for (int d = 0; d < kVarDim[S->vars[c.vars[k]].type]; d++) row.push_back(S->vars[c.vars[k]].xoff + d);
+      if ((rc = is_push(S, S->d_tree_fx + (size_t)id * ISAM2_TREE_ROW, row.data(), row.size() * sizeof(int32_t)))) return rc;
+      row.clear();
       for (size_t k = c.nfv; k < c.vars.size(); k++)
-        for (int d = 0; d < kVarDim[S->vars[c.vars[k]].type]; d++) sx[row + o++] = S->vars[c.vars[k]].xoff + d;
-      xrow_begin.push_back(0);
+        for (int d = 0; d < kVarDim[S->vars[c.vars[k]].type]; d++) row.push_back(S->vars[c.vars[k]].xoff + d);
+      if ((rc = is_push(S, S->d_tree_sx + (size_t)id * ISAM2_TREE_ROW, row.data(), row.size() * sizeof(int32_t)))) return rc;
     } else {
-      if (c.xrow_off < 0 && (rc = is_pool_alloc(S, (size_t)c.n / 2 + 1, &c.xrow_off))) return rc;
       F.par_off = c.xrow_off;
       F.par_ld = 1;
-      xrow_begin.push_back((int32_t)kids.size());
+      row.clear();
       for (size_t k = 0; k < c.vars.size(); k++)
-        for (int d = 0; d < kVarDim[S->vars[c.vars[k]].type]; d++) kids.push_back(S->vars[c.vars[k]].xoff + d);
+        for (int d = 0; d < kVarDim[S->vars[c.vars[k]].type]; d++) row.push_back(S->vars[c.vars[k]].xoff + d);
+      if ((rc = is_push(S, S->pool + c.xrow_off, row.data(), row.size() * sizeof(int32_t)))) return rc;
     }
-    kids_begin.push_back((int32_t)kids.size());
-    kids.insert(kids.end(), c.children.begin(), c.children.end());
-    ids.push_back(id);
-    td.push_back(F);
+    if (c.kids_n > 0 && (rc = is_push(S, S->pool + c.kids_off, c.children.data(), c.children.size() * sizeof(int32_t)))) return rc;
+    if ((rc = is_push(S, S->d_tree + id, &F, sizeof(F)))) return rc;
   }
   S->touched.clear();
-  if (ids.empty()) return LMGPU_OK;
-  int32_t *d_ids, *d_fx, *d_sx, *d_kids, *d_kb, *d_xb;
-  FrontDesc* d_td;
-  if ((rc = is_stage(S, ids, &d_ids)) || (rc = is_stage(S, td, &d_td)) || (rc = is_stage(S, fx, &d_fx)) || (rc = is_stage(S, sx, &d_sx)) ||
-      (rc = is_stage(S, kids, &d_kids)) || (rc = is_stage(S, kids_begin, &d_kb)) || (rc = is_stage(S, xrow_begin, &d_xb)))
-    return rc;
-  if ((rc = is_flush(S))) return rc;
-  hipLaunchKernelGGL(isam2_tree_patch_kernel, dim3((unsigned)ids.size()), dim3(256), 0, S->stream, (const int32_t*)d_ids, (const FrontDesc*)d_td,
-                     (const int32_t*)d_fx, (const int32_t*)d_sx, (const int32_t*)d_kids, (const int32_t*)d_kb, (const int32_t*)d_xb, S->d_tree,
-                     S->d_tree_fx, S->d_tree_sx, S->pool);
   return LMGPU_OK;
 }
 
@@ -1364,13 +1375,13 @@ int is_eliminate_fronts(lmgpu_isam2* S, const std::vector<IsGF>& gfs, const std:
   // the city10000 loop two to five, each a dependent launch of a few workgroups.
   bool any_wide = false;
   for (int l = 0; l <= max_level; l++) any_wide = any_wide || !wide[l].empty();
-  const bool merged = !any_wide && max_level >= 1 && list.size() <= 4096 && !dev_switch("LMGPU_ISAM2_NO_MERGE");
-  FillUpper* d_fu = nullptr;
+  const bool merged = !any_wide && list.size() <= 4096 && !dev_switch("LMGPU_ISAM2_NO_MERGE");  // (a single level too: the launch relays the status)
   int m_nmax = 1, m_jc = 96;
   if (merged) {
-    std::vector<FillUpper> fu;
     for (int32_t fi : list) {
-      fu.push_back(FillUpper{fds[fi].u_off, fds[fi].n - fds[fi].nf, fds[fi].ld_u});
+      // "not published yet" over the clique's update matrix: a fill record of the flush's scatter kernel (LDS cliques: a dense block of its own)
+      const int mm = fds[fi].n - fds[fi].nf;
+      S->pushes.push_back(lmgpu_isam2::PushRec{S->pool + fds[fi].u_off, nullptr, (uint32_t)(2 * mm * mm), 1u});
       m_nmax = std::max(m_nmax, fds[fi].n);
       int tot = 0;
       for (int k = 0; k < fds[fi].fac_count; k++) {
@@ -1379,26 +1390,25 @@ int is_eliminate_fronts(lmgpu_isam2* S, const std::vector<IsGF>& gfs, const std:
       }
       m_jc = std::max(m_jc, std::min(tot, LDSF_JCAP));
     }
-    if ((rc = is_stage(S, fu, &d_fu))) return rc;
-    if (!S->d_eticket) ISCHECK(hipMalloc((void**)&S->d_eticket, sizeof(unsigned int)));
-    const unsigned int zero = 0u;
-    if ((rc = is_push(S, S->d_eticket, &zero, sizeof(zero)))) return rc;
+    if (!S->d_eticket) ISCHECK(hipMalloc((void**)&S->d_eticket, 2 * sizeof(unsigned int)));
+    const unsigned int zero[2] = {0u, 0u};  // the ticket counter, the count of finished workgroups
+    if ((rc = is_push(S, S->d_eticket, zero, sizeof(zero)))) return rc;
   }
+  *S->h_status = 0x7f7f7f7f;  // (before the launch that may relay the status word)
   if ((rc = is_flush(S))) return rc;  // the tables above, and whatever the update pushed before (new values, factor rows)
   if (merged) {
     const int jcap = (m_jc + 7) & ~7;
     const size_t lds = kLdsFrontExtra - (size_t)(LDSF_JCAP - jcap) * 8 + 64 + (size_t)m_nmax * m_nmax * sizeof(double);
-    hipLaunchKernelGGL(fill_upper_kernel, dim3((unsigned)list.size()), dim3(256), 0, S->stream, (const FillUpper*)d_fu, S->pool);
     if (m_nmax > 72)
       hipLaunchKernelGGL(lds_front_merged_kernel<1024>, dim3((unsigned)list.size()), dim3(1024), lds, S->stream, (const int32_t*)d_list, 0, (int)list.size(),
                          (const FrontDesc*)d_fds, (const FrontFac*)d_ffac, (const FacDesc*)d_fd, (const ChildRef*)d_childs, (const int32_t*)d_cmap,
                          (const int32_t*)d_fxoff, S->pool, 0.0, (const double*)nullptr, (const double*)S->ones, S->d_status, m_nmax, jcap,
-                         (const double*)nullptr, S->d_eticket);
+                         (const double*)nullptr, S->d_eticket, S->h_status_dev);
     else
       hipLaunchKernelGGL(lds_front_merged_kernel<256>, dim3((unsigned)list.size()), dim3(m_nmax <= 24 ? 64 : (m_nmax <= 48 ? 128 : 256)), lds, S->stream,
                          (const int32_t*)d_list, 0, (int)list.size(), (const FrontDesc*)d_fds, (const FrontFac*)d_ffac, (const FacDesc*)d_fd,
                          (const ChildRef*)d_childs, (const int32_t*)d_cmap, (const int32_t*)d_fxoff, S->pool, 0.0, (const double*)nullptr,
-                         (const double*)S->ones, S->d_status, m_nmax, jcap, (const double*)nullptr, S->d_eticket);
+                         (const double*)S->ones, S->d_status, m_nmax, jcap, (const double*)nullptr, S->d_eticket, S->h_status_dev);
   }
   for (int l = 0; l <= max_level && !merged; l++) {
     for (int32_t fi : wide[l]) {  // (the level's LDS fronts and these only depend on the levels below)
@@ -1454,8 +1464,7 @@ int is_eliminate_fronts(lmgpu_isam2* S, const std::vector<IsGF>& gfs, const std:
   }
   // the status word comes back with the one wait that ends the update (is_finish_elimination): the mark kernel, the last launch of an
   // update that eliminated anything, relays it into the host's pinned word
-  *S->h_status = 0x7f7f7f7f;
-  S->elim_relay_pending = true;
+  S->elim_relay_pending = !merged;  // (the merged launch hands the status to the host itself)
   S->elim_cid = cid;
   S->elim_pending = true;
   return LMGPU_OK;
@@ -2097,6 +2106,14 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
     for (int id : bn) is_release_clique(S, id);
 
     std::set<int32_t> affectedSet;
+    // deltaReplacedMask_ |= affectedKeysSet: byte fills carried by the scatter kernel of the flush in front of the elimination
+    auto push_marks = [&]() {
+      for (int32_t v : affectedSet) {
+        if (unusedKeys.count(S->vars[v].key)) continue;  // leaves the system below
+        S->replaced[v] = 1;
+        S->pushes.push_back(lmgpu_isam2::PushRec{S->d_replaced + S->vars[v].xoff, (const void*)(uintptr_t)S->epoch, (uint32_t)kVarDim[S->vars[v].type], 2u});
+      }
+    };
     if ((double)affected.size() >= (double)S->vid_of.size() * 0.65) {
       // ---- recalculateBatch :178-247: reorder, relinearize and re-eliminate everything
       res.batch = 1;
@@ -2140,9 +2157,10 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
         gfs[i].vids = is_fac_vids(S, S->facs[i]);
       }
       lap(1);  // (batch: relinearization of everything counts with the linearize phase)
+      for (int32_t v : vids) affectedSet.insert(v);
+      push_marks();
       if ((rc = is_eliminate(S, gfs, vids, perm, &cols))) return rc;  // (variableIndex_ as it stands: GaussianEliminationTree(*linearized, affectedFactorsVarIndex, order))
       lap(4);
-      for (int32_t v : vids) affectedSet.insert(v);
       res.variablesReeliminated = (int32_t)vids.size();
       res.factorsRecalculated = (int32_t)S->facs.size();
     } else {
@@ -2212,23 +2230,10 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
       lap(2);  // removeTop, affected factors, variable index
       if ((rc = is_colamd(S, vids, cols, (int)gfs.size(), groups, &perm))) return rc;
       lap(3);  // constrained COLAMD callback
+      push_marks();
       if ((rc = is_eliminate(S, gfs, vids, perm))) return rc;
       lap(4);  // symbolic elimination, tables, launches
     }
-    // deltaReplacedMask_ |= affectedKeysSet
-    std::vector<int32_t> marks;  // (xoff, dim) pairs
-    for (int32_t v : affectedSet) {
-      if (unusedKeys.count(S->vars[v].key)) continue;  // leaves the system below
-      S->replaced[v] = 1;
-      marks.push_back(S->vars[v].xoff);
-      marks.push_back(kVarDim[S->vars[v].type]);
-    }
-    if ((rc = is_with_list(S, marks, [&](const int32_t* d, int cnt) {
-           hipLaunchKernelGGL(isam2_mark_kernel, dim3((cnt / 2 + 255) / 256), dim3(256), 0, S->stream, d, cnt / 2, S->d_replaced, S->epoch,
-                              (const int*)S->d_status, S->elim_relay_pending ? S->h_status_dev : (int*)nullptr);
-           S->elim_relay_pending = false;
-         })))
-      return rc;
     S->any_replaced = S->any_replaced || !affectedSet.empty();
   }
   // ---- removeVariables (ISAM2.cpp:385-398): the variable leaves theta / delta / the variable index; its storage is not reused

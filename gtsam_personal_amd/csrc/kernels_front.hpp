@@ -914,12 +914,26 @@ __global__ __launch_bounds__(MAXT) void lds_front_merged_kernel(const int32_t* _
                                                                 const ChildRef* __restrict__ childs, const int32_t* __restrict__ cmap,
                                                                 const int32_t* __restrict__ fxoff, double* __restrict__ pool, double lambda_v,
                                                                 const double* __restrict__ lambda_p, const double* __restrict__ dampw, int* __restrict__ status,
-                                                                int nmax, int jcap, const double* __restrict__ gex, unsigned int* __restrict__ ticket) {
+                                                                int nmax, int jcap, const double* __restrict__ gex, unsigned int* __restrict__ ticket,
+                                                                int* __restrict__ relay = nullptr) {
   __shared__ int s_ticket;
   if (threadIdx.x == 0) s_ticket = (int)atomicAdd(ticket, 1u);
   __syncthreads();
   lds_front_body<false, MAXT, true>(seg_begin + s_ticket, list, fronts, ffac, fd, childs, cmap, fxoff, pool, lambda_v, lambda_p, dampw, status, nmax, nmax,
                                     (double*)nullptr, jcap, gex, (const char*)nullptr, 0, FrontFlow{seg_begin, seg_end});
+  // relay (ISAM2): the last workgroup to finish hands the status word to the host's pinned word (ticket[1] counts the finished ones; the
+  // host resets it with the ticket) -- a kernel or a copy command of its own did that before
+  if (relay) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if (atomicAdd(ticket + 1, 1u) == gridDim.x - 1) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(relay, __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
 }
 
 // back-substitution for LDS-class fronts with at most LDSB_SMALL_NF frontal scalars (leaves and the levels just above them: the host
