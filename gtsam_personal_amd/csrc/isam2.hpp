@@ -180,6 +180,7 @@ struct lmgpu_isam2 {
   size_t stage_copy_mark = 0;
   unsigned char epoch = 1;  // value that means 'set' in d_replaced / d_changed for the NEXT back-substitution (no clears between them)
   int* h_status_dev = nullptr;  // device-side address of the pinned status word: the last kernel of a phase relays the status there
+  double *h_val = nullptr, *h_val_dev = nullptr;  // pinned + mapped: calculateEstimate(key) is retracted straight into it (no copy command)
   struct PushRec {
     void* dst;
     const void* src;  // in the device arena
@@ -2583,6 +2584,8 @@ int lmgpu_isam2_create(const lmgpu_config* cfg, const lmgpu_isam2_params* prm, l
   ISCHECK(hipMalloc((void**)&S->d_status, sizeof(int)));
   ISCHECK(hipHostMalloc((void**)&S->h_status, sizeof(int), hipHostMallocMapped));
   ISCHECK(hipHostGetDevicePointer((void**)&S->h_status_dev, S->h_status, 0));
+  ISCHECK(hipHostMalloc((void**)&S->h_val, 32 * sizeof(double), hipHostMallocMapped));
+  ISCHECK(hipHostGetDevicePointer((void**)&S->h_val_dev, S->h_val, 0));
   ISCHECK(hipFuncSetAttribute((const void*)lds_front_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra + 64));
   ISCHECK(hipFuncSetAttribute((const void*)lds_front_kernel<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra + 64));
   ISCHECK(hipFuncSetAttribute((const void*)lds_front_merged_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitN * kLdsLimitN * 8 + kLdsFrontExtra + 64));
@@ -2618,6 +2621,7 @@ int lmgpu_isam2_destroy(lmgpu_isam2* S) {
                     (void*)S->d_epart, (void*)S->delta_newton, (void*)S->rgprod, (void*)S->grad, (void*)S->dx_u, (void*)S->d_cerr, (void*)S->d_dlscal})
       if (p) (void)hipFree(p);
     if (S->h_status) (void)hipHostFree(S->h_status);
+    if (S->h_val) (void)hipHostFree(S->h_val);
     if (S->h_delta) (void)hipHostFree(S->h_delta);
     if (S->h_escal) (void)hipHostFree(S->h_escal);
     if (S->h_dlscal) (void)hipHostFree(S->h_dlscal);
@@ -2942,22 +2946,24 @@ int lmgpu_isam2_get_value(lmgpu_isam2* S, int32_t which, uint64_t key, int32_t* 
   if (walk && (rc = is_update_delta_enqueue(S, false, false))) return rc;
   const lmgpu_isam2::Var& v = S->vars[it->second];
   const int t = v.type;
-  const double* src = S->theta[t];
   if (which == 0) {
+    // retracted by one thread straight into pinned host memory (the kernel's output pointer is placed so that THIS variable's slot is the
+    // buffer): no copy command behind it
     const std::vector<int32_t> one{v.tidx};
     if ((rc = is_with_list(S, one, [&](const int32_t* d, int cnt) {
-           hipLaunchKernelGGL(retract_kernel, dim3(1), dim3(256), 0, S->stream, t, cnt, (const double*)S->theta[t], S->est[t],
-                              (const int32_t*)S->d_type_xoff[t], (const double*)S->delta, d);
+           hipLaunchKernelGGL(retract_kernel, dim3(1), dim3(256), 0, S->stream, t, cnt, (const double*)S->theta[t],
+                              S->h_val_dev - (size_t)v.tidx * kVarStore[t], (const int32_t*)S->d_type_xoff[t], (const double*)S->delta, d);
          })))
       return rc;
-    src = S->est[t];
+  } else {
+    ISCHECK(hipMemcpyAsync(S->h_val, S->theta[t] + (size_t)v.tidx * kVarStore[t], kVarStore[t] * sizeof(double), hipMemcpyDeviceToHost, S->stream));
   }
-  ISCHECK(hipMemcpyAsync(packed_out, src + (size_t)v.tidx * kVarStore[t], kVarStore[t] * sizeof(double), hipMemcpyDeviceToHost, S->stream));
   if (walk) {  // the one wait of this call, and the status of the back-substitution
     if ((rc = is_update_delta_finish(S))) return rc;
   } else {
     ISCHECK(hipStreamSynchronize(S->stream));
   }
+  std::memcpy(packed_out, S->h_val, kVarStore[t] * sizeof(double));
   if (type_out) *type_out = t;
   return LMGPU_OK;
 }
