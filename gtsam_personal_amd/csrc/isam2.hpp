@@ -1406,7 +1406,9 @@ int is_eliminate_fronts(lmgpu_isam2* S, const std::vector<IsGF>& gfs, const std:
                          (const int32_t*)d_fxoff, S->pool, 0.0, (const double*)nullptr, (const double*)S->ones, S->d_status, m_nmax, jcap,
                          (const double*)nullptr, S->d_eticket, S->h_status_dev);
     else
-      hipLaunchKernelGGL(lds_front_merged_kernel<256>, dim3((unsigned)list.size()), dim3(m_nmax <= 24 ? 64 : (m_nmax <= 48 ? 128 : 256)), lds, S->stream,
+      // (four waves unless every clique takes the one-wave register path: the blocked Cholesky of the LDS body needs four -- with two, the 30-40
+      //  pivots of VisualISAM2Example's root clique were taken one by one: 33 of the 100 us its launch took)
+      hipLaunchKernelGGL(lds_front_merged_kernel<256>, dim3((unsigned)list.size()), dim3(m_nmax <= 16 ? 64 : 256), lds, S->stream,
                          (const int32_t*)d_list, 0, (int)list.size(), (const FrontDesc*)d_fds, (const FrontFac*)d_ffac, (const FacDesc*)d_fd,
                          (const ChildRef*)d_childs, (const int32_t*)d_cmap, (const int32_t*)d_fxoff, S->pool, 0.0, (const double*)nullptr,
                          (const double*)S->ones, S->d_status, m_nmax, jcap, (const double*)nullptr, S->d_eticket, S->h_status_dev);
@@ -1450,7 +1452,7 @@ int is_eliminate_fronts(lmgpu_isam2* S, const std::vector<IsGF>& gfs, const std:
       jc = std::max(jc, std::min(tot, LDSF_JCAP));
     }
     const int jcap = (jc + 7) & ~7;
-    const int threads = nmax <= 24 ? 64 : (nmax <= 48 ? 128 : 256);
+    const int threads = nmax <= 24 ? 64 : 256;
     const size_t lds = kLdsFrontExtra - (size_t)(LDSF_JCAP - jcap) * 8 + 64 + (size_t)nmax * nmax * sizeof(double);
     if (nmax > 72 && lv[l].second <= 256)  // a handful of wide cliques: sixteen waves each (the batch path's rule)
       hipLaunchKernelGGL((lds_front_kernel<false, 1024>), dim3(lv[l].second), dim3(1024), lds, S->stream, (const int32_t*)(d_list + lv[l].first),

@@ -56,6 +56,22 @@ __device__ __forceinline__ int frexp_exp(double x) {
   return e;
 }
 
+// r = sqrt(piv) and inv = 1 / r for a pivot of the LDS Cholesky (piv > 0, normal): v_rsq_f64 + two Newton steps + one correction of r, a
+// dozen dependent fused multiply-adds instead of the IEEE sqrt and divide sequences (~600 cycles per pivot, and the pivots of a clique are a
+// chain: 48 of them were half of what VisualISAM2Example's root clique costs).  r within an ulp of sqrt(piv); inv = 1 / r to the same.
+__device__ __forceinline__ void pivot_sqrt_inv(double piv, double* r_out, double* inv_out) {
+  double y = __builtin_amdgcn_rsq(piv);
+  const double h = 0.5 * piv;
+  y = y * fma(-h * y, y, 1.5);
+  y = y * fma(-h * y, y, 1.5);
+  double r = piv * y;
+  r = fma(0.5 * y, fma(-r, r, piv), r);
+  // (inv against the corrected r: one more step of 1 / r)
+  y = fma(y, fma(-r, y, 1.0), y);
+  *r_out = r;
+  *inv_out = y;
+}
+
 // staged descriptor of one own factor of the front being assembled
 struct LFac {
   int64_t joff;
@@ -110,8 +126,17 @@ __device__ unsigned long long ldsf_dbg[16];
       ldsf_last = now_;                                                \
     }                                                                  \
   } while (0)
+#define LDSF_STAMP_W1(i)                                               \
+  do {                                                                 \
+    if (LDSF_SAMPLED && threadIdx.x == 64) {                           \
+      const unsigned long long now_ = wall_clock64();                  \
+      atomicAdd(&ldsf_dbg[i], now_ - ldsf_last);                       \
+      ldsf_last = now_;                                                \
+    }                                                                  \
+  } while (0)
 #else
 #define LDSF_STAMP(i) do { } while (0)
+#define LDSF_STAMP_W1(i) do { } while (0)
 #endif
 // A front of at most sixteen columns as ONE wave with the whole front in registers (the 16 x 16 accumulator layout of
 // v_mfma_f64_16x16x4_f64: entry (kk + 4 r, cc) in component r of lane 16 kk + cc): own factors as J^T J on the matrix core, the children's
@@ -228,7 +253,8 @@ __device__ __forceinline__ void lds_front_tiny(const FrontDesc& F, const FrontFa
       if (piv <= 0.0) failed = true;  // Eigen LLT: pivot <= 0 -> NumericalIssue (NaN passes, like Eigen)
       piv = (piv == piv && piv != 0.0) ? fabs(piv) : 1.0;
     }
-    const double r = sqrt(piv), inv = 1.0 / r;
+    double r, inv;
+    pivot_sqrt_inv(piv, &r, &inv);
     dprev = dlast;
     dlast = r;
     const double Rkj = __shfl(rowk, lk + cc) * inv;  // R[k][cc]
@@ -553,7 +579,7 @@ __device__ __forceinline__ void lds_front_body(const int work, const int32_t* __
   // (smaller fronts: the four-pivot groups below -- every thread factors the 4 x 4 block itself; and only the launch forms of upper levels carry
   //  the eight-pivot code: its registers would cost the per-level launches of leaf levels their occupancy)
   constexpr bool kEightOk = EIGHT;
-  const bool eight = kEightOk && nf >= 32;
+  const bool eight = kEightOk && nf >= 12;
   if constexpr (kEightOk)
   if (blocked && eight) {
     typedef double d4_t __attribute__((ext_vector_type(4)));
@@ -586,8 +612,8 @@ __device__ __forceinline__ void lds_front_body(const int work, const int32_t* __
               if (piv <= 0.0) failed = true;  // Eigen LLT: pivot <= 0 -> NumericalIssue (NaN passes, like Eigen)
               piv = (piv == piv && piv != 0.0) ? fabs(piv) : 1.0;
             }
-            const double r = sqrt(piv);
-            inv[q] = 1.0 / r;
+            double r;
+            pivot_sqrt_inv(piv, &r, &inv[q]);
             d[q][q] = r;
 #pragma unroll
             for (int c = q + 1; c < 8; c++) d[q][c] *= inv[q];
@@ -614,6 +640,8 @@ __device__ __forceinline__ void lds_front_body(const int work, const int32_t* __
         }
       }
       __syncthreads();  // the factored block and the reciprocals are in LDS
+      LDSF_STAMP(7);  // (eight-pivot groups) diagonal block by wave 0
+      LDSF_STAMP_W1(11);
       for (int j = k0 + kb + tid; j < n; j += nt) {
         double x[8];
 #pragma unroll
@@ -631,6 +659,8 @@ __device__ __forceinline__ void lds_front_body(const int work, const int32_t* __
           if (q < kb) S[(k0 + q) * n + j] = x[q];
       }
       __syncthreads();
+      LDSF_STAMP(8);  // (eight-pivot groups) panel solve
+      LDSF_STAMP_W1(12);
       const int t0 = k0 + kb;
       const int p0 = k0 & ~15, pend = min(p0 + 16, nf);
       if (t0 < pend) {  // rows t0 .. pend - 1 of the panel, all columns from t0: rank-kb
@@ -656,6 +686,8 @@ __device__ __forceinline__ void lds_front_body(const int work, const int32_t* __
             if (row < pend && col < n && col >= row) S[row * n + col] = c[rr];
           }
         }
+        LDSF_STAMP(9);  // (eight-pivot groups) rank-8 update inside the panel
+        LDSF_STAMP_W1(13);
         continue;
       }
       // the panel p0 .. pend - 1 is finished: everything below it
@@ -690,6 +722,8 @@ __device__ __forceinline__ void lds_front_body(const int work, const int32_t* __
           if (row < n && col < n && col >= row) S[row * n + col] = c[rr];
         }
       }
+      LDSF_STAMP(10);  // (eight-pivot groups) rank-16 update below the panel
+      LDSF_STAMP_W1(14);
     }
   }
   if (blocked && !eight) {
@@ -717,8 +751,8 @@ __device__ __forceinline__ void lds_front_body(const int work, const int32_t* __
             if (piv <= 0.0) failed = true;  // Eigen LLT: pivot <= 0 -> NumericalIssue (NaN passes, like Eigen)
             piv = (piv == piv && piv != 0.0) ? fabs(piv) : 1.0;
           }
-          const double r = sqrt(piv);
-          inv[q] = 1.0 / r;
+          double r;
+          pivot_sqrt_inv(piv, &r, &inv[q]);
           d[q][q] = r;
 #pragma unroll
           for (int c = q + 1; c < 4; c++) d[q][c] *= inv[q];
@@ -838,6 +872,12 @@ __device__ __forceinline__ void lds_front_body(const int work, const int32_t* __
       for (int j = i + lane; j < n; j += 64) S[i * n + j] -= rki * S[k * n + j];
     }
   }
+#ifdef LDSF_STAMPS
+  if (LDSF_SAMPLED && threadIdx.x == 0) {
+    atomicAdd(&ldsf_dbg[6], (unsigned long long)nf * 1000000ull + (unsigned long long)n * 1000ull + (blocked ? 100ull : 0ull) + (eight ? 10ull : 0ull) + 1ull);
+  }
+#endif
+  LDSF_STAMP(5);  // (up to the barrier that ends the Cholesky)
   __syncthreads();
   LDSF_STAMP(3);  // partial Cholesky
   if (tid == 0) {

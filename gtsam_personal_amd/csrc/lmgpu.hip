@@ -1018,7 +1018,7 @@ static bool level_lds_class(const lmgpu_handle* h, int l, int* nmax, int* jcap, 
   *nmax = kBinN[top];
   *jcap = jc;
   const bool wide16 = top >= 3 && cnt_top <= h->wide16_max && !h->no_wide16;
-  *threads = wide16 ? 1024 : (top == 0 ? 64 : (top == 1 ? 128 : 256));
+  *threads = wide16 ? 1024 : (top == 0 ? 64 : 256);  // (four waves from 25 columns on: the blocked Cholesky of the LDS body needs them)
   return true;
 }
 
