@@ -126,17 +126,8 @@ __device__ unsigned long long ldsf_dbg[16];
       ldsf_last = now_;                                                \
     }                                                                  \
   } while (0)
-#define LDSF_STAMP_W1(i)                                               \
-  do {                                                                 \
-    if (LDSF_SAMPLED && threadIdx.x == 64) {                           \
-      const unsigned long long now_ = wall_clock64();                  \
-      atomicAdd(&ldsf_dbg[i], now_ - ldsf_last);                       \
-      ldsf_last = now_;                                                \
-    }                                                                  \
-  } while (0)
 #else
 #define LDSF_STAMP(i) do { } while (0)
-#define LDSF_STAMP_W1(i) do { } while (0)
 #endif
 // A front of at most sixteen columns as ONE wave with the whole front in registers (the 16 x 16 accumulator layout of
 // v_mfma_f64_16x16x4_f64: entry (kk + 4 r, cc) in component r of lane 16 kk + cc): own factors as J^T J on the matrix core, the children's
@@ -641,7 +632,6 @@ __device__ __forceinline__ void lds_front_body(const int work, const int32_t* __
       }
       __syncthreads();  // the factored block and the reciprocals are in LDS
       LDSF_STAMP(7);  // (eight-pivot groups) diagonal block by wave 0
-      LDSF_STAMP_W1(11);
       for (int j = k0 + kb + tid; j < n; j += nt) {
         double x[8];
 #pragma unroll
@@ -660,7 +650,6 @@ __device__ __forceinline__ void lds_front_body(const int work, const int32_t* __
       }
       __syncthreads();
       LDSF_STAMP(8);  // (eight-pivot groups) panel solve
-      LDSF_STAMP_W1(12);
       const int t0 = k0 + kb;
       const int p0 = k0 & ~15, pend = min(p0 + 16, nf);
       if (t0 < pend) {  // rows t0 .. pend - 1 of the panel, all columns from t0: rank-kb
@@ -687,8 +676,7 @@ __device__ __forceinline__ void lds_front_body(const int work, const int32_t* __
           }
         }
         LDSF_STAMP(9);  // (eight-pivot groups) rank-8 update inside the panel
-        LDSF_STAMP_W1(13);
-        continue;
+          continue;
       }
       // the panel p0 .. pend - 1 is finished: everything below it
       const int m = n - pend;
@@ -723,7 +711,6 @@ __device__ __forceinline__ void lds_front_body(const int work, const int32_t* __
         }
       }
       LDSF_STAMP(10);  // (eight-pivot groups) rank-16 update below the panel
-      LDSF_STAMP_W1(14);
     }
   }
   if (blocked && !eight) {
@@ -872,11 +859,6 @@ __device__ __forceinline__ void lds_front_body(const int work, const int32_t* __
       for (int j = i + lane; j < n; j += 64) S[i * n + j] -= rki * S[k * n + j];
     }
   }
-#ifdef LDSF_STAMPS
-  if (LDSF_SAMPLED && threadIdx.x == 0) {
-    atomicAdd(&ldsf_dbg[6], (unsigned long long)nf * 1000000ull + (unsigned long long)n * 1000ull + (blocked ? 100ull : 0ull) + (eight ? 10ull : 0ull) + 1ull);
-  }
-#endif
   LDSF_STAMP(5);  // (up to the barrier that ends the Cholesky)
   __syncthreads();
   LDSF_STAMP(3);  // partial Cholesky

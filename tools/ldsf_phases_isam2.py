@@ -26,8 +26,8 @@ for i, (g, v) in enumerate(steps):
         dbg(out, 1)
     isam.update(g, v)
 dbg(out, 0)
-names = ["descriptors + clear + own factors", "extend-add of the children", "damping", "partial Cholesky (rest: trailing updates)", "emit [R S d] + update matrix", "  (from the last group to the barrier that ends the Cholesky)", "-", "  eight-pivot groups: diagonal block (wave 0)", "  eight-pivot groups: panel solve", "  eight-pivot groups: rank-8 update inside the panel", "  eight-pivot groups: rank-16 update below the panel", "  (wave 1) up to the diagonal block", "  (wave 1) panel solve", "  (wave 1) rank-8 update", "  (wave 1) rank-16 update"]
+names = ["descriptors + clear + own factors", "extend-add of the children", "damping", "partial Cholesky (rest: trailing updates)", "emit [R S d] + update matrix", "  (from the last group to the barrier that ends the Cholesky)", "-", "  eight-pivot groups: diagonal block (wave 0)", "  eight-pivot groups: panel solve", "  eight-pivot groups: rank-8 update inside the panel", "  eight-pivot groups: rank-16 update below the panel"]
 n = out[15]
-print(f"{n} sampled workgroups over the last 4 updates; sum of nf*1e6 + n*1e3 + blocked*100 + eight*10 + 1: {out[6]}")
+print(f"{n} sampled workgroups over the last 4 updates")
 for i, nm in enumerate(names):
     print(f"  {nm:36s} {out[i] * 0.01:9.1f} us total   {out[i] * 0.01 / max(n, 1):6.2f} us per workgroup")
