@@ -542,6 +542,54 @@ void is_linearize_sel(lmgpu_isam2* S, const lmgpu_isam2::Bkt& b, const int32_t* 
   }
 }
 
+// several (bucket, index list) linearizations behind ONE flush and -- for the factor types of the generic kernel -- in ONE launch
+int is_linearize_jobs(lmgpu_isam2* S, const std::vector<std::pair<int, std::vector<int32_t>>>& jobs) {
+  if (jobs.empty()) return LMGPU_OK;
+  std::vector<int32_t*> d(jobs.size(), nullptr);
+  int rc;
+  for (size_t q = 0; q < jobs.size(); q++)
+    if (!jobs[q].second.empty() && (rc = is_stage(S, jobs[q].second, &d[q]))) return rc;
+  if ((rc = is_flush(S))) return rc;
+  ValuesDev vals;
+  for (int t = 0; t < kNumVarTypes; t++) vals.v[t] = S->theta[t];
+  MultiLin ml{};
+  int blocks = 0;
+  auto launch = [&]() {
+    if (ml.nb == 0) return;
+    ml.first[ml.nb] = blocks;
+    hipLaunchKernelGGL(linearize_multi_kernel, dim3(blocks), dim3(128), 0, S->stream, ml, vals);
+    ml = MultiLin{};
+    blocks = 0;
+  };
+  for (size_t q = 0; q < jobs.size(); q++) {
+    const lmgpu_isam2::Bkt& b = S->bkts[jobs[q].first];
+    const int count = (int)jobs[q].second.size();
+    if (count == 0) continue;
+    if (b.type == LMGPU_F_SFM || b.type == LMGPU_F_SFM2) {  // kernels of their own shape
+      is_linearize_sel(S, b, d[q], count);
+      continue;
+    }
+    BucketDev bd;
+    bd.type = b.type;
+    bd.n = count;
+    bd.noise_kind = b.noise_kind;
+    bd.vidx = b.d_vidx;
+    bd.meas = b.d_meas;
+    bd.noise = b.d_noise;
+    bd.J = S->pool + b.joff;
+    bd.epos = nullptr;
+    bd.robust = b.robust;
+    bd.rk = b.rk;
+    bd.sel = d[q];
+    ml.b[ml.nb] = bd;
+    ml.first[ml.nb] = blocks;
+    blocks += (count + 127) / 128;
+    if (++ml.nb == LIN_MULTI_MAX) launch();
+  }
+  launch();
+  return LMGPU_OK;
+}
+
 }  // namespace
 
 // deltaReplacedMask_ |= affected keys (ISAM2.cpp:172): marks = (offset, dimension) pairs of the re-eliminated variables
@@ -2090,8 +2138,10 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
     res.variablesRelinearized = (int32_t)markedKeys.size();
   }
   // ---- 7. linearizeNewFactors (:454-468) + augmentVariableIndex
-  for (auto& kv : new_by_bucket)
-    if ((rc = is_with_list(S, kv.second, [&](const int32_t* d, int cnt) { is_linearize_sel(S, S->bkts[kv.first], d, cnt); }))) return rc;
+  {
+    std::vector<std::pair<int, std::vector<int32_t>>> jobs(new_by_bucket.begin(), new_by_bucket.end());
+    if ((rc = is_linearize_jobs(S, jobs))) return rc;
+  }
   for (int32_t i : new_idx)
     for (int k = 0; k < kFactorArity[S->facs[i].type]; k++) S->vindex[S->facs[i].v[k]].push_back(i);
   lap(1);  // new factors, relinearization check, retract, linearize
@@ -2146,10 +2196,14 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
       lap(2);
       if ((rc = is_colamd(S, vids, cols, (int)S->facs.size(), groups, &perm))) return rc;
       lap(3);
-      for (size_t b = 0; b < S->bkts.size(); b++) {
-        std::vector<int32_t> all(S->bkts[b].n);
-        for (int i = 0; i < S->bkts[b].n; i++) all[i] = i;
-        if ((rc = is_with_list(S, all, [&](const int32_t* d, int cnt) { is_linearize_sel(S, S->bkts[b], d, cnt); }))) return rc;
+      {
+        std::vector<std::pair<int, std::vector<int32_t>>> jobs;
+        for (size_t b = 0; b < S->bkts.size(); b++) {
+          std::vector<int32_t> all(S->bkts[b].n);
+          for (int i = 0; i < S->bkts[b].n; i++) all[i] = i;
+          jobs.emplace_back((int)b, std::move(all));
+        }
+        if ((rc = is_linearize_jobs(S, jobs))) return rc;
       }
       std::vector<IsGF> gfs(S->facs.size());
       for (size_t i = 0; i < S->facs.size(); i++) {
@@ -2194,8 +2248,10 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
         g.id = idx;
         gfs.push_back(std::move(g));
       }
-      for (auto& kv : relin_by_bucket)
-        if ((rc = is_with_list(S, kv.second, [&](const int32_t* d, int cnt) { is_linearize_sel(S, S->bkts[kv.first], d, cnt); }))) return rc;
+      {
+        std::vector<std::pair<int, std::vector<int32_t>>> jobs(relin_by_bucket.begin(), relin_by_bucket.end());
+        if ((rc = is_linearize_jobs(S, jobs))) return rc;
+      }
       res.variablesReeliminated = (int32_t)affectedAndNew.size();
       res.factorsRecalculated = (int32_t)gfs.size();
       for (int kind = 1; kind <= 2; kind++)  // GetCachedBoundaryFactors (ISAM2-impl.h:499-509), then the orphan wrappers

@@ -531,8 +531,7 @@ __global__ __launch_bounds__(128) void sfm2_factor_kernel(BucketDev b, ValuesDev
 
 // Generic bucket kernel.  TYPE selects the evaluator; M rows, D0/D1 tangent dims, S0/S1 stored doubles, T0/T1 value types.
 template <int TYPE, int M, int D0, int D1, int ML, int T0, int S0, int T1, int S1, bool JAC>
-__global__ __launch_bounds__(128) void generic_factor_kernel(BucketDev b, ValuesDev vals, double* __restrict__ ebuf) {
-  const int fi = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void generic_factor_body(const BucketDev& b, const ValuesDev& vals, double* __restrict__ ebuf, const int fi) {
   if (fi >= b.n) return;
   const int f = b.sel ? b.sel[fi] : fi;
   constexpr int AR = (D1 > 0) ? 2 : 1;
@@ -613,6 +612,42 @@ __global__ __launch_bounds__(128) void generic_factor_kernel(BucketDev b, Values
     ebuf[b.epos[f]] = whitened_half_sq<M>(e, b.noise_kind, nz, b.robust, b.rk);
   }
 }
+
+template <int TYPE, int M, int D0, int D1, int ML, int T0, int S0, int T1, int S1, bool JAC>
+__global__ __launch_bounds__(128) void generic_factor_kernel(BucketDev b, ValuesDev vals, double* __restrict__ ebuf) {
+  generic_factor_body<TYPE, M, D0, D1, ML, T0, S0, T1, S1, JAC>(b, vals, ebuf, (int)(blockIdx.x * blockDim.x + threadIdx.x));
+}
+
+// Linearization of SEVERAL buckets in one launch (ISAM2: an update relinearizes two or three factor types, each a launch of a few
+// workgroups of its own before): block blockIdx.x belongs to bucket k with first[k] <= blockIdx.x < first[k + 1]; 128 threads per block
+// like the per-bucket launches.  (The SFM types have kernels of their own shape and stay apart.)
+#define LIN_MULTI_MAX 6
+struct MultiLin {
+  BucketDev b[LIN_MULTI_MAX];
+  int32_t first[LIN_MULTI_MAX + 1];
+  int32_t nb;
+};
+__global__ __launch_bounds__(128) void linearize_multi_kernel(MultiLin ml, ValuesDev vals) {
+  int k = 0;
+  while (k + 1 < ml.nb && (int)blockIdx.x >= ml.first[k + 1]) k++;
+  const BucketDev& b = ml.b[k];
+  const int fi = ((int)blockIdx.x - ml.first[k]) * 128 + (int)threadIdx.x;
+  double* nob = nullptr;
+  switch (b.type) {
+    case 1: generic_factor_body<1, 3, 3, 3, 3, 0, 3, 0, 3, true>(b, vals, nob, fi); break;
+    case 2: generic_factor_body<2, 6, 6, 6, 12, 1, 12, 1, 12, true>(b, vals, nob, fi); break;
+    case 3: generic_factor_body<3, 3, 3, 0, 3, 0, 3, -1, 0, true>(b, vals, nob, fi); break;
+    case 4: generic_factor_body<4, 6, 6, 0, 12, 1, 12, -1, 0, true>(b, vals, nob, fi); break;
+    case 5: generic_factor_body<5, 3, 3, 0, 3, 2, 3, -1, 0, true>(b, vals, nob, fi); break;
+    case 6: generic_factor_body<6, 9, 9, 0, 15, 3, 15, -1, 0, true>(b, vals, nob, fi); break;
+    case 7: generic_factor_body<7, 2, 6, 3, 7, 1, 12, 2, 3, true>(b, vals, nob, fi); break;
+    case 8: generic_factor_body<8, 2, 6, 3, 19, 1, 12, 2, 3, true>(b, vals, nob, fi); break;
+    case 9: generic_factor_body<9, 2, 3, 2, 2, 0, 3, 4, 2, true>(b, vals, nob, fi); break;
+    case 11: generic_factor_body<11, 5, 5, 0, 5, 5, 5, -1, 0, true>(b, vals, nob, fi); break;
+    default: break;
+  }
+}
+
 
 // ---------------------------------------------------------------- linear error  (a8)
 // GaussianFactorGraph::error gtsam/linear/GaussianFactorGraph.cpp:71-78, JacobianFactor::error :509-514
