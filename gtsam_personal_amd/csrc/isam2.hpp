@@ -2128,12 +2128,27 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
       // ---- 6. theta_.retractMasked(delta_, relinKeys) on the device
       std::vector<int32_t> sel[kNumVarTypes];
       for (int32_t v : relin) sel[S->vars[v].type].push_back(S->vars[v].tidx);
-      for (int t = 0; t < kNumVarTypes; t++)
-        if ((rc = is_with_list(S, sel[t], [&](const int32_t* d, int cnt) {
-               hipLaunchKernelGGL(retract_kernel, dim3((cnt + 255) / 256), dim3(256), 0, S->stream, t, cnt, (const double*)S->theta[t], S->theta[t],
-                                  (const int32_t*)S->d_type_xoff[t], (const double*)S->delta, d);
-             })))
-          return rc;
+      {  // one launch for all the types
+        RetractMulti rm{};
+        int ne = 0, maxn = 0;
+        for (int t = 0; t < kNumVarTypes; t++) {
+          if (sel[t].empty()) continue;
+          int32_t* d = nullptr;
+          if ((rc = is_stage(S, sel[t], &d))) return rc;
+          rm.type[ne] = t;
+          rm.n[ne] = (int)sel[t].size();
+          rm.cur[ne] = S->theta[t];
+          rm.out[ne] = S->theta[t];
+          rm.xoff[ne] = S->d_type_xoff[t];
+          rm.sel[ne] = d;
+          maxn = std::max(maxn, (int)sel[t].size());
+          ne++;
+        }
+        if (ne > 0) {
+          if ((rc = is_flush(S))) return rc;
+          hipLaunchKernelGGL(retract_multi_kernel, dim3((maxn + 255) / 256, ne), dim3(256), 0, S->stream, rm, (const double*)S->delta);
+        }
+      }
     }
     res.variablesRelinearized = (int32_t)markedKeys.size();
   }

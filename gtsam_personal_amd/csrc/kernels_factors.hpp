@@ -776,9 +776,8 @@ __global__ __launch_bounds__(256) void reduce_stage2(const double* __restrict__ 
 // Values::retract gtsam/nonlinear/Values.cpp:53-64; one thread per variable of a type.
 // sel (may be null): the n variables to retract as indices into the type array (ISAM2's retractMasked, gtsam/nonlinear/ISAM2.cpp:465);
 // cur == out is allowed (every lane reads its variable before it writes it).
-__global__ __launch_bounds__(256) void retract_kernel(int type, int n, const double* cur, double* out, const int32_t* __restrict__ xoff,
-                                                       const double* __restrict__ delta, const int32_t* __restrict__ sel = nullptr) {
-  const int li = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void retract_body(int type, int n, const double* cur, double* out, const int32_t* __restrict__ xoff,
+                                             const double* __restrict__ delta, const int32_t* __restrict__ sel, const int li) {
   if (li >= n) return;
   const int i = sel ? sel[li] : li;
   const double* d = delta + xoff[i];
@@ -810,6 +809,22 @@ __global__ __launch_bounds__(256) void retract_kernel(int type, int n, const dou
     store_pose3(compose3(p, pose3_expmap(d)), o);
     o[12] = v[12] + d[6]; o[13] = v[13] + d[7]; o[14] = v[14] + d[8];
   }
+}
+__global__ __launch_bounds__(256) void retract_kernel(int type, int n, const double* cur, double* out, const int32_t* __restrict__ xoff,
+                                                       const double* __restrict__ delta, const int32_t* __restrict__ sel = nullptr) {
+  retract_body(type, n, cur, out, xoff, delta, sel, (int)(blockIdx.x * 256 + threadIdx.x));
+}
+// the variable types of one masked retraction in one launch (ISAM2 relinearizes poses and points in the same update): blockIdx.y = entry
+struct RetractMulti {
+  int32_t type[6], n[6];
+  const double* cur[6];
+  double* out[6];
+  const int32_t* xoff[6];
+  const int32_t* sel[6];
+};
+__global__ __launch_bounds__(256) void retract_multi_kernel(RetractMulti rm, const double* __restrict__ delta) {
+  const int k = blockIdx.y;
+  retract_body(rm.type[k], rm.n[k], rm.cur[k], rm.out[k], rm.xoff[k], delta, rm.sel[k], (int)(blockIdx.x * 256 + threadIdx.x));
 }
 
 }  // namespace lmgpu
