@@ -632,21 +632,32 @@ __device__ __forceinline__ void lds_front_body(const int work, const int32_t* __
       }
       __syncthreads();  // the factored block and the reciprocals are in LDS
       LDSF_STAMP(7);  // (eight-pivot groups) diagonal block by wave 0
-      for (int j = k0 + kb + tid; j < n; j += nt) {
-        double x[8];
+      if (k0 + kb + tid < n) {
+        // the factored block and the reciprocals into registers FIRST (36 broadcast reads in flight together): read where they are used,
+        // every step of the chain below waited for its own LDS round trip (2.2 us per group of eight pivots)
+        double Rq[8][8], iv[8];
 #pragma unroll
-        for (int q = 0; q < 8; q++) x[q] = (q < kb) ? S[(k0 + q) * n + j] : 0.0;
+        for (int q = 0; q < 8; q++) {
+          iv[q] = inv8[q];
 #pragma unroll
-        for (int q = 0; q < 8; q++)
-          if (q < kb) {
-            x[q] *= inv8[q];
+          for (int i = q + 1; i < 8; i++) Rq[q][i] = S[(k0 + min(q, kb - 1)) * n + k0 + min(i, kb - 1)];
+        }
+        for (int j = k0 + kb + tid; j < n; j += nt) {
+          double x[8];
 #pragma unroll
-            for (int i = q + 1; i < 8; i++)
-              if (i < kb) x[i] -= S[(k0 + q) * n + k0 + i] * x[q];
-          }
+          for (int q = 0; q < 8; q++) x[q] = (q < kb) ? S[(k0 + q) * n + j] : 0.0;
 #pragma unroll
-        for (int q = 0; q < 8; q++)
-          if (q < kb) S[(k0 + q) * n + j] = x[q];
+          for (int q = 0; q < 8; q++)
+            if (q < kb) {
+              x[q] *= iv[q];
+#pragma unroll
+              for (int i = q + 1; i < 8; i++)
+                if (i < kb) x[i] -= Rq[q][i] * x[q];
+            }
+#pragma unroll
+          for (int q = 0; q < 8; q++)
+            if (q < kb) S[(k0 + q) * n + j] = x[q];
+        }
       }
       __syncthreads();
       LDSF_STAMP(8);  // (eight-pivot groups) panel solve
