@@ -566,7 +566,8 @@ __device__ __forceinline__ void lds_front_body(const int work, const int32_t* __
   // LDS).  Row by row, every trailing entry is read-modify-written in LDS once per pivot -- ~0.75 us per pivot at n = 139 from
   // LDS bandwidth alone, 100-200 us per front, which is what a narrow tree level costs.  Same arithmetic up to the order of
   // the four subtractions.
-  const bool blocked = !gather && nf >= 8 && nw >= 4;
+  const bool blocked = !gather && nf >= 2 && nw >= 4;  // (from two pivots on: one group of four is three barriers and one pass over the trailing
+                                                         //  matrix on the matrix core, where pivot by pivot takes two barriers and a pass per pivot)
   // (smaller fronts: the four-pivot groups below -- every thread factors the 4 x 4 block itself; and only the launch forms of upper levels carry
   //  the eight-pivot code: its registers would cost the per-level launches of leaf levels their occupancy)
   constexpr bool kEightOk = EIGHT;
