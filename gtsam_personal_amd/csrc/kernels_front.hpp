@@ -91,6 +91,12 @@ __device__ __forceinline__ int fac_col(const FD& d, int c0, int c1, int c2, int 
 // row-major front, waves along rows.  GATHER fronts (leaves whose HBM parent gathers their update itself,
 // kernels_schur.hpp) only keep their nf frontal rows and the (rhs, rhs) corner: srows = max nf of the launch, which
 // lets ~7 workgroups share a CU instead of 2.
+// waves a workgroup needs for the blocked Cholesky (groups of four / eight pivots, trailing update on the matrix core): any number -- with
+// 4 (rounds 2-3) the one- and two-wave launches of small fronts took their pivots one by one (city10000 2.63 -> 2.58 ms, victoria_park
+// 6.92 -> 6.78)
+#ifndef LDSF_BLOCKED_MIN_WAVES
+#define LDSF_BLOCKED_MIN_WAVES 1
+#endif
 #define LDSF_JCAP 704
 #define LDSF_MAXB 32
 // Packed descriptor of an LDS front (one record per workgroup of a launch, `stride` bytes apart): everything the workgroup
@@ -566,7 +572,7 @@ __device__ __forceinline__ void lds_front_body(const int work, const int32_t* __
   // LDS).  Row by row, every trailing entry is read-modify-written in LDS once per pivot -- ~0.75 us per pivot at n = 139 from
   // LDS bandwidth alone, 100-200 us per front, which is what a narrow tree level costs.  Same arithmetic up to the order of
   // the four subtractions.
-  const bool blocked = !gather && nf >= 2 && nw >= 4;  // (from two pivots on: one group of four is three barriers and one pass over the trailing
+  const bool blocked = !gather && nf >= 2 && nw >= (LDSF_BLOCKED_MIN_WAVES);  // (from two pivots on: one group of four is three barriers and one pass over the trailing
                                                          //  matrix on the matrix core, where pivot by pivot takes two barriers and a pass per pivot)
   // (smaller fronts: the four-pivot groups below -- every thread factors the 4 x 4 block itself; and only the launch forms of upper levels carry
   //  the eight-pivot code: its registers would cost the per-level launches of leaf levels their occupancy)
