@@ -647,20 +647,27 @@ __global__ __launch_bounds__(256) void isam2_wildfire_kernel(long long* __restri
                                                               const int32_t* __restrict__ tree_sx, const double* __restrict__ pool,
                                                               double* __restrict__ delta, const unsigned char* __restrict__ replaced,
                                                               unsigned char* __restrict__ changed, double threshold, int* __restrict__ status,
-                                                              unsigned char epoch, int* __restrict__ relay, unsigned char* __restrict__ done) {
+                                                              unsigned char epoch, int* __restrict__ relay, unsigned char* __restrict__ done,
+                                                              int by_value) {
+  // by_value: the re-eliminated top of the tree (every clique reached from a root through replaced cliques; the host filled their frontal
+  // scalars of delta with the all-ones pattern in the flush in front of this launch) hands x over BY VALUE, as the merged back-substitution
+  // of the batch path does: the parent stores x_F with agent-scope stores right after its solve, the child polls its separator scalars.
+  // No done flag, no fence and no second round trip between two such cliques (a fixed-lag smoother re-eliminates its whole chain of ~50
+  // cliques every update: 5.5 us per clique before).  Bit 63 of a queue entry = "the parent is part of that top".
   extern __shared__ double Ls[];
-  __shared__ int s_id, s_par, flag;
+  __shared__ int s_id, s_par, s_pare, flag;
   __shared__ double red[4];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   for (;;) {
     if (tid == 0) {
       const unsigned int my = atomicAdd(&wl[1], 1u);
-      int id, par = -1;
+      int id, par = -1, pare = 0;
       long spins = 0;
       for (;;) {
         const long long ent = __hip_atomic_load(&queue[my], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         id = (int)(ent & 0xffffffffLL);
-        par = (int)(ent >> 32);
+        par = (int)((ent >> 32) & 0x7fffffffLL);
+        pare = (int)((unsigned long long)ent >> 63);
         if (ent != -1LL) break;
         id = -1;
         if (__hip_atomic_load(&wl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
@@ -675,7 +682,8 @@ __global__ __launch_bounds__(256) void isam2_wildfire_kernel(long long* __restri
       }
       if (id >= 0) __hip_atomic_store(&queue[my], -1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the slot is clean for the next launch
       s_id = id;
-      s_par = par;
+      s_par = par == 0x7fffffff ? -1 : par;
+      s_pare = pare;
     }
     __syncthreads();
     const int id = s_id;
@@ -703,10 +711,11 @@ __global__ __launch_bounds__(256) void isam2_wildfire_kernel(long long* __restri
     // changed flags of the separator, x_S -- waits for the parent's done flag (the epoch of this walk).  The hand-off between two levels was
     // ten dependent round trips (7.8 us per level of a chain of small cliques); now the parent's publish and the child's x_S.
     const int par = s_par;
+    const bool in_top = by_value && is_replaced && !wide && (par < 0 || s_pare);  // workgroup-uniform
     if (!wide) lmgpu::ldsb_stage(F, pool, Ls, tid);
     if (tid == 0) {
       int ok = 1;
-      if (par >= 0) {
+      if (par >= 0 && !in_top) {
         long spins = 0;
         while (__hip_atomic_load(&done[par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
           __builtin_amdgcn_s_sleep(1);
@@ -720,8 +729,8 @@ __global__ __launch_bounds__(256) void isam2_wildfire_kernel(long long* __restri
       flag = (threshold <= 0.0 || is_replaced) ? 1 : 0;
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the parent's delta / changed flags
-    const double xs_pre = delta[ns > 0 ? so : fo];  // (in flight together with the changed flags below: one round trip, not two)
+    if (!in_top) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the parent's delta / changed flags
+    const double xs_pre = in_top ? 0.0 : delta[ns > 0 ? so : fo];  // (in flight together with the changed flags below: one round trip, not two)
     if (!(threshold <= 0.0 || is_replaced)) {
       for (int j = tid; j < ns; j += 256)
         if (changed[sxr[j]] == epoch) flag = 1;  // benign race: every writer stores 1
@@ -738,8 +747,9 @@ __global__ __launch_bounds__(256) void isam2_wildfire_kernel(long long* __restri
       __syncthreads();
       const int32_t* kids = (const int32_t*)(pool + F.child_begin);
       for (int k = tid; k < nk; k += 256)
-        __hip_atomic_store(&queue[(unsigned int)s_id + k], (long long)(unsigned int)kids[k] | (long long)(unsigned int)id << 32, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&queue[(unsigned int)s_id + k],
+                           (long long)((unsigned long long)(unsigned int)kids[k] | (unsigned long long)(unsigned int)id << 32 | (in_top ? 1ull << 63 : 0ull)),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (dirty && wide) {
       // A clique too wide for the LDS staging (rare: loop closures of large graphs): x_S and y in LDS, R / S streamed from memory by this
@@ -813,6 +823,16 @@ __global__ __launch_bounds__(256) void isam2_wildfire_kernel(long long* __restri
           delta[xo] = y[i];
           changed[xo] = epoch;
         }
+    } else if (in_top) {
+      bool bad, timed_out = false;
+      const double* x = lmgpu::ldsb_solve_core<true>(F, Ls, ns > 0 ? so : fo, delta, &bad, &timed_out);
+      if (tid < nf) {
+        const double xv = x[tid];
+        __hip_atomic_store(&delta[fo], (xv != xv) ? __longlong_as_double(0x7ff8000000000000LL) : xv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // never the sentinel
+        changed[fo] = epoch;
+      }
+      if (timed_out) atomicMin(status, -1);  // never expected: spin bound hit (reported as a fault by the host)
+      if (bad && lane == 0) atomicMin(status, F.id);  // NaN: IndeterminantLinearSystemException (ISAM2Clique.cpp:124-126)
     } else if (dirty) {
       bool bad;
       const double* x = lmgpu::ldsb_solve_core(F, Ls, ns > 0 ? so : fo, delta, &bad, nullptr, &xs_pre);
@@ -1125,14 +1145,36 @@ int is_update_delta_enqueue(lmgpu_isam2* S, bool force_full, bool host_delta, do
     const unsigned int ctl[4] = {r, 0u, r, 0u};
     const int32_t fresh = 0x7f7f7f7f;
     std::vector<long long> seeds(r);
-    for (unsigned int q = 0; q < r; q++) seeds[q] = (long long)(unsigned int)S->roots[q] | (long long)0xffffffffu << 32;  // (no parent)
+    for (unsigned int q = 0; q < r; q++) seeds[q] = (long long)(unsigned int)S->roots[q] | (long long)0x7fffffff << 32;  // (no parent)
+    // the re-eliminated top of the tree hands x over by value (see the kernel): its frontal scalars carry the all-ones pattern until solved
+    const int by_value = (!S->dogleg && !target && !dev_switch("LMGPU_ISAM2_NO_BYVALUE")) ? 1 : 0;
+    if (by_value) {
+      std::vector<int32_t> stack;
+      std::vector<std::pair<int32_t, int32_t>> runs;  // (xoff, scalars)
+      for (int32_t rt : S->roots) stack.push_back(rt);
+      while (!stack.empty()) {
+        const lmgpu_isam2::Clq& c = S->clq[stack.back()];
+        stack.pop_back();
+        if (c.ld > 0 || !S->replaced[c.vars[0]]) continue;  // (the kernel's rule: a wide clique and everything below it wait for done flags)
+        for (int k = 0; k < c.nfv; k++) runs.emplace_back(S->vars[c.vars[k]].xoff, kVarDim[S->vars[c.vars[k]].type]);
+        for (int32_t ch : c.children) stack.push_back(ch);
+      }
+      std::sort(runs.begin(), runs.end());
+      for (size_t a = 0; a < runs.size();) {
+        size_t b = a + 1;
+        int32_t end = runs[a].first + runs[a].second;
+        while (b < runs.size() && runs[b].first == end) end += runs[b++].second;
+        S->pushes.push_back(lmgpu_isam2::PushRec{S->delta + runs[a].first, nullptr, (uint32_t)(2 * (end - runs[a].first)), 1u});
+        a = b;
+      }
+    }
     if ((rc = is_push(S, S->d_queue, seeds.data(), r * sizeof(long long)))) return rc;
     if ((rc = is_push(S, S->d_wl, ctl, sizeof(ctl)))) return rc;
     if ((rc = is_push(S, S->d_status, &fresh, sizeof(fresh)))) return rc;
     if ((rc = is_flush(S))) return rc;
     hipLaunchKernelGGL(isam2_wildfire_kernel, dim3(ISAM2_WL_GROUPS), dim3(256), (S->tree_lds + LDSB_TAIL) * sizeof(double), S->stream, S->d_queue, S->d_wl,
                        (const FrontDesc*)S->d_tree, (const int32_t*)S->d_tree_fx, (const int32_t*)S->d_tree_sx, (const double*)S->pool, wf_delta,
-                       (const unsigned char*)S->d_replaced, S->d_changed, thr, S->d_status, S->epoch, S->h_status_dev, S->d_tree_done);
+                       (const unsigned char*)S->d_replaced, S->d_changed, thr, S->d_status, S->epoch, S->h_status_dev, S->d_tree_done, by_value);
     ISCHECK(hipGetLastError());
   }
   if (++S->epoch == 0) {  // wrapped: start over from clean arrays

@@ -1,4 +1,4 @@
-# A/B of library builds / switches on the ISAM2 C++ driver in one box.  usage: tools/variants/ab_isam2.sh
+# A/B of library builds / switches on the ISAM2 C++ driver in one box.  usage: tools/variants/ab_isam2.sh "ENV=1" "ENV=0" ...  (test library preloaded)
 python - <<'PY'
 import sys
 sys.path.insert(0, ".")
@@ -6,10 +6,11 @@ import bench, os
 os.makedirs("gpurun_out/abi", exist_ok=True)
 for name, path in bench.isam2_sequences("gpurun_out/abi", 2000).items():
     print(name, path)
+print("fixed_lag", bench.fixed_lag_sequence("gpurun_out/abi"))
 PY
 run() { # label, env...
   label=$1; shift
-  for w in visual city10000; do
+  for w in visual city10000 fixed_lag; do
     FX=tests/golden/isam2_orderings_$w.bin
     rep=""; [ $w = visual ] && rep="repeat:3"
     best=999
@@ -22,7 +23,6 @@ run() { # label, env...
   done
 }
 run product X=0
-run testlib LD_PRELOAD=$PWD/gtsam_personal_amd/liblmgpu_test.so
-run testlib_nomerge LD_PRELOAD=$PWD/gtsam_personal_amd/liblmgpu_test.so LMGPU_ISAM2_NO_MERGE=1
-run norounds LD_PRELOAD=$PWD/gtsam_personal_amd/liblmgpu_norounds.so
-run norounds_nomerge LD_PRELOAD=$PWD/gtsam_personal_amd/liblmgpu_norounds.so LMGPU_ISAM2_NO_MERGE=1
+for v in "$@"; do
+  run "testlib_$v" LD_PRELOAD=$PWD/gtsam_personal_amd/liblmgpu_test.so $v
+done
