@@ -288,7 +288,11 @@ struct BsdBlock {  // everything a workgroup needs, in one record: it is ONE dep
 __global__ __launch_bounds__(256) void hbm_backsolve_blocks_kernel(const BsdBlock* __restrict__ table, unsigned int* __restrict__ ticket,
                                                                     const int32_t* __restrict__ fxoff, const int32_t* __restrict__ sxoff,
                                                                     const double* __restrict__ pool, double* __restrict__ delta,
-                                                                    double* __restrict__ xbuf, int* __restrict__ status) {
+                                                                    double* __restrict__ xbuf, int* __restrict__ status, int poll = 0) {
+  // poll != 0: the blocks of SEVERAL consecutive tree levels in this launch (levels that hold nothing but such fronts: the upper ten
+  // levels of sphere2500 are one or two mid-size fronts each).  delta was preset to all ones by the host and a front's separator values
+  // are awaited BY VALUE (the table lists the levels top-down, so a front's ancestors hold lower tickets); x_F is published with
+  // agent-scope stores.
   __shared__ double Db[64][65];
   __shared__ double yb[64];
   __shared__ int s_t;
@@ -340,7 +344,24 @@ __global__ __launch_bounds__(256) void hbm_backsolve_blocks_kernel(const BsdBloc
     for (int k = 0; k < 16; k++) v0[k] = Arow[k][nf + min(j0, ns - 1)];
 #pragma unroll
     for (int k = 0; k < 16; k++) v1[k] = Arow[k][nf + min(j1, ns - 1)];
-    const double d0 = delta[o0], d1 = delta[o1];
+    double d0, d1;
+    if (poll) {
+      long spins = 0;
+      for (;;) {
+        d0 = __hip_atomic_load(&delta[o0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        d1 = __hip_atomic_load(&delta[o1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__double_as_longlong(d0) != -1LL && __double_as_longlong(d1) != -1LL) break;
+        if (++spins > BSD_SPIN_LIMIT) {
+          atomicExch(status + 1, 1 + F.id);  // never expected: spin bound hit (a fault, reported apart from pivot failures)
+          d0 = d1 = 0.0;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    } else {
+      d0 = delta[o0];
+      d1 = delta[o1];
+    }
     const double x0 = (j0 < ns) ? d0 : 0.0, x1 = (j1 < ns) ? d1 : 0.0;
 #pragma unroll
     for (int k = 0; k < 16; k++) acc[k] += v0[k] * x0 + v1[k] * x1;
@@ -394,7 +415,10 @@ __global__ __launch_bounds__(256) void hbm_backsolve_blocks_kernel(const BsdBloc
     const double pub = (lane < nb) ? ((yi != yi) ? __longlong_as_double(0x7ff8000000000000LL) : yi) : 0.0;  // never the sentinel
     __hip_atomic_store(&xb[r0 + lane], pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (lane < nb) {
-      delta[fo] = yi;
+      if (poll)
+        __hip_atomic_store(&delta[fo], pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else
+        delta[fo] = yi;
       if (yi != yi) atomicMin(status, F.id);  // NaN -> IndeterminantLinearSystemException (linearAlgorithms-inst.h:99)
     }
   }

@@ -286,6 +286,13 @@ struct lmgpu_handle {
   int32_t *d_hbm_small = nullptr, *d_f_ld = nullptr, *d_med_list = nullptr;
   MedFront* d_med_fronts = nullptr;     // packed records of the medium fronts, level by level (same order as d_med_list)
   BsdBlock* d_bsd_table = nullptr;      // 64-row blocks of the smaller HBM fronts, per level, each front from its last block to its first
+  // runs of consecutive levels that hold nothing but such fronts: their blocks as ONE launch, levels top-down (merged back-substitution only)
+  struct BsdRun {
+    int lvl_hi, lvl_lo, begin, count;
+  };
+  std::vector<BsdRun> bsd_runs;
+  std::vector<int> bsd_run_of;          // per level: index of the run that starts (top) here, -2 inside a run, -1 none
+  BsdBlock* d_bsd_run_table = nullptr;
   double* d_bsd_x = nullptr;            // their published x (64 per block), preset to the all-ones sentinel at the start of a back-substitution
   unsigned int* d_bsd_ticket = nullptr; // one ticket counter per level
   size_t bsd_x_count = 0;
@@ -1028,6 +1035,7 @@ int do_backsub(lmgpu_handle* h) {
   if (h->cfg.world_size > 1) HIPCHECK(hipMemsetAsync(h->delta, 0, h->ntot * sizeof(double), s));
   // deep trees: the LDS fronts of consecutive levels without HBM fronts in between go as ONE dataflow launch
   const bool merge = h->merge_backsub && h->cfg.world_size == 1 && !(h->cfg.flags & LMGPU_FLAG_SPLIT_ROOT);
+  const bool no_bsd_runs = dev_switch("LMGPU_NO_BSD_RUNS") != nullptr;
   const int NFR = (int)h->h_fronts.size();
   if (merge) {
     HIPCHECK(hipMemsetAsync(h->d_bs_done, 0, (size_t)(NFR + h->levels.size() + 1) * sizeof(unsigned int), s));  // (the ticket counters)
@@ -1072,7 +1080,15 @@ int do_backsub(lmgpu_handle* h) {
       const int rcf = flush_segment();
       if (rcf) return rcf;
     }
-    if (L.bsd_count > 0) {  // the smaller HBM fronts of the level: one workgroup per 64-row block, one launch
+    const int brun = (merge && !h->bsd_run_of.empty() && !no_bsd_runs) ? h->bsd_run_of[li] : -1;
+    if (brun >= 0) {  // this level and the ones below it that hold nothing but block-solved fronts: one launch, separator values awaited by value
+      const lmgpu_handle::BsdRun& R = h->bsd_runs[brun];
+      const int kt = h->kt.begin(LMGPU_KT_BACKSUB_HBM, s);
+      hipLaunchKernelGGL(hbm_backsolve_blocks_kernel, dim3(R.count), dim3(256), 0, s, (const BsdBlock*)(h->d_bsd_run_table + R.begin), h->d_bsd_ticket + li,
+                         (const int32_t*)h->d_fxoff, (const int32_t*)h->d_sxoff, (const double*)h->pool, h->delta, h->d_bsd_x, h->d_status, 1);
+      h->kt.end(kt, s);
+    }
+    if (L.bsd_count > 0 && brun == -1) {  // the smaller HBM fronts of the level: one workgroup per 64-row block, one launch
       const int kt = h->kt.begin(LMGPU_KT_BACKSUB_HBM, s);
       hipLaunchKernelGGL(hbm_backsolve_blocks_kernel, dim3(L.bsd_count), dim3(256), 0, s, (const BsdBlock*)(h->d_bsd_table + L.bsd_begin),
                          (L.bsd_count <= h->num_cus && !h->bsd_ticket) ? (unsigned int*)nullptr : h->d_bsd_ticket + li, (const int32_t*)h->d_fxoff,
@@ -1757,7 +1773,7 @@ int lmgpu_destroy(lmgpu_handle* h) {
     for (int i = 0; i < 8; i++)
       if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     for (hipEvent_t e : h->kt.pool) (void)hipEventDestroy(e);
-    fr(h->bs_inv); fr(h->bs_x); fr(h->bs_flags); fr(h->inv16); fr(h->d_pflags); fr(h->d_bs_parent); fr(h->d_bs_pos); fr(h->d_bs_done); fr(h->d_fill_upper); fr(h->d_level_tasks); fr(h->d_level_sync); fr(h->d_bsd_table); fr(h->d_zero_ranges); fr(h->d_bsd_x); fr(h->d_bsd_ticket); fr(h->d_leafpack); fr(h->d_gzero);
+    fr(h->bs_inv); fr(h->bs_x); fr(h->bs_flags); fr(h->inv16); fr(h->d_pflags); fr(h->d_bs_parent); fr(h->d_bs_pos); fr(h->d_bs_done); fr(h->d_fill_upper); fr(h->d_level_tasks); fr(h->d_level_sync); fr(h->d_bsd_table); fr(h->d_bsd_run_table); fr(h->d_zero_ranges); fr(h->d_bsd_x); fr(h->d_bsd_ticket); fr(h->d_leafpack); fr(h->d_gzero);
     for (auto& kv : h->chain_plans)
       for (auto& cp : kv.second) fr(cp.d_tasks);
     fr(h->d_gpblk); fr(h->d_gpent); fr(h->d_gvblk); fr(h->d_gvent); fr(h->d_gcorner); fr(h->d_row_begin); fr(h->d_rowptr); fr(h->d_rowsrc);
@@ -2397,6 +2413,44 @@ int lmgpu_finalize_structure(lmgpu_handle* h) {
     }
     h->bsd_x_count = (size_t)xoff;
     if ((rc = upload(h, &h->d_bsd_table, bsd))) return rc;
+    {
+      h->bsd_runs.clear();
+      h->bsd_run_of.assign(h->levels.size(), -1);
+      std::vector<BsdBlock> runs;
+      // a level can open a run when every HBM front on it is block-solved; the next level down joins when, in addition, none of its
+      // fronts hangs below an LDS front of the run's levels (those are solved by the merged LDS launch BEHIND the run's launch)
+      auto opens = [&](int l) {
+        const LevelWork& L = h->levels[l];
+        return L.bsd_count > 0 && L.small_count == (int)L.hbm.size();
+      };
+      auto joins = [&](int l, int hi) {
+        if (!opens(l)) return false;
+        for (int fi : h->levels[l].hbm) {
+          const int par = P.fronts[fi].parent;
+          if (par >= 0 && P.fronts[par].cls != 1 && P.fronts[par].level <= hi) return false;
+        }
+        return true;
+      };
+      int l = (int)h->levels.size() - 1;
+      while (l >= 0) {
+        if (!opens(l)) {
+          l--;
+          continue;
+        }
+        int lo = l;
+        while (lo - 1 >= 0 && joins(lo - 1, l)) lo--;
+        if (lo < l) {
+          lmgpu_handle::BsdRun R{l, lo, (int)runs.size(), 0};
+          for (int q = l; q >= lo; q--) runs.insert(runs.end(), bsd.begin() + h->levels[q].bsd_begin, bsd.begin() + h->levels[q].bsd_begin + h->levels[q].bsd_count);
+          R.count = (int)runs.size() - R.begin;
+          h->bsd_run_of[l] = (int)h->bsd_runs.size();
+          for (int q = l - 1; q >= lo; q--) h->bsd_run_of[q] = -2;
+          h->bsd_runs.push_back(R);
+        }
+        l = lo - 1;
+      }
+      if (!runs.empty() && (rc = upload(h, &h->d_bsd_run_table, runs))) return rc;
+    }
     if (xoff > 0) {
       HIPCHECK(hipMalloc((void**)&h->d_bsd_x, (size_t)xoff * sizeof(double)));
       HIPCHECK(hipMalloc((void**)&h->d_bsd_ticket, h->levels.size() * sizeof(unsigned int)));
