@@ -98,6 +98,26 @@ __global__ __launch_bounds__(256) void zero_ranges_kernel(const ZeroRange* __res
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)gridDim.x * 256) p[i] = double2{0.0, 0.0};
 }
 
+// Every small clear / sentinel fill of a phase as ONE launch (a launch of a few hundred bytes costs ~5 us of stream time like any other:
+// sphere2500 spent 12 of its 101 launches per solve on them).  One workgroup per chunk of at most FILL_CHUNK_BYTES.
+#define FILL_CHUNK_BYTES 32768
+struct FillChunk {
+  unsigned long long dst;  // device address, 4-byte aligned
+  uint32_t bytes;          // multiple of 4
+  uint32_t value;          // the 32-bit pattern
+};
+__global__ __launch_bounds__(256) void fill_chunks_kernel(const FillChunk* __restrict__ table) {
+  const FillChunk c = table[blockIdx.x];
+  if (((c.dst | c.bytes) & 15ull) == 0) {
+    uint4* p = (uint4*)c.dst;
+    const uint4 v{c.value, c.value, c.value, c.value};
+    for (uint32_t i = threadIdx.x; i < (c.bytes >> 4); i += 256) p[i] = v;
+  } else {
+    uint32_t* p = (uint32_t*)c.dst;
+    for (uint32_t i = threadIdx.x; i < (c.bytes >> 2); i += 256) p[i] = c.value;
+  }
+}
+
 // ---------------------------------------------------------------- trailing update on the matrix cores
 // C[i][j] -= sum_{p < kp} P[p][i] P[p][j]   for r0 <= i < r1, i <= j < n,   P = rows p0 .. p0+kp-1 of A (finished [R S d] rows).
 // Block = 4 waves computing a 128x128 tile (each wave 64x64 = 4x4 MFMA 16x16x4 f64 tiles, 128 accumulator VGPRs).

@@ -293,6 +293,10 @@ struct lmgpu_handle {
   std::vector<BsdRun> bsd_runs;
   std::vector<int> bsd_run_of;          // per level: index of the run that starts (top) here, -2 inside a run, -1 none
   BsdBlock* d_bsd_run_table = nullptr;
+  // the clears and sentinel fills at the head of an elimination / a back-substitution, one launch each (fill_chunks_kernel)
+  FillChunk* d_fill_elim = nullptr;
+  FillChunk* d_fill_backsub = nullptr;
+  int n_fill_elim = -1, n_fill_backsub = -1, fill_backsub_merge = -1;
   double* d_bsd_x = nullptr;            // their published x (64 per block), preset to the all-ones sentinel at the start of a back-substitution
   unsigned int* d_bsd_ticket = nullptr; // one ticket counter per level
   size_t bsd_x_count = 0;
@@ -580,10 +584,23 @@ static bool gather_writes(const lmgpu_handle* h, int fi) {
   return (h->h_fronts[fi].pad & 1) != 0 && (h->comm || h->lgroup);  // the partial-assembly buffer is in use (`split` below)
 }
 
+static void add_fill(std::vector<FillChunk>& t, const void* p, size_t bytes, uint32_t value) {
+  for (size_t o = 0; o < bytes; o += FILL_CHUNK_BYTES)
+    t.push_back(FillChunk{(unsigned long long)(uintptr_t)p + o, (uint32_t)std::min<size_t>(FILL_CHUNK_BYTES, bytes - o), value});
+}
+
 int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  // lambda by value (eager) or in device memory (graph replay)
   hipStream_t s = h->stream;
-  HIPCHECK(hipMemsetAsync(h->d_status, 0x7f, sizeof(int), s));
-  HIPCHECK(hipMemsetAsync(h->d_status + 1, 0, sizeof(int), s));  // [1]: a dataflow hand-off timed out (1 + front id)
+  const bool merge_el = h->merge_elim && !h->elim_segs.empty();
+  std::vector<FillChunk> fills;
+  const bool build_fills = h->n_fill_elim < 0;
+  if (build_fills) {
+    add_fill(fills, h->d_status, sizeof(int), 0x7f7f7f7fu);
+    add_fill(fills, h->d_status + 1, sizeof(int), 0u);  // [1]: a dataflow hand-off timed out (1 + front id)
+    if (merge_el || h->fuse_levels)  // one ticket counter per level (shared with the back-substitution, which clears them again)
+      add_fill(fills, h->d_bs_done, (size_t)(h->h_fronts.size() + h->levels.size() + 1) * sizeof(unsigned int), 0u);
+    if (h->fuse_levels) add_fill(fills, h->d_level_sync, (size_t)h->n_level_sync * sizeof(LevelSync), 0u);
+  }
   {  // HBM fronts are accumulated into by their children (atomics) before their own level runs: clear them all first
     const int kt0 = h->kt.begin(LMGPU_KT_HBM_ASSEMBLE, s);
     int n_hbm = 0;
@@ -599,7 +616,7 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
     if (n_hbm > 4 && hi - lo <= 2 * sum) {
       // many mid-size fronts (general sparse graphs): one memset over their span; what lies between them ([R S d] / update
       // storage of LDS fronts, laid out in the same post-order) is rewritten by this elimination before it is read
-      HIPCHECK(hipMemsetAsync(h->pool + lo, 0, (size_t)(hi - lo) * sizeof(double), s));
+      if (build_fills) add_fill(fills, h->pool + lo, (size_t)(hi - lo) * sizeof(double), 0u);
     } else if (n_hbm > 4) {
       // scattered through the pool: one launch over the list of their ranges (built once; f_ld and the pool offsets are multiples of 16)
       if (!h->d_zero_ranges) {
@@ -628,17 +645,19 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
           if (!gw && h->s_off[fi] >= 0) HIPCHECK(hipMemsetAsync(h->pool + h->s_off[fi], 0, bytes, s));
         }
     }
+    if (build_fills) {
+      h->n_fill_elim = (int)fills.size();
+      const int rcu = upload(h, &h->d_fill_elim, fills);
+      if (rcu) return rcu;
+    }
+    hipLaunchKernelGGL(fill_chunks_kernel, dim3(h->n_fill_elim), dim3(256), 0, s, (const FillChunk*)h->d_fill_elim);
     h->kt.end(kt0, s);
   }
   // (Running a level's LDS fronts on a second stream beside its dense fronts -- they only depend on the levels below -- was measured
   //  with the replayed graph: 4.9 vs 2.5 ms per LM iteration on sphere2500; every cross-stream edge of the graph costs more than the
   //  45 us of LDS-front latency it hides.  Not kept.)
-  const bool merge_el = h->merge_elim && !h->elim_segs.empty();
-  if (merge_el || h->fuse_levels)  // one ticket counter per level (shared with the back-substitution, which clears them again)
-    HIPCHECK(hipMemsetAsync(h->d_bs_done, 0, (size_t)(h->h_fronts.size() + h->levels.size() + 1) * sizeof(unsigned int), s));
   if (merge_el)  // "not published yet" over the update matrices of the merged launches' fronts
     hipLaunchKernelGGL(fill_upper_kernel, dim3(h->n_fill_upper), dim3(256), 0, s, (const FillUpper*)h->d_fill_upper, h->pool);
-  if (h->fuse_levels) HIPCHECK(hipMemsetAsync(h->d_level_sync, 0, (size_t)h->n_level_sync * sizeof(LevelSync), s));
   for (size_t li = 0; li < h->levels.size(); li++) {
     const LevelWork& L = h->levels[li];
     const int seg = merge_el ? h->elim_seg_of[li] : -1;
@@ -1037,14 +1056,29 @@ int do_backsub(lmgpu_handle* h) {
   const bool merge = h->merge_backsub && h->cfg.world_size == 1 && !(h->cfg.flags & LMGPU_FLAG_SPLIT_ROOT);
   const bool no_bsd_runs = dev_switch("LMGPU_NO_BSD_RUNS") != nullptr;
   const int NFR = (int)h->h_fronts.size();
-  if (merge) {
-    HIPCHECK(hipMemsetAsync(h->d_bs_done, 0, (size_t)(NFR + h->levels.size() + 1) * sizeof(unsigned int), s));  // (the ticket counters)
-    HIPCHECK(hipMemsetAsync(h->delta, 0xff, h->ntot * sizeof(double), s));  // "not published yet": merged launches hand x over through delta itself
+  if (h->n_fill_backsub < 0 || h->fill_backsub_merge != (int)merge) {
+    std::vector<FillChunk> fills;
+    if (merge) {
+      add_fill(fills, h->d_bs_done, (size_t)(NFR + h->levels.size() + 1) * sizeof(unsigned int), 0u);  // (the ticket counters)
+      add_fill(fills, h->delta, h->ntot * sizeof(double), 0xffffffffu);  // "not published yet": merged launches hand x over through delta itself
+    }
+    if (h->bsd_x_count > 0) {
+      add_fill(fills, h->d_bsd_x, h->bsd_x_count * sizeof(double), 0xffffffffu);  // "not published yet"
+      add_fill(fills, h->d_bsd_ticket, h->levels.size() * sizeof(unsigned int), 0u);
+    }
+    if (h->d_fill_backsub) {
+      HIPCHECK(hipStreamSynchronize(s));
+      (void)hipFree(h->d_fill_backsub);
+      h->d_fill_backsub = nullptr;
+    }
+    h->n_fill_backsub = (int)fills.size();
+    h->fill_backsub_merge = (int)merge;
+    if (!fills.empty()) {
+      const int rcu = upload(h, &h->d_fill_backsub, fills);
+      if (rcu) return rcu;
+    }
   }
-  if (h->bsd_x_count > 0) {
-    HIPCHECK(hipMemsetAsync(h->d_bsd_x, 0xff, h->bsd_x_count * sizeof(double), s));  // "not published yet"
-    HIPCHECK(hipMemsetAsync(h->d_bsd_ticket, 0, h->levels.size() * sizeof(unsigned int), s));
-  }
+  if (h->n_fill_backsub > 0) hipLaunchKernelGGL(fill_chunks_kernel, dim3(h->n_fill_backsub), dim3(256), 0, s, (const FillChunk*)h->d_fill_backsub);
   int seg_hi = -1, seg_lo = -1;  // levels of the pending segment (top, bottom)
   auto run_level = [&](const LevelWork& L) {  // one level as a launch of its own
     if (L.lds_nf_max > LDSB_SMALL_NF) {
@@ -1773,7 +1807,7 @@ int lmgpu_destroy(lmgpu_handle* h) {
     for (int i = 0; i < 8; i++)
       if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     for (hipEvent_t e : h->kt.pool) (void)hipEventDestroy(e);
-    fr(h->bs_inv); fr(h->bs_x); fr(h->bs_flags); fr(h->inv16); fr(h->d_pflags); fr(h->d_bs_parent); fr(h->d_bs_pos); fr(h->d_bs_done); fr(h->d_fill_upper); fr(h->d_level_tasks); fr(h->d_level_sync); fr(h->d_bsd_table); fr(h->d_bsd_run_table); fr(h->d_zero_ranges); fr(h->d_bsd_x); fr(h->d_bsd_ticket); fr(h->d_leafpack); fr(h->d_gzero);
+    fr(h->bs_inv); fr(h->bs_x); fr(h->bs_flags); fr(h->inv16); fr(h->d_pflags); fr(h->d_bs_parent); fr(h->d_bs_pos); fr(h->d_bs_done); fr(h->d_fill_upper); fr(h->d_level_tasks); fr(h->d_level_sync); fr(h->d_bsd_table); fr(h->d_bsd_run_table); fr(h->d_fill_elim); fr(h->d_fill_backsub); fr(h->d_zero_ranges); fr(h->d_bsd_x); fr(h->d_bsd_ticket); fr(h->d_leafpack); fr(h->d_gzero);
     for (auto& kv : h->chain_plans)
       for (auto& cp : kv.second) fr(cp.d_tasks);
     fr(h->d_gpblk); fr(h->d_gpent); fr(h->d_gvblk); fr(h->d_gvent); fr(h->d_gcorner); fr(h->d_row_begin); fr(h->d_rowptr); fr(h->d_rowsrc);
