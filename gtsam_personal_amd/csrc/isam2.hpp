@@ -193,6 +193,10 @@ struct lmgpu_isam2 {
   size_t marg_cap = 0;
   double* h_delta = nullptr;  // pinned copy of delta for CheckRelinearizationFull
   size_t h_delta_cap = 0;
+  // (Gauss-Newton mode) the pinned copy is a MIRROR: delta only changes in the walk, which stores what it keeps to both places (no copy
+  // command behind the walk).  mirror_ntot = leading scalars of h_delta that equal the device's; 0 = not valid (a full copy brings it back)
+  double* h_delta_dev = nullptr;
+  size_t mirror_ntot = 0;
   // LMGPU_ISAM2_TRACE=1: wall time per phase of update(), printed when the handle is destroyed (development aid)
   bool trace = false;
   double t_phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -229,7 +233,15 @@ __global__ __launch_bounds__(256) void isam2_scatter_kernel(const lmgpu_isam2::P
     for (uint32_t w = threadIdx.x; w < r.words; w += 256) ((unsigned char*)r.dst)[w] = v;
     return;
   }
-  for (uint32_t w = threadIdx.x; w < r.words; w += 256) dst[w] = src[w];
+  // (the source is pinned host memory read over the link: four loads in flight per thread, one round trip per 4 KB, not one per KB)
+  for (uint32_t w = threadIdx.x; w < r.words; w += 1024) {
+    uint32_t v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) v[u] = (w + 256 * u < r.words) ? src[w + 256 * u] : 0u;
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (w + 256 * u < r.words) dst[w + 256 * u] = v[u];
+  }
 }
 
 namespace {
@@ -361,12 +373,12 @@ int is_push(lmgpu_isam2* S, void* dst, const void* src, size_t bytes) {
 int is_flush(lmgpu_isam2* S) {
   const lmgpu_isam2::PushRec* d_recs = nullptr;
   if (S->stage_copy_mark > S->stage_flushed) {
-    // device-arena tables staged since the last flush: carried by the scatter kernel too (records of 16 KB: it reads the pinned arena in
-    // place) -- a copy command of its own was one more dependent device operation per update
+    // device-arena tables staged since the last flush: carried by the scatter kernel too (records of 4 KB, one round trip over the link
+    // each, side by side: it reads the pinned arena in place) -- a copy command of its own was one more dependent device operation per update
     const size_t bytes = (S->stage_copy_mark - S->stage_flushed + 3) & ~size_t(3);
     if (bytes <= (size_t(1) << 20)) {
-      for (size_t o = 0; o < bytes; o += 16384) {
-        const size_t nb = std::min<size_t>(16384, bytes - o);
+      for (size_t o = 0; o < bytes; o += 4096) {
+        const size_t nb = std::min<size_t>(4096, bytes - o);
         S->pushes.push_back(lmgpu_isam2::PushRec{S->d_stage + S->stage_flushed + o, S->h_stage + S->stage_flushed + o, (uint32_t)(nb >> 2), 0u});
       }
     } else {  // (a batch step's tables: the copy engine)
@@ -648,7 +660,8 @@ __global__ __launch_bounds__(256) void isam2_wildfire_kernel(long long* __restri
                                                               double* __restrict__ delta, const unsigned char* __restrict__ replaced,
                                                               unsigned char* __restrict__ changed, double threshold, int* __restrict__ status,
                                                               unsigned char epoch, int* __restrict__ relay, unsigned char* __restrict__ done,
-                                                              int by_value) {
+                                                              int by_value, double* __restrict__ mirror) {
+  // mirror: (or null) the host's pinned copy of delta, kept equal to it: every x the walk keeps is stored there as well
   // by_value: the re-eliminated top of the tree (every clique reached from a root through replaced cliques; the host filled their frontal
   // scalars of delta with the all-ones pattern in the flush in front of this launch) hands x over BY VALUE, as the merged back-substitution
   // of the batch path does: the parent stores x_F with agent-scope stores right after its solve, the child polls its separator scalars.
@@ -822,6 +835,7 @@ __global__ __launch_bounds__(256) void isam2_wildfire_kernel(long long* __restri
           const int xo = fxr[i];
           delta[xo] = y[i];
           changed[xo] = epoch;
+          if (mirror) mirror[xo] = y[i];
         }
     } else if (in_top) {
       bool bad, timed_out = false;
@@ -830,6 +844,7 @@ __global__ __launch_bounds__(256) void isam2_wildfire_kernel(long long* __restri
         const double xv = x[tid];
         __hip_atomic_store(&delta[fo], (xv != xv) ? __longlong_as_double(0x7ff8000000000000LL) : xv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // never the sentinel
         changed[fo] = epoch;
+        if (mirror) mirror[fo] = xv;
       }
       if (timed_out) atomicMin(status, -1);  // never expected: spin bound hit (reported as a fault by the host)
       if (bad && lane == 0) atomicMin(status, F.id);  // NaN: IndeterminantLinearSystemException (ISAM2Clique.cpp:124-126)
@@ -848,6 +863,7 @@ __global__ __launch_bounds__(256) void isam2_wildfire_kernel(long long* __restri
       if (keep && tid < nf) {
         delta[fo] = x[tid];
         changed[fo] = epoch;
+        if (mirror) mirror[fo] = x[tid];
       }
     }
     // done: every wave's stores have been performed, then one release + the flag the children wait for
@@ -1136,6 +1152,27 @@ int is_update_delta_enqueue(lmgpu_isam2* S, bool force_full, bool host_delta, do
   if (S->ntot == 0) return LMGPU_OK;
   const double thr = force_full ? 0.0 : (S->dogleg ? S->dogleg_wildfire : S->prm.wildfireThreshold);
   double* const wf_delta = target ? target : S->delta;
+  // the host's mirror of delta (see h_delta): the scalars added since the last walk are zero on both sides (delta_.insert(zeroVectors))
+  double* mirror = nullptr;
+  if (!S->dogleg && !target) {
+    if ((size_t)S->ntot > S->h_delta_cap) {
+      if (S->h_delta) {
+        ISCHECK(hipStreamSynchronize(S->stream));
+        (void)hipHostFree(S->h_delta);
+      }
+      S->h_delta = nullptr;
+      S->mirror_ntot = 0;
+      S->h_delta_cap = is_next_cap(S->h_delta_cap, (size_t)S->ntot);
+      ISCHECK(hipHostMalloc((void**)&S->h_delta, S->h_delta_cap * sizeof(double), hipHostMallocMapped));
+      ISCHECK(hipHostGetDevicePointer((void**)&S->h_delta_dev, S->h_delta, 0));
+    }
+    if (dev_switch("LMGPU_ISAM2_NO_MIRROR")) S->mirror_ntot = 0;
+    if (S->mirror_ntot > 0) {
+      for (size_t i = S->mirror_ntot; i < (size_t)S->ntot; i++) S->h_delta[i] = 0.0;
+      S->mirror_ntot = (size_t)S->ntot;
+      mirror = S->h_delta_dev;
+    }
+  }
   // No clears and no status copy: d_changed / d_replaced hold the EPOCH of the walk that set them (a new epoch per walk; both arrays
   // are cleared only when the 8-bit epoch wraps), the status word is reset by the same scatter kernel that seeds the work list, and the
   // last workgroup to leave the walk stores it into the host's pinned word.  (Each was a device operation of its own: ~6 us of stream time.)
@@ -1174,7 +1211,7 @@ int is_update_delta_enqueue(lmgpu_isam2* S, bool force_full, bool host_delta, do
     if ((rc = is_flush(S))) return rc;
     hipLaunchKernelGGL(isam2_wildfire_kernel, dim3(ISAM2_WL_GROUPS), dim3(256), (S->tree_lds + LDSB_TAIL) * sizeof(double), S->stream, S->d_queue, S->d_wl,
                        (const FrontDesc*)S->d_tree, (const int32_t*)S->d_tree_fx, (const int32_t*)S->d_tree_sx, (const double*)S->pool, wf_delta,
-                       (const unsigned char*)S->d_replaced, S->d_changed, thr, S->d_status, S->epoch, S->h_status_dev, S->d_tree_done, by_value);
+                       (const unsigned char*)S->d_replaced, S->d_changed, thr, S->d_status, S->epoch, S->h_status_dev, S->d_tree_done, by_value, mirror);
     ISCHECK(hipGetLastError());
   }
   if (++S->epoch == 0) {  // wrapped: start over from clean arrays
@@ -1183,14 +1220,9 @@ int is_update_delta_enqueue(lmgpu_isam2* S, bool force_full, bool host_delta, do
     ISCHECK(hipMemsetAsync(S->d_replaced, 0, (size_t)S->ntot_cap, S->stream));
     if (S->d_tree_done) ISCHECK(hipMemsetAsync(S->d_tree_done, 0, S->tree_slots, S->stream));
   }
-  if (host_delta && !target) {
-    if ((size_t)S->ntot > S->h_delta_cap) {
-      if (S->h_delta) (void)hipHostFree(S->h_delta);
-      S->h_delta = nullptr;
-      S->h_delta_cap = is_next_cap(S->h_delta_cap, (size_t)S->ntot);
-      ISCHECK(hipHostMalloc((void**)&S->h_delta, S->h_delta_cap * sizeof(double), hipHostMallocDefault));
-    }
-    ISCHECK(hipMemcpyAsync(S->h_delta, S->delta, (size_t)S->ntot * sizeof(double), hipMemcpyDeviceToHost, S->stream));  // CheckRelinearizationFull reads it
+  if (host_delta && !target && !mirror) {  // CheckRelinearizationFull reads it; from here on the walk keeps it current
+    ISCHECK(hipMemcpyAsync(S->h_delta, S->delta, (size_t)S->ntot * sizeof(double), hipMemcpyDeviceToHost, S->stream));
+    S->mirror_ntot = (size_t)S->ntot;
   }
   return LMGPU_OK;
 }
