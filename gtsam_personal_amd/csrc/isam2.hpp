@@ -197,6 +197,10 @@ struct lmgpu_isam2 {
   // command behind the walk).  mirror_ntot = leading scalars of h_delta that equal the device's; 0 = not valid (a full copy brings it back)
   double* h_delta_dev = nullptr;
   size_t mirror_ntot = 0;
+  // what a walk needs on the device besides the tree patch (work-list seeds, counters, a fresh status word, the all-ones fill of the
+  // re-eliminated top) has been pushed -- by the update, whose elimination flush carries it (one scatter launch less per update + walk)
+  bool walk_prepared = false;
+  unsigned int seeded = 0;  // queue slots the last seeding wrote
   // LMGPU_ISAM2_TRACE=1: wall time per phase of update(), printed when the handle is destroyed (development aid)
   bool trace = false;
   double t_phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1144,10 +1148,53 @@ int is_patch_tree(lmgpu_isam2* S) {
 // is_update_delta_finish waits and looks at the status word.
 // host_delta: also bring delta to the pinned host copy (CheckRelinearizationFull reads it; the estimate readers do not need it)
 int is_update_delta_dogleg(lmgpu_isam2* S, bool force_full, bool host_delta);
-int is_update_delta_enqueue(lmgpu_isam2* S, bool force_full, bool host_delta, double* target = nullptr) {
-  if (S->dogleg && !target) return is_update_delta_dogleg(S, force_full, host_delta);  // (waits itself; _finish then finds an idle stream)
+static int is_walk_by_value(const lmgpu_isam2* S) { return (!S->dogleg && !dev_switch("LMGPU_ISAM2_NO_BYVALUE")) ? 1 : 0; }
+// the pushes a walk consumes (see walk_prepared): the tree patch, and for a non-empty tree the seeds, the counters, the status word and
+// (by_value) the all-ones pattern over the frontal scalars of the re-eliminated top
+int is_walk_prepare(lmgpu_isam2* S, int by_value) {
   int rc = is_patch_tree(S);
   if (rc) return rc;
+  S->walk_prepared = false;
+  if (S->ntot == 0 || S->roots.empty()) return LMGPU_OK;
+  // the walk starts at every root (ISAM2-impl.cpp:60-66): queue[0 .. r) = roots, tail = r, next ticket = 0, unfinished = r, leavers = 0
+  const unsigned int r = (unsigned int)S->roots.size();
+  const unsigned int ctl[4] = {r, 0u, r, 0u};
+  const int32_t fresh = 0x7f7f7f7f;
+  std::vector<long long> seeds(std::max(r, S->seeded), -1LL);  // (slots of an earlier seeding no walk consumed go back to "empty")
+  for (unsigned int q = 0; q < r; q++) seeds[q] = (long long)(unsigned int)S->roots[q] | (long long)0x7fffffff << 32;  // (no parent)
+  if (by_value) {
+    std::vector<int32_t> stack;
+    std::vector<std::pair<int32_t, int32_t>> runs;  // (xoff, scalars)
+    for (int32_t rt : S->roots) stack.push_back(rt);
+    while (!stack.empty()) {
+      const lmgpu_isam2::Clq& c = S->clq[stack.back()];
+      stack.pop_back();
+      if (c.ld > 0 || !S->replaced[c.vars[0]]) continue;  // (the kernel's rule: a wide clique and everything below it wait for done flags)
+      for (int k = 0; k < c.nfv; k++) runs.emplace_back(S->vars[c.vars[k]].xoff, kVarDim[S->vars[c.vars[k]].type]);
+      for (int32_t ch : c.children) stack.push_back(ch);
+    }
+    std::sort(runs.begin(), runs.end());
+    for (size_t a = 0; a < runs.size();) {
+      size_t b = a + 1;
+      int32_t end = runs[a].first + runs[a].second;
+      while (b < runs.size() && runs[b].first == end) end += runs[b++].second;
+      S->pushes.push_back(lmgpu_isam2::PushRec{S->delta + runs[a].first, nullptr, (uint32_t)(2 * (end - runs[a].first)), 1u});
+      a = b;
+    }
+  }
+  if ((rc = is_push(S, S->d_queue, seeds.data(), seeds.size() * sizeof(long long)))) return rc;
+  if ((rc = is_push(S, S->d_wl, ctl, sizeof(ctl)))) return rc;
+  if ((rc = is_push(S, S->d_status, &fresh, sizeof(fresh)))) return rc;
+  S->seeded = r;
+  S->walk_prepared = true;
+  return LMGPU_OK;
+}
+int is_update_delta_enqueue(lmgpu_isam2* S, bool force_full, bool host_delta, double* target = nullptr) {
+  if (S->dogleg && !target) return is_update_delta_dogleg(S, force_full, host_delta);  // (waits itself; _finish then finds an idle stream)
+  const int by_value = target ? 0 : is_walk_by_value(S);
+  int rc = S->walk_prepared ? is_patch_tree(S) : is_walk_prepare(S, by_value);  // (prepared by the update: only what touched the tree since)
+  if (rc) return rc;
+  S->walk_prepared = false;
   *S->h_status = 0x7f7f7f7f;
   if (S->ntot == 0) return LMGPU_OK;
   const double thr = force_full ? 0.0 : (S->dogleg ? S->dogleg_wildfire : S->prm.wildfireThreshold);
@@ -1177,37 +1224,6 @@ int is_update_delta_enqueue(lmgpu_isam2* S, bool force_full, bool host_delta, do
   // are cleared only when the 8-bit epoch wraps), the status word is reset by the same scatter kernel that seeds the work list, and the
   // last workgroup to leave the walk stores it into the host's pinned word.  (Each was a device operation of its own: ~6 us of stream time.)
   if (!S->roots.empty()) {
-    // the walk starts at every root (ISAM2-impl.cpp:60-66): queue[0 .. r) = roots, tail = r, next ticket = 0, unfinished = r, leavers = 0
-    const unsigned int r = (unsigned int)S->roots.size();
-    const unsigned int ctl[4] = {r, 0u, r, 0u};
-    const int32_t fresh = 0x7f7f7f7f;
-    std::vector<long long> seeds(r);
-    for (unsigned int q = 0; q < r; q++) seeds[q] = (long long)(unsigned int)S->roots[q] | (long long)0x7fffffff << 32;  // (no parent)
-    // the re-eliminated top of the tree hands x over by value (see the kernel): its frontal scalars carry the all-ones pattern until solved
-    const int by_value = (!S->dogleg && !target && !dev_switch("LMGPU_ISAM2_NO_BYVALUE")) ? 1 : 0;
-    if (by_value) {
-      std::vector<int32_t> stack;
-      std::vector<std::pair<int32_t, int32_t>> runs;  // (xoff, scalars)
-      for (int32_t rt : S->roots) stack.push_back(rt);
-      while (!stack.empty()) {
-        const lmgpu_isam2::Clq& c = S->clq[stack.back()];
-        stack.pop_back();
-        if (c.ld > 0 || !S->replaced[c.vars[0]]) continue;  // (the kernel's rule: a wide clique and everything below it wait for done flags)
-        for (int k = 0; k < c.nfv; k++) runs.emplace_back(S->vars[c.vars[k]].xoff, kVarDim[S->vars[c.vars[k]].type]);
-        for (int32_t ch : c.children) stack.push_back(ch);
-      }
-      std::sort(runs.begin(), runs.end());
-      for (size_t a = 0; a < runs.size();) {
-        size_t b = a + 1;
-        int32_t end = runs[a].first + runs[a].second;
-        while (b < runs.size() && runs[b].first == end) end += runs[b++].second;
-        S->pushes.push_back(lmgpu_isam2::PushRec{S->delta + runs[a].first, nullptr, (uint32_t)(2 * (end - runs[a].first)), 1u});
-        a = b;
-      }
-    }
-    if ((rc = is_push(S, S->d_queue, seeds.data(), r * sizeof(long long)))) return rc;
-    if ((rc = is_push(S, S->d_wl, ctl, sizeof(ctl)))) return rc;
-    if ((rc = is_push(S, S->d_status, &fresh, sizeof(fresh)))) return rc;
     if ((rc = is_flush(S))) return rc;
     hipLaunchKernelGGL(isam2_wildfire_kernel, dim3(ISAM2_WL_GROUPS), dim3(256), (S->tree_lds + LDSB_TAIL) * sizeof(double), S->stream, S->d_queue, S->d_wl,
                        (const FrontDesc*)S->d_tree, (const int32_t*)S->d_tree_fx, (const int32_t*)S->d_tree_sx, (const double*)S->pool, wf_delta,
@@ -1517,6 +1533,8 @@ int is_eliminate_fronts(lmgpu_isam2* S, const std::vector<IsGF>& gfs, const std:
     const unsigned int zero[2] = {0u, 0u};  // the ticket counter, the count of finished workgroups
     if ((rc = is_push(S, S->d_eticket, zero, sizeof(zero)))) return rc;
   }
+  // the tree is final here (new cliques, adopted orphans, roots): what the next walk needs rides this flush (see walk_prepared)
+  if (attach && !S->dogleg && !dev_switch("LMGPU_ISAM2_LATE_WALK_PREP") && (rc = is_walk_prepare(S, is_walk_by_value(S)))) return rc;
   *S->h_status = 0x7f7f7f7f;  // (before the launch that may relay the status word)
   if ((rc = is_flush(S))) return rc;  // the tables above, and whatever the update pushed before (new values, factor rows)
   if (merged) {
@@ -1610,6 +1628,7 @@ int is_finish_elimination(lmgpu_isam2* S) {
   if (*S->h_status < (int)S->elim_cid.size()) {
     S->failed_key = S->vars[S->clq[S->elim_cid[*S->h_status]].vars[0]].key;
     S->err = "indeterminate linear system";
+    S->walk_prepared = false;  // (the status word a walk starts from has to be pushed again)
     return LMGPU_INDETERMINATE;
   }
   return LMGPU_OK;
@@ -2003,7 +2022,9 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
       if ((rc = is_push(S, S->theta[t] + (size_t)first_tidx[t] * kVarStore[t], vals[t].data(), vals[t].size() * sizeof(double)))) return rc;
       if ((rc = is_push(S, S->d_type_xoff[t] + first_tidx[t], xoffs[t].data(), xoffs[t].size() * sizeof(int32_t)))) return rc;
     }
-    ISCHECK(hipMemsetAsync(S->delta + ntot0, 0, (size_t)(S->ntot - ntot0) * sizeof(double), S->stream));  // delta_.insert(zeroVectors)
+    // delta_.insert(zeroVectors): a byte-fill record of the next flush (a fill command of its own was one more device operation per update).
+    // (The all-ones fill a walk pushes over the same scalars comes after this update's elimination, whose flush carries this record.)
+    S->pushes.push_back(lmgpu_isam2::PushRec{S->delta + ntot0, (const void*)(uintptr_t)0, (uint32_t)((size_t)(S->ntot - ntot0) * sizeof(double)), 2u});
     if (S->dogleg) {  // deltaNewton_ / RgProd_.insert(zeroVectors) (ISAM2.cpp:373-374)
       ISCHECK(hipMemsetAsync(S->delta_newton + ntot0, 0, (size_t)(S->ntot - ntot0) * sizeof(double), S->stream));
       ISCHECK(hipMemsetAsync(S->rgprod + ntot0, 0, (size_t)(S->ntot - ntot0) * sizeof(double), S->stream));
@@ -2432,6 +2453,7 @@ int is_marginalize_leaves(lmgpu_isam2* S, const std::vector<uint64_t>& leafList)
     S->err = "ISAM2::marginalizeLeaves: variables or factors are waiting for an update";
     return LMGPU_INVALID;
   }
+  S->walk_prepared = false;  // (cliques and roots change below: the next walk seeds itself)
   const std::set<uint64_t> leafKeys(leafList.begin(), leafList.end());
   std::set<int32_t> leafV;
   for (uint64_t k : leafKeys) {
