@@ -201,6 +201,9 @@ struct lmgpu_isam2 {
   // re-eliminated top) has been pushed -- by the update, whose elimination flush carries it (one scatter launch less per update + walk)
   bool walk_prepared = false;
   unsigned int seeded = 0;  // queue slots the last seeding wrote
+  // An update ends with the walk (behind its elimination, under the same wait) when delta is going to be asked for before the next
+  // elimination anyway: the next update checks relinearization, or the caller read an estimate after the previous update.
+  int delta_reads = 0;      // readers of delta since the last update returned
   // LMGPU_ISAM2_TRACE=1: wall time per phase of update(), printed when the handle is destroyed (development aid)
   bool trace = false;
   double t_phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1184,7 +1187,7 @@ int is_walk_prepare(lmgpu_isam2* S, int by_value) {
   }
   if ((rc = is_push(S, S->d_queue, seeds.data(), seeds.size() * sizeof(long long)))) return rc;
   if ((rc = is_push(S, S->d_wl, ctl, sizeof(ctl)))) return rc;
-  if ((rc = is_push(S, S->d_status, &fresh, sizeof(fresh)))) return rc;
+  if ((rc = is_push(S, S->d_status + 1, &fresh, sizeof(fresh)))) return rc;  // (word 1: the walk's own, an elimination in front of it uses word 0)
   S->seeded = r;
   S->walk_prepared = true;
   return LMGPU_OK;
@@ -1195,7 +1198,7 @@ int is_update_delta_enqueue(lmgpu_isam2* S, bool force_full, bool host_delta, do
   int rc = S->walk_prepared ? is_patch_tree(S) : is_walk_prepare(S, by_value);  // (prepared by the update: only what touched the tree since)
   if (rc) return rc;
   S->walk_prepared = false;
-  *S->h_status = 0x7f7f7f7f;
+  S->h_status[1] = 0x7f7f7f7f;
   if (S->ntot == 0) return LMGPU_OK;
   const double thr = force_full ? 0.0 : (S->dogleg ? S->dogleg_wildfire : S->prm.wildfireThreshold);
   double* const wf_delta = target ? target : S->delta;
@@ -1227,7 +1230,7 @@ int is_update_delta_enqueue(lmgpu_isam2* S, bool force_full, bool host_delta, do
     if ((rc = is_flush(S))) return rc;
     hipLaunchKernelGGL(isam2_wildfire_kernel, dim3(ISAM2_WL_GROUPS), dim3(256), (S->tree_lds + LDSB_TAIL) * sizeof(double), S->stream, S->d_queue, S->d_wl,
                        (const FrontDesc*)S->d_tree, (const int32_t*)S->d_tree_fx, (const int32_t*)S->d_tree_sx, (const double*)S->pool, wf_delta,
-                       (const unsigned char*)S->d_replaced, S->d_changed, thr, S->d_status, S->epoch, S->h_status_dev, S->d_tree_done, by_value, mirror);
+                       (const unsigned char*)S->d_replaced, S->d_changed, thr, S->d_status + 1, S->epoch, S->h_status_dev + 1, S->d_tree_done, by_value, mirror);
     ISCHECK(hipGetLastError());
   }
   if (++S->epoch == 0) {  // wrapped: start over from clean arrays
@@ -1246,12 +1249,12 @@ int is_update_delta_finish(lmgpu_isam2* S) {
   ISCHECK(hipStreamSynchronize(S->stream));
   std::fill(S->replaced.begin(), S->replaced.end(), 0);
   S->any_replaced = false;
-  if (*S->h_status < 0) {
+  if (S->h_status[1] < 0) {
     S->err = "ISAM2 back-substitution: a parent-to-child hand-off timed out";
     return LMGPU_HIP_ERROR;
   }
-  if (*S->h_status < (int)S->clq.size()) {
-    S->failed_key = S->vars[S->clq[*S->h_status].vars[0]].key;
+  if (S->h_status[1] < (int)S->clq.size()) {
+    S->failed_key = S->vars[S->clq[S->h_status[1]].vars[0]].key;
     S->err = "indeterminate linear system in back-substitution";
     return LMGPU_INDETERMINATE;
   }
@@ -2031,7 +2034,19 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
     }
   }
   const bool relinNeeded = force_relinearize || (S->prm.enableRelinearization && S->prm.relinearizeSkip > 0 && S->update_count % S->prm.relinearizeSkip == 0);
-  if (relinNeeded && (rc = is_update_delta(S, up.force_full_solve, true))) return rc;
+  const bool reads_before = S->delta_reads > 0;
+  S->delta_reads = 0;
+  if (relinNeeded) {
+    // delta and the host's mirror of it are current when nothing was re-eliminated since the last walk (the previous update ended with
+    // it): updateDelta would visit the roots and find nothing to do
+    const bool current = !S->dogleg && !S->any_replaced && !up.force_full_solve && S->mirror_ntot > 0 && (size_t)S->ntot <= S->h_delta_cap;
+    if (current) {
+      for (size_t i = S->mirror_ntot; i < (size_t)S->ntot; i++) S->h_delta[i] = 0.0;  // delta_.insert(zeroVectors)
+      S->mirror_ntot = (size_t)S->ntot;
+    } else if ((rc = is_update_delta(S, up.force_full_solve, true))) {
+      return rc;
+    }
+  }
   const int relin_ntot = S->ntot;  // scalars of delta the pinned copy holds
   lap(0);  // new variables + updateDelta (wildfire, one wait)
   // ---- 1. pushBackFactors (ISAM2-impl.h:145-175): FactorGraph::add_factors (FactorGraph-inst.h:109-137) -- the indices continue the list,
@@ -2424,7 +2439,16 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
   res.cliques = S->n_alive;  // (every alive clique hangs in the tree again by now; counting them by a walk was O(cliques) per update)
   if (result) *result = res;
   lap(5);
-  rc = is_finish_elimination(S);  // the one wait of an update without relinearization
+  bool walked = false;
+  if (!S->dogleg && S->any_replaced && !dev_switch("LMGPU_ISAM2_NO_PREWALK")) {
+    const bool next_relin = S->prm.enableRelinearization && S->prm.relinearizeSkip > 0 && (S->update_count + 1) % S->prm.relinearizeSkip == 0;
+    if (next_relin || reads_before) {
+      if ((rc = is_update_delta_enqueue(S, false, next_relin))) return rc;
+      walked = true;
+    }
+  }
+  rc = is_finish_elimination(S);  // the one wait of an update
+  if (rc == LMGPU_OK && walked) rc = is_update_delta_finish(S);  // (an indeterminate back-substitution is reported one call early)
   lap(6);
   if (rc == LMGPU_OK && S->evaluate_error) {  // errorAfter (ISAM2.cpp:481-483), again through calculateEstimate()
     if (S->any_replaced && (rc = is_update_delta(S, false))) return rc;
@@ -2750,8 +2774,8 @@ int lmgpu_isam2_create(const lmgpu_config* cfg, const lmgpu_isam2_params* prm, l
   }
   ISCHECK(hipSetDevice(S->device));
   ISCHECK(hipStreamCreate(&S->stream));
-  ISCHECK(hipMalloc((void**)&S->d_status, sizeof(int)));
-  ISCHECK(hipHostMalloc((void**)&S->h_status, sizeof(int), hipHostMallocMapped));
+  ISCHECK(hipMalloc((void**)&S->d_status, 2 * sizeof(int)));  // [0] eliminations (and marginalCovariance), [1] the walks
+  ISCHECK(hipHostMalloc((void**)&S->h_status, 2 * sizeof(int), hipHostMallocMapped));
   ISCHECK(hipHostGetDevicePointer((void**)&S->h_status_dev, S->h_status, 0));
   ISCHECK(hipHostMalloc((void**)&S->h_val, 32 * sizeof(double), hipHostMallocMapped));
   ISCHECK(hipHostGetDevicePointer((void**)&S->h_val_dev, S->h_val, 0));
@@ -2941,6 +2965,7 @@ int lmgpu_isam2_error(lmgpu_isam2* S, int32_t which, double* out) {
   ISCHECK(hipSetDevice(S->device));
   int rc;
   if ((rc = is_stage_recycle(S))) return rc;
+  if (which == 0) S->delta_reads++;
   if (which == 0 && S->any_replaced && (rc = is_update_delta(S, false))) return rc;
   return is_graph_error(S, which == 0, out);
 }
@@ -3010,6 +3035,7 @@ int lmgpu_isam2_get_values(lmgpu_isam2* S, int32_t which, uint64_t* keys_out, in
   int rc;
   if ((rc = is_stage_recycle(S))) return rc;
   if ((rc = is_flush(S))) return rc;
+  if (which == 0) S->delta_reads++;
   if (which == 1) {  // calculateBestEstimate: full back-substitution (ISAM2.cpp:763-766)
     if ((rc = is_update_delta(S, true))) return rc;
   } else if (which == 0 && S->any_replaced) {  // getDelta (:776-779)
@@ -3111,6 +3137,7 @@ int lmgpu_isam2_get_value(lmgpu_isam2* S, int32_t which, uint64_t key, int32_t* 
   ISCHECK(hipSetDevice(S->device));
   int rc;
   if ((rc = is_stage_recycle(S))) return rc;
+  if (which == 0) S->delta_reads++;
   const bool walk = which == 0 && S->any_replaced;
   if (walk && (rc = is_update_delta_enqueue(S, false, false))) return rc;
   const lmgpu_isam2::Var& v = S->vars[it->second];
@@ -3143,6 +3170,7 @@ int lmgpu_isam2_get_delta(lmgpu_isam2* S, double* packed) {
   ISCHECK(hipSetDevice(S->device));
   int rc;
   if ((rc = is_stage_recycle(S))) return rc;
+  S->delta_reads++;
   if (S->any_replaced && (rc = is_update_delta(S, false))) return rc;
   std::vector<double> h((size_t)S->ntot);
   if (S->ntot) ISCHECK(hipMemcpy(h.data(), S->delta, h.size() * sizeof(double), hipMemcpyDeviceToHost));
