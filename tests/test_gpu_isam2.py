@@ -75,6 +75,27 @@ def test_updates_with_a_staging_arena_that_always_overflows(monkeypatch, dev_swi
     isam.close()
 
 
+@pytest.mark.parametrize("switch", ["LMGPU_ISAM2_NO_BYVALUE", "LMGPU_ISAM2_NO_MIRROR", "LMGPU_ISAM2_NO_PREWALK", "LMGPU_ISAM2_LATE_WALK_PREP"])
+def test_walk_scheduling_forms_against_the_oracle(monkeypatch, dev_switches, switch):
+    """the back-substitution walk's round-3 forms, each switched OFF in turn (the default is what every other test here runs): the
+    re-eliminated top of the tree handing x over by value, the host's mirror of delta written by the walk, the walk behind the update's
+    elimination when delta is going to be read anyway, its seeds / status word / all-ones fills pushed with the elimination's flush"""
+    monkeypatch.setenv(switch, "1")
+    isam, _ = run_sequence(visual_steps(), ISAM2Params(relinearizeThreshold=0.01, relinearizeSkip=1))
+    isam.close()
+    isam, _ = run_sequence(slamlike_steps(), ISAM2Params())
+    isam.close()
+
+
+@pytest.mark.parametrize("params", [ISAM2Params(), ISAM2Params(ISAM2GaussNewtonParams(0.001), 0.01, 1, True), ISAM2Params(ISAM2GaussNewtonParams(0.001), 0.05, 3, True)],
+                         ids=["defaults", "eager", "skip3"])
+def test_updates_without_a_reader_in_between(params):
+    """nobody asks for delta between the updates: an update then only ends with the walk when the NEXT one checks relinearization
+    (relinearizeSkip), and several updates' re-eliminated sets reach one walk; counts per update and the final state against the oracle"""
+    isam, _ = run_sequence(slamlike_steps(), params, check_every_step=False)
+    isam.close()
+
+
 @pytest.mark.parametrize("params", [
     ISAM2Params(ISAM2GaussNewtonParams(0.001), 0.0, 0, False),   # tests/testGaussianISAM2.cpp:303: relinearization off
     ISAM2Params(),                                                # defaults: threshold 0.1, every 10th update

@@ -175,6 +175,31 @@ def test_deep_tree_launch_forms_agree(monkeypatch, dev_switches):
             assert abs(e1 - e10) <= max(tol, 1e-15) * max(1.0, abs(e10)), mode
 
 
+def test_block_backsolve_runs_over_levels_are_bitwise_the_per_level_launches(monkeypatch, dev_switches):
+    """round 3: the block-solved fronts of consecutive levels go as ONE launch (separator values awaited by value); every block computes
+    what it computes in a launch per level (LMGPU_NO_BSD_RUNS), so delta is the same to the bit.  sphere2500 / COLAMD: a run of sixteen
+    levels; city10000 / COLAMD: runs that pass levels which also hold LDS fronts."""
+    from gtsam_personal_amd import noiseModel
+    from gtsam_personal_amd.datasets import chain_initial_pose3, load3D
+    import bench
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "slam_orderings.npz"))
+    for wl in ("sphere2500", "city10000"):
+        graph, initial = bench.slam_workload(wl)
+        keys = np.array(sorted(graph.keys()), dtype=np.uint64)
+        ordering = [int(k) for k in keys[fx[f"{wl}_colamd"]]]
+        out = {}
+        for mode in ("default", "LMGPU_NO_BSD_RUNS"):
+            monkeypatch.delenv("LMGPU_NO_BSD_RUNS", raising=False)
+            if mode != "default":
+                monkeypatch.setenv(mode, "1")
+            opt = LevenbergMarquardtOptimizer(graph, initial, ordering, LevenbergMarquardtParams(), device=0)
+            opt.linearize()
+            out[mode] = [opt.solve(lam)[1].copy() for lam in (1e-5, 1.0)]
+            opt.close()
+        for d, d0 in zip(out["LMGPU_NO_BSD_RUNS"], out["default"]):
+            assert np.array_equal(d, d0), wl
+
+
 def test_kernel_timers_modes():
     """lmgpu_set_kernel_timing: 1 = every category, 2 = only the roofline kernels (what bench.py keeps inside its timed region); the
     timers never change results"""
