@@ -168,7 +168,9 @@ struct lmgpu_isam2 {
   // factor, were most of the 0.4-0.7 ms an update cost.)  Requests beyond the arena get a chunk of their own, freed at the next update.
   char *h_stage = nullptr, *d_stage = nullptr;
   size_t stage_cap = 0, stage_used = 0, stage_want = 0;
-  std::vector<std::pair<void*, void*>> stage_extra;  // (pinned host, device)
+  std::vector<std::pair<void*, void*>> stage_extra;  // (pinned host, device): overflow slabs
+  char *ovf_h = nullptr, *ovf_d = nullptr;           // the current one
+  size_t ovf_used = 0, ovf_cap = 0;
   // Deferred uploads: what is_stage / is_push put into the pinned arena since the last flush travels to the device arena in ONE copy,
   // and the pushes (payload in the arena -> a persistent device array) are carried out by ONE scatter kernel (is_flush) -- an update
   // issued 28 copy commands of a few hundred bytes each before (rocprofv3: half of its GPU time, and ~4 us of host time apiece).
@@ -199,6 +201,7 @@ struct lmgpu_isam2 {
   size_t mirror_ntot = 0;
   // what a walk needs on the device besides the tree patch (work-list seeds, counters, a fresh status word, the all-ones fill of the
   // re-eliminated top) has been pushed -- by the update, whose elimination flush carries it (one scatter launch less per update + walk)
+  bool delta_zero_pending = false;  // a zero-fill record over new scalars of delta waits for its flush (an all-ones fill must not share it)
   bool walk_prepared = false;
   unsigned int seeded = 0;  // queue slots the last seeding wrote
   // An update ends with the walk (behind its elimination, under the same wait) when delta is going to be asked for before the next
@@ -290,6 +293,8 @@ int is_stage_begin(lmgpu_isam2* S) {
     if (e.second) (void)hipFree(e.second);
   }
   S->stage_extra.clear();
+  S->ovf_h = S->ovf_d = nullptr;
+  S->ovf_used = S->ovf_cap = 0;
   size_t floor_bytes = size_t(1) << 20;
   if (const char* e = dev_switch("LMGPU_ISAM2_STAGE_BYTES")) floor_bytes = (size_t)std::max(64L, atol(e));  // tests: a tiny arena, every request overflows
   const size_t want = dev_switch("LMGPU_ISAM2_STAGE_BYTES") ? floor_bytes : std::max<size_t>(floor_bytes, 2 * S->stage_want);
@@ -331,13 +336,24 @@ int is_stage_raw(lmgpu_isam2* S, size_t bytes, char** hp, char** dp) {
     S->stage_used += b;
     return LMGPU_OK;
   }
-  void *h = nullptr, *d = nullptr;
-  if (S->trace) std::fprintf(stderr, "isam2 staging: request of %zu bytes beyond the arena (%zu of %zu used) in update %d\n", b, S->stage_used, S->stage_cap, S->update_count);
-  ISCHECK(hipHostMalloc(&h, b, hipHostMallocMapped));
-  if (dp) ISCHECK(hipMalloc(&d, b));
-  S->stage_extra.emplace_back(h, d);
-  *hp = (char*)h;
-  if (dp) *dp = (char*)d;
+  // beyond the arena: overflow slabs of the arena's size (freed when the next update starts a bigger arena), requests bump-allocated from
+  // the current one -- a pinned allocation per request was 0.1 ms each, and a loop closure that re-eliminates thousands of cliques makes
+  // thousands of requests (400 ms in the last update of city10000, and 6 s to free them one by one)
+  if (!S->ovf_h || S->ovf_used + b > S->ovf_cap) {
+    void *h = nullptr, *d = nullptr;
+    const size_t cap = dev_switch("LMGPU_ISAM2_STAGE_BYTES") ? b : std::max(b, std::max<size_t>(S->stage_cap, size_t(1) << 20));
+    if (S->trace) std::fprintf(stderr, "isam2 staging: overflow slab of %zu bytes (request %zu, arena %zu of %zu used) in update %d\n", cap, b, S->stage_used, S->stage_cap, S->update_count);
+    ISCHECK(hipHostMalloc(&h, cap, hipHostMallocMapped));
+    ISCHECK(hipMalloc(&d, cap));
+    S->stage_extra.emplace_back(h, d);
+    S->ovf_h = (char*)h;
+    S->ovf_d = (char*)d;
+    S->ovf_used = 0;
+    S->ovf_cap = cap;
+  }
+  *hp = S->ovf_h + S->ovf_used;
+  if (dp) *dp = S->ovf_d + S->ovf_used;
+  S->ovf_used += b;
   return LMGPU_OK;
 }
 // a table the update's kernels read: host vector -> device arena (with the next flush; a request beyond the arena is copied at once)
@@ -345,7 +361,6 @@ int is_stage_raw(lmgpu_isam2* S, size_t bytes, char** hp, char** dp) {
 template <typename T>
 int is_stage(lmgpu_isam2* S, const std::vector<T>& src, T** d, bool device_copy = false) {
   char *hp, *dp = nullptr;
-  const size_t before = S->stage_extra.size();
   const int rc = is_stage_raw(S, src.size() * sizeof(T), &hp, device_copy ? &dp : nullptr);
   if (rc) return rc;
   if (!src.empty()) std::memcpy(hp, src.data(), src.size() * sizeof(T));
@@ -353,7 +368,7 @@ int is_stage(lmgpu_isam2* S, const std::vector<T>& src, T** d, bool device_copy 
     *d = (T*)hp;  // pinned host memory is mapped at the same address on the device
     return LMGPU_OK;
   }
-  if (S->stage_extra.size() != before) {
+  if (!(S->h_stage && hp >= S->h_stage && hp < S->h_stage + S->stage_cap)) {  // from an overflow slab
     if (!src.empty()) ISCHECK(hipMemcpyAsync(dp, hp, src.size() * sizeof(T), hipMemcpyHostToDevice, S->stream));
   } else {
     S->stage_copy_mark = S->stage_used;
@@ -395,6 +410,7 @@ int is_flush(lmgpu_isam2* S) {
     S->stage_flushed = S->stage_copy_mark;
   }
   const size_t npush = S->pushes.size();
+  S->delta_zero_pending = false;
   bool recs_in_arena = true;
   if (npush) {
     char* hp;
@@ -1166,6 +1182,7 @@ int is_walk_prepare(lmgpu_isam2* S, int by_value) {
   std::vector<long long> seeds(std::max(r, S->seeded), -1LL);  // (slots of an earlier seeding no walk consumed go back to "empty")
   for (unsigned int q = 0; q < r; q++) seeds[q] = (long long)(unsigned int)S->roots[q] | (long long)0x7fffffff << 32;  // (no parent)
   if (by_value) {
+    if (S->delta_zero_pending && (rc = is_flush(S))) return rc;
     std::vector<int32_t> stack;
     std::vector<std::pair<int32_t, int32_t>> runs;  // (xoff, scalars)
     for (int32_t rt : S->roots) stack.push_back(rt);
@@ -1956,6 +1973,7 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
     if (!S->trace) return;
     const double t = now();
     S->t_phase[i] += t - t_last;
+    if (t - t_last > 0.02) std::fprintf(stderr, "isam2 update %d: phase %d took %.1f ms\n", S->update_count, i, 1e3 * (t - t_last));
     t_last = t;
   };
   if ((rc = is_stage_begin(S))) return rc;
@@ -2026,7 +2044,9 @@ int is_update(lmgpu_isam2* S, const lmgpu_isam2::UpParams& up, lmgpu_isam2_resul
       if ((rc = is_push(S, S->d_type_xoff[t] + first_tidx[t], xoffs[t].data(), xoffs[t].size() * sizeof(int32_t)))) return rc;
     }
     // delta_.insert(zeroVectors): a byte-fill record of the next flush (a fill command of its own was one more device operation per update).
-    // (The all-ones fill a walk pushes over the same scalars comes after this update's elimination, whose flush carries this record.)
+    // (The all-ones fill a walk pushes over the same scalars must not ride the same flush: two records of one scatter launch are not
+    // ordered.  The linearization of the new factors flushes in between; is_walk_prepare flushes itself if it did not.)
+    S->delta_zero_pending = true;
     S->pushes.push_back(lmgpu_isam2::PushRec{S->delta + ntot0, (const void*)(uintptr_t)0, (uint32_t)((size_t)(S->ntot - ntot0) * sizeof(double)), 2u});
     if (S->dogleg) {  // deltaNewton_ / RgProd_.insert(zeroVectors) (ISAM2.cpp:373-374)
       ISCHECK(hipMemsetAsync(S->delta_newton + ntot0, 0, (size_t)(S->ntot - ntot0) * sizeof(double), S->stream));
@@ -3036,11 +3056,14 @@ int lmgpu_isam2_get_values(lmgpu_isam2* S, int32_t which, uint64_t* keys_out, in
   if ((rc = is_stage_recycle(S))) return rc;
   if ((rc = is_flush(S))) return rc;
   if (which == 0) S->delta_reads++;
+  auto tnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double tg0 = tnow();
   if (which == 1) {  // calculateBestEstimate: full back-substitution (ISAM2.cpp:763-766)
     if ((rc = is_update_delta(S, true))) return rc;
   } else if (which == 0 && S->any_replaced) {  // getDelta (:776-779)
     if ((rc = is_update_delta(S, false))) return rc;
   }
+  if (S->trace) std::fprintf(stderr, "isam2 get_values(%d): updateDelta %.1f ms\n", which, 1e3 * (tnow() - tg0));
   std::vector<std::vector<double>> host(kNumVarTypes);
   for (int t = 0; t < kNumVarTypes; t++) {
     const int n = S->type_count[t];
@@ -3055,6 +3078,7 @@ int lmgpu_isam2_get_values(lmgpu_isam2* S, int32_t which, uint64_t* keys_out, in
     ISCHECK(hipMemcpyAsync(host[t].data(), src, host[t].size() * sizeof(double), hipMemcpyDeviceToHost, S->stream));
   }
   ISCHECK(hipStreamSynchronize(S->stream));
+  if (S->trace) std::fprintf(stderr, "isam2 get_values(%d): retract + copies %.1f ms\n", which, 1e3 * (tnow() - tg0));
   for (auto& kv : S->vid_of) {  // ascending by key
     const lmgpu_isam2::Var& v = S->vars[kv.second];
     if (keys_out) *keys_out++ = v.key;
