@@ -288,6 +288,11 @@ int lmgpu_selftest_chain_schedule(int n, int nf, int i0, int nsteps, int far_pct
  * Robust noise models: lmgpu_isam2_add_factors_robust.
  * ISAM2::marginalizeLeaves: lmgpu_isam2_marginalize_leaves; ISAM2Params::findUnusedFactorSlots: lmgpu_isam2_set_find_unused_factor_slots.
  * Not bound: QR, newAffectedKeys (smart factors).
+ * updateDelta (ISAM2.cpp:701-719) is scheduled by the library: Gauss-Newton mode runs it BEHIND an update's elimination, under the update's
+ * one wait, when delta is going to be read before the next elimination anyway (the next update checks relinearization, or the caller read an
+ * estimate after the previous update); otherwise where the reference runs it (at the next reader).  Same delta either way; the one visible
+ * difference: an indeterminate back-substitution would be returned by that update instead of the next call (the elimination's own pivot
+ * test reports such a system first).
  *
  * The fill-reducing ordering is a boundary input like in the batch path, but here it is needed per update: the caller hands over
  * ITS ccolamd (the reference side: the one Ordering::ColamdConstrained calls, gtsam/inference/Ordering.cpp:50-125) as a callback:
