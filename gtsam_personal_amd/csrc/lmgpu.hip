@@ -1874,10 +1874,6 @@ int lmgpu_add_factor_bucket_robust(lmgpu_handle* h, int32_t type, int32_t n, con
         return LMGPU_INVALID;
       }
     }
-  if (robust_kind != LMGPU_ROBUST_NONE && ar > 2) {
-    h->err = "robust noise models are not wired for three-variable factors";
-    return LMGPU_INVALID;
-  }
   Bucket b;
   b.type = type;
   b.n = n;

@@ -171,6 +171,47 @@ def test_gpu_self_calibration_matches_oracle(kind):
     assert np.allclose(vd.at(K0)[[0, 2, 3]], np.array(K_TRUE)[[0, 2, 3]], atol=1.0)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mest", ["Huber", "Cauchy"])
+def test_gpu_self_calibration_with_robust_noise_matches_oracle(mest):
+    """GeneralSFMFactor2 under noiseModel::Robust (gtsam/linear/NoiseModel.cpp:705-735: the whitened [A1 A2 A3 b] of the three-variable
+    factor reweighted by sqrt(w(||b||)), its error the m-estimator's loss), two measurements pushed off by tens of pixels: linearization,
+    error and four LM iterations against the oracle"""
+    points, poses = create_points()[:8], create_poses()[:8]
+    g = NonlinearFactorGraph()
+    g.add_PriorFactorPose3(X(0), poses[0][0], poses[0][1], noiseModel.Diagonal.Sigmas([0.1, 0.1, 0.1, 0.3, 0.3, 0.3]))
+    est = getattr(noiseModel.mEstimator, mest)
+    robust = noiseModel.Robust.Create(est.Create(1.345 if mest == "Huber" else 2.0), noiseModel.Isotropic.Sigma(2, 1.0))
+    for i, (R, t) in enumerate(poses):
+        for j, p in enumerate(points):
+            z = project_cal3_s2(R, t, p, K_TRUE)
+            if (i, j) in ((2, 3), (5, 1)):
+                z = z + np.array([25.0, -40.0])
+            g.add_GeneralSFMFactor2(z, robust, X(i), L(j), K0)
+    g.add_PriorFactorPoint3(L(0), points[0], noiseModel.Isotropic.Sigma(3, 0.1))
+    g.add_PriorFactorCal3_S2(K0, K_TRUE, noiseModel.Diagonal.Sigmas([500, 500, 0.1, 100, 100]))
+    _, v = self_calibration()
+    ordering = oh.colamd(g)
+    orc = oh.OracleProblem(g, v, ordering)
+    params = LevenbergMarquardtParams()
+    opt = LevenbergMarquardtOptimizer(g, v, ordering, params, device=0)
+    assert abs(opt.error() - orc.error()) <= 1e-9 * max(1.0, abs(orc.error()))
+    orc.linearize()
+    opt.linearize()
+    for fidx in range(g.size()):
+        assert np.allclose(opt.jacobian(fidx), orc.jacobian(fidx), rtol=1e-9, atol=1e-9), fidx
+    orc.lm_init(params)
+    for it in range(4):
+        orc.lm_iterate(params)
+        opt.iterate()
+        so, sd = orc.lm_state(), opt.state
+        assert abs(so["error"] - sd.error) <= 1e-6 * max(1.0, abs(so["error"])), (it, so["error"], sd.error)
+        assert abs(so["lambda_"] - sd.lambda_) <= 1e-9 * so["lambda_"]
+    vo, vd = orc.values(), opt.values()
+    for k in vo.keys():
+        assert np.allclose(vo[k], vd.at(k)[:len(vo[k])], rtol=1e-6, atol=1e-6), k
+
+
 def ring_problem(n_poses=30, n_points=40, seed=5):
     """the example's set-up on a larger scene: cameras on a ring of radius 30 facing the centre, random points in the 20-cube"""
     rng = np.random.default_rng(seed)
