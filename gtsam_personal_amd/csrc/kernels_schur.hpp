@@ -49,6 +49,19 @@ __device__ __forceinline__ long long readlane_ll(long long v, int src /* wave-un
   return ((long long)hi << 32) | (unsigned int)lo;
 }
 
+// an 8-byte global load that only the lanes of `mask` (wave-uniform) take part in: no branch (the compiler waits for a load issued under a
+// branch at the join), and the address unit is given 27 lanes instead of 64.  The compiler does not count this load: the caller waits with
+// an explicit s_waitcnt before it uses the values (the compiler's own counts only ever come out too high with these loads outstanding).
+__device__ __forceinline__ double schur_load_masked(const double* p, unsigned long long mask) {
+  double v;
+  unsigned long long save;
+  asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, %2\n\tglobal_load_dwordx2 %0, %3, off\n\ts_mov_b64 exec, %1"
+               : "=&v"(v), "=&s"(save)
+               : "s"(mask), "v"(p)
+               : "memory");
+  return v;
+}
+
 // WAVES waves per destination block (1 for short lists, 4 for long ones); grid = number of blocks.
 // One v_mfma_f64_16x16x4_f64 per list entry:  D[i][j] += sum_k S_a[k][i] S_b[k][j]  with lane (i = lane & 15, k = lane >> 4)
 // supplying S_a[k][i] as the A operand and S_b[k][i] as the B operand (two 8-byte loads per lane and entry; rows k >= nf and
@@ -83,6 +96,38 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(8, 8
       mmeta = ((long long)(unsigned short)E.sa) | ((long long)(unsigned short)E.sb << 16) | ((long long)(unsigned short)E.nf << 32);
     }
     for (int e = 0; e < cnt; e += 4) {
+      if (write_mode & 2) {
+        // the operands of four entries as masked loads (BAL: 27 of 64 lanes hold an element of a 3 x 9 block), one wait, four products
+        double av[4], bv[4];
+        bool kav[4], kbv[4];
+        bool small = true;
+        long long offs[4], metas[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int eu = min(e + u, cnt - 1);
+          offs[u] = readlane_ll(moff, eu);
+          metas[u] = readlane_ll(mmeta, eu);
+          small = small && (int)((metas[u] >> 32) & 0xffff) <= 4;
+        }
+        if (small) {  // (wave-uniform)
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int sa = (int)(metas[u] & 0xffff), sb = (int)((metas[u] >> 16) & 0xffff), nf = (int)((metas[u] >> 32) & 0xffff);
+            const double* St = pool + offs[u];
+            const bool valid = e + u < cnt;
+            kav[u] = valid && va && kk < nf;
+            kbv[u] = valid && vb && kk < nf;
+            av[u] = schur_load_masked(St + sa + cc * nf + kk, __builtin_amdgcn_ballot_w64(kav[u]));
+            bv[u] = schur_load_masked(St + sb + cc * nf + kk, __builtin_amdgcn_ballot_w64(kbv[u]));
+          }
+          asm volatile("s_waitcnt vmcnt(0)"
+                       : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3])::"memory");
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(kav[u] ? av[u] : 0.0, kbv[u] ? bv[u] : 0.0, acc[u], 0, 0, 0);
+          continue;
+        }
+      }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const int eu = min(e + u, cnt - 1);
@@ -117,7 +162,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(8, 8
   // (Issuing them before the list walk was measured slower: 1.41 vs 1.26 ms per C4 assembly.)
   // write_mode: this gather is the FIRST contribution to the front (no clear beforehand): the block is written, not added to
   double cur[4] = {0.0, 0.0, 0.0, 0.0};
-  if (!write_mode) {
+  if (!(write_mode & 1)) {
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const int i = min(kk + 4 * r, B.da - 1), j = min(cc, B.db - 1);
@@ -135,7 +180,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(8, 8
 // A operand lane (i, k): A_v[k][i];  B operand lane (j, k): A_v[k][j] for j < d, b[k] for j == d.
 #define SCHUR_FW 16
 __global__ __launch_bounds__(64 * SCHUR_FW) void schur_factor_kernel(const GVarBlock* __restrict__ blocks, const GVarEntry* __restrict__ entries,
-                                                                      double* __restrict__ pool, int64_t f_off, int ld, int n) {
+                                                                      double* __restrict__ pool, int64_t f_off, int ld, int n, int masked) {
   __shared__ double part[SCHUR_FW][4][64];
   const GVarBlock B = blocks[blockIdx.x];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), d = B.dv;
@@ -155,6 +200,38 @@ __global__ __launch_bounds__(64 * SCHUR_FW) void schur_factor_kernel(const GVarB
       mmeta = ((long long)(unsigned short)E.rows) | ((long long)(unsigned short)E.c0 << 16) | ((long long)(unsigned short)E.cb << 32);
     }
     for (int e = 0; e < cnt; e += 4) {
+      if (masked) {  // (as in schur_pairs_kernel: factors of at most four rows -- BAL's have two -- take masked loads)
+        double av[4], bv[4];
+        bool kav[4], kbv[4];
+        bool small = true;
+        long long offs[4], metas[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int eu = min(e + u, cnt - 1);
+          offs[u] = readlane_ll(moff, eu);
+          metas[u] = readlane_ll(mmeta, eu);
+          small = small && (int)(metas[u] & 0xffff) <= 4;
+        }
+        if (small) {  // (wave-uniform)
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int m = (int)(metas[u] & 0xffff), c0 = (int)((metas[u] >> 16) & 0xffff), cbc = (int)((metas[u] >> 32) & 0xffff);
+            const double* J = pool + offs[u];
+            const bool valid = e + u < cnt;
+            const int bcol = (cc < d) ? c0 + cc : cbc;
+            kav[u] = valid && va && kk < m;
+            kbv[u] = valid && vb && kk < m;
+            av[u] = schur_load_masked(J + (c0 + cc) * m + kk, __builtin_amdgcn_ballot_w64(kav[u]));
+            bv[u] = schur_load_masked(J + bcol * m + kk, __builtin_amdgcn_ballot_w64(kbv[u]));
+          }
+          asm volatile("s_waitcnt vmcnt(0)"
+                       : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3])::"memory");
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(kav[u] ? av[u] : 0.0, kbv[u] ? bv[u] : 0.0, acc[u], 0, 0, 0);
+          continue;
+        }
+      }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const int eu = min(e + u, cnt - 1);

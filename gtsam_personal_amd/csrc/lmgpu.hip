@@ -814,20 +814,21 @@ int do_eliminate(lmgpu_handle* h, double lambda_v, const double* lambda_p) {  //
         hipLaunchKernelGGL(hbm_damp_kernel, dim3((F.nf + 255) / 256), dim3(256), 0, sa, F, aoff, ld, (const int32_t*)h->d_fxoff, h->pool, lambda_v,
                            lambda_p, (const double*)h->dampw, (const double*)h->gex_active);
       // leaf children in Schur form: deterministic gather instead of atomics; rows [c0, c1) of the chunk table
+      const int schur_masked = dev_switch("LMGPU_SCHUR_UNMASKED") ? 0 : 2;  // (operand loads that only the lanes holding an element take part in)
       auto gather_chunks = [&](int c0, int c1, bool whole) {
         const int s0 = whole ? 0 : G.cs[c0], s1 = whole ? G.pblk_short : G.cs[c1];
         const int l0 = whole ? 0 : G.cl[c0], l1 = whole ? G.pblk_long : G.cl[c1];
         const int v0 = whole ? 0 : G.cv[c0], v1 = whole ? G.vblk_count : G.cv[c1];
         if (s1 > s0)
           hipLaunchKernelGGL((schur_pairs_kernel<1>), dim3((s1 - s0 + 7) & ~7), dim3(64), 0, sa, (const GPairBlock*)(h->d_gpblk + G.pblk_begin + s0),
-                             (const GPairEntry*)h->d_gpent, h->pool, aoff, ld, s1 - s0, gwrite ? 1 : 0);
+                             (const GPairEntry*)h->d_gpent, h->pool, aoff, ld, s1 - s0, (gwrite ? 1 : 0) | schur_masked);
         if (l1 > l0)
           hipLaunchKernelGGL((schur_pairs_kernel<4>), dim3((l1 - l0 + 7) & ~7), dim3(256), 0, sa,
                              (const GPairBlock*)(h->d_gpblk + G.pblk_begin + G.pblk_short + l0), (const GPairEntry*)h->d_gpent, h->pool, aoff, ld,
-                             l1 - l0, gwrite ? 1 : 0);
+                             l1 - l0, (gwrite ? 1 : 0) | schur_masked);
         if (v1 > v0)
           hipLaunchKernelGGL(schur_factor_kernel, dim3(v1 - v0), dim3(64 * SCHUR_FW), 0, sa, (const GVarBlock*)(h->d_gvblk + G.vblk_begin + v0),
-                             (const GVarEntry*)h->d_gvent, h->pool, aoff, ld, F.n);
+                             (const GVarEntry*)h->d_gvent, h->pool, aoff, ld, F.n, schur_masked);
         if (G.leaf_count > 0 && (whole || c1 == nchunks)) {  // the (rhs, rhs) corner lives in the last chunk
           double* scal = h->dscal + 4;
           reduce_to(h, h->d_gcorner + G.leaf_begin, G.leaf_count, scal, sa, nullptr);

@@ -45,7 +45,7 @@ def test_launch_forms_agree_on_a_large_root(monkeypatch, dev_switches):
 
     def run(env):
         for k in ("LMGPU_NO_FUSE", "LMGPU_PANEL_2L", "LMGPU_NO_CHAIN", "LMGPU_CHAIN_FAR", "LMGPU_NO_TAIL", "LMGPU_NO_GATHER_WRITE", "LMGPU_NO_INV16_REUSE",
-                  "LMGPU_NO_LEAFPACK", "LMGPU_NO_MERGE"):
+                  "LMGPU_NO_LEAFPACK", "LMGPU_NO_MERGE", "LMGPU_SCHUR_UNMASKED"):
             monkeypatch.delenv(k, raising=False)
         for k in env:
             monkeypatch.setenv(k, "100" if k == "LMGPU_CHAIN_FAR" else "1")  # CHAIN_FAR=100: plain step order in the chained launch
@@ -64,7 +64,7 @@ def test_launch_forms_agree_on_a_large_root(monkeypatch, dev_switches):
     # (+ the remaining A/B switches of this front: the end of the front as separate launches, the gather adding into a cleared front
     #  instead of writing it, the 16x16 inverses recomputed for the back-substitution, LDS-front descriptors unpacked)
     for env in (["LMGPU_CHAIN_FAR"], ["LMGPU_NO_MERGE"], ["LMGPU_NO_MERGE", "LMGPU_CHAIN_FAR"], ["LMGPU_NO_CHAIN"], ["LMGPU_NO_FUSE"], ["LMGPU_PANEL_2L"], ["LMGPU_NO_FUSE", "LMGPU_PANEL_2L"], ["LMGPU_NO_TAIL"],
-                ["LMGPU_NO_GATHER_WRITE"], ["LMGPU_NO_INV16_REUSE"], ["LMGPU_NO_LEAFPACK"]):
+                ["LMGPU_NO_GATHER_WRITE"], ["LMGPU_NO_INV16_REUSE"], ["LMGPU_NO_LEAFPACK"], ["LMGPU_SCHUR_UNMASKED"]):
         other = run(env)
         assert other[0] == base[0]
         for a, b in zip(other[1], base[1]):
